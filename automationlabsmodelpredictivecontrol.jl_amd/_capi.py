@@ -1,0 +1,191 @@
+"""ctypes binding of libalmpc.so (include/almpc.h).  The HIP library is the only compute path: if it is
+missing or fails to load this module raises -- there is no CPU fallback."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libalmpc.so")
+
+ALMPC_OK = 0
+ERR_NAMES = {0: "ALMPC_OK", -1: "ALMPC_ERR_INVALID", -2: "ALMPC_ERR_NO_DEVICE", -3: "ALMPC_ERR_HIP",
+             -4: "ALMPC_ERR_UNSUPPORTED", -5: "ALMPC_ERR_NOT_DESIGNED", -6: "ALMPC_ERR_NUMERIC"}
+FLAG_TIMING = 0x1
+SOLVED, MAX_ITER, NON_FINITE = 0, 1, 2
+
+
+class AlmpcError(RuntimeError):
+    def __init__(self, code, msg=""):
+        self.code = code
+        super().__init__(f"{ERR_NAMES.get(code, code)}: {msg}")
+
+
+class almpc_opts(ctypes.Structure):
+    _fields_ = [("rho", ctypes.c_double), ("sigma", ctypes.c_double), ("alpha", ctypes.c_double),
+                ("eps_abs", ctypes.c_double), ("eps_rel", ctypes.c_double), ("max_iter", ctypes.c_int32),
+                ("check_every", ctypes.c_int32), ("polish", ctypes.c_int32), ("polish_max_iter", ctypes.c_int32),
+                ("warm_start", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3)]
+
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int32)
+_fp = ctypes.POINTER(ctypes.c_float)
+_hp = ctypes.c_void_p
+_lib = None
+
+
+def load():
+    """Load libalmpc.so and declare the prototypes of include/almpc.h.  Raises OSError if the
+    library has not been built (`make lib` or `python -c 'import __graft_entry__ as g; g.build()'`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError(f"{LIB_PATH} not found: build the HIP library first (make lib). There is no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    L.almpc_default_opts.argtypes = [ctypes.POINTER(almpc_opts)]
+    L.almpc_default_opts.restype = None
+    L.almpc_create.argtypes = [ctypes.POINTER(_hp), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                               ctypes.c_int, ctypes.c_uint32]
+    L.almpc_destroy.argtypes = [_hp]
+    L.almpc_destroy.restype = None
+    L.almpc_last_error.argtypes = [_hp]
+    L.almpc_last_error.restype = ctypes.c_char_p
+    L.almpc_design_shared.argtypes = [_hp] + [_dp] * 10 + [ctypes.c_double, ctypes.c_double]
+    L.almpc_set_reference.argtypes = [_hp, _dp, _dp, ctypes.c_int]
+    L.almpc_update_initialization.argtypes = [_hp, _dp]
+    L.almpc_update_initialization_device.argtypes = [_hp, ctypes.c_void_p]
+    L.almpc_calculate.argtypes = [_hp, ctypes.POINTER(almpc_opts)]
+    L.almpc_calculate_async.argtypes = [_hp, ctypes.POINTER(almpc_opts)]
+    L.almpc_synchronize.argtypes = [_hp]
+    L.almpc_get_results.argtypes = [_hp, _dp, _dp, _dp, _dp, _ip, _ip, _ip]
+    L.almpc_get_design.argtypes = [_hp, _dp, _dp, _dp, _dp]
+    L.almpc_device_results.argtypes = [_hp] + [ctypes.POINTER(ctypes.c_void_p)] * 4
+    L.almpc_get_timing.argtypes = [_hp, _fp, _fp, _fp, _fp]
+    for name in ("almpc_create", "almpc_design_shared", "almpc_set_reference", "almpc_update_initialization",
+                 "almpc_update_initialization_device", "almpc_calculate", "almpc_calculate_async", "almpc_synchronize",
+                 "almpc_get_results", "almpc_get_design", "almpc_device_results", "almpc_get_timing"):
+        getattr(L, name).restype = ctypes.c_int
+    _lib = L
+    return L
+
+
+def default_opts(**kw) -> almpc_opts:
+    o = almpc_opts()
+    load().almpc_default_opts(ctypes.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise TypeError(f"unknown solver option {k!r}")
+        setattr(o, k, v)
+    return o
+
+
+def _colmajor(a, shape=None):
+    a = np.asfortranarray(np.asarray(a, dtype=np.float64))
+    if shape is not None and a.shape != shape:
+        raise ValueError(f"expected shape {shape}, got {a.shape}")
+    return a
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+class Solver:
+    """Thin object wrapper of an almpc_handle: one device, one batch shard."""
+
+    def __init__(self, n, m, N, batch, device=0, timing=False):
+        self.L = load()
+        self.n, self.m, self.N, self.batch = int(n), int(m), int(N), int(batch)
+        self.nz = self.m * self.N
+        h = _hp()
+        rc = self.L.almpc_create(ctypes.byref(h), self.n, self.m, self.N, self.batch, int(device),
+                                 FLAG_TIMING if timing else 0)
+        if rc != ALMPC_OK:
+            raise AlmpcError(rc, "almpc_create failed (is a gfx950 GPU visible? there is no CPU fallback)")
+        self.h = h
+
+    def _check(self, rc):
+        if rc != ALMPC_OK:
+            raise AlmpcError(rc, (self.L.almpc_last_error(self.h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.almpc_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def design_shared(self, A, B, Q, R, S=None, P=None, umin=None, umax=None, xmin=None, xmax=None, rho=0.1, sigma=1e-6):
+        n, m = self.n, self.m
+        A, B, Q, R = _colmajor(A, (n, n)), _colmajor(B, (n, m)), _colmajor(Q, (n, n)), _colmajor(R, (m, m))
+        S = None if S is None else _colmajor(S, (m, m))
+        P = None if P is None else _colmajor(P, (n, n))
+        umin = np.ascontiguousarray(umin, dtype=np.float64).reshape(m)
+        umax = np.ascontiguousarray(umax, dtype=np.float64).reshape(m)
+        xmin = None if xmin is None else np.ascontiguousarray(xmin, dtype=np.float64).reshape(n)
+        xmax = None if xmax is None else np.ascontiguousarray(xmax, dtype=np.float64).reshape(n)
+        self._check(self.L.almpc_design_shared(self.h, _ptr(A), _ptr(B), _ptr(Q), _ptr(R), _ptr(S), _ptr(P), _ptr(umin),
+                                               _ptr(umax), _ptr(xmin), _ptr(xmax), float(rho), float(sigma)))
+
+    def set_reference(self, x_ref, u_ref, per_instance=False):
+        """x_ref (n, N+1) / u_ref (m, N), or with per_instance (batch, n, N+1) / (batch, m, N)."""
+        n, m, N = self.n, self.m, self.N
+        x_ref, u_ref = np.asarray(x_ref, dtype=np.float64), np.asarray(u_ref, dtype=np.float64)
+        if per_instance:
+            xr = np.ascontiguousarray(x_ref.reshape(self.batch, n, N + 1).transpose(0, 2, 1))
+            ur = np.ascontiguousarray(u_ref.reshape(self.batch, m, N).transpose(0, 2, 1))
+        else:
+            xr = np.ascontiguousarray(x_ref.reshape(n, N + 1).T)
+            ur = np.ascontiguousarray(u_ref.reshape(m, N).T)
+        self._check(self.L.almpc_set_reference(self.h, _ptr(xr), _ptr(ur), 1 if per_instance else 0))
+
+    def update_initialization(self, x0):
+        x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(self.batch, self.n)
+        self._check(self.L.almpc_update_initialization(self.h, _ptr(x0)))
+
+    def update_initialization_device(self, dev_ptr: int):
+        self._check(self.L.almpc_update_initialization_device(self.h, ctypes.c_void_p(dev_ptr)))
+
+    def calculate(self, opts: almpc_opts | None = None, sync=True):
+        fn = self.L.almpc_calculate if sync else self.L.almpc_calculate_async
+        self._check(fn(self.h, None if opts is None else ctypes.byref(opts)))
+
+    def synchronize(self):
+        self._check(self.L.almpc_synchronize(self.h))
+
+    def get_results(self, want=("x", "e_x", "u", "e_u", "status", "iters", "polish_iters")):
+        b, n, m, N = self.batch, self.n, self.m, self.N
+        bufs = {}
+        if "x" in want: bufs["x"] = np.empty((b, N + 1, n))
+        if "e_x" in want: bufs["e_x"] = np.empty((b, N + 1, n))
+        if "u" in want: bufs["u"] = np.empty((b, N, m))
+        if "e_u" in want: bufs["e_u"] = np.empty((b, N, m))
+        for k in ("status", "iters", "polish_iters"):
+            if k in want: bufs[k] = np.empty(b, dtype=np.int32)
+        ip = lambda k: bufs[k].ctypes.data_as(_ip) if k in bufs else None
+        self._check(self.L.almpc_get_results(self.h, _ptr(bufs.get("x")), _ptr(bufs.get("e_x")), _ptr(bufs.get("u")),
+                                             _ptr(bufs.get("e_u")), ip("status"), ip("iters"), ip("polish_iters")))
+        # Julia-shaped views: (batch, n, N+1) and (batch, m, N)
+        for k in ("x", "e_x", "u", "e_u"):
+            if k in bufs: bufs[k] = bufs[k].transpose(0, 2, 1)
+        return bufs
+
+    def get_design(self):
+        n, nz = self.n, self.nz
+        H = np.empty((nz, nz), order="F"); F = np.empty((nz, n), order="F"); P = np.empty((n, n), order="F"); d = np.empty(nz)
+        self._check(self.L.almpc_get_design(self.h, _ptr(H), _ptr(F), _ptr(P), _ptr(d)))
+        return dict(H=H, F=F, P=P, d=d)
+
+    def device_results(self):
+        ps = [ctypes.c_void_p() for _ in range(4)]
+        self._check(self.L.almpc_device_results(self.h, *[ctypes.byref(p) for p in ps]))
+        return dict(zip(("x", "e_x", "u", "e_u"), [p.value for p in ps]))
+
+    def get_timing(self):
+        v = [ctypes.c_float() for _ in range(4)]
+        self._check(self.L.almpc_get_timing(self.h, *[ctypes.byref(x) for x in v]))
+        return dict(zip(("admm_ms", "polish_ms", "rollout_ms", "total_ms"), [x.value for x in v]))

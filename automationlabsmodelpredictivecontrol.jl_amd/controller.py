@@ -1,0 +1,250 @@
+"""Host-side mirror of the reference's operator interface for the linear MPC path.
+
+The reference is Julia; `julia` is not in this image, so the host side above the C ABI is Python that
+keeps the reference's names, argument meaning and error behaviour (the Julia shim a maintainer would use
+is julia/AlmpcHIP.jl).  Reference (paths relative to /root/reference):
+
+  proceed_controller                     src/main/main_mpc.jl:22-53
+  _design_reference_mpc                  src/main/main_mpc.jl:105-117
+  _model_predictive_control_design       src/sub/design_mpc.jl:54-129   (ConstrainedLinearControlDiscreteSystem)
+  _create_weights_coefficients           src/sub/design_mpc.jl:264-283
+  _IMPLEMENTATION_SOLVER_LIST            src/sub/solver_selection.jl:9-14  (+ new tag "hip")
+  update_initialization!                 src/main/computation_mpc.jl:17-29  -> update_initialization
+  calculate!                             src/main/computation_mpc.jl:38-55  -> calculate
+  structs                                src/types/types.jl:24-27,46-50,89-92,114-122,134-139,151-156
+
+`_model_predictive_control_computation` is named by BASELINE.json but does not exist in the reference
+(SURVEY.md section 0); here it is update_initialization + calculate for a batch.
+
+Every solve goes through libalmpc.so (HIP); there is no CPU path in this module.
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Any, Optional
+
+import numpy as np
+
+from . import _capi
+
+__all__ = [
+    "Hyperrectangle", "ConstrainedLinearControlDiscreteSystem", "ReferencesStateInput", "WeightsCoefficient",
+    "TerminalIngredient", "ModelPredictiveControlTuning", "ModelPredictiveControlResults",
+    "ModelPredictiveControlController", "proceed_controller", "_design_reference_mpc",
+    "_model_predictive_control_design", "_create_weights_coefficients", "update_initialization", "calculate",
+    "_model_predictive_control_computation", "HipModeler", "shard_range",
+]
+
+
+# ---- stand-ins for LazySets.Hyperrectangle / MathematicalSystems.ConstrainedLinearControlDiscreteSystem ----
+@dataclasses.dataclass
+class Hyperrectangle:
+    low: np.ndarray
+    high: np.ndarray
+
+    def __post_init__(self):
+        self.low = np.asarray(self.low, dtype=np.float64)
+        self.high = np.asarray(self.high, dtype=np.float64)
+        if self.low.shape != self.high.shape or np.any(self.low > self.high):
+            raise ValueError("Hyperrectangle: need low <= high of equal length")
+
+
+@dataclasses.dataclass
+class ConstrainedLinearControlDiscreteSystem:
+    A: np.ndarray
+    B: np.ndarray
+    X: Hyperrectangle
+    U: Hyperrectangle
+
+    def __post_init__(self):
+        self.A = np.asarray(self.A, dtype=np.float64)
+        self.B = np.asarray(self.B, dtype=np.float64)
+        n, m = self.B.shape
+        if self.A.shape != (n, n) or self.X.low.shape != (n,) or self.U.low.shape != (m,):
+            raise ValueError("ConstrainedLinearControlDiscreteSystem: inconsistent dimensions")
+
+
+# ---- structs of src/types/types.jl ------------------------------------------------------------------------
+@dataclasses.dataclass
+class ReferencesStateInput:
+    x: np.ndarray  # n x (N+1)
+    u: np.ndarray  # m x N
+
+
+@dataclasses.dataclass
+class WeightsCoefficient:
+    Q: np.ndarray
+    R: np.ndarray
+    S: np.ndarray
+
+
+@dataclasses.dataclass
+class TerminalIngredient:
+    Xf: Any
+    P: np.ndarray
+
+
+@dataclasses.dataclass
+class ModelPredictiveControlTuning:
+    modeler: Any  # the reference stores a JuMP model here (`modeler::Any`, types.jl:115); here a HipModeler
+    reference: ReferencesStateInput
+    horizon: int
+    weights: WeightsCoefficient
+    terminal_ingredient: TerminalIngredient
+    sample_time: float
+    max_time: int
+
+
+@dataclasses.dataclass
+class ModelPredictiveControlResults:
+    x: np.ndarray
+    e_x: np.ndarray
+    u: np.ndarray
+    e_u: np.ndarray
+
+
+@dataclasses.dataclass
+class ModelPredictiveControlController:
+    system: Any
+    tuning: ModelPredictiveControlTuning
+    initialization: np.ndarray
+    computation_results: ModelPredictiveControlResults
+
+
+_DEFAULT_PARAMETERS_MODEL_PREDICTIVE_CONTROL = dict(  # src/main/main_mpc.jl:87-94
+    mpc_solver="auto", mpc_terminal_ingredient="none", mpc_Q=100.0, mpc_R=0.1, mpc_S=0.0, mpc_max_time=30.0)
+
+# src/sub/solver_selection.jl:9-14 plus the new "hip" tag; "auto" for the linear method resolves to "hip" here
+# (the reference resolves it to SCIP, solver_selection.jl:56-65); the CPU solvers are not part of this build.
+_IMPLEMENTATION_SOLVER_LIST = ("osqp", "scip", "ipopt", "auto", "hip")
+IMPLEMENTATION_PROGRAMMING_LIST = ("linear", "non_linear", "mixed_linear", "fuzzy_linear")  # src/types/types.jl:229-234
+
+
+def _kws(kws_):
+    # the reference's idiom: dict_kws = Dict(kws_); kws = get(dict_kws, :kws, kws_)  (src/main/main_mpc.jl:33-34)
+    return dict(kws_.get("kws", kws_))
+
+
+class HipModeler:
+    """What sits in `tuning.modeler` instead of a JuMP model: the almpc handle plus solver options."""
+
+    def __init__(self, solver: _capi.Solver, opts: _capi.almpc_opts, batch: int):
+        self.solver, self.opts, self.batch = solver, opts, batch
+
+
+def _design_reference_mpc(state_reference, input_reference, horizon: int) -> ReferencesStateInput:
+    xr = np.asarray(state_reference, dtype=np.float64).reshape(-1, 1)
+    ur = np.asarray(input_reference, dtype=np.float64).reshape(-1, 1)
+    return ReferencesStateInput(xr * np.ones((xr.shape[0], horizon + 1)), ur * np.ones((ur.shape[0], horizon)))
+
+
+def _create_weights_coefficients(system: ConstrainedLinearControlDiscreteSystem, **kws_) -> WeightsCoefficient:
+    kws = _kws(kws_)
+    D = _DEFAULT_PARAMETERS_MODEL_PREDICTIVE_CONTROL
+    n, m = system.B.shape
+    return WeightsCoefficient(float(kws.get("mpc_Q", D["mpc_Q"])) * np.eye(n),
+                              float(kws.get("mpc_R", D["mpc_R"])) * np.eye(m),
+                              float(kws.get("mpc_S", D["mpc_S"])) * np.eye(m))
+
+
+def proceed_controller(system, mpc_controller_type: str, mpc_horizon: int, mpc_sample_time: int,
+                       mpc_state_reference, mpc_input_reference, **kws_):
+    """Same positional contract as the reference (src/main/main_mpc.jl:22-30).  Returns None for a
+    controller type other than "model_predictive_control", as the reference falls through."""
+    kws = _kws(kws_)
+    if not isinstance(mpc_horizon, (int, np.integer)) or not isinstance(mpc_sample_time, (int, np.integer)):
+        raise TypeError("mpc_horizon and mpc_sample_time must be Int (src/main/main_mpc.jl:25-26)")
+    if mpc_controller_type == "model_predictive_control":
+        refs = _design_reference_mpc(mpc_state_reference, mpc_input_reference, mpc_horizon)
+        return _model_predictive_control_design(system, mpc_horizon, mpc_sample_time, refs, kws=kws)
+    return None
+
+
+def _model_predictive_control_design(system: ConstrainedLinearControlDiscreteSystem, horizon: int, sample_time: int,
+                                     references: ReferencesStateInput, **kws_):
+    """Design for the discrete linear system (src/sub/design_mpc.jl:54-129).  Extra keys of this build:
+    mpc_batch (instances sharing this design, default 1), mpc_device (HIP device id, default 0),
+    mpc_solver_options (dict of almpc_opts fields), mpc_timing (bool)."""
+    kws = _kws(kws_)
+    D = _DEFAULT_PARAMETERS_MODEL_PREDICTIVE_CONTROL
+    ptype = kws.get("mpc_programming_type", "linear")
+    if ptype not in IMPLEMENTATION_PROGRAMMING_LIST:
+        raise KeyError(ptype)  # the reference indexes a NamedTuple and throws
+    if ptype != "linear":
+        raise NotImplementedError(f"mpc_programming_type={ptype!r}: only the LinearProgramming path is built (SURVEY.md section 8)")
+    solver_name = kws.get("mpc_solver", D["mpc_solver"])
+    if solver_name not in _IMPLEMENTATION_SOLVER_LIST:
+        raise KeyError(solver_name)
+    if solver_name in ("osqp", "scip", "ipopt"):
+        raise NotImplementedError(f"mpc_solver={solver_name!r} is the reference's CPU path; this build provides 'hip' (and 'auto' -> 'hip')")
+    terminal = kws.get("mpc_terminal_ingredient", D["mpc_terminal_ingredient"])
+    if terminal in ("equality", "contractive"):
+        raise NotImplementedError(f"terminal ingredient {terminal!r} is not built yet (SURVEY.md section 8f rank 1)")
+    if "mpc_state_constraint" in kws:
+        raise NotImplementedError("mpc_state_constraint (state box) is not built yet (SURVEY.md section 8f rank 1)")
+    max_time = kws.get("mpc_max_time", D["mpc_max_time"])
+    weights = _create_weights_coefficients(system, kws=kws)
+    n, m = system.B.shape
+    batch = int(kws.get("mpc_batch", 1))
+    x_ref, u_ref = np.asarray(references.x, dtype=np.float64), np.asarray(references.u, dtype=np.float64)
+    if x_ref.shape != (n, horizon + 1) or u_ref.shape != (m, horizon):
+        raise ValueError("references must be n x (N+1) and m x N")
+    sopt = dict(kws.get("mpc_solver_options", {}))
+    rho, sigma = float(sopt.get("rho", 0.1)), float(sopt.get("sigma", 1e-6))
+    solver = _capi.Solver(n, m, horizon, batch, device=int(kws.get("mpc_device", 0)), timing=bool(kws.get("mpc_timing", False)))
+    # bounds as the reference reads them: low = last vertex, high = first vertex of the hyperrectangle
+    # (..linear.jl:34-38); P = DARE at the (linear) system (src/sub/design_mpc.jl:327), computed in the library.
+    solver.design_shared(system.A, system.B, weights.Q, weights.R, weights.S, None, system.U.low, system.U.high,
+                         rho=rho, sigma=sigma)
+    solver.set_reference(x_ref, u_ref)
+    P = solver.get_design()["P"]
+    opts = _capi.default_opts(**sopt)
+    tuning = ModelPredictiveControlTuning(HipModeler(solver, opts, batch), references, horizon, weights,
+                                          TerminalIngredient(terminal, np.array(P)), float(sample_time), int(max_time))
+    shape = (lambda *s: s) if batch == 1 else (lambda *s: (batch, *s))
+    results = ModelPredictiveControlResults(np.empty(shape(n, horizon + 1)), np.empty(shape(n, horizon + 1)),
+                                            np.empty(shape(m, horizon)), np.empty(shape(m, horizon)))
+    return ModelPredictiveControlController(system, tuning, np.empty(shape(n)), results)
+
+
+def update_initialization(C: ModelPredictiveControlController, initialization) -> None:
+    """update_initialization!(C, x0): x0 of length n (batch 1) or shape (batch, n)."""
+    mod: HipModeler = C.tuning.modeler
+    x0 = np.asarray(initialization, dtype=np.float64)
+    n = C.system.A.shape[0]
+    if x0.size != mod.batch * n:
+        raise ValueError(f"initialization must hold {mod.batch} x {n} values")
+    C.initialization = x0.reshape((n,) if mod.batch == 1 else (mod.batch, n)).copy()
+    mod.solver.update_initialization(x0.reshape(mod.batch, n))
+
+
+def calculate(C: ModelPredictiveControlController) -> None:
+    """calculate!(C): solve and copy u, e_u, x, e_x into C.computation_results.  The reference does not
+    check the solver status and lets JuMP.value throw when no solution exists; here a non-finite instance
+    raises ArithmeticError, and per-instance status/iterations are kept on the modeler."""
+    mod: HipModeler = C.tuning.modeler
+    mod.solver.calculate(mod.opts)
+    r = mod.solver.get_results()
+    mod.last_status, mod.last_iters, mod.last_polish_iters = r["status"], r["iters"], r["polish_iters"]
+    if np.any(r["status"] == _capi.NON_FINITE):
+        raise ArithmeticError("calculate!: non-finite values in at least one instance (no solution to read)")
+    res = C.computation_results
+    for k in ("x", "e_x", "u", "e_u"):
+        getattr(res, k)[...] = r[k][0] if mod.batch == 1 else r[k]
+
+
+def _model_predictive_control_computation(C: ModelPredictiveControlController, X0):
+    """Batch step: update_initialization! + calculate!; returns C.computation_results."""
+    update_initialization(C, X0)
+    calculate(C)
+    return C.computation_results
+
+
+def shard_range(batch: int, rank: int, world: int):
+    """Contiguous shard [lo, hi) of a batch of independent instances for `rank` of `world` (SURVEY.md
+    section 8e): sizes differ by at most one, earlier ranks take the remainder."""
+    if not (0 <= rank < world) or batch < 0:
+        raise ValueError("need 0 <= rank < world and batch >= 0")
+    base, rem = divmod(batch, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)

@@ -1,0 +1,407 @@
+// almpc_api.hip -- C ABI of libalmpc.so (declared in include/almpc.h) over the gfx950 kernels.
+//
+// Host side of the drop-in boundary.  Reference entry points this replaces (relative to
+// /root/reference): _model_predictive_control_design src/sub/design_mpc.jl:54-129 (-> almpc_design_shared),
+// update_initialization! src/main/computation_mpc.jl:17-29, calculate! src/main/computation_mpc.jl:38-55.
+// No torch, no BLAS, no CPU solve path: every per-step computation runs in almpc_kernels.hip.h.
+#include "almpc_kernels.hip.h"
+#include "almpc_design.hip.h"
+#include "almpc_host_math.h"
+#include "../../include/almpc.h"
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace almpc;
+
+struct almpc_handle {
+    int n = 0, m = 0, N = 0, batch = 0, nz = 0, nzs = 0, nrb = 0, ks = 0, ksf = 0, device = 0;
+    uint32_t flags = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool designed = false;
+    double rho = 0.1, sigma = 1e-6;
+    // host copies of the design (almpc_get_design)
+    std::vector<double> H, F, P, d;
+    // device: shared design
+    double *dMinvFrag = nullptr, *dGFrag = nullptr, *dHFrag = nullptr, *dFFrag = nullptr, *dG = nullptr;
+    double *dD = nullptr, *dUmin = nullptr, *dUmax = nullptr, *dA = nullptr, *dB = nullptr;
+    double *dXref = nullptr, *dUref = nullptr, *dFS = nullptr;
+    long xref_stride = 0, uref_stride = 0, fS_stride = 0;
+    std::vector<double> hS;  // S weight (for fS with per-instance references)
+    // device: per-instance state and results
+    double *dX0 = nullptr, *dXs = nullptr, *dZs = nullptr, *dYs = nullptr, *dV0 = nullptr, *dW = nullptr;
+    double *dX = nullptr, *dEx = nullptr, *dU = nullptr, *dEu = nullptr;
+    int32_t *dStatus = nullptr, *dIters = nullptr, *dPiters = nullptr, *dOverflow = nullptr;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool timed = false;
+};
+
+namespace {
+
+int fail(almpc_handle* h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    return code;
+}
+
+#define HIP_TRY(h, call)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(h, ALMPC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+template <typename T>
+hipError_t dalloc(T** p, size_t count) {
+    return hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T) + 64);
+}
+
+int pick_ks(int nz, int nrb) {
+    const int exact = (nz + 3) / 4;
+    // instantiated (NRB, KS) pairs: KS = 4*NRB always; plus the exact-fit specials below
+    if (nrb == 8 && exact <= 30) return 30;
+    if (nrb == 3 && exact <= 10) return 10;
+    if (nrb == 1 && exact <= 3) return 3;
+    return 4 * nrb;
+}
+
+template <int NRB, int KS>
+hipError_t launch_admm_t(const AdmmParams& p, int grid, size_t lds, hipStream_t st) {
+    hipLaunchKernelGGL((k_admm<NRB, KS>), dim3(grid), dim3(64 * NRB), lds, st, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_admm(int nrb, int ks, const AdmmParams& p, int grid, size_t lds, hipStream_t st) {
+#define CASE(NRB_, KS_) if (nrb == NRB_ && ks == KS_) return launch_admm_t<NRB_, KS_>(p, grid, lds, st)
+    CASE(1, 3); CASE(1, 4); CASE(2, 8); CASE(3, 10); CASE(3, 12); CASE(4, 16); CASE(5, 20); CASE(6, 24);
+    CASE(7, 28); CASE(8, 30); CASE(8, 32);
+#undef CASE
+    return hipErrorInvalidValue;
+}
+
+void free_all(almpc_handle* h) {
+    void* ptrs[] = {h->dMinvFrag, h->dGFrag, h->dHFrag, h->dFFrag, h->dG, h->dD, h->dUmin, h->dUmax, h->dA, h->dB,
+                    h->dXref, h->dUref, h->dFS, h->dX0, h->dXs, h->dZs, h->dYs, h->dV0, h->dW, h->dX, h->dEx,
+                    h->dU, h->dEu, h->dStatus, h->dIters, h->dPiters, h->dOverflow};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (auto& e : h->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+void almpc_default_opts(almpc_opts* o) {
+    if (!o) return;
+    std::memset(o, 0, sizeof(*o));
+    o->rho = 0.1;
+    o->sigma = 1e-6;
+    o->alpha = 1.6;
+    o->eps_abs = 1e-3;
+    o->eps_rel = 1e-3;
+    o->max_iter = 50;
+    o->check_every = 25;
+    o->polish = 1;
+    o->polish_max_iter = 0;
+    o->warm_start = 0;
+}
+
+const char* almpc_last_error(const almpc_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int almpc_create(almpc_handle** out, int n, int m, int N, int batch, int device_id, uint32_t flags) {
+    if (!out) return ALMPC_ERR_INVALID;
+    *out = nullptr;
+    if (n < 1 || m < 1 || N < 1 || batch < 1) return ALMPC_ERR_INVALID;
+    if (n > 64 || (long)m * N > 128) return ALMPC_ERR_UNSUPPORTED;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count < 1) return ALMPC_ERR_NO_DEVICE;
+    if (device_id < 0 || device_id >= count) return ALMPC_ERR_NO_DEVICE;
+    almpc_handle* h = new almpc_handle();
+    h->n = n; h->m = m; h->N = N; h->batch = batch; h->device = device_id; h->flags = flags;
+    h->nz = m * N;
+    h->nrb = (h->nz + 15) / 16;
+    h->nzs = 16 * h->nrb;
+    h->ks = pick_ks(h->nz, h->nrb);
+    h->ksf = (n + 3) / 4;
+    auto bail = [&](int code, const std::string& msg) {
+        std::fprintf(stderr, "almpc_create: %s\n", msg.c_str());
+        free_all(h);
+        delete h;
+        return code;
+    };
+#define TRY(call)                                                                  \
+    do {                                                                           \
+        hipError_t e_ = (call);                                                    \
+        if (e_ != hipSuccess) return bail(ALMPC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+    TRY(hipSetDevice(device_id));
+    TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    const size_t fr = (size_t)h->nrb * h->ks * 64, b = (size_t)batch;
+    TRY(dalloc(&h->dMinvFrag, fr)); TRY(dalloc(&h->dGFrag, fr)); TRY(dalloc(&h->dHFrag, fr));
+    TRY(dalloc(&h->dFFrag, (size_t)h->nrb * h->ksf * 64));
+    TRY(dalloc(&h->dG, (size_t)h->nz * h->nzs));
+    TRY(dalloc(&h->dD, (size_t)h->nzs)); TRY(dalloc(&h->dUmin, (size_t)m)); TRY(dalloc(&h->dUmax, (size_t)m));
+    TRY(dalloc(&h->dA, (size_t)n * n)); TRY(dalloc(&h->dB, (size_t)n * m));
+    TRY(dalloc(&h->dX0, b * n));
+    TRY(dalloc(&h->dXs, b * h->nzs)); TRY(dalloc(&h->dZs, b * h->nzs)); TRY(dalloc(&h->dYs, b * h->nzs));
+    TRY(dalloc(&h->dV0, b * h->nzs)); TRY(dalloc(&h->dW, b * h->nzs));
+    TRY(dalloc(&h->dX, b * n * (N + 1))); TRY(dalloc(&h->dEx, b * n * (N + 1)));
+    TRY(dalloc(&h->dU, b * h->nz)); TRY(dalloc(&h->dEu, b * h->nz));
+    TRY(dalloc(&h->dStatus, b)); TRY(dalloc(&h->dIters, b)); TRY(dalloc(&h->dPiters, b)); TRY(dalloc(&h->dOverflow, b));
+    TRY(hipMemset(h->dXs, 0, b * h->nzs * sizeof(double)));
+    TRY(hipMemset(h->dZs, 0, b * h->nzs * sizeof(double)));
+    TRY(hipMemset(h->dYs, 0, b * h->nzs * sizeof(double)));
+    TRY(hipMemset(h->dX0, 0, b * n * sizeof(double)));
+    for (auto& e : h->ev) TRY(hipEventCreate(&e));
+#undef TRY
+    *out = h;
+    return ALMPC_OK;
+}
+
+void almpc_destroy(almpc_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    free_all(h);
+    delete h;
+}
+
+int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const double* Q, const double* R,
+                        const double* S, const double* P, const double* umin, const double* umax,
+                        const double* xmin, const double* xmax, double rho, double sigma) {
+    if (!h) return ALMPC_ERR_INVALID;
+    if (!A || !B || !Q || !R || !umin || !umax) return fail(h, ALMPC_ERR_INVALID, "design: null matrix pointer");
+    if (xmin || xmax) return fail(h, ALMPC_ERR_UNSUPPORTED, "design: state box (mpc_state_constraint) is not built yet");
+    if (!(rho > 0.0) || !(sigma >= 0.0)) return fail(h, ALMPC_ERR_INVALID, "design: rho must be > 0 and sigma >= 0");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int n = h->n, m = h->m, N = h->N, nz = h->nz;
+    for (int i = 0; i < m; ++i)
+        if (!(umin[i] <= umax[i])) return fail(h, ALMPC_ERR_INVALID, "design: umin > umax");
+    hm::mat Am(A, A + (size_t)n * n), Bm(B, B + (size_t)n * m), Qm(Q, Q + (size_t)n * n), Rm(R, R + (size_t)m * m);
+    hm::mat Sm = S ? hm::mat(S, S + (size_t)m * m) : hm::mat((size_t)m * m, 0.0);
+    hm::mat Pm;
+    if (P) Pm.assign(P, P + (size_t)n * n);
+    else if (!hm::dare(Am, Bm, Qm, Rm, n, m, Pm)) return fail(h, ALMPC_ERR_NUMERIC, "design: DARE did not converge");
+    h->P = Pm;
+    h->hS = Sm;
+    h->rho = rho; h->sigma = sigma;
+
+    int rc = design_shared_device(h->stream, n, m, N, h->nzs, h->nrb, h->ks, h->ksf, Am, Bm, Qm, Rm, Sm, Pm, rho, sigma,
+                                  h->dMinvFrag, h->dGFrag, h->dHFrag, h->dFFrag, h->dG, h->dD, h->H, h->F, h->d, h->err);
+    if (rc != ALMPC_OK) return rc;
+    HIP_TRY(h, hipMemcpy(h->dUmin, umin, m * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->dUmax, umax, m * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->dA, A, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->dB, B, (size_t)n * m * sizeof(double), hipMemcpyHostToDevice));
+    h->designed = true;
+    // default references: zeros, shared
+    std::vector<double> xr((size_t)n * (N + 1), 0.0), ur((size_t)nz, 0.0);
+    return almpc_set_reference(h, xr.data(), ur.data(), 0);
+}
+
+int almpc_set_reference(almpc_handle* h, const double* xref, const double* uref, int per_instance) {
+    if (!h) return ALMPC_ERR_INVALID;
+    if (!h->designed) return fail(h, ALMPC_ERR_NOT_DESIGNED, "set_reference before design");
+    if (!xref || !uref) return fail(h, ALMPC_ERR_INVALID, "set_reference: null pointer");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int n = h->n, m = h->m, N = h->N, nz = h->nz;
+    const size_t cnt = per_instance ? (size_t)h->batch : 1;
+    const size_t xs = (size_t)n * (N + 1), us = (size_t)nz;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->dXref) { (void)hipFree(h->dXref); h->dXref = nullptr; }
+    if (h->dUref) { (void)hipFree(h->dUref); h->dUref = nullptr; }
+    if (h->dFS) { (void)hipFree(h->dFS); h->dFS = nullptr; }
+    HIP_TRY(h, dalloc(&h->dXref, cnt * xs));
+    HIP_TRY(h, dalloc(&h->dUref, cnt * us));
+    HIP_TRY(h, dalloc(&h->dFS, cnt * us));
+    HIP_TRY(h, hipMemcpy(h->dXref, xref, cnt * xs * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->dUref, uref, cnt * us * sizeof(double), hipMemcpyHostToDevice));
+    // fS = d .* (2 D'Sbar D u_ref): the input-rate cost is on u, not e_u (src/sub/design_mpc.jl:423-446)
+    std::vector<double> fS(cnt * us, 0.0);
+    if (h->hS[0] != 0.0) {
+        for (size_t c = 0; c < cnt; ++c) {
+            const double* ur = uref + c * us;
+            double* f = fS.data() + c * us;
+            for (int i = 0; i + 1 < N; ++i)
+                for (int a = 0; a < m; ++a) {
+                    double sd = 0.0;  // (S (u_i - u_{i+1}))_a
+                    for (int b2 = 0; b2 < m; ++b2) sd += h->hS[(size_t)b2 * m + a] * (ur[i * m + b2] - ur[(i + 1) * m + b2]);
+                    f[i * m + a] += 2.0 * sd;
+                    f[(i + 1) * m + a] -= 2.0 * sd;
+                }
+            for (int r = 0; r < nz; ++r) f[r] *= h->d[r];
+        }
+    }
+    HIP_TRY(h, hipMemcpy(h->dFS, fS.data(), cnt * us * sizeof(double), hipMemcpyHostToDevice));
+    h->xref_stride = per_instance ? (long)xs : 0;
+    h->uref_stride = per_instance ? (long)us : 0;
+    h->fS_stride = per_instance ? (long)us : 0;
+    return ALMPC_OK;
+}
+
+int almpc_update_initialization(almpc_handle* h, const double* x0) {
+    if (!h || !x0) return h ? fail(h, ALMPC_ERR_INVALID, "update_initialization: null x0") : ALMPC_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(h->dX0, x0, (size_t)h->batch * h->n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return ALMPC_OK;
+}
+
+int almpc_update_initialization_device(almpc_handle* h, const double* d_x0) {
+    if (!h || !d_x0) return h ? fail(h, ALMPC_ERR_INVALID, "update_initialization_device: null x0") : ALMPC_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(h->dX0, d_x0, (size_t)h->batch * h->n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    return ALMPC_OK;
+}
+
+int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
+    if (!h) return ALMPC_ERR_INVALID;
+    if (!h->designed) return fail(h, ALMPC_ERR_NOT_DESIGNED, "calculate before design");
+    almpc_opts o;
+    almpc_default_opts(&o);
+    if (user) o = *user;
+    if (o.rho == 0.0) o.rho = h->rho;
+    if (o.sigma == 0.0) o.sigma = h->sigma;
+    if (o.rho != h->rho || o.sigma != h->sigma)
+        return fail(h, ALMPC_ERR_INVALID, "calculate: rho/sigma differ from the design values (the shared KKT inverse is built for them)");
+    if (o.max_iter < 1 || o.check_every < 1 || !(o.alpha > 0.0 && o.alpha < 2.0) || !(o.eps_abs >= 0.0) || !(o.eps_rel >= 0.0))
+        return fail(h, ALMPC_ERR_INVALID, "calculate: bad options");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const bool timing = (h->flags & ALMPC_FLAG_TIMING) != 0;
+    hipStream_t st = h->stream;
+    if (timing) HIP_TRY(h, hipEventRecord(h->ev[0], st));
+
+    AdmmParams ap;
+    ap.nz = h->nz; ap.n = h->n; ap.m = h->m; ap.batch = h->batch; ap.nzs = h->nzs;
+    ap.MinvFrag = h->dMinvFrag; ap.GFrag = h->dGFrag; ap.HFrag = h->dHFrag; ap.FFrag = h->dFFrag; ap.ksf = h->ksf;
+    ap.dvec = h->dD; ap.umin = h->dUmin; ap.umax = h->dUmax;
+    ap.uref = h->dUref; ap.uref_stride = h->uref_stride; ap.xref = h->dXref; ap.xref_stride = h->xref_stride;
+    ap.fS = h->dFS; ap.fS_stride = h->fS_stride; ap.x0 = h->dX0;
+    ap.xs = h->dXs; ap.zs = h->dZs; ap.ys = h->dYs; ap.v0 = h->dV0; ap.status = h->dStatus; ap.iters = h->dIters;
+    ap.rho = o.rho; ap.sigma = o.sigma; ap.alpha = o.alpha; ap.eps_abs = o.eps_abs; ap.eps_rel = o.eps_rel;
+    ap.max_iter = o.max_iter; ap.check_every = o.check_every; ap.warm = o.warm_start ? 1 : 0;
+    const int grid = (h->batch + TILE - 1) / TILE;
+    const size_t lds = ((size_t)2 * h->nzs * TILE + (size_t)h->nrb * 8 * TILE + (size_t)4 * h->ksf * TILE) * sizeof(double);
+    HIP_TRY(h, launch_admm(h->nrb, h->ks, ap, grid, lds, st));
+    if (timing) HIP_TRY(h, hipEventRecord(h->ev[1], st));
+
+    const double* wsrc = h->dZs;
+    if (o.polish) {
+        HIP_TRY(h, hipMemsetAsync(h->dPiters, 0, (size_t)h->batch * sizeof(int32_t), st));
+        HIP_TRY(h, hipMemsetAsync(h->dOverflow, 0, (size_t)h->batch * sizeof(int32_t), st));
+        // instances the polish cannot take (working set beyond the largest tier) keep the ADMM iterate
+        HIP_TRY(h, hipMemcpyAsync(h->dW, h->dZs, (size_t)h->batch * h->nzs * sizeof(double), hipMemcpyDeviceToDevice, st));
+        PolishParams pp;
+        pp.nz = h->nz; pp.m = h->m; pp.batch = h->batch; pp.nzs = h->nzs; pp.G = h->dG; pp.dvec = h->dD;
+        pp.umin = h->dUmin; pp.umax = h->dUmax; pp.uref = h->dUref; pp.uref_stride = h->uref_stride;
+        pp.zs = h->dZs; pp.ys = h->dYs; pp.v0 = h->dV0; pp.w = h->dW; pp.status = h->dStatus; pp.piters = h->dPiters;
+        pp.overflow = h->dOverflow;
+        pp.max_iter = o.polish_max_iter > 0 ? o.polish_max_iter : 20 * h->nz + 50;
+        {
+            constexpr int WL = 32, WAVES = 4;
+            pp.tier = 0;
+            const size_t l = (size_t)WAVES * (WL * WL + 2 * WL) * sizeof(double);
+            hipLaunchKernelGGL((k_polish<WL, WAVES>), dim3((h->batch + WAVES - 1) / WAVES), dim3(64 * WAVES), l, st, pp);
+            HIP_TRY(h, hipGetLastError());
+        }
+        {
+            constexpr int WL = 64, WAVES = 1;
+            pp.tier = 1;
+            const size_t l = (size_t)WAVES * (WL * WL + 2 * WL) * sizeof(double);
+            hipLaunchKernelGGL((k_polish<WL, WAVES>), dim3((h->batch + WAVES - 1) / WAVES), dim3(64 * WAVES), l, st, pp);
+            HIP_TRY(h, hipGetLastError());
+        }
+        wsrc = h->dW;
+    }
+    if (timing) HIP_TRY(h, hipEventRecord(h->ev[2], st));
+
+    RolloutParams rp;
+    rp.n = h->n; rp.m = h->m; rp.N = h->N; rp.batch = h->batch; rp.nzs = h->nzs; rp.A = h->dA; rp.B = h->dB;
+    rp.dvec = h->dD; rp.w = wsrc; rp.x0 = h->dX0; rp.xref = h->dXref; rp.xref_stride = h->xref_stride;
+    rp.uref = h->dUref; rp.uref_stride = h->uref_stride; rp.x = h->dX; rp.ex = h->dEx; rp.u = h->dU; rp.eu = h->dEu;
+    {
+        constexpr int WAVES = 4;
+        const size_t l = ((size_t)h->n * h->n + (size_t)h->n * h->m + (size_t)WAVES * (h->n + h->nz)) * sizeof(double);
+        hipLaunchKernelGGL((k_rollout<WAVES>), dim3((h->batch + WAVES - 1) / WAVES), dim3(64 * WAVES), l, st, rp);
+        HIP_TRY(h, hipGetLastError());
+    }
+    if (timing) {
+        HIP_TRY(h, hipEventRecord(h->ev[3], st));
+        h->timed = true;
+    }
+    return ALMPC_OK;
+}
+
+int almpc_synchronize(almpc_handle* h) {
+    if (!h) return ALMPC_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return ALMPC_OK;
+}
+
+int almpc_calculate(almpc_handle* h, const almpc_opts* opts) {
+    int rc = almpc_calculate_async(h, opts);
+    if (rc != ALMPC_OK) return rc;
+    return almpc_synchronize(h);
+}
+
+int almpc_get_results(almpc_handle* h, double* x, double* e_x, double* u, double* e_u, int32_t* status,
+                      int32_t* iters, int32_t* polish_iters) {
+    if (!h) return ALMPC_ERR_INVALID;
+    if (!h->designed) return fail(h, ALMPC_ERR_NOT_DESIGNED, "get_results before design");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const size_t b = (size_t)h->batch, xs = (size_t)h->n * (h->N + 1), us = (size_t)h->nz;
+    if (x) HIP_TRY(h, hipMemcpy(x, h->dX, b * xs * sizeof(double), hipMemcpyDeviceToHost));
+    if (e_x) HIP_TRY(h, hipMemcpy(e_x, h->dEx, b * xs * sizeof(double), hipMemcpyDeviceToHost));
+    if (u) HIP_TRY(h, hipMemcpy(u, h->dU, b * us * sizeof(double), hipMemcpyDeviceToHost));
+    if (e_u) HIP_TRY(h, hipMemcpy(e_u, h->dEu, b * us * sizeof(double), hipMemcpyDeviceToHost));
+    if (status) HIP_TRY(h, hipMemcpy(status, h->dStatus, b * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (iters) HIP_TRY(h, hipMemcpy(iters, h->dIters, b * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (polish_iters) HIP_TRY(h, hipMemcpy(polish_iters, h->dPiters, b * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return ALMPC_OK;
+}
+
+int almpc_get_design(almpc_handle* h, double* H, double* F, double* P, double* d) {
+    if (!h) return ALMPC_ERR_INVALID;
+    if (!h->designed) return fail(h, ALMPC_ERR_NOT_DESIGNED, "get_design before design");
+    if (H) std::memcpy(H, h->H.data(), h->H.size() * sizeof(double));
+    if (F) std::memcpy(F, h->F.data(), h->F.size() * sizeof(double));
+    if (P) std::memcpy(P, h->P.data(), h->P.size() * sizeof(double));
+    if (d) std::memcpy(d, h->d.data(), (size_t)h->nz * sizeof(double));
+    return ALMPC_OK;
+}
+
+int almpc_device_results(almpc_handle* h, const double** d_x, const double** d_e_x, const double** d_u,
+                         const double** d_e_u) {
+    if (!h) return ALMPC_ERR_INVALID;
+    if (d_x) *d_x = h->dX;
+    if (d_e_x) *d_e_x = h->dEx;
+    if (d_u) *d_u = h->dU;
+    if (d_e_u) *d_e_u = h->dEu;
+    return ALMPC_OK;
+}
+
+int almpc_get_timing(almpc_handle* h, float* ms_admm, float* ms_polish, float* ms_rollout, float* ms_total) {
+    if (!h) return ALMPC_ERR_INVALID;
+    if (!(h->flags & ALMPC_FLAG_TIMING) || !h->timed) return fail(h, ALMPC_ERR_INVALID, "timing not enabled or no step timed yet");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipEventSynchronize(h->ev[3]));
+    float a = 0, p = 0, r = 0, t = 0;
+    HIP_TRY(h, hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
+    HIP_TRY(h, hipEventElapsedTime(&p, h->ev[1], h->ev[2]));
+    HIP_TRY(h, hipEventElapsedTime(&r, h->ev[2], h->ev[3]));
+    HIP_TRY(h, hipEventElapsedTime(&t, h->ev[0], h->ev[3]));
+    if (ms_admm) *ms_admm = a;
+    if (ms_polish) *ms_polish = p;
+    if (ms_rollout) *ms_rollout = r;
+    if (ms_total) *ms_total = t;
+    return ALMPC_OK;
+}
+
+}  // extern "C"

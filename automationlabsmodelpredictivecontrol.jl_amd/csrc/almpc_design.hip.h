@@ -1,0 +1,353 @@
+// almpc_design.hip.h -- design-time kernels: prediction matrices, condensed Hessian, shared inverses.
+//
+// Reference functions restated (paths relative to /root/reference):
+//   dynamics e_x[:,k+1] = A e_x[:,k] + B e_u[:,k]   src/sub/model_modeler_implementation/linear/mpc_modeler_implementation_linear.jl:58-60
+//   objective                                        src/sub/design_mpc.jl:405-468
+//   terminal weight P on stage N+1                   src/sub/design_mpc.jl:327,448-456
+// condensed as in SURVEY.md section 8a:  E = Phi e0 + Gamma v,  H = 2(Gamma' Qbar Gamma + Rbar + D'Sbar D),
+// F = 2 Gamma' Qbar Phi.  Kernels (SURVEY.md Appendix B ids):
+//   k_design_blocks   K1/K2  Phi_k = A^(k+1), G_k = A^k B
+//   k_design_gamma           Gamma, W = Qbar Gamma, WP = Qbar Phi   (row-major, zero padded)
+//   k_design_hessian  K3/K4  H and F tiles by FP64 MFMA over LDS-staged row panels (the B'QB contraction)
+//   k_design_scale           d = diag(H)^-1/2, H' = DHD, F' = DF
+//   k_design_inverse  K5     (H' + cI)^-1 by in-LDS Cholesky, triangular inverse, X'X
+//   k_pack_frags             dense -> MFMA A-fragment layout used by k_admm
+#pragma once
+#include "almpc_kernels.hip.h"
+
+#include <string>
+#include <vector>
+
+namespace almpc {
+
+// ---- K1/K2 -------------------------------------------------------------------------------------
+// One workgroup.  Phi[k] (n x n, column-major) = A^(k+1); Gk[k] (n x m, column-major) = A^k B.
+__global__ __launch_bounds__(256) void k_design_blocks(int n, int m, int N, const double* A, const double* B,
+                                                       double* Phi, double* Gk) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* As = smem;           // n*n
+    double* Bs = As + n * n;     // n*m
+    double* cur = Bs + n * m;    // n*n  = A^k
+    double* nxt = cur + n * n;
+    for (int t = threadIdx.x; t < n * n; t += blockDim.x) {
+        As[t] = A[t];
+        cur[t] = (t % n == t / n) ? 1.0 : 0.0;
+    }
+    for (int t = threadIdx.x; t < n * m; t += blockDim.x) Bs[t] = B[t];
+    __syncthreads();
+    for (int k = 0; k < N; ++k) {
+        for (int t = threadIdx.x; t < n * m; t += blockDim.x) {
+            const int i = t % n, j = t / n;
+            double s = 0.0;
+            for (int l = 0; l < n; ++l) s += cur[l * n + i] * Bs[j * n + l];
+            Gk[(size_t)k * n * m + t] = s;
+        }
+        for (int t = threadIdx.x; t < n * n; t += blockDim.x) {
+            const int i = t % n, j = t / n;
+            double s = 0.0;
+            for (int l = 0; l < n; ++l) s += As[l * n + i] * cur[j * n + l];
+            nxt[t] = s;
+            Phi[(size_t)k * n * n + t] = s;
+        }
+        __syncthreads();
+        double* tmp = cur; cur = nxt; nxt = tmp;
+    }
+}
+
+// ---- Gamma, W = Qbar Gamma, WP = Qbar Phi -------------------------------------------------------
+// Block k = stage k (rows k*n .. k*n+n-1).  Row-major with strides gs (Gam, W) and ps (WP); buffers are
+// zero-initialised by the host so padding rows/columns stay zero.
+__global__ __launch_bounds__(256) void k_design_gamma(int n, int m, int N, const double* Q, const double* P,
+                                                      const double* Phi, const double* Gk, double* Gam, double* W,
+                                                      double* WP, int gs, int ps) {
+    const int k = blockIdx.x;
+    const double* Qk = (k == N - 1) ? P : Q;  // stage N+1 carries only P (src/sub/design_mpc.jl:448-456)
+    const int nz = m * N;
+    for (int t = threadIdx.x; t < n * nz; t += blockDim.x) {
+        const int p = t / nz, c = t % nz;
+        const int i = c / m, a = c % m;
+        double g = 0.0, w = 0.0;
+        if (k >= i) {
+            const double* G = Gk + (size_t)(k - i) * n * m + (size_t)a * n;
+            g = G[p];
+            for (int q2 = 0; q2 < n; ++q2) w += Qk[(size_t)q2 * n + p] * G[q2];
+        }
+        Gam[(size_t)(k * n + p) * gs + c] = g;
+        W[(size_t)(k * n + p) * gs + c] = w;
+    }
+    for (int t = threadIdx.x; t < n * n; t += blockDim.x) {
+        const int p = t / n, j = t % n;
+        double w = 0.0;
+        for (int q2 = 0; q2 < n; ++q2) w += Qk[(size_t)q2 * n + p] * Phi[(size_t)k * n * n + (size_t)j * n + q2];
+        WP[(size_t)(k * n + p) * ps + j] = w;
+    }
+}
+
+// ---- K3/K4: H = 2 Gamma' W (+ 2 Rbar + 2 D'Sbar D), F = 2 Gamma' WP ------------------------------
+// Workgroup I = row block of 16 condensed variables.  Wave J < nrb computes the H tile (I, J); wave
+// J >= nrb computes F tile (I, J - nrb).  The contraction index (rows of Gamma, n*N of them) is walked in
+// panels of KC rows staged through LDS; panels above the block-triangular zero region are skipped.
+struct HessParams {
+    int n, m, N, nz, nrb, njf;  // njf = ceil(n/16)
+    int kr;                     // padded contraction length (multiple of KC)
+    const double* Gam; const double* W; const double* WP;
+    int gs, ps;
+    const double* R; const double* S;
+    int useR, useS;
+    double* H;  // column-major nz x nz
+    double* F;  // column-major nz x n
+};
+
+constexpr int HESS_KC = 32;
+
+__global__ __launch_bounds__(768) void k_design_hessian(HessParams p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int ws = p.gs + 16, pps = p.ps + 16;  // padded LDS strides: the 4 k-groups of a B read hit different banks
+    double* GI = smem;                       // [KC][16]
+    double* Wc = GI + HESS_KC * 16;          // [KC][ws]
+    double* WPc = Wc + HESS_KC * ws;         // [KC][pps]
+    const int I = blockIdx.x;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, col = lane & 15, q = lane >> 4;
+    const int J = wv;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    // Gamma[:, 16I..16I+15] is zero for rows of stages < floor(16 I / m)
+    const int first_row = (16 * I / p.m) * p.n;
+    const int kstart = (first_row / HESS_KC) * HESS_KC;
+    for (int kc = kstart; kc < p.kr; kc += HESS_KC) {
+        for (int t = threadIdx.x; t < HESS_KC * 16; t += blockDim.x) {
+            const int r = t / 16, c = t % 16;
+            GI[t] = p.Gam[(size_t)(kc + r) * p.gs + I * 16 + c];
+        }
+        for (int t = threadIdx.x; t < HESS_KC * p.gs; t += blockDim.x) {
+            const int r = t / p.gs, c = t % p.gs;
+            Wc[r * ws + c] = p.W[(size_t)(kc + r) * p.gs + c];
+        }
+        for (int t = threadIdx.x; t < HESS_KC * p.ps; t += blockDim.x) {
+            const int r = t / p.ps, c = t % p.ps;
+            WPc[r * pps + c] = p.WP[(size_t)(kc + r) * p.ps + c];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < HESS_KC / 4; ++s) {
+            const double a = GI[(4 * s + q) * 16 + col];
+            const double b = (J < p.nrb) ? Wc[(4 * s + q) * ws + J * 16 + col] : WPc[(4 * s + q) * pps + (J - p.nrb) * 16 + col];
+            acc = mfma_f64(a, b, acc);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int r = I * 16 + q + 4 * reg;
+        if (r >= p.nz) continue;
+        if (J < p.nrb) {
+            const int c = J * 16 + col;
+            if (c >= p.nz) continue;
+            double v = 2.0 * acc[reg];
+            const int ir = r / p.m, ar = r % p.m, ic = c / p.m, ac = c % p.m;
+            if (p.useR && ir == ic) v += 2.0 * p.R[(size_t)ac * p.m + ar];
+            if (p.useS) {  // delta_u[:,i] = u[:,i] - u[:,i+1], i = 1..N-1 (src/sub/design_mpc.jl:429-431)
+                if (ir == ic) {
+                    const int cnt = (ir <= p.N - 2 ? 1 : 0) + (ir >= 1 ? 1 : 0);
+                    v += 2.0 * cnt * p.S[(size_t)ac * p.m + ar];
+                } else if (ir - ic == 1 || ic - ir == 1) {
+                    v -= 2.0 * p.S[(size_t)ac * p.m + ar];
+                }
+            }
+            p.H[(size_t)c * p.nz + r] = v;
+        } else {
+            const int j = (J - p.nrb) * 16 + col;
+            if (j < p.n) p.F[(size_t)j * p.nz + r] = 2.0 * acc[reg];
+        }
+    }
+}
+
+// ---- scaling -------------------------------------------------------------------------------------
+// d = diag(H)^-1/2 (pad rows 1), Hs (ld = nzs, symmetrised) = D H D, Fs (ld = nzs) = D F.  flag[0] != 0 on a
+// non-positive diagonal.
+__global__ __launch_bounds__(256) void k_design_scale(int nz, int nzs, int n, const double* H, const double* F,
+                                                      double* d, double* Hs, double* Fs, int* flag) {
+    for (int t = threadIdx.x; t < nzs; t += blockDim.x) {
+        double v = 1.0;
+        if (t < nz) {
+            const double h = H[(size_t)t * nz + t];
+            if (!(h > 0.0)) { atomicExch(flag, 1); v = 1.0; }
+            else v = 1.0 / sqrt(h);
+        }
+        d[t] = v;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < nz * nz; t += blockDim.x) {
+        const int r = t % nz, c = t / nz;
+        const double h = 0.5 * (H[(size_t)c * nz + r] + H[(size_t)r * nz + c]);
+        Hs[(size_t)c * nzs + r] = d[r] * h * d[c];
+    }
+    for (int t = threadIdx.x; t < nz * n; t += blockDim.x) {
+        const int r = t % nz, c = t / nz;
+        Fs[(size_t)c * nzs + r] = d[r] * F[(size_t)c * nz + r];
+    }
+}
+
+// ---- K5: Minv = (Hs + c I)^-1 -------------------------------------------------------------------------
+// One workgroup, matrix in LDS (ld = nz+1 to spread banks).  Cholesky (right-looking), in-place inverse of
+// the triangular factor, then X'X.  flag[0] != 0 if a pivot is not positive.
+__global__ __launch_bounds__(512) void k_design_inverse(int nz, int nzs, const double* Hs, double cshift, double* Out,
+                                                        int* flag) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int ld = nz + 1;
+    double* L = smem;         // [nz][ld], element (i,j) at L[j*ld + i]
+    double* xo = L + (size_t)nz * ld;  // [nz] scratch column
+    int* badp = reinterpret_cast<int*>(xo + nz);  // in the dynamic region: a static __shared__ would misalign it
+    if (threadIdx.x == 0) *badp = 0;
+    for (int t = threadIdx.x; t < nz * nz; t += blockDim.x) {
+        const int i = t % nz, j = t / nz;
+        L[j * ld + i] = Hs[(size_t)j * nzs + i] + (i == j ? cshift : 0.0);
+    }
+    __syncthreads();
+    for (int j = 0; j < nz; ++j) {
+        const double piv = L[j * ld + j];
+        if (!(piv > 0.0)) { if (threadIdx.x == 0) *badp = 1; }
+        const double ljj = sqrt(piv > 0.0 ? piv : 1.0);
+        __syncthreads();
+        for (int i = j + threadIdx.x; i < nz; i += blockDim.x) L[j * ld + i] = (i == j) ? ljj : L[j * ld + i] / ljj;
+        __syncthreads();
+        const int rem = nz - j - 1;
+        for (int t = threadIdx.x; t < rem * rem; t += blockDim.x) {
+            const int i = j + 1 + t % rem, k = j + 1 + t / rem;
+            if (i >= k) L[k * ld + i] -= L[j * ld + i] * L[j * ld + k];
+        }
+        __syncthreads();
+    }
+    // in-place inverse of the lower-triangular factor (unblocked dtrti2, lower): columns right to left
+    for (int j = nz - 1; j >= 0; --j) {
+        const double ajj = 1.0 / L[j * ld + j];
+        // x := T x with T = already inverted trailing block, x = L[j+1:, j]
+        for (int i = j + 1 + threadIdx.x; i < nz; i += blockDim.x) {
+            double s = 0.0;
+            for (int k = j + 1; k <= i; ++k) s += L[k * ld + i] * L[j * ld + k];
+            xo[i] = -s * ajj;
+        }
+        __syncthreads();
+        for (int i = j + threadIdx.x; i < nz; i += blockDim.x) L[j * ld + i] = (i == j) ? ajj : xo[i];
+        __syncthreads();
+    }
+    // Out = X'X, X = L^-1 (lower): Out[i][j] = sum_{k >= max(i,j)} X[k][i] X[k][j]
+    for (int t = threadIdx.x; t < nz * nz; t += blockDim.x) {
+        const int i = t % nz, j = t / nz;
+        if (i < j) continue;
+        double s = 0.0;
+        for (int k = i; k < nz; ++k) s += L[i * ld + k] * L[j * ld + k];
+        Out[(size_t)j * nzs + i] = s;
+        Out[(size_t)i * nzs + j] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && *badp) atomicExch(flag, 2);
+}
+
+// ---- dense (column-major, ld) -> MFMA A-fragment layout ---------------------------------------------
+// frag[(rb*ks + s)*64 + l] = M[rb*16 + (l&15)][4 s + (l>>4)]  (zero outside rows x cols)
+__global__ __launch_bounds__(256) void k_pack_frags(const double* M, int rows, int cols, int ld, int nrb, int ks,
+                                                    double* frag) {
+    const int total = nrb * ks * 64;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const int l = t & 63, s = (t >> 6) % ks, rb = (t >> 6) / ks;
+        const int r = rb * 16 + (l & 15), c = 4 * s + (l >> 4);
+        frag[t] = (r < rows && c < cols) ? M[(size_t)c * ld + r] : 0.0;
+    }
+}
+
+// Runs the whole shared-model design on `stream` and leaves the packed operands in the handle's buffers.
+// Returns 0 or a negative almpc_status value (numbers as in include/almpc.h).
+inline int design_shared_device(hipStream_t stream, int n, int m, int N, int nzs, int nrb, int ks, int ksf,
+                                const std::vector<double>& A, const std::vector<double>& B, std::vector<double> Q,
+                                std::vector<double> R, std::vector<double> S, std::vector<double> P, double rho,
+                                double sigma, double* dMinvFrag, double* dGFrag, double* dHFrag, double* dFFrag,
+                                double* dG, double* dD, std::vector<double>& hH, std::vector<double>& hF,
+                                std::vector<double>& hd, std::string& err) {
+    const int nz = m * N;
+    const int useR = R[0] != 0.0, useS = useR && S[0] != 0.0;  // the reference tests only element [1,1]
+    auto symmetrise = [](std::vector<double>& M, int k) {
+        for (int j = 0; j < k; ++j)
+            for (int i = 0; i < j; ++i) {
+                const double v = 0.5 * (M[(size_t)j * k + i] + M[(size_t)i * k + j]);
+                M[(size_t)j * k + i] = M[(size_t)i * k + j] = v;
+            }
+    };
+    symmetrise(Q, n); symmetrise(P, n); symmetrise(R, m); symmetrise(S, m);
+    const int njf = (n + 15) / 16, ps = 16 * njf, gs = nzs;
+    const int kr = ((n * N + HESS_KC - 1) / HESS_KC) * HESS_KC;
+    std::vector<void*> tmp;
+    auto cleanup = [&]() { for (void* p : tmp) (void)hipFree(p); };
+#define DTRY(call)                                                                           \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e_); cleanup(); return -3; } \
+    } while (0)
+    auto dnew = [&](double** p, size_t cnt) -> hipError_t {
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(p), cnt * sizeof(double) + 64);
+        if (e == hipSuccess) { tmp.push_back(*p); e = hipMemsetAsync(*p, 0, cnt * sizeof(double), stream); }
+        return e;
+    };
+    double *dA, *dB, *dQ, *dR, *dS, *dP, *dPhi, *dGk, *dGam, *dW, *dWP, *dH, *dF, *dHs, *dFs, *dMinv;
+    int* dFlag;
+    DTRY(dnew(&dA, (size_t)n * n)); DTRY(dnew(&dB, (size_t)n * m)); DTRY(dnew(&dQ, (size_t)n * n));
+    DTRY(dnew(&dR, (size_t)m * m)); DTRY(dnew(&dS, (size_t)m * m)); DTRY(dnew(&dP, (size_t)n * n));
+    DTRY(dnew(&dPhi, (size_t)N * n * n)); DTRY(dnew(&dGk, (size_t)N * n * m));
+    DTRY(dnew(&dGam, (size_t)kr * gs)); DTRY(dnew(&dW, (size_t)kr * gs)); DTRY(dnew(&dWP, (size_t)kr * ps));
+    DTRY(dnew(&dH, (size_t)nz * nz)); DTRY(dnew(&dF, (size_t)nz * n));
+    DTRY(dnew(&dHs, (size_t)nz * nzs)); DTRY(dnew(&dFs, (size_t)n * nzs)); DTRY(dnew(&dMinv, (size_t)nz * nzs));
+    {
+        double* f = nullptr;
+        DTRY(dnew(&f, 8));
+        dFlag = reinterpret_cast<int*>(f);
+    }
+    DTRY(hipMemcpyAsync(dA, A.data(), A.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    DTRY(hipMemcpyAsync(dB, B.data(), B.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    DTRY(hipMemcpyAsync(dQ, Q.data(), Q.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    DTRY(hipMemcpyAsync(dR, R.data(), R.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    DTRY(hipMemcpyAsync(dS, S.data(), S.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    DTRY(hipMemcpyAsync(dP, P.data(), P.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+
+    hipLaunchKernelGGL(k_design_blocks, dim3(1), dim3(256), (size_t)(3 * n * n + n * m) * sizeof(double), stream, n, m, N,
+                       dA, dB, dPhi, dGk);
+    DTRY(hipGetLastError());
+    hipLaunchKernelGGL(k_design_gamma, dim3(N), dim3(256), 0, stream, n, m, N, dQ, dP, dPhi, dGk, dGam, dW, dWP, gs, ps);
+    DTRY(hipGetLastError());
+    HessParams hp;
+    hp.n = n; hp.m = m; hp.N = N; hp.nz = nz; hp.nrb = nrb; hp.njf = njf; hp.kr = kr;
+    hp.Gam = dGam; hp.W = dW; hp.WP = dWP; hp.gs = gs; hp.ps = ps; hp.R = dR; hp.S = dS; hp.useR = useR; hp.useS = useS;
+    hp.H = dH; hp.F = dF;
+    const size_t hess_lds = (size_t)HESS_KC * (16 + (gs + 16) + (ps + 16)) * sizeof(double);
+    hipLaunchKernelGGL(k_design_hessian, dim3(nrb), dim3(64 * (nrb + njf)), hess_lds, stream, hp);
+    DTRY(hipGetLastError());
+    hipLaunchKernelGGL(k_design_scale, dim3(1), dim3(256), 0, stream, nz, nzs, n, dH, dF, dD, dHs, dFs, dFlag);
+    DTRY(hipGetLastError());
+    const size_t inv_lds = ((size_t)nz * (nz + 1) + nz + 2) * sizeof(double);
+    DTRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_design_inverse), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)inv_lds));
+    hipLaunchKernelGGL(k_design_inverse, dim3(1), dim3(512), inv_lds, stream, nz, nzs, dHs, sigma + rho, dMinv, dFlag);
+    DTRY(hipGetLastError());
+    hipLaunchKernelGGL(k_design_inverse, dim3(1), dim3(512), inv_lds, stream, nz, nzs, dHs, 0.0, dG, dFlag);
+    DTRY(hipGetLastError());
+    hipLaunchKernelGGL(k_pack_frags, dim3(32), dim3(256), 0, stream, dMinv, nz, nz, nzs, nrb, ks, dMinvFrag);
+    hipLaunchKernelGGL(k_pack_frags, dim3(32), dim3(256), 0, stream, dG, nz, nz, nzs, nrb, ks, dGFrag);
+    hipLaunchKernelGGL(k_pack_frags, dim3(32), dim3(256), 0, stream, dHs, nz, nz, nzs, nrb, ks, dHFrag);
+    hipLaunchKernelGGL(k_pack_frags, dim3(32), dim3(256), 0, stream, dFs, nz, n, nzs, nrb, ksf, dFFrag);
+    DTRY(hipGetLastError());
+    hH.assign((size_t)nz * nz, 0.0); hF.assign((size_t)nz * n, 0.0); hd.assign((size_t)nzs, 0.0);
+    int flag = 0;
+    DTRY(hipMemcpyAsync(hH.data(), dH, hH.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+    DTRY(hipMemcpyAsync(hF.data(), dF, hF.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+    DTRY(hipMemcpyAsync(hd.data(), dD, hd.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+    DTRY(hipMemcpyAsync(&flag, dFlag, sizeof(int), hipMemcpyDeviceToHost, stream));
+    DTRY(hipStreamSynchronize(stream));
+#undef DTRY
+    cleanup();
+    if (flag != 0) {
+        err = flag == 1 ? "design: condensed Hessian has a non-positive diagonal (R = 0 with an input that does not reach the cost?)"
+                        : "design: Cholesky pivot not positive (Hessian not positive definite)";
+        return -6;
+    }
+    return 0;
+}
+
+}  // namespace almpc

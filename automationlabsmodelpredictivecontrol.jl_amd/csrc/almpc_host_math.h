@@ -1,0 +1,115 @@
+// almpc_host_math.h -- small dense column-major float64 helpers for the design-time host code
+// (DARE on n x n, packing).  Not a CPU path of the solve: nothing here runs per step.
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <vector>
+
+namespace almpc {
+namespace hm {
+
+typedef std::vector<double> mat;  // column-major, explicit dims at call sites
+
+inline mat eye(int n) {
+    mat I((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) I[(size_t)i * n + i] = 1.0;
+    return I;
+}
+
+// C(r x c) = A(r x k) * B(k x c)
+inline mat mul(const mat& A, const mat& B, int r, int k, int c) {
+    mat C((size_t)r * c, 0.0);
+    for (int j = 0; j < c; ++j)
+        for (int l = 0; l < k; ++l) {
+            const double b = B[(size_t)j * k + l];
+            if (b == 0.0) continue;
+            for (int i = 0; i < r; ++i) C[(size_t)j * r + i] += A[(size_t)l * r + i] * b;
+        }
+    return C;
+}
+
+inline mat transpose(const mat& A, int r, int c) {
+    mat T((size_t)r * c);
+    for (int j = 0; j < c; ++j)
+        for (int i = 0; i < r; ++i) T[(size_t)i * c + j] = A[(size_t)j * r + i];
+    return T;
+}
+
+// Solve A X = B (A n x n general, B n x c) by LU with partial pivoting. Returns false if singular.
+inline bool lu_solve(mat A, mat& B, int n, int c) {
+    std::vector<int> piv(n);
+    for (int k = 0; k < n; ++k) {
+        int p = k;
+        double best = std::fabs(A[(size_t)k * n + k]);
+        for (int i = k + 1; i < n; ++i)
+            if (std::fabs(A[(size_t)k * n + i]) > best) { best = std::fabs(A[(size_t)k * n + i]); p = i; }
+        if (!(best > 0.0)) return false;
+        if (p != k) {
+            for (int j = 0; j < n; ++j) std::swap(A[(size_t)j * n + k], A[(size_t)j * n + p]);
+            for (int j = 0; j < c; ++j) std::swap(B[(size_t)j * n + k], B[(size_t)j * n + p]);
+        }
+        const double inv = 1.0 / A[(size_t)k * n + k];
+        for (int i = k + 1; i < n; ++i) {
+            const double f = A[(size_t)k * n + i] * inv;
+            if (f == 0.0) continue;
+            A[(size_t)k * n + i] = f;
+            for (int j = k + 1; j < n; ++j) A[(size_t)j * n + i] -= f * A[(size_t)j * n + k];
+            for (int j = 0; j < c; ++j) B[(size_t)j * n + i] -= f * B[(size_t)j * n + k];
+        }
+    }
+    for (int j = 0; j < c; ++j)
+        for (int i = n - 1; i >= 0; --i) {
+            double s = B[(size_t)j * n + i];
+            for (int l = i + 1; l < n; ++l) s -= A[(size_t)l * n + i] * B[(size_t)j * n + l];
+            B[(size_t)j * n + i] = s / A[(size_t)i * n + i];
+        }
+    return true;
+}
+
+inline double fro(const mat& A) {
+    double s = 0.0;
+    for (double v : A) s += v * v;
+    return std::sqrt(s);
+}
+
+// Stabilising solution of the discrete algebraic Riccati equation
+//   A'PA - P - A'PB (R + B'PB)^-1 B'PA + Q = 0
+// by the structure-preserving doubling algorithm.  Stands in for ControlSystems.are(Discrete, A, B, Q, R)
+// (reference: src/sub/design_mpc.jl:327).
+inline bool dare(const mat& A, const mat& B, const mat& Q, const mat& R, int n, int m, mat& P) {
+    mat Rinv_Bt = transpose(B, n, m);  // m x n
+    if (!lu_solve(R, Rinv_Bt, m, n)) return false;
+    mat Ak = A, Gk = mul(B, Rinv_Bt, n, m, n), Hk = Q;
+    const mat I = eye(n);
+    for (int it = 0; it < 200; ++it) {
+        mat W = mul(Gk, Hk, n, n, n);
+        for (size_t i = 0; i < W.size(); ++i) W[i] += I[i];
+        mat WinvA = Ak, WinvG = Gk;
+        if (!lu_solve(W, WinvA, n, n)) return false;
+        if (!lu_solve(W, WinvG, n, n)) return false;
+        const mat At = transpose(Ak, n, n);
+        mat A1 = mul(Ak, WinvA, n, n, n);
+        mat G1 = mul(mul(Ak, WinvG, n, n, n), At, n, n, n);
+        mat H1 = mul(mul(At, Hk, n, n, n), WinvA, n, n, n);
+        for (size_t i = 0; i < G1.size(); ++i) { G1[i] += Gk[i]; H1[i] += Hk[i]; }
+        for (int j = 0; j < n; ++j)
+            for (int i = 0; i < j; ++i) {
+                const double h = 0.5 * (H1[(size_t)j * n + i] + H1[(size_t)i * n + j]);
+                H1[(size_t)j * n + i] = H1[(size_t)i * n + j] = h;
+                const double g = 0.5 * (G1[(size_t)j * n + i] + G1[(size_t)i * n + j]);
+                G1[(size_t)j * n + i] = G1[(size_t)i * n + j] = g;
+            }
+        mat diff = H1;
+        for (size_t i = 0; i < diff.size(); ++i) diff[i] -= Hk[i];
+        const bool done = fro(diff) <= 1e-13 * std::fmax(1.0, fro(H1));
+        Ak.swap(A1); Gk.swap(G1); Hk.swap(H1);
+        if (done) break;
+    }
+    for (double v : Hk)
+        if (!std::isfinite(v)) return false;
+    P = Hk;
+    return true;
+}
+
+}  // namespace hm
+}  // namespace almpc

@@ -1,0 +1,165 @@
+/*
+ * almpc.h -- C ABI of libalmpc.so, the MI355X (gfx950) batched condensed-QP MPC solve engine.
+ *
+ * Drop-in boundary for ONE path of AutomationLabsModelPredictiveControl.jl (reference paths are
+ * relative to /root/reference): the per-step solve that the reference runs through
+ *   JuMP.Model(OSQP.Optimizer)             src/sub/solver_selection.jl:92-98   (solver slot)
+ *   update_initialization!(C, x0)           src/main/computation_mpc.jl:17-29
+ *   calculate!(C)                           src/main/computation_mpc.jl:38-55
+ * on the QP posed by
+ *   _model_predictive_control_modeler_implementation(::LinearProgramming, ...)
+ *                                           src/sub/model_modeler_implementation/linear/mpc_modeler_implementation_linear.jl:20-103
+ *   _create_weights_coefficients            src/sub/design_mpc.jl:264-283
+ *   _create_terminal_ingredient             src/sub/design_mpc.jl:298-394
+ *   _create_quadratic_cost_function         src/sub/design_mpc.jl:405-468
+ * for a BATCH of independent controller instances that share (A, B, weights, box).
+ *
+ * Conventions
+ *  - every matrix is column-major Float64, i.e. the memory of a Julia Matrix{Float64}
+ *    (zero-copy `ccall` with Ptr{Float64}); batch is the slowest axis:
+ *    x0[batch][n], u[batch][N][m], x[batch][N+1][n]  ==  Julia Array{Float64,3}(m, N, batch) etc.
+ *  - the caller owns every host buffer; the library owns device memory behind the handle.
+ *  - every entry point returns 0 (ALMPC_OK) or a negative almpc_status; nothing throws across
+ *    the boundary; almpc_last_error(h) gives the message of the last failure on that handle.
+ *  - per-instance solver outcome goes to status[] (almpc_solve_status), never to the return code.
+ *  - a handle is bound to one HIP device and one stream; it is not thread-safe; distinct handles
+ *    are independent.  One process per GPU: multi-GPU runs create one handle per rank on its own
+ *    shard of the batch (instances never interact, so there is no data-path collective).
+ *  - there is NO CPU fallback: if no gfx950 device is usable almpc_create fails with
+ *    ALMPC_ERR_NO_DEVICE.
+ */
+#ifndef ALMPC_H
+#define ALMPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALMPC_VERSION_MAJOR 0
+#define ALMPC_VERSION_MINOR 1
+
+typedef struct almpc_handle almpc_handle;
+
+typedef enum almpc_status {
+    ALMPC_OK = 0,
+    ALMPC_ERR_INVALID = -1,      /* bad argument (null pointer, non-positive size, ...)          */
+    ALMPC_ERR_NO_DEVICE = -2,    /* no usable HIP device / device id out of range                */
+    ALMPC_ERR_HIP = -3,          /* a HIP runtime call failed (message in almpc_last_error)      */
+    ALMPC_ERR_UNSUPPORTED = -4,  /* size or option outside what the kernels are built for        */
+    ALMPC_ERR_NOT_DESIGNED = -5, /* calculate/get before design                                  */
+    ALMPC_ERR_NUMERIC = -6       /* design-time numerical failure (DARE / Cholesky)              */
+} almpc_status;
+
+/* per-instance outcome written by almpc_calculate */
+typedef enum almpc_solve_status {
+    ALMPC_SOLVED = 0,          /* KKT conditions hold: ADMM met its tolerance and/or the polish certified */
+    ALMPC_MAX_ITER = 1,        /* ADMM hit max_iter and polish was off or hit its own cap                   */
+    ALMPC_NON_FINITE = 2       /* a non-finite value appeared (bad inputs)                                  */
+} almpc_solve_status;
+
+/*
+ * Solver options.  The ADMM fields are OSQP's settings of the same name (the reference builds
+ * OSQP.Optimizer without attributes, src/sub/solver_selection.jl:94-95, i.e. OSQP defaults:
+ * rho 0.1, sigma 1e-6, alpha 1.6, eps_abs = eps_rel = 1e-3, check_termination 25, max_iter 4000,
+ * polish off).  Defaults here differ in two documented places: `polish` is ON (it is what brings
+ * u* within 1e-5 of the exact optimum) and `max_iter` is 50 (ADMM only has to identify the active
+ * set for the polish).  almpc_default_opts fills the defaults.
+ */
+typedef struct almpc_opts {
+    double rho;
+    double sigma;
+    double alpha;
+    double eps_abs;
+    double eps_rel;
+    int32_t max_iter;
+    int32_t check_every;
+    int32_t polish;           /* 0 off, 1 on                                                   */
+    int32_t polish_max_iter;  /* cap on active-set changes per instance; <=0 -> 20*nz+50       */
+    int32_t warm_start;       /* 1: start ADMM from the previous step's (x, z, y) of each instance */
+    int32_t reserved[3];
+} almpc_opts;
+
+void almpc_default_opts(almpc_opts* opts);
+
+/* flags for almpc_create */
+#define ALMPC_FLAG_TIMING 0x1u /* record HIP events around every kernel of almpc_calculate */
+
+/*
+ * Create a solver for `batch` instances of an (n states, m inputs, horizon N) controller on HIP
+ * device `device_id`.  Supported: 1 <= m*N <= 128, 1 <= n <= 64.
+ */
+int almpc_create(almpc_handle** out, int n, int m, int N, int batch, int device_id, uint32_t flags);
+void almpc_destroy(almpc_handle* h);
+const char* almpc_last_error(const almpc_handle* h);
+
+/*
+ * Design for a model shared by all instances (replaces _model_predictive_control_design for the
+ * linear system, src/sub/design_mpc.jl:54-129).
+ *   A n*n, B n*m, Q n*n, R m*m, S m*m (NULL -> 0), P n*n (NULL -> DARE(A,B,Q,R) as
+ *   src/sub/design_mpc.jl:327), umin/umax m.  xmin/xmax must be NULL (state box: not yet built,
+ *   returns ALMPC_ERR_UNSUPPORTED).  rho/sigma are fixed at design time because the shared
+ *   KKT inverse depends on them.
+ * Builds Phi, Gamma blocks, H = 2(Gamma' Qbar Gamma + Rbar + D'SbarD), F = 2 Gamma' Qbar Phi,
+ * the Jacobi scaling, (H' + (sigma+rho) I)^-1 and H'^-1 on the device.
+ */
+int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const double* Q,
+                        const double* R, const double* S, const double* P, const double* umin,
+                        const double* umax, const double* xmin, const double* xmax, double rho,
+                        double sigma);
+
+/*
+ * References (replaces _design_reference_mpc, src/main/main_mpc.jl:105-117, and the JuMP.fix of
+ * x_reference/u_reference, ...linear.jl:90-100).  per_instance = 0: xref n*(N+1), uref m*N shared
+ * by all instances.  per_instance = 1: xref [batch][N+1][n], uref [batch][N][m].
+ * Default after design: all zeros.
+ */
+int almpc_set_reference(almpc_handle* h, const double* xref, const double* uref, int per_instance);
+
+/* x0: host pointer, [batch][n].  Replaces update_initialization! (src/main/computation_mpc.jl:17-29). */
+int almpc_update_initialization(almpc_handle* h, const double* x0);
+/* same, x0 already in device memory of h's device (HBM-resident benchmark / closed loop on device) */
+int almpc_update_initialization_device(almpc_handle* h, const double* d_x0);
+
+/*
+ * One MPC step for every instance: gradient f = F e0, ADMM, polish, rollout.  Replaces
+ * JuMP.optimize! + the four JuMP.value reads of calculate! (src/main/computation_mpc.jl:41-53).
+ * opts == NULL -> defaults.  opts->rho / opts->sigma must equal the design values (or be 0).
+ * Synchronous: results are complete in device memory on return.
+ */
+int almpc_calculate(almpc_handle* h, const almpc_opts* opts);
+/* enqueue only (no host sync); pair with almpc_synchronize */
+int almpc_calculate_async(almpc_handle* h, const almpc_opts* opts);
+int almpc_synchronize(almpc_handle* h);
+
+/*
+ * Copy results to host.  Any pointer may be NULL.  Layouts: x, e_x [batch][N+1][n];
+ * u, e_u [batch][N][m]  (ModelPredictiveControlResults, src/types/types.jl:134-139);
+ * status, iters, polish_iters [batch].
+ */
+int almpc_get_results(almpc_handle* h, double* x, double* e_x, double* u, double* e_u,
+                      int32_t* status, int32_t* iters, int32_t* polish_iters);
+
+/* Design data for parity tests: H nz*nz, F nz*n (both unscaled, column-major), P n*n, d nz. */
+int almpc_get_design(almpc_handle* h, double* H, double* F, double* P, double* d);
+
+/*
+ * Device pointers of the handle's result buffers (same layouts as almpc_get_results), for callers
+ * that keep the loop on the GPU.  Valid until almpc_destroy.
+ */
+int almpc_device_results(almpc_handle* h, const double** d_x, const double** d_e_x,
+                         const double** d_u, const double** d_e_u);
+
+/*
+ * Timing of the last almpc_calculate (needs ALMPC_FLAG_TIMING): milliseconds spent in the ADMM
+ * kernel, the polish kernel(s), the rollout kernel, and the whole enqueue->done span, measured
+ * with HIP events on the handle's stream.
+ */
+int almpc_get_timing(almpc_handle* h, float* ms_admm, float* ms_polish, float* ms_rollout,
+                     float* ms_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALMPC_H */

@@ -1,0 +1,741 @@
+"""CPU oracle (numpy, float64) for the condensed-QP MPC hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is part of the product
+path: only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg
+of ``bench.py`` may import it, and only as the checker.
+
+What is restated here (reference = AutomationLabsModelPredictiveControl.jl v0.1.4,
+paths relative to /root/reference):
+
+* the QP the reference poses through JuMP
+    - variables / dynamics / input box / optional state box / deviation defs:
+      src/sub/model_modeler_implementation/linear/mpc_modeler_implementation_linear.jl:48-100
+    - objective (no 1/2 factor, stage sum i=1..N with Q and R, P on stage N+1 only,
+      optional S on delta_u for i=1..N-1): src/sub/design_mpc.jl:405-468
+    - terminal cost P = DARE(A,B,Q,R), terminal "equality": src/sub/design_mpc.jl:298-394
+    - weights Q=q*I, R=r*I, S=s*I with defaults 100/0.1/0: src/sub/design_mpc.jl:264-283,
+      src/main/main_mpc.jl:87-94
+    - constant references over the horizon: src/main/main_mpc.jl:105-117
+    - per step: fix x[:,1]=x0, optimise, read back u,e_u,x,e_x: src/main/computation_mpc.jl:17-55
+* the solver arithmetic the reference delegates to OSQP (third-party, NOT in
+  /root/reference: Julia package OSQP compat "0.8", Project.toml:28 -> libosqp 0.6.x,
+  exact version unpinned because no Manifest.toml is committed).  Restated from the
+  published algorithm (Stellato et al., "OSQP: an operator splitting solver for
+  quadratic programs", Alg. 1) in ``osqp_admm`` (general l<=Az<=u form, used on the
+  reference's sparse multiple-shooting statement) and ``admm_box`` (the condensed,
+  box-only specialisation the HIP kernels implement).
+
+PARITY PIN STATUS: the reference's tests contain no numeric golden vector for a
+QP solution.  The oracle is pinned against what the reference's
+tests do hold: the linear-regressor fixture (A,B) and the scenario + loose
+assertions of test/computation_mpc_test.jl:981-1054, and the structural constraint
+counts 74/78 of test/terminal_ingredient_test.jl:160,317.  Beyond those tolerances
+(0.5 on x, 3 on u) the OSQP numerics are "parity unpinned"; truth for the 1e-5 bar
+is the exact optimum of the reference's strictly convex QP, certified by a KKT
+residual (``kkt_residual``) that does not depend on the method that produced it.
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+from typing import Optional
+
+import numpy as np
+
+__all__ = [
+    "MPCProblem", "dare", "condense", "condensed_qp", "solve_box_qp_exact", "kkt_residual",
+    "rollout", "solve_mpc_exact", "sparse_problem", "osqp_admm", "admm_box", "polish_active_set",
+    "design_shared", "solve_mpc_admm_polish",
+    "jacobi_scaling", "decode_linear_regressor_fixture", "splitmix_normal",
+    "double_integrator", "quadrotor", "qtp_linear_fixture_problem", "quadrotor_x0_batch",
+]
+
+
+# --------------------------------------------------------------------------------------
+# problem container
+# --------------------------------------------------------------------------------------
+@dataclasses.dataclass
+class MPCProblem:
+    """Design data of one linear MPC controller (one `proceed_controller` call).
+
+    Shapes follow the reference's Julia matrices (column-major there; here the
+    same logical indices): A n*n, B n*m, Q n*n, R m*m, S m*m, P n*n,
+    x_ref n*(N+1), u_ref m*N, u_min/u_max m, x_min/x_max n (or None: the reference
+    adds the state box only when kw `mpc_state_constraint` is present,
+    ...linear.jl:62-70), terminal in {"none","equality"}.
+    """
+    A: np.ndarray
+    B: np.ndarray
+    N: int
+    Q: np.ndarray
+    R: np.ndarray
+    S: np.ndarray
+    P: np.ndarray
+    x_ref: np.ndarray
+    u_ref: np.ndarray
+    u_min: np.ndarray
+    u_max: np.ndarray
+    x_min: Optional[np.ndarray] = None
+    x_max: Optional[np.ndarray] = None
+    terminal: str = "none"
+
+    @property
+    def n(self) -> int:
+        return self.A.shape[0]
+
+    @property
+    def m(self) -> int:
+        return self.B.shape[1]
+
+    @property
+    def nz(self) -> int:
+        return self.m * self.N
+
+
+def make_problem(A, B, N, u_min, u_max, x_ref=None, u_ref=None, q=100.0, r=0.1, s=0.0,
+                 x_min=None, x_max=None, terminal="none", P=None) -> MPCProblem:
+    """Defaults as the reference: Q=100*I, R=0.1*I, S=0 (src/main/main_mpc.jl:87-94),
+    P = DARE (src/sub/design_mpc.jl:327), references broadcast over the horizon
+    (src/main/main_mpc.jl:105-117)."""
+    A = np.asarray(A, dtype=np.float64)
+    B = np.asarray(B, dtype=np.float64)
+    n, m = B.shape
+    Q = q * np.eye(n)
+    R = r * np.eye(m)
+    S = s * np.eye(m)
+    if P is None:
+        P = dare(A, B, Q, R)
+    xr = np.zeros(n) if x_ref is None else np.asarray(x_ref, dtype=np.float64)
+    ur = np.zeros(m) if u_ref is None else np.asarray(u_ref, dtype=np.float64)
+    x_ref_h = xr.reshape(n, -1) * np.ones((n, N + 1)) if xr.ndim == 1 else xr
+    u_ref_h = ur.reshape(m, -1) * np.ones((m, N)) if ur.ndim == 1 else ur
+    return MPCProblem(A, B, N, Q, R, S, P, x_ref_h, u_ref_h,
+                      np.asarray(u_min, dtype=np.float64), np.asarray(u_max, dtype=np.float64),
+                      None if x_min is None else np.asarray(x_min, dtype=np.float64),
+                      None if x_max is None else np.asarray(x_max, dtype=np.float64),
+                      terminal)
+
+
+# --------------------------------------------------------------------------------------
+# DARE  (reference: ControlSystems.are(Discrete, A, B, Q, R), src/sub/design_mpc.jl:327)
+# --------------------------------------------------------------------------------------
+def dare(A, B, Q, R, tol=1e-13, max_iter=200):
+    """Stabilising solution of A'PA - P - A'PB (R + B'PB)^-1 B'PA + Q = 0 by the
+    structure-preserving doubling algorithm (quadratically convergent; also fine
+    for eigenvalues on the unit circle as long as (A,B) is stabilisable and
+    (A,Q^1/2) detectable).  scipy.linalg.solve_discrete_are is the independent
+    check in tests/test_oracle.py."""
+    A = np.asarray(A, dtype=np.float64)
+    n = A.shape[0]
+    Ak = A.copy()
+    Gk = B @ np.linalg.solve(R, B.T)
+    Hk = np.asarray(Q, dtype=np.float64).copy()
+    I = np.eye(n)
+    for _ in range(max_iter):
+        W = I + Gk @ Hk
+        WinvA = np.linalg.solve(W, Ak)
+        WinvG = np.linalg.solve(W, Gk)
+        A1 = Ak @ WinvA
+        G1 = Gk + Ak @ WinvG @ Ak.T
+        H1 = Hk + Ak.T @ Hk @ WinvA
+        H1 = 0.5 * (H1 + H1.T)
+        G1 = 0.5 * (G1 + G1.T)
+        done = np.linalg.norm(H1 - Hk, ord="fro") <= tol * max(1.0, np.linalg.norm(H1, ord="fro"))
+        Ak, Gk, Hk = A1, G1, H1
+        if done:
+            break
+    return Hk
+
+
+def dare_residual(A, B, Q, R, P):
+    K = np.linalg.solve(R + B.T @ P @ B, B.T @ P @ A)
+    return A.T @ P @ A - P - A.T @ P @ B @ K + Q
+
+
+# --------------------------------------------------------------------------------------
+# condensation  (SURVEY.md section 8a "condensed restatement")
+# --------------------------------------------------------------------------------------
+def condense(p: MPCProblem):
+    """E = vec(e_x[:,2..N+1]) = Phi e0 + Gamma v,  v = vec(e_u).
+
+    Phi = [A; A^2; ...; A^N]  (nN x n); Gamma block (i,j) = A^(i-j) B, i>=j  (nN x nz).
+    Qbar = blkdiag(Q x (N-1), P): the reference's stage sum runs over columns
+    1..N of e_x with Q (column 1 = e0 is a constant) and column N+1 carries only P
+    (src/sub/design_mpc.jl:448-456).  OSQP convention 1/2 v'Hv + f'v, so the
+    reference's factor-free objective gives H = 2(Gamma' Qbar Gamma + Rbar [+ D'SbarD]),
+    F = 2 Gamma' Qbar Phi, f = F e0.
+    """
+    n, m, N = p.n, p.m, p.N
+    Phi = np.zeros((n * N, n))
+    Gam = np.zeros((n * N, m * N))
+    Ak = np.eye(n)
+    G = []  # G[k] = A^k B
+    for k in range(N):
+        G.append(Ak @ p.B)
+        Ak = Ak @ p.A
+        Phi[k * n:(k + 1) * n, :] = Ak
+    for i in range(N):
+        for j in range(i + 1):
+            Gam[i * n:(i + 1) * n, j * m:(j + 1) * m] = G[i - j]
+    Qbar = np.zeros((n * N, n * N))
+    for k in range(N):
+        Qbar[k * n:(k + 1) * n, k * n:(k + 1) * n] = p.P if k == N - 1 else p.Q
+    H = Gam.T @ Qbar @ Gam
+    if p.R[0, 0] != 0.0:  # the reference tests only element [1,1] (src/sub/design_mpc.jl:436,448)
+        H = H + np.kron(np.eye(N), p.R)
+    if p.S[0, 0] != 0.0:  # delta_u[:,i] = u[:,i]-u[:,i+1], i=1..N-1 (src/sub/design_mpc.jl:423-446)
+        D = np.zeros((m * (N - 1), m * N))
+        for i in range(N - 1):
+            D[i * m:(i + 1) * m, i * m:(i + 1) * m] = np.eye(m)
+            D[i * m:(i + 1) * m, (i + 1) * m:(i + 2) * m] = -np.eye(m)
+        H = H + D.T @ np.kron(np.eye(N - 1), p.S) @ D
+    H = 2.0 * H
+    H = 0.5 * (H + H.T)
+    F = 2.0 * Gam.T @ Qbar @ Phi
+    return Phi, Gam, H, F
+
+
+def s_rate_gradient(p: MPCProblem):
+    """Linear term contributed by the S (input-rate) cost when u_ref varies over the
+    horizon: delta_u is defined on u (not e_u), u = v + u_ref, so
+    sum ||D(v+u_ref)||_S^2 adds 2 D'Sbar D u_ref to f.  Zero for constant references."""
+    m, N = p.m, p.N
+    if p.S[0, 0] == 0.0:
+        return np.zeros(m * N)
+    D = np.zeros((m * (N - 1), m * N))
+    for i in range(N - 1):
+        D[i * m:(i + 1) * m, i * m:(i + 1) * m] = np.eye(m)
+        D[i * m:(i + 1) * m, (i + 1) * m:(i + 2) * m] = -np.eye(m)
+    return 2.0 * D.T @ np.kron(np.eye(N - 1), p.S) @ D @ p.u_ref.T.reshape(-1)
+
+
+def condensed_qp(p: MPCProblem, x0):
+    """(H, f, lo, hi) of  min 1/2 v'Hv + f'v  s.t. lo <= v <= hi  for initial state x0."""
+    Phi, Gam, H, F = condense(p)
+    e0 = np.asarray(x0, dtype=np.float64) - p.x_ref[:, 0]
+    f = F @ e0 + s_rate_gradient(p)
+    lo = (p.u_min[:, None] - p.u_ref).T.reshape(-1)  # stage-major: v = [e_u[:,1]; e_u[:,2]; ...]
+    hi = (p.u_max[:, None] - p.u_ref).T.reshape(-1)
+    return H, f, lo, hi
+
+
+def rollout(p: MPCProblem, x0, v):
+    """Outputs of calculate! (src/main/computation_mpc.jl:50-53): u, e_u (m x N), x, e_x (n x (N+1))."""
+    n, m, N = p.n, p.m, p.N
+    e_u = np.asarray(v).reshape(N, m).T
+    e_x = np.zeros((n, N + 1))
+    e_x[:, 0] = np.asarray(x0, dtype=np.float64) - p.x_ref[:, 0]
+    for k in range(N):
+        e_x[:, k + 1] = p.A @ e_x[:, k] + p.B @ e_u[:, k]
+    return dict(u=e_u + p.u_ref, e_u=e_u, x=e_x + p.x_ref, e_x=e_x)
+
+
+# --------------------------------------------------------------------------------------
+# exact box-QP solver + method-independent certificate
+# --------------------------------------------------------------------------------------
+def kkt_residual(H, f, lo, hi, v):
+    """|| v - clip(v - (Hv+f), lo, hi) ||_inf : zero iff v is the (unique) minimiser."""
+    g = H @ v + f
+    return float(np.max(np.abs(v - np.clip(v - g, lo, hi)))) if v.size else 0.0
+
+
+def _solve_fixed(H, f, lo, hi, act_lo, act_hi):
+    v = np.where(act_lo, lo, np.where(act_hi, hi, 0.0))
+    free = ~(act_lo | act_hi)
+    if free.any():
+        rhs = -(f[free] + H[np.ix_(free, ~free)] @ v[~free])
+        c = np.linalg.cholesky(H[np.ix_(free, free)])
+        v[free] = np.linalg.solve(c.T, np.linalg.solve(c, rhs))
+    return v
+
+
+def solve_box_qp_exact(H, f, lo, hi, max_iter=None, tol=1e-9):
+    """Exact minimiser of the strictly convex box QP by the classical primal active-set
+    method (Nocedal & Wright, Alg. 16.3, specialised to bounds), run in Jacobi-scaled
+    coordinates v = D w (D = diag(H)^-1/2) so that multipliers of differently scaled inputs
+    are comparable.  No objective evaluations (they cancel catastrophically at
+    cond(H) ~ 1e10): feasibility is kept by a ratio test, optimality is decided by
+    multiplier signs on the minimiser of the current face.  The result is accepted only
+    with the method-independent KKT certificate in scaled coordinates
+    (``kkt_residual`` <= tol * max(1, |f'|_inf))."""
+    nz = f.size
+    if nz == 0:
+        return np.zeros(0)
+    d = 1.0 / np.sqrt(np.diag(H))
+    Hs = H * d[:, None] * d[None, :]
+    fs, los, his = f * d, lo / d, hi / d
+    scale = max(1.0, float(np.max(np.abs(fs))))
+    none = np.zeros(nz, dtype=bool)
+    w = np.clip(_solve_fixed(Hs, fs, los, his, none, none), los, his)
+    W_lo, W_hi = w <= los, w >= his
+    max_iter = 20 * nz + 50 if max_iter is None else max_iter
+    for _ in range(max_iter):
+        t_full = _solve_fixed(Hs, fs, los, his, W_lo, W_hi)
+        step = t_full - w
+        free = ~(W_lo | W_hi)
+        # ratio test on the free variables
+        with np.errstate(divide="ignore", invalid="ignore"):
+            r_hi = np.where(free & (step > 0), (his - w) / step, np.inf)
+            r_lo = np.where(free & (step < 0), (los - w) / step, np.inf)
+        r = np.minimum(r_hi, r_lo)
+        j = int(np.argmin(r))
+        if r[j] < 1.0:
+            w = w + max(r[j], 0.0) * step
+            if r_hi[j] <= r_lo[j]:
+                w[j] = his[j]
+                W_hi[j] = True
+            else:
+                w[j] = los[j]
+                W_lo[j] = True
+            continue
+        w = t_full
+        g = Hs @ w + fs
+        viol = np.where(W_lo, -g, np.where(W_hi, g, -np.inf))  # >0 means wrong multiplier sign
+        j = int(np.argmax(viol))
+        if viol[j] <= 1e-13 * scale:
+            break
+        W_lo[j] = False
+        W_hi[j] = False
+    res = kkt_residual(Hs, fs, los, his, w)
+    if not res <= tol * scale:
+        raise RuntimeError(f"exact box-QP solver did not certify: scaled KKT residual {res:g}")
+    return np.clip(w * d, lo, hi)
+
+
+def solve_mpc_exact(p: MPCProblem, x0):
+    """One MPC step, exact: returns rollout dict plus v (for box-only problems)."""
+    if p.x_min is not None or p.terminal != "none":
+        raise NotImplementedError("exact oracle covers the box-only path (SURVEY.md section 8f rank 1 is 'next')")
+    H, f, lo, hi = condensed_qp(p, x0)
+    v = solve_box_qp_exact(H, f, lo, hi)
+    out = rollout(p, x0, v)
+    out["v"] = v
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# the reference's own (sparse, multiple-shooting) statement of the QP
+# --------------------------------------------------------------------------------------
+def sparse_problem(p: MPCProblem, x0):
+    """The QP exactly as the reference builds it in JuMP, in OSQP form
+    min 1/2 z'Pz + q'z  s.t.  l <= Az <= u,  z = [x; e_x; x_reference; u; e_u; u_reference]
+    (variable blocks in declaration order, ...linear.jl:48-55; each block column-major).
+
+    Rows, in the order the reference adds them: dynamics (..linear.jl:58-60), optional
+    state box (:62-70), input box (:73-78, two one-sided rows per input and stage),
+    e_x defs (:81-83), e_u defs (:85-87), optional terminal equality
+    (src/sub/design_mpc.jl:330-331); then the `JuMP.fix`ed variables as equality rows
+    (x_reference, u_reference :90-100; x[:,1] src/main/computation_mpc.jl:23-27).
+
+    Returns dict(P,q,A,l,u, idx=block offsets, n_constraints=<number of JuMP constraint
+    rows, i.e. excluding fixed-variable bounds> ) -- n_constraints is what
+    `JuMP.num_constraints(...; count_variable_in_set_constraints=false)` would count and
+    is pinned to 74 / 78 by test/terminal_ingredient_test.jl:160,317 for N=5,n=4,m=2.
+    """
+    n, m, N = p.n, p.m, p.N
+    nx, nu = n * (N + 1), m * N
+    off = {}
+    o = 0
+    for name, sz in (("x", nx), ("e_x", nx), ("x_reference", nx), ("u", nu), ("e_u", nu), ("u_reference", nu)):
+        off[name] = o
+        o += sz
+    nv = o
+    ix = lambda name, i, k: off[name] + i + (n if name in ("x", "e_x", "x_reference") else m) * k
+    rows, lo, hi = [], [], []
+
+    def add(coefs, l, u):
+        r = np.zeros(nv)
+        for j, c in coefs:
+            r[j] += c
+        rows.append(r)
+        lo.append(l)
+        hi.append(u)
+
+    for k in range(N):  # e_x[:,k+1] == A e_x[:,k] + B e_u[:,k]
+        for i in range(n):
+            co = [(ix("e_x", i, k + 1), 1.0)]
+            co += [(ix("e_x", j, k), -p.A[i, j]) for j in range(n)]
+            co += [(ix("e_u", j, k), -p.B[i, j]) for j in range(m)]
+            add(co, 0.0, 0.0)
+    if p.x_min is not None:
+        for k in range(N + 1):
+            for i in range(n):
+                add([(ix("x", i, k), 1.0)], -np.inf, p.x_max[i])
+                add([(ix("x", i, k), 1.0)], p.x_min[i], np.inf)
+    for k in range(N):
+        for i in range(m):
+            add([(ix("u", i, k), 1.0)], -np.inf, p.u_max[i])
+            add([(ix("u", i, k), 1.0)], p.u_min[i], np.inf)
+    for k in range(N + 1):
+        for i in range(n):
+            add([(ix("e_x", i, k), 1.0), (ix("x", i, k), -1.0), (ix("x_reference", i, k), 1.0)], 0.0, 0.0)
+    for k in range(N):
+        for i in range(m):
+            add([(ix("e_u", i, k), 1.0), (ix("u", i, k), -1.0), (ix("u_reference", i, k), 1.0)], 0.0, 0.0)
+    if p.terminal == "equality":
+        for i in range(n):
+            add([(ix("e_x", i, N), 1.0)], 0.0, 0.0)
+    n_constraints = len(rows)
+    if p.S[0, 0] != 0.0:
+        raise NotImplementedError("delta_u variables of the S branch are not part of this sparse statement")
+    # fixed variables
+    for k in range(N + 1):
+        for i in range(n):
+            add([(ix("x_reference", i, k), 1.0)], p.x_ref[i, k], p.x_ref[i, k])
+    for k in range(N):
+        for i in range(m):
+            add([(ix("u_reference", i, k), 1.0)], p.u_ref[i, k], p.u_ref[i, k])
+    for i in range(n):
+        add([(ix("x", i, 0), 1.0)], float(x0[i]), float(x0[i]))
+    Pm = np.zeros((nv, nv))
+    for k in range(N):  # stages 1..N: Q on e_x[:,k], R on e_u[:,k]  (objective has no 1/2 -> P = 2*blk)
+        s = off["e_x"] + n * k
+        Pm[s:s + n, s:s + n] += 2.0 * p.Q
+        if p.R[0, 0] != 0.0:
+            s = off["e_u"] + m * k
+            Pm[s:s + m, s:s + m] += 2.0 * p.R
+    s = off["e_x"] + n * N
+    Pm[s:s + n, s:s + n] += 2.0 * p.P
+    return dict(P=Pm, q=np.zeros(nv), A=np.array(rows), l=np.array(lo), u=np.array(hi), idx=off,
+                n_constraints=n_constraints, nv=nv)
+
+
+# --------------------------------------------------------------------------------------
+# OSQP iteration restated (general form) -- third-party arithmetic, see module docstring
+# --------------------------------------------------------------------------------------
+def osqp_admm(P, q, A, l, u, rho=0.1, sigma=1e-6, alpha=1.6, eps_abs=1e-3, eps_rel=1e-3,
+              max_iter=4000, check_every=25, adaptive_rho=True, x0=None, y0=None):
+    """OSQP Algorithm 1 with per-row rho (1e3*rho on equality rows), termination every
+    `check_every` iterations on unscaled residuals, adaptive rho with refactorisation when
+    the estimate moves by more than 5x.  Dense linear algebra (oracle sizes only).  No Ruiz
+    scaling (it changes the iterates, not the fixed point)."""
+    nv, nc = P.shape[0], A.shape[0]
+    eq = (l == u)
+    x = np.zeros(nv) if x0 is None else x0.copy()
+    y = np.zeros(nc) if y0 is None else y0.copy()
+    z = np.clip(A @ x, l, u)
+
+    def factor(rho_):
+        rv = np.where(eq, 1e3 * rho_, rho_)
+        K = np.block([[P + sigma * np.eye(nv), A.T], [A, -np.diag(1.0 / rv)]])
+        import scipy.linalg as sla
+        return rv, sla.lu_factor(K)
+
+    import scipy.linalg as sla
+    rv, lu = factor(rho)
+    status, it = 1, 0
+    for it in range(1, max_iter + 1):
+        rhs = np.concatenate([sigma * x - q, z - y / rv])
+        sol = sla.lu_solve(lu, rhs)
+        xt, nu = sol[:nv], sol[nv:]
+        zt = z + (nu - y) / rv
+        x = alpha * xt + (1 - alpha) * x
+        w = alpha * zt + (1 - alpha) * z
+        zn = np.clip(w + y / rv, l, u)
+        y = y + rv * (w - zn)
+        z = zn
+        if it % check_every == 0 or it == max_iter:
+            Ax, Px, Aty = A @ x, P @ x, A.T @ y
+            rp = np.max(np.abs(Ax - z))
+            rd = np.max(np.abs(Px + q + Aty))
+            np_ = max(np.max(np.abs(Ax)), np.max(np.abs(z)))
+            nd_ = max(np.max(np.abs(Px)), np.max(np.abs(Aty)), np.max(np.abs(q)))
+            if rp <= eps_abs + eps_rel * np_ and rd <= eps_abs + eps_rel * nd_:
+                status = 0
+                break
+            if adaptive_rho:
+                est = rho * math.sqrt((rp / max(np_, 1e-300)) / max(rd / max(nd_, 1e-300), 1e-300))
+                est = min(max(est, 1e-6), 1e6)
+                if est > 5 * rho or est < rho / 5:
+                    rho = est
+                    rv, lu = factor(rho)
+    return dict(x=x, z=z, y=y, iters=it, status=status, rho=rho)
+
+
+# --------------------------------------------------------------------------------------
+# condensed, box-only specialisation: the algorithm the HIP kernels implement
+# --------------------------------------------------------------------------------------
+def jacobi_scaling(H):
+    """Diagonal scaling v = D w with D = diag(H)^-1/2: H' = D H D has unit diagonal and the
+    box stays a box (lo/D <= w <= hi/D).  This is the k=1 pass of OSQP's Ruiz equilibration
+    restricted to the variables block."""
+    return 1.0 / np.sqrt(np.diag(H))
+
+
+def admm_box(Hs, fs, lo, hi, rho=0.1, sigma=1e-6, alpha=1.6, eps_abs=1e-3, eps_rel=1e-3,
+             max_iter=4000, check_every=25, Minv=None, unscale=None, x0=None, y0=None):
+    """OSQP iteration for constraint matrix A = I (box form) on an
+    already scaled problem (Hs, fs, lo, hi in the w coordinates of ``design_shared``);
+    `unscale` = d maps back (v = d*w) so that residuals and the termination test are
+    evaluated on the UNSCALED problem, as OSQP does with its own scaling.
+
+        xt   = (Hs + (sigma+rho) I)^-1 (sigma x - fs + rho z - y)
+        x+   = alpha xt + (1-alpha) x
+        w    = alpha xt + (1-alpha) z + y/rho
+        z+   = clip(w, lo, hi);   y+ = rho (w - z+)
+
+    Termination (every `check_every` iterations, and at max_iter):
+        |d(x-z)|_inf <= eps_abs + eps_rel max(|dx|_inf, |dz|_inf)   and
+        |(Hs x + fs + y)/d|_inf <= eps_abs + eps_rel max(|Hs x/d|_inf, |y/d|_inf, |fs/d|_inf).
+    Returns x, z, y (scaled coordinates), iters, status (0 solved, 1 max-iter)."""
+    nz = fs.size
+    d = np.ones(nz) if unscale is None else unscale
+    if Minv is None:
+        Minv = np.linalg.inv(Hs + (sigma + rho) * np.eye(nz))
+    x = np.zeros(nz) if x0 is None else x0.copy()
+    y = np.zeros(nz) if y0 is None else y0.copy()
+    z = np.clip(x, lo, hi)
+    status, it = 1, 0
+    for it in range(1, max_iter + 1):
+        xt = Minv @ (sigma * x - fs + rho * z - y)
+        x = alpha * xt + (1 - alpha) * x
+        w = alpha * xt + (1 - alpha) * z + y / rho
+        zn = np.clip(w, lo, hi)
+        y = rho * (w - zn)
+        z = zn
+        if it % check_every == 0 or it == max_iter:
+            Hx = Hs @ x
+            rp = np.max(np.abs(d * (x - z)))
+            rd = np.max(np.abs((Hx + fs + y) / d))
+            np_ = max(np.max(np.abs(d * x)), np.max(np.abs(d * z)))
+            nd_ = max(np.max(np.abs(Hx / d)), np.max(np.abs(y / d)), np.max(np.abs(fs / d)))
+            if rp <= eps_abs + eps_rel * np_ and rd <= eps_abs + eps_rel * nd_:
+                status = 0
+                break
+    return dict(x=x, z=z, y=y, iters=it, status=status)
+
+
+def polish_active_set(G, v0, lo, hi, z, y, max_iter=None, refine=True):
+    """Polish = exact active-set finish started from the ADMM iterate, in the scaled
+    coordinates of ``design_shared`` (OSQP's polish guesses the active rows from the sign of
+    y and solves one equality-constrained KKT system; here the guess is then corrected by
+    the primal active-set method until the multipliers have the right signs, which is what
+    makes the 1e-5 bar reachable at cond(H) ~ 1e10).
+
+    Only the SHARED inverse G = H'^-1 is used.  With working set W held at its bounds b
+        t = v0 - G[:,W] lam,     G[W,W] lam = v0[W] - b,     v0 = -G f'
+    is the minimiser of the face, and lam are the bound multipliers (H't + f' + E_W lam = 0),
+    so a sweep needs a |W|x|W| solve instead of an nz x nz one.  (G[W,W])^-1 is kept
+    explicitly and updated by bordering (add) / Schur down-dating (remove), the form the
+    HIP kernel uses because every step of it is lane-parallel.
+
+    Returns dict(w, iters, n_add, n_remove, n_active).
+    """
+    nz = v0.size
+    max_iter = 20 * nz + 50 if max_iter is None else max_iter
+    W, side = [], {}
+    Sinv = np.zeros((0, 0))
+
+    def add(j, s):
+        nonlocal Sinv
+        c = G[W, j]
+        u = Sinv @ c
+        sc = G[j, j] - c @ u
+        k = len(W)
+        Sn = np.empty((k + 1, k + 1))
+        Sn[:k, :k] = Sinv + np.outer(u, u) / sc
+        Sn[:k, k] = -u / sc
+        Sn[k, :k] = -u / sc
+        Sn[k, k] = 1.0 / sc
+        Sinv = Sn
+        W.append(j)
+        side[j] = s
+
+    def remove(pos):
+        nonlocal Sinv
+        keep = [i for i in range(len(W)) if i != pos]
+        Sinv = Sinv[np.ix_(keep, keep)] - np.outer(Sinv[keep, pos], Sinv[pos, keep]) / Sinv[pos, pos]
+        del side[W.pop(pos)]
+
+    w = np.clip(z, lo, hi)
+    for j in range(nz):
+        if y[j] < 0 and w[j] <= lo[j]:
+            add(j, -1)
+        elif y[j] > 0 and w[j] >= hi[j]:
+            add(j, +1)
+    n_add = n_rem = 0
+    it = 0
+    for it in range(1, max_iter + 1):
+        if W:
+            b = np.array([hi[j] if side[j] > 0 else lo[j] for j in W])
+            r = v0[W] - b
+            lam = Sinv @ r
+            if refine:
+                lam = lam + Sinv @ (r - G[np.ix_(W, W)] @ lam)
+            t = v0 - G[:, W] @ lam
+            t[W] = b
+        else:
+            lam = np.zeros(0)
+            t = v0.copy()
+        step = t - w
+        free = np.ones(nz, dtype=bool)
+        free[W] = False
+        with np.errstate(divide="ignore", invalid="ignore"):
+            r_hi = np.where(free & (t > hi), (hi - w) / step, np.inf)
+            r_lo = np.where(free & (t < lo), (lo - w) / step, np.inf)
+        rr = np.minimum(r_hi, r_lo)
+        j = int(np.argmin(rr))
+        if rr[j] < 1.0:
+            w = w + max(rr[j], 0.0) * step
+            if r_hi[j] <= r_lo[j]:
+                w[j] = hi[j]
+                add(j, +1)
+            else:
+                w[j] = lo[j]
+                add(j, -1)
+            n_add += 1
+            continue
+        w = t
+        if not W:
+            break
+        viol = np.array([-lam[i] if side[W[i]] > 0 else lam[i] for i in range(len(W))])
+        i = int(np.argmax(viol))
+        if viol[i] <= 1e-12 * max(1.0, float(np.max(np.abs(lam)))):
+            break
+        remove(i)
+        n_rem += 1
+    return dict(w=np.clip(w, lo, hi), iters=it, n_add=n_add, n_remove=n_rem, n_active=len(W))
+
+
+def design_shared(p: MPCProblem, rho=0.1, sigma=1e-6):
+    """Everything `almpc_design_shared` precomputes for a model shared by the whole batch,
+    in scaled coordinates v = D w:  d, H' = DHD, F' = DF, Minv = (H' + (sigma+rho) I)^-1,
+    G = H'^-1, lo' = lo/d, hi' = hi/d, plus the unscaled H, F (for `almpc_get_design`)."""
+    Phi, Gam, H, F = condense(p)
+    d = jacobi_scaling(H)
+    Hs = H * d[:, None] * d[None, :]
+    Hs = 0.5 * (Hs + Hs.T)
+    nz = p.nz
+    lo = (p.u_min[:, None] - p.u_ref).T.reshape(-1)
+    hi = (p.u_max[:, None] - p.u_ref).T.reshape(-1)
+
+    def spd_inv(M):
+        c = np.linalg.cholesky(M)
+        ci = np.linalg.solve(c, np.eye(nz))
+        return ci.T @ ci
+
+    return dict(H=H, F=F, d=d, Hs=Hs, Fs=F * d[:, None], fS=s_rate_gradient(p) * d,
+                Minv=spd_inv(Hs + (sigma + rho) * np.eye(nz)), G=spd_inv(Hs),
+                lo=lo / d, hi=hi / d, rho=rho, sigma=sigma, Phi=Phi, Gam=Gam)
+
+
+def solve_mpc_admm_polish(p: MPCProblem, x0, des=None, rho=0.1, sigma=1e-6, alpha=1.6,
+                          eps_abs=1e-3, eps_rel=1e-3, max_iter=4000, check_every=25, polish=True):
+    """One MPC step by the algorithm of the HIP path: scaled box ADMM to OSQP's default
+    tolerance, then the active-set polish.  Returns rollout dict + v, iters, status,
+    polish_iters."""
+    des = design_shared(p, rho, sigma) if des is None else des
+    d = des["d"]
+    e0 = np.asarray(x0, dtype=np.float64) - p.x_ref[:, 0]
+    fs = des["Fs"] @ e0 + des["fS"]
+    r = admm_box(des["Hs"], fs, des["lo"], des["hi"], rho=des["rho"], sigma=des["sigma"], alpha=alpha,
+                 eps_abs=eps_abs, eps_rel=eps_rel, max_iter=max_iter, check_every=check_every,
+                 Minv=des["Minv"], unscale=d)
+    w, pit = r["z"], 0
+    if polish:
+        pol = polish_active_set(des["G"], -des["G"] @ fs, des["lo"], des["hi"], r["z"], r["y"])
+        w, pit = pol["w"], pol["iters"]
+    v = w * d
+    out = rollout(p, x0, v)
+    out.update(v=v, iters=r["iters"], status=r["status"], polish_iters=pit)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# fixtures and synthetic configurations
+# --------------------------------------------------------------------------------------
+def decode_linear_regressor_fixture(blob: bytes):
+    """(A, B) from the reference's test fixture test/models_saved/linear_regressor_train_result.jls
+    (a Julia `Serialization` MLJ machine, 555 bytes).  The fitted 6x4 Float32 coefficient
+    matrix sits at byte offset 221, column-major; the test builds AB = coefficients',
+    A = AB[:,1:4], B = AB[:,5:6] (test/computation_mpc_test.jl:1003-1006)."""
+    coef = np.frombuffer(blob, dtype="<f4", count=24, offset=221).reshape((6, 4), order="F")
+    AB = coef.T.astype(np.float64)
+    return AB[:, :4].copy(), AB[:, 4:].copy()
+
+
+def qtp_linear_fixture_problem(A, B):
+    """Scenario of test/computation_mpc_test.jl:981-1054: N=5, x_ref=0.65, u_ref=1.2,
+    u in [0,4]x[0,3.26], defaults Q=100I, R=0.1I, terminal "none"; x0 = 0.6 (:1040).
+    (`mpc_state_constraint` is not passed, so there is no state box.)"""
+    return make_problem(A, B, 5, [0.0, 0.0], [4.0, 3.26], x_ref=[0.65] * 4, u_ref=[1.2] * 2)
+
+
+def double_integrator(N=10):
+    """BASELINE config 1: Ts=1, u in [-1,1], refs 0."""
+    return make_problem([[1.0, 1.0], [0.0, 1.0]], [[0.5], [1.0]], N, [-1.0], [1.0])
+
+
+def _expm(M):
+    import scipy.linalg as sla
+    return sla.expm(M)
+
+
+def quadrotor_model(Ts=0.1, mass=0.5, J=(4e-3, 4e-3, 8e-3), g=9.81):
+    """Hover-linearised quadrotor, states [p(3), v(3), (phi,theta,psi), omega(3)], inputs
+    [dT, tau_x, tau_y, tau_z]; exact zero-order hold via expm([[Ac,Bc],[0,0]] Ts)
+    (SURVEY.md section 8d config 2)."""
+    Ac = np.zeros((12, 12))
+    Bc = np.zeros((12, 4))
+    Ac[0:3, 3:6] = np.eye(3)
+    Ac[3, 7] = g
+    Ac[4, 6] = -g
+    Ac[6:9, 9:12] = np.eye(3)
+    Bc[5, 0] = 1.0 / mass
+    Bc[9, 1] = 1.0 / J[0]
+    Bc[10, 2] = 1.0 / J[1]
+    Bc[11, 3] = 1.0 / J[2]
+    M = np.zeros((16, 16))
+    M[:12, :12] = Ac
+    M[:12, 12:] = Bc
+    E = _expm(M * Ts)
+    return E[:12, :12].copy(), E[:12, 12:].copy()
+
+
+def quadrotor(N=30):
+    """BASELINE config 2/3 controller: Q=100 I, R=0.1 I, S=0, P=DARE, input box
+    [-2,3]x[+-0.05]x[+-0.05]x[+-0.02], references 0 (deviation coordinates)."""
+    A, B = quadrotor_model()
+    return make_problem(A, B, N, [-2.0, -0.05, -0.05, -0.02], [3.0, 0.05, 0.05, 0.02])
+
+
+_MASK = (1 << 64) - 1
+
+
+def _mix64(z):
+    z = np.asarray(z, dtype=np.uint64)
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def splitmix_normal(seed: int, first_instance: int, count: int, dim: int):
+    """Standard normals, shape (count, dim): one SplitMix64 stream per instance
+    (state0 = mix64(seed + 0x632BE59BD9B4E019*(instance+1))), uniforms = top 53 bits,
+    Box-Muller pairs (cos branch first).  Depends only on (seed, instance index), so a
+    shard can generate its own slice of the batch."""
+    with np.errstate(over="ignore"):
+        inst = np.arange(first_instance, first_instance + count, dtype=np.uint64)
+        state = _mix64(np.uint64(seed & _MASK) + np.uint64(0x632BE59BD9B4E019) * (inst + np.uint64(1)))
+        npair = (dim + 1) // 2
+        out = np.empty((count, 2 * npair))
+        gamma = np.uint64(0x9E3779B97F4A7C15)
+        for j in range(npair):
+            state = state + gamma
+            u1 = (_mix64(state) >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
+            state = state + gamma
+            u2 = (_mix64(state) >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
+            r = np.sqrt(-2.0 * np.log(1.0 - u1))
+            out[:, 2 * j] = r * np.cos(2.0 * np.pi * u2)
+            out[:, 2 * j + 1] = r * np.sin(2.0 * np.pi * u2)
+    return out[:, :dim]
+
+
+QUADROTOR_X0_SCALE = np.array([1, 1, 1, .5, .5, .5, .1, .1, .1, .1, .1, .1])
+
+
+def quadrotor_x0_batch(batch, amplitude=1.0, seed=0x5EED0002, first_instance=0):
+    """x0_i = s * diag(1,1,1,.5,.5,.5,.1 x6) * xi_i, xi_i ~ N(0, I12).
+    Returns (batch, 12), C-contiguous: instance-major, i.e. the C-ABI's [batch][state]."""
+    xi = splitmix_normal(seed, first_instance, batch, 12)
+    return np.ascontiguousarray(amplitude * xi * QUADROTOR_X0_SCALE[None, :])
