@@ -26,6 +26,7 @@ from typing import Any, Optional
 import numpy as np
 
 from . import _capi
+from .sharding import shard_range  # noqa: F401  (re-exported)
 
 __all__ = [
     "Hyperrectangle", "ConstrainedLinearControlDiscreteSystem", "ReferencesStateInput", "WeightsCoefficient",
@@ -238,13 +239,3 @@ def _model_predictive_control_computation(C: ModelPredictiveControlController, X
     update_initialization(C, X0)
     calculate(C)
     return C.computation_results
-
-
-def shard_range(batch: int, rank: int, world: int):
-    """Contiguous shard [lo, hi) of a batch of independent instances for `rank` of `world` (SURVEY.md
-    section 8e): sizes differ by at most one, earlier ranks take the remainder."""
-    if not (0 <= rank < world) or batch < 0:
-        raise ValueError("need 0 <= rank < world and batch >= 0")
-    base, rem = divmod(batch, world)
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)

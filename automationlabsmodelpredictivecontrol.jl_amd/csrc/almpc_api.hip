@@ -35,8 +35,9 @@ struct almpc_handle {
     double *dX0 = nullptr, *dXs = nullptr, *dZs = nullptr, *dYs = nullptr, *dV0 = nullptr, *dW = nullptr;
     double *dX = nullptr, *dEx = nullptr, *dU = nullptr, *dEu = nullptr;
     int32_t *dStatus = nullptr, *dIters = nullptr, *dPiters = nullptr, *dOverflow = nullptr;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool timed = false;
+    // timing (ALMPC_FLAG_TIMING): one set of 4 events per step since the last almpc_timing_reset
+    std::vector<hipEvent_t> ev;  // 4 per step
+    size_t ev_used = 0;          // steps recorded
 };
 
 namespace {
@@ -89,6 +90,7 @@ void free_all(almpc_handle* h) {
         if (p) (void)hipFree(p);
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
+    h->ev.clear();
     if (h->stream) (void)hipStreamDestroy(h->stream);
 }
 
@@ -157,7 +159,6 @@ int almpc_create(almpc_handle** out, int n, int m, int N, int batch, int device_
     TRY(hipMemset(h->dZs, 0, b * h->nzs * sizeof(double)));
     TRY(hipMemset(h->dYs, 0, b * h->nzs * sizeof(double)));
     TRY(hipMemset(h->dX0, 0, b * n * sizeof(double)));
-    for (auto& e : h->ev) TRY(hipEventCreate(&e));
 #undef TRY
     *out = h;
     return ALMPC_OK;
@@ -274,7 +275,16 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
     HIP_TRY(h, hipSetDevice(h->device));
     const bool timing = (h->flags & ALMPC_FLAG_TIMING) != 0;
     hipStream_t st = h->stream;
-    if (timing) HIP_TRY(h, hipEventRecord(h->ev[0], st));
+    hipEvent_t* ev = nullptr;
+    if (timing) {
+        if (h->ev.size() < 4 * (h->ev_used + 1)) {
+            const size_t old = h->ev.size();
+            h->ev.resize(old + 4 * 64, nullptr);
+            for (size_t i = old; i < h->ev.size(); ++i) HIP_TRY(h, hipEventCreate(&h->ev[i]));
+        }
+        ev = &h->ev[4 * h->ev_used];
+        HIP_TRY(h, hipEventRecord(ev[0], st));
+    }
 
     AdmmParams ap;
     ap.nz = h->nz; ap.n = h->n; ap.m = h->m; ap.batch = h->batch; ap.nzs = h->nzs;
@@ -288,7 +298,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
     const int grid = (h->batch + TILE - 1) / TILE;
     const size_t lds = ((size_t)2 * h->nzs * TILE + (size_t)h->nrb * 8 * TILE + (size_t)4 * h->ksf * TILE) * sizeof(double);
     HIP_TRY(h, launch_admm(h->nrb, h->ks, ap, grid, lds, st));
-    if (timing) HIP_TRY(h, hipEventRecord(h->ev[1], st));
+    if (timing) HIP_TRY(h, hipEventRecord(ev[1], st));
 
     const double* wsrc = h->dZs;
     if (o.polish) {
@@ -318,7 +328,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         }
         wsrc = h->dW;
     }
-    if (timing) HIP_TRY(h, hipEventRecord(h->ev[2], st));
+    if (timing) HIP_TRY(h, hipEventRecord(ev[2], st));
 
     RolloutParams rp;
     rp.n = h->n; rp.m = h->m; rp.N = h->N; rp.batch = h->batch; rp.nzs = h->nzs; rp.A = h->dA; rp.B = h->dB;
@@ -331,8 +341,8 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         HIP_TRY(h, hipGetLastError());
     }
     if (timing) {
-        HIP_TRY(h, hipEventRecord(h->ev[3], st));
-        h->timed = true;
+        HIP_TRY(h, hipEventRecord(ev[3], st));
+        h->ev_used += 1;
     }
     return ALMPC_OK;
 }
@@ -387,16 +397,55 @@ int almpc_device_results(almpc_handle* h, const double** d_x, const double** d_e
     return ALMPC_OK;
 }
 
+int almpc_timing_reset(almpc_handle* h, int reserve_steps) {
+    if (!h) return ALMPC_ERR_INVALID;
+    if (!(h->flags & ALMPC_FLAG_TIMING)) return fail(h, ALMPC_ERR_INVALID, "handle was created without ALMPC_FLAG_TIMING");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->ev_used = 0;
+    const size_t need = 4 * (size_t)(reserve_steps > 0 ? reserve_steps : 0);
+    if (h->ev.size() < need) {
+        const size_t old = h->ev.size();
+        h->ev.resize(need, nullptr);
+        for (size_t i = old; i < need; ++i) HIP_TRY(h, hipEventCreate(&h->ev[i]));
+    }
+    return ALMPC_OK;
+}
+
+int almpc_timing_summary(almpc_handle* h, int* steps, double* ms_admm, double* ms_polish, double* ms_rollout,
+                         double* ms_total) {
+    if (!h) return ALMPC_ERR_INVALID;
+    if (!(h->flags & ALMPC_FLAG_TIMING)) return fail(h, ALMPC_ERR_INVALID, "handle was created without ALMPC_FLAG_TIMING");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    double a = 0, p = 0, r = 0, t = 0;
+    for (size_t sidx = 0; sidx < h->ev_used; ++sidx) {
+        hipEvent_t* ev = &h->ev[4 * sidx];
+        float f = 0;
+        HIP_TRY(h, hipEventElapsedTime(&f, ev[0], ev[1])); a += f;
+        HIP_TRY(h, hipEventElapsedTime(&f, ev[1], ev[2])); p += f;
+        HIP_TRY(h, hipEventElapsedTime(&f, ev[2], ev[3])); r += f;
+        HIP_TRY(h, hipEventElapsedTime(&f, ev[0], ev[3])); t += f;
+    }
+    if (steps) *steps = (int)h->ev_used;
+    if (ms_admm) *ms_admm = a;
+    if (ms_polish) *ms_polish = p;
+    if (ms_rollout) *ms_rollout = r;
+    if (ms_total) *ms_total = t;
+    return ALMPC_OK;
+}
+
 int almpc_get_timing(almpc_handle* h, float* ms_admm, float* ms_polish, float* ms_rollout, float* ms_total) {
     if (!h) return ALMPC_ERR_INVALID;
-    if (!(h->flags & ALMPC_FLAG_TIMING) || !h->timed) return fail(h, ALMPC_ERR_INVALID, "timing not enabled or no step timed yet");
+    if (!(h->flags & ALMPC_FLAG_TIMING) || h->ev_used == 0) return fail(h, ALMPC_ERR_INVALID, "timing not enabled or no step timed yet");
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipEventSynchronize(h->ev[3]));
+    hipEvent_t* ev = &h->ev[4 * (h->ev_used - 1)];
+    HIP_TRY(h, hipEventSynchronize(ev[3]));
     float a = 0, p = 0, r = 0, t = 0;
-    HIP_TRY(h, hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
-    HIP_TRY(h, hipEventElapsedTime(&p, h->ev[1], h->ev[2]));
-    HIP_TRY(h, hipEventElapsedTime(&r, h->ev[2], h->ev[3]));
-    HIP_TRY(h, hipEventElapsedTime(&t, h->ev[0], h->ev[3]));
+    HIP_TRY(h, hipEventElapsedTime(&a, ev[0], ev[1]));
+    HIP_TRY(h, hipEventElapsedTime(&p, ev[1], ev[2]));
+    HIP_TRY(h, hipEventElapsedTime(&r, ev[2], ev[3]));
+    HIP_TRY(h, hipEventElapsedTime(&t, ev[0], ev[3]));
     if (ms_admm) *ms_admm = a;
     if (ms_polish) *ms_polish = p;
     if (ms_rollout) *ms_rollout = r;

@@ -1,0 +1,74 @@
+"""Multi-GPU split of a batch of independent MPC instances.
+
+Instances never interact (the reference has a single-instance API, src/main/computation_mpc.jl:17-55), so the
+batch is cut into contiguous shards, one per rank / GPU, with NO data-path collective.  torch.distributed
+(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests) is used only for the barrier around
+the timed region and for the max-over-ranks of the elapsed time."""
+from __future__ import annotations
+
+import os
+
+
+def shard_range(batch: int, rank: int, world: int):
+    """Contiguous shard [lo, hi) of `batch` instances for `rank` of `world`: sizes differ by at most one,
+    earlier ranks take the remainder."""
+    if not (0 <= rank < world) or batch < 0:
+        raise ValueError("need 0 <= rank < world and batch >= 0")
+    base, rem = divmod(batch, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class Ranks:
+    """Process-group plumbing shared by bench.py and the gloo tests."""
+
+    def __init__(self, backend=None, device_index=None):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.dist = None
+        self.device = "cpu"
+        if self.world > 1:
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            import torch
+            import torch.distributed as dist
+            backend = backend or "nccl"
+            if backend == "nccl":
+                idx = self.local_rank if device_index is None else device_index
+                torch.cuda.set_device(idx)
+                self.device = f"cuda:{idx}"
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", idx))
+            else:
+                dist.init_process_group(backend=backend)
+            self.dist = dist
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def max_over_ranks(self, value: float) -> float:
+        if self.dist is None:
+            return float(value)
+        import torch
+        t = torch.tensor([float(value)], dtype=torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, value: float) -> float:
+        if self.dist is None:
+            return float(value)
+        import torch
+        t = torch.tensor([float(value)], dtype=torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+            self.dist = None
+
+
+def aggregate_rate(units_per_rank: float, steps: int, elapsed_max: float, world: int) -> float:
+    """Whole-job throughput: units all ranks processed / max-over-ranks time (weak scaling)."""
+    return world * units_per_rank * steps / elapsed_max

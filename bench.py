@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- MPC steps/s of the HIP condensed-QP path on BASELINE.json's headline configuration.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (gradient, ADMM, polish, rollout) over ONE batch of 4096 quadrotor
+instances (n=12, m=4, N=30; BASELINE.json configs[1]) per GPU; inputs (x0) are resident in HBM before the
+timed region, results stay in HBM.  N > 1: one process per GPU (launched by torch.distributed.run), each rank
+solves its own contiguous 4096-instance shard of the 4096*N batch (weak scaling, no data-path collective;
+torch.distributed over RCCL is used only for the barrier and the max-over-ranks of the elapsed time).
+
+`value` is 4096-instance batch steps per second over all GPUs (= instance-steps/s / 4096);
+`instance_steps_per_s` is printed beside it.  The workload mixes the three amplitude classes of SURVEY.md
+section 8d (s = 0.3 / 1.0 / 3.0, interleaved by instance index); per-class rates are in `classes`.
+
+The oracle (oracle/) is used here only as the checker (`u_err_inf`) and as the `cpu_baseline` leg.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import numpy as np  # noqa: E402
+
+BATCH_PER_GPU = 4096
+N_HORIZON, NX, NU = 30, 12, 4
+NZ = NU * N_HORIZON
+FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector = matrix peak (public spec)
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
+# algorithmic HBM bytes per instance-step (x0, refs, warm start in; u, x, warm start out)
+ALG_BYTES_PER_INSTANCE_STEP = 11808
+AMPLITUDES = (0.3, 1.0, 3.0)
+
+
+def make_x0(mo, first_instance, count, amplitude=None, seed=0x5EED0002):
+    """x0 of instances [first, first+count): amplitude class by instance index unless one is forced."""
+    xi = mo.splitmix_normal(seed, first_instance, count, NX) * mo.QUADROTOR_X0_SCALE[None, :]
+    if amplitude is None:
+        amp = np.array(AMPLITUDES)[(np.arange(first_instance, first_instance + count) % 3)]
+        return np.ascontiguousarray(xi * amp[:, None])
+    return np.ascontiguousarray(xi * amplitude)
+
+
+def time_steps(solver, opts, steps, barrier):
+    barrier()
+    solver.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        solver.calculate(opts, sync=False)
+    solver.synchronize()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--max-iter", type=int, default=None, help="ADMM max_iter (default: library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-classes", action="store_true")
+    args = ap.parse_args()
+
+    import almpc_loader
+    import mpc_oracle as mo
+    pkg = almpc_loader.load_package()
+    capi = pkg._capi
+    ranks = pkg.sharding.Ranks(backend="nccl")  # one process per GPU; RCCL only for barrier / max-reduce
+    rank, local_rank, world = ranks.rank, ranks.local_rank, ranks.world
+    if world > 1 and args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    barrier, max_over_ranks = ranks.barrier, ranks.max_over_ranks
+
+    p = mo.quadrotor(N_HORIZON)
+    first, _ = pkg.sharding.shard_range(world * BATCH_PER_GPU, rank, world)
+    X0 = make_x0(mo, first, BATCH_PER_GPU)
+    solver = capi.Solver(NX, NU, N_HORIZON, BATCH_PER_GPU, device=local_rank, timing=True)
+    solver.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max)
+    solver.set_reference(p.x_ref, p.u_ref)
+    solver.update_initialization(X0)  # x0 resident in HBM from here on
+    opts = capi.default_opts() if args.max_iter is None else capi.default_opts(max_iter=args.max_iter)
+
+    time_steps(solver, opts, args.warmup, barrier)
+    solver.timing_reset(args.steps)
+    elapsed = max_over_ranks(time_steps(solver, opts, args.steps, barrier))
+    tsum = solver.timing_summary()
+    res = solver.get_results(want=("u", "status", "iters", "polish_iters"))
+
+    inst_steps_per_s = pkg.sharding.aggregate_rate(BATCH_PER_GPU, args.steps, elapsed, world)
+    out = {
+        "metric": "MPC steps/s (batch=4096, nx=12, nu=4, N=30)",
+        "value": inst_steps_per_s / BATCH_PER_GPU,
+        "unit": "batch-steps/s (one step = 4096 instance QP solves)",
+        "instance_steps_per_s": inst_steps_per_s,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "configs[1]: hover-linearised quadrotor nx=12 nu=4 N=30, 4096 instances per GPU, shared model, "
+                               "x0 amplitude classes 0.3/1.0/3.0 interleaved, cold start every step",
+                   "batch_per_gpu": BATCH_PER_GPU, "global_batch": world * BATCH_PER_GPU,
+                   "admm_max_iter": int(opts.max_iter), "check_every": int(opts.check_every), "polish": int(opts.polish),
+                   "rho": opts.rho, "eps": opts.eps_abs, "parallelism": f"instances sharded over {world} GPU(s), 16-instance tile per workgroup"},
+    }
+    if rank == 0:
+        # ---- roofline of the dominant kernel, from the HIP events recorded inside the timed region
+        stage_ms = {k: tsum[k] / max(1, tsum["steps"]) for k in ("admm_ms", "polish_ms", "rollout_ms", "total_ms")}
+        iters_total = int(res["iters"].astype(np.int64).sum())
+        # algorithmic flops of one k_admm launch: per instance and iteration one nz x nz product (2 nz^2) plus ~10 nz
+        # vector work; once per instance the gradient (2 nz n) and v0 = -G f' (2 nz^2)
+        flops = iters_total * (2 * NZ * NZ + 10 * NZ) + BATCH_PER_GPU * (2 * NZ * NX + 2 * NZ * NZ)
+        admm_tflops = flops / (stage_ms["admm_ms"] * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": "k_admm<8,30>", "achieved": admm_tflops, "peak": FP64_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": admm_tflops / FP64_PEAK_TFLOPS, "traffic": None,
+                           "avg_kernel_ms": stage_ms["admm_ms"], "admm_iters_per_launch": iters_total,
+                           "note": "FP64 MFMA (v_mfma_f64_16x16x4_f64); peak = public-spec FP64 78.6 TFLOP/s"}
+        hbm_gbs = BATCH_PER_GPU * ALG_BYTES_PER_INSTANCE_STEP / (stage_ms["total_ms"] * 1e-3) / 1e9
+        out["hbm"] = {"algorithmic_bytes_per_instance_step": ALG_BYTES_PER_INSTANCE_STEP, "achieved_GBps": hbm_gbs,
+                      "peak_GBps": HBM_PEAK_GBS, "frac": hbm_gbs / HBM_PEAK_GBS,
+                      "note": "whole step (all kernels); the shared-model path is FP64-compute bound, not HBM bound"}
+        out["stage_ms"] = stage_ms
+        out["solver"] = {"status_counts": np.bincount(res["status"], minlength=3).tolist(),
+                         "admm_iters_mean": float(res["iters"].mean()), "polish_iters_mean": float(res["polish_iters"].mean()),
+                         "polish_iters_max": int(res["polish_iters"].max())}
+        # ---- parity on a sample of this very run: exact (KKT-certified) optimum from the oracle
+        nchk = 96
+        err = 0.0
+        for i in range(nchk):
+            e = mo.solve_mpc_exact(p, X0[i])
+            err = max(err, float(np.abs(res["u"][i] - e["u"]).max()))
+        out["u_err_inf"] = err
+        out["u_err_sample"] = f"first {nchk} instances of rank 0 vs oracle exact optimum"
+        _, _, Hq, _ = mo.condense(p)
+        out["cond_H"] = float(np.linalg.cond(Hq))
+
+    if not args.no_classes:
+        # per-class rates (each class alone on the whole batch), short runs
+        cls = {}
+        for s_ in AMPLITUDES:
+            solver.update_initialization(make_x0(mo, first, BATCH_PER_GPU, amplitude=s_))
+            time_steps(solver, opts, max(5, args.warmup // 5), barrier)
+            k = max(20, args.steps // 5)
+            el = max_over_ranks(time_steps(solver, opts, k, barrier))
+            cls[str(s_)] = world * k / el
+        out["classes"] = {"unit": "batch-steps/s", **cls}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # ---- CPU baseline (kind "port": oracle/almpc_oracle.c, OpenMP over instances, all host cores) on a bounded
+        # sample of the same workload: the same 4096 x0, same options, repeated until ~10 s of wall time
+        import c_oracle
+        des = mo.design_shared(p, rho=opts.rho, sigma=opts.sigma)
+        kw = dict(alpha=opts.alpha, eps_abs=opts.eps_abs, eps_rel=opts.eps_rel, max_iter=int(opts.max_iter),
+                  check_every=int(opts.check_every), polish=bool(opts.polish))
+        c_oracle.step_batch(p, des, X0[:256], **kw)  # warm
+        reps, t0, used = 0, time.perf_counter(), 1
+        while True:
+            r = c_oracle.step_batch(p, des, X0, **kw)
+            used = r["threads"]
+            reps += 1
+            if time.perf_counter() - t0 > 10.0 or reps >= 200:
+                break
+        cpu_el = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": reps / cpu_el, "unit": "batch-steps/s (one step = 4096 instance QP solves)",
+                               "cores": int(used), "kind": "port",
+                               "sample": f"{reps} passes over the same 4096 instances ({cpu_el:.1f} s wall), oracle/almpc_oracle.c "
+                                         f"(gcc -O3 -march=native, OpenMP): same ADMM+polish+rollout as the HIP path",
+                               "instance_steps_per_s": reps * BATCH_PER_GPU / cpu_el}
+    solver.close()
+    if rank == 0:
+        print(json.dumps(out))
+    ranks.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -158,6 +158,15 @@ int almpc_device_results(almpc_handle* h, const double** d_x, const double** d_e
  */
 int almpc_get_timing(almpc_handle* h, float* ms_admm, float* ms_polish, float* ms_rollout,
                      float* ms_total);
+/*
+ * Timing over many steps: with ALMPC_FLAG_TIMING every almpc_calculate records its own set of events.
+ * almpc_timing_reset forgets the recorded steps (and pre-creates events for `reserve_steps` steps so that
+ * no event is created inside a timed region); almpc_timing_summary synchronises and returns the number of
+ * steps recorded since the reset and the SUM of their per-stage milliseconds.
+ */
+int almpc_timing_reset(almpc_handle* h, int reserve_steps);
+int almpc_timing_summary(almpc_handle* h, int* steps, double* ms_admm, double* ms_polish,
+                         double* ms_rollout, double* ms_total);
 
 #ifdef __cplusplus
 }

@@ -183,7 +183,8 @@ def condense(p: MPCProblem):
     H = Gam.T @ Qbar @ Gam
     if p.R[0, 0] != 0.0:  # the reference tests only element [1,1] (src/sub/design_mpc.jl:436,448)
         H = H + np.kron(np.eye(N), p.R)
-    if p.S[0, 0] != 0.0:  # delta_u[:,i] = u[:,i]-u[:,i+1], i=1..N-1 (src/sub/design_mpc.jl:423-446)
+    # the S term enters only in the branch `R[1,1] != 0 && S[1,1] != 0` (src/sub/design_mpc.jl:436-446)
+    if p.R[0, 0] != 0.0 and p.S[0, 0] != 0.0:  # delta_u[:,i] = u[:,i]-u[:,i+1], i=1..N-1
         D = np.zeros((m * (N - 1), m * N))
         for i in range(N - 1):
             D[i * m:(i + 1) * m, i * m:(i + 1) * m] = np.eye(m)
@@ -200,7 +201,7 @@ def s_rate_gradient(p: MPCProblem):
     horizon: delta_u is defined on u (not e_u), u = v + u_ref, so
     sum ||D(v+u_ref)||_S^2 adds 2 D'Sbar D u_ref to f.  Zero for constant references."""
     m, N = p.m, p.N
-    if p.S[0, 0] == 0.0:
+    if p.S[0, 0] == 0.0 or p.R[0, 0] == 0.0:
         return np.zeros(m * N)
     D = np.zeros((m * (N - 1), m * N))
     for i in range(N - 1):

@@ -1,0 +1,343 @@
+"""Parity of the HIP path (through the C ABI) with the oracle.  Run on an MI355X: pytest -m gpu.
+
+Tolerance: BASELINE.json north_star states ||u* - u*_ref||_inf <= 1e-5 (absolute, input units); the tests use
+U_TOL = 1e-6 on u (ten times tighter) and X_TOL = 1e-5 on the rolled-out states (the rollout amplifies input errors
+through A^k on this marginally unstable plant)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+U_TOL = 1e-6
+X_TOL = 1e-5
+
+
+def make_solver(capi, p, batch, **kw):
+    s = capi.Solver(p.n, p.m, p.N, batch, device=0, **kw)
+    s.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max)
+    s.set_reference(p.x_ref, p.u_ref)
+    return s
+
+
+def step(capi, p, X0, opts=None, **kw):
+    X0 = np.atleast_2d(np.asarray(X0, dtype=np.float64))
+    s = make_solver(capi, p, X0.shape[0], **kw)
+    s.update_initialization(X0)
+    s.calculate(opts)
+    r = s.get_results()
+    s.close()
+    return r
+
+
+def _load(name):
+    with open(os.path.join(GOLDEN, name + ".json")) as f:
+        return json.load(f)
+
+
+def _problem(mo, g):
+    return mo.make_problem(g["A"], g["B"], g["N"], g["u_min"], g["u_max"], x_ref=g["x_ref"], u_ref=g["u_ref"],
+                           q=g["q"], r=g["r"], s=g["s"])
+
+
+# ---------------------------------------------------------------------------- design kernels
+@pytest.mark.parametrize("which", ["di", "di_S", "qtp", "quad"])
+def test_design_matches_oracle(capi, mo, qtp_ab, which):
+    p = {"di": mo.double_integrator, "quad": mo.quadrotor,
+         "di_S": lambda: _problem(mo, _load("double_integrator_S")),
+         "qtp": lambda: mo.qtp_linear_fixture_problem(*qtp_ab)}[which]()
+    s = make_solver(capi, p, 1)
+    d = s.get_design()
+    s.close()
+    od = mo.design_shared(p)
+    assert np.abs(d["P"] - p.P).max() <= 1e-9 * np.abs(p.P).max()           # DARE (src/sub/design_mpc.jl:327)
+    assert np.abs(d["H"] - od["H"]).max() <= 1e-10 * np.abs(od["H"]).max()  # H = 2(Gamma'Qbar Gamma + Rbar + D'SbarD)
+    assert np.abs(d["F"] - od["F"]).max() <= 1e-10 * np.abs(od["F"]).max()  # F = 2 Gamma'Qbar Phi
+    np.testing.assert_allclose(d["d"], od["d"], rtol=1e-10)
+    assert np.allclose(d["H"], d["H"].T, rtol=0, atol=1e-9 * np.abs(d["H"]).max())
+
+
+def test_user_supplied_terminal_weight(capi, mo):
+    p = mo.double_integrator()
+    P = np.array([[3.0, 0.5], [0.5, 2.0]])
+    p2 = mo.make_problem(p.A, p.B, p.N, p.u_min, p.u_max, P=P)
+    s = capi.Solver(2, 1, 10, 1)
+    s.design_shared(p.A, p.B, p.Q, p.R, None, P, p.u_min, p.u_max)
+    d = s.get_design()
+    s.update_initialization([[4.0, 1.0]])
+    s.calculate()
+    r = s.get_results()
+    s.close()
+    assert np.abs(d["H"] - mo.design_shared(p2)["H"]).max() <= 1e-10 * np.abs(d["H"]).max()
+    assert np.abs(r["u"][0] - mo.solve_mpc_exact(p2, np.array([4.0, 1.0]))["u"]).max() <= U_TOL
+
+
+# ---------------------------------------------------------------------------- golden vectors through the C ABI
+@pytest.mark.parametrize("name", ["double_integrator", "double_integrator_S", "qtp_linear", "quadrotor"])
+def test_golden_vectors(capi, mo, name):
+    g = _load(name)
+    p = _problem(mo, g)
+    X0 = np.array([c["x0"] for c in g["cases"]])
+    r = step(capi, p, X0)
+    assert np.all(r["status"] == 0)
+    for i, c in enumerate(g["cases"]):
+        assert np.abs(r["u"][i] - np.array(c["u"])).max() <= U_TOL
+        assert np.abs(r["x"][i] - np.array(c["x"])).max() <= X_TOL
+    np.testing.assert_allclose(r["e_u"], r["u"] - p.u_ref[None], atol=1e-14)
+    np.testing.assert_allclose(r["e_x"], r["x"] - p.x_ref[None], atol=1e-12)
+    np.testing.assert_array_equal(r["x"][:, :, 0], X0)  # x[:,1] is fixed to x0
+
+
+def test_reference_scenario_assertions(capi, mo, qtp_ab):
+    """test/computation_mpc_test.jl:1053-1054 on the reference's own fixture."""
+    r = step(capi, mo.qtp_linear_fixture_problem(*qtp_ab), np.full((1, 4), 0.6))
+    assert np.all(np.abs(r["x"][0] - 0.65) <= 0.5) and np.all(np.abs(r["u"][0][:, 0] - 1.2) <= 3.0)
+    assert np.all(r["x"] != 0) and np.all(r["u"] != 0)  # the `!= 0` assertions of test/terminal_ingredient_test.jl:162-168
+
+
+# ---------------------------------------------------------------------------- seeded batches vs the oracle
+@pytest.mark.parametrize("amp", [0.3, 1.0, 3.0])
+@pytest.mark.parametrize("batch", [1, 15, 16, 17, 100])
+def test_quadrotor_batches_vs_exact_oracle(capi, mo, amp, batch):
+    p = mo.quadrotor()
+    X0 = mo.quadrotor_x0_batch(batch, amp, first_instance=1000)
+    r = step(capi, p, X0)
+    assert np.all(r["status"] == 0)
+    for i in range(batch):
+        e = mo.solve_mpc_exact(p, X0[i])
+        assert np.abs(r["u"][i] - e["u"]).max() <= U_TOL
+        assert np.abs(r["x"][i] - e["x"]).max() <= X_TOL
+    assert np.all(r["u"] <= p.u_max[None, :, None] + 1e-15) and np.all(r["u"] >= p.u_min[None, :, None] - 1e-15)
+
+
+def test_algorithm_parity_with_c_restatement(capi, mo, co):
+    """Same algorithm, same options: ADMM iteration counts, polish sweep counts and iterates agree with the C
+    restatement (the HIP kernel tracks H'x by the KKT identity, the oracle multiplies: counts may differ only if a
+    residual sits within rounding of its threshold -- allowed on <= 0.2 % of the instances)."""
+    p = mo.quadrotor()
+    X0 = np.concatenate([mo.quadrotor_x0_batch(512, a, first_instance=512 * k) for k, a in enumerate((0.3, 1.0, 3.0))])
+    des = mo.design_shared(p)
+    for max_iter in (25, 50, 200):
+        r = step(capi, p, X0, capi.default_opts(max_iter=max_iter))
+        c = co.step_batch(p, des, X0, max_iter=max_iter)
+        assert (r["iters"] != c["iters"]).mean() <= 2e-3
+        assert (r["polish_iters"] != c["polish_iters"]).mean() <= 2e-3
+        assert np.array_equal(r["status"], c["status"])
+        assert np.abs(r["u"] - c["u"]).max() <= U_TOL and np.abs(r["x"] - c["x"]).max() <= X_TOL
+
+
+def test_admm_only_matches_oracle_iterate(capi, mo, co):
+    """polish off: the result is the ADMM iterate z itself -> compare the iterates of the two implementations."""
+    p = mo.quadrotor()
+    X0 = mo.quadrotor_x0_batch(64, 3.0)
+    des = mo.design_shared(p)
+    for kw in (dict(max_iter=25), dict(max_iter=100, check_every=10), dict(max_iter=37, check_every=5, alpha=1.0)):
+        r = step(capi, p, X0, capi.default_opts(polish=0, **kw))
+        c = co.step_batch(p, des, X0, polish=False, **kw)
+        assert np.array_equal(r["iters"], c["iters"]) and np.array_equal(r["status"], c["status"])
+        assert np.abs(r["u"] - c["u"]).max() <= 1e-9
+        assert np.all(r["polish_iters"] == 0)
+
+
+def test_osqp_default_settings_converge(capi, mo):
+    """OSQP's own defaults (max_iter 4000): every instance meets the ADMM tolerance on the double integrator."""
+    p = mo.double_integrator()
+    X0 = np.array([[1.0, 0.0], [5.0, 0.0], [-8.0, 2.0]])
+    r = step(capi, p, X0, capi.default_opts(max_iter=4000, polish=0))
+    assert np.all(r["status"] == 0) and np.all(r["iters"] % 25 == 0) and np.all(r["iters"] < 4000)
+    for i in range(3):
+        assert np.abs(r["u"][i] - mo.solve_mpc_exact(p, X0[i])["u"]).max() <= 5e-2  # eps = 1e-3 quality only
+
+
+# ---------------------------------------------------------------------------- edge cases
+def test_heavy_saturation_uses_second_polish_tier(capi, mo):
+    """Amplitude 10: working sets beyond 32 rows overflow the first polish tier (LDS 32x32) into the 64-row tier."""
+    p = mo.quadrotor()
+    X0 = mo.quadrotor_x0_batch(48, 10.0, first_instance=300)
+    r = step(capi, p, X0)
+    nact = [(np.isclose(r["u"][i], p.u_min[:, None]) | np.isclose(r["u"][i], p.u_max[:, None])).sum() for i in range(48)]
+    assert max(nact) > 32, "test input does not force the overflow branch"
+    assert np.all(r["status"] == 0)
+    for i in range(48):
+        assert np.abs(r["u"][i] - mo.solve_mpc_exact(p, X0[i])["u"]).max() <= U_TOL
+
+
+def test_working_set_beyond_largest_tier_keeps_admm_iterate(capi, mo):
+    """More than 64 active bounds: no polish tier takes the instance; it keeps the (feasible) ADMM iterate and is
+    reported as ALMPC_MAX_ITER unless ADMM itself met its tolerance."""
+    p = mo.quadrotor()
+    X0 = mo.quadrotor_x0_batch(8, 100.0)
+    r = step(capi, p, X0, capi.default_opts(max_iter=25))
+    assert np.all(r["u"] <= p.u_max[None, :, None]) and np.all(r["u"] >= p.u_min[None, :, None])
+    assert np.all(np.isin(r["status"], (0, 1)))
+
+
+def test_all_inputs_inside_bounds_and_zero_state(capi, mo):
+    p = mo.quadrotor()
+    r = step(capi, p, np.zeros((3, 12)))
+    assert np.all(r["status"] == 0) and np.abs(r["u"]).max() <= 1e-12 and np.abs(r["x"]).max() <= 1e-12
+
+
+def test_non_finite_input_is_flagged(capi, mo):
+    p = mo.quadrotor()
+    X0 = mo.quadrotor_x0_batch(20, 1.0)
+    X0[3, 2] = np.nan
+    X0[18, 0] = np.inf
+    r = step(capi, p, X0)
+    assert r["status"][3] == 2 and r["status"][18] == 2
+    ok = np.ones(20, bool)
+    ok[[3, 18]] = False
+    assert np.all(r["status"][ok] == 0)
+    for i in np.flatnonzero(ok)[:6]:
+        assert np.abs(r["u"][i] - mo.solve_mpc_exact(p, X0[i])["u"]).max() <= U_TOL
+
+
+def test_nonzero_and_per_instance_references(capi, mo, qtp_ab):
+    A, B = qtp_ab
+    p = mo.qtp_linear_fixture_problem(A, B)
+    batch = 5
+    rng = np.random.default_rng(3)
+    X0 = 0.6 + 0.1 * rng.standard_normal((batch, 4))
+    xr = 0.65 + 0.05 * rng.standard_normal((batch, 4, 1)) * np.ones((1, 1, 6))
+    ur = 1.2 + 0.5 * rng.standard_normal((batch, 2, 1)) * np.ones((1, 1, 5))
+    s = make_solver(capi, p, batch)
+    s.set_reference(xr, ur, per_instance=True)
+    s.update_initialization(X0)
+    s.calculate()
+    r = s.get_results()
+    s.close()
+    for i in range(batch):
+        pi = mo.make_problem(A, B, 5, p.u_min, p.u_max, x_ref=xr[i], u_ref=ur[i])
+        e = mo.solve_mpc_exact(pi, X0[i])
+        assert np.abs(r["u"][i] - e["u"]).max() <= U_TOL and np.abs(r["x"][i] - e["x"]).max() <= X_TOL
+        np.testing.assert_allclose(r["e_u"][i], r["u"][i] - ur[i], atol=1e-14)
+
+
+def test_input_rate_weight_with_time_varying_reference(capi, mo):
+    """S != 0 penalises u[:,i]-u[:,i+1] on u (not e_u): with a time-varying u_ref it adds a linear term."""
+    ur = np.linspace(-0.3, 0.4, 8).reshape(1, 8)
+    p = mo.make_problem([[1.0, 1.0], [0.0, 1.0]], [[0.5], [1.0]], 8, [-1.0], [1.0], x_ref=np.zeros((2, 9)), u_ref=ur, s=2.0)
+    X0 = np.array([[2.0, 0.5], [-1.0, 0.2]])
+    r = step(capi, p, X0)
+    for i in range(2):
+        assert np.abs(r["u"][i] - mo.solve_mpc_exact(p, X0[i])["u"]).max() <= U_TOL
+
+
+def test_warm_start_closed_loop(capi, mo):
+    """Receding horizon: 30 closed-loop steps with warm-started ADMM reach the reference and agree with the oracle."""
+    p = mo.quadrotor()
+    batch = 32
+    X = mo.quadrotor_x0_batch(batch, 1.0, first_instance=77)
+    s = make_solver(capi, p, batch)
+    warm = capi.default_opts(warm_start=1)
+    for k in range(30):
+        s.update_initialization(X)
+        s.calculate(warm if k else None)
+        r = s.get_results(want=("u", "status"))
+        assert np.all(r["status"] == 0)
+        if k % 10 == 0:
+            for i in range(0, batch, 8):
+                assert np.abs(r["u"][i] - mo.solve_mpc_exact(p, X[i])["u"]).max() <= U_TOL
+        X = X @ p.A.T + r["u"][:, :, 0] @ p.B.T
+    s.close()
+    assert np.abs(X[:, :3]).max() < 0.5 * np.abs(mo.quadrotor_x0_batch(batch, 1.0, first_instance=77)[:, :3]).max()
+
+
+def test_api_error_behaviour(capi, mo):
+    p = mo.double_integrator()
+    s = capi.Solver(2, 1, 10, 2)
+    with pytest.raises(capi.AlmpcError) as ei:
+        s.calculate()
+    assert ei.value.code == -5  # not designed
+    with pytest.raises(capi.AlmpcError) as ei:
+        s.design_shared(p.A, p.B, p.Q, p.R, None, None, p.u_min, p.u_max, xmin=[-1, -1], xmax=[1, 1])
+    assert ei.value.code == -4  # state box not built
+    with pytest.raises(capi.AlmpcError) as ei:
+        s.design_shared(p.A, p.B, p.Q, p.R, None, None, [1.0], [-1.0])
+    assert ei.value.code == -1
+    with pytest.raises(capi.AlmpcError) as ei:
+        s.design_shared(p.A, p.B, p.Q, 0.0 * p.R, None, None, p.u_min, p.u_max, rho=-1.0)
+    assert ei.value.code == -1
+    s.design_shared(p.A, p.B, p.Q, p.R, None, None, p.u_min, p.u_max)
+    with pytest.raises(capi.AlmpcError) as ei:
+        s.calculate(capi.default_opts(rho=0.5))  # differs from the design rho
+    assert ei.value.code == -1
+    with pytest.raises(capi.AlmpcError):
+        s.calculate(capi.default_opts(alpha=2.5))
+    s.update_initialization([[1.0, 0.0], [5.0, 0.0]])
+    s.calculate()
+    assert np.all(s.get_results()["status"] == 0)
+    s.close()
+
+
+# ---------------------------------------------------------------------------- host mirror of the reference API
+def test_proceed_controller_mirror(pkg, mo, qtp_ab):
+    """proceed_controller -> update_initialization! -> calculate! with the reference's argument order and result
+    shapes (test/computation_mpc_test.jl:981-1054; design asserts of test/design_mpc_implementation_test.jl:82-115)."""
+    A, B = qtp_ab
+    sys_ = pkg.ConstrainedLinearControlDiscreteSystem(A, B, pkg.Hyperrectangle([0.2] * 4, [1.36, 1.36, 1.30, 1.30]),
+                                                      pkg.Hyperrectangle([0, 0], [4, 3.26]))
+    C = pkg.proceed_controller(sys_, "model_predictive_control", 5, 5, [0.65] * 4, [1.2] * 2, mpc_terminal_ingredient="none")
+    assert C.tuning.horizon == 5 and C.tuning.sample_time == 5.0 and C.tuning.max_time == 30
+    assert C.tuning.terminal_ingredient.Xf == "none" and np.all(C.tuning.terminal_ingredient.P != 0)
+    assert C.computation_results.x.shape == (4, 6) and C.computation_results.u.shape == (2, 5)
+    pkg.update_initialization(C, [0.6] * 4)
+    pkg.calculate(C)
+    e = mo.solve_mpc_exact(mo.qtp_linear_fixture_problem(A, B), np.full(4, 0.6))
+    res = C.computation_results
+    assert np.abs(res.u - e["u"]).max() <= U_TOL and np.abs(res.x - e["x"]).max() <= X_TOL
+    assert np.abs(res.e_x - e["e_x"]).max() <= X_TOL and np.abs(res.e_u - e["e_u"]).max() <= U_TOL
+    assert np.all(np.abs(res.x - 0.65) <= 0.5) and np.all(np.abs(res.u[:, 0] - 1.2) <= 3)
+    C.tuning.modeler.solver.close()
+
+
+def test_batched_computation_mirror(pkg, mo):
+    p = mo.quadrotor()
+    sys_ = pkg.ConstrainedLinearControlDiscreteSystem(p.A, p.B, pkg.Hyperrectangle([-100] * 12, [100] * 12),
+                                                      pkg.Hyperrectangle(p.u_min, p.u_max))
+    C = pkg.proceed_controller(sys_, "model_predictive_control", 30, 1, [0.0] * 12, [0.0] * 4, mpc_batch=40, mpc_solver="hip")
+    X0 = mo.quadrotor_x0_batch(40, 3.0)
+    res = pkg._model_predictive_control_computation(C, X0)
+    assert res.u.shape == (40, 4, 30) and res.x.shape == (40, 12, 31)
+    for i in range(0, 40, 5):
+        assert np.abs(res.u[i] - mo.solve_mpc_exact(p, X0[i])["u"]).max() <= U_TOL
+    C.tuning.modeler.solver.close()
+
+
+# ---------------------------------------------------------------------------- full size: size-independent properties
+def test_full_size_batch_properties(capi, mo):
+    """BASELINE configs[1] size (4096 instances): KKT certificate of every instance (scaled coordinates), dynamics
+    consistency of the rollout, and agreement with the exact oracle on a sample."""
+    p = mo.quadrotor()
+    batch = 4096
+    amp = np.array([0.3, 1.0, 3.0])[np.arange(batch) % 3]
+    X0 = mo.splitmix_normal(0x5EED0002, 0, batch, 12) * mo.QUADROTOR_X0_SCALE[None] * amp[:, None]
+    r = step(capi, p, X0)
+    assert np.all(r["status"] == 0)
+    des = mo.design_shared(p)
+    d = des["d"]
+    W = (r["e_u"].transpose(0, 2, 1).reshape(batch, -1)) / d[None]
+    Fs = X0 @ des["Fs"].T
+    Gd = W @ des["Hs"] + Fs                                    # gradient H'w + f' per instance
+    kkt = np.abs(W - np.clip(W - Gd, des["lo"][None], des["hi"][None])).max(axis=1)
+    assert kkt.max() <= 1e-8 * max(1.0, np.abs(Fs).max())
+    # rollout obeys the deviation dynamics e_x[:,k+1] = A e_x[:,k] + B e_u[:,k]  (..linear.jl:58-60)
+    ex, eu = r["e_x"], r["e_u"]
+    pred = np.einsum("ij,bjk->bik", p.A, ex[:, :, :-1]) + np.einsum("ij,bjk->bik", p.B, eu)
+    assert np.abs(pred - ex[:, :, 1:]).max() <= 1e-9 * max(1.0, np.abs(ex).max())
+    for i in range(0, batch, 128):
+        assert np.abs(r["u"][i] - mo.solve_mpc_exact(p, X0[i])["u"]).max() <= U_TOL
+
+
+def test_repeatability(capi, mo):
+    """Two launches on the same inputs give bitwise identical results (no atomics, fixed reduction order)."""
+    p = mo.quadrotor()
+    X0 = mo.quadrotor_x0_batch(256, 3.0)
+    a = step(capi, p, X0)
+    b = step(capi, p, X0)
+    for k in ("u", "x", "iters", "polish_iters"):
+        assert np.array_equal(a[k], b[k])

@@ -1,0 +1,72 @@
+"""Host-side mirror of the reference interface: argument handling and error behaviour (CPU only)."""
+import numpy as np
+import pytest
+
+
+def test_design_reference_broadcast(pkg):
+    # src/main/main_mpc.jl:105-117: x = x_ref .* ones(n, N+1), u = u_ref .* ones(m, N)
+    r = pkg._design_reference_mpc([0.65] * 4, [1.2, 1.3], 5)
+    assert r.x.shape == (4, 6) and r.u.shape == (2, 5)
+    assert np.all(r.x == 0.65) and np.all(r.u[0] == 1.2) and np.all(r.u[1] == 1.3)
+
+
+def test_weights_defaults_and_kws_idiom(pkg):
+    sys_ = pkg.ConstrainedLinearControlDiscreteSystem(np.eye(3), np.ones((3, 2)), pkg.Hyperrectangle([0] * 3, [1] * 3),
+                                                      pkg.Hyperrectangle([0, 0], [1, 1]))
+    w = pkg._create_weights_coefficients(sys_)
+    assert np.array_equal(w.Q, 100 * np.eye(3)) and np.array_equal(w.R, 0.1 * np.eye(2)) and not w.S.any()
+    w = pkg._create_weights_coefficients(sys_, kws=dict(mpc_Q=7.0, mpc_S=2.0))  # kws passed through, as the reference does
+    assert w.Q[0, 0] == 7.0 and w.S[1, 1] == 2.0
+    w = pkg._create_weights_coefficients(sys_, mpc_R=3.0)
+    assert w.R[0, 0] == 3.0
+
+
+def _sys(pkg):
+    return pkg.ConstrainedLinearControlDiscreteSystem([[1, 1], [0, 1]], [[0.5], [1.0]], pkg.Hyperrectangle([-5, -5], [5, 5]),
+                                                      pkg.Hyperrectangle([-1], [1]))
+
+
+def test_proceed_controller_argument_errors(pkg):
+    s = _sys(pkg)
+    assert pkg.proceed_controller(s, "economic_model_predictive_control", 10, 1, [0, 0], [0]) is None  # removed in v0.1.4
+    with pytest.raises(TypeError):
+        pkg.proceed_controller(s, "model_predictive_control", 10, 1.5, [0, 0], [0])  # sample time must be Int
+    with pytest.raises(KeyError):
+        pkg.proceed_controller(s, "model_predictive_control", 10, 1, [0, 0], [0], mpc_solver="highs")
+    with pytest.raises(KeyError):
+        pkg.proceed_controller(s, "model_predictive_control", 10, 1, [0, 0], [0], mpc_programming_type="quadratic")
+    for kw in (dict(mpc_solver="osqp"), dict(mpc_programming_type="non_linear"), dict(mpc_terminal_ingredient="equality"),
+               dict(mpc_state_constraint=True)):
+        with pytest.raises(NotImplementedError):
+            pkg.proceed_controller(s, "model_predictive_control", 10, 1, [0, 0], [0], **kw)
+
+
+def test_design_fails_loudly_without_gpu(pkg):
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg._capi.AlmpcError):
+        pkg.proceed_controller(_sys(pkg), "model_predictive_control", 10, 1, [0, 0], [0])
+
+
+def test_system_validation(pkg):
+    with pytest.raises(ValueError):
+        pkg.Hyperrectangle([1.0], [0.0])
+    with pytest.raises(ValueError):
+        pkg.ConstrainedLinearControlDiscreteSystem(np.eye(2), np.ones((3, 1)), pkg.Hyperrectangle([0, 0], [1, 1]),
+                                                   pkg.Hyperrectangle([0], [1]))
+
+
+@pytest.mark.parametrize("batch,world", [(4096, 1), (32768, 8), (10, 3), (5, 8), (0, 2)])
+def test_shard_range_partitions(pkg, batch, world):
+    rs = [pkg.shard_range(batch, r, world) for r in range(world)]
+    assert rs[0][0] == 0 and rs[-1][1] == batch
+    assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
+    sizes = [b - a for a, b in rs]
+    assert max(sizes) - min(sizes) <= 1 and sorted(sizes, reverse=True) == sizes
+    with pytest.raises(ValueError):
+        pkg.shard_range(batch, world, world)
+
+
+def test_aggregate_rate(pkg):
+    assert pkg.sharding.aggregate_rate(4096, 10, 2.0, 8) == 8 * 4096 * 10 / 2.0
