@@ -35,6 +35,7 @@ struct almpc_handle {
     double *dX0 = nullptr, *dXs = nullptr, *dZs = nullptr, *dYs = nullptr, *dV0 = nullptr, *dW = nullptr;
     double *dX = nullptr, *dEx = nullptr, *dU = nullptr, *dEu = nullptr;
     int32_t *dStatus = nullptr, *dIters = nullptr, *dPiters = nullptr, *dOverflow = nullptr;
+    double* dSglobal = nullptr;  // polish scratch for working sets beyond 32 rows
     // timing (ALMPC_FLAG_TIMING): one set of 4 events per step since the last almpc_timing_reset
     std::vector<hipEvent_t> ev;  // 4 per step
     size_t ev_used = 0;          // steps recorded
@@ -85,7 +86,7 @@ hipError_t launch_admm(int nrb, int ks, const AdmmParams& p, int grid, size_t ld
 void free_all(almpc_handle* h) {
     void* ptrs[] = {h->dMinvFrag, h->dGFrag, h->dHFrag, h->dFFrag, h->dG, h->dD, h->dUmin, h->dUmax, h->dA, h->dB,
                     h->dXref, h->dUref, h->dFS, h->dX0, h->dXs, h->dZs, h->dYs, h->dV0, h->dW, h->dX, h->dEx,
-                    h->dU, h->dEu, h->dStatus, h->dIters, h->dPiters, h->dOverflow};
+                    h->dU, h->dEu, h->dStatus, h->dIters, h->dPiters, h->dOverflow, h->dSglobal};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& e : h->ev)
@@ -154,6 +155,7 @@ int almpc_create(almpc_handle** out, int n, int m, int N, int batch, int device_
     TRY(dalloc(&h->dV0, b * h->nzs)); TRY(dalloc(&h->dW, b * h->nzs));
     TRY(dalloc(&h->dX, b * n * (N + 1))); TRY(dalloc(&h->dEx, b * n * (N + 1)));
     TRY(dalloc(&h->dU, b * h->nz)); TRY(dalloc(&h->dEu, b * h->nz));
+    TRY(dalloc(&h->dSglobal, b * POLISH_GLB_PER_INST));
     TRY(dalloc(&h->dStatus, b)); TRY(dalloc(&h->dIters, b)); TRY(dalloc(&h->dPiters, b)); TRY(dalloc(&h->dOverflow, b));
     TRY(hipMemset(h->dXs, 0, b * h->nzs * sizeof(double)));
     TRY(hipMemset(h->dZs, 0, b * h->nzs * sizeof(double)));
@@ -293,6 +295,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
     ap.uref = h->dUref; ap.uref_stride = h->uref_stride; ap.xref = h->dXref; ap.xref_stride = h->xref_stride;
     ap.fS = h->dFS; ap.fS_stride = h->fS_stride; ap.x0 = h->dX0;
     ap.xs = h->dXs; ap.zs = h->dZs; ap.ys = h->dYs; ap.v0 = h->dV0; ap.status = h->dStatus; ap.iters = h->dIters;
+    ap.piters = h->dPiters; ap.overflow = h->dOverflow;
     ap.rho = o.rho; ap.sigma = o.sigma; ap.alpha = o.alpha; ap.eps_abs = o.eps_abs; ap.eps_rel = o.eps_rel;
     ap.max_iter = o.max_iter; ap.check_every = o.check_every; ap.warm = o.warm_start ? 1 : 0;
     const int grid = (h->batch + TILE - 1) / TILE;
@@ -302,30 +305,15 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
 
     const double* wsrc = h->dZs;
     if (o.polish) {
-        HIP_TRY(h, hipMemsetAsync(h->dPiters, 0, (size_t)h->batch * sizeof(int32_t), st));
-        HIP_TRY(h, hipMemsetAsync(h->dOverflow, 0, (size_t)h->batch * sizeof(int32_t), st));
-        // instances the polish cannot take (working set beyond the largest tier) keep the ADMM iterate
-        HIP_TRY(h, hipMemcpyAsync(h->dW, h->dZs, (size_t)h->batch * h->nzs * sizeof(double), hipMemcpyDeviceToDevice, st));
         PolishParams pp;
         pp.nz = h->nz; pp.m = h->m; pp.batch = h->batch; pp.nzs = h->nzs; pp.G = h->dG; pp.dvec = h->dD;
         pp.umin = h->dUmin; pp.umax = h->dUmax; pp.uref = h->dUref; pp.uref_stride = h->uref_stride;
         pp.zs = h->dZs; pp.ys = h->dYs; pp.v0 = h->dV0; pp.w = h->dW; pp.status = h->dStatus; pp.piters = h->dPiters;
-        pp.overflow = h->dOverflow;
+        pp.sglobal = h->dSglobal;
         pp.max_iter = o.polish_max_iter > 0 ? o.polish_max_iter : 20 * h->nz + 50;
-        {
-            constexpr int WL = 32, WAVES = 4;
-            pp.tier = 0;
-            const size_t l = (size_t)WAVES * (WL * WL + 2 * WL) * sizeof(double);
-            hipLaunchKernelGGL((k_polish<WL, WAVES>), dim3((h->batch + WAVES - 1) / WAVES), dim3(64 * WAVES), l, st, pp);
-            HIP_TRY(h, hipGetLastError());
-        }
-        {
-            constexpr int WL = 64, WAVES = 1;
-            pp.tier = 1;
-            const size_t l = (size_t)WAVES * (WL * WL + 2 * WL) * sizeof(double);
-            hipLaunchKernelGGL((k_polish<WL, WAVES>), dim3((h->batch + WAVES - 1) / WAVES), dim3(64 * WAVES), l, st, pp);
-            HIP_TRY(h, hipGetLastError());
-        }
+        const size_t l = (size_t)POLISH_WAVES * POLISH_LDS_PER_WAVE * sizeof(double);
+        hipLaunchKernelGGL(k_polish, dim3((h->batch + POLISH_WAVES - 1) / POLISH_WAVES), dim3(64 * POLISH_WAVES), l, st, pp);
+        HIP_TRY(h, hipGetLastError());
         wsrc = h->dW;
     }
     if (timing) HIP_TRY(h, hipEventRecord(ev[2], st));
@@ -333,7 +321,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
     RolloutParams rp;
     rp.n = h->n; rp.m = h->m; rp.N = h->N; rp.batch = h->batch; rp.nzs = h->nzs; rp.A = h->dA; rp.B = h->dB;
     rp.dvec = h->dD; rp.w = wsrc; rp.x0 = h->dX0; rp.xref = h->dXref; rp.xref_stride = h->xref_stride;
-    rp.uref = h->dUref; rp.uref_stride = h->uref_stride; rp.x = h->dX; rp.ex = h->dEx; rp.u = h->dU; rp.eu = h->dEu;
+    rp.uref = h->dUref; rp.uref_stride = h->uref_stride; rp.umin = h->dUmin; rp.umax = h->dUmax; rp.x = h->dX; rp.ex = h->dEx; rp.u = h->dU; rp.eu = h->dEu;
     {
         constexpr int WAVES = 4;
         const size_t l = ((size_t)h->n * h->n + (size_t)h->n * h->m + (size_t)WAVES * (h->n + h->nz)) * sizeof(double);

@@ -10,7 +10,7 @@
 //   k_admm<NRB,KS>  gradient f' = F'e0 (MFMA), box ADMM loop with the shared KKT inverse
 //                   (H'+(sigma+rho)I)^-1 register-resident as FP64 MFMA A-fragments, one 16-instance
 //                   tile per workgroup; v0 = -H'^-1 f' for the polish with the same machinery.
-//   k_polish<WL>    exact active-set finish, one wave per instance, (G_WW)^-1 in LDS.
+//   k_polish        exact active-set finish, one wave per instance, (G_WW)^-1 in LDS (global past 32 rows).
 //   k_rollout       u, e_u, x, e_x from w (recursive e+ = A e + B v).
 //
 // MFMA used: v_mfma_f64_16x16x4_f64.  Lane l holds A[i=l&15][k=l>>4], B[k=l>>4][j=l&15];
@@ -75,6 +75,8 @@ struct AdmmParams {
     double* v0;                // -H'^-1 f', [batch][nzs]
     int32_t* status;
     int32_t* iters;
+    int32_t* piters;    // zeroed here so that the step needs no memset nodes
+    int32_t* overflow;
     double rho, sigma, alpha, eps_abs, eps_rel;
     int max_iter, check_every, warm;
 };
@@ -261,6 +263,8 @@ __global__ __launch_bounds__(64 * NRB) void k_admm(AdmmParams p) {
         if (wv == 0 && q == 0) {
             p.iters[inst] = my_iters;
             p.status[inst] = my_status;
+            p.piters[inst] = 0;
+            p.overflow[inst] = 0;
         }
     }
 
@@ -295,9 +299,8 @@ struct PolishParams {
     double* w;           // result (scaled), [batch][nzs]
     int32_t* status;     // in: ADMM status; out: final
     int32_t* piters;
-    int32_t* overflow;   // per instance: 1 if the working set outgrew WL (handled by the next tier)
+    double* sglobal;     // [batch][64*64] scratch for working sets beyond 32 rows
     int max_iter;
-    int tier;            // 0: process every finite instance; >0: only those flagged by the previous tier
 };
 
 __device__ __forceinline__ double readlane_d(double v, int l) {
@@ -312,239 +315,491 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+// ---- wave-wide reductions on the DPP cross-lane path (no LDS crossbar): row_ror butterflies inside each 16-lane
+// row, then row_bcast15 / row_bcast31 to fold the four rows; lane 63 holds the result, returned wave-uniform.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_d(double v) {  // lanes without a valid source (or masked rows) keep v
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-    return v;
-}
-// (min value, smallest index among ties) over the wave; every lane gets the result
-__device__ __forceinline__ void wave_argmin(double& v, int& idx) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double ov = __shfl_xor(v, o);
-        const int oi = __shfl_xor(idx, o);
-        if (ov < v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+#define ALMPC_WAVE_REDUCE(NAME, OP)                                                     \
+    __device__ __forceinline__ double NAME(double v) {                                  \
+        v = OP(v, dpp_d<0x121, 0xF>(v)); /* row_ror:1 */                                \
+        v = OP(v, dpp_d<0x122, 0xF>(v)); /* row_ror:2 */                                \
+        v = OP(v, dpp_d<0x124, 0xF>(v)); /* row_ror:4 */                                \
+        v = OP(v, dpp_d<0x128, 0xF>(v)); /* row_ror:8 */                                \
+        { const double o = dpp_d<0x142, 0xA>(v); /* row_bcast15 -> rows 1,3 */          \
+          const bool take = ((threadIdx.x >> 4) & 1) != 0; v = take ? OP(v, o) : v; }   \
+        { const double o = dpp_d<0x143, 0xC>(v); /* row_bcast31 -> rows 2,3 */          \
+          const bool take = ((threadIdx.x >> 5) & 1) != 0; v = take ? OP(v, o) : v; }   \
+        return readlane_d(v, 63);                                                       \
     }
+__device__ __forceinline__ double op_add(double a, double b) { return a + b; }
+__device__ __forceinline__ double op_min(double a, double b) { return fmin(a, b); }
+__device__ __forceinline__ double op_max(double a, double b) { return fmax(a, b); }
+ALMPC_WAVE_REDUCE(wave_sum, op_add)
+ALMPC_WAVE_REDUCE(wave_min, op_min)
+ALMPC_WAVE_REDUCE(wave_max, op_max)
+#undef ALMPC_WAVE_REDUCE
+
+__device__ __forceinline__ void wave_fence_lds() {  // order this wave's LDS writes before its later LDS reads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// One wave per instance.  nz <= 128: lane l holds rows l and l+64.  Working set size k <= WL <= 64:
-// lane i < k owns row/column i of Sinv = (G_WW)^-1, stored column-major in LDS (S[c*WL + r]) so that a
-// sweep over columns reads consecutive addresses across lanes.
-template <int WL, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void k_polish(PolishParams p) {
-    static_assert(WL <= 64, "one lane per working-set row");
+// One wave per instance.  nz <= 128: lane l holds rows l and l+64 of the instance vectors ("row-distributed").
+// "Position-distributed" quantities (row index, bound, side, multiplier lam, bordering vectors) live in registers,
+// position i of the working set W on lane i.  Sinv = (G_WW)^-1 is stored column-major (S[c*LD + r]: a sweep over
+// columns reads consecutive addresses across lanes) in one of two modes:
+//   LDS mode   (|W| <= 32): Sinv in LDS; both half-waves mirror the positions (position = lane & 31) so that each
+//                           half takes every other column of a sweep.
+//   global mode (|W| <= 64): when the set outgrows 32 the wave copies Sinv to its slot of a global scratch and
+//                           carries on (no restart); slower per update, but only the updates beyond 32 pay for it.
+//
+// The kernel is latency bound (one dependent chain per instance), so every active-set change is O(1) round trips:
+//   add j   : c = G[W,j], u = Sinv c, sc = G_jj - c'u, mu = (t_j - b_j)/sc;  lam_W -= u mu, lam_j = mu;
+//             t -= mu (G[:,j] - G[:,W] u);  Sinv bordered.
+//   drop p  : s = Sinv[:,p], a = lam_p / s_p;  lam -= s a;  t += a G[:,W] s;  Sinv down-dated.
+// where t = v0 - G[:,W] lam is the minimiser of the current face (kept for every row) -- algebraically the same
+// iterates as recomputing lam and t from scratch (what oracle/mpc_oracle.py::polish_active_set does).  Before
+// accepting a face as optimal lam and t ARE recomputed from scratch and the tests repeated, so rounding drift of
+// the incremental form cannot end the loop early.  Reductions use the DPP path.
+template <bool GLB>
+struct PolishMode {
+    static constexpr bool glb = GLB;
+    static constexpr bool half = !GLB;
+    static constexpr int WL = GLB ? 64 : 32;  // capacity and leading dimension
+    static constexpr int PMASK = WL - 1;
+};
+
+constexpr int POLISH_WAVES = 4;
+// LDS per wave (doubles): Sinv 32x32 | row buffer 128 | two position buffers 64 | row-index buffer (64 ints)
+constexpr int POLISH_LDS_PER_WAVE = 32 * 32 + 128 + 64 + 64 + 32;
+constexpr int POLISH_GLB_PER_INST = 64 * 64;        // doubles of global scratch per instance
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
+    constexpr int CH = 16;  // positions per chunk of G rows
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    constexpr int PER_WAVE = WL * WL + WL + WL;  // S | Wb | (Widx, Wsd as int pairs)
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int inst = blockIdx.x * WAVES + wv;
+    const int inst = blockIdx.x * POLISH_WAVES + wv;
     if (inst >= p.batch) return;
     const int st_in = p.status[inst];
-    if (st_in == 2) return;  // non-finite: nothing to polish
-    if (p.tier > 0 && p.overflow[inst] != p.tier) return;
-
-    double* S = smem + (size_t)wv * PER_WAVE;
-    double* Wb = S + WL * WL;
-    int* Widx = reinterpret_cast<int*>(Wb + WL);
-    int* Wsd = Widx + WL;
-
     const int nz = p.nz, nzs = p.nzs;
     const size_t base = (size_t)inst * nzs;
-    // rows of this lane
-    const int r0 = lane, r1 = lane + 64;
+    // row-distributed vectors: lane l owns the two consecutive rows 2l, 2l+1 (one 16-byte access per vector)
+    const int r0 = 2 * lane, r1 = 2 * lane + 1;
     const bool in0 = r0 < nz, in1 = r1 < nz;
-    double lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0, v00 = 0, v01 = 0, w0 = 0, w1 = 0, y0 = 0, y1 = 0;
-    if (in0) {
-        const double di = 1.0 / p.dvec[r0];
-        const double ur = p.uref[(size_t)inst * p.uref_stride + r0];
-        lo0 = (p.umin[r0 % p.m] - ur) * di; hi0 = (p.umax[r0 % p.m] - ur) * di;
-        v00 = p.v0[base + r0]; y0 = p.ys[base + r0];
-        w0 = fmin(fmax(p.zs[base + r0], lo0), hi0);
-    }
-    if (in1) {
-        const double di = 1.0 / p.dvec[r1];
-        const double ur = p.uref[(size_t)inst * p.uref_stride + r1];
-        lo1 = (p.umin[r1 % p.m] - ur) * di; hi1 = (p.umax[r1 % p.m] - ur) * di;
-        v01 = p.v0[base + r1]; y1 = p.ys[base + r1];
-        w1 = fmin(fmax(p.zs[base + r1], lo1), hi1);
-    }
-    int pos0 = -1, pos1 = -1;  // position of the lane's rows in W (or -1)
-    int k = 0;                 // |W| (wave-uniform)
-    bool overflow = false;
-
-    // add row j (uniform) at bound value bval with side sd (+1 upper, -1 lower)
-    auto add_row = [&](int j, double bval, int sd) {
-        // c = G[W, j]; u = Sinv c; sc = G_jj - c'u
-        double c = 0.0;
-        if (lane < k) c = p.G[(size_t)Widx[lane] * nzs + j];
-        double u = 0.0;
-        for (int l = 0; l < k; ++l) {
-            const double cl = readlane_d(c, l);
-            if (lane < k) u += S[l * WL + lane] * cl;
-        }
-        const double sc = p.G[(size_t)j * nzs + j] - wave_sum(lane < k ? c * u : 0.0);
-        const double isc = 1.0 / sc;
-        for (int l = 0; l < k; ++l) {
-            const double ul = readlane_d(u, l);
-            if (lane < k) S[l * WL + lane] += u * ul * isc;
-        }
-        if (lane < k) {
-            S[k * WL + lane] = -u * isc;  // new column k
-            S[lane * WL + k] = -u * isc;  // new row k
-        }
-        if (lane == 0) {
-            S[k * WL + k] = isc;
-            Widx[k] = j; Wsd[k] = sd; Wb[k] = bval;
-        }
-        if (j == r0) pos0 = k;
-        if (j == r1) pos1 = k;
-        k += 1;
-        wave_lds_sync();
-    };
-    // remove position pos (uniform): Schur down-date, then move the last row/column into the hole
-    auto remove_pos = [&](int pos) {
-        double pc = 0.0;
-        if (lane < k) pc = S[pos * WL + lane];
-        const double ipp = 1.0 / readlane_d(pc, pos);
-        for (int l = 0; l < k; ++l) {
-            const double pl = readlane_d(pc, l);
-            if (lane < k) S[l * WL + lane] -= pc * pl * ipp;
-        }
-        wave_lds_sync();
-        const int last = k - 1;
-        const int jrem = Widx[pos], jlast = Widx[last];
-        if (pos != last) {
-            double colv = 0.0;
-            if (lane < k) colv = S[last * WL + lane];  // column `last` (== row `last`, symmetric)
-            const double corner = readlane_d(colv, last);
-            wave_lds_sync();
-            if (lane < k && lane != pos && lane != last) {
-                S[pos * WL + lane] = colv;
-                S[lane * WL + pos] = colv;
-            }
-            if (lane == 0) {
-                S[pos * WL + pos] = corner;
-                Widx[pos] = jlast; Wsd[pos] = Wsd[last]; Wb[pos] = Wb[last];
-            }
-        }
-        if (r0 == jrem) pos0 = -1;
-        if (r1 == jrem) pos1 = -1;
-        if (pos != last) {
-            if (r0 == jlast) pos0 = pos;
-            if (r1 == jlast) pos1 = pos;
-        }
-        k -= 1;
-        wave_lds_sync();
-    };
-
-    // ---- initial working set from the ADMM multipliers (OSQP polish rule: sign of y), rows in order
-    for (int j = 0; j < nz && !overflow; ++j) {
-        const int src = j & 63;
-        const bool second = j >= 64;
-        const double yy = readlane_d(second ? y1 : y0, src);
-        const double ww = readlane_d(second ? w1 : w0, src);
-        const double ll = readlane_d(second ? lo1 : lo0, src);
-        const double hh = readlane_d(second ? hi1 : hi0, src);
-        int sd = 0;
-        if (yy < 0.0 && ww <= ll) sd = -1;
-        else if (yy > 0.0 && ww >= hh) sd = +1;
-        if (sd != 0) {
-            if (k == WL) { overflow = true; break; }
-            add_row(j, sd > 0 ? hh : ll, sd);
-        }
-    }
-
-    int it = 0;
-    int fin = 1;  // 0 = certified
-    const int max_iter = p.max_iter;
-    while (!overflow && it < max_iter) {
-        ++it;
-        // ---- face minimiser t = v0 - G[:,W] lam,  lam = Sinv (v0_W - b)
-        double lam = 0.0;
-        if (k > 0) {
-            // r_i = v0[W_i] - b_i : lane i fetches v0 of row Widx[i] from its owner lane
-            const int jw = (lane < k) ? Widx[lane] : 0;
-            const double a0 = __shfl(v00, jw & 63);
-            const double a1 = __shfl(v01, jw & 63);
-            const double r = (lane < k) ? ((jw >= 64 ? a1 : a0) - Wb[lane]) : 0.0;
-            for (int l = 0; l < k; ++l) {
-                const double rl = readlane_d(r, l);
-                if (lane < k) lam += S[l * WL + lane] * rl;
-            }
-        }
-        double t0 = v00, t1 = v01;
-        for (int l = 0; l < k; ++l) {
-            const int j = Widx[l];
-            const double ll = readlane_d(lam, l);
-            if (in0) t0 -= p.G[(size_t)j * nzs + r0] * ll;
-            if (in1) t1 -= p.G[(size_t)j * nzs + r1] * ll;
-        }
-        if (pos0 >= 0) t0 = Wb[pos0];
-        if (pos1 >= 0) t1 = Wb[pos1];
-        // ---- ratio test over the free rows
-        double rr = __builtin_inf();
-        int rj = 0x7fffffff;
-        int rside = 0;
-        if (in0 && pos0 < 0) {
-            if (t0 > hi0) { rr = (hi0 - w0) / (t0 - w0); rj = r0; rside = +1; }
-            else if (t0 < lo0) { rr = (lo0 - w0) / (t0 - w0); rj = r0; rside = -1; }
-        }
-        if (in1 && pos1 < 0) {
-            double c = __builtin_inf();
-            int s = 0;
-            if (t1 > hi1) { c = (hi1 - w1) / (t1 - w1); s = +1; }
-            else if (t1 < lo1) { c = (lo1 - w1) / (t1 - w1); s = -1; }
-            if (c < rr) { rr = c; rj = r1; rside = s; }  // r1 > r0: ties keep the smaller row
-        }
-        double rmin = rr;
-        int jmin = rj;
-        wave_argmin(rmin, jmin);
-        jmin = __builtin_amdgcn_readfirstlane(jmin);
-        if (rmin < 1.0) {
-            const double tt = fmax(rmin, 0.0);
-            if (in0 && pos0 < 0) w0 += tt * (t0 - w0);
-            if (in1 && pos1 < 0) w1 += tt * (t1 - w1);
-            // owner lane of jmin knows the side and the bound
-            const int owner = jmin & 63;
-            int sd = (rj == jmin) ? rside : 0;
-            sd = __shfl(sd, owner);
-            const double bh = __shfl(jmin >= 64 ? hi1 : hi0, owner);
-            const double bl = __shfl(jmin >= 64 ? lo1 : lo0, owner);
-            const double bval = sd > 0 ? bh : bl;
-            if (r0 == jmin) w0 = bval;
-            if (r1 == jmin) w1 = bval;
-            if (k == WL) { overflow = true; break; }
-            add_row(jmin, bval, sd);
-            continue;
-        }
-        w0 = t0; w1 = t1;
-        if (k == 0) { fin = 0; break; }
-        // ---- multiplier signs: upper bound needs lam >= 0, lower bound lam <= 0
-        double viol = -__builtin_inf();
-        int vi = 0x7fffffff;
-        if (lane < k) { viol = (Wsd[lane] > 0) ? -lam : lam; vi = lane; }
-        const double lmax = wave_max(lane < k ? fabs(lam) : 0.0);
-        double nv = -viol;
-        wave_argmin(nv, vi);  // argmax of viol, smallest position among ties
-        vi = __builtin_amdgcn_readfirstlane(vi);
-        if (-nv <= 1e-12 * fmax(1.0, lmax)) { fin = 0; break; }
-        remove_pos(vi);
-    }
-
-    if (overflow) {
-        if (lane == 0) p.overflow[inst] = p.tier + 1;
+    const bool inrow = r0 < nzs;            // nzs is even: the pair (r0, r1) is inside the padded vector or not at all
+    const int rc = inrow ? r0 : 0;          // clamped pair index for loads (lanes beyond the vector read pair 0)
+    if (st_in == 2) {  // non-finite instance: nothing to polish, hand the ADMM iterate on
+        if (inrow) *reinterpret_cast<d2*>(p.w + base + r0) = *reinterpret_cast<const d2*>(p.zs + base + r0);
         return;
     }
-    if (in0) p.w[base + r0] = fmin(fmax(w0, lo0), hi0);
-    if (in1) p.w[base + r1] = fmin(fmax(w1, lo1), hi1);
+
+    double* Sl = smem + (size_t)wv * POLISH_LDS_PER_WAVE;
+    double* rowbuf = Sl + 32 * 32;     // [128] one row-distributed vector, for gathers by row index
+    double* pbufa = rowbuf + 128;      // [64]  one position-distributed vector, for broadcasts by position
+    double* pbufb = pbufa + 64;        // [64]  a second one
+    int* wrow_s = reinterpret_cast<int*>(pbufb + 64);  // [64] row index of each position (copy of wrow)
+    double* Sg = p.sglobal + (size_t)inst * POLISH_GLB_PER_INST;
+
+    double lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0, v00, v01, w0 = 0, w1 = 0, y0, y1, z0, z1;
+    {
+        const d2 dv = *reinterpret_cast<const d2*>(p.dvec + rc);
+        const d2 vv = *reinterpret_cast<const d2*>(p.v0 + base + rc);
+        const d2 yy = *reinterpret_cast<const d2*>(p.ys + base + rc);
+        const d2 zz = *reinterpret_cast<const d2*>(p.zs + base + rc);
+        v00 = vv[0]; v01 = vv[1]; y0 = yy[0]; y1 = yy[1]; z0 = zz[0]; z1 = zz[1];
+        // bounds exactly as k_admm forms them ((umin - uref) * (1/d)): its z sits ON these values when active
+        if (in0) {
+            const double di = 1.0 / dv[0], ur = p.uref[(size_t)inst * p.uref_stride + r0];
+            lo0 = (p.umin[r0 % p.m] - ur) * di; hi0 = (p.umax[r0 % p.m] - ur) * di; w0 = fmin(fmax(z0, lo0), hi0);
+        } else { v00 = 0.0; y0 = 0.0; z0 = 0.0; }
+        if (in1) {
+            const double di = 1.0 / dv[1], ur = p.uref[(size_t)inst * p.uref_stride + r1];
+            lo1 = (p.umin[r1 % p.m] - ur) * di; hi1 = (p.umax[r1 % p.m] - ur) * di; w1 = fmin(fmax(z1, lo1), hi1);
+        } else { v01 = 0.0; y1 = 0.0; z1 = 0.0; }
+    }
+    int wrow = 0, wsd = 0;   // position-distributed: row index, side (+1 upper / -1 lower)
+    double wbnd = 0.0;       // position-distributed: bound value
+    double lam = 0.0;        // position-distributed: multiplier of the bound (H't + f' + E_W lam = 0)
+    bool act0 = false, act1 = false;  // row-distributed: row is in the working set
+    double bnd0 = 0.0, bnd1 = 0.0;    // row-distributed: the bound it sits on
+    double t0 = v00, t1 = v01;        // row-distributed: face minimiser v0 - G[:,W] lam
+    int k = 0;               // |W|, wave-uniform
+    bool overflow = false;   // the set outgrew the current mode
+    wrow_s[lane] = 0;
+
+    // Sinv is kept padded with the identity beyond the k x k block and position-distributed vectors are exactly
+    // zero beyond position k, so every sweep below runs over chunk-rounded ranges with UNCONDITIONAL loads and
+    // stores (no exec-masked branches around memory operations: they would serialise every LDS round trip).
+    // Broadcasts of a position-distributed vector go through a 64-entry LDS buffer (one uniform-address read per
+    // element, pipelined with the Sinv reads) rather than through v_readlane pairs.
+    auto sync_s = [&](auto m) {  // order this wave's writes to Sinv before its later reads
+        if constexpr (decltype(m)::glb) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        } else {
+            wave_fence_lds();
+        }
+    };
+    auto sptr = [&](auto m) -> double* { if constexpr (decltype(m)::glb) return Sg; else return Sl; };
+    auto put_pos = [&](auto m, double* buf, double v) {  // position-distributed register -> LDS buffer
+        buf[decltype(m)::half ? (lane & 31) : lane] = v;  // (both halves write the same value in LDS mode)
+        wave_fence_lds();
+    };
+
+    // u = Sinv * c, c given in LDS buffer cb (zero beyond k); result position-distributed (zero beyond k)
+    auto s_matvec = [&](auto m, const double* cb) -> double {
+        using M = decltype(m);
+        double* S = sptr(m);
+        double acc = 0.0;
+        if constexpr (M::half) {
+            const int pos = lane & 31, hf = lane >> 5;
+            for (int l0 = 0; l0 < k; l0 += 16) {
+                double sv[8], cv[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) { sv[t] = S[(l0 + 2 * t + hf) * M::WL + pos]; cv[t] = cb[l0 + 2 * t + hf]; }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc += sv[t] * cv[t];
+            }
+            acc += __shfl_xor(acc, 32);
+        } else {
+            for (int l0 = 0; l0 < k; l0 += 8) {
+                double sv[8], cv[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) { sv[t] = S[(l0 + t) * M::WL + lane]; cv[t] = cb[l0 + t]; }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc += sv[t] * cv[t];
+            }
+        }
+        return acc;
+    };
+    // Sinv += a a' * scale: a position-distributed in register AND in LDS buffer ab (zero beyond k)
+    auto s_rank1 = [&](auto m, double a, const double* ab, double scale) {
+        using M = decltype(m);
+        double* S = sptr(m);
+        const double as = a * scale;
+        if constexpr (M::half) {
+            const int pos = lane & 31, hf = lane >> 5;
+            for (int l0 = 0; l0 < k; l0 += 16) {
+                double cur[8], av[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) { cur[t] = S[(l0 + 2 * t + hf) * M::WL + pos]; av[t] = ab[l0 + 2 * t + hf]; }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) S[(l0 + 2 * t + hf) * M::WL + pos] = cur[t] + as * av[t];
+            }
+        } else {
+            for (int l0 = 0; l0 < k; l0 += 8) {
+                double cur[8], av[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) { cur[t] = S[(l0 + t) * M::WL + lane]; av[t] = ab[l0 + t]; }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) S[(l0 + t) * M::WL + lane] = cur[t] + as * av[t];
+            }
+        }
+    };
+    // (q0, q1) = sum_{l<k} G[W_l, rows] * a_l, a given in LDS buffer ab (zero beyond k): the only O(nz k) part of an
+    // update.  One 16-byte load per row and lane; row indices come from the LDS copy of wrow (zero beyond k: row 0
+    // is a valid address and its weight is zero).
+    auto g_rows_times = [&](const double* ab, double& q0, double& q1) {
+        q0 = 0.0; q1 = 0.0;
+        for (int l0 = 0; l0 < k; l0 += CH) {
+            d2 g[CH];
+            double av[CH];
+#pragma unroll
+            for (int t = 0; t < CH; ++t) {
+                const int jrow = wrow_s[l0 + t];
+                g[t] = *reinterpret_cast<const d2*>(p.G + (size_t)jrow * nzs + rc);
+                av[t] = ab[l0 + t];
+            }
+#pragma unroll
+            for (int t = 0; t < CH; ++t) { q0 += g[t][0] * av[t]; q1 += g[t][1] * av[t]; }
+        }
+    };
+    auto put_rows = [&](double a0, double a1) {  // row-distributed pair -> rowbuf
+        d2 v; v[0] = a0; v[1] = a1;
+        *reinterpret_cast<d2*>(rowbuf + r0) = v;
+        wave_fence_lds();
+    };
+    auto recompute = [&](auto m) {  // lam = Sinv (v0_W - b), t = v0 - G[:,W] lam from scratch
+        using M = decltype(m);
+        const int pos = M::half ? (lane & 31) : lane;
+        put_rows(v00, v01);
+        const double rv = rowbuf[wrow] - wbnd;  // wrow is always a valid row index
+        put_pos(m, pbufa, (pos < k) ? rv : 0.0);
+        const double lm = s_matvec(m, pbufa);
+        lam = (pos < k) ? lm : 0.0;
+        put_pos(m, pbufb, lam);
+        double q0, q1;
+        g_rows_times(pbufb, q0, q1);
+        t0 = v00 - q0;
+        t1 = v01 - q1;
+    };
+    // add row j (uniform) at bound bval with side sd; the caller guarantees k < capacity
+    auto add_row = [&](auto m, int j, double bval, int sd) {
+        using M = decltype(m);
+        double* S = sptr(m);
+        const int pos = M::half ? (lane & 31) : lane;
+        const bool lowhalf = M::half ? (lane < 32) : true;
+        const d2 gj = *reinterpret_cast<const d2*>(p.G + (size_t)j * nzs + rc);  // row j = column j
+        put_rows(gj[0], gj[1]);
+        const double cv = rowbuf[wrow];
+        const double c = (pos < k) ? cv : 0.0;
+        const double gjj = rowbuf[j];
+        const double tj = readlane_d((j & 1) ? t1 : t0, j >> 1);
+        put_pos(m, pbufa, c);
+        const double u = s_matvec(m, pbufa);  // zero beyond k (identity padding)
+        put_pos(m, pbufb, u);
+        double q0, q1;
+        g_rows_times(pbufb, q0, q1);
+        const double sc = gjj - wave_sum(lowhalf ? c * u : 0.0);
+        const double isc = 1.0 / sc;
+        const double mu = (tj - bval) * isc;
+        t0 -= mu * (gj[0] - q0);
+        t1 -= mu * (gj[1] - q1);
+        lam -= u * mu;
+        s_rank1(m, u, pbufb, isc);
+        {   // border: new column k and new row k (u is zero beyond k, so the padding stays zero)
+            const double bv = (pos == k) ? isc : -u * isc;
+            S[k * M::WL + pos] = bv;
+            S[pos * M::WL + k] = bv;
+        }
+        if (pos == k) { wrow = j; wsd = sd; wbnd = bval; lam = mu; }
+        if (lane == 0) wrow_s[k] = j;
+        if (r0 == j) { act0 = true; bnd0 = bval; }
+        if (r1 == j) { act1 = true; bnd1 = bval; }
+        k += 1;
+        sync_s(m);
+    };
+    // remove position rp (uniform)
+    auto remove_pos = [&](auto m, int rp) {
+        using M = decltype(m);
+        double* S = sptr(m);
+        const int pos = M::half ? (lane & 31) : lane;
+        const double sp = S[rp * M::WL + pos];  // column rp of Sinv (zero beyond k)
+        const double spp = readlane_d(sp, rp);
+        const double a = readlane_d(lam, rp) / spp;
+        put_pos(m, pbufb, sp);
+        double q0, q1;
+        g_rows_times(pbufb, q0, q1);
+        t0 += a * q0;
+        t1 += a * q1;
+        lam -= sp * a;
+        s_rank1(m, sp, pbufb, -1.0 / spp);  // row and column rp become zero
+        sync_s(m);
+        const int last = k - 1;
+        const int jrem = __builtin_amdgcn_readlane(wrow, rp);
+        if (rp != last) {  // move the last position into the hole
+            const double colv = S[last * M::WL + pos];
+            const double corner = readlane_d(colv, last);
+            const double nv = (pos == rp) ? corner : ((pos == last) ? 0.0 : colv);
+            S[rp * M::WL + pos] = nv;
+            S[pos * M::WL + rp] = nv;
+            const int lrow = __builtin_amdgcn_readlane(wrow, last), lsd = __builtin_amdgcn_readlane(wsd, last);
+            const double lbv = readlane_d(wbnd, last), llam = readlane_d(lam, last);
+            if (pos == rp) { wrow = lrow; wsd = lsd; wbnd = lbv; lam = llam; }
+            if (lane == 0) wrow_s[rp] = lrow;
+        }
+        {   // position `last` returns to the identity padding
+            const double iv = (pos == last) ? 1.0 : 0.0;
+            S[last * M::WL + pos] = iv;
+            S[pos * M::WL + last] = iv;
+        }
+        if (pos == last) lam = 0.0;
+        if (lane == 0) wrow_s[last] = 0;
+        if (r0 == jrem) act0 = false;
+        if (r1 == jrem) act1 = false;
+        k -= 1;
+        sync_s(m);
+    };
+
+    int it = 0;
+    int fin = 1;         // 0 = certified
+    bool fresh = true;   // lam and t were recomputed from scratch since the last change of W
+    const int max_iter = p.max_iter;
+    // the active-set loop in one storage mode; returns with overflow = true if an add does not fit
+    auto run = [&](auto m) {
+        using M = decltype(m);
+        const int pos = M::half ? (lane & 31) : lane;
+        const bool lowhalf = M::half ? (lane < 32) : true;
+        while (it < max_iter) {
+            ++it;
+            // ---- ratio test over the free rows: first bound hit on the way from w to the face minimiser t
+            double rr = __builtin_inf();
+            int rside = 0;
+            bool second = false;
+            {
+                const bool f0 = in0 && !act0, f1 = in1 && !act1;
+                const bool up0 = t0 > hi0, dn0 = t0 < lo0, up1 = t1 > hi1, dn1 = t1 < lo1;
+                const double c0 = ((up0 ? hi0 : lo0) - w0) / (t0 - w0);
+                const double c1 = ((up1 ? hi1 : lo1) - w1) / (t1 - w1);
+                const bool v0 = f0 && (up0 || dn0), v1 = f1 && (up1 || dn1);
+                if (v0) { rr = c0; rside = up0 ? 1 : -1; }
+                if (v1 && (!v0 || c1 < c0)) { rr = c1; rside = up1 ? 1 : -1; second = true; }  // ties keep the smaller row
+            }
+            const double rmin = wave_min(rr);
+            if (rmin < 1.0) {
+                if (k == M::WL) { --it; overflow = true; return; }  // redo this pass in the next mode
+                const int owner = __builtin_ctzll(__ballot(rr == rmin));  // smallest lane = smallest row among ties
+                const int jmin = 2 * owner + (__builtin_amdgcn_readlane(second ? 1 : 0, owner));
+                const double tt = fmax(rmin, 0.0);
+                if (in0 && !act0) w0 += tt * (t0 - w0);
+                if (in1 && !act1) w1 += tt * (t1 - w1);
+                const int sd = __builtin_amdgcn_readlane(rside, owner);
+                const double bh = readlane_d((jmin & 1) ? hi1 : hi0, owner);
+                const double bl = readlane_d((jmin & 1) ? lo1 : lo0, owner);
+                const double bval = sd > 0 ? bh : bl;
+                if (r0 == jmin) w0 = bval;
+                if (r1 == jmin) w1 = bval;
+                add_row(m, jmin, bval, sd);
+                fresh = false;
+                continue;
+            }
+            if (!act0) w0 = t0;
+            if (!act1) w1 = t1;
+            // ---- multiplier signs: upper bound needs lam >= 0, lower bound lam <= 0
+            bool ok = true;
+            int vi = 0;
+            if (k > 0) {
+                const bool mine = lowhalf && pos < k;
+                const double viol = mine ? ((wsd > 0) ? -lam : lam) : -__builtin_inf();
+                const double lmax = wave_max(mine ? fabs(lam) : 0.0);
+                const double vmax = wave_max(viol);
+                ok = vmax <= 1e-12 * fmax(1.0, lmax);
+                vi = __builtin_ctzll(__ballot(mine && viol == vmax));  // smallest position among ties
+            }
+            if (ok) {
+                if (fresh) { fin = 0; return; }
+                recompute(m);  // confirm on values computed from scratch (does not count as an iteration)
+                fresh = true;
+                --it;
+                continue;
+            }
+            remove_pos(m, vi);
+            fresh = false;
+        }
+    };
+    auto to_global = [&]() {  // carry Sinv (k <= 32 positions) over to the global slot: leading dimension 64, identity padded
+        for (int c = 0; c < 64; ++c) {
+            const double v = (c < 32 && lane < 32) ? Sl[(c & 31) * 32 + (lane & 31)] : ((c == lane) ? 1.0 : 0.0);
+            Sg[c * 64 + lane] = v;
+        }
+        if (lane >= 32) lam = 0.0;  // lanes 32..63 stop mirroring positions 0..31: they are positions 32..63 now
+        sync_s(PolishMode<true>{});
+    };
+
+    // ---- initial working set from the ADMM multipliers (OSQP polish rule: sign of y), rows in ascending order.
+    // Sinv of the first (up to 32) rows at once: gather G_WW into LDS, Gauss-Jordan in place (SPD: no pivoting);
+    // flagged rows beyond 32 are then added one by one in global mode.
+    const int s0 = (in0 && y0 < 0.0 && w0 <= lo0) ? -1 : ((in0 && y0 > 0.0 && w0 >= hi0) ? 1 : 0);
+    const int s1 = (in1 && y1 < 0.0 && w1 <= lo1) ? -1 : ((in1 && y1 > 0.0 && w1 >= hi1) ? 1 : 0);
+    const unsigned long long m0 = __ballot(s0 != 0), m1 = __ballot(s1 != 0);
+    const int k0 = __popcll(m0) + __popcll(m1);
+    bool give_up = k0 > 64;  // more than 64 bounds active: beyond the largest mode, keep the ADMM iterate
+    if (!give_up && k0 > 0) {
+        using M = PolishMode<false>;
+        const M m{};
+        const int pos = lane & 31, hf = lane >> 5;
+        // position of a flagged row = number of flagged rows before it (rows ascend with the lane, then first/second)
+        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        const int p0 = __popcll(m0 & below) + __popcll(m1 & below), p1 = p0 + (s0 != 0 ? 1 : 0);
+        int* ibuf = reinterpret_cast<int*>(rowbuf);  // [0..64): row of position, [64..128): side
+        if (s0 != 0) { ibuf[p0] = r0; ibuf[64 + p0] = s0; }
+        if (s1 != 0) { ibuf[p1] = r1; ibuf[64 + p1] = s1; }
+        wave_fence_lds();
+        k = k0 < 32 ? k0 : 32;
+        if (pos < k) { wrow = ibuf[pos]; wsd = ibuf[64 + pos]; }
+        // pending rows (positions >= 32) are remembered on the lanes of the same number
+        const int pend_row = (lane >= 32 && lane < k0) ? ibuf[lane] : 0;
+        const int pend_sd = (lane >= 32 && lane < k0) ? ibuf[64 + lane] : 0;
+        wave_fence_lds();
+        if (s0 != 0 && p0 < 32) { act0 = true; bnd0 = s0 > 0 ? hi0 : lo0; }
+        if (s1 != 0 && p1 < 32) { act1 = true; bnd1 = s1 > 0 ? hi1 : lo1; }
+        put_rows(s0 > 0 ? hi0 : lo0, s1 > 0 ? hi1 : lo1);  // bound a flagged row sits on
+        if (pos < k) wbnd = rowbuf[wrow];
+        const double pend_bnd = (lane >= 32 && lane < k0) ? rowbuf[pend_row] : 0.0;
+        if (lane < 32) wrow_s[lane] = (lane < k) ? wrow : 0;
+        // Sinv := identity, then K = G[W,W] into the leading k x k block (each half every other column)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) Sl[(2 * t + hf) * 32 + pos] = ((2 * t + hf) == pos) ? 1.0 : 0.0;
+        wave_fence_lds();
+        for (int l0 = 0; l0 < k; l0 += 16) {
+            double gv[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) gv[t] = p.G[(size_t)wrow_s[l0 + 2 * t + hf] * nzs + wrow];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int l = l0 + 2 * t + hf;
+                const double idv = (l == pos) ? 1.0 : 0.0;
+                Sl[l * 32 + pos] = (l < k && pos < k) ? gv[t] : idv;
+            }
+        }
+        wave_fence_lds();
+        // Gauss-Jordan in place on the padded matrix: columns are independent once the pivot column is read
+        for (int pv = 0; pv < k; ++pv) {
+            const double ip = 1.0 / Sl[pv * 32 + pv];
+            const double f = Sl[pv * 32 + pos] * ip;  // S[i][pv] / pivot
+            for (int c0 = 0; c0 < k; c0 += 16) {
+                double rowpc[8], mine[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int c = c0 + 2 * t + hf;
+                    rowpc[t] = Sl[c * 32 + pv];   // S[pv][c]
+                    mine[t] = Sl[c * 32 + pos];   // S[i][c]
+                }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int c = c0 + 2 * t + hf;
+                    double v;
+                    if (pos == pv) v = (c == pv) ? ip : rowpc[t] * ip;
+                    else v = (c == pv) ? -f : mine[t] - f * rowpc[t];
+                    Sl[c * 32 + pos] = v;
+                }
+            }
+            wave_fence_lds();
+        }
+        recompute(m);
+        if (k0 > 32) {
+            to_global();
+            for (int q = 32; q < k0; ++q)
+                add_row(PolishMode<true>{}, __builtin_amdgcn_readlane(pend_row, q), readlane_d(pend_bnd, q),
+                        __builtin_amdgcn_readlane(pend_sd, q));
+            fresh = false;
+            overflow = true;  // continue in global mode below
+        }
+    }
+    if (!give_up) {
+        if (!overflow) {
+            run(PolishMode<false>{});
+            if (overflow) to_global();
+        }
+        if (overflow) {
+            overflow = false;
+            run(PolishMode<true>{});
+            give_up = overflow;  // outgrew 64
+        }
+    }
+
+    d2 wout;
+    if (give_up) {  // keep the (feasible) ADMM iterate; status stays what ADMM reported
+        wout[0] = fmin(fmax(z0, lo0), hi0);
+        wout[1] = fmin(fmax(z1, lo1), hi1);
+        if (inrow) *reinterpret_cast<d2*>(p.w + base + r0) = wout;
+        return;
+    }
+    wout[0] = act0 ? bnd0 : fmin(fmax(w0, lo0), hi0);
+    wout[1] = act1 ? bnd1 : fmin(fmax(w1, lo1), hi1);
+    if (inrow) *reinterpret_cast<d2*>(p.w + base + r0) = wout;
     if (lane == 0) {
         p.piters[inst] = it;
         p.status[inst] = (fin == 0) ? 0 : st_in;
-        p.overflow[inst] = 0;
     }
 }
 
@@ -564,6 +819,8 @@ struct RolloutParams {
     long xref_stride;
     const double* uref;
     long uref_stride;
+    const double* umin;  // [m]: u is clamped to the box after un-scaling (d*(b/d) may be 1 ulp off b)
+    const double* umax;
     double* x;   // [batch][N+1][n]
     double* ex;
     double* u;   // [batch][N][m]
@@ -588,10 +845,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_rollout(RolloutParams p) {
     double* v = e + n;
     // inputs: u, e_u
     for (int r = lane; r < nz; r += 64) {
-        const double ev = p.w[(size_t)inst * p.nzs + r] * p.dvec[r];
+        const double ur = p.uref[(size_t)inst * p.uref_stride + r];
+        const double uu = fmin(fmax(p.w[(size_t)inst * p.nzs + r] * p.dvec[r] + ur, p.umin[r % m]), p.umax[r % m]);
+        const double ev = uu - ur;
         v[r] = ev;
         p.eu[(size_t)inst * nz + r] = ev;
-        p.u[(size_t)inst * nz + r] = ev + p.uref[(size_t)inst * p.uref_stride + r];
+        p.u[(size_t)inst * nz + r] = uu;
     }
     const size_t xo = (size_t)inst * n * (N + 1);
     double ei = 0.0;

@@ -72,3 +72,29 @@ class Ranks:
 def aggregate_rate(units_per_rank: float, steps: int, elapsed_max: float, world: int) -> float:
     """Whole-job throughput: units all ranks processed / max-over-ranks time (weak scaling)."""
     return world * units_per_rank * steps / elapsed_max
+
+
+def host_cpu_share() -> int:
+    """CPUs this process may actually use: cgroup quota (cpu.max) if set, else the affinity mask.  On the GPU boxes
+    `nproc` shows the whole host while the container is limited to a share of it."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]) + 0.5)))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                        n = min(n, max(1, int(q / int(g.read()) + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)

@@ -156,7 +156,7 @@ def main():
         import c_oracle
         des = mo.design_shared(p, rho=opts.rho, sigma=opts.sigma)
         kw = dict(alpha=opts.alpha, eps_abs=opts.eps_abs, eps_rel=opts.eps_rel, max_iter=int(opts.max_iter),
-                  check_every=int(opts.check_every), polish=bool(opts.polish))
+                  check_every=int(opts.check_every), polish=bool(opts.polish), threads=pkg.sharding.host_cpu_share())
         c_oracle.step_batch(p, des, X0[:256], **kw)  # warm
         reps, t0, used = 0, time.perf_counter(), 1
         while True:
