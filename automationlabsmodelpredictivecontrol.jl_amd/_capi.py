@@ -8,7 +8,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libalmpc.so")
+# ALMPC_LIB overrides the library path (A/B builds of the same ABI); the default is the in-tree build
+LIB_PATH = os.environ.get("ALMPC_LIB") or os.path.join(_HERE, "lib", "libalmpc.so")
 
 ALMPC_OK = 0
 ERR_NAMES = {0: "ALMPC_OK", -1: "ALMPC_ERR_INVALID", -2: "ALMPC_ERR_NO_DEVICE", -3: "ALMPC_ERR_HIP",

@@ -107,7 +107,7 @@ void almpc_default_opts(almpc_opts* o) {
     o->alpha = 1.6;
     o->eps_abs = 1e-3;
     o->eps_rel = 1e-3;
-    o->max_iter = 50;
+    o->max_iter = 25;
     o->check_every = 25;
     o->polish = 1;
     o->polish_max_iter = 0;
@@ -303,7 +303,11 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
     HIP_TRY(h, launch_admm(h->nrb, h->ks, ap, grid, lds, st));
     if (timing) HIP_TRY(h, hipEventRecord(ev[1], st));
 
-    const double* wsrc = h->dZs;
+    RolloutParams rp;
+    rp.n = h->n; rp.m = h->m; rp.N = h->N; rp.batch = h->batch; rp.nzs = h->nzs; rp.A = h->dA; rp.B = h->dB;
+    rp.dvec = h->dD; rp.w = h->dZs; rp.x0 = h->dX0; rp.xref = h->dXref; rp.xref_stride = h->xref_stride;
+    rp.uref = h->dUref; rp.uref_stride = h->uref_stride; rp.umin = h->dUmin; rp.umax = h->dUmax; rp.x = h->dX; rp.ex = h->dEx; rp.u = h->dU; rp.eu = h->dEu;
+    bool fused = false;
     if (o.polish) {
         PolishParams pp;
         pp.nz = h->nz; pp.m = h->m; pp.batch = h->batch; pp.nzs = h->nzs; pp.G = h->dG; pp.dvec = h->dD;
@@ -311,21 +315,32 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         pp.zs = h->dZs; pp.ys = h->dYs; pp.v0 = h->dV0; pp.w = h->dW; pp.status = h->dStatus; pp.piters = h->dPiters;
         pp.sglobal = h->dSglobal;
         pp.max_iter = o.polish_max_iter > 0 ? o.polish_max_iter : 20 * h->nz + 50;
+        // rollout fused into the tail of the polish when its trajectory buffer fits the wave's LDS slot
+        int g = 1;
+        while (2 * g * h->n <= 64) g *= 2;
+        const int C = h->n + h->m;
+        int cpl = (C + g - 1) / g;
+        cpl = cpl <= 1 ? 1 : (cpl <= 2 ? 2 : (cpl <= 4 ? 4 : 8));
+        fused = (size_t)(h->N + 1) * C <= 32 * 32 && (C + g - 1) / g <= 8;
+        pp.fuse_rollout = fused ? 1 : 0; pp.roll_g = g; pp.roll_cpl = cpl; pp.roll = rp;
         const size_t l = (size_t)POLISH_WAVES * POLISH_LDS_PER_WAVE * sizeof(double);
         hipLaunchKernelGGL(k_polish, dim3((h->batch + POLISH_WAVES - 1) / POLISH_WAVES), dim3(64 * POLISH_WAVES), l, st, pp);
         HIP_TRY(h, hipGetLastError());
-        wsrc = h->dW;
+        rp.w = h->dW;
     }
     if (timing) HIP_TRY(h, hipEventRecord(ev[2], st));
 
-    RolloutParams rp;
-    rp.n = h->n; rp.m = h->m; rp.N = h->N; rp.batch = h->batch; rp.nzs = h->nzs; rp.A = h->dA; rp.B = h->dB;
-    rp.dvec = h->dD; rp.w = wsrc; rp.x0 = h->dX0; rp.xref = h->dXref; rp.xref_stride = h->xref_stride;
-    rp.uref = h->dUref; rp.uref_stride = h->uref_stride; rp.umin = h->dUmin; rp.umax = h->dUmax; rp.x = h->dX; rp.ex = h->dEx; rp.u = h->dU; rp.eu = h->dEu;
-    {
-        constexpr int WAVES = 4;
-        const size_t l = ((size_t)h->n * h->n + (size_t)h->n * h->m + (size_t)WAVES * (h->n + h->nz)) * sizeof(double);
-        hipLaunchKernelGGL((k_rollout<WAVES>), dim3((h->batch + WAVES - 1) / WAVES), dim3(64 * WAVES), l, st, rp);
+    if (!fused) {
+        const size_t per_wave = (size_t)h->n * (h->N + 1) + h->nz, shared = (size_t)h->n * h->n + (size_t)h->n * h->m;
+        if ((shared + 4 * per_wave) * sizeof(double) <= 60 * 1024) {
+            const size_t l = (shared + 4 * per_wave) * sizeof(double);
+            hipLaunchKernelGGL((k_rollout<4>), dim3((h->batch + 3) / 4), dim3(256), l, st, rp);
+        } else {  // long horizons with many states: one instance per workgroup, LDS beyond the 64 KiB default
+            const size_t l = (shared + per_wave) * sizeof(double);
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout<1>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)l));
+            hipLaunchKernelGGL((k_rollout<1>), dim3(h->batch), dim3(64), l, st, rp);
+        }
         HIP_TRY(h, hipGetLastError());
     }
     if (timing) {
@@ -440,5 +455,23 @@ int almpc_get_timing(almpc_handle* h, float* ms_admm, float* ms_polish, float* m
     if (ms_total) *ms_total = t;
     return ALMPC_OK;
 }
+
+#ifdef ALMPC_STAMPS
+// diagnostic build: allocate / fetch the stamp buffer ([waves][16] int64)
+int almpc_dbg_stamps_enable(almpc_handle* h, int waves) {
+    long long* d = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&d), (size_t)waves * 16 * sizeof(long long)) != hipSuccess) return -3;
+    (void)hipMemset(d, 0, (size_t)waves * 16 * sizeof(long long));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(almpc::g_stamps), &d, sizeof(d));
+    return 0;
+}
+int almpc_dbg_stamps_fetch(almpc_handle* h, long long* out, int waves) {
+    long long* d = nullptr;
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(&d, HIP_SYMBOL(almpc::g_stamps), sizeof(d));
+    if (!d) return -1;
+    return hipMemcpy(out, d, (size_t)waves * 16 * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+}
+#endif
 
 }  // extern "C"

@@ -21,7 +21,22 @@
 
 namespace almpc {
 
+// Diagnostic build only (-DALMPC_STAMPS): lane 0 of every wave records the shader clock at phase boundaries into a
+// debug buffer of its own (never read by kernel code).  The shipped library has no stamps.
+#ifdef ALMPC_STAMPS
+__device__ long long* g_stamps = nullptr;  // [waves][16]
+#define ALMPC_STAMP(WAVE_ID, SLOT)                                                                     \
+    do {                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        if (g_stamps && (threadIdx.x & 63) == 0) g_stamps[(size_t)(WAVE_ID) * 16 + (SLOT)] = __builtin_readcyclecounter(); \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+    } while (0)
+#else
+#define ALMPC_STAMP(WAVE_ID, SLOT) do { } while (0)
+#endif
+
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2v __attribute__((ext_vector_type(2)));
 
 constexpr int TILE = 16;  // instances per workgroup tile = MFMA N dimension
 
@@ -100,12 +115,33 @@ __global__ __launch_bounds__(64 * NRB) void k_admm(AdmmParams p) {
     const int inst = blockIdx.x * TILE + col;
     const bool valid = inst < p.batch;
     const int instc = valid ? inst : p.batch - 1;  // clamp: pad columns recompute the last instance, never stored
+    ALMPC_STAMP(blockIdx.x * NRB + wv, 0);
 
     // ---- shared KKT inverse -> registers (A fragments), coalesced 512 B per wave-instruction
     double a[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) a[ks] = p.MinvFrag[((size_t)(wv * KS + ks)) * 64 + lane];
 
+    // ---- every other global load of the prologue is requested up front as well (one exposed latency, not five):
+    // F' fragments, the row constants, and x0 / x_ref for e0
+    constexpr int KSF_MAX = 16;  // n <= 64
+    double af[KSF_MAX];
+#pragma unroll
+    for (int ks = 0; ks < KSF_MAX; ++ks)
+        af[ks] = (ks < p.ksf) ? p.FFrag[((size_t)(wv * p.ksf + ks)) * 64 + lane] : 0.0;
+    int row[4];
+    double dv[4], dinv[4], lo[4], hi[4], fs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        row[i] = wv * 16 + q + 4 * i;
+        const bool in = row[i] < p.nz;
+        const int r = in ? row[i] : 0;
+        dv[i] = in ? p.dvec[r] : 1.0;
+        const double ur = p.uref[(size_t)instc * p.uref_stride + r];
+        lo[i] = p.umin[r % p.m] - ur;   // scaled below
+        hi[i] = p.umax[r % p.m] - ur;
+        fs[i] = in ? p.fS[(size_t)instc * p.fS_stride + r] : 0.0;
+    }
     // ---- e0 = x0 - x_ref[:,1] into LDS as B operand [k][16]
     const int kpf = 4 * p.ksf;
     for (int t = threadIdx.x; t < kpf * TILE; t += blockDim.x) {
@@ -119,26 +155,18 @@ __global__ __launch_bounds__(64 * NRB) void k_admm(AdmmParams p) {
     __syncthreads();
 
     // ---- per-row constants and f' = F' e0 + fS
-    int row[4];
-    double dv[4], dinv[4], lo[4], hi[4], fs[4];
     {
         d4 acc = {0.0, 0.0, 0.0, 0.0};
-        for (int ks = 0; ks < p.ksf; ++ks) {
-            double af = p.FFrag[((size_t)(wv * p.ksf + ks)) * 64 + lane];
-            double b = e0s[(4 * ks + q) * TILE + col];
-            acc = mfma_f64(af, b, acc);
-        }
+#pragma unroll
+        for (int ks = 0; ks < KSF_MAX; ++ks)
+            if (ks < p.ksf) acc = mfma_f64(af[ks], e0s[(4 * ks + q) * TILE + col], acc);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            row[i] = wv * 16 + q + 4 * i;
             const bool in = row[i] < p.nz;
-            const int r = in ? row[i] : 0;
-            dv[i] = in ? p.dvec[r] : 1.0;
             dinv[i] = 1.0 / dv[i];
-            const double ur = p.uref[(size_t)instc * p.uref_stride + r];
-            lo[i] = in ? (p.umin[r % p.m] - ur) * dinv[i] : 0.0;
-            hi[i] = in ? (p.umax[r % p.m] - ur) * dinv[i] : 0.0;
-            fs[i] = in ? acc[i] + p.fS[(size_t)instc * p.fS_stride + r] : 0.0;
+            lo[i] = in ? lo[i] * dinv[i] : 0.0;
+            hi[i] = in ? hi[i] * dinv[i] : 0.0;
+            fs[i] = in ? acc[i] + fs[i] : 0.0;
         }
     }
 
@@ -186,6 +214,7 @@ __global__ __launch_bounds__(64 * NRB) void k_admm(AdmmParams p) {
     for (int w2 = 0; w2 < NRB; ++w2) nf = fmax(nf, red[(w2 * 8 + 7) * TILE + col]);
     __syncthreads();
 
+    ALMPC_STAMP(blockIdx.x * NRB + wv, 1);
     bool active = true;
     int my_iters = p.max_iter, my_status = 1;
     double* cur = rhs0;
@@ -251,40 +280,70 @@ __global__ __launch_bounds__(64 * NRB) void k_admm(AdmmParams p) {
         double* t = cur; cur = nxt; nxt = t;
     }
 
-    // ---- results of the ADMM stage (scaled coordinates)
-    if (valid) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const size_t o = (size_t)inst * p.nzs + row[i];
-            p.xs[o] = x[i];
-            p.zs[o] = z[i];
-            p.ys[o] = y[i];
-        }
-        if (wv == 0 && q == 0) {
-            p.iters[inst] = my_iters;
-            p.status[inst] = my_status;
-            p.piters[inst] = 0;
-            p.overflow[inst] = 0;
-        }
-    }
-
-    // ---- v0 = -H'^-1 f' for the polish: same tile product with the G fragments
+    ALMPC_STAMP(blockIdx.x * NRB + wv, 2);
+    // ---- v0 = -H'^-1 f' for the polish: same tile product with the G fragments (loads issued before the stores)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) a[ks] = p.GFrag[((size_t)(wv * KS + ks)) * 64 + lane];
+    if (valid && wv == 0 && q == 0) {
+        p.iters[inst] = my_iters;
+        p.status[inst] = my_status;
+        p.piters[inst] = 0;
+        p.overflow[inst] = 0;
+    }
     __syncthreads();  // everyone is done reading cur/nxt
 #pragma unroll
-    for (int i = 0; i < 4; ++i) nxt[row[i] * TILE + col] = -fs[i];
+    for (int i = 0; i < 4; ++i) rhs1[row[i] * TILE + col] = -fs[i];
     __syncthreads();
-    const d4 v04 = tile_matmul<KS>(a, nxt, q, col);
-    if (valid) {
+    const d4 v04 = tile_matmul<KS>(a, rhs1, q, col);
+    ALMPC_STAMP(blockIdx.x * NRB + wv, 3);
+
+    // ---- results (scaled coordinates) to HBM: transpose each [row][instance] register tile through LDS so that every
+    // instance vector (nzs contiguous doubles) leaves as full 16-byte-per-lane coalesced stores
+    constexpr int TS = RP + 2;  // staging stride per instance: even (16-byte pairs) and conflict-free for the scatter
+    static_assert(TILE * TS <= 2 * RP * TILE, "staging tile must fit the two rhs buffers");
+    double* stage = smem;
+    auto flush = [&](const double (&v)[4], double* dst) {
+        __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) p.v0[(size_t)inst * p.nzs + row[i]] = v04[i];
-    }
+        for (int i = 0; i < 4; ++i) stage[col * TS + row[i]] = v[i];
+        __syncthreads();
+        for (int e = 2 * threadIdx.x; e < TILE * RP; e += 2 * blockDim.x) {
+            const int ci = e / RP, r = e % RP;
+            const int ii = blockIdx.x * TILE + ci;
+            if (ii < p.batch)
+                *reinterpret_cast<d2v*>(dst + (size_t)ii * p.nzs + r) = *reinterpret_cast<const d2v*>(stage + ci * TS + r);
+        }
+    };
+    const double v0r[4] = {v04[0], v04[1], v04[2], v04[3]};
+    flush(x, p.xs);
+    flush(z, p.zs);
+    flush(y, p.ys);
+    flush(v0r, p.v0);
+    ALMPC_STAMP(blockIdx.x * NRB + wv, 4);
 }
 
 // ------------------------------------------------------------------------------------------------
 // polish: primal active-set finish with the shared inverse G = H'^-1 (oracle: polish_active_set)
 // ------------------------------------------------------------------------------------------------
+struct RolloutParams {
+    int n, m, N, batch, nzs;
+    const double* A;  // n*n column-major
+    const double* B;  // n*m column-major
+    const double* dvec;
+    const double* w;  // scaled solution [batch][nzs]
+    const double* x0;
+    const double* xref;  // [xref_stride*inst + n*k + i]
+    long xref_stride;
+    const double* uref;
+    long uref_stride;
+    const double* umin;  // [m]: u is clamped to the box after un-scaling (d*(b/d) may be 1 ulp off b)
+    const double* umax;
+    double* x;   // [batch][N+1][n]
+    double* ex;
+    double* u;   // [batch][N][m]
+    double* eu;
+};
+
 struct PolishParams {
     int nz, m, batch, nzs;
     const double* G;     // dense [nz][nzs], symmetric
@@ -301,6 +360,9 @@ struct PolishParams {
     int32_t* piters;
     double* sglobal;     // [batch][64*64] scratch for working sets beyond 32 rows
     int max_iter;
+    int fuse_rollout;    // 1: this kernel also produces u, e_u, x, e_x (roll.*), no separate k_rollout launch
+    int roll_g, roll_cpl; // rollout lane decomposition: roll_g lanes per state row, roll_cpl columns of [A B] per lane
+    RolloutParams roll;
 };
 
 __device__ __forceinline__ double readlane_d(double v, int l) {
@@ -375,6 +437,46 @@ struct PolishMode {
     static constexpr int PMASK = WL - 1;
 };
 
+// Rollout of one instance by one wave (fused tail of k_polish): Z[k] = [e_x[:,k]; e_u[:,k]] rows of length C = n+m in
+// LDS; lane (i = lane / G, g = lane % G) holds CPL consecutive coefficients of row i of [A B] in registers, so a step
+// is one short LDS read, CPL FMAs, a log2(G) butterfly and one LDS write.
+template <int CPL>
+__device__ __forceinline__ void rollout_steps(double* Z, int n, int m, int N, int G, int lane, const double* A,
+                                              const double* B) {
+    const int C = n + m;
+    const int i = lane / G, g = lane % G;
+    double coef[CPL];
+    int jc[CPL];
+#pragma unroll
+    for (int t = 0; t < CPL; ++t) {
+        const int j = g * CPL + t;
+        const bool ok = (i < n) && (j < C);
+        const int ic = i < n ? i : 0;
+        const double av = A[(size_t)(j < n ? j : 0) * n + ic], bv = B[(size_t)((j >= n && j < C) ? j - n : 0) * n + ic];
+        coef[t] = ok ? (j < n ? av : bv) : 0.0;
+        jc[t] = j < C ? j : C - 1;
+    }
+    for (int k = 0; k < N; ++k) {
+        const double* zk = Z + (size_t)k * C;
+        double zv[CPL];
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) zv[t] = zk[jc[t]];
+        double acc = 0.0;
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) acc += coef[t] * zv[t];
+        if (G == 4) {  // butterfly inside each quad on the DPP path
+            acc += dpp_d<0xB1, 0xF>(acc);  // quad_perm [1,0,3,2]
+            acc += dpp_d<0x4E, 0xF>(acc);  // quad_perm [2,3,0,1]
+        } else {
+            for (int o = 1; o < G; o <<= 1) acc += __shfl_xor(acc, o);
+        }
+        if (g == 0 && i < n) Z[(size_t)(k + 1) * C + i] = acc;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 constexpr int POLISH_WAVES = 4;
 // LDS per wave (doubles): Sinv 32x32 | row buffer 128 | two position buffers 64 | row-index buffer (64 ints)
 constexpr int POLISH_LDS_PER_WAVE = 32 * 32 + 128 + 64 + 64 + 32;
@@ -388,6 +490,7 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int inst = blockIdx.x * POLISH_WAVES + wv;
     if (inst >= p.batch) return;
+    ALMPC_STAMP(inst, 8);
     const int st_in = p.status[inst];
     const int nz = p.nz, nzs = p.nzs;
     const size_t base = (size_t)inst * nzs;
@@ -396,10 +499,7 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
     const bool in0 = r0 < nz, in1 = r1 < nz;
     const bool inrow = r0 < nzs;            // nzs is even: the pair (r0, r1) is inside the padded vector or not at all
     const int rc = inrow ? r0 : 0;          // clamped pair index for loads (lanes beyond the vector read pair 0)
-    if (st_in == 2) {  // non-finite instance: nothing to polish, hand the ADMM iterate on
-        if (inrow) *reinterpret_cast<d2*>(p.w + base + r0) = *reinterpret_cast<const d2*>(p.zs + base + r0);
-        return;
-    }
+    const bool skip = (st_in == 2);  // non-finite instance: nothing to polish, the ADMM iterate is handed on as is
 
     double* Sl = smem + (size_t)wv * POLISH_LDS_PER_WAVE;
     double* rowbuf = Sl + 32 * 32;     // [128] one row-distributed vector, for gathers by row index
@@ -434,6 +534,7 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
     int k = 0;               // |W|, wave-uniform
     bool overflow = false;   // the set outgrew the current mode
     wrow_s[lane] = 0;
+    ALMPC_STAMP(inst, 9);
 
     // Sinv is kept padded with the identity beyond the k x k block and position-distributed vectors are exactly
     // zero beyond position k, so every sweep below runs over chunk-rounded ranges with UNCONDITIONAL loads and
@@ -507,20 +608,25 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
     };
     // (q0, q1) = sum_{l<k} G[W_l, rows] * a_l, a given in LDS buffer ab (zero beyond k): the only O(nz k) part of an
     // update.  One 16-byte load per row and lane; row indices come from the LDS copy of wrow (zero beyond k: row 0
-    // is a valid address and its weight is zero).
+    // is a valid address and its weight is zero).  Split in a load half and an FMA half so that the first chunk's L2
+    // round trip can be started before the LDS work that produces the weights.
+    auto g_load = [&](int l0, d2 (&g)[CH]) {
+#pragma unroll
+        for (int t = 0; t < CH; ++t) g[t] = *reinterpret_cast<const d2*>(p.G + (size_t)wrow_s[l0 + t] * nzs + rc);
+    };
+    auto g_fma = [&](int l0, const double* ab, const d2 (&g)[CH], double& q0, double& q1) {
+        double av[CH];
+#pragma unroll
+        for (int t = 0; t < CH; ++t) av[t] = ab[l0 + t];
+#pragma unroll
+        for (int t = 0; t < CH; ++t) { q0 += g[t][0] * av[t]; q1 += g[t][1] * av[t]; }
+    };
     auto g_rows_times = [&](const double* ab, double& q0, double& q1) {
         q0 = 0.0; q1 = 0.0;
         for (int l0 = 0; l0 < k; l0 += CH) {
             d2 g[CH];
-            double av[CH];
-#pragma unroll
-            for (int t = 0; t < CH; ++t) {
-                const int jrow = wrow_s[l0 + t];
-                g[t] = *reinterpret_cast<const d2*>(p.G + (size_t)jrow * nzs + rc);
-                av[t] = ab[l0 + t];
-            }
-#pragma unroll
-            for (int t = 0; t < CH; ++t) { q0 += g[t][0] * av[t]; q1 += g[t][1] * av[t]; }
+            g_load(l0, g);
+            g_fma(l0, ab, g, q0, q1);
         }
     };
     auto put_rows = [&](double a0, double a1) {  // row-distributed pair -> rowbuf
@@ -549,6 +655,8 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
         const int pos = M::half ? (lane & 31) : lane;
         const bool lowhalf = M::half ? (lane < 32) : true;
         const d2 gj = *reinterpret_cast<const d2*>(p.G + (size_t)j * nzs + rc);  // row j = column j
+        d2 g[CH];
+        g_load(0, g);  // rows of positions 0..CH-1: in flight while Sinv c is formed
         put_rows(gj[0], gj[1]);
         const double cv = rowbuf[wrow];
         const double c = (pos < k) ? cv : 0.0;
@@ -557,8 +665,12 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
         put_pos(m, pbufa, c);
         const double u = s_matvec(m, pbufa);  // zero beyond k (identity padding)
         put_pos(m, pbufb, u);
-        double q0, q1;
-        g_rows_times(pbufb, q0, q1);
+        double q0 = 0.0, q1 = 0.0;
+        g_fma(0, pbufb, g, q0, q1);
+        for (int l0 = CH; l0 < k; l0 += CH) {
+            g_load(l0, g);
+            g_fma(l0, pbufb, g, q0, q1);
+        }
         const double sc = gjj - wave_sum(lowhalf ? c * u : 0.0);
         const double isc = 1.0 / sc;
         const double mu = (tj - bval) * isc;
@@ -702,7 +814,7 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
     const int s1 = (in1 && y1 < 0.0 && w1 <= lo1) ? -1 : ((in1 && y1 > 0.0 && w1 >= hi1) ? 1 : 0);
     const unsigned long long m0 = __ballot(s0 != 0), m1 = __ballot(s1 != 0);
     const int k0 = __popcll(m0) + __popcll(m1);
-    bool give_up = k0 > 64;  // more than 64 bounds active: beyond the largest mode, keep the ADMM iterate
+    bool give_up = skip || k0 > 64;  // more than 64 bounds active: beyond the largest mode, keep the ADMM iterate
     if (!give_up && k0 > 0) {
         using M = PolishMode<false>;
         const M m{};
@@ -775,6 +887,7 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
             overflow = true;  // continue in global mode below
         }
     }
+    ALMPC_STAMP(inst, 10);
     if (!give_up) {
         if (!overflow) {
             run(PolishMode<false>{});
@@ -787,19 +900,61 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
         }
     }
 
+    ALMPC_STAMP(inst, 11);
     d2 wout;
     if (give_up) {  // keep the (feasible) ADMM iterate; status stays what ADMM reported
-        wout[0] = fmin(fmax(z0, lo0), hi0);
-        wout[1] = fmin(fmax(z1, lo1), hi1);
+        wout[0] = skip ? z0 : fmin(fmax(z0, lo0), hi0);
+        wout[1] = skip ? z1 : fmin(fmax(z1, lo1), hi1);
+    } else {
+        wout[0] = act0 ? bnd0 : fmin(fmax(w0, lo0), hi0);
+        wout[1] = act1 ? bnd1 : fmin(fmax(w1, lo1), hi1);
+        if (lane == 0) {
+            p.piters[inst] = it;
+            p.status[inst] = (fin == 0) ? 0 : st_in;
+        }
+    }
+    if (!p.fuse_rollout) {
         if (inrow) *reinterpret_cast<d2*>(p.w + base + r0) = wout;
         return;
     }
-    wout[0] = act0 ? bnd0 : fmin(fmax(w0, lo0), hi0);
-    wout[1] = act1 ? bnd1 : fmin(fmax(w1, lo1), hi1);
-    if (inrow) *reinterpret_cast<d2*>(p.w + base + r0) = wout;
-    if (lane == 0) {
-        p.piters[inst] = it;
-        p.status[inst] = (fin == 0) ? 0 : st_in;
+    // ---- fused rollout: outputs of calculate! (src/main/computation_mpc.jl:50-53) for this instance
+    {
+        const RolloutParams& rp = p.roll;
+        const int n = rp.n, m = rp.m, N = rp.N, C = n + m;
+        double* Z = Sl;  // (N+1) x C trajectory buffer over the (now free) Sinv area; the host checks that it fits
+        const d2 dvp = *reinterpret_cast<const d2*>(p.dvec + rc);
+        if (in0) {
+            const double ur = rp.uref[(size_t)inst * rp.uref_stride + r0];
+            const double uu = fmin(fmax(wout[0] * dvp[0] + ur, rp.umin[r0 % m]), rp.umax[r0 % m]);
+            rp.u[(size_t)inst * nz + r0] = uu;
+            rp.eu[(size_t)inst * nz + r0] = uu - ur;
+            Z[(size_t)(r0 / m) * C + n + r0 % m] = uu - ur;
+        }
+        if (in1) {
+            const double ur = rp.uref[(size_t)inst * rp.uref_stride + r1];
+            const double uu = fmin(fmax(wout[1] * dvp[1] + ur, rp.umin[r1 % m]), rp.umax[r1 % m]);
+            rp.u[(size_t)inst * nz + r1] = uu;
+            rp.eu[(size_t)inst * nz + r1] = uu - ur;
+            Z[(size_t)(r1 / m) * C + n + r1 % m] = uu - ur;
+        }
+        for (int i = lane; i < n; i += 64) Z[i] = rp.x0[(size_t)inst * n + i] - rp.xref[(size_t)inst * rp.xref_stride + i];
+        wave_fence_lds();
+        ALMPC_STAMP(inst, 12);
+        switch (p.roll_cpl) {
+            case 1: rollout_steps<1>(Z, n, m, N, p.roll_g, lane, rp.A, rp.B); break;
+            case 2: rollout_steps<2>(Z, n, m, N, p.roll_g, lane, rp.A, rp.B); break;
+            case 4: rollout_steps<4>(Z, n, m, N, p.roll_g, lane, rp.A, rp.B); break;
+            default: rollout_steps<8>(Z, n, m, N, p.roll_g, lane, rp.A, rp.B); break;
+        }
+        ALMPC_STAMP(inst, 13);
+        const int nx = n * (N + 1);
+        const size_t xo = (size_t)inst * nx;
+        for (int t = lane; t < nx; t += 64) {
+            const double ev = Z[(size_t)(t / n) * C + t % n];
+            rp.ex[xo + t] = ev;
+            rp.x[xo + t] = (t < n) ? rp.x0[(size_t)inst * n + t] : ev + rp.xref[(size_t)inst * rp.xref_stride + t];
+        }
+        ALMPC_STAMP(inst, 14);
     }
 }
 
@@ -808,42 +963,26 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
 //   e_u = reshape(d .* w), u = e_u + u_ref, e_x[:,1] = x0 - x_ref[:,1], e_x[:,k+1] = A e_x[:,k] + B e_u[:,k],
 //   x = e_x + x_ref.   One wave per instance, lane i < n owns state row i.
 // ------------------------------------------------------------------------------------------------
-struct RolloutParams {
-    int n, m, N, batch, nzs;
-    const double* A;  // n*n column-major
-    const double* B;  // n*m column-major
-    const double* dvec;
-    const double* w;  // scaled solution [batch][nzs]
-    const double* x0;
-    const double* xref;  // [xref_stride*inst + n*k + i]
-    long xref_stride;
-    const double* uref;
-    long uref_stride;
-    const double* umin;  // [m]: u is clamped to the box after un-scaling (d*(b/d) may be 1 ulp off b)
-    const double* umax;
-    double* x;   // [batch][N+1][n]
-    double* ex;
-    double* u;   // [batch][N][m]
-    double* eu;
-};
 
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_rollout(RolloutParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int n = p.n, m = p.m, N = p.N;
+    const int nz = m * N, nx = n * (N + 1);
     double* As = smem;                 // [n][n]  As[j*n + i] = A[i][j] (column-major as given)
     double* Bs = As + n * n;           // [m][n]
-    double* ebuf = Bs + n * m;         // per wave: e (n) + v (m*N)
+    double* wbuf = Bs + n * m;         // per wave: e_x trajectory (nx) + e_u (nz)
+    ALMPC_STAMP(blockIdx.x * WAVES + (threadIdx.x >> 6), 4);
     for (int t = threadIdx.x; t < n * n; t += blockDim.x) As[t] = p.A[t];
     for (int t = threadIdx.x; t < n * m; t += blockDim.x) Bs[t] = p.B[t];
     __syncthreads();
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int inst = blockIdx.x * WAVES + wv;
     if (inst >= p.batch) return;
-    const int nz = m * N;
-    double* e = ebuf + (size_t)wv * (n + nz);
-    double* v = e + n;
-    // inputs: u, e_u
+    ALMPC_STAMP(inst, 0);
+    double* e = wbuf + (size_t)wv * (nx + nz);
+    double* v = e + nx;
+    // inputs: u, e_u (contiguous per instance: coalesced)
     for (int r = lane; r < nz; r += 64) {
         const double ur = p.uref[(size_t)inst * p.uref_stride + r];
         const double uu = fmin(fmax(p.w[(size_t)inst * p.nzs + r] * p.dvec[r] + ur, p.umin[r % m]), p.umax[r % m]);
@@ -852,29 +991,50 @@ __global__ __launch_bounds__(64 * WAVES) void k_rollout(RolloutParams p) {
         p.eu[(size_t)inst * nz + r] = ev;
         p.u[(size_t)inst * nz + r] = uu;
     }
-    const size_t xo = (size_t)inst * n * (N + 1);
-    double ei = 0.0;
-    if (lane < n) {
-        ei = p.x0[(size_t)inst * n + lane] - p.xref[(size_t)inst * p.xref_stride + lane];
-        e[lane] = ei;
-        p.ex[xo + lane] = ei;
-        p.x[xo + lane] = p.x0[(size_t)inst * n + lane];
-    }
-    wave_lds_sync();
+    if (lane < n) e[lane] = p.x0[(size_t)inst * n + lane] - p.xref[(size_t)inst * p.xref_stride + lane];
+    wave_fence_lds();
+    ALMPC_STAMP(inst, 1);
+    // recursion e+ = A e + B v_k into the LDS trajectory; coefficient and vector reads go out in groups of four so
+    // that their LDS round trips overlap (out-of-range columns: index clamped, coefficient forced to zero)
+    const int li = lane < n ? lane : 0;
     for (int k = 0; k < N; ++k) {
+        const double* ek = e + (size_t)k * n;
+        const double* vk = v + (size_t)k * m;
         double acc = 0.0;
-        if (lane < n) {
-            for (int j = 0; j < n; ++j) acc += As[j * n + lane] * e[j];
-            for (int j = 0; j < m; ++j) acc += Bs[j * n + lane] * v[k * m + j];
+        for (int j0 = 0; j0 < n; j0 += 4) {
+            double a[4], x[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int j = (j0 + t < n) ? j0 + t : n - 1;
+                a[t] = As[j * n + li];
+                x[t] = ek[j];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc += ((j0 + t < n) ? a[t] : 0.0) * x[t];
         }
-        wave_lds_sync();
-        if (lane < n) {
-            e[lane] = acc;
-            p.ex[xo + (size_t)(k + 1) * n + lane] = acc;
-            p.x[xo + (size_t)(k + 1) * n + lane] = acc + p.xref[(size_t)inst * p.xref_stride + (size_t)(k + 1) * n + lane];
+        for (int j0 = 0; j0 < m; j0 += 4) {
+            double a[4], x[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int j = (j0 + t < m) ? j0 + t : m - 1;
+                a[t] = Bs[j * n + li];
+                x[t] = vk[j];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc += ((j0 + t < m) ? a[t] : 0.0) * x[t];
         }
-        wave_lds_sync();
+        if (lane < n) e[(size_t)(k + 1) * n + lane] = acc;
+        wave_fence_lds();
     }
+    ALMPC_STAMP(inst, 2);
+    // outputs: e_x and x = e_x + x_ref, contiguous per instance (x[:,1] is x0 itself)
+    const size_t xo = (size_t)inst * nx;
+    for (int t = lane; t < nx; t += 64) {
+        const double ev = e[t];
+        p.ex[xo + t] = ev;
+        p.x[xo + t] = (t < n) ? p.x0[(size_t)inst * n + t] : ev + p.xref[(size_t)inst * p.xref_stride + t];
+    }
+    ALMPC_STAMP(inst, 3);
 }
 
 }  // namespace almpc

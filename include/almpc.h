@@ -64,8 +64,8 @@ typedef enum almpc_solve_status {
  * OSQP.Optimizer without attributes, src/sub/solver_selection.jl:94-95, i.e. OSQP defaults:
  * rho 0.1, sigma 1e-6, alpha 1.6, eps_abs = eps_rel = 1e-3, check_termination 25, max_iter 4000,
  * polish off).  Defaults here differ in two documented places: `polish` is ON (it is what brings
- * u* within 1e-5 of the exact optimum) and `max_iter` is 50 (ADMM only has to identify the active
- * set for the polish).  almpc_default_opts fills the defaults.
+ * u* within 1e-5 of the exact optimum) and `max_iter` is 25, one check interval (ADMM only has to
+ * identify the active set for the polish).  almpc_default_opts fills the defaults.
  */
 typedef struct almpc_opts {
     double rho;

@@ -53,7 +53,7 @@ def _d(a):
     return a.ctypes.data_as(_dp)
 
 
-def step_batch(p, des, X0, alpha=1.6, eps_abs=1e-3, eps_rel=1e-3, max_iter=50, check_every=25, polish=True,
+def step_batch(p, des, X0, alpha=1.6, eps_abs=1e-3, eps_rel=1e-3, max_iter=25, check_every=25, polish=True,
                polish_max_iter=0, threads=0):
     """One MPC step for every row of X0 ([batch][n]) with the C restatement.  `p` is an
     mpc_oracle.MPCProblem (shared references: column 0 of x_ref/u_ref is NOT assumed constant, the

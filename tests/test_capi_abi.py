@@ -37,7 +37,7 @@ def test_library_has_gfx950_code_object(capi):
 def test_default_opts_are_osqp_defaults_plus_documented_changes(capi):
     o = capi.default_opts()
     assert (o.rho, o.sigma, o.alpha, o.eps_abs, o.eps_rel, o.check_every) == (0.1, 1e-6, 1.6, 1e-3, 1e-3, 25)
-    assert o.polish == 1 and o.max_iter == 50 and o.warm_start == 0
+    assert o.polish == 1 and o.max_iter == 25 and o.warm_start == 0
     with pytest.raises(TypeError):
         capi.default_opts(no_such_option=1)
 

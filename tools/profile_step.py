@@ -15,7 +15,7 @@ s = capi.Solver(12, 4, 30, B, timing=True)
 s.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max)
 s.set_reference(p.x_ref, p.u_ref)
 s.update_initialization(X0)
-opts = capi.default_opts() if len(sys.argv) <= 3 else capi.default_opts(max_iter=int(sys.argv[3]))
+opts = capi.default_opts() if len(sys.argv) <= 3 else capi.default_opts(max_iter=int(sys.argv[3]), check_every=int(sys.argv[4]) if len(sys.argv) > 4 else 25)
 for _ in range(5):
     s.calculate(opts)
 s.timing_reset(steps)
