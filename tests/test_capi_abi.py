@@ -70,10 +70,16 @@ def test_create_rejects_bad_sizes(capi):
 
 
 def test_product_never_imports_oracle():
-    """The oracle is test infrastructure: nothing in the package may import or load it."""
+    """The oracle is test infrastructure: nothing in the package may import, include, link or load it
+    (doc comments may cite it)."""
+    import re
     pkg = os.path.join(ROOT, "automationlabsmodelpredictivecontrol.jl_amd")
+    bad = re.compile(r"^\s*(from|import)\s+(mpc_oracle|c_oracle)|#\s*include[^\n]*oracle|dlopen|libalmpc_oracle|CDLL\([^)]*oracle", re.M)
     for dirpath, _, files in os.walk(pkg):
         for fn in files:
             if fn.endswith((".py", ".h", ".hip", ".cpp")):
                 txt = open(os.path.join(dirpath, fn)).read()
-                assert "mpc_oracle" not in txt and "c_oracle" not in txt and "almpc_oracle" not in txt, fn
+                assert not bad.search(txt), fn
+    mk = open(os.path.join(ROOT, "Makefile")).read()
+    lib_rule = mk[mk.index("$(LIB):"):mk.index("$(ORACLE):")]
+    assert "oracle" not in lib_rule
