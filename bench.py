@@ -111,21 +111,44 @@ def main():
                    "rho": opts.rho, "eps": opts.eps_abs, "parallelism": f"instances sharded over {world} GPU(s), 16-instance tile per workgroup"},
     }
     if rank == 0:
-        # ---- roofline of the dominant kernel, from the HIP events recorded inside the timed region
+        # ---- rooflines from the HIP events recorded inside the timed region (one event set per step on the stream the
+        # kernels run on).  Two kernels per step: k_admm (FP64 MFMA bound) and k_polish (+ fused rollout; dependent
+        # chains per instance, its only hardware roofline is HBM).  `roofline` is the one that took more time.
         stage_ms = {k: tsum[k] / max(1, tsum["steps"]) for k in ("admm_ms", "polish_ms", "rollout_ms", "total_ms")}
         iters_total = int(res["iters"].astype(np.int64).sum())
-        # algorithmic flops of one k_admm launch: per instance and iteration one nz x nz product (2 nz^2) plus ~10 nz
+        traffic = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")) as f:
+                traffic = json.load(f)
+        except OSError:
+            pass
+        # k_admm, algorithmic flops per launch: per instance and iteration one nz x nz product (2 nz^2) plus ~10 nz of
         # vector work; once per instance the gradient (2 nz n) and v0 = -G f' (2 nz^2)
         flops = iters_total * (2 * NZ * NZ + 10 * NZ) + BATCH_PER_GPU * (2 * NZ * NX + 2 * NZ * NZ)
         admm_tflops = flops / (stage_ms["admm_ms"] * 1e-3) / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": "k_admm<8,30>", "achieved": admm_tflops, "peak": FP64_PEAK_TFLOPS,
-                           "unit": "TFLOP/s", "frac": admm_tflops / FP64_PEAK_TFLOPS, "traffic": None,
-                           "avg_kernel_ms": stage_ms["admm_ms"], "admm_iters_per_launch": iters_total,
-                           "note": "FP64 MFMA (v_mfma_f64_16x16x4_f64); peak = public-spec FP64 78.6 TFLOP/s"}
+        roof_admm = {"bound": "mfma", "kernel": "k_admm<8,30>", "achieved": admm_tflops, "peak": FP64_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": admm_tflops / FP64_PEAK_TFLOPS,
+                     "traffic": traffic.get("k_admm", {}).get("hbm_bytes_per_launch"),
+                     "avg_kernel_ms": stage_ms["admm_ms"], "admm_iters_per_launch": iters_total,
+                     "note": "FP64 MFMA v_mfma_f64_16x16x4_f64; peak = public-spec FP64 78.6 TFLOP/s (71-76 measured with "
+                             "tools/microbench/f64_pipes.hip); traffic = PMC bytes per launch from profiles/r1_hbm_traffic.json"}
+        # k_polish (+ rollout), algorithmic bytes per launch: z, y, v0 in (3 nz doubles), u, e_u, x, e_x out
+        pol_bytes = BATCH_PER_GPU * 8 * (3 * NZ + 2 * NZ + 2 * NX * (N_HORIZON + 1))
+        pol_ms = stage_ms["polish_ms"] + stage_ms["rollout_ms"]
+        pol_gbs = pol_bytes / (pol_ms * 1e-3) / 1e9
+        roof_polish = {"bound": "hbm", "kernel": "k_polish (active-set polish + fused rollout)", "achieved": pol_gbs,
+                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": pol_gbs / HBM_PEAK_GBS,
+                       "traffic": traffic.get("k_polish", {}).get("hbm_bytes_per_launch"), "avg_kernel_ms": pol_ms,
+                       "algorithmic_bytes_per_launch": pol_bytes,
+                       "note": "latency bound: one dependent active-set chain per instance (one wave each); HBM is the only "
+                               "hardware roofline it touches"}
+        out["roofline"] = roof_admm if stage_ms["admm_ms"] >= pol_ms else roof_polish
+        out["roofline_kernels"] = [roof_admm, roof_polish]
         hbm_gbs = BATCH_PER_GPU * ALG_BYTES_PER_INSTANCE_STEP / (stage_ms["total_ms"] * 1e-3) / 1e9
         out["hbm"] = {"algorithmic_bytes_per_instance_step": ALG_BYTES_PER_INSTANCE_STEP, "achieved_GBps": hbm_gbs,
                       "peak_GBps": HBM_PEAK_GBS, "frac": hbm_gbs / HBM_PEAK_GBS,
-                      "note": "whole step (all kernels); the shared-model path is FP64-compute bound, not HBM bound"}
+                      "note": "whole step (all kernels), SURVEY.md section 8d byte count; the shared-model path is FP64-compute / "
+                              "latency bound, not HBM bound"}
         out["stage_ms"] = stage_ms
         out["solver"] = {"status_counts": np.bincount(res["status"], minlength=3).tolist(),
                          "admm_iters_mean": float(res["iters"].mean()), "polish_iters_mean": float(res["polish_iters"].mean()),
@@ -165,12 +188,12 @@ def main():
             r = c_oracle.step_batch(p, des, X0, **kw)
             used = r["threads"]
             reps += 1
-            if time.perf_counter() - t0 > 10.0 or reps >= 200:
+            if time.perf_counter() - t0 > 12.0 or reps >= 100000:
                 break
         cpu_el = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": reps / cpu_el, "unit": "batch-steps/s (one step = 4096 instance QP solves)",
                                "cores": int(used), "kind": "port",
-                               "sample": f"{reps} passes over the same 4096 instances ({cpu_el:.1f} s wall), oracle/almpc_oracle.c "
+                               "sample": f"{reps} passes over the same 4096 instances of this run ({cpu_el:.1f} s wall), oracle/almpc_oracle.c "
                                          f"(gcc -O3 -march=native, OpenMP): same ADMM+polish+rollout as the HIP path",
                                "instance_steps_per_s": reps * BATCH_PER_GPU / cpu_el}
     solver.close()
