@@ -67,6 +67,8 @@ def load():
     L.almpc_device_results.argtypes = [_hp] + [ctypes.POINTER(ctypes.c_void_p)] * 4
     L.almpc_get_timing.argtypes = [_hp, _fp, _fp, _fp, _fp]
     L.almpc_timing_reset.argtypes = [_hp, ctypes.c_int]
+    L.almpc_debug_poison_lds.argtypes = [_hp]
+    L.almpc_debug_poison_lds.restype = ctypes.c_int
     L.almpc_timing_summary.argtypes = [_hp, ctypes.POINTER(ctypes.c_int)] + [_dp] * 4
     for name in ("almpc_create", "almpc_design_shared", "almpc_set_reference", "almpc_update_initialization",
                  "almpc_update_initialization_device", "almpc_calculate", "almpc_calculate_async", "almpc_synchronize",
@@ -193,6 +195,9 @@ class Solver:
         v = [ctypes.c_float() for _ in range(4)]
         self._check(self.L.almpc_get_timing(self.h, *[ctypes.byref(x) for x in v]))
         return dict(zip(("admm_ms", "polish_ms", "rollout_ms", "total_ms"), [x.value for x in v]))
+
+    def debug_poison_lds(self):
+        self._check(self.L.almpc_debug_poison_lds(self.h))
 
     def timing_reset(self, reserve_steps=0):
         self._check(self.L.almpc_timing_reset(self.h, int(reserve_steps)))

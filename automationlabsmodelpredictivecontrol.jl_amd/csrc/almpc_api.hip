@@ -456,6 +456,19 @@ int almpc_get_timing(almpc_handle* h, float* ms_admm, float* ms_polish, float* m
     return ALMPC_OK;
 }
 
+int almpc_debug_poison_lds(almpc_handle* h) {
+    if (!h) return ALMPC_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int bytes = 160 * 1024;
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_poison_lds), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    // one workgroup owns a whole CU's LDS; several waves of workgroups so that every CU is visited
+    hipLaunchKernelGGL(k_poison_lds, dim3(1024), dim3(1024), bytes, h->stream, 0x7ff8dead0000beefULL, bytes / 8,
+                       reinterpret_cast<unsigned long long*>(h->dSglobal));
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return ALMPC_OK;
+}
+
 #ifdef ALMPC_STAMPS
 // diagnostic build: allocate / fetch the stamp buffer ([waves][16] int64)
 int almpc_dbg_stamps_enable(almpc_handle* h, int waves) {

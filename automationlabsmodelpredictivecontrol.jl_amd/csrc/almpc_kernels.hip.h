@@ -534,6 +534,11 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
     int k = 0;               // |W|, wave-uniform
     bool overflow = false;   // the set outgrew the current mode
     wrow_s[lane] = 0;
+    {   // Sinv := identity.  ALWAYS (also when the initial set is empty): the sweeps rely on the padding being finite
+        const int pos = lane & 31, hf = lane >> 5;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) Sl[(2 * t + hf) * 32 + pos] = ((2 * t + hf) == pos) ? 1.0 : 0.0;
+    }
     ALMPC_STAMP(inst, 9);
 
     // Sinv is kept padded with the identity beyond the k x k block and position-distributed vectors are exactly
@@ -838,10 +843,7 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
         if (pos < k) wbnd = rowbuf[wrow];
         const double pend_bnd = (lane >= 32 && lane < k0) ? rowbuf[pend_row] : 0.0;
         if (lane < 32) wrow_s[lane] = (lane < k) ? wrow : 0;
-        // Sinv := identity, then K = G[W,W] into the leading k x k block (each half every other column)
-#pragma unroll
-        for (int t = 0; t < 16; ++t) Sl[(2 * t + hf) * 32 + pos] = ((2 * t + hf) == pos) ? 1.0 : 0.0;
-        wave_fence_lds();
+        // K = G[W,W] into the leading k x k block of the (identity-initialised) Sinv, each half every other column
         for (int l0 = 0; l0 < k; l0 += 16) {
             double gv[8];
 #pragma unroll
@@ -854,27 +856,46 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
             }
         }
         wave_fence_lds();
-        // Gauss-Jordan in place on the padded matrix: columns are independent once the pivot column is read
+        // Gauss-Jordan in place on the padded matrix.  Per pivot ALL reads (pivot, pivot column, pivot row, own
+        // elements) are issued before any write, so a pivot costs one LDS round trip plus the reciprocal; rows/columns
+        // beyond k are identity and stay so (their f or row element is zero).
+        const bool two = k > 16;  // second group of 16 columns in use
         for (int pv = 0; pv < k; ++pv) {
-            const double ip = 1.0 / Sl[pv * 32 + pv];
-            const double f = Sl[pv * 32 + pos] * ip;  // S[i][pv] / pivot
-            for (int c0 = 0; c0 < k; c0 += 16) {
-                double rowpc[8], mine[8];
+            const double piv = Sl[pv * 32 + pv];
+            const double fcol = Sl[pv * 32 + pos];  // S[i][pv]
+            double rowpc[16], mine[16];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int c = 2 * t + hf;
+                rowpc[t] = Sl[c * 32 + pv];   // S[pv][c]
+                mine[t] = Sl[c * 32 + pos];   // S[i][c]
+            }
+            if (two) {
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
-                    const int c = c0 + 2 * t + hf;
-                    rowpc[t] = Sl[c * 32 + pv];   // S[pv][c]
-                    mine[t] = Sl[c * 32 + pos];   // S[i][c]
-                }
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const int c = c0 + 2 * t + hf;
-                    double v;
-                    if (pos == pv) v = (c == pv) ? ip : rowpc[t] * ip;
-                    else v = (c == pv) ? -f : mine[t] - f * rowpc[t];
-                    Sl[c * 32 + pos] = v;
+                    const int c = 16 + 2 * t + hf;
+                    rowpc[8 + t] = Sl[c * 32 + pv];
+                    mine[8 + t] = Sl[c * 32 + pos];
                 }
             }
+            const double ip = 1.0 / piv;
+            const bool isp = pos == pv;
+            const double f = isp ? 0.0 : fcol * ip;  // row pv itself is rescaled below, not eliminated
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int c = 2 * t + hf;
+                const double v = mine[t] - f * rowpc[t];
+                Sl[c * 32 + pos] = isp ? rowpc[t] * ip : v;
+            }
+            if (two) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int c = 16 + 2 * t + hf;
+                    const double v = mine[8 + t] - f * rowpc[8 + t];
+                    Sl[c * 32 + pos] = isp ? rowpc[8 + t] * ip : v;
+                }
+            }
+            Sl[pv * 32 + pos] = isp ? ip : -f;  // column pv (after the sweep above, which left 0 there)
             wave_fence_lds();
         }
         recompute(m);
@@ -1035,6 +1056,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_rollout(RolloutParams p) {
         p.x[xo + t] = (t < n) ? p.x0[(size_t)inst * n + t] : ev + p.xref[(size_t)inst * p.xref_stride + t];
     }
     ALMPC_STAMP(inst, 3);
+}
+
+// Test hook: fill the LDS of every CU with NaN bit patterns so that a kernel that reads LDS it did not write shows up
+// as a wrong result instead of passing on stale finite values (tests/test_gpu_parity.py poisons before it solves).
+__global__ __launch_bounds__(1024) void k_poison_lds(unsigned long long pattern, int words, unsigned long long* sink) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    unsigned long long* w = reinterpret_cast<unsigned long long*>(smem);
+    for (int t = threadIdx.x; t < words; t += blockDim.x) w[t] = pattern;
+    __syncthreads();
+    if (threadIdx.x == 0 && w[words - 1] != pattern) sink[0] = w[0];  // keep the stores alive
 }
 
 }  // namespace almpc

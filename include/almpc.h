@@ -168,6 +168,12 @@ int almpc_timing_reset(almpc_handle* h, int reserve_steps);
 int almpc_timing_summary(almpc_handle* h, int* steps, double* ms_admm, double* ms_polish,
                          double* ms_rollout, double* ms_total);
 
+/*
+ * Test hook: overwrite the LDS of every compute unit with NaN bit patterns (a kernel that reads LDS it has not written
+ * then produces NaNs instead of passing on stale values).  Synchronous.  Not needed by callers.
+ */
+int almpc_debug_poison_lds(almpc_handle* h);
+
 #ifdef __cplusplus
 }
 #endif

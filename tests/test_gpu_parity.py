@@ -339,6 +339,26 @@ def test_full_size_batch_properties(capi, mo):
         assert np.abs(r["u"][i] - mo.solve_mpc_exact(p, X0[i])["u"]).max() <= U_TOL
 
 
+@pytest.mark.parametrize("max_iter", [1, 3, 25])
+def test_poisoned_lds_and_empty_initial_guess(capi, mo, max_iter):
+    """Every kernel must initialise the LDS it reads: the LDS of all CUs is filled with NaN patterns before each solve.
+    max_iter = 1 also forces the polish to start from an (almost) empty working set and add every active row itself
+    (the branch that once read uninitialised Sinv padding)."""
+    p = mo.quadrotor()
+    X0 = np.concatenate([mo.quadrotor_x0_batch(64, a, first_instance=40 * k) for k, a in enumerate((0.3, 1.0, 3.0, 6.0))])
+    s = make_solver(capi, p, len(X0))
+    s.update_initialization(X0)
+    opts = capi.default_opts(max_iter=max_iter, check_every=max_iter)
+    for _ in range(3):
+        s.debug_poison_lds()
+        s.calculate(opts)
+        r = s.get_results()
+        assert np.all(r["status"] == 0) and np.isfinite(r["u"]).all() and np.isfinite(r["x"]).all()
+    s.close()
+    for i in range(0, len(X0), 7):
+        assert np.abs(r["u"][i] - mo.solve_mpc_exact(p, X0[i])["u"]).max() <= U_TOL
+
+
 def test_repeatability(capi, mo):
     """Two launches on the same inputs give bitwise identical results (no atomics, fixed reduction order)."""
     p = mo.quadrotor()
