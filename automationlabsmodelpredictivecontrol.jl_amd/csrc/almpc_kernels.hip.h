@@ -31,8 +31,16 @@ __device__ long long* g_stamps = nullptr;  // [waves][16]
         if (g_stamps && (threadIdx.x & 63) == 0) g_stamps[(size_t)(WAVE_ID) * 16 + (SLOT)] = __builtin_readcyclecounter(); \
         __builtin_amdgcn_sched_barrier(0);                                                             \
     } while (0)
+#define ALMPC_ACC_DECL long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long acc_prev = 0; int acc_n = 0;
+#define ALMPC_ACC_START do { __builtin_amdgcn_sched_barrier(0); acc_prev = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define ALMPC_ACC(SLOT) do { __builtin_amdgcn_sched_barrier(0); const long long n_ = __builtin_readcyclecounter(); acc_t[SLOT] += n_ - acc_prev; acc_prev = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define ALMPC_ACC_FLUSH(WAVE_ID) do { if (g_stamps && (threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 8; ++i_) g_stamps[(size_t)(4096 + (WAVE_ID)) * 16 + i_] = acc_t[i_]; g_stamps[(size_t)(4096 + (WAVE_ID)) * 16 + 8] = acc_n; } } while (0)
 #else
 #define ALMPC_STAMP(WAVE_ID, SLOT) do { } while (0)
+#define ALMPC_ACC_DECL
+#define ALMPC_ACC_START do { } while (0)
+#define ALMPC_ACC(SLOT) do { } while (0)
+#define ALMPC_ACC_FLUSH(WAVE_ID) do { } while (0)
 #endif
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -533,6 +541,7 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
     double t0 = v00, t1 = v01;        // row-distributed: face minimiser v0 - G[:,W] lam
     int k = 0;               // |W|, wave-uniform
     bool overflow = false;   // the set outgrew the current mode
+    ALMPC_ACC_DECL
     wrow_s[lane] = 0;
     {   // Sinv := identity.  ALWAYS (also when the initial set is empty): the sweeps rely on the padding being finite
         const int pos = lane & 31, hf = lane >> 5;
@@ -659,6 +668,7 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
         double* S = sptr(m);
         const int pos = M::half ? (lane & 31) : lane;
         const bool lowhalf = M::half ? (lane < 32) : true;
+        ALMPC_ACC_START;
         const d2 gj = *reinterpret_cast<const d2*>(p.G + (size_t)j * nzs + rc);  // row j = column j
         d2 g[CH];
         g_load(0, g);  // rows of positions 0..CH-1: in flight while Sinv c is formed
@@ -667,8 +677,10 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
         const double c = (pos < k) ? cv : 0.0;
         const double gjj = rowbuf[j];
         const double tj = readlane_d((j & 1) ? t1 : t0, j >> 1);
+        ALMPC_ACC(0);
         put_pos(m, pbufa, c);
         const double u = s_matvec(m, pbufa);  // zero beyond k (identity padding)
+        ALMPC_ACC(1);
         put_pos(m, pbufb, u);
         double q0 = 0.0, q1 = 0.0;
         g_fma(0, pbufb, g, q0, q1);
@@ -676,12 +688,14 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
             g_load(l0, g);
             g_fma(l0, pbufb, g, q0, q1);
         }
+        ALMPC_ACC(2);
         const double sc = gjj - wave_sum(lowhalf ? c * u : 0.0);
         const double isc = 1.0 / sc;
         const double mu = (tj - bval) * isc;
         t0 -= mu * (gj[0] - q0);
         t1 -= mu * (gj[1] - q1);
         lam -= u * mu;
+        ALMPC_ACC(3);
         s_rank1(m, u, pbufb, isc);
         {   // border: new column k and new row k (u is zero beyond k, so the padding stays zero)
             const double bv = (pos == k) ? isc : -u * isc;
@@ -694,6 +708,10 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
         if (r1 == j) { act1 = true; bnd1 = bval; }
         k += 1;
         sync_s(m);
+        ALMPC_ACC(4);
+#ifdef ALMPC_STAMPS
+        acc_n += 1;
+#endif
     };
     // remove position rp (uniform)
     auto remove_pos = [&](auto m, int rp) {
@@ -748,6 +766,7 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
         const bool lowhalf = M::half ? (lane < 32) : true;
         while (it < max_iter) {
             ++it;
+            ALMPC_ACC_START;
             // ---- ratio test over the free rows: first bound hit on the way from w to the face minimiser t
             double rr = __builtin_inf();
             int rside = 0;
@@ -775,6 +794,7 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
                 const double bval = sd > 0 ? bh : bl;
                 if (r0 == jmin) w0 = bval;
                 if (r1 == jmin) w1 = bval;
+                ALMPC_ACC(5);
                 add_row(m, jmin, bval, sd);
                 fresh = false;
                 continue;
@@ -922,6 +942,7 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
     }
 
     ALMPC_STAMP(inst, 11);
+    ALMPC_ACC_FLUSH(inst);
     d2 wout;
     if (give_up) {  // keep the (feasible) ADMM iterate; status stays what ADMM reported
         wout[0] = skip ? z0 : fmin(fmax(z0, lo0), hi0);

@@ -11,12 +11,14 @@ X0 = bench.make_x0(mo, 0, B, None if amp == "mix" else float(amp))
 s = capi.Solver(12, 4, 30, B); s.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max); s.set_reference(p.x_ref, p.u_ref); s.update_initialization(X0)
 opts = capi.default_opts(max_iter=int(sys.argv[2]) if len(sys.argv) > 2 else 25, check_every=int(sys.argv[2]) if len(sys.argv) > 2 else 25)
 for _ in range(3): s.calculate(opts)
-L = s.L; W = B
+L = s.L; W = 2 * B
 L.almpc_dbg_stamps_enable(s.h, W)
 s.calculate(opts)
 out = np.zeros((W, 16), dtype=np.int64)
 L.almpc_dbg_stamps_fetch(s.h, out.ctypes.data_as(ctypes.c_void_p), W)
 pit = s.get_results(want=("polish_iters",))["polish_iters"]
+full = out
+out = full[:B]
 sl = [8, 9, 10, 11, 12, 13, 14]
 names = ["prologue(loads)", "initial set+GJ+recompute", "active-set loop", "w/u/eu + Z fill", "rollout steps", "x/ex out"]
 ok = out[:, 8] > 0
@@ -24,7 +26,7 @@ d = np.diff(out[ok][:, sl], axis=1)
 for i, nm in enumerate(names):
     v = d[:, i]
     print(f"{nm:28s} cycles: median {int(np.median(v)):7d}  p90 {int(np.percentile(v,90)):7d}  max {v.max():7d}   mean {v.mean():9.0f}")
-ok2 = out[:, 0] > 0
+ok2 = (out[:, 0] > 0) & (out[:, 4] > 0) & (np.arange(B) < B // 16 * 8)
 da = np.diff(out[ok2][:, [0, 1, 2, 3, 4]], axis=1)
 for i, nm in enumerate(["admm prologue", "admm loop", "admm v0 product", "admm result flush"]):
     v = da[:, i]
@@ -34,4 +36,10 @@ tot = out[ok][:, 14] - out[ok][:, 8]
 print("total per wave: median", int(np.median(tot)), "p90", int(np.percentile(tot, 90)), "max", tot.max(), " (2.4 GHz: max = %.1f us)" % (tot.max() / 2400.0))
 loop = d[:, 2]; its = pit[ok]
 print("loop cycles per polish iteration (instances with >= 5 its): median", int(np.median(loop[its >= 5] / its[its >= 5])))
+acc = full[4096:4096 + B]
+n = acc[:, 8]
+sel = n >= 8
+print("per-add phase cycles (instances with >= 8 adds in the loop), mean per add:")
+for i, nm in enumerate(["A loads+rowbuf+gather c", "B put c + Sinv matvec", "C put u + G rows fma", "D sum/div/t update", "E rank1+border+sync", "F ratio test"]):
+    print(f"   {nm:26s} {np.mean(acc[sel, i] / n[sel]):8.0f}")
 s.close()
