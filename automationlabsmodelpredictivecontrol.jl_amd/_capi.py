@@ -15,7 +15,7 @@ ALMPC_OK = 0
 ERR_NAMES = {0: "ALMPC_OK", -1: "ALMPC_ERR_INVALID", -2: "ALMPC_ERR_NO_DEVICE", -3: "ALMPC_ERR_HIP",
              -4: "ALMPC_ERR_UNSUPPORTED", -5: "ALMPC_ERR_NOT_DESIGNED", -6: "ALMPC_ERR_NUMERIC"}
 FLAG_TIMING = 0x1
-SOLVED, MAX_ITER, NON_FINITE = 0, 1, 2
+SOLVED, MAX_ITER, NON_FINITE, INFEASIBLE = 0, 1, 2, 3
 
 
 class AlmpcError(RuntimeError):
@@ -57,6 +57,8 @@ def load():
     L.almpc_last_error.restype = ctypes.c_char_p
     L.almpc_design_shared.argtypes = [_hp] + [_dp] * 10 + [ctypes.c_double, ctypes.c_double]
     L.almpc_set_reference.argtypes = [_hp, _dp, _dp, ctypes.c_int]
+    L.almpc_set_terminal_equality.argtypes = [_hp, ctypes.c_int]
+    L.almpc_set_terminal_equality.restype = ctypes.c_int
     L.almpc_update_initialization.argtypes = [_hp, _dp]
     L.almpc_update_initialization_device.argtypes = [_hp, ctypes.c_void_p]
     L.almpc_calculate.argtypes = [_hp, ctypes.POINTER(almpc_opts)]
@@ -125,8 +127,13 @@ class Solver:
 
     __del__ = close
 
-    def design_shared(self, A, B, Q, R, S=None, P=None, umin=None, umax=None, xmin=None, xmax=None, rho=0.1, sigma=1e-6):
+    def design_shared(self, A, B, Q, R, S=None, P=None, umin=None, umax=None, xmin=None, xmax=None, rho=0.1, sigma=1e-6,
+                      terminal="none"):
+        """xmin/xmax: state box (the reference's kw mpc_state_constraint); terminal: "none" | "equality"."""
         n, m = self.n, self.m
+        if terminal not in ("none", "equality"):
+            raise ValueError("terminal must be 'none' or 'equality'")
+        self._check(self.L.almpc_set_terminal_equality(self.h, 1 if terminal == "equality" else 0))
         A, B, Q, R = _colmajor(A, (n, n)), _colmajor(B, (n, m)), _colmajor(Q, (n, n)), _colmajor(R, (m, m))
         S = None if S is None else _colmajor(S, (m, m))
         P = None if P is None else _colmajor(P, (n, n))

@@ -179,10 +179,16 @@ def _model_predictive_control_design(system: ConstrainedLinearControlDiscreteSys
     if solver_name in ("osqp", "scip", "ipopt"):
         raise NotImplementedError(f"mpc_solver={solver_name!r} is the reference's CPU path; this build provides 'hip' (and 'auto' -> 'hip')")
     terminal = kws.get("mpc_terminal_ingredient", D["mpc_terminal_ingredient"])
-    if terminal in ("equality", "contractive"):
-        raise NotImplementedError(f"terminal ingredient {terminal!r} is not built yet (SURVEY.md section 8f rank 1)")
-    if "mpc_state_constraint" in kws:
-        raise NotImplementedError("mpc_state_constraint (state box) is not built yet (SURVEY.md section 8f rank 1)")
+    if terminal == "contractive":
+        raise NotImplementedError("terminal ingredient 'contractive' is a quadratic constraint (src/sub/design_mpc.jl:333-340), "
+                                  "not a QP row: the reference itself cannot pass it to OSQP")
+    if terminal == "neighborhood":  # the reference only warns and adds nothing (src/sub/design_mpc.jl:342-345)
+        import warnings
+        warnings.warn("neighborhood terminal state constraint is not yet implemented")
+    elif terminal not in ("none", "equality"):
+        terminal_constraint = "none"  # the reference's final `else`: no terminal constraint to add
+    # the state box exists only if the kw is PRESENT (its value is never read), bounds come from system.X (..linear.jl:62-70)
+    state_box = "mpc_state_constraint" in kws
     max_time = kws.get("mpc_max_time", D["mpc_max_time"])
     weights = _create_weights_coefficients(system, kws=kws)
     n, m = system.B.shape
@@ -196,7 +202,8 @@ def _model_predictive_control_design(system: ConstrainedLinearControlDiscreteSys
     # bounds as the reference reads them: low = last vertex, high = first vertex of the hyperrectangle
     # (..linear.jl:34-38); P = DARE at the (linear) system (src/sub/design_mpc.jl:327), computed in the library.
     solver.design_shared(system.A, system.B, weights.Q, weights.R, weights.S, None, system.U.low, system.U.high,
-                         rho=rho, sigma=sigma)
+                         xmin=system.X.low if state_box else None, xmax=system.X.high if state_box else None,
+                         rho=rho, sigma=sigma, terminal="equality" if terminal == "equality" else "none")
     solver.set_reference(x_ref, u_ref)
     P = solver.get_design()["P"]
     opts = _capi.default_opts(**sopt)
@@ -229,6 +236,8 @@ def calculate(C: ModelPredictiveControlController) -> None:
     mod.last_status, mod.last_iters, mod.last_polish_iters = r["status"], r["iters"], r["polish_iters"]
     if np.any(r["status"] == _capi.NON_FINITE):
         raise ArithmeticError("calculate!: non-finite values in at least one instance (no solution to read)")
+    if np.any(r["status"] == _capi.INFEASIBLE):  # the reference: JuMP.value throws when the solver has no primal
+        raise ArithmeticError("calculate!: infeasible problem in at least one instance (state box / terminal equality)")
     res = C.computation_results
     for k in ("x", "e_x", "u", "e_u"):
         getattr(res, k)[...] = r[k][0] if mod.batch == 1 else r[k]

@@ -6,6 +6,7 @@
 // No torch, no BLAS, no CPU solve path: every per-step computation runs in almpc_kernels.hip.h.
 #include "almpc_kernels.hip.h"
 #include "almpc_design.hip.h"
+#include "almpc_polish_gen.hip.h"
 #include "almpc_host_math.h"
 #include "../../include/almpc.h"
 
@@ -36,6 +37,10 @@ struct almpc_handle {
     double *dX = nullptr, *dEx = nullptr, *dU = nullptr, *dEu = nullptr;
     int32_t *dStatus = nullptr, *dIters = nullptr, *dPiters = nullptr, *dOverflow = nullptr;
     double* dSglobal = nullptr;  // polish scratch for working sets beyond 32 rows
+    // state rows (state box / terminal equality): constraint-space data for k_polish_gen
+    int terminal_eq = 0, has_box = 0, mc = 0, R = 0, Rs = 0, np_pairs = 0;
+    double *dGhat = nullptr, *dGnorm = nullptr, *dXmin = nullptr, *dXmax = nullptr;
+    int *dRowTraj = nullptr, *dRowEq = nullptr, *dRowXidx = nullptr, *dRowState = nullptr;
     // timing (ALMPC_FLAG_TIMING): one set of 4 events per step since the last almpc_timing_reset
     std::vector<hipEvent_t> ev;  // 4 per step
     size_t ev_used = 0;          // steps recorded
@@ -86,7 +91,8 @@ hipError_t launch_admm(int nrb, int ks, const AdmmParams& p, int grid, size_t ld
 void free_all(almpc_handle* h) {
     void* ptrs[] = {h->dMinvFrag, h->dGFrag, h->dHFrag, h->dFFrag, h->dG, h->dD, h->dUmin, h->dUmax, h->dA, h->dB,
                     h->dXref, h->dUref, h->dFS, h->dX0, h->dXs, h->dZs, h->dYs, h->dV0, h->dW, h->dX, h->dEx,
-                    h->dU, h->dEu, h->dStatus, h->dIters, h->dPiters, h->dOverflow, h->dSglobal};
+                    h->dU, h->dEu, h->dStatus, h->dIters, h->dPiters, h->dOverflow, h->dSglobal, h->dGhat, h->dGnorm, h->dXmin,
+                    h->dXmax, h->dRowTraj, h->dRowEq, h->dRowXidx, h->dRowState};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& e : h->ev)
@@ -174,12 +180,19 @@ void almpc_destroy(almpc_handle* h) {
     delete h;
 }
 
+int almpc_set_terminal_equality(almpc_handle* h, int on) {
+    if (!h) return ALMPC_ERR_INVALID;
+    h->terminal_eq = on ? 1 : 0;
+    h->designed = false;  // takes effect at the next design
+    return ALMPC_OK;
+}
+
 int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const double* Q, const double* R,
                         const double* S, const double* P, const double* umin, const double* umax,
                         const double* xmin, const double* xmax, double rho, double sigma) {
     if (!h) return ALMPC_ERR_INVALID;
     if (!A || !B || !Q || !R || !umin || !umax) return fail(h, ALMPC_ERR_INVALID, "design: null matrix pointer");
-    if (xmin || xmax) return fail(h, ALMPC_ERR_UNSUPPORTED, "design: state box (mpc_state_constraint) is not built yet");
+    if ((xmin == nullptr) != (xmax == nullptr)) return fail(h, ALMPC_ERR_INVALID, "design: give both xmin and xmax or neither");
     if (!(rho > 0.0) || !(sigma >= 0.0)) return fail(h, ALMPC_ERR_INVALID, "design: rho must be > 0 and sigma >= 0");
     HIP_TRY(h, hipSetDevice(h->device));
     const int n = h->n, m = h->m, N = h->N, nz = h->nz;
@@ -194,8 +207,55 @@ int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const
     h->hS = Sm;
     h->rho = rho; h->sigma = sigma;
 
+    // ---- state rows: the state box for stages 2..N+1 (stage 1 is x0 itself, checked per instance) and/or the terminal
+    // equality on stage N+1 (which then replaces the box rows of that stage)
+    h->has_box = xmin ? 1 : 0;
+    std::vector<int> rowsel, row_traj, row_eq, row_xidx, row_state;
+    if (h->has_box)
+        for (int i = 0; i < n; ++i)
+            if (!(xmin[i] <= xmax[i])) return fail(h, ALMPC_ERR_INVALID, "design: xmin > xmax");
+    for (int k = 0; k < N; ++k)
+        for (int i = 0; i < n; ++i) {
+            const bool is_eq = h->terminal_eq && k == N - 1;
+            if (!(h->has_box || is_eq)) continue;
+            rowsel.push_back(k * n + i);
+            row_traj.push_back((k + 1) * (n + m) + i);
+            row_eq.push_back(is_eq ? 1 : 0);
+            row_xidx.push_back((k + 1) * n + i);
+            row_state.push_back(i);
+        }
+    h->mc = (int)rowsel.size();
+    h->R = nz + h->mc;
+    h->np_pairs = (h->R + 127) / 128;
+    h->Rs = 128 * h->np_pairs;
+    for (void* q : {(void*)h->dGhat, (void*)h->dGnorm, (void*)h->dXmin, (void*)h->dXmax, (void*)h->dRowTraj, (void*)h->dRowEq,
+                    (void*)h->dRowXidx, (void*)h->dRowState})
+        if (q) (void)hipFree(q);
+    h->dGhat = h->dGnorm = h->dXmin = h->dXmax = nullptr;
+    h->dRowTraj = h->dRowEq = h->dRowXidx = h->dRowState = nullptr;
+    if (h->mc > 0) {
+        if (h->np_pairs > 4) return fail(h, ALMPC_ERR_UNSUPPORTED, "design: state rows need n*N + m*N <= 512");
+        if ((size_t)(N + 1) * (n + m) > 32 * 32) return fail(h, ALMPC_ERR_UNSUPPORTED, "design: state rows need (N+1)*(n+m) <= 1024");
+        HIP_TRY(h, dalloc(&h->dGhat, (size_t)h->R * h->Rs));
+        HIP_TRY(h, dalloc(&h->dGnorm, (size_t)h->Rs));
+        HIP_TRY(h, dalloc(&h->dXmin, (size_t)n)); HIP_TRY(h, dalloc(&h->dXmax, (size_t)n));
+        HIP_TRY(h, dalloc(&h->dRowTraj, (size_t)h->Rs)); HIP_TRY(h, dalloc(&h->dRowEq, (size_t)h->Rs));
+        HIP_TRY(h, dalloc(&h->dRowXidx, (size_t)h->Rs)); HIP_TRY(h, dalloc(&h->dRowState, (size_t)h->Rs));
+        auto up = [&](int* dst, const std::vector<int>& v, int fill) {
+            std::vector<int> full((size_t)h->Rs, fill);
+            for (size_t i = 0; i < v.size(); ++i) full[(size_t)nz + i] = v[i];
+            return hipMemcpy(dst, full.data(), full.size() * sizeof(int), hipMemcpyHostToDevice);
+        };
+        HIP_TRY(h, up(h->dRowTraj, row_traj, 0)); HIP_TRY(h, up(h->dRowEq, row_eq, 0));
+        HIP_TRY(h, up(h->dRowXidx, row_xidx, 0)); HIP_TRY(h, up(h->dRowState, row_state, 0));
+        std::vector<double> lo(n, -1e300), hi(n, 1e300);
+        if (h->has_box) { lo.assign(xmin, xmin + n); hi.assign(xmax, xmax + n); }
+        HIP_TRY(h, hipMemcpy(h->dXmin, lo.data(), n * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->dXmax, hi.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    }
     int rc = design_shared_device(h->stream, n, m, N, h->nzs, h->nrb, h->ks, h->ksf, Am, Bm, Qm, Rm, Sm, Pm, rho, sigma,
-                                  h->dMinvFrag, h->dGFrag, h->dHFrag, h->dFFrag, h->dG, h->dD, h->H, h->F, h->d, h->err);
+                                  h->dMinvFrag, h->dGFrag, h->dHFrag, h->dFFrag, h->dG, h->dD, h->H, h->F, h->d, h->err,
+                                  rowsel, h->Rs, h->dGhat, h->dGnorm);
     if (rc != ALMPC_OK) return rc;
     HIP_TRY(h, hipMemcpy(h->dUmin, umin, m * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->dUmax, umax, m * sizeof(double), hipMemcpyHostToDevice));
@@ -308,7 +368,35 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
     rp.dvec = h->dD; rp.w = h->dZs; rp.x0 = h->dX0; rp.xref = h->dXref; rp.xref_stride = h->xref_stride;
     rp.uref = h->dUref; rp.uref_stride = h->uref_stride; rp.umin = h->dUmin; rp.umax = h->dUmax; rp.x = h->dX; rp.ex = h->dEx; rp.u = h->dU; rp.eu = h->dEu;
     bool fused = false;
-    if (o.polish) {
+    if (h->mc > 0 && !o.polish)
+        return fail(h, ALMPC_ERR_UNSUPPORTED, "calculate: problems with state rows (state box / terminal equality) need opts.polish = 1");
+    int roll_g = 1;
+    while (2 * roll_g * h->n <= 64) roll_g *= 2;
+    const int roll_C = h->n + h->m;
+    int roll_cpl = (roll_C + roll_g - 1) / roll_g;
+    const bool roll_fits = (size_t)(h->N + 1) * roll_C <= 32 * 32 && roll_cpl <= 8;
+    roll_cpl = roll_cpl <= 1 ? 1 : (roll_cpl <= 2 ? 2 : (roll_cpl <= 4 ? 4 : 8));
+    if (h->mc > 0) {
+        if (!roll_fits) return fail(h, ALMPC_ERR_UNSUPPORTED, "calculate: state rows need the fused rollout (n + m <= 8 * lanes-per-row)");
+        PolishGenParams gp;
+        gp.nz = h->nz; gp.mc = h->mc; gp.R = h->R; gp.Rs = h->Rs; gp.m = h->m; gp.n = h->n; gp.N = h->N; gp.batch = h->batch; gp.nzs = h->nzs;
+        gp.Ghat = h->dGhat; gp.gnorm = h->dGnorm; gp.row_traj = h->dRowTraj; gp.row_eq = h->dRowEq; gp.row_xidx = h->dRowXidx;
+        gp.row_state = h->dRowState; gp.xmin = h->dXmin; gp.xmax = h->dXmax; gp.has_box = h->has_box;
+        gp.dvec = h->dD; gp.umin = h->dUmin; gp.umax = h->dUmax; gp.uref = h->dUref; gp.uref_stride = h->uref_stride;
+        gp.zs = h->dZs; gp.ys = h->dYs; gp.v0 = h->dV0; gp.status = h->dStatus; gp.piters = h->dPiters;
+        gp.max_iter = o.polish_max_iter > 0 ? o.polish_max_iter : 20 * h->R + 50;
+        gp.roll_g = roll_g; gp.roll_cpl = roll_cpl; gp.roll = rp;
+        const size_t l = (size_t)PGEN_WAVES * PGEN_LDS_PER_WAVE * sizeof(double);
+        const dim3 grid((h->batch + PGEN_WAVES - 1) / PGEN_WAVES), block(64 * PGEN_WAVES);
+        switch (h->np_pairs) {
+            case 1: hipLaunchKernelGGL((k_polish_gen<1>), grid, block, l, st, gp); break;
+            case 2: hipLaunchKernelGGL((k_polish_gen<2>), grid, block, l, st, gp); break;
+            case 3: hipLaunchKernelGGL((k_polish_gen<3>), grid, block, l, st, gp); break;
+            default: hipLaunchKernelGGL((k_polish_gen<4>), grid, block, l, st, gp); break;
+        }
+        HIP_TRY(h, hipGetLastError());
+        fused = true;
+    } else if (o.polish) {
         PolishParams pp;
         pp.nz = h->nz; pp.m = h->m; pp.batch = h->batch; pp.nzs = h->nzs; pp.G = h->dG; pp.dvec = h->dD;
         pp.umin = h->dUmin; pp.umax = h->dUmax; pp.uref = h->dUref; pp.uref_stride = h->uref_stride;
@@ -316,13 +404,8 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         pp.sglobal = h->dSglobal;
         pp.max_iter = o.polish_max_iter > 0 ? o.polish_max_iter : 20 * h->nz + 50;
         // rollout fused into the tail of the polish when its trajectory buffer fits the wave's LDS slot
-        int g = 1;
-        while (2 * g * h->n <= 64) g *= 2;
-        const int C = h->n + h->m;
-        int cpl = (C + g - 1) / g;
-        cpl = cpl <= 1 ? 1 : (cpl <= 2 ? 2 : (cpl <= 4 ? 4 : 8));
-        fused = (size_t)(h->N + 1) * C <= 32 * 32 && (C + g - 1) / g <= 8;
-        pp.fuse_rollout = fused ? 1 : 0; pp.roll_g = g; pp.roll_cpl = cpl; pp.roll = rp;
+        fused = roll_fits;
+        pp.fuse_rollout = fused ? 1 : 0; pp.roll_g = roll_g; pp.roll_cpl = roll_cpl; pp.roll = rp;
         const size_t l = (size_t)POLISH_WAVES * POLISH_LDS_PER_WAVE * sizeof(double);
         hipLaunchKernelGGL(k_polish, dim3((h->batch + POLISH_WAVES - 1) / POLISH_WAVES), dim3(64 * POLISH_WAVES), l, st, pp);
         HIP_TRY(h, hipGetLastError());

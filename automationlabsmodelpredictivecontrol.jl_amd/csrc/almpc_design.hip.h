@@ -255,6 +255,45 @@ __global__ __launch_bounds__(256) void k_pack_frags(const double* M, int rows, i
     }
 }
 
+// ---- constraint space for state rows (state box / terminal equality): Ghat = A G A',  A = [I; C'],  C' = Gamma[rows] D ----
+// Cold path: one thread per output element.
+__global__ __launch_bounds__(256) void k_build_cprime(int mc, int nz, int nzs, int gs, const int* rowsel, const double* Gam,
+                                                      const double* d, double* Cp) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < mc * nzs; t += gridDim.x * blockDim.x) {
+        const int r = t / nzs, c = t % nzs;
+        Cp[t] = (c < nz) ? Gam[(size_t)rowsel[r] * gs + c] * d[c] : 0.0;
+    }
+}
+// CG[r][c] = sum_j Cp[r][j] G[j][c]
+__global__ __launch_bounds__(256) void k_cg(int mc, int nz, int nzs, const double* Cp, const double* G, double* CG) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < mc * nzs; t += gridDim.x * blockDim.x) {
+        const int r = t / nzs, c = t % nzs;
+        double s = 0.0;
+        if (c < nz)
+            for (int j = 0; j < nz; ++j) s += Cp[(size_t)r * nzs + j] * G[(size_t)j * nzs + c];
+        CG[t] = s;
+    }
+}
+__global__ __launch_bounds__(256) void k_ghat(int nz, int mc, int nzs, int Rs, const double* G, const double* Cp,
+                                              const double* CG, double* Ghat, double* gnorm) {
+    const int R = nz + mc;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < R * Rs; t += gridDim.x * blockDim.x) {
+        const int a = t / Rs, b = t % Rs;
+        double v = 0.0;
+        if (b < R) {
+            if (a < nz && b < nz) v = G[(size_t)a * nzs + b];
+            else if (a < nz) v = CG[(size_t)(b - nz) * nzs + a];
+            else if (b < nz) v = CG[(size_t)(a - nz) * nzs + b];
+            else
+                for (int j = 0; j < nz; ++j) v += CG[(size_t)(a - nz) * nzs + j] * Cp[(size_t)(b - nz) * nzs + j];
+        }
+        Ghat[t] = v;
+        if (a == b) gnorm[a] = sqrt(v > 0.0 ? v : 1.0);
+    }
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < Rs; t += gridDim.x * blockDim.x)
+        if (t >= R) gnorm[t] = 1.0;
+}
+
 // Runs the whole shared-model design on `stream` and leaves the packed operands in the handle's buffers.
 // Returns 0 or a negative almpc_status value (numbers as in include/almpc.h).
 inline int design_shared_device(hipStream_t stream, int n, int m, int N, int nzs, int nrb, int ks, int ksf,
@@ -262,7 +301,8 @@ inline int design_shared_device(hipStream_t stream, int n, int m, int N, int nzs
                                 std::vector<double> R, std::vector<double> S, std::vector<double> P, double rho,
                                 double sigma, double* dMinvFrag, double* dGFrag, double* dHFrag, double* dFFrag,
                                 double* dG, double* dD, std::vector<double>& hH, std::vector<double>& hF,
-                                std::vector<double>& hd, std::string& err) {
+                                std::vector<double>& hd, std::string& err, const std::vector<int>& rowsel = std::vector<int>(),
+                                int Rs = 0, double* dGhat = nullptr, double* dGnorm = nullptr) {
     const int nz = m * N;
     const int useR = R[0] != 0.0, useS = useR && S[0] != 0.0;  // the reference tests only element [1,1]
     auto symmetrise = [](std::vector<double>& M, int k) {
@@ -333,6 +373,22 @@ inline int design_shared_device(hipStream_t stream, int n, int m, int N, int nzs
     hipLaunchKernelGGL(k_pack_frags, dim3(32), dim3(256), 0, stream, dHs, nz, nz, nzs, nrb, ks, dHFrag);
     hipLaunchKernelGGL(k_pack_frags, dim3(32), dim3(256), 0, stream, dFs, nz, n, nzs, nrb, ksf, dFFrag);
     DTRY(hipGetLastError());
+    if (!rowsel.empty()) {  // state rows: Ghat = A G A' in constraint space
+        const int mc = (int)rowsel.size();
+        double *dCp, *dCG;
+        int* dSel;
+        DTRY(dnew(&dCp, (size_t)mc * nzs)); DTRY(dnew(&dCG, (size_t)mc * nzs));
+        {
+            double* tmpi = nullptr;
+            DTRY(dnew(&tmpi, (size_t)(mc + 1) / 2 + 1));
+            dSel = reinterpret_cast<int*>(tmpi);
+        }
+        DTRY(hipMemcpyAsync(dSel, rowsel.data(), mc * sizeof(int), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(k_build_cprime, dim3(64), dim3(256), 0, stream, mc, nz, nzs, gs, dSel, dGam, dD, dCp);
+        hipLaunchKernelGGL(k_cg, dim3(256), dim3(256), 0, stream, mc, nz, nzs, dCp, dG, dCG);
+        hipLaunchKernelGGL(k_ghat, dim3(512), dim3(256), 0, stream, nz, mc, nzs, Rs, dG, dCp, dCG, dGhat, dGnorm);
+        DTRY(hipGetLastError());
+    }
     hH.assign((size_t)nz * nz, 0.0); hF.assign((size_t)nz * n, 0.0); hd.assign((size_t)nzs, 0.0);
     int flag = 0;
     DTRY(hipMemcpyAsync(hH.data(), dH, hH.size() * sizeof(double), hipMemcpyDeviceToHost, stream));

@@ -1,0 +1,504 @@
+// almpc_polish_gen.hip.h -- exact finish for problems with STATE rows (state box, terminal equality).
+//
+// Reference rows restated (paths relative to /root/reference):
+//   state box  x_min <= x[i,k] <= x_max, k = 1..N+1, only when kw `mpc_state_constraint` is present
+//              src/sub/model_modeler_implementation/linear/mpc_modeler_implementation_linear.jl:62-70
+//   terminal equality  e_x[:,N+1] == 0      src/sub/design_mpc.jl:330-331
+//
+// Method: Goldfarb-Idnani dual active set in CONSTRAINT space (oracle: mpc_oracle.py::solve_qp_dual_active_set).
+// Rows of A = [I; C'] (input box rows, then state rows; C' = rows of Gamma D), shared Ghat = A H'^-1 A' (R x R).
+// With working set W at bounds b:  s = s0 - Ghat[:,W] lam,  Ghat[W,W] lam = s0_W - b,  s0 = A v0 + [0; Phi e0]
+// (= the unconstrained minimiser v0 and ITS state trajectory, which one rollout gives).  The box-only ADMM of
+// k_admm supplies v0 and the guess for the input rows; violated rows (input or state) are then added one at a
+// time, with partial steps and drops when a multiplier would change sign.  Dual feasible throughout, so the first
+// primal-feasible iterate is the optimum; infeasibility shows as a dependent violated row without a blocking
+// multiplier (status ALMPC_INFEASIBLE).
+//
+// One wave per instance; lane l owns row pairs (2l, 2l+1) + 128 q, q < NP (R <= 128 NP).  Same machinery as
+// k_polish: Sinv = (Ghat_WW)^-1 in LDS (32 x 32, identity padded, both half-waves mirror the positions),
+// position-distributed data in registers, LDS broadcasts, DPP reductions, branch-free sweeps.
+#pragma once
+#include "almpc_kernels.hip.h"
+
+namespace almpc {
+
+struct PolishGenParams {
+    int nz, mc, R, Rs, m, n, N, batch, nzs;
+    const double* Ghat;   // [R][Rs] dense symmetric
+    const double* gnorm;  // [Rs] sqrt(Ghat_rr) (pad rows: 1)
+    const int* row_traj;  // [Rs] for state rows: offset of e_x[i,k] in the wave's trajectory buffer Z ((k)*C + i); else -1
+    const int* row_eq;    // [Rs] 1 for terminal-equality rows
+    const int* row_xidx;  // [Rs] for state rows: i + n*k index into x_ref (k = reference stage 2..N+1 -> 1..N); else 0
+    const int* row_state; // [Rs] for state rows: state index i; else 0
+    const double* xmin;   // [n] (only read when has_box)
+    const double* xmax;
+    int has_box;
+    const double* dvec; const double* umin; const double* umax;
+    const double* uref; long uref_stride;
+    const double* zs; const double* ys; const double* v0;
+    int32_t* status; int32_t* piters;
+    int max_iter;
+    int roll_g, roll_cpl;
+    RolloutParams roll;
+};
+
+constexpr int PGEN_WAVES = 4;
+// LDS per wave (doubles): Sinv 32x32 | rowbuf Rs(<=512) | pbufa 32 | pbufb 32 | wrow_s (32 ints) | Z trajectory shares Sinv
+constexpr int PGEN_LDS_PER_WAVE = 32 * 32 + 512 + 32 + 32 + 16;
+
+template <int NP>
+__global__ __launch_bounds__(64 * PGEN_WAVES) void k_polish_gen(PolishGenParams p) {
+    constexpr int WL = 32;
+    constexpr int CH = 8;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int inst = blockIdx.x * PGEN_WAVES + wv;
+    if (inst >= p.batch) return;
+    const int st_in = p.status[inst];
+    const int nz = p.nz, nzs = p.nzs, R = p.R, Rs = p.Rs;
+    const size_t base = (size_t)inst * nzs;
+    const int pos = lane & 31, hf = lane >> 5;
+    const bool lowhalf = lane < 32;
+
+    double* Sl = smem + (size_t)wv * PGEN_LDS_PER_WAVE;
+    double* rowbuf = Sl + 32 * 32;  // [Rs]
+    double* pbufa = rowbuf + 512;
+    double* pbufb = pbufa + 32;
+    int* wrow_s = reinterpret_cast<int*>(pbufb + 32);
+    const RolloutParams& rp = p.roll;
+    const int n = p.n, m = p.m, N = p.N, C = n + m;
+    double* Z = Sl;  // trajectory buffer (N+1) x C, first use (s0) and last use (outputs); Sinv lives here in between
+
+    // ---- rows of this lane: pairs (2 lane, 2 lane + 1) + 128 q
+    int rrow[NP][2];
+    double s0v[NP][2], sv[NP][2], lo[NP][2], hi[NP][2], gn[NP][2], bnd[NP][2];
+    bool act[NP][2], valid[NP][2];
+    double y0 = 0, y1 = 0, z0 = 0, z1 = 0;
+    bool x0_bad = false;
+    // unconstrained minimiser v0 and the box-ADMM iterate (input rows live in pair 0)
+    {
+        const int rc = (2 * lane < nzs) ? 2 * lane : 0;
+        const d2 vv = *reinterpret_cast<const d2*>(p.v0 + base + rc);
+        const d2 yy = *reinterpret_cast<const d2*>(p.ys + base + rc);
+        const d2 zz = *reinterpret_cast<const d2*>(p.zs + base + rc);
+        const d2 dv = *reinterpret_cast<const d2*>(p.dvec + rc);
+        y0 = yy[0]; y1 = yy[1]; z0 = zz[0]; z1 = zz[1];
+        // trajectory of v0: Z rows [e_x(k); e_u(k)]
+        for (int e = 0; e < 2; ++e) {
+            const int r = 2 * lane + e;
+            if (r < nz) Z[(size_t)(r / m) * C + n + r % m] = vv[e] * dv[e];
+        }
+        for (int i = lane; i < n; i += 64) {
+            const double xv = rp.x0[(size_t)inst * n + i];
+            Z[i] = xv - rp.xref[(size_t)inst * rp.xref_stride + i];
+            if (p.has_box && !(xv >= p.xmin[i] && xv <= p.xmax[i])) x0_bad = true;  // stage 1 is x0 itself
+        }
+        wave_fence_lds();
+        switch (p.roll_cpl) {
+            case 1: rollout_steps<1>(Z, n, m, N, p.roll_g, lane, rp.A, rp.B); break;
+            case 2: rollout_steps<2>(Z, n, m, N, p.roll_g, lane, rp.A, rp.B); break;
+            case 4: rollout_steps<4>(Z, n, m, N, p.roll_g, lane, rp.A, rp.B); break;
+            default: rollout_steps<8>(Z, n, m, N, p.roll_g, lane, rp.A, rp.B); break;
+        }
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int r = 2 * lane + e + 128 * q;
+                rrow[q][e] = r;
+                valid[q][e] = r < R;
+                act[q][e] = false;
+                bnd[q][e] = 0.0;
+                const int rcl = valid[q][e] ? r : 0;
+                gn[q][e] = valid[q][e] ? p.gnorm[rcl] : 1.0;
+                if (r < nz) {  // input row, bounds exactly as k_admm forms them
+                    const double di = 1.0 / (e ? dv[1] : dv[0]);
+                    const double ur = p.uref[(size_t)inst * p.uref_stride + r];
+                    lo[q][e] = (p.umin[r % m] - ur) * di;
+                    hi[q][e] = (p.umax[r % m] - ur) * di;
+                    s0v[q][e] = e ? vv[1] : vv[0];
+                } else if (valid[q][e]) {  // state row: value e_x[i,k] of the v0 trajectory, shared bounds
+                    const int tr = p.row_traj[rcl];
+                    s0v[q][e] = Z[tr];
+                    if (p.row_eq[rcl]) { lo[q][e] = 0.0; hi[q][e] = 0.0; }
+                    else {
+                        const double xr = rp.xref[(size_t)inst * rp.xref_stride + p.row_xidx[rcl]];
+                        lo[q][e] = p.xmin[p.row_state[rcl]] - xr;
+                        hi[q][e] = p.xmax[p.row_state[rcl]] - xr;
+                    }
+                } else { lo[q][e] = -__builtin_inf(); hi[q][e] = __builtin_inf(); s0v[q][e] = 0.0; }
+                sv[q][e] = s0v[q][e];
+            }
+    }
+    x0_bad = __any(x0_bad);
+    wave_fence_lds();
+    // ---- Sinv := identity (Z is dead now)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) Sl[(2 * t + hf) * 32 + pos] = ((2 * t + hf) == pos) ? 1.0 : 0.0;
+    wrow_s[pos] = 0;
+    wave_fence_lds();
+
+    int wrow = 0, wsd = 0;
+    double wbnd = 0.0, lam = 0.0;
+    int k = 0;
+    int fin = 1;  // 0 optimal, 1 cap / capacity, 3 infeasible
+    int it = 0;
+
+    auto put_pos = [&](double* buf, double v) __attribute__((always_inline)) { buf[pos] = v; wave_fence_lds(); };
+    auto put_rows = [&](const double (&a)[NP][2]) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            d2 v; v[0] = a[q][0]; v[1] = a[q][1];
+            *reinterpret_cast<d2*>(rowbuf + 2 * lane + 128 * q) = v;
+        }
+        wave_fence_lds();
+    };
+    auto s_matvec = [&](const double* cb) __attribute__((always_inline)) -> double {
+        double acc = 0.0;
+        for (int l0 = 0; l0 < k; l0 += 16) {
+            double a[8], c[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { a[t] = Sl[(l0 + 2 * t + hf) * WL + pos]; c[t] = cb[l0 + 2 * t + hf]; }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc += a[t] * c[t];
+        }
+        acc += __shfl_xor(acc, 32);
+        return acc;
+    };
+    auto s_rank1 = [&](double a, const double* ab, double scale) __attribute__((always_inline)) {
+        const double as = a * scale;
+        for (int l0 = 0; l0 < k; l0 += 16) {
+            double cur[8], av[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { cur[t] = Sl[(l0 + 2 * t + hf) * WL + pos]; av[t] = ab[l0 + 2 * t + hf]; }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) Sl[(l0 + 2 * t + hf) * WL + pos] = cur[t] + as * av[t];
+        }
+    };
+    // q[.] = sum_{l<k} Ghat[W_l, rows] * a_l  (a in LDS buffer ab, zero beyond k)
+    auto g_rows_times = [&](const double* ab, double (&qv)[NP][2]) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) { qv[q][0] = 0.0; qv[q][1] = 0.0; }
+        for (int l0 = 0; l0 < k; l0 += CH) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                d2 g[CH];
+                double av[CH];
+#pragma unroll
+                for (int t = 0; t < CH; ++t) {
+                    const int off = 2 * lane + 128 * q;
+                    g[t] = *reinterpret_cast<const d2*>(p.Ghat + (size_t)wrow_s[l0 + t] * Rs + (off < Rs ? off : 0));
+                    av[t] = ab[l0 + t];
+                }
+#pragma unroll
+                for (int t = 0; t < CH; ++t) { qv[q][0] += g[t][0] * av[t]; qv[q][1] += g[t][1] * av[t]; }
+            }
+        }
+    };
+    auto load_row = [&](int j, double (&gj)[NP][2]) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int off = 2 * lane + 128 * q;
+            const d2 g = *reinterpret_cast<const d2*>(p.Ghat + (size_t)j * Rs + (off < Rs ? off : 0));
+            gj[q][0] = g[0]; gj[q][1] = g[1];
+        }
+    };
+    auto row_value = [&](const double (&a)[NP][2], int j) -> double {  // a[row j], uniform j
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const double c = readlane_d((j & 1) ? a[q][1] : a[q][0], (j >> 1) & 63);
+            if ((j >> 7) == q) v = c;
+        }
+        return v;
+    };
+    auto recompute = [&]() __attribute__((always_inline)) {  // lam = Sinv (s0_W - b), s = s0 - Ghat[:,W] lam
+        put_rows(s0v);
+        const double rv = rowbuf[wrow] - wbnd;
+        put_pos(pbufa, (pos < k) ? rv : 0.0);
+        const double lm = s_matvec(pbufa);
+        lam = (pos < k) ? lm : 0.0;
+        put_pos(pbufb, lam);
+        double qv[NP][2];
+        g_rows_times(pbufb, qv);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) { sv[q][0] = s0v[q][0] - qv[q][0]; sv[q][1] = s0v[q][1] - qv[q][1]; }
+    };
+    auto mark = [&](int j, bool on, double bval) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                if (rrow[q][e] == j) { act[q][e] = on; bnd[q][e] = bval; }
+    };
+    // border Sinv with row j given u = Sinv c and isc = 1/(Ghat_jj - c'u)
+    auto border = [&](int j, double u, double isc, double bval, int sd, double lamj) __attribute__((always_inline)) {
+        s_rank1(u, pbufb, isc);  // pbufb holds u
+        const double bv = (pos == k) ? isc : -u * isc;
+        Sl[k * WL + pos] = bv;
+        Sl[pos * WL + k] = bv;
+        if (pos == k) { wrow = j; wsd = sd; wbnd = bval; lam = lamj; }
+        if (lane == 0) wrow_s[k] = j;
+        mark(j, true, bval);
+        k += 1;
+        wave_fence_lds();
+    };
+    // remove position rp; with_state: move s and lam so that lam_rp becomes 0 first (used to restore dual feasibility)
+    auto remove_pos = [&](int rp, bool with_state) __attribute__((always_inline)) {
+        const double sp = Sl[rp * WL + pos];
+        const double spp = readlane_d(sp, rp);
+        put_pos(pbufb, sp);
+        if (with_state) {
+            const double a = readlane_d(lam, rp) / spp;
+            double qv[NP][2];
+            g_rows_times(pbufb, qv);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) { sv[q][0] += a * qv[q][0]; sv[q][1] += a * qv[q][1]; }
+            lam -= sp * a;
+        }
+        s_rank1(sp, pbufb, -1.0 / spp);
+        wave_fence_lds();
+        const int last = k - 1;
+        const int jrem = __builtin_amdgcn_readlane(wrow, rp);
+        if (rp != last) {
+            const double colv = Sl[last * WL + pos];
+            const double corner = readlane_d(colv, last);
+            const double nv = (pos == rp) ? corner : ((pos == last) ? 0.0 : colv);
+            Sl[rp * WL + pos] = nv;
+            Sl[pos * WL + rp] = nv;
+            const int lrow = __builtin_amdgcn_readlane(wrow, last), lsd = __builtin_amdgcn_readlane(wsd, last);
+            const double lbv = readlane_d(wbnd, last), llam = readlane_d(lam, last);
+            if (pos == rp) { wrow = lrow; wsd = lsd; wbnd = lbv; lam = llam; }
+            if (lane == 0) wrow_s[rp] = lrow;
+        }
+        const double iv = (pos == last) ? 1.0 : 0.0;
+        Sl[last * WL + pos] = iv;
+        Sl[pos * WL + last] = iv;
+        if (pos == last) lam = 0.0;
+        if (lane == 0) wrow_s[last] = 0;
+        mark(jrem, false, 0.0);
+        k -= 1;
+        wave_fence_lds();
+    };
+    // direction of adding row j, first half: c = Ghat[W,j] -> u = Sinv c (also left in pbufb), dp = Ghat_jj - c'u
+    auto dir_u = [&](int j, double (&gj)[NP][2], double& u, double& dp, double& gjj) __attribute__((always_inline)) {
+        load_row(j, gj);
+        put_rows(gj);
+        const double cv = rowbuf[wrow];
+        const double c = (pos < k) ? cv : 0.0;
+        gjj = rowbuf[j];
+        put_pos(pbufa, c);
+        u = s_matvec(pbufa);
+        put_pos(pbufb, u);
+        dp = gjj - wave_sum(lowhalf ? c * u : 0.0);
+    };
+    // second half: d = Ghat[:,j] - Ghat[:,W] u  (u in pbufb)
+    auto dir_d = [&](const double (&gj)[NP][2], double (&dv)[NP][2]) __attribute__((always_inline)) {
+        double qv[NP][2];
+        g_rows_times(pbufb, qv);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) { dv[q][0] = gj[q][0] - qv[q][0]; dv[q][1] = gj[q][1] - qv[q][1]; }
+    };
+
+    const bool skip = (st_in == 2) || x0_bad;
+    bool give_up = skip;
+    if (!skip) {
+        // ---- initial working set: equality rows, then the input rows the ADMM multipliers flag (rows ascending)
+        int flag[NP][2];
+        int cnt = 0;
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                int f = 0;
+                const int r = rrow[q][e];
+                if (valid[q][e]) {
+                    if (r >= nz) { if (p.row_eq[r]) f = 2; }
+                    else {
+                        const double yy = e ? y1 : y0, ww = fmin(fmax(e ? z1 : z0, lo[q][e]), hi[q][e]);
+                        if (yy < 0.0 && ww <= lo[q][e]) f = -1;
+                        else if (yy > 0.0 && ww >= hi[q][e]) f = 1;
+                    }
+                }
+                flag[q][e] = f;
+            }
+        // positions: equality rows first (in row order), then flagged input rows (row order)
+        int* ibuf = reinterpret_cast<int*>(rowbuf);  // [0..64) row of position, [64..128) side
+        int base_pos = 0;
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const bool f0 = pass == 0 ? flag[q][0] == 2 : (flag[q][0] == 1 || flag[q][0] == -1);
+                const bool f1 = pass == 0 ? flag[q][1] == 2 : (flag[q][1] == 1 || flag[q][1] == -1);
+                const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1);
+                const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+                const int p0 = base_pos + __popcll(m0 & below) + __popcll(m1 & below), p1 = p0 + (f0 ? 1 : 0);
+                if (f0 && p0 < 64) { ibuf[p0] = rrow[q][0]; ibuf[64 + p0] = pass == 0 ? 0 : flag[q][0]; }
+                if (f1 && p1 < 64) { ibuf[p1] = rrow[q][1]; ibuf[64 + p1] = pass == 0 ? 0 : flag[q][1]; }
+                base_pos += __popcll(m0) + __popcll(m1);
+            }
+        }
+        cnt = base_pos;
+        wave_fence_lds();
+        // guessed rows live in registers of lane = guess index (up to 64 of them)
+        const int g_row = (lane < cnt && lane < 64) ? ibuf[lane] : 0;
+        const int g_sd = (lane < cnt && lane < 64) ? ibuf[64 + lane] : 0;
+        double bsel[NP][2];
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) bsel[q][e] = (flag[q][e] == -1) ? lo[q][e] : hi[q][e];  // equality rows: lo == hi
+        wave_fence_lds();
+        // Build the working set row by row (bordering), skipping rows that are linearly dependent on the rows already
+        // taken: a saturated guess can hold more rows than there are variables.
+        const int ng = cnt < 64 ? cnt : 64;
+        for (int gi = 0; gi < ng; ++gi) {
+            if (k == WL) { give_up = true; break; }
+            const int j = __builtin_amdgcn_readlane(g_row, gi), sd = __builtin_amdgcn_readlane(g_sd, gi);
+            double gj[NP][2], u, dp, gjj;
+            dir_u(j, gj, u, dp, gjj);
+            if (!(dp > 1e-10 * gjj)) continue;
+            border(j, u, 1.0 / dp, row_value(bsel, j), sd, 0.0);
+        }
+        if (!give_up && k > 0) recompute();
+    }
+
+    const int max_iter = p.max_iter;
+    if (!give_up) {
+        // ---- restore dual feasibility of the guess: drop wrong-sign multipliers, worst first
+        while (k > 0 && it < max_iter) {
+            const bool mine = lowhalf && pos < k && wsd != 0;
+            const double viol = mine ? ((wsd > 0) ? -lam : lam) : -__builtin_inf();
+            const double lmax = wave_max((lowhalf && pos < k) ? fabs(lam) : 0.0);
+            const double vmax = wave_max(viol);
+            if (!(vmax > 1e-12 * fmax(1.0, lmax))) break;
+            const int vi = __builtin_ctzll(__ballot(mine && viol == vmax));
+            remove_pos(vi, true);
+            ++it;
+        }
+        // ---- Goldfarb-Idnani main loop
+        bool fresh = false;
+        while (it < max_iter) {
+            ++it;
+            // most violated row outside W, in the H'^-1 metric
+            double vbest = -__builtin_inf();
+            int which = 0;
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const double v = (valid[q][e] && !act[q][e]) ? fmax(sv[q][e] - hi[q][e], lo[q][e] - sv[q][e]) / gn[q][e] : -__builtin_inf();
+                    if (v > vbest) { vbest = v; which = 2 * q + e; }
+                }
+            const double vmax = wave_max(vbest);
+            if (!(vmax == vmax) || !(vmax < __builtin_inf())) { fin = 1; break; }  // numerical breakdown: never report it as solved
+            if (!(vmax > 1e-9)) {
+                if (fresh) { fin = 0; break; }
+                recompute();  // confirm on values computed from scratch
+                fresh = true;
+                --it;
+                continue;
+            }
+            fresh = false;
+            const int owner = __builtin_ctzll(__ballot(vbest == vmax));
+            const int wsel = __builtin_amdgcn_readlane(which, owner);
+            const int pr = 2 * owner + (wsel & 1) + 128 * (wsel >> 1);
+            const double sp_ = row_value(sv, pr), hip = row_value(hi, pr), lop = row_value(lo, pr);
+            const int sd = sp_ > hip ? 1 : -1;
+            const double bp = sd > 0 ? hip : lop;
+            double lam_p = 0.0;
+            bool added = false;
+            while (it < max_iter) {
+                if (k == WL) { fin = 1; give_up = true; break; }
+                double u, dp, gjj, dv[NP][2], gj[NP][2];
+                dir_u(pr, gj, u, dp, gjj);
+                dir_d(gj, dv);
+                const bool dependent = !(dp > 1e-12 * gjj);
+                const double spn = row_value(sv, pr);
+                const double tau2 = dependent ? (double)sd * __builtin_inf() : (spn - bp) / dp;
+                // multipliers that would change sign on the way: lam_i - u_i tau = 0
+                const bool cand = lowhalf && pos < k && wsd != 0 && u != 0.0;
+                const double ti = lam / u;
+                const bool zero_blk = cand && lam == 0.0 && (u * sd * wsd > 0.0);
+                const bool pos_blk = cand && lam != 0.0 && (ti * sd > 0.0);
+                const double tabs = zero_blk ? 0.0 : (pos_blk ? fabs(ti) : __builtin_inf());
+                const double tau1 = wave_min(tabs);
+                if (dependent && !(tau1 < __builtin_inf())) { fin = 3; break; }
+                if (tau1 < fabs(tau2)) {  // partial step, drop the blocking row, try again
+                    const double tau = sd * tau1;
+                    if (!dependent) {
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) { sv[q][0] -= tau * dv[q][0]; sv[q][1] -= tau * dv[q][1]; }
+                    }
+                    lam -= u * tau;
+                    lam_p += tau;
+                    const int blk = __builtin_ctzll(__ballot(tabs == tau1));
+                    if (pos == blk) lam = 0.0;
+                    remove_pos(blk, false);
+                    ++it;
+                    continue;
+                }
+#pragma unroll
+                for (int q = 0; q < NP; ++q) { sv[q][0] -= tau2 * dv[q][0]; sv[q][1] -= tau2 * dv[q][1]; }
+                lam -= u * tau2;
+                lam_p += tau2;
+                border(pr, u, 1.0 / dp, bp, sd, lam_p);
+                added = true;
+                break;
+            }
+            if (!added) break;
+        }
+    }
+    if (x0_bad && st_in != 2) fin = 3;
+
+    // ---- result: w = input rows of s (pair 0), then the fused rollout
+    d2 wout;
+    if (give_up || fin == 3) {
+        wout[0] = (st_in == 2) ? z0 : fmin(fmax(z0, lo[0][0]), hi[0][0]);
+        wout[1] = (st_in == 2) ? z1 : fmin(fmax(z1, lo[0][1]), hi[0][1]);
+    } else {
+        wout[0] = act[0][0] ? bnd[0][0] : fmin(fmax(sv[0][0], lo[0][0]), hi[0][0]);
+        wout[1] = act[0][1] ? bnd[0][1] : fmin(fmax(sv[0][1], lo[0][1]), hi[0][1]);
+    }
+    if (lane == 0) {
+        p.piters[inst] = it;
+        p.status[inst] = (st_in == 2) ? 2 : ((fin == 0) ? 0 : (fin == 3 ? 3 : 1));
+    }
+    wave_fence_lds();
+    {
+        const int r0 = 2 * lane, r1 = 2 * lane + 1;
+        const int rc = (r0 < nzs) ? r0 : 0;
+        const d2 dvp = *reinterpret_cast<const d2*>(p.dvec + rc);
+        if (r0 < nz) {
+            const double ur = rp.uref[(size_t)inst * rp.uref_stride + r0];
+            const double uu = fmin(fmax(wout[0] * dvp[0] + ur, rp.umin[r0 % m]), rp.umax[r0 % m]);
+            rp.u[(size_t)inst * nz + r0] = uu;
+            rp.eu[(size_t)inst * nz + r0] = uu - ur;
+            Z[(size_t)(r0 / m) * C + n + r0 % m] = uu - ur;
+        }
+        if (r1 < nz) {
+            const double ur = rp.uref[(size_t)inst * rp.uref_stride + r1];
+            const double uu = fmin(fmax(wout[1] * dvp[1] + ur, rp.umin[r1 % m]), rp.umax[r1 % m]);
+            rp.u[(size_t)inst * nz + r1] = uu;
+            rp.eu[(size_t)inst * nz + r1] = uu - ur;
+            Z[(size_t)(r1 / m) * C + n + r1 % m] = uu - ur;
+        }
+        for (int i = lane; i < n; i += 64) Z[i] = rp.x0[(size_t)inst * n + i] - rp.xref[(size_t)inst * rp.xref_stride + i];
+        wave_fence_lds();
+        switch (p.roll_cpl) {
+            case 1: rollout_steps<1>(Z, n, m, N, p.roll_g, lane, rp.A, rp.B); break;
+            case 2: rollout_steps<2>(Z, n, m, N, p.roll_g, lane, rp.A, rp.B); break;
+            case 4: rollout_steps<4>(Z, n, m, N, p.roll_g, lane, rp.A, rp.B); break;
+            default: rollout_steps<8>(Z, n, m, N, p.roll_g, lane, rp.A, rp.B); break;
+        }
+        const int nx = n * (N + 1);
+        const size_t xo = (size_t)inst * nx;
+        for (int t = lane; t < nx; t += 64) {
+            const double ev = Z[(size_t)(t / n) * C + t % n];
+            rp.ex[xo + t] = ev;
+            rp.x[xo + t] = (t < n) ? rp.x0[(size_t)inst * n + t] : ev + rp.xref[(size_t)inst * rp.xref_stride + t];
+        }
+    }
+}
+
+}  // namespace almpc

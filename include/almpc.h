@@ -56,7 +56,8 @@ typedef enum almpc_status {
 typedef enum almpc_solve_status {
     ALMPC_SOLVED = 0,          /* KKT conditions hold: ADMM met its tolerance and/or the polish certified */
     ALMPC_MAX_ITER = 1,        /* ADMM hit max_iter and polish was off or hit its own cap                   */
-    ALMPC_NON_FINITE = 2       /* a non-finite value appeared (bad inputs)                                  */
+    ALMPC_NON_FINITE = 2,      /* a non-finite value appeared (bad inputs)                                  */
+    ALMPC_INFEASIBLE = 3       /* state rows only: no point satisfies the box / terminal equality           */
 } almpc_solve_status;
 
 /*
@@ -98,12 +99,20 @@ const char* almpc_last_error(const almpc_handle* h);
  * Design for a model shared by all instances (replaces _model_predictive_control_design for the
  * linear system, src/sub/design_mpc.jl:54-129).
  *   A n*n, B n*m, Q n*n, R m*m, S m*m (NULL -> 0), P n*n (NULL -> DARE(A,B,Q,R) as
- *   src/sub/design_mpc.jl:327), umin/umax m.  xmin/xmax must be NULL (state box: not yet built,
- *   returns ALMPC_ERR_UNSUPPORTED).  rho/sigma are fixed at design time because the shared
- *   KKT inverse depends on them.
+ *   src/sub/design_mpc.jl:327), umin/umax m.  xmin/xmax n, or NULL: non-NULL adds the state box
+ *   x_min <= x[:,k] <= x_max for k = 1..N+1, i.e. the reference's kw `mpc_state_constraint`
+ *   (..linear.jl:62-70); needs n*N + m*N <= 512.  rho/sigma are fixed at design time because the
+ *   shared KKT inverse depends on them.
  * Builds Phi, Gamma blocks, H = 2(Gamma' Qbar Gamma + Rbar + D'SbarD), F = 2 Gamma' Qbar Phi,
  * the Jacobi scaling, (H' + (sigma+rho) I)^-1 and H'^-1 on the device.
  */
+/*
+ * Terminal constraint e_x[:,N+1] == 0 (mpc_terminal_ingredient = "equality", src/sub/design_mpc.jl:330-331):
+ * call with 1 BEFORE almpc_design_shared.  Problems with state rows (state box and/or terminal equality) are
+ * finished by a dual active-set method in constraint space (k_polish_gen); they require opts.polish = 1.
+ */
+int almpc_set_terminal_equality(almpc_handle* h, int on);
+
 int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const double* Q,
                         const double* R, const double* S, const double* P, const double* umin,
                         const double* umax, const double* xmin, const double* xmax, double rho,

@@ -44,7 +44,7 @@ import numpy as np
 
 __all__ = [
     "MPCProblem", "dare", "condense", "condensed_qp", "solve_box_qp_exact", "kkt_residual",
-    "rollout", "solve_mpc_exact", "sparse_problem", "osqp_admm", "admm_box", "polish_active_set",
+    "rollout", "solve_mpc_exact", "constraint_rows", "solve_qp_dual_active_set", "kkt_general", "sparse_problem", "osqp_admm", "admm_box", "polish_active_set",
     "design_shared", "solve_mpc_admm_polish",
     "jacobi_scaling", "decode_linear_regressor_fixture", "splitmix_normal",
     "double_integrator", "quadrotor", "qtp_linear_fixture_problem", "quadrotor_x0_batch",
@@ -303,15 +303,219 @@ def solve_box_qp_exact(H, f, lo, hi, max_iter=None, tol=1e-9):
     return np.clip(w * d, lo, hi)
 
 
-def solve_mpc_exact(p: MPCProblem, x0):
-    """One MPC step, exact: returns rollout dict plus v (for box-only problems)."""
-    if p.x_min is not None or p.terminal != "none":
-        raise NotImplementedError("exact oracle covers the box-only path (SURVEY.md section 8f rank 1 is 'next')")
+def constraint_rows(p: MPCProblem, d=None):
+    """General-constraint statement of the condensed QP in the scaled variables w (v = d*w; d=None -> unscaled):
+    rows of  A = [I; C],  lo_r <= (A w + a0(e0))_r <= hi_r,  where the first nz rows are the input box and the C rows
+    are the STATE rows the reference adds: the state box for stages 2..N+1 when `mpc_state_constraint` is present
+    (..linear.jl:62-70; stage 1 is the fixed x0 and only decides feasibility) and/or the terminal equality
+    e_x[:,N+1] = 0 (src/sub/design_mpc.jl:330-331).  A state row's value is e_x[i,k] = (Phi e0 + Gamma v)[i,k], so its
+    offset a0 = Phi e0 depends on the instance while its bounds (x_min - x_ref, x_max - x_ref; 0,0 for the equality)
+    are shared.  Returns dict(C (mc x nz), stage (mc,), state (mc,), lo_c, hi_c, eq (mc,) bool)."""
+    n, m, N = p.n, p.m, p.N
+    Phi, Gam, _, _ = condense(p)
+    d = np.ones(p.nz) if d is None else d
+    rows, lo, hi, eq, st, ix = [], [], [], [], [], []
+    box = p.x_min is not None
+    for k in range(N):  # stage k+2 of the reference = block k of E
+        for i in range(n):
+            is_eq = p.terminal == "equality" and k == N - 1
+            if not (box or is_eq):
+                continue
+            rows.append(k * n + i)
+            st.append(k)
+            ix.append(i)
+            eq.append(is_eq)
+            if is_eq:
+                lo.append(0.0)
+                hi.append(0.0)
+            else:
+                lo.append(p.x_min[i] - p.x_ref[i, k + 1])
+                hi.append(p.x_max[i] - p.x_ref[i, k + 1])
+    rows = np.array(rows, dtype=int)
+    return dict(C=Gam[rows] * d[None, :] if rows.size else np.zeros((0, p.nz)), Phi=Phi[rows] if rows.size else np.zeros((0, n)),
+                lo_c=np.array(lo), hi_c=np.array(hi), eq=np.array(eq, dtype=bool), stage=np.array(st, dtype=int),
+                state=np.array(ix, dtype=int))
+
+
+def solve_qp_dual_active_set(Ghat, s0, lo, hi, eq=None, W0=None, side0=None, max_iter=None, tol=1e-9):
+    """Goldfarb-Idnani dual active-set method in CONSTRAINT space for the strictly convex QP
+        min 1/2 w'H'w + f'w   s.t.  lo <= A w + a0 <= hi,
+    given only  Ghat = A H'^-1 A'  (R x R)  and  s0 = A v0 + a0  (v0 = -H'^-1 f', the unconstrained minimiser):
+    with working set W at bounds b, the row values are  s = s0 - Ghat[:,W] lam,  Ghat[W,W] lam = s0[W] - b.
+    Dual feasible throughout (lam >= 0 at upper, <= 0 at lower bounds, free on equality rows), primal feasibility is
+    restored one violated row at a time, with partial steps when a multiplier would change sign (that row is dropped).
+    Returns dict(s, lam (R,), W, iters, status) with status 0 optimal, 1 iteration cap, 3 infeasible."""
+    R = s0.size
+    eq = np.zeros(R, dtype=bool) if eq is None else eq
+    max_iter = 20 * R + 50 if max_iter is None else max_iter
+    gn = np.sqrt(np.maximum(np.diag(Ghat), 1e-300))  # row norms in the H'^-1 metric, for the violation measure
+    W, side = [], {}
+    Sinv = np.zeros((0, 0))
+    lam = np.zeros(R)
+
+    def add(j, sd):
+        nonlocal Sinv
+        c = Ghat[W, j]
+        u = Sinv @ c
+        sc = Ghat[j, j] - c @ u
+        k = len(W)
+        Sn = np.empty((k + 1, k + 1))
+        Sn[:k, :k] = Sinv + np.outer(u, u) / sc
+        Sn[:k, k] = -u / sc
+        Sn[k, :k] = -u / sc
+        Sn[k, k] = 1.0 / sc
+        Sinv = Sn
+        W.append(j)
+        side[j] = sd
+
+    def remove(pos):
+        nonlocal Sinv
+        keep = [i for i in range(len(W)) if i != pos]
+        Sinv = Sinv[np.ix_(keep, keep)] - np.outer(Sinv[keep, pos], Sinv[pos, keep]) / Sinv[pos, pos]
+        j = W.pop(pos)
+        del side[j]
+        lam[j] = 0.0
+
+    def face():
+        if W:
+            b = np.array([hi[j] if side[j] >= 0 else lo[j] for j in W])
+            lam[:] = 0.0
+            lam[W] = Sinv @ (s0[W] - b)
+            return s0 - Ghat[:, W] @ lam[W]
+        lam[:] = 0.0
+        return s0.copy()
+
+    # equality rows are always in the working set; then the warm-start guess
+    for j in np.flatnonzero(eq):
+        add(int(j), 0)
+    if W0 is not None:
+        for j, sd in zip(W0, side0):
+            if j not in side:
+                add(int(j), int(sd))
+    s = face()
+    # restore dual feasibility of the guess: drop wrong-sign multipliers (worst first)
+    it = 0
+    while True:
+        viol = [(-lam[j] if side[j] > 0 else lam[j]) if side[j] != 0 else -np.inf for j in W]
+        if not W or max(viol) <= 1e-12 * max(1.0, np.max(np.abs(lam))):
+            break
+        remove(int(np.argmax(viol)))
+        s = face()
+        it += 1
+    status = 1
+    while it < max_iter:
+        it += 1
+        inW = np.zeros(R, dtype=bool)
+        inW[W] = True
+        viol = np.where(inW, -np.inf, np.maximum(s - hi, lo - s) / gn)
+        p_ = int(np.argmax(viol))
+        if viol[p_] <= tol:
+            status = 0
+            break
+        sd = 1 if s[p_] > hi[p_] else -1
+        bp = hi[p_] if sd > 0 else lo[p_]
+        lam_p = 0.0
+        while True:  # partial steps until row p can be added (or infeasibility shows)
+            c = Ghat[W, p_]
+            r = Sinv @ c if W else np.zeros(0)
+            dvec = Ghat[:, p_] - (Ghat[:, W] @ r if W else 0.0)
+            dp = Ghat[p_, p_] - (c @ r if W else 0.0)
+            dependent = dp <= 1e-12 * Ghat[p_, p_]
+            tau2 = np.inf * sd if dependent else (s[p_] - bp) / dp
+            # multipliers that would change sign on the way: lam_i - r_i tau = 0
+            tau1, blk = np.inf, -1
+            for i, j in enumerate(W):
+                if side[j] == 0 or r[i] == 0.0:
+                    continue
+                ti = lam[j] / r[i]
+                if ti * sd > 0 and abs(ti) < tau1 or (lam[j] == 0.0 and r[i] * sd * side[j] > 0 and tau1 > 0):
+                    if lam[j] == 0.0:
+                        tau1, blk = 0.0, i
+                    else:
+                        tau1, blk = abs(ti), i
+            if dependent and blk < 0:
+                return dict(s=s, lam=lam, W=list(W), iters=it, status=3)
+            if tau1 < abs(tau2):  # partial step, drop the blocking row, try again
+                tau = sd * tau1
+                if not dependent:
+                    s = s - tau * dvec
+                lam[W] = lam[W] - tau * r
+                lam_p += tau
+                remove(blk)
+                it += 1
+                if it >= max_iter:
+                    break
+                continue
+            tau = tau2
+            s = s - tau * dvec
+            lam[W] = lam[W] - tau * r
+            lam_p += tau
+            add(p_, sd)
+            lam[p_] = lam_p
+            s[p_] = bp
+            break
+    return dict(s=s, lam=lam, W=list(W), iters=it, status=status)
+
+
+def solve_mpc_exact(p: MPCProblem, x0, return_info=False):
+    """One MPC step, exact (KKT-certified).  Box-only problems: primal active set on the condensed QP.  With the
+    state box and/or the terminal equality: dual active set in constraint space (`solve_qp_dual_active_set`),
+    certified by `kkt_general`.  Raises ValueError if the problem is infeasible (the reference would throw from
+    JuMP.value)."""
+    if p.x_min is None and p.terminal == "none":
+        H, f, lo, hi = condensed_qp(p, x0)
+        v = solve_box_qp_exact(H, f, lo, hi)
+        out = rollout(p, x0, v)
+        out["v"] = v
+        return out
+    if p.terminal not in ("none", "equality"):
+        raise NotImplementedError(f"terminal ingredient {p.terminal!r} is not a QP constraint")
+    x0 = np.asarray(x0, dtype=np.float64)
+    if p.x_min is not None and (np.any(x0 < p.x_min) or np.any(x0 > p.x_max)):
+        raise ValueError("infeasible: x[:,1] = x0 violates the state box (..linear.jl:62-70 constrains stage 1 too)")
     H, f, lo, hi = condensed_qp(p, x0)
-    v = solve_box_qp_exact(H, f, lo, hi)
+    d = jacobi_scaling(H)
+    Hs = H * d[:, None] * d[None, :]
+    cr = constraint_rows(p, d)
+    e0 = x0 - p.x_ref[:, 0]
+    A = np.vstack([np.eye(p.nz), cr["C"]])
+    G = np.linalg.inv(Hs)
+    Ghat = A @ G @ A.T
+    v0 = -G @ (f * d)
+    s0 = A @ v0 + np.concatenate([np.zeros(p.nz), cr["Phi"] @ e0])
+    lo_r = np.concatenate([lo / d, cr["lo_c"]])
+    hi_r = np.concatenate([hi / d, cr["hi_c"]])
+    eq = np.concatenate([np.zeros(p.nz, dtype=bool), cr["eq"]])
+    r = solve_qp_dual_active_set(Ghat, s0, lo_r, hi_r, eq)
+    if r["status"] == 3:
+        raise ValueError("infeasible QP")
+    w = r["s"][:p.nz]
+    res = kkt_general(Hs, f * d, A, s0 - A @ v0, lo_r, hi_r, w, r["lam"])
+    if r["status"] != 0 or res > 1e-7 * max(1.0, float(np.max(np.abs(f * d)))):
+        raise RuntimeError(f"general exact solver did not certify: status {r['status']}, KKT residual {res:g}")
+    v = np.clip(w * d, lo, hi)
     out = rollout(p, x0, v)
     out["v"] = v
+    if return_info:
+        out["info"] = dict(n_active_state=int(sum(1 for j in r["W"] if j >= p.nz)), iters=r["iters"], W=r["W"])
     return out
+
+
+def kkt_general(Hs, fs, A, a0, lo, hi, w, lam):
+    """Method-independent optimality certificate for  min 1/2 w'Hs w + fs'w  s.t. lo <= A w + a0 <= hi :
+    max of stationarity |Hs w + fs + A'lam|_inf, primal violation, and complementarity/sign violation of lam."""
+    s = A @ w + a0
+    stat = np.max(np.abs(Hs @ w + fs + A.T @ lam))
+    prim = max(0.0, float(np.max(s - hi)), float(np.max(lo - s)))
+    at_hi = np.isclose(s, hi, rtol=0, atol=1e-9 * (1 + np.abs(hi)))
+    at_lo = np.isclose(s, lo, rtol=0, atol=1e-9 * (1 + np.abs(lo)))
+    sign = 0.0
+    for i in range(lam.size):
+        if lam[i] > 0 and not at_hi[i]:
+            sign = max(sign, lam[i])
+        if lam[i] < 0 and not at_lo[i]:
+            sign = max(sign, -lam[i])
+    return float(max(stat, prim, sign))
 
 
 # --------------------------------------------------------------------------------------

@@ -260,8 +260,11 @@ def test_api_error_behaviour(capi, mo):
         s.calculate()
     assert ei.value.code == -5  # not designed
     with pytest.raises(capi.AlmpcError) as ei:
-        s.design_shared(p.A, p.B, p.Q, p.R, None, None, p.u_min, p.u_max, xmin=[-1, -1], xmax=[1, 1])
-    assert ei.value.code == -4  # state box not built
+        s.design_shared(p.A, p.B, p.Q, p.R, None, None, p.u_min, p.u_max, xmin=[-1, -1])
+    assert ei.value.code == -1  # xmin without xmax
+    with pytest.raises(capi.AlmpcError) as ei:
+        s.design_shared(p.A, p.B, p.Q, p.R, None, None, p.u_min, p.u_max, xmin=[1, 1], xmax=[-1, -1])
+    assert ei.value.code == -1
     with pytest.raises(capi.AlmpcError) as ei:
         s.design_shared(p.A, p.B, p.Q, p.R, None, None, [1.0], [-1.0])
     assert ei.value.code == -1
@@ -278,6 +281,95 @@ def test_api_error_behaviour(capi, mo):
     s.calculate()
     assert np.all(s.get_results()["status"] == 0)
     s.close()
+
+
+# ---------------------------------------------------------------------------- state rows: state box, terminal equality
+def _constrained_problems(mo):
+    A, B = [[1.0, 1.0], [0.0, 1.0]], [[0.5], [1.0]]
+    q = mo.quadrotor()
+    xm = np.array([50, 50, 50, 1.0, 1.0, 1.0, 0.3, 0.3, 0.3, 2, 2, 2.0])
+    return {
+        "di_box": (mo.make_problem(A, B, 10, [-1.0], [1.0], x_min=[-10.0, -0.8], x_max=[10.0, 0.8]),
+                   np.array([[5.0, 0.0], [-6.0, 0.5], [1.0, 0.0], [0.0, 0.0], [20.0, 0.0], [3.0, 0.7], [0.0, 0.9]])),
+        "di_eq": (mo.make_problem(A, B, 10, [-1.0], [1.0], terminal="equality"),
+                  np.array([[2.0, 0.0], [1.0, -0.5], [30.0, 0.0], [0.0, 0.0]])),
+        "di_box_eq": (mo.make_problem(A, B, 10, [-1.0], [1.0], x_min=[-10.0, -0.8], x_max=[10.0, 0.8], terminal="equality"),
+                      np.array([[2.0, 0.0], [1.0, -0.5], [3.0, 0.5], [0.0, 0.0]])),
+        "quad_box": (mo.make_problem(q.A, q.B, 30, q.u_min, q.u_max, x_min=-xm, x_max=xm),
+                     np.concatenate([mo.quadrotor_x0_batch(40, 1.0), mo.quadrotor_x0_batch(24, 0.5, first_instance=500)])),
+        "quad_eq": (mo.make_problem(q.A, q.B, 30, q.u_min, q.u_max, terminal="equality"), mo.quadrotor_x0_batch(24, 0.1)),
+    }
+
+
+@pytest.mark.parametrize("name", ["di_box", "di_eq", "di_box_eq", "quad_box", "quad_eq"])
+def test_state_rows_vs_exact_oracle(capi, mo, name):
+    """State box (kw mpc_state_constraint, ..linear.jl:62-70) and terminal equality (src/sub/design_mpc.jl:330-331):
+    solved instances match the KKT-certified oracle; infeasible ones (x0 outside the box, unreachable terminal set)
+    are reported as ALMPC_INFEASIBLE exactly where the oracle finds no feasible point."""
+    p, X0 = _constrained_problems(mo)[name]
+    s = capi.Solver(p.n, p.m, p.N, len(X0))
+    s.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max, xmin=p.x_min, xmax=p.x_max, terminal=p.terminal)
+    s.set_reference(p.x_ref, p.u_ref)
+    s.update_initialization(X0)
+    s.debug_poison_lds()
+    s.calculate()
+    r = s.get_results()
+    s.close()
+    n_state_active = 0
+    for i in range(len(X0)):
+        try:
+            e = mo.solve_mpc_exact(p, X0[i], return_info=True)
+        except ValueError:
+            assert r["status"][i] == 3
+            continue
+        assert r["status"][i] == 0
+        assert np.abs(r["u"][i] - e["u"]).max() <= U_TOL and np.abs(r["x"][i] - e["x"]).max() <= X_TOL
+        n_state_active += e["info"]["n_active_state"]
+        if p.x_min is not None:
+            assert np.all(r["x"][i] <= p.x_max[:, None] + 1e-9) and np.all(r["x"][i] >= p.x_min[:, None] - 1e-9)
+        if p.terminal == "equality":
+            assert np.abs(r["e_x"][i][:, -1]).max() <= 1e-9
+    assert n_state_active > 0, "test inputs never activate a state row"
+
+
+def test_state_rows_need_polish(capi, mo):
+    p, X0 = _constrained_problems(mo)["di_box"]
+    s = capi.Solver(2, 1, 10, len(X0))
+    s.design_shared(p.A, p.B, p.Q, p.R, None, None, p.u_min, p.u_max, xmin=p.x_min, xmax=p.x_max)
+    s.update_initialization(X0)
+    with pytest.raises(capi.AlmpcError) as ei:
+        s.calculate(capi.default_opts(polish=0))
+    assert ei.value.code == -4
+    s.close()
+
+
+def test_state_constraint_mirror(pkg, mo):
+    """Host mirror: the state box exists only if kw mpc_state_constraint is PRESENT; terminal "equality"; an
+    infeasible instance raises like JuMP.value would."""
+    p, X0 = _constrained_problems(mo)["di_box"]
+    sys_ = pkg.ConstrainedLinearControlDiscreteSystem(p.A, p.B, pkg.Hyperrectangle(p.x_min, p.x_max), pkg.Hyperrectangle(p.u_min, p.u_max))
+    C = pkg.proceed_controller(sys_, "model_predictive_control", 10, 1, [0.0, 0.0], [0.0], mpc_state_constraint=True)
+    pkg.update_initialization(C, [5.0, 0.0])
+    pkg.calculate(C)
+    e = mo.solve_mpc_exact(p, np.array([5.0, 0.0]))
+    assert np.abs(C.computation_results.u - e["u"]).max() <= U_TOL
+    assert C.computation_results.x[1].min() >= -0.8 - 1e-9
+    pkg.update_initialization(C, [20.0, 0.0])  # outside the state box: stage 1 is constrained too
+    with pytest.raises(ArithmeticError):
+        pkg.calculate(C)
+    C.tuning.modeler.solver.close()
+    # without the kw the same system has no state rows (the reference reads only the presence of the key)
+    C2 = pkg.proceed_controller(sys_, "model_predictive_control", 10, 1, [0.0, 0.0], [0.0])
+    pkg.update_initialization(C2, [5.0, 0.0])
+    pkg.calculate(C2)
+    assert C2.computation_results.x[1].min() < -0.8
+    C2.tuning.modeler.solver.close()
+    C3 = pkg.proceed_controller(sys_, "model_predictive_control", 10, 1, [0.0, 0.0], [0.0], mpc_terminal_ingredient="equality")
+    assert C3.tuning.terminal_ingredient.Xf == "equality"
+    pkg.update_initialization(C3, [2.0, 0.0])
+    pkg.calculate(C3)
+    assert np.abs(C3.computation_results.e_x[:, -1]).max() <= 1e-9
+    C3.tuning.modeler.solver.close()
 
 
 # ---------------------------------------------------------------------------- host mirror of the reference API

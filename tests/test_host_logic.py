@@ -35,8 +35,7 @@ def test_proceed_controller_argument_errors(pkg):
         pkg.proceed_controller(s, "model_predictive_control", 10, 1, [0, 0], [0], mpc_solver="highs")
     with pytest.raises(KeyError):
         pkg.proceed_controller(s, "model_predictive_control", 10, 1, [0, 0], [0], mpc_programming_type="quadratic")
-    for kw in (dict(mpc_solver="osqp"), dict(mpc_programming_type="non_linear"), dict(mpc_terminal_ingredient="equality"),
-               dict(mpc_state_constraint=True)):
+    for kw in (dict(mpc_solver="osqp"), dict(mpc_programming_type="non_linear"), dict(mpc_terminal_ingredient="contractive")):
         with pytest.raises(NotImplementedError):
             pkg.proceed_controller(s, "model_predictive_control", 10, 1, [0, 0], [0], **kw)
 

@@ -138,6 +138,46 @@ def test_kkt_certificate_detects_wrong_point(mo):
     assert mo.kkt_residual(H, f, lo, hi, v + 1e-3) > 1e-4
 
 
+# ---------------------------------------------------------------------------- state rows (state box, terminal equality)
+@pytest.mark.parametrize("case,x0", [("box", [5.0, 0.0]), ("box", [-6.0, 0.5]), ("box", [1.0, 0.0]), ("eq", [2.0, 0.0]),
+                                     ("eq", [1.0, -0.5]), ("box_eq", [3.0, 0.5])])
+def test_state_rows_exact_equals_sparse_statement(mo, case, x0):
+    """Dual active set in constraint space vs the reference's own sparse statement (with its state-box rows,
+    ..linear.jl:62-70, and terminal equality rows, src/sub/design_mpc.jl:330-331) solved by the OSQP restatement."""
+    kw = dict(box=dict(x_min=[-10.0, -0.8], x_max=[10.0, 0.8]), eq=dict(terminal="equality"),
+              box_eq=dict(x_min=[-10.0, -0.8], x_max=[10.0, 0.8], terminal="equality"))[case]
+    p = mo.make_problem([[1.0, 1.0], [0.0, 1.0]], [[0.5], [1.0]], 10, [-1.0], [1.0], **kw)
+    x0 = np.array(x0)
+    e = mo.solve_mpc_exact(p, x0, return_info=True)
+    sp = mo.sparse_problem(p, x0)
+    r = mo.osqp_admm(sp["P"], sp["q"], sp["A"], sp["l"], sp["u"], eps_abs=1e-10, eps_rel=1e-10, max_iter=200000)
+    assert r["status"] == 0
+    u_sparse = r["x"][sp["idx"]["u"]:sp["idx"]["u"] + 10].reshape(10, 1).T
+    assert np.abs(u_sparse - e["u"]).max() <= 1e-6
+    if case != "eq":
+        assert np.all(e["x"][1] >= -0.8 - 1e-10) and np.all(e["x"][1] <= 0.8 + 1e-10)
+    if case != "box":
+        assert np.abs(e["e_x"][:, -1]).max() <= 1e-10
+
+
+def test_state_rows_infeasible_cases(mo):
+    p = mo.make_problem([[1.0, 1.0], [0.0, 1.0]], [[0.5], [1.0]], 10, [-1.0], [1.0], x_min=[-10.0, -0.8], x_max=[10.0, 0.8])
+    with pytest.raises(ValueError):
+        mo.solve_mpc_exact(p, np.array([20.0, 0.0]))   # x0 outside the box: stage 1 is constrained too
+    with pytest.raises(ValueError):
+        mo.solve_mpc_exact(p, np.array([9.9, 0.8]))    # inside now, but cannot stay inside
+    pe = mo.make_problem([[1.0, 1.0], [0.0, 1.0]], [[0.5], [1.0]], 10, [-1.0], [1.0], terminal="equality")
+    with pytest.raises(ValueError):
+        mo.solve_mpc_exact(pe, np.array([30.0, 0.0]))  # origin not reachable in N steps with |u| <= 1
+
+
+def test_state_box_inactive_equals_box_only(mo):
+    q = mo.quadrotor()
+    qb = mo.make_problem(q.A, q.B, 30, q.u_min, q.u_max, x_min=-1e3 * np.ones(12), x_max=1e3 * np.ones(12))
+    x0 = mo.quadrotor_x0_batch(1, 3.0)[0]
+    np.testing.assert_allclose(mo.solve_mpc_exact(qb, x0)["u"], mo.solve_mpc_exact(q, x0)["u"], atol=1e-8)
+
+
 # ---------------------------------------------------------------------------- golden vectors
 @pytest.mark.parametrize("name", ["double_integrator", "double_integrator_S", "qtp_linear", "quadrotor"])
 def test_golden_vectors(mo, name):
