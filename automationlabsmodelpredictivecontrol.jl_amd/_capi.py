@@ -70,6 +70,10 @@ def load():
     L.almpc_get_timing.argtypes = [_hp, _fp, _fp, _fp, _fp]
     L.almpc_timing_reset.argtypes = [_hp, ctypes.c_int]
     L.almpc_debug_poison_lds.argtypes = [_hp]
+    L.almpc_dare.argtypes = [ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, _dp]
+    L.almpc_dare.restype = ctypes.c_int
+    L.almpc_fnn_linearize.argtypes = [ctypes.c_int] * 6 + [_dp] * 4 + [ctypes.c_int] + [_dp] * 5
+    L.almpc_fnn_linearize.restype = ctypes.c_int
     L.almpc_debug_poison_lds.restype = ctypes.c_int
     L.almpc_timing_summary.argtypes = [_hp, ctypes.POINTER(ctypes.c_int)] + [_dp] * 4
     for name in ("almpc_create", "almpc_design_shared", "almpc_set_reference", "almpc_update_initialization",
@@ -100,6 +104,41 @@ def _colmajor(a, shape=None):
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(_dp)
+
+
+def dare(A, B, Q, R):
+    """P = DARE(A, B, Q, R) through the library (host code, as ControlSystems.are at src/sub/design_mpc.jl:327)."""
+    L = load()
+    A, B = np.asfortranarray(A, dtype=np.float64), np.asfortranarray(B, dtype=np.float64)
+    n, m = B.shape
+    Q, R = _colmajor(Q, (n, n)), _colmajor(R, (m, m))
+    P = np.empty((n, n), order="F")
+    rc = L.almpc_dare(n, m, _ptr(A), _ptr(B), _ptr(Q), _ptr(R), _ptr(P))
+    if rc != ALMPC_OK:
+        raise AlmpcError(rc, "almpc_dare")
+    return P
+
+
+def fnn_linearize(W_in, W_h, b_h, W_out, x, u, act="relu", device=0, want_f=False):
+    """Batched Jacobians of an Fnn model on the GPU: x (batch, n), u (batch, m) -> A (batch, n, n), B (batch, n, m)."""
+    L = load()
+    W_in, W_out = np.asfortranarray(W_in, dtype=np.float64), np.asfortranarray(W_out, dtype=np.float64)
+    H, nin = W_in.shape
+    n = W_out.shape[0]
+    m = nin - n
+    nl = len(W_h)
+    Wh = np.ascontiguousarray(np.stack([np.asfortranarray(W, dtype=np.float64).T for W in W_h])) if nl else np.zeros((1, 1, 1))
+    bh = np.ascontiguousarray(np.stack([np.asarray(b, dtype=np.float64) for b in b_h])) if nl else np.zeros((1, 1))
+    x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.float64)
+    u = np.ascontiguousarray(np.atleast_2d(u), dtype=np.float64)
+    batch = x.shape[0]
+    A = np.empty((batch, n, n)); B = np.empty((batch, m, n)); f = np.empty((batch, n)) if want_f else None
+    rc = L.almpc_fnn_linearize(int(device), n, m, H, nl, {"identity": 0, "relu": 1}[act], _ptr(W_in), _ptr(Wh), _ptr(bh), _ptr(W_out),
+                               batch, _ptr(x), _ptr(u), _ptr(A), _ptr(B), _ptr(f))
+    if rc != ALMPC_OK:
+        raise AlmpcError(rc, "almpc_fnn_linearize")
+    A, B = A.transpose(0, 2, 1), B.transpose(0, 2, 1)  # column-major buffers -> (batch, row, col)
+    return (A, B, f) if want_f else (A, B)
 
 
 class Solver:

@@ -29,7 +29,8 @@ from . import _capi
 from .sharding import shard_range  # noqa: F401  (re-exported)
 
 __all__ = [
-    "Hyperrectangle", "ConstrainedLinearControlDiscreteSystem", "ReferencesStateInput", "WeightsCoefficient",
+    "Hyperrectangle", "ConstrainedLinearControlDiscreteSystem", "ConstrainedBlackBoxControlDiscreteSystem", "Fnn",
+    "proceed_system_linearization", "ReferencesStateInput", "WeightsCoefficient",
     "TerminalIngredient", "ModelPredictiveControlTuning", "ModelPredictiveControlResults",
     "ModelPredictiveControlController", "proceed_controller", "_design_reference_mpc",
     "_model_predictive_control_design", "_create_weights_coefficients", "update_initialization", "calculate",
@@ -63,6 +64,39 @@ class ConstrainedLinearControlDiscreteSystem:
         n, m = self.B.shape
         if self.A.shape != (n, n) or self.X.low.shape != (n,) or self.U.low.shape != (m,):
             raise ValueError("ConstrainedLinearControlDiscreteSystem: inconsistent dimensions")
+
+
+@dataclasses.dataclass
+class Fnn:
+    """Feed-forward network in the layout the reference reads from Flux.params
+    (src/sub/model_modeler_implementation/fnn/mpc_modeler_implementation_fnn.jl:88-107): W_in H x (n+m) (no bias, no
+    activation), hidden layers (W_h[l], b_h[l]) with activation `act` ("relu" | "identity"), W_out n x H (no bias).
+    Also the model tag AutomationLabsSystems.Fnn() of src/sub/design_mpc.jl:176."""
+    W_in: np.ndarray
+    W_h: list
+    b_h: list
+    W_out: np.ndarray
+    act: str = "relu"
+
+
+@dataclasses.dataclass
+class ConstrainedBlackBoxControlDiscreteSystem:
+    """Stand-in for MathematicalSystems.ConstrainedBlackBoxControlDiscreteSystem(f, statedim, inputdim, X, U)."""
+    f: Fnn
+    statedim: int
+    inputdim: int
+    X: Hyperrectangle
+    U: Hyperrectangle
+
+
+def proceed_system_linearization(system: ConstrainedBlackBoxControlDiscreteSystem, state, input, device: int = 0):
+    """AutomationLabsSystems.proceed_system_linearization(system, x, u) (call sites: .../fnn/...:42-46,
+    src/sub/design_mpc.jl:319-326): the linear system (A, B) = Jacobians of f at (x, u), same constraint sets.
+    Computed on the GPU (k_fnn_jacobian)."""
+    f = system.f
+    A, B = _capi.fnn_linearize(f.W_in, f.W_h, f.b_h, f.W_out, np.asarray(state, dtype=np.float64).reshape(1, -1),
+                               np.asarray(input, dtype=np.float64).reshape(1, -1), act=f.act, device=device)
+    return ConstrainedLinearControlDiscreteSystem(A[0], B[0], system.X, system.U)
 
 
 # ---- structs of src/types/types.jl ------------------------------------------------------------------------
@@ -161,8 +195,33 @@ def proceed_controller(system, mpc_controller_type: str, mpc_horizon: int, mpc_s
     return None
 
 
-def _model_predictive_control_design(system: ConstrainedLinearControlDiscreteSystem, horizon: int, sample_time: int,
-                                     references: ReferencesStateInput, **kws_):
+def _model_predictive_control_design(system, horizon: int, sample_time: int, references: ReferencesStateInput, **kws_):
+    if isinstance(system, ConstrainedBlackBoxControlDiscreteSystem):
+        return _design_blackbox(system, horizon, sample_time, references, **kws_)
+    return _design_linear(system, horizon, sample_time, references, **kws_)
+
+
+def _design_blackbox(system: ConstrainedBlackBoxControlDiscreteSystem, horizon: int, sample_time: int,
+                     references: ReferencesStateInput, **kws_):
+    """Black-box (Fnn) model, LinearProgramming branch (src/sub/design_mpc.jl:143-225 ->
+    .../fnn/mpc_modeler_implementation_fnn.jl:23-58): dynamics linearised at the FIRST reference, terminal weight
+    P = DARE at the linearisation about the LAST reference (src/sub/design_mpc.jl:312-327), then the linear path."""
+    kws = _kws(kws_)
+    if not isinstance(system.f, Fnn):
+        raise NotImplementedError("only the Fnn model family is built (SURVEY.md section 2, components 8-14 are out of scope)")
+    dev = int(kws.get("mpc_device", 0))
+    x_ref, u_ref = np.asarray(references.x, dtype=np.float64), np.asarray(references.u, dtype=np.float64)
+    lin_first = proceed_system_linearization(system, x_ref[:, 0], u_ref[:, 0], device=dev)
+    lin_last = proceed_system_linearization(system, x_ref[:, -1], u_ref[:, -1], device=dev)
+    weights = _create_weights_coefficients(lin_first, kws=kws)
+    P = _capi.dare(lin_last.A, lin_last.B, weights.Q, weights.R)
+    C = _design_linear(lin_first, horizon, sample_time, references, kws=kws, _terminal_P=P)
+    C.system = system
+    return C
+
+
+def _design_linear(system: ConstrainedLinearControlDiscreteSystem, horizon: int, sample_time: int,
+                   references: ReferencesStateInput, _terminal_P=None, **kws_):
     """Design for the discrete linear system (src/sub/design_mpc.jl:54-129).  Extra keys of this build:
     mpc_batch (instances sharing this design, default 1), mpc_device (HIP device id, default 0),
     mpc_solver_options (dict of almpc_opts fields), mpc_timing (bool)."""
@@ -201,7 +260,7 @@ def _model_predictive_control_design(system: ConstrainedLinearControlDiscreteSys
     solver = _capi.Solver(n, m, horizon, batch, device=int(kws.get("mpc_device", 0)), timing=bool(kws.get("mpc_timing", False)))
     # bounds as the reference reads them: low = last vertex, high = first vertex of the hyperrectangle
     # (..linear.jl:34-38); P = DARE at the (linear) system (src/sub/design_mpc.jl:327), computed in the library.
-    solver.design_shared(system.A, system.B, weights.Q, weights.R, weights.S, None, system.U.low, system.U.high,
+    solver.design_shared(system.A, system.B, weights.Q, weights.R, weights.S, _terminal_P, system.U.low, system.U.high,
                          xmin=system.X.low if state_box else None, xmax=system.X.high if state_box else None,
                          rho=rho, sigma=sigma, terminal="equality" if terminal == "equality" else "none")
     solver.set_reference(x_ref, u_ref)
@@ -219,7 +278,7 @@ def update_initialization(C: ModelPredictiveControlController, initialization) -
     """update_initialization!(C, x0): x0 of length n (batch 1) or shape (batch, n)."""
     mod: HipModeler = C.tuning.modeler
     x0 = np.asarray(initialization, dtype=np.float64)
-    n = C.system.A.shape[0]
+    n = C.tuning.modeler.solver.n
     if x0.size != mod.batch * n:
         raise ValueError(f"initialization must hold {mod.batch} x {n} values")
     C.initialization = x0.reshape((n,) if mod.batch == 1 else (mod.batch, n)).copy()

@@ -7,6 +7,7 @@
 #include "almpc_kernels.hip.h"
 #include "almpc_design.hip.h"
 #include "almpc_polish_gen.hip.h"
+#include "almpc_fnn.hip.h"
 #include "almpc_host_math.h"
 #include "../../include/almpc.h"
 
@@ -537,6 +538,60 @@ int almpc_get_timing(almpc_handle* h, float* ms_admm, float* ms_polish, float* m
     if (ms_rollout) *ms_rollout = r;
     if (ms_total) *ms_total = t;
     return ALMPC_OK;
+}
+
+int almpc_dare(int n, int m, const double* A, const double* B, const double* Q, const double* R, double* P) {
+    if (n < 1 || m < 1 || !A || !B || !Q || !R || !P) return ALMPC_ERR_INVALID;
+    hm::mat Am(A, A + (size_t)n * n), Bm(B, B + (size_t)n * m), Qm(Q, Q + (size_t)n * n), Rm(R, R + (size_t)m * m), Pm;
+    if (!hm::dare(Am, Bm, Qm, Rm, n, m, Pm)) return ALMPC_ERR_NUMERIC;
+    std::memcpy(P, Pm.data(), (size_t)n * n * sizeof(double));
+    return ALMPC_OK;
+}
+
+int almpc_fnn_linearize(int device_id, int n, int m, int H, int L, int activation, const double* W_in, const double* W_h,
+                        const double* b_h, const double* W_out, int batch, const double* x, const double* u, double* A,
+                        double* B, double* f) {
+    if (n < 1 || m < 1 || H < 1 || L < 0 || batch < 1 || !W_in || !W_out || !x || !u || !A || !B || (L > 0 && (!W_h || !b_h)))
+        return ALMPC_ERR_INVALID;
+    if (activation != 0 && activation != 1) return ALMPC_ERR_UNSUPPORTED;
+    const size_t nin = (size_t)n + m;
+    const size_t lds = (2 * (size_t)H + 2 * (size_t)H * nin + nin) * sizeof(double);
+    if (lds > 160 * 1024) return ALMPC_ERR_UNSUPPORTED;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device_id < 0 || device_id >= count) return ALMPC_ERR_NO_DEVICE;
+    if (hipSetDevice(device_id) != hipSuccess) return ALMPC_ERR_HIP;
+    std::vector<void*> bufs;
+    auto up = [&](const double* src, size_t cnt) -> double* {
+        double* d = nullptr;
+        if (cnt == 0) cnt = 1;
+        if (hipMalloc(reinterpret_cast<void**>(&d), cnt * sizeof(double)) != hipSuccess) return nullptr;
+        bufs.push_back(d);
+        if (src && hipMemcpy(d, src, cnt * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        return d;
+    };
+    FnnParams p;
+    p.n = n; p.m = m; p.H = H; p.L = L; p.act = activation; p.batch = batch;
+    p.W_in = up(W_in, (size_t)H * nin); p.W_h = up(W_h, (size_t)L * H * H); p.b_h = up(b_h, (size_t)L * H);
+    p.W_out = up(W_out, (size_t)n * H); p.x = up(x, (size_t)batch * n); p.u = up(u, (size_t)batch * m);
+    p.A = up(nullptr, (size_t)batch * n * n); p.B = up(nullptr, (size_t)batch * n * m); p.f = f ? up(nullptr, (size_t)batch * n) : nullptr;
+    int rc = ALMPC_OK;
+    if (!p.W_in || !p.W_h || !p.b_h || !p.W_out || !p.x || !p.u || !p.A || !p.B || (f && !p.f)) rc = ALMPC_ERR_HIP;
+    if (rc == ALMPC_OK) {
+        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k_fnn_jacobian),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) rc = ALMPC_ERR_HIP;
+    }
+    if (rc == ALMPC_OK) {
+        hipLaunchKernelGGL(k_fnn_jacobian, dim3(batch), dim3(256), lds, 0, p);
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = ALMPC_ERR_HIP;
+    }
+    if (rc == ALMPC_OK) {
+        if (hipMemcpy(A, p.A, (size_t)batch * n * n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(B, p.B, (size_t)batch * n * m * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+            (f && hipMemcpy(f, p.f, (size_t)batch * n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess))
+            rc = ALMPC_ERR_HIP;
+    }
+    for (void* b : bufs) (void)hipFree(b);
+    return rc;
 }
 
 int almpc_debug_poison_lds(almpc_handle* h) {

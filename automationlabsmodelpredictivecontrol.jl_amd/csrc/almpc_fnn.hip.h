@@ -1,0 +1,80 @@
+// almpc_fnn.hip.h -- batched linearisation of a black-box Fnn model (forward value + Jacobian per instance).
+//
+// Stands in for AutomationLabsSystems.proceed_system_linearization(system, x, u) (third-party, not in /root/reference;
+// call sites: src/sub/model_modeler_implementation/fnn/mpc_modeler_implementation_fnn.jl:42-46,
+// src/sub/design_mpc.jl:319-326), for the Fnn layout the reference reads from Flux.params (.../fnn/...:88-107, 127-144):
+//     y1 = W_in [x;u] (no bias, no activation);  yj = act(W_h[j-2] y(j-1) + b_h[j-2]);  x+ = W_out y(L+1) (no bias).
+// One workgroup (256 threads) per linearisation point; the H x (n+m) forward-mode Jacobian lives in LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace almpc {
+
+struct FnnParams {
+    int n, m, H, L, act;  // act: 0 identity, 1 relu
+    const double* W_in;   // H x (n+m) column-major
+    const double* W_h;    // [L] H x H column-major
+    const double* b_h;    // [L] H
+    const double* W_out;  // n x H column-major
+    int batch;
+    const double* x;      // [batch][n]
+    const double* u;      // [batch][m]
+    double* A;            // [batch] n x n column-major
+    double* B;            // [batch] n x m column-major
+    double* f;            // [batch][n] or null
+};
+
+__global__ __launch_bounds__(256) void k_fnn_jacobian(FnnParams p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int n = p.n, m = p.m, H = p.H, nin = n + m;
+    double* y = smem;             // [H]
+    double* yn = y + H;           // [H]
+    double* J = yn + H;           // [H][nin]  (row-major: J[i*nin + c])
+    double* Jn = J + (size_t)H * nin;
+    double* z = Jn + (size_t)H * nin;  // [nin]
+    const int inst = blockIdx.x;
+    for (int t = threadIdx.x; t < nin; t += blockDim.x) z[t] = t < n ? p.x[(size_t)inst * n + t] : p.u[(size_t)inst * m + (t - n)];
+    __syncthreads();
+    for (int i = threadIdx.x; i < H; i += blockDim.x) {
+        double s = 0.0;
+        for (int c = 0; c < nin; ++c) s += p.W_in[(size_t)c * H + i] * z[c];
+        y[i] = s;
+    }
+    for (int t = threadIdx.x; t < H * nin; t += blockDim.x) J[t] = p.W_in[(size_t)(t % nin) * H + t / nin];
+    __syncthreads();
+    for (int l = 0; l < p.L; ++l) {
+        const double* W = p.W_h + (size_t)l * H * H;
+        const double* b = p.b_h + (size_t)l * H;
+        for (int i = threadIdx.x; i < H; i += blockDim.x) {
+            double s = b[i];
+            for (int j = 0; j < H; ++j) s += W[(size_t)j * H + i] * y[j];
+            yn[i] = s;  // pre-activation
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < H * nin; t += blockDim.x) {
+            const int i = t / nin, c = t % nin;
+            double s = 0.0;
+            for (int j = 0; j < H; ++j) s += W[(size_t)j * H + i] * J[(size_t)j * nin + c];
+            Jn[t] = (p.act == 1 && !(yn[i] > 0.0)) ? 0.0 : s;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < H; i += blockDim.x) y[i] = (p.act == 1) ? fmax(yn[i], 0.0) : yn[i];
+        for (int t = threadIdx.x; t < H * nin; t += blockDim.x) J[t] = Jn[t];
+        __syncthreads();
+    }
+    for (int t = threadIdx.x; t < n * nin; t += blockDim.x) {
+        const int i = t % n, c = t / n;
+        double s = 0.0;
+        for (int j = 0; j < H; ++j) s += p.W_out[(size_t)j * n + i] * J[(size_t)j * nin + c];
+        if (c < n) p.A[(size_t)inst * n * n + (size_t)c * n + i] = s;
+        else p.B[(size_t)inst * n * m + (size_t)(c - n) * n + i] = s;
+    }
+    if (p.f)
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            double s = 0.0;
+            for (int j = 0; j < H; ++j) s += p.W_out[(size_t)j * n + i] * y[j];
+            p.f[(size_t)inst * n + i] = s;
+        }
+}
+
+}  // namespace almpc

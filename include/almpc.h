@@ -178,6 +178,26 @@ int almpc_timing_summary(almpc_handle* h, int* steps, double* ms_admm, double* m
                          double* ms_rollout, double* ms_total);
 
 /*
+ * Discrete algebraic Riccati solution P of  A'PA - P - A'PB (R + B'PB)^-1 B'PA + Q = 0  (host, n x n): what
+ * ControlSystems.are(Discrete, A, B, Q, R) returns at src/sub/design_mpc.jl:327.  Exposed because a black-box model takes
+ * its terminal weight from the linearisation at the LAST reference while its dynamics come from the FIRST
+ * (src/sub/design_mpc.jl:312-327 vs .../fnn/mpc_modeler_implementation_fnn.jl:38-46): pass the result as P to the design.
+ */
+int almpc_dare(int n, int m, const double* A, const double* B, const double* Q, const double* R, double* P);
+
+/*
+ * Batched linearisation of a black-box Fnn model on the GPU: for each of `batch` points (x_i, u_i) the Jacobians
+ * A_i = df/dx (n x n), B_i = df/du (n x m), both column-major, and optionally f_i = f(x_i, u_i).  Stands in for
+ * AutomationLabsSystems.proceed_system_linearization (.../fnn/mpc_modeler_implementation_fnn.jl:42-46).  Layout as the
+ * reference reads it from Flux.params (.../fnn/...:88-107): W_in H x (n+m) without bias or activation, L hidden layers
+ * (W_h[l] H x H, b_h[l] H) with `activation` (0 identity, 1 relu), W_out n x H without bias; all column-major.
+ * Host pointers; synchronous.
+ */
+int almpc_fnn_linearize(int device_id, int n, int m, int H, int L, int activation, const double* W_in,
+                        const double* W_h, const double* b_h, const double* W_out, int batch, const double* x,
+                        const double* u, double* A, double* B, double* f);
+
+/*
  * Test hook: overwrite the LDS of every compute unit with NaN bit patterns (a kernel that reads LDS it has not written
  * then produces NaNs instead of passing on stale values).  Synchronous.  Not needed by callers.
  */

@@ -48,6 +48,7 @@ __all__ = [
     "design_shared", "solve_mpc_admm_polish",
     "jacobi_scaling", "decode_linear_regressor_fixture", "splitmix_normal",
     "double_integrator", "quadrotor", "qtp_linear_fixture_problem", "quadrotor_x0_batch",
+    "FnnModel", "synthetic_fnn", "fnn_linear_problem",
 ]
 
 
@@ -844,6 +845,90 @@ def solve_mpc_admm_polish(p: MPCProblem, x0, des=None, rho=0.1, sigma=1e-6, alph
     out = rollout(p, x0, v)
     out.update(v=v, iters=r["iters"], status=r["status"], polish_iters=pit)
     return out
+
+
+# --------------------------------------------------------------------------------------
+# black-box (Fnn) models: linearise, then the linear path   (reference: .../fnn/mpc_modeler_implementation_fnn.jl:23-58)
+# --------------------------------------------------------------------------------------
+@dataclasses.dataclass
+class FnnModel:
+    """Discrete-time model x+ = f(x,u) in the layout the reference reads from Flux.params
+    (.../fnn/mpc_modeler_implementation_fnn.jl:88-107, 127-144):
+        y1 = W_in [x;u]                      (no bias, no activation)
+        yj = act(W_h[j-2] y(j-1) + b_h[j-2]) j = 2..L+1
+        x+ = W_out y(L+1)                    (no bias)
+    act in {"relu", "identity"} (the activation found at f[2][1].sigma, src/sub/design_mpc.jl:472-483)."""
+    W_in: np.ndarray          # H x (n+m)
+    W_h: list                 # L matrices H x H
+    b_h: list                 # L vectors H
+    W_out: np.ndarray         # n x H
+    act: str = "relu"
+
+    def forward(self, x, u):
+        y = self.W_in @ np.concatenate([x, u])
+        for W, b in zip(self.W_h, self.b_h):
+            pre = W @ y + b
+            y = np.maximum(pre, 0.0) if self.act == "relu" else pre
+        return self.W_out @ y
+
+    def jacobian(self, x, u):
+        """(A, B) = d f / d x, d f / d u at (x, u): what AutomationLabsSystems.proceed_system_linearization returns
+        as .A, .B (the package is not in /root/reference; the reference uses only these two fields and ignores the
+        affine offset)."""
+        y = self.W_in @ np.concatenate([x, u])
+        J = self.W_in.copy()
+        for W, b in zip(self.W_h, self.b_h):
+            pre = W @ y + b
+            if self.act == "relu":
+                mask = (pre > 0).astype(np.float64)
+                y = np.maximum(pre, 0.0)
+                J = (W @ J) * mask[:, None]
+            else:
+                y = pre
+                J = W @ J
+        J = self.W_out @ J
+        n = self.W_out.shape[0]
+        return J[:, :n].copy(), J[:, n:].copy()
+
+
+def synthetic_fnn(n=4, m=2, H=16, L=2, seed=0x5EED0004, act="relu"):
+    """BASELINE config 4 model: weights ~ U(-1,1)/sqrt(fan_in) from the SplitMix64 generator
+    (one stream per tensor); W_out is then rescaled so that the Jacobian at the origin has spectral radius 0.95
+    (a slowly decaying plant; unscaled random weights give a radius of 0.04, i.e. nothing to control)."""
+    def uni(stream, shape, fan_in):
+        with np.errstate(over="ignore"):
+            cnt = int(np.prod(shape))
+            state = _mix64(np.uint64(seed & _MASK) + np.uint64(0x632BE59BD9B4E019) * np.uint64(stream + 1))
+            out = np.empty(cnt)
+            gamma = np.uint64(0x9E3779B97F4A7C15)
+            for i in range(cnt):
+                state = state + gamma
+                out[i] = float(_mix64(state) >> np.uint64(11)) * 2.0 ** -53
+        return (2.0 * out.reshape(shape) - 1.0) / math.sqrt(fan_in)
+    W_in = uni(0, (H, n + m), n + m)
+    W_h = [uni(1 + 2 * j, (H, H), H) for j in range(L)]
+    b_h = [0.1 * uni(2 + 2 * j, (H,), H) * math.sqrt(H) for j in range(L)]
+    W_out = uni(100, (n, H), H)
+    model = FnnModel(W_in, W_h, b_h, W_out, act)
+    A0, _ = model.jacobian(np.zeros(n), np.zeros(m))
+    model.W_out = W_out * (0.95 / max(1e-12, float(np.max(np.abs(np.linalg.eigvals(A0))))))
+    return model
+
+
+def fnn_linear_problem(model: FnnModel, N, u_min, u_max, x_ref, u_ref, **kw):
+    """The reference's LinearProgramming branch for a black-box model: dynamics linearised at the FIRST reference
+    (.../fnn/...:38-46), terminal weight from the linearisation at the LAST reference (src/sub/design_mpc.jl:312-327),
+    then exactly the linear path."""
+    x_ref = np.asarray(x_ref, dtype=np.float64)
+    u_ref = np.asarray(u_ref, dtype=np.float64)
+    xr = x_ref.reshape(len(x_ref), -1)
+    ur = u_ref.reshape(len(u_ref), -1)
+    A, B = model.jacobian(xr[:, 0], ur[:, 0])
+    Al, Bl = model.jacobian(xr[:, -1], ur[:, -1])
+    n, m = B.shape
+    q, r = kw.get("q", 100.0), kw.get("r", 0.1)
+    P = dare(Al, Bl, q * np.eye(n), r * np.eye(m))
+    return make_problem(A, B, N, u_min, u_max, x_ref=x_ref, u_ref=u_ref, P=P, **kw)
 
 
 # --------------------------------------------------------------------------------------

@@ -372,6 +372,59 @@ def test_state_constraint_mirror(pkg, mo):
     C3.tuning.modeler.solver.close()
 
 
+# ---------------------------------------------------------------------------- black-box (Fnn) models: BASELINE config 4
+def test_fnn_jacobian_kernel_vs_oracle(capi, mo):
+    """Batched linearisation on the GPU (stand-in for AutomationLabsSystems.proceed_system_linearization) vs the numpy
+    restatement, at random points on both sides of the relu kinks, for relu and identity activations."""
+    for act in ("relu", "identity"):
+        f = mo.synthetic_fnn(act=act)
+        X = mo.splitmix_normal(0x5EED0004, 0, 200, 4) * 2.0
+        U = mo.splitmix_normal(0x5EED0005, 0, 200, 2)
+        A, B, fx = capi.fnn_linearize(f.W_in, f.W_h, f.b_h, f.W_out, X, U, act=act, want_f=True)
+        for i in range(0, 200, 3):
+            Ao, Bo = f.jacobian(X[i], U[i])
+            assert np.abs(A[i] - Ao).max() <= 1e-13 and np.abs(B[i] - Bo).max() <= 1e-13
+            assert np.abs(fx[i] - f.forward(X[i], U[i])).max() <= 1e-13
+    # deeper / wider network, no hidden layer edge case
+    f = mo.synthetic_fnn(n=3, m=1, H=40, L=4)
+    A, B = capi.fnn_linearize(f.W_in, f.W_h, f.b_h, f.W_out, np.ones((2, 3)) * 0.3, np.ones((2, 1)) * -0.2)
+    Ao, Bo = f.jacobian(np.ones(3) * 0.3, np.ones(1) * -0.2)
+    assert np.abs(A[1] - Ao).max() <= 1e-13 and np.abs(B[0] - Bo).max() <= 1e-13
+    f0 = mo.FnnModel(f.W_in, [], [], f.W_out)
+    A, B = capi.fnn_linearize(f0.W_in, [], [], f0.W_out, np.zeros((1, 3)), np.zeros((1, 1)))
+    assert np.abs(A[0] - (f0.W_out @ f0.W_in)[:, :3]).max() <= 1e-12 * np.abs(A[0]).max()
+
+
+def test_config4_fnn_linearised_mpc(pkg, capi, mo):
+    """BASELINE configs[3] in the reference's own semantics: Fnn model, LinearProgramming branch = linearise at the first
+    reference, P from the linearisation at the last reference, then the condensed QP; N = 20, batch = 1024."""
+    f = mo.synthetic_fnn()
+    sys_ = pkg.ConstrainedBlackBoxControlDiscreteSystem(pkg.Fnn(f.W_in, f.W_h, f.b_h, f.W_out, f.act), 4, 2,
+                                                        pkg.Hyperrectangle([-10] * 4, [10] * 4), pkg.Hyperrectangle([-1, -1], [1, 1]))
+    x_ref, u_ref = [0.2, -0.1, 0.05, 0.0], [0.1, -0.2]
+    batch = 1024
+    C = pkg.proceed_controller(sys_, "model_predictive_control", 20, 1, x_ref, u_ref, mpc_batch=batch)
+    p = mo.fnn_linear_problem(f, 20, [-1, -1], [1, 1], x_ref, u_ref)
+    assert np.abs(C.tuning.terminal_ingredient.P - p.P).max() <= 1e-9 * np.abs(p.P).max()
+    X0 = np.asarray(x_ref)[None, :] + mo.splitmix_normal(0x5EED0004, 0, batch, 4) * 2.0
+    res = pkg._model_predictive_control_computation(C, X0)
+    assert res.u.shape == (batch, 2, 20) and res.x.shape == (batch, 4, 21)
+    nact = 0
+    for i in range(0, batch, 16):
+        e = mo.solve_mpc_exact(p, X0[i])
+        assert np.abs(res.u[i] - e["u"]).max() <= U_TOL and np.abs(res.x[i] - e["x"]).max() <= X_TOL
+        nact += ((e["u"] <= -1) | (e["u"] >= 1)).sum()
+    assert nact > 50
+    C.tuning.modeler.solver.close()
+
+
+def test_dare_export(capi, mo, qtp_ab):
+    import scipy.linalg as sla
+    A, B = qtp_ab
+    P = capi.dare(A, B, 100 * np.eye(4), 0.1 * np.eye(2))
+    assert np.abs(P - sla.solve_discrete_are(A, B, 100 * np.eye(4), 0.1 * np.eye(2))).max() <= 1e-9 * np.abs(P).max()
+
+
 # ---------------------------------------------------------------------------- host mirror of the reference API
 def test_proceed_controller_mirror(pkg, mo, qtp_ab):
     """proceed_controller -> update_initialization! -> calculate! with the reference's argument order and result

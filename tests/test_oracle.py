@@ -178,6 +178,19 @@ def test_state_box_inactive_equals_box_only(mo):
     np.testing.assert_allclose(mo.solve_mpc_exact(qb, x0)["u"], mo.solve_mpc_exact(q, x0)["u"], atol=1e-8)
 
 
+def test_fnn_jacobian_matches_finite_differences(mo):
+    for act in ("relu", "identity"):
+        f = mo.synthetic_fnn(act=act)
+        x, u = np.array([0.3, -0.2, 0.1, 0.4]), np.array([0.2, -0.5])
+        A, B = f.jacobian(x, u)
+        eps = 1e-6
+        Afd = np.array([(f.forward(x + eps * np.eye(4)[j], u) - f.forward(x - eps * np.eye(4)[j], u)) / (2 * eps) for j in range(4)]).T
+        Bfd = np.array([(f.forward(x, u + eps * np.eye(2)[j]) - f.forward(x, u - eps * np.eye(2)[j])) / (2 * eps) for j in range(2)]).T
+        assert np.abs(A - Afd).max() <= 1e-8 and np.abs(B - Bfd).max() <= 1e-8
+    A0, _ = mo.synthetic_fnn().jacobian(np.zeros(4), np.zeros(2))
+    assert abs(np.max(np.abs(np.linalg.eigvals(A0))) - 0.95) < 1e-9
+
+
 # ---------------------------------------------------------------------------- golden vectors
 @pytest.mark.parametrize("name", ["double_integrator", "double_integrator_S", "qtp_linear", "quadrotor"])
 def test_golden_vectors(mo, name):
