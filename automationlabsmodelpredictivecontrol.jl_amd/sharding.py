@@ -32,7 +32,8 @@ class Ranks:
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             import torch
             import torch.distributed as dist
-            backend = backend or "nccl"
+            # ALMPC_DIST_BACKEND=gloo lets the multi-process plumbing be exercised on a box with fewer GPUs than ranks
+            backend = os.environ.get("ALMPC_DIST_BACKEND") or backend or "nccl"
             if backend == "nccl":
                 idx = self.local_rank if device_index is None else device_index
                 torch.cuda.set_device(idx)

@@ -67,6 +67,7 @@ def main():
                          "the library default is 25")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-classes", action="store_true")
+    ap.add_argument("--no-pipelined", action="store_true")
     args = ap.parse_args()
 
     import almpc_loader
@@ -82,7 +83,9 @@ def main():
     p = mo.quadrotor(N_HORIZON)
     first, _ = pkg.sharding.shard_range(world * BATCH_PER_GPU, rank, world)
     X0 = make_x0(mo, first, BATCH_PER_GPU)
-    solver = capi.Solver(NX, NU, N_HORIZON, BATCH_PER_GPU, device=local_rank, timing=True)
+    ndev = int(os.environ.get("ALMPC_NUM_DEVICES", "0"))  # test hook: fold ranks onto fewer devices (with ALMPC_DIST_BACKEND=gloo)
+    dev_index = (local_rank % ndev) if ndev > 0 else local_rank
+    solver = capi.Solver(NX, NU, N_HORIZON, BATCH_PER_GPU, device=dev_index, timing=True)
     solver.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max)
     solver.set_reference(p.x_ref, p.u_ref)
     solver.update_initialization(X0)  # x0 resident in HBM from here on
@@ -163,6 +166,29 @@ def main():
         out["u_err_sample"] = f"first {nchk} instances of rank 0 vs oracle exact optimum"
         _, _, Hq, _ = mo.condense(p)
         out["cond_H"] = float(np.linalg.cond(Hq))
+
+    if not args.no_pipelined:
+        # Secondary figure: two INDEPENDENT batches in flight on two handles / HIP streams of this rank (Monte-Carlo use:
+        # batches do not depend on each other), which lets one batch's ADMM fill the CUs left idle by the other's
+        # active-set tail.  Not the headline `value` (a closed loop has one batch in flight).
+        solver2 = capi.Solver(NX, NU, N_HORIZON, BATCH_PER_GPU, device=dev_index)
+        solver2.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max)
+        solver2.set_reference(p.x_ref, p.u_ref)
+        solver2.update_initialization(make_x0(mo, first + world * BATCH_PER_GPU, BATCH_PER_GPU))
+        pair = (solver, solver2)
+        for i in range(2 * max(5, args.warmup // 5)):
+            pair[i & 1].calculate(opts, sync=False)
+        solver.synchronize(); solver2.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            pair[i & 1].calculate(opts, sync=False)
+        solver.synchronize(); solver2.synchronize()
+        barrier()
+        el2 = max_over_ranks(time.perf_counter() - t0)
+        out["two_batches_in_flight"] = {"value": world * args.steps / el2, "unit": "batch-steps/s",
+                                        "note": "independent batches alternated over two handles/streams per GPU"}
+        solver2.close()
 
     if not args.no_classes:
         # per-class rates (each class alone on the whole batch), short runs

@@ -153,6 +153,29 @@ def test_osqp_default_settings_converge(capi, mo):
         assert np.abs(r["u"][i] - mo.solve_mpc_exact(p, X0[i])["u"]).max() <= 0.5  # eps = 1e-3 quality only (cf. the reference's atol = 3)
 
 
+# ---------------------------------------------------------------------------- odd shapes
+@pytest.mark.parametrize("n,m,N", [(1, 1, 1), (1, 1, 7), (3, 2, 7), (5, 3, 9), (2, 1, 128), (7, 5, 25), (16, 8, 16), (20, 1, 40), (64, 2, 3)])
+def test_random_stable_plants_of_many_shapes(capi, mo, n, m, N):
+    """nz = m*N from 1 to 128 (odd values too), n up to 64 (n = 20, 64: the separate rollout kernels): random plants
+    with spectral radius 0.97, bounds tight enough to be active, batch not a multiple of anything."""
+    rng = np.random.default_rng(1000 * n + 10 * m + N)
+    A = rng.standard_normal((n, n))
+    A *= 0.97 / np.max(np.abs(np.linalg.eigvals(A)))
+    B = rng.standard_normal((n, m))
+    p = mo.make_problem(A, B, N, -0.5 * np.ones(m), 0.7 * np.ones(m), x_ref=0.1 * rng.standard_normal(n), u_ref=0.05 * rng.standard_normal(m),
+                        q=10.0, r=1.0, s=0.5 if N > 2 else 0.0)
+    batch = 37
+    X0 = 3.0 * rng.standard_normal((batch, n))
+    r = step(capi, p, X0)
+    assert np.all(r["status"] == 0)
+    nact = 0
+    for i in range(0, batch, 3):
+        e = mo.solve_mpc_exact(p, X0[i])
+        assert np.abs(r["u"][i] - e["u"]).max() <= U_TOL and np.abs(r["x"][i] - e["x"]).max() <= 10 * X_TOL
+        nact += (np.isclose(e["u"], p.u_min[:, None] + p.u_ref * 0) | np.isclose(e["u"], p.u_max[:, None])).sum()
+    assert nact > 0
+
+
 # ---------------------------------------------------------------------------- edge cases
 def test_heavy_saturation_uses_second_polish_tier(capi, mo):
     """Amplitude 10: working sets beyond 32 rows leave the LDS mode of the polish and continue in its global mode."""
