@@ -58,6 +58,8 @@ def load():
     L.almpc_design_shared.argtypes = [_hp] + [_dp] * 10 + [ctypes.c_double, ctypes.c_double]
     L.almpc_set_reference.argtypes = [_hp, _dp, _dp, ctypes.c_int]
     L.almpc_set_terminal_equality.argtypes = [_hp, ctypes.c_int]
+    L.almpc_set_rho_profile.argtypes = [_hp, ctypes.c_int]
+    L.almpc_set_rho_profile.restype = ctypes.c_int
     L.almpc_set_terminal_equality.restype = ctypes.c_int
     L.almpc_update_initialization.argtypes = [_hp, _dp]
     L.almpc_update_initialization_device.argtypes = [_hp, ctypes.c_void_p]
@@ -167,12 +169,14 @@ class Solver:
     __del__ = close
 
     def design_shared(self, A, B, Q, R, S=None, P=None, umin=None, umax=None, xmin=None, xmax=None, rho=0.1, sigma=1e-6,
-                      terminal="none"):
-        """xmin/xmax: state box (the reference's kw mpc_state_constraint); terminal: "none" | "equality"."""
+                      terminal="none", rho_profile="scalar"):
+        """xmin/xmax: state box (the reference's kw mpc_state_constraint); terminal: "none" | "equality";
+        rho_profile: "scalar" (OSQP: rho for every row) | "stiffness" (rho_i = rho / (H'^-1)_ii)."""
         n, m = self.n, self.m
         if terminal not in ("none", "equality"):
             raise ValueError("terminal must be 'none' or 'equality'")
         self._check(self.L.almpc_set_terminal_equality(self.h, 1 if terminal == "equality" else 0))
+        self._check(self.L.almpc_set_rho_profile(self.h, {"scalar": 0, "stiffness": 1}[rho_profile]))
         A, B, Q, R = _colmajor(A, (n, n)), _colmajor(B, (n, m)), _colmajor(Q, (n, n)), _colmajor(R, (m, m))
         S = None if S is None else _colmajor(S, (m, m))
         P = None if P is None else _colmajor(P, (n, n))

@@ -30,7 +30,8 @@ struct almpc_handle {
     // device: shared design
     double *dMinvFrag = nullptr, *dGFrag = nullptr, *dHFrag = nullptr, *dFFrag = nullptr, *dG = nullptr;
     double *dD = nullptr, *dUmin = nullptr, *dUmax = nullptr, *dA = nullptr, *dB = nullptr;
-    double *dXref = nullptr, *dUref = nullptr, *dFS = nullptr;
+    double *dXref = nullptr, *dUref = nullptr, *dFS = nullptr, *dRho = nullptr;
+    int rho_mode = 0;  // 0 scalar rho (OSQP), 1 stiffness profile rho / G_ii
     long xref_stride = 0, uref_stride = 0, fS_stride = 0;
     std::vector<double> hS;  // S weight (for fS with per-instance references)
     // device: per-instance state and results
@@ -91,7 +92,7 @@ hipError_t launch_admm(int nrb, int ks, const AdmmParams& p, int grid, size_t ld
 
 void free_all(almpc_handle* h) {
     void* ptrs[] = {h->dMinvFrag, h->dGFrag, h->dHFrag, h->dFFrag, h->dG, h->dD, h->dUmin, h->dUmax, h->dA, h->dB,
-                    h->dXref, h->dUref, h->dFS, h->dX0, h->dXs, h->dZs, h->dYs, h->dV0, h->dW, h->dX, h->dEx,
+                    h->dXref, h->dUref, h->dFS, h->dRho, h->dX0, h->dXs, h->dZs, h->dYs, h->dV0, h->dW, h->dX, h->dEx,
                     h->dU, h->dEu, h->dStatus, h->dIters, h->dPiters, h->dOverflow, h->dSglobal, h->dGhat, h->dGnorm, h->dXmin,
                     h->dXmax, h->dRowTraj, h->dRowEq, h->dRowXidx, h->dRowState};
     for (void* p : ptrs)
@@ -155,7 +156,7 @@ int almpc_create(almpc_handle** out, int n, int m, int N, int batch, int device_
     TRY(dalloc(&h->dMinvFrag, fr)); TRY(dalloc(&h->dGFrag, fr)); TRY(dalloc(&h->dHFrag, fr));
     TRY(dalloc(&h->dFFrag, (size_t)h->nrb * h->ksf * 64));
     TRY(dalloc(&h->dG, (size_t)h->nz * h->nzs));
-    TRY(dalloc(&h->dD, (size_t)h->nzs)); TRY(dalloc(&h->dUmin, (size_t)m)); TRY(dalloc(&h->dUmax, (size_t)m));
+    TRY(dalloc(&h->dD, (size_t)h->nzs)); TRY(dalloc(&h->dRho, (size_t)h->nzs)); TRY(dalloc(&h->dUmin, (size_t)m)); TRY(dalloc(&h->dUmax, (size_t)m));
     TRY(dalloc(&h->dA, (size_t)n * n)); TRY(dalloc(&h->dB, (size_t)n * m));
     TRY(dalloc(&h->dX0, b * n));
     TRY(dalloc(&h->dXs, b * h->nzs)); TRY(dalloc(&h->dZs, b * h->nzs)); TRY(dalloc(&h->dYs, b * h->nzs));
@@ -179,6 +180,14 @@ void almpc_destroy(almpc_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_all(h);
     delete h;
+}
+
+int almpc_set_rho_profile(almpc_handle* h, int mode) {
+    if (!h) return ALMPC_ERR_INVALID;
+    if (mode != 0 && mode != 1) return fail(h, ALMPC_ERR_INVALID, "rho profile: 0 (scalar) or 1 (stiffness)");
+    h->rho_mode = mode;
+    h->designed = false;  // takes effect at the next design
+    return ALMPC_OK;
 }
 
 int almpc_set_terminal_equality(almpc_handle* h, int on) {
@@ -256,7 +265,7 @@ int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const
     }
     int rc = design_shared_device(h->stream, n, m, N, h->nzs, h->nrb, h->ks, h->ksf, Am, Bm, Qm, Rm, Sm, Pm, rho, sigma,
                                   h->dMinvFrag, h->dGFrag, h->dHFrag, h->dFFrag, h->dG, h->dD, h->H, h->F, h->d, h->err,
-                                  rowsel, h->Rs, h->dGhat, h->dGnorm);
+                                  rowsel, h->Rs, h->dGhat, h->dGnorm, h->rho_mode, h->dRho);
     if (rc != ALMPC_OK) return rc;
     HIP_TRY(h, hipMemcpy(h->dUmin, umin, m * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->dUmax, umax, m * sizeof(double), hipMemcpyHostToDevice));
@@ -352,7 +361,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
     AdmmParams ap;
     ap.nz = h->nz; ap.n = h->n; ap.m = h->m; ap.batch = h->batch; ap.nzs = h->nzs;
     ap.MinvFrag = h->dMinvFrag; ap.GFrag = h->dGFrag; ap.HFrag = h->dHFrag; ap.FFrag = h->dFFrag; ap.ksf = h->ksf;
-    ap.dvec = h->dD; ap.umin = h->dUmin; ap.umax = h->dUmax;
+    ap.dvec = h->dD; ap.rhovec = h->dRho; ap.umin = h->dUmin; ap.umax = h->dUmax;
     ap.uref = h->dUref; ap.uref_stride = h->uref_stride; ap.xref = h->dXref; ap.xref_stride = h->xref_stride;
     ap.fS = h->dFS; ap.fS_stride = h->fS_stride; ap.x0 = h->dX0;
     ap.xs = h->dXs; ap.zs = h->dZs; ap.ys = h->dYs; ap.v0 = h->dV0; ap.status = h->dStatus; ap.iters = h->dIters;

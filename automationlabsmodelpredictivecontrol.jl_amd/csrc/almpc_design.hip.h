@@ -190,8 +190,8 @@ __global__ __launch_bounds__(256) void k_design_scale(int nz, int nzs, int n, co
 // ---- K5: Minv = (Hs + c I)^-1 -------------------------------------------------------------------------
 // One workgroup, matrix in LDS (ld = nz+1 to spread banks).  Cholesky (right-looking), in-place inverse of
 // the triangular factor, then X'X.  flag[0] != 0 if a pivot is not positive.
-__global__ __launch_bounds__(512) void k_design_inverse(int nz, int nzs, const double* Hs, double cshift, double* Out,
-                                                        int* flag) {
+__global__ __launch_bounds__(512) void k_design_inverse(int nz, int nzs, const double* Hs, double cshift, const double* dshift,
+                                                        double* Out, int* flag) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int ld = nz + 1;
     double* L = smem;         // [nz][ld], element (i,j) at L[j*ld + i]
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(512) void k_design_inverse(int nz, int nzs, const d
     if (threadIdx.x == 0) *badp = 0;
     for (int t = threadIdx.x; t < nz * nz; t += blockDim.x) {
         const int i = t % nz, j = t / nz;
-        L[j * ld + i] = Hs[(size_t)j * nzs + i] + (i == j ? cshift : 0.0);
+        L[j * ld + i] = Hs[(size_t)j * nzs + i] + (i == j ? cshift + (dshift ? dshift[i] : 0.0) : 0.0);
     }
     __syncthreads();
     for (int j = 0; j < nz; ++j) {
@@ -241,6 +241,12 @@ __global__ __launch_bounds__(512) void k_design_inverse(int nz, int nzs, const d
     }
     __syncthreads();
     if (threadIdx.x == 0 && *badp) atomicExch(flag, 2);
+}
+
+// ---- ADMM penalty per row: scalar rho (OSQP), or the stiffness profile rho_i = rho / G_ii (G = H'^-1), pad rows 1
+__global__ __launch_bounds__(256) void k_design_rho(int nz, int nzs, int mode, double rho, const double* G, double* rhovec) {
+    for (int t = threadIdx.x; t < nzs; t += blockDim.x)
+        rhovec[t] = (t < nz) ? (mode == 1 ? rho / G[(size_t)t * nzs + t] : rho) : 1.0;
 }
 
 // ---- dense (column-major, ld) -> MFMA A-fragment layout ---------------------------------------------
@@ -302,7 +308,8 @@ inline int design_shared_device(hipStream_t stream, int n, int m, int N, int nzs
                                 double sigma, double* dMinvFrag, double* dGFrag, double* dHFrag, double* dFFrag,
                                 double* dG, double* dD, std::vector<double>& hH, std::vector<double>& hF,
                                 std::vector<double>& hd, std::string& err, const std::vector<int>& rowsel = std::vector<int>(),
-                                int Rs = 0, double* dGhat = nullptr, double* dGnorm = nullptr) {
+                                int Rs = 0, double* dGhat = nullptr, double* dGnorm = nullptr, int rho_mode = 0,
+                                double* dRho = nullptr) {
     const int nz = m * N;
     const int useR = R[0] != 0.0, useS = useR && S[0] != 0.0;  // the reference tests only element [1,1]
     auto symmetrise = [](std::vector<double>& M, int k) {
@@ -364,9 +371,11 @@ inline int design_shared_device(hipStream_t stream, int n, int m, int N, int nzs
     const size_t inv_lds = ((size_t)nz * (nz + 1) + nz + 2) * sizeof(double);
     DTRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_design_inverse), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)inv_lds));
-    hipLaunchKernelGGL(k_design_inverse, dim3(1), dim3(512), inv_lds, stream, nz, nzs, dHs, sigma + rho, dMinv, dFlag);
+    // G = H'^-1 first: the stiffness profile of the ADMM penalty (rho_i = rho / G_ii) is read off its diagonal
+    hipLaunchKernelGGL(k_design_inverse, dim3(1), dim3(512), inv_lds, stream, nz, nzs, dHs, 0.0, (const double*)nullptr, dG, dFlag);
     DTRY(hipGetLastError());
-    hipLaunchKernelGGL(k_design_inverse, dim3(1), dim3(512), inv_lds, stream, nz, nzs, dHs, 0.0, dG, dFlag);
+    hipLaunchKernelGGL(k_design_rho, dim3(1), dim3(256), 0, stream, nz, nzs, rho_mode, rho, dG, dRho);
+    hipLaunchKernelGGL(k_design_inverse, dim3(1), dim3(512), inv_lds, stream, nz, nzs, dHs, sigma, (const double*)dRho, dMinv, dFlag);
     DTRY(hipGetLastError());
     hipLaunchKernelGGL(k_pack_frags, dim3(32), dim3(256), 0, stream, dMinv, nz, nz, nzs, nrb, ks, dMinvFrag);
     hipLaunchKernelGGL(k_pack_frags, dim3(32), dim3(256), 0, stream, dG, nz, nz, nzs, nrb, ks, dGFrag);

@@ -83,6 +83,7 @@ struct AdmmParams {
     const double* FFrag;       // [NRB][KSF][64]  F' = D F
     int ksf;
     const double* dvec;        // [nzs] scaling d (pad rows: 1)
+    const double* rhovec;      // [nzs] ADMM penalty per row (scalar rho, or the stiffness profile rho/G_ii)
     const double* umin;        // [m]
     const double* umax;        // [m]
     const double* uref;        // [uref_stride*inst + row]
@@ -179,14 +180,17 @@ __global__ __launch_bounds__(64 * NRB) void k_admm(AdmmParams p) {
     }
 
     // ---- initial iterate
-    double x[4], z[4], y[4], px[4], rown[4];
-    const double rho = p.rho, sigma = p.sigma, alpha = p.alpha, rho_inv = 1.0 / p.rho;
+    // y is carried in scaled form yt = y / rho_i (the update needs no 1/rho then); rho_i is per row
+    double x[4], z[4], yt[4], px[4], rown[4], rho[4];
+    const double sigma = p.sigma, alpha = p.alpha;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rho[i] = p.rhovec[row[i] < p.nz ? row[i] : 0];
     if (p.warm) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const size_t o = (size_t)instc * p.nzs + row[i];
             x[i] = p.xs[o];
-            y[i] = p.ys[o];
+            yt[i] = p.ys[o] / rho[i];
             z[i] = fmin(fmax(p.zs[o], lo[i]), hi[i]);
             rhs0[row[i] * TILE + col] = x[i];
         }
@@ -202,11 +206,11 @@ __global__ __launch_bounds__(64 * NRB) void k_admm(AdmmParams p) {
         __syncthreads();
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) x[i] = z[i] = y[i] = px[i] = 0.0;
+        for (int i = 0; i < 4; ++i) x[i] = z[i] = yt[i] = px[i] = 0.0;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        rown[i] = sigma * x[i] - fs[i] + rho * z[i] - y[i];
+        rown[i] = sigma * x[i] - fs[i] + rho[i] * (z[i] - yt[i]);
         rhs0[row[i] * TILE + col] = rown[i];
     }
     // |f/d|_inf per instance (constant part of the dual tolerance)
@@ -233,14 +237,14 @@ __global__ __launch_bounds__(64 * NRB) void k_admm(AdmmParams p) {
         for (int i = 0; i < 4; ++i) {
             const double xt = xt4[i];
             if (active) {
-                const double hxt = rown[i] - (sigma + rho) * xt;  // H' xt, from the KKT identity
+                const double hxt = rown[i] - (sigma + rho[i]) * xt;  // H' xt, from the KKT identity
                 px[i] = alpha * hxt + (1.0 - alpha) * px[i];
                 x[i] = alpha * xt + (1.0 - alpha) * x[i];
-                const double w = alpha * xt + (1.0 - alpha) * z[i] + y[i] * rho_inv;
+                const double w = alpha * xt + (1.0 - alpha) * z[i] + yt[i];
                 const double zn = fmin(fmax(w, lo[i]), hi[i]);
-                y[i] = rho * (w - zn);
+                yt[i] = w - zn;
                 z[i] = zn;
-                rown[i] = sigma * x[i] - fs[i] + rho * z[i] - y[i];
+                rown[i] = sigma * x[i] - fs[i] + rho[i] * (z[i] - yt[i]);
             }
             nxt[row[i] * TILE + col] = rown[i];
         }
@@ -252,10 +256,11 @@ __global__ __launch_bounds__(64 * NRB) void k_admm(AdmmParams p) {
                 m_rp = fmax(m_rp, fabs(dv[i] * (x[i] - z[i])));
                 m_x = fmax(m_x, fabs(dv[i] * x[i]));
                 m_z = fmax(m_z, fabs(dv[i] * z[i]));
-                m_rd = fmax(m_rd, fabs((px[i] + fs[i] + y[i]) * dinv[i]));
+                const double yi = rho[i] * yt[i];
+                m_rd = fmax(m_rd, fabs((px[i] + fs[i] + yi) * dinv[i]));
                 m_hx = fmax(m_hx, fabs(px[i] * dinv[i]));
-                m_y = fmax(m_y, fabs(y[i] * dinv[i]));
-                const double s = x[i] + y[i] + px[i];
+                m_y = fmax(m_y, fabs(yi * dinv[i]));
+                const double s = x[i] + yi + px[i];
                 if (!(fabs(s) <= 1.79e308)) m_bad = 1.0;
             }
             m_rp = qmax(m_rp); m_x = qmax(m_x); m_z = qmax(m_z); m_rd = qmax(m_rd);
@@ -323,6 +328,9 @@ __global__ __launch_bounds__(64 * NRB) void k_admm(AdmmParams p) {
         }
     };
     const double v0r[4] = {v04[0], v04[1], v04[2], v04[3]};
+    double y[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = rho[i] * yt[i];
     flush(x, p.xs);
     flush(z, p.zs);
     flush(y, p.ys);
@@ -626,7 +634,7 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
     // round trip can be started before the LDS work that produces the weights.
     auto g_load = [&](int l0, d2 (&g)[CH]) {
 #pragma unroll
-        for (int t = 0; t < CH; ++t) g[t] = *reinterpret_cast<const d2*>(p.G + (size_t)wrow_s[l0 + t] * nzs + rc);
+        for (int t = 0; t < CH; ++t) g[t] = *reinterpret_cast<const d2*>(p.G + (wrow_s[l0 + t] * nzs + rc));  // 32-bit index math
     };
     auto g_fma = [&](int l0, const double* ab, const d2 (&g)[CH], double& q0, double& q1) {
         double av[CH];

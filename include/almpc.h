@@ -113,6 +113,15 @@ const char* almpc_last_error(const almpc_handle* h);
  */
 int almpc_set_terminal_equality(almpc_handle* h, int on);
 
+/*
+ * ADMM penalty profile, call BEFORE almpc_design_shared.  0 (default): one scalar rho for every row, as OSQP does for
+ * inequality rows.  1: stiffness-matched rho_i = rho / G_ii with G = H'^-1 (a diagonal preconditioning of the
+ * constraint rows, the role OSQP's Ruiz scaling E plays): rows in soft directions of the Hessian get a small penalty.
+ * On the benchmark plant this cuts the active-set work after 10 ADMM iterations by ~3x; `rho` of
+ * almpc_design_shared is then the numerator (10 is the tuned value).
+ */
+int almpc_set_rho_profile(almpc_handle* h, int mode);
+
 int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const double* Q,
                         const double* R, const double* S, const double* P, const double* umin,
                         const double* umax, const double* xmin, const double* xmax, double rho,

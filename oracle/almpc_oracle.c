@@ -47,7 +47,7 @@ static void symv(int nz, const double* M, const double* x, double* y) {
  * 2 non-finite.  x, z, y: in = start (cold start: zeros), out = final iterate.  work: 4*nz doubles.
  */
 int almpc_oracle_admm(int nz, const double* Minv, const double* Hs, const double* fs, const double* lo,
-                      const double* hi, const double* d, double rho, double sigma, double alpha, double eps_abs,
+                      const double* hi, const double* d, const double* rho, double sigma, double alpha, double eps_abs,
                       double eps_rel, int max_iter, int check_every, double* x, double* z, double* y, int* iters,
                       double* work) {
     double* rhs = work;
@@ -56,13 +56,13 @@ int almpc_oracle_admm(int nz, const double* Minv, const double* Hs, const double
     int status = 1, it = 0;
     for (int i = 0; i < nz; ++i) z[i] = clip(z[i], lo[i], hi[i]);
     for (it = 1; it <= max_iter; ++it) {
-        for (int i = 0; i < nz; ++i) rhs[i] = sigma * x[i] - fs[i] + rho * z[i] - y[i];
+        for (int i = 0; i < nz; ++i) rhs[i] = sigma * x[i] - fs[i] + rho[i] * z[i] - y[i];
         symv(nz, Minv, rhs, xt);
         for (int i = 0; i < nz; ++i) {
             x[i] = alpha * xt[i] + (1.0 - alpha) * x[i];
-            const double w = alpha * xt[i] + (1.0 - alpha) * z[i] + y[i] / rho;
+            const double w = alpha * xt[i] + (1.0 - alpha) * z[i] + y[i] / rho[i];
             const double zn = clip(w, lo[i], hi[i]);
-            y[i] = rho * (w - zn);
+            y[i] = rho[i] * (w - zn);
             z[i] = zn;
         }
         if (it % check_every == 0 || it == max_iter) {
@@ -232,7 +232,7 @@ void almpc_oracle_rollout(int n, int m, int N, const double* A, const double* B,
 int almpc_oracle_step_batch(int n, int m, int N, int batch, const double* A, const double* B, const double* Minv,
                             const double* Hs, const double* G, const double* Fs, const double* fS, const double* lo,
                             const double* hi, const double* d, const double* xref, const double* uref,
-                            const double* x0, double rho, double sigma, double alpha, double eps_abs, double eps_rel,
+                            const double* x0, const double* rho, double sigma, double alpha, double eps_abs, double eps_rel,
                             int max_iter, int check_every, int polish, int polish_max_iter, double* x, double* e_x,
                             double* u, double* e_u, int32_t* status, int32_t* iters, int32_t* piters, int threads) {
     const int nz = m * N;

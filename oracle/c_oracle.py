@@ -66,6 +66,7 @@ def step_batch(p, des, X0, alpha=1.6, eps_abs=1e-3, eps_rel=1e-3, max_iter=25, c
     A, B, Minv, Hs, G, Fs = f(p.A), f(p.B), f(des["Minv"]), f(des["Hs"]), f(des["G"]), f(des["Fs"])
     c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
     fS, lo, hi, d = c(des["fS"]), c(des["lo"]), c(des["hi"]), c(des["d"])
+    rho_vec = c(des["rho_vec"])
     xref, uref = f(p.x_ref), f(p.u_ref)  # column-major n x (N+1) == [N+1][n]
     x = np.empty((batch, N + 1, n))
     e_x = np.empty((batch, N + 1, n))
@@ -76,7 +77,7 @@ def step_batch(p, des, X0, alpha=1.6, eps_abs=1e-3, eps_rel=1e-3, max_iter=25, c
     piters = np.empty(batch, dtype=np.int32)
     used = lib().almpc_oracle_step_batch(
         n, m, N, batch, _d(A), _d(B), _d(Minv), _d(Hs), _d(G), _d(Fs), _d(fS), _d(lo), _d(hi), _d(d), _d(xref),
-        _d(uref), _d(X0), ctypes.c_double(des["rho"]), ctypes.c_double(des["sigma"]), ctypes.c_double(alpha),
+        _d(uref), _d(X0), _d(rho_vec), ctypes.c_double(des["sigma"]), ctypes.c_double(alpha),
         ctypes.c_double(eps_abs), ctypes.c_double(eps_rel), int(max_iter), int(check_every), int(bool(polish)),
         int(polish_max_iter), _d(x), _d(e_x), _d(u), _d(e_u), status.ctypes.data_as(_ip), iters.ctypes.data_as(_ip),
         piters.ctypes.data_as(_ip), int(threads))

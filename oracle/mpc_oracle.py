@@ -686,8 +686,9 @@ def admm_box(Hs, fs, lo, hi, rho=0.1, sigma=1e-6, alpha=1.6, eps_abs=1e-3, eps_r
     Returns x, z, y (scaled coordinates), iters, status (0 solved, 1 max-iter)."""
     nz = fs.size
     d = np.ones(nz) if unscale is None else unscale
+    rho = np.full(nz, float(rho)) if np.ndim(rho) == 0 else np.asarray(rho, dtype=np.float64)  # per-row penalty
     if Minv is None:
-        Minv = np.linalg.inv(Hs + (sigma + rho) * np.eye(nz))
+        Minv = np.linalg.inv(Hs + sigma * np.eye(nz) + np.diag(rho))
     x = np.zeros(nz) if x0 is None else x0.copy()
     y = np.zeros(nz) if y0 is None else y0.copy()
     z = np.clip(x, lo, hi)
@@ -803,7 +804,7 @@ def polish_active_set(G, v0, lo, hi, z, y, max_iter=None, refine=True):
     return dict(w=np.clip(w, lo, hi), iters=it, n_add=n_add, n_remove=n_rem, n_active=len(W))
 
 
-def design_shared(p: MPCProblem, rho=0.1, sigma=1e-6):
+def design_shared(p: MPCProblem, rho=0.1, sigma=1e-6, rho_profile="scalar"):
     """Everything `almpc_design_shared` precomputes for a model shared by the whole batch,
     in scaled coordinates v = D w:  d, H' = DHD, F' = DF, Minv = (H' + (sigma+rho) I)^-1,
     G = H'^-1, lo' = lo/d, hi' = hi/d, plus the unscaled H, F (for `almpc_get_design`)."""
@@ -820,9 +821,12 @@ def design_shared(p: MPCProblem, rho=0.1, sigma=1e-6):
         ci = np.linalg.solve(c, np.eye(nz))
         return ci.T @ ci
 
+    G = spd_inv(Hs)
+    # ADMM penalty per row: OSQP's scalar rho, or the stiffness profile rho / G_ii (almpc_set_rho_profile)
+    rho_vec = rho / np.diag(G) if rho_profile == "stiffness" else np.full(nz, float(rho))
     return dict(H=H, F=F, d=d, Hs=Hs, Fs=F * d[:, None], fS=s_rate_gradient(p) * d,
-                Minv=spd_inv(Hs + (sigma + rho) * np.eye(nz)), G=spd_inv(Hs),
-                lo=lo / d, hi=hi / d, rho=rho, sigma=sigma, Phi=Phi, Gam=Gam)
+                Minv=spd_inv(Hs + sigma * np.eye(nz) + np.diag(rho_vec)), G=G,
+                lo=lo / d, hi=hi / d, rho=rho, rho_vec=rho_vec, sigma=sigma, Phi=Phi, Gam=Gam)
 
 
 def solve_mpc_admm_polish(p: MPCProblem, x0, des=None, rho=0.1, sigma=1e-6, alpha=1.6,
@@ -834,7 +838,7 @@ def solve_mpc_admm_polish(p: MPCProblem, x0, des=None, rho=0.1, sigma=1e-6, alph
     d = des["d"]
     e0 = np.asarray(x0, dtype=np.float64) - p.x_ref[:, 0]
     fs = des["Fs"] @ e0 + des["fS"]
-    r = admm_box(des["Hs"], fs, des["lo"], des["hi"], rho=des["rho"], sigma=des["sigma"], alpha=alpha,
+    r = admm_box(des["Hs"], fs, des["lo"], des["hi"], rho=des["rho_vec"], sigma=des["sigma"], alpha=alpha,
                  eps_abs=eps_abs, eps_rel=eps_rel, max_iter=max_iter, check_every=check_every,
                  Minv=des["Minv"], unscale=d)
     w, pit = r["z"], 0

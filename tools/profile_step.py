@@ -12,10 +12,11 @@ p = mo.quadrotor()
 B = int(os.environ.get("ALMPC_BATCH", "4096"))
 X0 = bench.make_x0(mo, 0, B, None if amp == "mix" else float(amp))
 s = capi.Solver(12, 4, 30, B, timing=True)
-s.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max)
+prof = os.environ.get('ALMPC_RHO_PROFILE', 'scalar'); rho = float(os.environ.get('ALMPC_RHO', '0.1'))
+s.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max, rho=rho, rho_profile=prof)
 s.set_reference(p.x_ref, p.u_ref)
 s.update_initialization(X0)
-opts = capi.default_opts() if len(sys.argv) <= 3 else capi.default_opts(max_iter=int(sys.argv[3]), check_every=int(sys.argv[4]) if len(sys.argv) > 4 else 25)
+opts = capi.default_opts(rho=rho) if len(sys.argv) <= 3 else capi.default_opts(rho=rho, max_iter=int(sys.argv[3]), check_every=int(sys.argv[4]) if len(sys.argv) > 4 else 25)
 for _ in range(5):
     s.calculate(opts)
 s.timing_reset(steps)
