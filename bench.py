@@ -62,9 +62,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--max-iter", type=int, default=10,
-                    help="ADMM iterations before the polish (= check interval); 10 is the tuned value for this workload, "
+    ap.add_argument("--max-iter", type=int, default=8,
+                    help="ADMM iterations before the polish (= check interval); 8 is the tuned value for this workload, "
                          "the library default is 25")
+    ap.add_argument("--rho-profile", default="stiffness", choices=("scalar", "stiffness"),
+                    help="ADMM penalty: OSQP's scalar rho, or rho_i = rho / (H'^-1)_ii (almpc_set_rho_profile)")
+    ap.add_argument("--rho", type=float, default=None, help="rho (default 30 for the stiffness profile, 0.1 for scalar)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-classes", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true")
@@ -86,10 +89,12 @@ def main():
     ndev = int(os.environ.get("ALMPC_NUM_DEVICES", "0"))  # test hook: fold ranks onto fewer devices (with ALMPC_DIST_BACKEND=gloo)
     dev_index = (local_rank % ndev) if ndev > 0 else local_rank
     solver = capi.Solver(NX, NU, N_HORIZON, BATCH_PER_GPU, device=dev_index, timing=True)
-    solver.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max)
+    rho = args.rho if args.rho is not None else (30.0 if args.rho_profile == "stiffness" else 0.1)
+    design_kw = dict(rho=rho, rho_profile=args.rho_profile)
+    solver.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max, **design_kw)
     solver.set_reference(p.x_ref, p.u_ref)
     solver.update_initialization(X0)  # x0 resident in HBM from here on
-    opts = capi.default_opts(max_iter=args.max_iter, check_every=args.max_iter)
+    opts = capi.default_opts(rho=rho, max_iter=args.max_iter, check_every=args.max_iter)
 
     time_steps(solver, opts, args.warmup, barrier)
     solver.timing_reset(args.steps)
@@ -111,7 +116,7 @@ def main():
                                "x0 amplitude classes 0.3/1.0/3.0 interleaved, cold start every step",
                    "batch_per_gpu": BATCH_PER_GPU, "global_batch": world * BATCH_PER_GPU,
                    "admm_max_iter": int(opts.max_iter), "check_every": int(opts.check_every), "polish": int(opts.polish),
-                   "rho": opts.rho, "eps": opts.eps_abs, "parallelism": f"instances sharded over {world} GPU(s), 16-instance tile per workgroup"},
+                   "rho": opts.rho, "rho_profile": args.rho_profile, "eps": opts.eps_abs, "parallelism": f"instances sharded over {world} GPU(s), 16-instance tile per workgroup"},
     }
     if rank == 0:
         # ---- rooflines from the HIP events recorded inside the timed region (one event set per step on the stream the
@@ -167,15 +172,17 @@ def main():
         _, _, Hq, _ = mo.condense(p)
         out["cond_H"] = float(np.linalg.cond(Hq))
 
+    solver2 = None
     if not args.no_pipelined:
         # Secondary figure: two INDEPENDENT batches in flight on two handles / HIP streams of this rank (Monte-Carlo use:
         # batches do not depend on each other), which lets one batch's ADMM fill the CUs left idle by the other's
         # active-set tail.  Not the headline `value` (a closed loop has one batch in flight).
         solver2 = capi.Solver(NX, NU, N_HORIZON, BATCH_PER_GPU, device=dev_index)
-        solver2.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max)
+        solver2.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max, **design_kw)
         solver2.set_reference(p.x_ref, p.u_ref)
         solver2.update_initialization(make_x0(mo, first + world * BATCH_PER_GPU, BATCH_PER_GPU))
         pair = (solver, solver2)
+        solver.timing_reset(args.steps + args.warmup)
         for i in range(2 * max(5, args.warmup // 5)):
             pair[i & 1].calculate(opts, sync=False)
         solver.synchronize(); solver2.synchronize()
@@ -188,15 +195,15 @@ def main():
         el2 = max_over_ranks(time.perf_counter() - t0)
         out["two_batches_in_flight"] = {"value": world * args.steps / el2, "unit": "batch-steps/s",
                                         "note": "independent batches alternated over two handles/streams per GPU"}
-        solver2.close()
 
     if not args.no_classes:
         # per-class rates (each class alone on the whole batch), short runs
         cls = {}
         for s_ in AMPLITUDES:
             solver.update_initialization(make_x0(mo, first, BATCH_PER_GPU, amplitude=s_))
-            time_steps(solver, opts, max(5, args.warmup // 5), barrier)
             k = max(20, args.steps // 5)
+            solver.timing_reset(k + args.warmup)  # no event creation inside the timed loop
+            time_steps(solver, opts, max(5, args.warmup // 5), barrier)
             el = max_over_ranks(time_steps(solver, opts, k, barrier))
             cls[str(s_)] = world * k / el
         out["classes"] = {"unit": "batch-steps/s", **cls}
@@ -205,7 +212,7 @@ def main():
         # ---- CPU baseline (kind "port": oracle/almpc_oracle.c, OpenMP over instances, all host cores) on a bounded
         # sample of the same workload: the same 4096 x0, same options, repeated until ~10 s of wall time
         import c_oracle
-        des = mo.design_shared(p, rho=opts.rho, sigma=opts.sigma)
+        des = mo.design_shared(p, rho=opts.rho, sigma=opts.sigma, rho_profile=args.rho_profile)
         kw = dict(alpha=opts.alpha, eps_abs=opts.eps_abs, eps_rel=opts.eps_rel, max_iter=int(opts.max_iter),
                   check_every=int(opts.check_every), polish=bool(opts.polish), threads=pkg.sharding.host_cpu_share())
         c_oracle.step_batch(p, des, X0[:256], **kw)  # warm
@@ -223,6 +230,8 @@ def main():
                                          f"(gcc -O3 -march=native, OpenMP): same ADMM+polish+rollout as the HIP path",
                                "instance_steps_per_s": reps * BATCH_PER_GPU / cpu_el}
     solver.close()
+    if solver2 is not None:
+        solver2.close()  # (freed only now: a large hipFree in the middle slows the launches that follow it)
     if rank == 0:
         print(json.dumps(out))
     ranks.close()

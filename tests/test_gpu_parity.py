@@ -130,6 +130,29 @@ def test_algorithm_parity_with_c_restatement(capi, mo, co):
         assert np.abs(r["u"] - c["u"]).max() <= U_TOL and np.abs(r["x"] - c["x"]).max() <= X_TOL
 
 
+def test_stiffness_rho_profile_parity(capi, mo, co):
+    """almpc_set_rho_profile(1): rho_i = rho / (H'^-1)_ii.  Same algorithm parity with the C restatement (ADMM iterates with
+    polish off; iteration counts and results with polish on) and the exact optimum."""
+    p = mo.quadrotor()
+    X0 = np.concatenate([mo.quadrotor_x0_batch(160, a, first_instance=160 * k) for k, a in enumerate((0.3, 1.0, 3.0, 4.0))])
+    des = mo.design_shared(p, rho=30.0, rho_profile="stiffness")
+    s = capi.Solver(p.n, p.m, p.N, len(X0))
+    s.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max, rho=30.0, rho_profile="stiffness")
+    s.set_reference(p.x_ref, p.u_ref)
+    s.update_initialization(X0)
+    for kw in (dict(max_iter=8, check_every=8, polish=0), dict(max_iter=8, check_every=8), dict(max_iter=25)):
+        s.calculate(capi.default_opts(rho=30.0, **kw))
+        r = s.get_results()
+        c = co.step_batch(p, des, X0, max_iter=kw["max_iter"], check_every=kw.get("check_every", 25), polish=bool(kw.get("polish", 1)))
+        assert np.array_equal(r["iters"], c["iters"])
+        if kw.get("polish", 1):
+            assert np.all(r["status"] == 0) and (r["polish_iters"] != c["polish_iters"]).mean() <= 5e-3
+        assert np.abs(r["u"] - c["u"]).max() <= (1e-9 if not kw.get("polish", 1) else U_TOL)
+    s.close()
+    for i in range(0, len(X0), 16):
+        assert np.abs(r["u"][i] - mo.solve_mpc_exact(p, X0[i])["u"]).max() <= U_TOL
+
+
 def test_admm_only_matches_oracle_iterate(capi, mo, co):
     """polish off: the result is the ADMM iterate z itself -> compare the iterates of the two implementations."""
     p = mo.quadrotor()
