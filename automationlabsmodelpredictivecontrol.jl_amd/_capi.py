@@ -71,6 +71,8 @@ def load():
     L.almpc_device_results.argtypes = [_hp] + [ctypes.POINTER(ctypes.c_void_p)] * 4
     L.almpc_get_timing.argtypes = [_hp, _fp, _fp, _fp, _fp]
     L.almpc_timing_reset.argtypes = [_hp, ctypes.c_int]
+    L.almpc_timing_set_stride.argtypes = [_hp, ctypes.c_int]
+    L.almpc_timing_set_stride.restype = ctypes.c_int
     L.almpc_debug_poison_lds.argtypes = [_hp]
     L.almpc_dare.argtypes = [ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, _dp]
     L.almpc_dare.restype = ctypes.c_int
@@ -248,6 +250,9 @@ class Solver:
 
     def debug_poison_lds(self):
         self._check(self.L.almpc_debug_poison_lds(self.h))
+
+    def timing_set_stride(self, every):
+        self._check(self.L.almpc_timing_set_stride(self.h, int(every)))
 
     def timing_reset(self, reserve_steps=0):
         self._check(self.L.almpc_timing_reset(self.h, int(reserve_steps)))

@@ -46,6 +46,8 @@ struct almpc_handle {
     // timing (ALMPC_FLAG_TIMING): one set of 4 events per step since the last almpc_timing_reset
     std::vector<hipEvent_t> ev;  // 4 per step
     size_t ev_used = 0;          // steps recorded
+    int timing_stride = 1;       // record events on every timing_stride-th step only (each event costs ~3 us of stream time)
+    size_t step_count = 0;
 };
 
 namespace {
@@ -345,7 +347,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
     if (o.max_iter < 1 || o.check_every < 1 || !(o.alpha > 0.0 && o.alpha < 2.0) || !(o.eps_abs >= 0.0) || !(o.eps_rel >= 0.0))
         return fail(h, ALMPC_ERR_INVALID, "calculate: bad options");
     HIP_TRY(h, hipSetDevice(h->device));
-    const bool timing = (h->flags & ALMPC_FLAG_TIMING) != 0;
+    const bool timing = (h->flags & ALMPC_FLAG_TIMING) != 0 && (h->step_count++ % (size_t)h->timing_stride) == 0;
     hipStream_t st = h->stream;
     hipEvent_t* ev = nullptr;
     if (timing) {
@@ -493,12 +495,20 @@ int almpc_device_results(almpc_handle* h, const double** d_x, const double** d_e
     return ALMPC_OK;
 }
 
+int almpc_timing_set_stride(almpc_handle* h, int every) {
+    if (!h || every < 1) return ALMPC_ERR_INVALID;
+    h->timing_stride = every;
+    h->step_count = 0;
+    return ALMPC_OK;
+}
+
 int almpc_timing_reset(almpc_handle* h, int reserve_steps) {
     if (!h) return ALMPC_ERR_INVALID;
     if (!(h->flags & ALMPC_FLAG_TIMING)) return fail(h, ALMPC_ERR_INVALID, "handle was created without ALMPC_FLAG_TIMING");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->ev_used = 0;
+    h->step_count = 0;
     const size_t need = 4 * (size_t)(reserve_steps > 0 ? reserve_steps : 0);
     if (h->ev.size() < need) {
         const size_t old = h->ev.size();

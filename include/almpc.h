@@ -183,6 +183,9 @@ int almpc_get_timing(almpc_handle* h, float* ms_admm, float* ms_polish, float* m
  * steps recorded since the reset and the SUM of their per-stage milliseconds.
  */
 int almpc_timing_reset(almpc_handle* h, int reserve_steps);
+/* Record the events only on every `every`-th almpc_calculate (default 1).  One step's four event records cost ~14 us of
+ * stream time on MI355X, so a throughput run samples (bench.py: every 16th step) instead of timing every step. */
+int almpc_timing_set_stride(almpc_handle* h, int every);
 int almpc_timing_summary(almpc_handle* h, int* steps, double* ms_admm, double* ms_polish,
                          double* ms_rollout, double* ms_total);
 

@@ -8,8 +8,9 @@ capi = almpc_loader.load_package()._capi
 amp = sys.argv[1] if len(sys.argv) > 1 else "mix"
 p = mo.quadrotor(); B = 4096
 X0 = bench.make_x0(mo, 0, B, None if amp == "mix" else float(amp))
-s = capi.Solver(12, 4, 30, B); s.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max); s.set_reference(p.x_ref, p.u_ref); s.update_initialization(X0)
-opts = capi.default_opts(max_iter=int(sys.argv[2]) if len(sys.argv) > 2 else 25, check_every=int(sys.argv[2]) if len(sys.argv) > 2 else 25)
+prof = os.environ.get('ALMPC_RHO_PROFILE', 'scalar'); rho = float(os.environ.get('ALMPC_RHO', '0.1'))
+s = capi.Solver(12, 4, 30, B); s.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max, rho=rho, rho_profile=prof); s.set_reference(p.x_ref, p.u_ref); s.update_initialization(X0)
+opts = capi.default_opts(rho=rho, max_iter=int(sys.argv[2]) if len(sys.argv) > 2 else 25, check_every=int(sys.argv[2]) if len(sys.argv) > 2 else 25)
 for _ in range(3): s.calculate(opts)
 L = s.L; W = 2 * B
 L.almpc_dbg_stamps_enable(s.h, W)
