@@ -74,6 +74,8 @@ def load():
     L.almpc_timing_set_stride.argtypes = [_hp, ctypes.c_int]
     L.almpc_timing_set_stride.restype = ctypes.c_int
     L.almpc_debug_poison_lds.argtypes = [_hp]
+    L.almpc_advance_plant.argtypes = [_hp]
+    L.almpc_advance_plant.restype = ctypes.c_int
     L.almpc_dare.argtypes = [ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, _dp]
     L.almpc_dare.restype = ctypes.c_int
     L.almpc_fnn_linearize.argtypes = [ctypes.c_int] * 6 + [_dp] * 4 + [ctypes.c_int] + [_dp] * 5
@@ -247,6 +249,9 @@ class Solver:
         v = [ctypes.c_float() for _ in range(4)]
         self._check(self.L.almpc_get_timing(self.h, *[ctypes.byref(x) for x in v]))
         return dict(zip(("admm_ms", "polish_ms", "rollout_ms", "total_ms"), [x.value for x in v]))
+
+    def advance_plant(self):
+        self._check(self.L.almpc_advance_plant(self.h))
 
     def debug_poison_lds(self):
         self._check(self.L.almpc_debug_poison_lds(self.h))

@@ -613,6 +613,17 @@ int almpc_fnn_linearize(int device_id, int n, int m, int H, int L, int activatio
     return rc;
 }
 
+int almpc_advance_plant(almpc_handle* h) {
+    if (!h) return ALMPC_ERR_INVALID;
+    if (!h->designed) return fail(h, ALMPC_ERR_NOT_DESIGNED, "advance_plant before design");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int per_block = 256 / h->n;
+    hipLaunchKernelGGL(k_advance_plant, dim3((h->batch + per_block - 1) / per_block), dim3(256), (size_t)per_block * h->n * sizeof(double),
+                       h->stream, h->n, h->m, h->N, h->batch, h->dA, h->dB, h->dU, h->dX0);
+    HIP_TRY(h, hipGetLastError());
+    return ALMPC_OK;
+}
+
 int almpc_debug_poison_lds(almpc_handle* h) {
     if (!h) return ALMPC_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));

@@ -1087,6 +1087,24 @@ __global__ __launch_bounds__(64 * WAVES) void k_rollout(RolloutParams p) {
     ALMPC_STAMP(inst, 3);
 }
 
+// Closed loop on the device: x0 <- A x0 + B u[:,1] for every instance (the plant the controller was designed for), so that a
+// receding-horizon run needs no host round trip between steps.  One thread per (instance, state).
+__global__ __launch_bounds__(256) void k_advance_plant(int n, int m, int N, int batch, const double* A, const double* B,
+                                                      const double* u, double* x0) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];  // old x0 of the block's instances
+    const int per_block = blockDim.x / n;  // instances per block
+    const int li = threadIdx.x / n, i = threadIdx.x % n;
+    const int inst = blockIdx.x * per_block + li;
+    const bool ok = li < per_block && inst < batch;
+    if (ok) smem[li * n + i] = x0[(size_t)inst * n + i];
+    __syncthreads();
+    if (!ok) return;
+    double s = 0.0;
+    for (int j = 0; j < n; ++j) s += A[(size_t)j * n + i] * smem[li * n + j];
+    for (int a = 0; a < m; ++a) s += B[(size_t)a * n + i] * u[(size_t)inst * m * N + a];
+    x0[(size_t)inst * n + i] = s;
+}
+
 // Test hook: fill the LDS of every CU with NaN bit patterns so that a kernel that reads LDS it did not write shows up
 // as a wrong result instead of passing on stale finite values (tests/test_gpu_parity.py poisons before it solves).
 __global__ __launch_bounds__(1024) void k_poison_lds(unsigned long long pattern, int words, unsigned long long* sink) {

@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-classes", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true")
+    ap.add_argument("--no-closed-loop", action="store_true")
     args = ap.parse_args()
 
     import almpc_loader
@@ -198,6 +199,30 @@ def main():
         el2 = max_over_ranks(time.perf_counter() - t0)
         out["two_batches_in_flight"] = {"value": world * args.steps / el2, "unit": "batch-steps/s",
                                         "note": "independent batches alternated over two handles/streams per GPU"}
+
+    if not args.no_closed_loop:
+        # Secondary figure: receding-horizon closed loop on the device (x0 <- A x0 + B u[:,1], warm-started ADMM), the
+        # mixed batch driven for 100 consecutive steps from its initial states (closed-loop variant)
+        solver.update_initialization(X0)
+        warm = capi.default_opts(rho=rho, max_iter=args.max_iter, check_every=args.max_iter, warm_start=1)
+        solver.timing_reset(0)
+        solver.timing_set_stride(1 << 30)  # no events in this section
+        solver.calculate(opts, sync=False)
+        solver.advance_plant()
+        barrier(); solver.synchronize()
+        t0 = time.perf_counter()
+        T = 100
+        for _ in range(T):
+            solver.calculate(warm, sync=False)
+            solver.advance_plant()
+        solver.synchronize(); barrier()
+        elc = max_over_ranks(time.perf_counter() - t0)
+        rc_ = solver.get_results(want=("status", "polish_iters", "x"))
+        out["closed_loop"] = {"value": world * T / elc, "unit": "batch-steps/s", "steps": T,
+                              "status_counts_last": np.bincount(rc_["status"], minlength=4).tolist(),
+                              "max_abs_position_last": float(np.abs(rc_["x"][:, :3, 0]).max())}
+        solver.timing_set_stride(TIMING_STRIDE)
+        solver.update_initialization(X0)
 
     if not args.no_classes:
         # per-class rates (each class alone on the whole batch), short runs

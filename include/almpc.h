@@ -152,6 +152,13 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* opts);
 int almpc_synchronize(almpc_handle* h);
 
 /*
+ * Closed loop without host round trips: x0 <- A x0 + B u[:,1] on the device, per instance, with the (A, B) of the design
+ * and the first input of the last almpc_calculate (enqueued on the handle's stream; no host sync).  Follow with
+ * almpc_calculate(_async) -- typically with opts.warm_start = 1 -- for the next receding-horizon step.
+ */
+int almpc_advance_plant(almpc_handle* h);
+
+/*
  * Copy results to host.  Any pointer may be NULL.  Layouts: x, e_x [batch][N+1][n];
  * u, e_u [batch][N][m]  (ModelPredictiveControlResults, src/types/types.jl:134-139);
  * status, iters, polish_iters [batch].

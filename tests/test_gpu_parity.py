@@ -299,6 +299,31 @@ def test_warm_start_closed_loop(capi, mo):
     assert np.abs(X[:, :3]).max() < 0.5 * np.abs(mo.quadrotor_x0_batch(batch, 1.0, first_instance=77)[:, :3]).max()
 
 
+def test_closed_loop_on_device(capi, mo):
+    """almpc_advance_plant: 25 receding-horizon steps entirely on the device (warm-started ADMM) equal the host loop
+    x+ = A x + B u[:,1] driven by the exact oracle at every step (within tolerance accumulation)."""
+    p = mo.quadrotor()
+    batch = 24
+    X = mo.quadrotor_x0_batch(batch, 2.0, first_instance=5)
+    s = make_solver(capi, p, batch)
+    s.update_initialization(X)
+    Xh = X.copy()
+    for k in range(25):
+        s.calculate(capi.default_opts(warm_start=1) if k else None, sync=False)
+        s.advance_plant()
+        if k in (0, 7, 24):
+            r = s.get_results(want=("u", "x", "status"))
+            assert np.all(r["status"] == 0)
+            np.testing.assert_allclose(r["x"][:, :, 0], Xh, atol=1e-8)          # the device x0 is the host-propagated state
+            for i in range(0, batch, 6):
+                assert np.abs(r["u"][i] - mo.solve_mpc_exact(p, Xh[i])["u"]).max() <= U_TOL
+        u0 = np.array([mo.solve_mpc_exact(p, Xh[i])["u"][:, 0] for i in range(batch)])
+        Xh = Xh @ p.A.T + u0 @ p.B.T
+    s.synchronize()
+    s.close()
+    assert np.abs(Xh[:, :3]).max() < np.abs(X[:, :3]).max()
+
+
 def test_api_error_behaviour(capi, mo):
     p = mo.double_integrator()
     s = capi.Solver(2, 1, 10, 2)
