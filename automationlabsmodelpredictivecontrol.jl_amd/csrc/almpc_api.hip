@@ -37,7 +37,8 @@ struct almpc_handle {
     // device: per-instance state and results
     double *dX0 = nullptr, *dXs = nullptr, *dZs = nullptr, *dYs = nullptr, *dV0 = nullptr, *dW = nullptr;
     double *dX = nullptr, *dEx = nullptr, *dU = nullptr, *dEu = nullptr;
-    int32_t *dStatus = nullptr, *dIters = nullptr, *dPiters = nullptr, *dOverflow = nullptr;
+    int32_t *dStatus = nullptr, *dIters = nullptr, *dPiters = nullptr, *dOverflow = nullptr, *dPerm = nullptr, *dPermCnt = nullptr;
+    int parity = 0;
     double* dSglobal = nullptr;  // polish scratch for working sets beyond 32 rows
     // state rows (state box / terminal equality): constraint-space data for k_polish_gen
     int terminal_eq = 0, has_box = 0, mc = 0, R = 0, Rs = 0, np_pairs = 0;
@@ -95,7 +96,7 @@ hipError_t launch_admm(int nrb, int ks, const AdmmParams& p, int grid, size_t ld
 void free_all(almpc_handle* h) {
     void* ptrs[] = {h->dMinvFrag, h->dGFrag, h->dHFrag, h->dFFrag, h->dG, h->dD, h->dUmin, h->dUmax, h->dA, h->dB,
                     h->dXref, h->dUref, h->dFS, h->dRho, h->dX0, h->dXs, h->dZs, h->dYs, h->dV0, h->dW, h->dX, h->dEx,
-                    h->dU, h->dEu, h->dStatus, h->dIters, h->dPiters, h->dOverflow, h->dSglobal, h->dGhat, h->dGnorm, h->dXmin,
+                    h->dU, h->dEu, h->dStatus, h->dIters, h->dPiters, h->dOverflow, h->dPerm, h->dPermCnt, h->dSglobal, h->dGhat, h->dGnorm, h->dXmin,
                     h->dXmax, h->dRowTraj, h->dRowEq, h->dRowXidx, h->dRowState};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -166,6 +167,8 @@ int almpc_create(almpc_handle** out, int n, int m, int N, int batch, int device_
     TRY(dalloc(&h->dX, b * n * (N + 1))); TRY(dalloc(&h->dEx, b * n * (N + 1)));
     TRY(dalloc(&h->dU, b * h->nz)); TRY(dalloc(&h->dEu, b * h->nz));
     TRY(dalloc(&h->dSglobal, b * POLISH_GLB_PER_INST));
+    TRY(dalloc(&h->dPerm, b)); TRY(dalloc(&h->dPermCnt, (size_t)4));
+    TRY(hipMemset(h->dPermCnt, 0, 4 * sizeof(int32_t)));
     TRY(dalloc(&h->dStatus, b)); TRY(dalloc(&h->dIters, b)); TRY(dalloc(&h->dPiters, b)); TRY(dalloc(&h->dOverflow, b));
     TRY(hipMemset(h->dXs, 0, b * h->nzs * sizeof(double)));
     TRY(hipMemset(h->dZs, 0, b * h->nzs * sizeof(double)));
@@ -368,6 +371,8 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
     ap.fS = h->dFS; ap.fS_stride = h->fS_stride; ap.x0 = h->dX0;
     ap.xs = h->dXs; ap.zs = h->dZs; ap.ys = h->dYs; ap.v0 = h->dV0; ap.status = h->dStatus; ap.iters = h->dIters;
     ap.piters = h->dPiters; ap.overflow = h->dOverflow;
+    ap.perm = h->dPerm; ap.perm_cnt = h->dPermCnt; ap.parity = h->parity; ap.hard_threshold = 8;
+    h->parity ^= 1;
     ap.rho = o.rho; ap.sigma = o.sigma; ap.alpha = o.alpha; ap.eps_abs = o.eps_abs; ap.eps_rel = o.eps_rel;
     ap.max_iter = o.max_iter; ap.check_every = o.check_every; ap.warm = o.warm_start ? 1 : 0;
     const int grid = (h->batch + TILE - 1) / TILE;
@@ -413,7 +418,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         pp.nz = h->nz; pp.m = h->m; pp.batch = h->batch; pp.nzs = h->nzs; pp.G = h->dG; pp.dvec = h->dD;
         pp.umin = h->dUmin; pp.umax = h->dUmax; pp.uref = h->dUref; pp.uref_stride = h->uref_stride;
         pp.zs = h->dZs; pp.ys = h->dYs; pp.v0 = h->dV0; pp.w = h->dW; pp.status = h->dStatus; pp.piters = h->dPiters;
-        pp.sglobal = h->dSglobal;
+        pp.sglobal = h->dSglobal; pp.perm = h->dPerm;
         pp.max_iter = o.polish_max_iter > 0 ? o.polish_max_iter : 20 * h->nz + 50;
         // rollout fused into the tail of the polish when its trajectory buffer fits the wave's LDS slot
         fused = roll_fits;

@@ -101,6 +101,9 @@ struct AdmmParams {
     int32_t* iters;
     int32_t* piters;    // zeroed here so that the step needs no memset nodes
     int32_t* overflow;
+    int32_t* perm;      // [batch] polish processing order: instances with a large active-set guess first (see k_polish)
+    int32_t* perm_cnt;  // [2][2] {hard count, easy count} per step parity
+    int parity, hard_threshold;
     double rho, sigma, alpha, eps_abs, eps_rel;
     int max_iter, check_every, warm;
 };
@@ -303,7 +306,30 @@ __global__ __launch_bounds__(64 * NRB) void k_admm(AdmmParams p) {
         p.piters[inst] = 0;
         p.overflow[inst] = 0;
     }
-    __syncthreads();  // everyone is done reading cur/nxt
+    // ---- polish order: the polish is bound by its slowest instance, so instances whose guess already holds many active rows
+    // (a proxy for a long active-set chain) are handed to it first.  Slots: hard ones from the front, the rest from the back.
+    {
+        int cntf = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cntf += (row[i] < p.nz && yt[i] != 0.0) ? 1 : 0;
+        cntf += __shfl_xor(cntf, 16);
+        cntf += __shfl_xor(cntf, 32);
+        if (q == 0) red[(wv * 8 + 0) * TILE + col] = (double)cntf;
+    }
+    __syncthreads();  // everyone is done reading cur/nxt; red holds the per-wave counts
+    if (wv == 0 && q == 0 && valid) {
+        int k0 = 0;
+        for (int w2 = 0; w2 < NRB; ++w2) k0 += (int)red[(w2 * 8 + 0) * TILE + col];
+        int32_t* cnt = p.perm_cnt + 2 * p.parity;
+        int slot;
+        if (k0 >= p.hard_threshold) slot = atomicAdd(&cnt[0], 1);
+        else slot = p.batch - 1 - atomicAdd(&cnt[1], 1);
+        if (slot >= 0 && slot < p.batch) p.perm[slot] = inst;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // the other parity's counters are free again: zero them for the next step
+        p.perm_cnt[2 * (1 - p.parity)] = 0;
+        p.perm_cnt[2 * (1 - p.parity) + 1] = 0;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) rhs1[row[i] * TILE + col] = -fs[i];
     __syncthreads();
@@ -375,6 +401,7 @@ struct PolishParams {
     int32_t* status;     // in: ADMM status; out: final
     int32_t* piters;
     double* sglobal;     // [batch][64*64] scratch for working sets beyond 32 rows
+    const int32_t* perm; // [batch] processing order written by k_admm (hard instances first)
     int max_iter;
     int fuse_rollout;    // 1: this kernel also produces u, e_u, x, e_x (roll.*), no separate k_rollout launch
     int roll_g, roll_cpl; // rollout lane decomposition: roll_g lanes per state row, roll_cpl columns of [A B] per lane
@@ -504,8 +531,9 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
     constexpr int CH = 16;  // positions per chunk of G rows
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int inst = blockIdx.x * POLISH_WAVES + wv;
-    if (inst >= p.batch) return;
+    const int slot = blockIdx.x * POLISH_WAVES + wv;
+    if (slot >= p.batch) return;
+    const int inst = p.perm[slot];
     ALMPC_STAMP(inst, 8);
     const int st_in = p.status[inst];
     const int nz = p.nz, nzs = p.nzs;
