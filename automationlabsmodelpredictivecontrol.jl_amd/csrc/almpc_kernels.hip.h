@@ -449,6 +449,14 @@ ALMPC_WAVE_REDUCE(wave_min, op_min)
 ALMPC_WAVE_REDUCE(wave_max, op_max)
 #undef ALMPC_WAVE_REDUCE
 
+// x(lane) + x(lane ^ 32) in every lane: two v_permlane32_swap (gfx950) instead of an LDS-path ds_bpermute
+__device__ __forceinline__ double half_sum(double v) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+
 __device__ __forceinline__ void wave_fence_lds() {  // order this wave's LDS writes before its later LDS reads
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -459,8 +467,11 @@ __device__ __forceinline__ void wave_fence_lds() {  // order this wave's LDS wri
 // "Position-distributed" quantities (row index, bound, side, multiplier lam, bordering vectors) live in registers,
 // position i of the working set W on lane i.  Sinv = (G_WW)^-1 is stored column-major (S[c*LD + r]: a sweep over
 // columns reads consecutive addresses across lanes) in one of two modes:
-//   LDS mode   (|W| <= 32): Sinv in LDS; both half-waves mirror the positions (position = lane & 31) so that each
-//                           half takes every other column of a sweep.
+//   register mode (|W| <= 32): Sinv in registers, zero padded: lane (pos = lane & 31, hf = lane >> 5) holds
+//                           Sinv[pos][16 hf .. 16 hf + 15]; both half-waves mirror the positions.  A product with Sinv
+//                           is 16 FMAs on broadcast operands, a bordering or down-date is ONE FMA per register (the
+//                           new row/column comes out of the same rank-1 form), the initial inverse is a Gauss-Jordan
+//                           sweep whose only LDS traffic is the broadcast of the pivot column.
 //   global mode (|W| <= 64): when the set outgrows 32 the wave copies Sinv to its slot of a global scratch and
 //                           carries on (no restart); slower per update, but only the updates beyond 32 pay for it.
 //
@@ -527,7 +538,7 @@ constexpr int POLISH_GLB_PER_INST = 64 * 64;        // doubles of global scratch
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
+__global__ __launch_bounds__(64 * POLISH_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_polish(PolishParams p) {
     constexpr int CH = 16;  // positions per chunk of G rows
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -579,16 +590,35 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
     bool overflow = false;   // the set outgrew the current mode
     ALMPC_ACC_DECL
     wrow_s[lane] = 0;
-    {   // Sinv := identity.  ALWAYS (also when the initial set is empty): the sweeps rely on the padding being finite
-        const int pos = lane & 31, hf = lane >> 5;
+    const int hpos = lane & 31, hhf = lane >> 5;
+    double Sr[16];  // register mode: Sr[t] = Sinv[hpos][16 hhf + t], exactly zero outside the k x k block
 #pragma unroll
-        for (int t = 0; t < 16; ++t) Sl[(2 * t + hf) * 32 + pos] = ((2 * t + hf) == pos) ? 1.0 : 0.0;
-    }
+    for (int t = 0; t < 16; ++t) Sr[t] = 0.0;
+    auto bcast16 = [&](const double* buf, double (&o)[16]) {  // this half's 16 entries of a position buffer
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const d2 v = *reinterpret_cast<const d2*>(buf + 16 * hhf + 2 * t);
+            o[2 * t] = v[0]; o[2 * t + 1] = v[1];
+        }
+    };
+    auto col_to_buf = [&](int j, double* buf) {  // buf[pos] = Sinv[pos][j] for a wave-uniform j (register mode)
+        const int tj = j & 15;
+        double v = Sr[0];
+#pragma unroll
+        for (int t = 1; t < 16; ++t) {
+            double x = Sr[t];
+            asm volatile("" : "+v"(x));  // keeps this a select of VALUES: a select of addresses would put Sr in scratch
+            v = (tj == t) ? x : v;
+        }
+        if (hhf == (j >> 4)) buf[hpos] = v;
+        wave_fence_lds();
+    };
     ALMPC_STAMP(inst, 9);
 
-    // Sinv is kept padded with the identity beyond the k x k block and position-distributed vectors are exactly
-    // zero beyond position k, so every sweep below runs over chunk-rounded ranges with UNCONDITIONAL loads and
-    // stores (no exec-masked branches around memory operations: they would serialise every LDS round trip).
+    // Sinv is padded beyond the k x k block (zeros in register mode, the identity in global mode) and
+    // position-distributed vectors are exactly zero beyond position k, so every sweep below runs over chunk-rounded
+    // ranges with UNCONDITIONAL loads and stores (no exec-masked branches around memory operations: they would
+    // serialise every LDS round trip).
     // Broadcasts of a position-distributed vector go through a 64-entry LDS buffer (one uniform-address read per
     // element, pipelined with the Sinv reads) rather than through v_readlane pairs.
     auto sync_s = [&](auto m) {  // order this wave's writes to Sinv before its later reads
@@ -609,19 +639,16 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
     // u = Sinv * c, c given in LDS buffer cb (zero beyond k); result position-distributed (zero beyond k)
     auto s_matvec = [&](auto m, const double* cb) -> double {
         using M = decltype(m);
-        double* S = sptr(m);
         double acc = 0.0;
         if constexpr (M::half) {
-            const int pos = lane & 31, hf = lane >> 5;
-            for (int l0 = 0; l0 < k; l0 += 16) {
-                double sv[8], cv[8];
+            double cv[16];
+            bcast16(cb, cv);
+            double acc2 = 0.0;
 #pragma unroll
-                for (int t = 0; t < 8; ++t) { sv[t] = S[(l0 + 2 * t + hf) * M::WL + pos]; cv[t] = cb[l0 + 2 * t + hf]; }
-#pragma unroll
-                for (int t = 0; t < 8; ++t) acc += sv[t] * cv[t];
-            }
-            acc += __shfl_xor(acc, 32);
+            for (int t = 0; t < 16; t += 2) { acc += Sr[t] * cv[t]; acc2 += Sr[t + 1] * cv[t + 1]; }
+            acc = half_sum(acc + acc2);
         } else {
+            double* S = sptr(m);
             for (int l0 = 0; l0 < k; l0 += 8) {
                 double sv[8], cv[8];
 #pragma unroll
@@ -635,18 +662,14 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
     // Sinv += a a' * scale: a position-distributed in register AND in LDS buffer ab (zero beyond k)
     auto s_rank1 = [&](auto m, double a, const double* ab, double scale) {
         using M = decltype(m);
-        double* S = sptr(m);
         const double as = a * scale;
         if constexpr (M::half) {
-            const int pos = lane & 31, hf = lane >> 5;
-            for (int l0 = 0; l0 < k; l0 += 16) {
-                double cur[8], av[8];
+            double av[16];
+            bcast16(ab, av);
 #pragma unroll
-                for (int t = 0; t < 8; ++t) { cur[t] = S[(l0 + 2 * t + hf) * M::WL + pos]; av[t] = ab[l0 + 2 * t + hf]; }
-#pragma unroll
-                for (int t = 0; t < 8; ++t) S[(l0 + 2 * t + hf) * M::WL + pos] = cur[t] + as * av[t];
-            }
+            for (int t = 0; t < 16; ++t) Sr[t] = __builtin_fma(as, av[t], Sr[t]);
         } else {
+            double* S = sptr(m);
             for (int l0 = 0; l0 < k; l0 += 8) {
                 double cur[8], av[8];
 #pragma unroll
@@ -701,7 +724,6 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
     // add row j (uniform) at bound bval with side sd; the caller guarantees k < capacity
     auto add_row = [&](auto m, int j, double bval, int sd) {
         using M = decltype(m);
-        double* S = sptr(m);
         const int pos = M::half ? (lane & 31) : lane;
         const bool lowhalf = M::half ? (lane < 32) : true;
         ALMPC_ACC_START;
@@ -732,8 +754,21 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
         t1 -= mu * (gj[1] - q1);
         lam -= u * mu;
         ALMPC_ACC(3);
-        s_rank1(m, u, pbufb, isc);
-        {   // border: new column k and new row k (u is zero beyond k, so the padding stays zero)
+        if constexpr (M::half) {
+            // [Sinv + u u'/sc, -u/sc; -u'/sc, 1/sc] as ONE rank-1 update of the zero-padded registers: with -1 in
+            // position k of the broadcast vector and -1/sc as the factor of lane k, the new row, column and corner come
+            // out of the same FMA as the update of the old block
+            if (lane == k) pbufb[k] = -1.0;
+            wave_fence_lds();
+            double av[16];
+            bcast16(pbufb, av);
+            const double as = (pos == k) ? -isc : u * isc;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) Sr[t] = __builtin_fma(as, av[t], Sr[t]);
+        } else {
+            double* S = sptr(m);
+            s_rank1(m, u, pbufb, isc);
+            // border: new column k and new row k (u is zero beyond k, so the padding stays zero)
             const double bv = (pos == k) ? isc : -u * isc;
             S[k * M::WL + pos] = bv;
             S[pos * M::WL + k] = bv;
@@ -752,36 +787,71 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
     // remove position rp (uniform)
     auto remove_pos = [&](auto m, int rp) {
         using M = decltype(m);
-        double* S = sptr(m);
         const int pos = M::half ? (lane & 31) : lane;
-        const double sp = S[rp * M::WL + pos];  // column rp of Sinv (zero beyond k)
-        const double spp = readlane_d(sp, rp);
-        const double a = readlane_d(lam, rp) / spp;
-        put_pos(m, pbufb, sp);
-        double q0, q1;
-        g_rows_times(pbufb, q0, q1);
-        t0 += a * q0;
-        t1 += a * q1;
-        lam -= sp * a;
-        s_rank1(m, sp, pbufb, -1.0 / spp);  // row and column rp become zero
-        sync_s(m);
         const int last = k - 1;
         const int jrem = __builtin_amdgcn_readlane(wrow, rp);
-        if (rp != last) {  // move the last position into the hole
-            const double colv = S[last * M::WL + pos];
-            const double corner = readlane_d(colv, last);
-            const double nv = (pos == rp) ? corner : ((pos == last) ? 0.0 : colv);
-            S[rp * M::WL + pos] = nv;
-            S[pos * M::WL + rp] = nv;
-            const int lrow = __builtin_amdgcn_readlane(wrow, last), lsd = __builtin_amdgcn_readlane(wsd, last);
-            const double lbv = readlane_d(wbnd, last), llam = readlane_d(lam, last);
-            if (pos == rp) { wrow = lrow; wsd = lsd; wbnd = lbv; lam = llam; }
-            if (lane == 0) wrow_s[rp] = lrow;
-        }
-        {   // position `last` returns to the identity padding
-            const double iv = (pos == last) ? 1.0 : 0.0;
-            S[last * M::WL + pos] = iv;
-            S[pos * M::WL + last] = iv;
+        if constexpr (M::half) {
+            col_to_buf(rp, pbufb);
+            const double sp = pbufb[pos];  // column rp of Sinv (zero beyond k)
+            double av[16];
+            bcast16(pbufb, av);
+            const double spp = readlane_d(sp, rp);
+            const double a = readlane_d(lam, rp) / spp;
+            double q0, q1;
+            g_rows_times(pbufb, q0, q1);
+            t0 += a * q0;
+            t1 += a * q1;
+            lam -= sp * a;
+            const double as = -sp / spp;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) Sr[t] = __builtin_fma(as, av[t], Sr[t]);  // row and column rp become ~zero
+            if (rp != last) {  // move the last position into the hole
+                col_to_buf(last, pbufa);
+                const double colv = pbufa[pos];
+                const double corner = readlane_d(colv, last);
+                const double nv = (pos == rp) ? corner : ((pos == last) ? 0.0 : colv);
+                put_pos(m, pbufa, nv);
+                double rv[16];
+                bcast16(pbufa, rv);
+#pragma unroll
+                for (int t = 0; t < 16; ++t) Sr[t] = (pos == rp) ? rv[t] : ((16 * hhf + t == rp) ? nv : Sr[t]);
+                const int lrow = __builtin_amdgcn_readlane(wrow, last), lsd = __builtin_amdgcn_readlane(wsd, last);
+                const double lbv = readlane_d(wbnd, last), llam = readlane_d(lam, last);
+                if (pos == rp) { wrow = lrow; wsd = lsd; wbnd = lbv; lam = llam; }
+                if (lane == 0) wrow_s[rp] = lrow;
+            }
+            // position `last` returns to the zero padding
+#pragma unroll
+            for (int t = 0; t < 16; ++t) Sr[t] = (pos == last || 16 * hhf + t == last) ? 0.0 : Sr[t];
+        } else {
+            double* S = sptr(m);
+            const double sp = S[rp * M::WL + pos];  // column rp of Sinv (zero beyond k)
+            const double spp = readlane_d(sp, rp);
+            const double a = readlane_d(lam, rp) / spp;
+            put_pos(m, pbufb, sp);
+            double q0, q1;
+            g_rows_times(pbufb, q0, q1);
+            t0 += a * q0;
+            t1 += a * q1;
+            lam -= sp * a;
+            s_rank1(m, sp, pbufb, -1.0 / spp);  // row and column rp become zero
+            sync_s(m);
+            if (rp != last) {  // move the last position into the hole
+                const double colv = S[last * M::WL + pos];
+                const double corner = readlane_d(colv, last);
+                const double nv = (pos == rp) ? corner : ((pos == last) ? 0.0 : colv);
+                S[rp * M::WL + pos] = nv;
+                S[pos * M::WL + rp] = nv;
+                const int lrow = __builtin_amdgcn_readlane(wrow, last), lsd = __builtin_amdgcn_readlane(wsd, last);
+                const double lbv = readlane_d(wbnd, last), llam = readlane_d(lam, last);
+                if (pos == rp) { wrow = lrow; wsd = lsd; wbnd = lbv; lam = llam; }
+                if (lane == 0) wrow_s[rp] = lrow;
+            }
+            {   // position `last` returns to the identity padding
+                const double iv = (pos == last) ? 1.0 : 0.0;
+                S[last * M::WL + pos] = iv;
+                S[pos * M::WL + last] = iv;
+            }
         }
         if (pos == last) lam = 0.0;
         if (lane == 0) wrow_s[last] = 0;
@@ -859,7 +929,10 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
             fresh = false;
         }
     };
-    auto to_global = [&]() {  // carry Sinv (k <= 32 positions) over to the global slot: leading dimension 64, identity padded
+    auto to_global = [&]() {  // carry Sinv (k = 32 positions) over to the global slot: leading dimension 64, identity padded
+#pragma unroll
+        for (int t = 0; t < 16; ++t) Sl[(16 * hhf + t) * 32 + hpos] = Sr[t];  // staged through LDS (symmetric)
+        wave_fence_lds();
         for (int c = 0; c < 64; ++c) {
             const double v = (c < 32 && lane < 32) ? Sl[(c & 31) * 32 + (lane & 31)] : ((c == lane) ? 1.0 : 0.0);
             Sg[c * 64 + lane] = v;
@@ -879,7 +952,7 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
     if (!give_up && k0 > 0) {
         using M = PolishMode<false>;
         const M m{};
-        const int pos = lane & 31, hf = lane >> 5;
+        const int pos = lane & 31;
         // position of a flagged row = number of flagged rows before it (rows ascend with the lane, then first/second)
         const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
         const int p0 = __popcll(m0 & below) + __popcll(m1 & below), p1 = p0 + (s0 != 0 ? 1 : 0);
@@ -899,60 +972,40 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) void k_polish(PolishParams p) {
         if (pos < k) wbnd = rowbuf[wrow];
         const double pend_bnd = (lane >= 32 && lane < k0) ? rowbuf[pend_row] : 0.0;
         if (lane < 32) wrow_s[lane] = (lane < k) ? wrow : 0;
-        // K = G[W,W] into the leading k x k block of the (identity-initialised) Sinv, each half every other column
-        for (int l0 = 0; l0 < k; l0 += 16) {
-            double gv[8];
+        // K = G[W,W] into the leading k x k block of the (zero padded) register Sinv
+        {
+            double gv[16];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) gv[t] = p.G[(size_t)wrow_s[l0 + 2 * t + hf] * nzs + wrow];
+            for (int t = 0; t < 16; ++t) gv[t] = p.G[(size_t)wrow_s[16 * hhf + t] * nzs + wrow];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int l = l0 + 2 * t + hf;
-                const double idv = (l == pos) ? 1.0 : 0.0;
-                Sl[l * 32 + pos] = (l < k && pos < k) ? gv[t] : idv;
-            }
+            for (int t = 0; t < 16; ++t) Sr[t] = (16 * hhf + t < k && pos < k) ? gv[t] : 0.0;
         }
-        wave_fence_lds();
-        // Gauss-Jordan in place on the padded matrix.  Per pivot ALL reads (pivot, pivot column, pivot row, own
-        // elements) are issued before any write, so a pivot costs one LDS round trip plus the reciprocal; rows/columns
-        // beyond k are identity and stay so (their f or row element is zero).
-        const bool two = k > 16;  // second group of 16 columns in use
-        for (int pv = 0; pv < k; ++pv) {
-            const double piv = Sl[pv * 32 + pv];
-            const double fcol = Sl[pv * 32 + pos];  // S[i][pv]
-            double rowpc[16], mine[16];
+        // Gauss-Jordan in place (SPD: no pivoting).  Before pivot pv the swept matrix satisfies S[pv][c] = -S[c][pv] for
+        // the columns already done (c < pv) and S[pv][c] = S[c][pv] for the others, so the pivot ROW every lane needs
+        // is the pivot COLUMN (one register of each lane of the owning half) broadcast with that sign through LDS:
+        // one write + one round trip of reads per pivot, everything else is register arithmetic.
+        for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int c = 2 * t + hf;
-                rowpc[t] = Sl[c * 32 + pv];   // S[pv][c]
-                mine[t] = Sl[c * 32 + pos];   // S[i][c]
-            }
-            if (two) {
+            for (int tj = 0; tj < 16; ++tj) {
+                const int pv = 16 * hh + tj;
+                if (pv < k) {
+                    if (hhf == hh) {
+                        pbufa[hpos] = Sr[tj];
+                        pbufb[hpos] = (hpos < pv) ? -Sr[tj] : Sr[tj];
+                    }
+                    wave_fence_lds();
+                    const double fcol = pbufa[hpos], piv = pbufa[pv];
+                    double rowpv[16];
+                    bcast16(pbufb, rowpv);
+                    const double ip = 1.0 / piv;
+                    const bool isp = hpos == pv;
+                    const double f = isp ? 0.0 : fcol * ip;   // the pivot row itself is rescaled, not eliminated
+                    const double scale = isp ? ip : 1.0;
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const int c = 16 + 2 * t + hf;
-                    rowpc[8 + t] = Sl[c * 32 + pv];
-                    mine[8 + t] = Sl[c * 32 + pos];
+                    for (int t = 0; t < 16; ++t) Sr[t] = __builtin_fma(-f, rowpv[t], Sr[t]) * scale;
+                    Sr[tj] = (hhf == hh) ? (isp ? ip : -f) : Sr[tj];  // column pv
                 }
             }
-            const double ip = 1.0 / piv;
-            const bool isp = pos == pv;
-            const double f = isp ? 0.0 : fcol * ip;  // row pv itself is rescaled below, not eliminated
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int c = 2 * t + hf;
-                const double v = mine[t] - f * rowpc[t];
-                Sl[c * 32 + pos] = isp ? rowpc[t] * ip : v;
-            }
-            if (two) {
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const int c = 16 + 2 * t + hf;
-                    const double v = mine[8 + t] - f * rowpc[8 + t];
-                    Sl[c * 32 + pos] = isp ? rowpc[8 + t] * ip : v;
-                }
-            }
-            Sl[pv * 32 + pos] = isp ? ip : -f;  // column pv (after the sweep above, which left 0 there)
-            wave_fence_lds();
         }
         recompute(m);
         if (k0 > 32) {

@@ -44,3 +44,10 @@ print("per-add phase cycles (instances with >= 8 adds in the loop), mean per add
 for i, nm in enumerate(["A loads+rowbuf+gather c", "B put c + Sinv matvec", "C put u + G rows fma", "D sum/div/t update", "E rank1+border+sync", "F ratio test"]):
     print(f"   {nm:26s} {np.mean(acc[sel, i] / n[sel]):8.0f}")
 s.close()
+# the slowest waves in detail
+okidx = np.nonzero(ok)[0]
+order = np.argsort(-tot)[:6]
+print("slowest instances: inst, total, per-phase cycles, polish its, adds counted")
+for o in order:
+    i = okidx[o]
+    print("  ", i, int(tot[o]), d[o].tolist(), int(pit[i]), int(acc[i, 8]), "acc", (acc[i, :6]).tolist())
