@@ -28,17 +28,19 @@ struct almpc_handle {
     // host copies of the design (almpc_get_design)
     std::vector<double> H, F, P, d;
     // device: shared design
-    double *dMinvFrag = nullptr, *dGFrag = nullptr, *dHFrag = nullptr, *dFFrag = nullptr, *dG = nullptr;
+    double *dMinvFrag = nullptr, *dVFrag = nullptr, *dHFrag = nullptr, *dFFrag = nullptr, *dG = nullptr;
     double *dD = nullptr, *dUmin = nullptr, *dUmax = nullptr, *dA = nullptr, *dB = nullptr;
-    double *dXref = nullptr, *dUref = nullptr, *dFS = nullptr, *dRho = nullptr;
+    double *dXref = nullptr, *dUref = nullptr, *dFS = nullptr, *dV0S = nullptr, *dRho = nullptr;
     int rho_mode = 0;  // 0 scalar rho (OSQP), 1 stiffness profile rho / G_ii
     long xref_stride = 0, uref_stride = 0, fS_stride = 0;
     std::vector<double> hS;  // S weight (for fS with per-instance references)
     // device: per-instance state and results
     double *dX0 = nullptr, *dXs = nullptr, *dZs = nullptr, *dYs = nullptr, *dV0 = nullptr, *dW = nullptr;
     double *dX = nullptr, *dEx = nullptr, *dU = nullptr, *dEu = nullptr;
-    int32_t *dStatus = nullptr, *dIters = nullptr, *dPiters = nullptr, *dOverflow = nullptr, *dPerm = nullptr, *dPermCnt = nullptr;
-    int parity = 0;
+    int32_t *dStatus = nullptr, *dIters = nullptr, *dPiters = nullptr, *dOverflow = nullptr, *dPerm = nullptr;
+    int num_cus = 256;            // persistent-grid size of k_polish<true>
+    size_t polish_glds_bytes = 0; // dynamic-LDS attribute last set on k_polish<true>
+    int polish_no_glds = 0;       // diagnostic: force the G-through-L2 build (ALMPC_POLISH_NO_GLDS=1)
     double* dSglobal = nullptr;  // polish scratch for working sets beyond 32 rows
     // state rows (state box / terminal equality): constraint-space data for k_polish_gen
     int terminal_eq = 0, has_box = 0, mc = 0, R = 0, Rs = 0, np_pairs = 0;
@@ -94,9 +96,9 @@ hipError_t launch_admm(int nrb, int ks, const AdmmParams& p, int grid, size_t ld
 }
 
 void free_all(almpc_handle* h) {
-    void* ptrs[] = {h->dMinvFrag, h->dGFrag, h->dHFrag, h->dFFrag, h->dG, h->dD, h->dUmin, h->dUmax, h->dA, h->dB,
-                    h->dXref, h->dUref, h->dFS, h->dRho, h->dX0, h->dXs, h->dZs, h->dYs, h->dV0, h->dW, h->dX, h->dEx,
-                    h->dU, h->dEu, h->dStatus, h->dIters, h->dPiters, h->dOverflow, h->dPerm, h->dPermCnt, h->dSglobal, h->dGhat, h->dGnorm, h->dXmin,
+    void* ptrs[] = {h->dMinvFrag, h->dVFrag, h->dHFrag, h->dFFrag, h->dG, h->dD, h->dUmin, h->dUmax, h->dA, h->dB,
+                    h->dXref, h->dUref, h->dFS, h->dV0S, h->dRho, h->dX0, h->dXs, h->dZs, h->dYs, h->dV0, h->dW, h->dX, h->dEx,
+                    h->dU, h->dEu, h->dStatus, h->dIters, h->dPiters, h->dOverflow, h->dPerm, h->dSglobal, h->dGhat, h->dGnorm, h->dXmin,
                     h->dXmax, h->dRowTraj, h->dRowEq, h->dRowXidx, h->dRowState};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -155,8 +157,15 @@ int almpc_create(almpc_handle** out, int n, int m, int N, int batch, int device_
     } while (0)
     TRY(hipSetDevice(device_id));
     TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    {
+        int cus = 0;
+        TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id));
+        if (cus > 0) h->num_cus = cus;
+        const char* e = getenv("ALMPC_POLISH_NO_GLDS");
+        h->polish_no_glds = (e && e[0] == '1') ? 1 : 0;
+    }
     const size_t fr = (size_t)h->nrb * h->ks * 64, b = (size_t)batch;
-    TRY(dalloc(&h->dMinvFrag, fr)); TRY(dalloc(&h->dGFrag, fr)); TRY(dalloc(&h->dHFrag, fr));
+    TRY(dalloc(&h->dMinvFrag, fr)); TRY(dalloc(&h->dVFrag, (size_t)h->nrb * h->ksf * 64)); TRY(dalloc(&h->dHFrag, fr));
     TRY(dalloc(&h->dFFrag, (size_t)h->nrb * h->ksf * 64));
     TRY(dalloc(&h->dG, (size_t)h->nz * h->nzs));
     TRY(dalloc(&h->dD, (size_t)h->nzs)); TRY(dalloc(&h->dRho, (size_t)h->nzs)); TRY(dalloc(&h->dUmin, (size_t)m)); TRY(dalloc(&h->dUmax, (size_t)m));
@@ -167,8 +176,7 @@ int almpc_create(almpc_handle** out, int n, int m, int N, int batch, int device_
     TRY(dalloc(&h->dX, b * n * (N + 1))); TRY(dalloc(&h->dEx, b * n * (N + 1)));
     TRY(dalloc(&h->dU, b * h->nz)); TRY(dalloc(&h->dEu, b * h->nz));
     TRY(dalloc(&h->dSglobal, b * POLISH_GLB_PER_INST));
-    TRY(dalloc(&h->dPerm, b)); TRY(dalloc(&h->dPermCnt, (size_t)4));
-    TRY(hipMemset(h->dPermCnt, 0, 4 * sizeof(int32_t)));
+    TRY(dalloc(&h->dPerm, ((b + 15) / 16) * 16));
     TRY(dalloc(&h->dStatus, b)); TRY(dalloc(&h->dIters, b)); TRY(dalloc(&h->dPiters, b)); TRY(dalloc(&h->dOverflow, b));
     TRY(hipMemset(h->dXs, 0, b * h->nzs * sizeof(double)));
     TRY(hipMemset(h->dZs, 0, b * h->nzs * sizeof(double)));
@@ -269,7 +277,7 @@ int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const
         HIP_TRY(h, hipMemcpy(h->dXmax, hi.data(), n * sizeof(double), hipMemcpyHostToDevice));
     }
     int rc = design_shared_device(h->stream, n, m, N, h->nzs, h->nrb, h->ks, h->ksf, Am, Bm, Qm, Rm, Sm, Pm, rho, sigma,
-                                  h->dMinvFrag, h->dGFrag, h->dHFrag, h->dFFrag, h->dG, h->dD, h->H, h->F, h->d, h->err,
+                                  h->dMinvFrag, h->dVFrag, h->dHFrag, h->dFFrag, h->dG, h->dD, h->H, h->F, h->d, h->err,
                                   rowsel, h->Rs, h->dGhat, h->dGnorm, h->rho_mode, h->dRho);
     if (rc != ALMPC_OK) return rc;
     HIP_TRY(h, hipMemcpy(h->dUmin, umin, m * sizeof(double), hipMemcpyHostToDevice));
@@ -294,9 +302,11 @@ int almpc_set_reference(almpc_handle* h, const double* xref, const double* uref,
     if (h->dXref) { (void)hipFree(h->dXref); h->dXref = nullptr; }
     if (h->dUref) { (void)hipFree(h->dUref); h->dUref = nullptr; }
     if (h->dFS) { (void)hipFree(h->dFS); h->dFS = nullptr; }
+    if (h->dV0S) { (void)hipFree(h->dV0S); h->dV0S = nullptr; }
     HIP_TRY(h, dalloc(&h->dXref, cnt * xs));
     HIP_TRY(h, dalloc(&h->dUref, cnt * us));
     HIP_TRY(h, dalloc(&h->dFS, cnt * us));
+    HIP_TRY(h, dalloc(&h->dV0S, cnt * us));
     HIP_TRY(h, hipMemcpy(h->dXref, xref, cnt * xs * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->dUref, uref, cnt * us * sizeof(double), hipMemcpyHostToDevice));
     // fS = d .* (2 D'Sbar D u_ref): the input-rate cost is on u, not e_u (src/sub/design_mpc.jl:423-446)
@@ -316,6 +326,14 @@ int almpc_set_reference(almpc_handle* h, const double* xref, const double* uref,
         }
     }
     HIP_TRY(h, hipMemcpy(h->dFS, fS.data(), cnt * us * sizeof(double), hipMemcpyHostToDevice));
+    // v0S = -G fS: constant part of the polish's unconstrained minimiser (k_admm adds the part linear in e0)
+    {
+        const size_t blocks = (cnt * us + 255) / 256;
+        hipLaunchKernelGGL(k_neg_gm, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, h->stream, nz, h->nzs,
+                           (int)cnt, (int)us, h->dG, h->dFS, h->dV0S);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
     h->xref_stride = per_instance ? (long)xs : 0;
     h->uref_stride = per_instance ? (long)us : 0;
     h->fS_stride = per_instance ? (long)us : 0;
@@ -365,14 +383,13 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
 
     AdmmParams ap;
     ap.nz = h->nz; ap.n = h->n; ap.m = h->m; ap.batch = h->batch; ap.nzs = h->nzs;
-    ap.MinvFrag = h->dMinvFrag; ap.GFrag = h->dGFrag; ap.HFrag = h->dHFrag; ap.FFrag = h->dFFrag; ap.ksf = h->ksf;
+    ap.MinvFrag = h->dMinvFrag; ap.VFrag = h->dVFrag; ap.v0S = h->dV0S; ap.v0S_stride = h->fS_stride; ap.HFrag = h->dHFrag; ap.FFrag = h->dFFrag; ap.ksf = h->ksf;
     ap.dvec = h->dD; ap.rhovec = h->dRho; ap.umin = h->dUmin; ap.umax = h->dUmax;
     ap.uref = h->dUref; ap.uref_stride = h->uref_stride; ap.xref = h->dXref; ap.xref_stride = h->xref_stride;
     ap.fS = h->dFS; ap.fS_stride = h->fS_stride; ap.x0 = h->dX0;
     ap.xs = h->dXs; ap.zs = h->dZs; ap.ys = h->dYs; ap.v0 = h->dV0; ap.status = h->dStatus; ap.iters = h->dIters;
     ap.piters = h->dPiters; ap.overflow = h->dOverflow;
-    ap.perm = h->dPerm; ap.perm_cnt = h->dPermCnt; ap.parity = h->parity; ap.hard_threshold = 8;
-    h->parity ^= 1;
+    ap.perm = h->dPerm;
     ap.rho = o.rho; ap.sigma = o.sigma; ap.alpha = o.alpha; ap.eps_abs = o.eps_abs; ap.eps_rel = o.eps_rel;
     ap.max_iter = o.max_iter; ap.check_every = o.check_every; ap.warm = o.warm_start ? 1 : 0;
     const int grid = (h->batch + TILE - 1) / TILE;
@@ -418,13 +435,30 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         pp.nz = h->nz; pp.m = h->m; pp.batch = h->batch; pp.nzs = h->nzs; pp.G = h->dG; pp.dvec = h->dD;
         pp.umin = h->dUmin; pp.umax = h->dUmax; pp.uref = h->dUref; pp.uref_stride = h->uref_stride;
         pp.zs = h->dZs; pp.ys = h->dYs; pp.v0 = h->dV0; pp.w = h->dW; pp.status = h->dStatus; pp.piters = h->dPiters;
-        pp.sglobal = h->dSglobal; pp.perm = h->dPerm;
+        pp.sglobal = h->dSglobal; pp.perm = h->dPerm; pp.ntiles = (h->batch + 15) / 16;
         pp.max_iter = o.polish_max_iter > 0 ? o.polish_max_iter : 20 * h->nz + 50;
         // rollout fused into the tail of the polish when its trajectory buffer fits the wave's LDS slot
         fused = roll_fits;
         pp.fuse_rollout = fused ? 1 : 0; pp.roll_g = roll_g; pp.roll_cpl = roll_cpl; pp.roll = rp;
-        const size_t l = (size_t)POLISH_WAVES * POLISH_LDS_PER_WAVE * sizeof(double);
-        hipLaunchKernelGGL(k_polish, dim3((h->batch + POLISH_WAVES - 1) / POLISH_WAVES), dim3(64 * POLISH_WAVES), l, st, pp);
+        int per_wave = POLISH_LDS_MIN_PER_WAVE;
+        if (fused && (h->N + 1) * (h->n + h->m) > per_wave) per_wave = (h->N + 1) * (h->n + h->m);
+        per_wave = (per_wave + 1) & ~1;
+        pp.lds_per_wave = per_wave;
+        // G in LDS when it fits beside the buffers of 8 waves (gfx950: 160 KB per workgroup)
+        const size_t l_glds = ((size_t)h->nz * h->nzs + (size_t)POLISH_WAVES_GLDS * per_wave + 2) * sizeof(double);
+        if (l_glds <= 160 * 1024 && !h->polish_no_glds) {
+            if (h->polish_glds_bytes != l_glds) {
+                HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_polish<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)l_glds));
+                h->polish_glds_bytes = l_glds;
+            }
+            int wgs = pp.ntiles;  // one ADMM tile (16 instances) per workgroup and round
+            if (wgs > h->num_cus) wgs = h->num_cus;
+            hipLaunchKernelGGL((k_polish<true>), dim3(wgs), dim3(64 * POLISH_WAVES_GLDS), l_glds, st, pp);
+        } else {
+            const size_t l = (size_t)POLISH_WAVES * per_wave * sizeof(double);
+            hipLaunchKernelGGL((k_polish<false>), dim3((pp.ntiles * 16 + POLISH_WAVES - 1) / POLISH_WAVES), dim3(64 * POLISH_WAVES), l, st, pp);
+        }
         HIP_TRY(h, hipGetLastError());
         rp.w = h->dW;
     }

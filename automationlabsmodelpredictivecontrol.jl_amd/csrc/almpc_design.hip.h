@@ -261,6 +261,20 @@ __global__ __launch_bounds__(256) void k_pack_frags(const double* M, int rows, i
     }
 }
 
+// ---- Out[:, c] = -G M[:, c] for a few columns (leading dimension ld for M and Out; G dense symmetric, leading dimension nzs).
+// Design-time / set_reference-time helper for the polish's unconstrained minimiser v0 = -G f' = (-G F') e0 + (-G fS):
+// with V = -G F' packed like F', k_admm gets v0 from n columns instead of a second nz x nz product per step.
+__global__ __launch_bounds__(256) void k_neg_gm(int nz, int nzs, int ncols, int ld, const double* G, const double* M, double* Out) {
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < (long)ncols * nz; t += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(t / nz), r = (int)(t % nz);
+        const double* g = G + (size_t)r * nzs;
+        const double* mcol = M + (size_t)c * ld;
+        double acc = 0.0;
+        for (int j = 0; j < nz; ++j) acc += g[j] * mcol[j];
+        Out[(size_t)c * ld + r] = -acc;
+    }
+}
+
 // ---- constraint space for state rows (state box / terminal equality): Ghat = A G A',  A = [I; C'],  C' = Gamma[rows] D ----
 // Cold path: one thread per output element.
 __global__ __launch_bounds__(256) void k_build_cprime(int mc, int nz, int nzs, int gs, const int* rowsel, const double* Gam,
@@ -305,7 +319,7 @@ __global__ __launch_bounds__(256) void k_ghat(int nz, int mc, int nzs, int Rs, c
 inline int design_shared_device(hipStream_t stream, int n, int m, int N, int nzs, int nrb, int ks, int ksf,
                                 const std::vector<double>& A, const std::vector<double>& B, std::vector<double> Q,
                                 std::vector<double> R, std::vector<double> S, std::vector<double> P, double rho,
-                                double sigma, double* dMinvFrag, double* dGFrag, double* dHFrag, double* dFFrag,
+                                double sigma, double* dMinvFrag, double* dVFrag, double* dHFrag, double* dFFrag,
                                 double* dG, double* dD, std::vector<double>& hH, std::vector<double>& hF,
                                 std::vector<double>& hd, std::string& err, const std::vector<int>& rowsel = std::vector<int>(),
                                 int Rs = 0, double* dGhat = nullptr, double* dGnorm = nullptr, int rho_mode = 0,
@@ -334,14 +348,14 @@ inline int design_shared_device(hipStream_t stream, int n, int m, int N, int nzs
         if (e == hipSuccess) { tmp.push_back(*p); e = hipMemsetAsync(*p, 0, cnt * sizeof(double), stream); }
         return e;
     };
-    double *dA, *dB, *dQ, *dR, *dS, *dP, *dPhi, *dGk, *dGam, *dW, *dWP, *dH, *dF, *dHs, *dFs, *dMinv;
+    double *dA, *dB, *dQ, *dR, *dS, *dP, *dPhi, *dGk, *dGam, *dW, *dWP, *dH, *dF, *dHs, *dFs, *dVs, *dMinv;
     int* dFlag;
     DTRY(dnew(&dA, (size_t)n * n)); DTRY(dnew(&dB, (size_t)n * m)); DTRY(dnew(&dQ, (size_t)n * n));
     DTRY(dnew(&dR, (size_t)m * m)); DTRY(dnew(&dS, (size_t)m * m)); DTRY(dnew(&dP, (size_t)n * n));
     DTRY(dnew(&dPhi, (size_t)N * n * n)); DTRY(dnew(&dGk, (size_t)N * n * m));
     DTRY(dnew(&dGam, (size_t)kr * gs)); DTRY(dnew(&dW, (size_t)kr * gs)); DTRY(dnew(&dWP, (size_t)kr * ps));
     DTRY(dnew(&dH, (size_t)nz * nz)); DTRY(dnew(&dF, (size_t)nz * n));
-    DTRY(dnew(&dHs, (size_t)nz * nzs)); DTRY(dnew(&dFs, (size_t)n * nzs)); DTRY(dnew(&dMinv, (size_t)nz * nzs));
+    DTRY(dnew(&dHs, (size_t)nz * nzs)); DTRY(dnew(&dFs, (size_t)n * nzs)); DTRY(dnew(&dVs, (size_t)n * nzs)); DTRY(dnew(&dMinv, (size_t)nz * nzs));
     {
         double* f = nullptr;
         DTRY(dnew(&f, 8));
@@ -378,7 +392,8 @@ inline int design_shared_device(hipStream_t stream, int n, int m, int N, int nzs
     hipLaunchKernelGGL(k_design_inverse, dim3(1), dim3(512), inv_lds, stream, nz, nzs, dHs, sigma, (const double*)dRho, dMinv, dFlag);
     DTRY(hipGetLastError());
     hipLaunchKernelGGL(k_pack_frags, dim3(32), dim3(256), 0, stream, dMinv, nz, nz, nzs, nrb, ks, dMinvFrag);
-    hipLaunchKernelGGL(k_pack_frags, dim3(32), dim3(256), 0, stream, dG, nz, nz, nzs, nrb, ks, dGFrag);
+    hipLaunchKernelGGL(k_neg_gm, dim3(32), dim3(256), 0, stream, nz, nzs, n, nzs, dG, dFs, dVs);
+    hipLaunchKernelGGL(k_pack_frags, dim3(32), dim3(256), 0, stream, dVs, nz, n, nzs, nrb, ksf, dVFrag);
     hipLaunchKernelGGL(k_pack_frags, dim3(32), dim3(256), 0, stream, dHs, nz, nz, nzs, nrb, ks, dHFrag);
     hipLaunchKernelGGL(k_pack_frags, dim3(32), dim3(256), 0, stream, dFs, nz, n, nzs, nrb, ksf, dFFrag);
     DTRY(hipGetLastError());

@@ -78,7 +78,9 @@ __device__ __forceinline__ double qmax(double v) {  // max over the 4 lanes that
 struct AdmmParams {
     int nz, n, m, batch, nzs;  // nzs: row stride of per-instance vectors (= 16*NRB)
     const double* MinvFrag;    // [NRB][KS][64]   (H' + (sigma+rho) I)^-1
-    const double* GFrag;       // [NRB][KS][64]   H'^-1
+    const double* VFrag;       // [NRB][ksf][64]  -H'^-1 F'  (v0 = V e0 + v0S)
+    const double* v0S;         // [1 or batch][nz] -H'^-1 fS
+    long v0S_stride;
     const double* HFrag;       // [NRB][KS][64]   H'   (warm start only)
     const double* FFrag;       // [NRB][KSF][64]  F' = D F
     int ksf;
@@ -101,9 +103,7 @@ struct AdmmParams {
     int32_t* iters;
     int32_t* piters;    // zeroed here so that the step needs no memset nodes
     int32_t* overflow;
-    int32_t* perm;      // [batch] polish processing order: instances with a large active-set guess first (see k_polish)
-    int32_t* perm_cnt;  // [2][2] {hard count, easy count} per step parity
-    int parity, hard_threshold;
+    int32_t* perm;      // [tiles*16] polish processing order inside each tile: large active-set guess first (see k_polish)
     double rho, sigma, alpha, eps_abs, eps_rel;
     int max_iter, check_every, warm;
 };
@@ -297,17 +297,23 @@ __global__ __launch_bounds__(64 * NRB) void k_admm(AdmmParams p) {
     }
 
     ALMPC_STAMP(blockIdx.x * NRB + wv, 2);
-    // ---- v0 = -H'^-1 f' for the polish: same tile product with the G fragments (loads issued before the stores)
+    // ---- v0 = -H'^-1 f' for the polish.  f' = F' e0 + fS is affine in e0, so v0 = V e0 + v0S with V = -H'^-1 F' (design)
+    // and v0S = -H'^-1 fS (set_reference): n columns instead of a second nz x nz tile product.  Loads issued before the stores.
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) a[ks] = p.GFrag[((size_t)(wv * KS + ks)) * 64 + lane];
+    for (int ks = 0; ks < KSF_MAX; ++ks)
+        af[ks] = (ks < p.ksf) ? p.VFrag[((size_t)(wv * p.ksf + ks)) * 64 + lane] : 0.0;
+    double v0s[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v0s[i] = (row[i] < p.nz) ? p.v0S[(size_t)instc * p.v0S_stride + row[i]] : 0.0;
     if (valid && wv == 0 && q == 0) {
         p.iters[inst] = my_iters;
         p.status[inst] = my_status;
         p.piters[inst] = 0;
         p.overflow[inst] = 0;
     }
-    // ---- polish order: the polish is bound by its slowest instance, so instances whose guess already holds many active rows
-    // (a proxy for a long active-set chain) are handed to it first.  Slots: hard ones from the front, the rest from the back.
+    // ---- polish order: the polish is bound by its slowest instances, so within every tile the instances are ranked by the
+    // size of their active-set guess (a proxy for a long active-set chain): perm[tile*16 + rank] = instance (-1: pad column).
+    // The polish hands out rank 0 of every tile first, then rank 1, ...  No global counters or atomics are involved.
     {
         int cntf = 0;
 #pragma unroll
@@ -317,23 +323,25 @@ __global__ __launch_bounds__(64 * NRB) void k_admm(AdmmParams p) {
         if (q == 0) red[(wv * 8 + 0) * TILE + col] = (double)cntf;
     }
     __syncthreads();  // everyone is done reading cur/nxt; red holds the per-wave counts
-    if (wv == 0 && q == 0 && valid) {
-        int k0 = 0;
-        for (int w2 = 0; w2 < NRB; ++w2) k0 += (int)red[(w2 * 8 + 0) * TILE + col];
-        int32_t* cnt = p.perm_cnt + 2 * p.parity;
-        int slot;
-        if (k0 >= p.hard_threshold) slot = atomicAdd(&cnt[0], 1);
-        else slot = p.batch - 1 - atomicAdd(&cnt[1], 1);
-        if (slot >= 0 && slot < p.batch) p.perm[slot] = inst;
+    if (wv == 0 && q == 0) {  // lanes 0..15 of wave 0: one instance each
+        int k0 = valid ? 0 : -1;  // pad columns sort last
+        if (valid)
+            for (int w2 = 0; w2 < NRB; ++w2) k0 += (int)red[(w2 * 8 + 0) * TILE + col];
+        red[(0 * 8 + 1) * TILE + col] = (double)k0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int rank = 0;
+        for (int c2 = 0; c2 < TILE; ++c2) {
+            const int ko = (int)red[(0 * 8 + 1) * TILE + c2];
+            rank += (ko > k0 || (ko == k0 && c2 < col)) ? 1 : 0;
+        }
+        p.perm[blockIdx.x * TILE + rank] = valid ? inst : -1;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {  // the other parity's counters are free again: zero them for the next step
-        p.perm_cnt[2 * (1 - p.parity)] = 0;
-        p.perm_cnt[2 * (1 - p.parity) + 1] = 0;
-    }
+    d4 v04 = {v0s[0], v0s[1], v0s[2], v0s[3]};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) rhs1[row[i] * TILE + col] = -fs[i];
-    __syncthreads();
-    const d4 v04 = tile_matmul<KS>(a, rhs1, q, col);
+    for (int ks = 0; ks < KSF_MAX; ++ks)
+        if (ks < p.ksf) v04 = mfma_f64(af[ks], e0s[(4 * ks + q) * TILE + col], v04);
     ALMPC_STAMP(blockIdx.x * NRB + wv, 3);
 
     // ---- results (scaled coordinates) to HBM: transpose each [row][instance] register tile through LDS so that every
@@ -401,7 +409,9 @@ struct PolishParams {
     int32_t* status;     // in: ADMM status; out: final
     int32_t* piters;
     double* sglobal;     // [batch][64*64] scratch for working sets beyond 32 rows
-    const int32_t* perm; // [batch] processing order written by k_admm (hard instances first)
+    const int32_t* perm; // [ntiles*16] per-tile processing order written by k_admm (hard instances first, -1 = pad)
+    int ntiles;          // ADMM tiles (16 instances each)
+    int lds_per_wave;    // doubles of LDS per wave (>= POLISH_LDS_MIN_PER_WAVE and >= the rollout trajectory buffer)
     int max_iter;
     int fuse_rollout;    // 1: this kernel also produces u, e_u, x, e_x (roll.*), no separate k_rollout launch
     int roll_g, roll_cpl; // rollout lane decomposition: roll_g lanes per state row, roll_cpl columns of [A B] per lane
@@ -455,6 +465,13 @@ __device__ __forceinline__ double half_sum(double v) {
     const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
     const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
     return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+
+// generic -> global -> generic: tells the optimiser that a pointer it cannot trace back to the kernel arguments is a
+// global one (global_load instead of flat_load, which would also tie up the LDS wait counter)
+template <class T>
+__device__ __forceinline__ T* GL(T* q) {
+    return (T*)(__attribute__((address_space(1))) T*)q;
 }
 
 __device__ __forceinline__ void wave_fence_lds() {  // order this wave's LDS writes before its later LDS reads
@@ -531,23 +548,54 @@ __device__ __forceinline__ void rollout_steps(double* Z, int n, int m, int N, in
     }
 }
 
+// Two builds of the polish.  k_polish<false>: 4 waves per workgroup, one instance per wave, G read through L2.
+// k_polish<true>: ONE persistent workgroup of 8 waves per CU that first copies the shared G = H'^-1 into LDS (115 KB
+// for nz = 120: it fits beside the waves' small buffers in the 160 KB of a gfx950 CU) and then lets each wave pull
+// instances from a queue (hard ones first, see k_admm) until it is empty: every row of G an update needs is an LDS
+// read instead of an L2 round trip, which is what the dependent chain of an active-set change was waiting on.
 constexpr int POLISH_WAVES = 4;
-// LDS per wave (doubles): Sinv 32x32 | row buffer 128 | two position buffers 64 | row-index buffer (64 ints)
-constexpr int POLISH_LDS_PER_WAVE = 32 * 32 + 128 + 64 + 64 + 32;
+constexpr int POLISH_WAVES_GLDS = 8;
+// LDS per wave (doubles): row buffer 128 | two position buffers 64 | row-index buffer (64 ints); the trajectory
+// buffer of the fused rollout lies over the same words (the active-set state is dead by then)
+constexpr int POLISH_LDS_MIN_PER_WAVE = 128 + 64 + 64 + 32;
 constexpr int POLISH_GLB_PER_INST = 64 * 64;        // doubles of global scratch per instance
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(64 * POLISH_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_polish(PolishParams p) {
+template <bool GLDS>
+__global__ __launch_bounds__(64 * (GLDS ? POLISH_WAVES_GLDS : POLISH_WAVES)) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_polish(PolishParams p_arg) {
+    const PolishParams& p = p_arg;
     constexpr int CH = 16;  // positions per chunk of G rows
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * POLISH_WAVES + wv;
-    if (slot >= p.batch) return;
-    const int inst = p.perm[slot];
-    ALMPC_STAMP(inst, 8);
-    const int st_in = p.status[inst];
+    const int wv = threadIdx.x >> 6, lane_k = threadIdx.x & 63;
     const int nz = p.nz, nzs = p.nzs;
+    const double* Gp = p.G;
+    double* wave_lds = smem + (size_t)wv * p.lds_per_wave;
+    int* qcnt = nullptr;
+    ALMPC_STAMP(8192 + blockIdx.x * 8 + wv, 0);
+    if constexpr (GLDS) {
+        const int cnt2 = nz * nzs / 2;  // nzs is even
+        const d2* src = reinterpret_cast<const d2*>(p.G);
+        d2* dst = reinterpret_cast<d2*>(smem);
+        for (int i = threadIdx.x; i < cnt2; i += 64 * POLISH_WAVES_GLDS) dst[i] = src[i];
+        qcnt = reinterpret_cast<int*>(smem + (size_t)nz * nzs + (size_t)POLISH_WAVES_GLDS * p.lds_per_wave);
+        if (threadIdx.x == 0) *qcnt = POLISH_WAVES_GLDS;
+        __syncthreads();
+        Gp = smem;
+        wave_lds = smem + (size_t)nz * nzs + (size_t)wv * p.lds_per_wave;
+    }
+  auto process = [&](const int inst) {
+    // the parameters are re-read from the kernarg segment through a pointer the optimiser cannot see through: otherwise
+    // every instance-independent load (bounds, scaling, [A B] coefficients, ~40 pointers) is hoisted out of the queue
+    // loop and the kernel spills hundreds of registers
+    auto ka_ = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka_));
+    const PolishParams& p = *(const PolishParams*)ka_;
+    int lane = lane_k;
+    asm volatile("" : "+v"(lane));  // same reason: masks and constants derived from the lane number stay inside the instance
+    ALMPC_STAMP(inst, 8);
+    const int st_in = GL(p.status)[inst];
     const size_t base = (size_t)inst * nzs;
     // row-distributed vectors: lane l owns the two consecutive rows 2l, 2l+1 (one 16-byte access per vector)
     const int r0 = 2 * lane, r1 = 2 * lane + 1;
@@ -556,28 +604,27 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) __attribute__((amdgpu_waves_per_
     const int rc = inrow ? r0 : 0;          // clamped pair index for loads (lanes beyond the vector read pair 0)
     const bool skip = (st_in == 2);  // non-finite instance: nothing to polish, the ADMM iterate is handed on as is
 
-    double* Sl = smem + (size_t)wv * POLISH_LDS_PER_WAVE;
-    double* rowbuf = Sl + 32 * 32;     // [128] one row-distributed vector, for gathers by row index
+    double* rowbuf = wave_lds;         // [128] one row-distributed vector, for gathers by row index
     double* pbufa = rowbuf + 128;      // [64]  one position-distributed vector, for broadcasts by position
     double* pbufb = pbufa + 64;        // [64]  a second one
     int* wrow_s = reinterpret_cast<int*>(pbufb + 64);  // [64] row index of each position (copy of wrow)
-    double* Sg = p.sglobal + (size_t)inst * POLISH_GLB_PER_INST;
+    double* Sg = GL(p.sglobal) + (size_t)inst * POLISH_GLB_PER_INST;
 
     double lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0, v00, v01, w0 = 0, w1 = 0, y0, y1, z0, z1;
     {
-        const d2 dv = *reinterpret_cast<const d2*>(p.dvec + rc);
-        const d2 vv = *reinterpret_cast<const d2*>(p.v0 + base + rc);
-        const d2 yy = *reinterpret_cast<const d2*>(p.ys + base + rc);
-        const d2 zz = *reinterpret_cast<const d2*>(p.zs + base + rc);
+        const d2 dv = *reinterpret_cast<const d2*>(GL(p.dvec) + rc);
+        const d2 vv = *reinterpret_cast<const d2*>(GL(p.v0) + base + rc);
+        const d2 yy = *reinterpret_cast<const d2*>(GL(p.ys) + base + rc);
+        const d2 zz = *reinterpret_cast<const d2*>(GL(p.zs) + base + rc);
         v00 = vv[0]; v01 = vv[1]; y0 = yy[0]; y1 = yy[1]; z0 = zz[0]; z1 = zz[1];
         // bounds exactly as k_admm forms them ((umin - uref) * (1/d)): its z sits ON these values when active
         if (in0) {
-            const double di = 1.0 / dv[0], ur = p.uref[(size_t)inst * p.uref_stride + r0];
-            lo0 = (p.umin[r0 % p.m] - ur) * di; hi0 = (p.umax[r0 % p.m] - ur) * di; w0 = fmin(fmax(z0, lo0), hi0);
+            const double di = 1.0 / dv[0], ur = GL(p.uref)[(size_t)inst * p.uref_stride + r0];
+            lo0 = (GL(p.umin)[r0 % p.m] - ur) * di; hi0 = (GL(p.umax)[r0 % p.m] - ur) * di; w0 = fmin(fmax(z0, lo0), hi0);
         } else { v00 = 0.0; y0 = 0.0; z0 = 0.0; }
         if (in1) {
-            const double di = 1.0 / dv[1], ur = p.uref[(size_t)inst * p.uref_stride + r1];
-            lo1 = (p.umin[r1 % p.m] - ur) * di; hi1 = (p.umax[r1 % p.m] - ur) * di; w1 = fmin(fmax(z1, lo1), hi1);
+            const double di = 1.0 / dv[1], ur = GL(p.uref)[(size_t)inst * p.uref_stride + r1];
+            lo1 = (GL(p.umin)[r1 % p.m] - ur) * di; hi1 = (GL(p.umax)[r1 % p.m] - ur) * di; w1 = fmin(fmax(z1, lo1), hi1);
         } else { v01 = 0.0; y1 = 0.0; z1 = 0.0; }
     }
     int wrow = 0, wsd = 0;   // position-distributed: row index, side (+1 upper / -1 lower)
@@ -630,7 +677,7 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) __attribute__((amdgpu_waves_per_
             wave_fence_lds();
         }
     };
-    auto sptr = [&](auto m) -> double* { if constexpr (decltype(m)::glb) return Sg; else return Sl; };
+    auto sptr = [&](auto) -> double* { return Sg; };  // only the global mode keeps Sinv in memory
     auto put_pos = [&](auto m, double* buf, double v) {  // position-distributed register -> LDS buffer
         buf[decltype(m)::half ? (lane & 31) : lane] = v;  // (both halves write the same value in LDS mode)
         wave_fence_lds();
@@ -685,7 +732,7 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) __attribute__((amdgpu_waves_per_
     // round trip can be started before the LDS work that produces the weights.
     auto g_load = [&](int l0, d2 (&g)[CH]) {
 #pragma unroll
-        for (int t = 0; t < CH; ++t) g[t] = *reinterpret_cast<const d2*>(p.G + (wrow_s[l0 + t] * nzs + rc));  // 32-bit index math
+        for (int t = 0; t < CH; ++t) g[t] = *reinterpret_cast<const d2*>(Gp + (wrow_s[l0 + t] * nzs + rc));  // 32-bit index math
     };
     auto g_fma = [&](int l0, const double* ab, const d2 (&g)[CH], double& q0, double& q1) {
         double av[CH];
@@ -727,7 +774,7 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) __attribute__((amdgpu_waves_per_
         const int pos = M::half ? (lane & 31) : lane;
         const bool lowhalf = M::half ? (lane < 32) : true;
         ALMPC_ACC_START;
-        const d2 gj = *reinterpret_cast<const d2*>(p.G + (size_t)j * nzs + rc);  // row j = column j
+        const d2 gj = *reinterpret_cast<const d2*>(Gp + (j * nzs + rc));  // row j = column j
         d2 g[CH];
         g_load(0, g);  // rows of positions 0..CH-1: in flight while Sinv c is formed
         put_rows(gj[0], gj[1]);
@@ -758,7 +805,11 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) __attribute__((amdgpu_waves_per_
             // [Sinv + u u'/sc, -u/sc; -u'/sc, 1/sc] as ONE rank-1 update of the zero-padded registers: with -1 in
             // position k of the broadcast vector and -1/sc as the factor of lane k, the new row, column and corner come
             // out of the same FMA as the update of the old block
-            if (lane == k) pbufb[k] = -1.0;
+            if (lane == k) {
+                double m1 = -1.0;
+                asm volatile("" : "+v"(m1));  // materialised here (the optimiser otherwise keeps it in a spill slot)
+                pbufb[k] = m1;
+            }
             wave_fence_lds();
             double av[16];
             bcast16(pbufb, av);
@@ -931,12 +982,13 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) __attribute__((amdgpu_waves_per_
     };
     auto to_global = [&]() {  // carry Sinv (k = 32 positions) over to the global slot: leading dimension 64, identity padded
 #pragma unroll
-        for (int t = 0; t < 16; ++t) Sl[(16 * hhf + t) * 32 + hpos] = Sr[t];  // staged through LDS (symmetric)
-        wave_fence_lds();
-        for (int c = 0; c < 64; ++c) {
-            const double v = (c < 32 && lane < 32) ? Sl[(c & 31) * 32 + (lane & 31)] : ((c == lane) ? 1.0 : 0.0);
-            Sg[c * 64 + lane] = v;
+        for (int t = 0; t < 16; ++t) {  // Sinv is symmetric: lane (hpos, hhf) writes its piece of columns 16 hhf + t
+            Sg[(16 * hhf + t) * 64 + hpos] = Sr[t];
+            Sg[(16 * hhf + t) * 64 + 32 + hpos] = 0.0;
         }
+#pragma unroll 4
+        for (int c = 32; c < 64; ++c) Sg[c * 64 + lane] = 0.0;
+        if (lane >= 32) Sg[lane * 64 + lane] = 1.0;  // same lane as the zero above: program order
         if (lane >= 32) lam = 0.0;  // lanes 32..63 stop mirroring positions 0..31: they are positions 32..63 now
         sync_s(PolishMode<true>{});
     };
@@ -976,7 +1028,7 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) __attribute__((amdgpu_waves_per_
         {
             double gv[16];
 #pragma unroll
-            for (int t = 0; t < 16; ++t) gv[t] = p.G[(size_t)wrow_s[16 * hhf + t] * nzs + wrow];
+            for (int t = 0; t < 16; ++t) gv[t] = Gp[wrow_s[16 * hhf + t] * nzs + wrow];
 #pragma unroll
             for (int t = 0; t < 16; ++t) Sr[t] = (16 * hhf + t < k && pos < k) ? gv[t] : 0.0;
         }
@@ -984,6 +1036,7 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) __attribute__((amdgpu_waves_per_
         // the columns already done (c < pv) and S[pv][c] = S[c][pv] for the others, so the pivot ROW every lane needs
         // is the pivot COLUMN (one register of each lane of the owning half) broadcast with that sign through LDS:
         // one write + one round trip of reads per pivot, everything else is register arithmetic.
+#pragma unroll 1
         for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
             for (int tj = 0; tj < 16; ++tj) {
@@ -1040,52 +1093,87 @@ __global__ __launch_bounds__(64 * POLISH_WAVES) __attribute__((amdgpu_waves_per_
         wout[0] = act0 ? bnd0 : fmin(fmax(w0, lo0), hi0);
         wout[1] = act1 ? bnd1 : fmin(fmax(w1, lo1), hi1);
         if (lane == 0) {
-            p.piters[inst] = it;
-            p.status[inst] = (fin == 0) ? 0 : st_in;
+            GL(p.piters)[inst] = it;
+            GL(p.status)[inst] = (fin == 0) ? 0 : st_in;
         }
     }
     if (!p.fuse_rollout) {
-        if (inrow) *reinterpret_cast<d2*>(p.w + base + r0) = wout;
+        if (inrow) *reinterpret_cast<d2*>(GL(p.w) + base + r0) = wout;
         return;
     }
     // ---- fused rollout: outputs of calculate! (src/main/computation_mpc.jl:50-53) for this instance
     {
         const RolloutParams& rp = p.roll;
         const int n = rp.n, m = rp.m, N = rp.N, C = n + m;
-        double* Z = Sl;  // (N+1) x C trajectory buffer over the (now free) Sinv area; the host checks that it fits
-        const d2 dvp = *reinterpret_cast<const d2*>(p.dvec + rc);
+        double* Z = wave_lds;  // (N+1) x C trajectory buffer over the (now dead) active-set buffers; sized by the host
+        const d2 dvp = *reinterpret_cast<const d2*>(GL(p.dvec) + rc);
         if (in0) {
-            const double ur = rp.uref[(size_t)inst * rp.uref_stride + r0];
-            const double uu = fmin(fmax(wout[0] * dvp[0] + ur, rp.umin[r0 % m]), rp.umax[r0 % m]);
-            rp.u[(size_t)inst * nz + r0] = uu;
-            rp.eu[(size_t)inst * nz + r0] = uu - ur;
+            const double ur = GL(rp.uref)[(size_t)inst * rp.uref_stride + r0];
+            const double uu = fmin(fmax(wout[0] * dvp[0] + ur, GL(rp.umin)[r0 % m]), GL(rp.umax)[r0 % m]);
+            GL(rp.u)[(size_t)inst * nz + r0] = uu;
+            GL(rp.eu)[(size_t)inst * nz + r0] = uu - ur;
             Z[(size_t)(r0 / m) * C + n + r0 % m] = uu - ur;
         }
         if (in1) {
-            const double ur = rp.uref[(size_t)inst * rp.uref_stride + r1];
-            const double uu = fmin(fmax(wout[1] * dvp[1] + ur, rp.umin[r1 % m]), rp.umax[r1 % m]);
-            rp.u[(size_t)inst * nz + r1] = uu;
-            rp.eu[(size_t)inst * nz + r1] = uu - ur;
+            const double ur = GL(rp.uref)[(size_t)inst * rp.uref_stride + r1];
+            const double uu = fmin(fmax(wout[1] * dvp[1] + ur, GL(rp.umin)[r1 % m]), GL(rp.umax)[r1 % m]);
+            GL(rp.u)[(size_t)inst * nz + r1] = uu;
+            GL(rp.eu)[(size_t)inst * nz + r1] = uu - ur;
             Z[(size_t)(r1 / m) * C + n + r1 % m] = uu - ur;
         }
-        for (int i = lane; i < n; i += 64) Z[i] = rp.x0[(size_t)inst * n + i] - rp.xref[(size_t)inst * rp.xref_stride + i];
+        for (int i = lane; i < n; i += 64) Z[i] = GL(rp.x0)[(size_t)inst * n + i] - GL(rp.xref)[(size_t)inst * rp.xref_stride + i];
         wave_fence_lds();
         ALMPC_STAMP(inst, 12);
         switch (p.roll_cpl) {
-            case 1: rollout_steps<1>(Z, n, m, N, p.roll_g, lane, rp.A, rp.B); break;
-            case 2: rollout_steps<2>(Z, n, m, N, p.roll_g, lane, rp.A, rp.B); break;
-            case 4: rollout_steps<4>(Z, n, m, N, p.roll_g, lane, rp.A, rp.B); break;
-            default: rollout_steps<8>(Z, n, m, N, p.roll_g, lane, rp.A, rp.B); break;
+            case 1: rollout_steps<1>(Z, n, m, N, p.roll_g, lane, GL(rp.A), GL(rp.B)); break;
+            case 2: rollout_steps<2>(Z, n, m, N, p.roll_g, lane, GL(rp.A), GL(rp.B)); break;
+            case 4: rollout_steps<4>(Z, n, m, N, p.roll_g, lane, GL(rp.A), GL(rp.B)); break;
+            default: rollout_steps<8>(Z, n, m, N, p.roll_g, lane, GL(rp.A), GL(rp.B)); break;
         }
         ALMPC_STAMP(inst, 13);
         const int nx = n * (N + 1);
         const size_t xo = (size_t)inst * nx;
         for (int t = lane; t < nx; t += 64) {
             const double ev = Z[(size_t)(t / n) * C + t % n];
-            rp.ex[xo + t] = ev;
-            rp.x[xo + t] = (t < n) ? rp.x0[(size_t)inst * n + t] : ev + rp.xref[(size_t)inst * rp.xref_stride + t];
+            GL(rp.ex)[xo + t] = ev;
+            GL(rp.x)[xo + t] = (t < n) ? GL(rp.x0)[(size_t)inst * n + t] : ev + GL(rp.xref)[(size_t)inst * rp.xref_stride + t];
         }
         ALMPC_STAMP(inst, 14);
+    }
+  };  // process
+
+    if constexpr (GLDS) {
+        // work queue: slots are handed out in the order k_admm wrote them (hard instances first); every wave leaves once
+        // the counter has passed the batch, so the grid always drains
+        ALMPC_STAMP(8192 + blockIdx.x * 8 + wv, 1);
+        int nproc = 0;
+        // work queue of this workgroup: it owns the ADMM tiles blockIdx.x, blockIdx.x + gridDim.x, ... (workgroup b of
+        // k_admm and of this kernel land on the same XCD, so the iterates it reads are still in that L2) and walks their
+        // instances in the per-tile order k_admm left (hardest first); wave w takes i = w, afterwards the waves pull
+        // the next i from an LDS counter.  No global atomics: 2048 waves popping one device-scope counter cost more
+        // than the polish itself.  Every wave leaves once i runs past the last tile, so the grid always drains.
+        for (int i = wv;;) {
+            const int tile = (i >> 4) * (int)gridDim.x + (int)blockIdx.x;
+            if (tile >= p.ntiles) break;
+            const int inst = p.perm[tile * 16 + (i & 15)];
+            if (inst >= 0) {
+                process(inst);
+                ++nproc;
+            }
+            if (lane_k == 0) i = atomicAdd(qcnt, 1);
+            i = __builtin_amdgcn_readfirstlane(i);
+        }
+        ALMPC_STAMP(8192 + blockIdx.x * 8 + wv, 2);
+#ifdef ALMPC_STAMPS
+        if (g_stamps && (threadIdx.x & 63) == 0) g_stamps[(size_t)(8192 + blockIdx.x * 8 + wv) * 16 + 3] = nproc;
+#endif
+    } else {
+        // slot s -> (tile s % ntiles, rank s / ntiles): the dispatch order starts with the hardest instance of every tile
+        const int slot = blockIdx.x * POLISH_WAVES + wv;
+        if (slot < p.ntiles * 16) {
+            const int inst = p.perm[(slot % p.ntiles) * 16 + slot / p.ntiles];
+            if (inst >= 0) process(inst);
+        }
     }
 }
 

@@ -12,7 +12,7 @@ prof = os.environ.get('ALMPC_RHO_PROFILE', 'scalar'); rho = float(os.environ.get
 s = capi.Solver(12, 4, 30, B); s.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max, rho=rho, rho_profile=prof); s.set_reference(p.x_ref, p.u_ref); s.update_initialization(X0)
 opts = capi.default_opts(rho=rho, max_iter=int(sys.argv[2]) if len(sys.argv) > 2 else 25, check_every=int(sys.argv[2]) if len(sys.argv) > 2 else 25)
 for _ in range(3): s.calculate(opts)
-L = s.L; W = 2 * B
+L = s.L; W = 3 * B
 L.almpc_dbg_stamps_enable(s.h, W)
 s.calculate(opts)
 out = np.zeros((W, 16), dtype=np.int64)
@@ -51,3 +51,11 @@ print("slowest instances: inst, total, per-phase cycles, polish its, adds counte
 for o in order:
     i = okidx[o]
     print("  ", i, int(tot[o]), d[o].tolist(), int(pit[i]), int(acc[i, 8]), "acc", (acc[i, :6]).tolist())
+
+tl = full[8192:8192 + 2048]
+okw = tl[:, 0] > 0
+if okw.any():
+    gl = tl[okw, 1] - tl[okw, 0]; tt = tl[okw, 2] - tl[okw, 0]; cnt = tl[okw, 3]
+    print("persistent waves:", int(okw.sum()), " G load cycles median", int(np.median(gl)), "max", int(gl.max()),
+          " total cycles median", int(np.median(tt)), "max", int(tt.max()), " instances per wave min/median/max", int(cnt.min()), int(np.median(cnt)), int(cnt.max()))
+    print("kernel span over all waves (if clocks comparable):", int(tl[okw, 2].max() - tl[okw, 0].min()))
