@@ -445,7 +445,8 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         per_wave = (per_wave + 1) & ~1;
         pp.lds_per_wave = per_wave;
         // G in LDS when it fits beside the buffers of 8 waves (gfx950: 160 KB per workgroup)
-        const size_t l_glds = ((size_t)h->nz * h->nzs + (size_t)POLISH_WAVES_GLDS * per_wave + 2) * sizeof(double);
+        const PolishShared SL = polish_shared_layout(h->n, h->m, h->N, h->nz, h->nzs, fused ? 1 : 0);
+        const size_t l_glds = ((size_t)h->nz * h->nzs + SL.total + (size_t)POLISH_WAVES_GLDS * per_wave + 2) * sizeof(double);
         if (l_glds <= 160 * 1024 && !h->polish_no_glds) {
             if (h->polish_glds_bytes != l_glds) {
                 HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_polish<true>),
@@ -456,7 +457,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
             if (wgs > h->num_cus) wgs = h->num_cus;
             hipLaunchKernelGGL((k_polish<true>), dim3(wgs), dim3(64 * POLISH_WAVES_GLDS), l_glds, st, pp);
         } else {
-            const size_t l = (size_t)POLISH_WAVES * per_wave * sizeof(double);
+            const size_t l = ((size_t)SL.total + (size_t)POLISH_WAVES * per_wave) * sizeof(double);
             hipLaunchKernelGGL((k_polish<false>), dim3((pp.ntiles * 16 + POLISH_WAVES - 1) / POLISH_WAVES), dim3(64 * POLISH_WAVES), l, st, pp);
         }
         HIP_TRY(h, hipGetLastError());

@@ -558,6 +558,23 @@ constexpr int POLISH_WAVES_GLDS = 8;
 // LDS per wave (doubles): row buffer 128 | two position buffers 64 | row-index buffer (64 ints); the trajectory
 // buffer of the fused rollout lies over the same words (the active-set state is dead by then)
 constexpr int POLISH_LDS_MIN_PER_WAVE = 128 + 64 + 64 + 32;
+// Workgroup-shared constants kept in LDS (doubles): d[nzs] | umin[m] | umax[m] | u_ref[nz] and, with the fused rollout,
+// [A B] (n x (n+m), column-major) | x_ref[(N+1) n].  The two references are only used from here when they are shared by
+// all instances (stride 0); per-instance references are read from global memory as before.
+struct PolishShared {
+    int off_d, off_umin, off_umax, off_uref, off_ab, off_xref, total;
+};
+__host__ __device__ inline PolishShared polish_shared_layout(int n, int m, int N, int nz, int nzs, int fused) {
+    PolishShared L;
+    L.off_d = 0;
+    L.off_umin = nzs;
+    L.off_umax = L.off_umin + m;
+    L.off_uref = L.off_umax + m;
+    L.off_ab = L.off_uref + nz;
+    L.off_xref = L.off_ab + (fused ? n * (n + m) : 0);
+    L.total = (L.off_xref + (fused ? (N + 1) * n : 0) + 1) & ~1;
+    return L;
+}
 constexpr int POLISH_GLB_PER_INST = 64 * 64;        // doubles of global scratch per instance
 
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -571,20 +588,50 @@ void k_polish(PolishParams p_arg) {
     const int wv = threadIdx.x >> 6, lane_k = threadIdx.x & 63;
     const int nz = p.nz, nzs = p.nzs;
     const double* Gp = p.G;
-    double* wave_lds = smem + (size_t)wv * p.lds_per_wave;
+    const PolishShared SL = polish_shared_layout(p.roll.n, p.m, p.roll.N, nz, nzs, p.fuse_rollout);
+    double* shc = smem + (GLDS ? (size_t)nz * nzs : 0);  // workgroup-shared constants
+    double* wave_lds = shc + SL.total + (size_t)wv * p.lds_per_wave;
     int* qcnt = nullptr;
+    const bool uref_sh = p.uref_stride == 0, xref_sh = p.roll.xref_stride == 0;
+    {
+        constexpr int TPB = 64 * (GLDS ? POLISH_WAVES_GLDS : POLISH_WAVES);
+        const int n = p.roll.n, m = p.m, N = p.roll.N;
+        for (int t = threadIdx.x; t < nzs; t += TPB) shc[SL.off_d + t] = p.dvec[t];
+        for (int t = threadIdx.x; t < m; t += TPB) { shc[SL.off_umin + t] = p.umin[t]; shc[SL.off_umax + t] = p.umax[t]; }
+        if (uref_sh)
+            for (int t = threadIdx.x; t < nz; t += TPB) shc[SL.off_uref + t] = p.uref[t];
+        if (p.fuse_rollout) {
+            for (int t = threadIdx.x; t < n * n; t += TPB) shc[SL.off_ab + t] = p.roll.A[t];
+            for (int t = threadIdx.x; t < n * m; t += TPB) shc[SL.off_ab + n * n + t] = p.roll.B[t];
+            if (xref_sh)
+                for (int t = threadIdx.x; t < (N + 1) * n; t += TPB) shc[SL.off_xref + t] = p.roll.xref[t];
+        }
+    }
     ALMPC_STAMP(8192 + blockIdx.x * 8 + wv, 0);
     if constexpr (GLDS) {
         const int cnt2 = nz * nzs / 2;  // nzs is even
         const d2* src = reinterpret_cast<const d2*>(p.G);
         d2* dst = reinterpret_cast<d2*>(smem);
-        for (int i = threadIdx.x; i < cnt2; i += 64 * POLISH_WAVES_GLDS) dst[i] = src[i];
-        qcnt = reinterpret_cast<int*>(smem + (size_t)nz * nzs + (size_t)POLISH_WAVES_GLDS * p.lds_per_wave);
+        // 8 independent 16-byte loads per thread in flight per round (a plain copy loop pays one L2 round trip per trip)
+        constexpr int TPB = 64 * POLISH_WAVES_GLDS, UNR = 8;
+        for (int i0 = threadIdx.x; i0 < cnt2; i0 += TPB * UNR) {
+            d2 v[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int i = i0 + u * TPB;
+                v[u] = src[i < cnt2 ? i : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int i = i0 + u * TPB;
+                if (i < cnt2) dst[i] = v[u];
+            }
+        }
+        qcnt = reinterpret_cast<int*>(shc + SL.total + (size_t)POLISH_WAVES_GLDS * p.lds_per_wave);
         if (threadIdx.x == 0) *qcnt = POLISH_WAVES_GLDS;
-        __syncthreads();
         Gp = smem;
-        wave_lds = smem + (size_t)nz * nzs + (size_t)wv * p.lds_per_wave;
     }
+    __syncthreads();
   auto process = [&](const int inst) {
     // the parameters are re-read from the kernarg segment through a pointer the optimiser cannot see through: otherwise
     // every instance-independent load (bounds, scaling, [A B] coefficients, ~40 pointers) is hoisted out of the queue
@@ -611,20 +658,23 @@ void k_polish(PolishParams p_arg) {
     double* Sg = GL(p.sglobal) + (size_t)inst * POLISH_GLB_PER_INST;
 
     double lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0, v00, v01, w0 = 0, w1 = 0, y0, y1, z0, z1;
+    // x0 of this instance for the fused rollout (n <= 64: one state per lane), requested with the other prologue loads
+    double x0r = 0.0;
+    if (p.fuse_rollout && lane < p.roll.n) x0r = GL(p.roll.x0)[(size_t)inst * p.roll.n + lane];
     {
-        const d2 dv = *reinterpret_cast<const d2*>(GL(p.dvec) + rc);
+        const d2 dv = *reinterpret_cast<const d2*>(shc + SL.off_d + rc);
         const d2 vv = *reinterpret_cast<const d2*>(GL(p.v0) + base + rc);
         const d2 yy = *reinterpret_cast<const d2*>(GL(p.ys) + base + rc);
         const d2 zz = *reinterpret_cast<const d2*>(GL(p.zs) + base + rc);
         v00 = vv[0]; v01 = vv[1]; y0 = yy[0]; y1 = yy[1]; z0 = zz[0]; z1 = zz[1];
         // bounds exactly as k_admm forms them ((umin - uref) * (1/d)): its z sits ON these values when active
         if (in0) {
-            const double di = 1.0 / dv[0], ur = GL(p.uref)[(size_t)inst * p.uref_stride + r0];
-            lo0 = (GL(p.umin)[r0 % p.m] - ur) * di; hi0 = (GL(p.umax)[r0 % p.m] - ur) * di; w0 = fmin(fmax(z0, lo0), hi0);
+            const double di = 1.0 / dv[0], ur = uref_sh ? shc[SL.off_uref + r0] : GL(p.uref)[(size_t)inst * p.uref_stride + r0];
+            lo0 = (shc[SL.off_umin + r0 % p.m] - ur) * di; hi0 = (shc[SL.off_umax + r0 % p.m] - ur) * di; w0 = fmin(fmax(z0, lo0), hi0);
         } else { v00 = 0.0; y0 = 0.0; z0 = 0.0; }
         if (in1) {
-            const double di = 1.0 / dv[1], ur = GL(p.uref)[(size_t)inst * p.uref_stride + r1];
-            lo1 = (GL(p.umin)[r1 % p.m] - ur) * di; hi1 = (GL(p.umax)[r1 % p.m] - ur) * di; w1 = fmin(fmax(z1, lo1), hi1);
+            const double di = 1.0 / dv[1], ur = uref_sh ? shc[SL.off_uref + r1] : GL(p.uref)[(size_t)inst * p.uref_stride + r1];
+            lo1 = (shc[SL.off_umin + r1 % p.m] - ur) * di; hi1 = (shc[SL.off_umax + r1 % p.m] - ur) * di; w1 = fmin(fmax(z1, lo1), hi1);
         } else { v01 = 0.0; y1 = 0.0; z1 = 0.0; }
     }
     int wrow = 0, wsd = 0;   // position-distributed: row index, side (+1 upper / -1 lower)
@@ -777,10 +827,10 @@ void k_polish(PolishParams p_arg) {
         const d2 gj = *reinterpret_cast<const d2*>(Gp + (j * nzs + rc));  // row j = column j
         d2 g[CH];
         g_load(0, g);  // rows of positions 0..CH-1: in flight while Sinv c is formed
-        put_rows(gj[0], gj[1]);
-        const double cv = rowbuf[wrow];
+        // c = G[W, j] = G[j, W] (symmetric) gathered straight from row j, beside the load of the row itself
+        const double cv = Gp[j * nzs + wrow];  // wrow is always a valid row index
+        const double gjj = Gp[j * nzs + j];
         const double c = (pos < k) ? cv : 0.0;
-        const double gjj = rowbuf[j];
         const double tj = readlane_d((j & 1) ? t1 : t0, j >> 1);
         ALMPC_ACC(0);
         put_pos(m, pbufa, c);
@@ -808,7 +858,7 @@ void k_polish(PolishParams p_arg) {
             if (lane == k) {
                 double m1 = -1.0;
                 asm volatile("" : "+v"(m1));  // materialised here (the optimiser otherwise keeps it in a spill slot)
-                pbufb[k] = m1;
+                pbufb[hpos] = m1;  // hpos == k on this lane: the address put_pos already uses (k < 32 in register mode)
             }
             wave_fence_lds();
             double av[16];
@@ -1023,6 +1073,11 @@ void k_polish(PolishParams p_arg) {
         put_rows(s0 > 0 ? hi0 : lo0, s1 > 0 ? hi1 : lo1);  // bound a flagged row sits on
         if (pos < k) wbnd = rowbuf[wrow];
         const double pend_bnd = (lane >= 32 && lane < k0) ? rowbuf[pend_row] : 0.0;
+        // Two passes at most: if the multipliers of the guessed set come out with the wrong sign on two or more rows,
+        // those rows are all dropped at once and the inverse is rebuilt for the rest (one more Gauss-Jordan sweep is
+        // cheaper than one down-date per row; the primal active-set loop below starts from a feasible point and a
+        // working set either way, so its finite termination does not depend on this shortcut).
+        for (int pass = 0; pass < 2; ++pass) {
         if (lane < 32) wrow_s[lane] = (lane < k) ? wrow : 0;
         // K = G[W,W] into the leading k x k block of the (zero padded) register Sinv
         {
@@ -1061,6 +1116,38 @@ void k_polish(PolishParams p_arg) {
             }
         }
         recompute(m);
+        if (pass == 1 || k0 > 32) break;
+        {
+            const bool mine = lane < 32 && pos < k;
+            const double viol = mine ? ((wsd > 0) ? -lam : lam) : -__builtin_inf();
+            const double lmax = wave_max(mine ? fabs(lam) : 0.0);
+            const bool bad = mine && viol > 1e-12 * fmax(1.0, lmax);
+            const unsigned badm = (unsigned)__ballot(bad);
+            const int nb = __popc(badm);
+            if (nb < 2) break;
+            const unsigned usedm = (k >= 32) ? 0xffffffffu : ((1u << k) - 1u);
+            const unsigned keepm = usedm & ~badm;
+            // rows that leave the set: clear their row-distributed flags (marker vector through rowbuf)
+            put_rows(0.0, 0.0);
+            if (bad) rowbuf[wrow] = 1.0;
+            wave_fence_lds();
+            {
+                const d2 mk = *reinterpret_cast<const d2*>(rowbuf + r0);
+                if (mk[0] != 0.0) act0 = false;
+                if (mk[1] != 0.0) act1 = false;
+            }
+            // the others move up to consecutive positions
+            const bool keep = lane < 32 && ((keepm >> pos) & 1u) != 0u;
+            const int np = __popc(keepm & ((1u << pos) - 1u));
+            if (keep) { ibuf[np] = wrow; ibuf[64 + np] = wsd; pbufa[np] = wbnd; }
+            wave_fence_lds();
+            k = __popc(keepm);
+            wrow = 0; wsd = 0; wbnd = 0.0; lam = 0.0;
+            if (pos < k) { wrow = ibuf[pos]; wsd = ibuf[64 + pos]; wbnd = pbufa[pos]; }
+            wave_fence_lds();
+            it += nb;
+        }
+        }  // pass
         if (k0 > 32) {
             to_global();
             for (int q = 32; q < k0; ++q)
@@ -1106,37 +1193,38 @@ void k_polish(PolishParams p_arg) {
         const RolloutParams& rp = p.roll;
         const int n = rp.n, m = rp.m, N = rp.N, C = n + m;
         double* Z = wave_lds;  // (N+1) x C trajectory buffer over the (now dead) active-set buffers; sized by the host
-        const d2 dvp = *reinterpret_cast<const d2*>(GL(p.dvec) + rc);
+        const d2 dvp = *reinterpret_cast<const d2*>(shc + SL.off_d + rc);
         if (in0) {
-            const double ur = GL(rp.uref)[(size_t)inst * rp.uref_stride + r0];
-            const double uu = fmin(fmax(wout[0] * dvp[0] + ur, GL(rp.umin)[r0 % m]), GL(rp.umax)[r0 % m]);
+            const double ur = uref_sh ? shc[SL.off_uref + r0] : GL(rp.uref)[(size_t)inst * rp.uref_stride + r0];
+            const double uu = fmin(fmax(wout[0] * dvp[0] + ur, shc[SL.off_umin + r0 % m]), shc[SL.off_umax + r0 % m]);
             GL(rp.u)[(size_t)inst * nz + r0] = uu;
             GL(rp.eu)[(size_t)inst * nz + r0] = uu - ur;
             Z[(size_t)(r0 / m) * C + n + r0 % m] = uu - ur;
         }
         if (in1) {
-            const double ur = GL(rp.uref)[(size_t)inst * rp.uref_stride + r1];
-            const double uu = fmin(fmax(wout[1] * dvp[1] + ur, GL(rp.umin)[r1 % m]), GL(rp.umax)[r1 % m]);
+            const double ur = uref_sh ? shc[SL.off_uref + r1] : GL(rp.uref)[(size_t)inst * rp.uref_stride + r1];
+            const double uu = fmin(fmax(wout[1] * dvp[1] + ur, shc[SL.off_umin + r1 % m]), shc[SL.off_umax + r1 % m]);
             GL(rp.u)[(size_t)inst * nz + r1] = uu;
             GL(rp.eu)[(size_t)inst * nz + r1] = uu - ur;
             Z[(size_t)(r1 / m) * C + n + r1 % m] = uu - ur;
         }
-        for (int i = lane; i < n; i += 64) Z[i] = GL(rp.x0)[(size_t)inst * n + i] - GL(rp.xref)[(size_t)inst * rp.xref_stride + i];
+        if (lane < n) Z[lane] = x0r - (xref_sh ? shc[SL.off_xref + lane] : GL(rp.xref)[(size_t)inst * rp.xref_stride + lane]);
         wave_fence_lds();
         ALMPC_STAMP(inst, 12);
         switch (p.roll_cpl) {
-            case 1: rollout_steps<1>(Z, n, m, N, p.roll_g, lane, GL(rp.A), GL(rp.B)); break;
-            case 2: rollout_steps<2>(Z, n, m, N, p.roll_g, lane, GL(rp.A), GL(rp.B)); break;
-            case 4: rollout_steps<4>(Z, n, m, N, p.roll_g, lane, GL(rp.A), GL(rp.B)); break;
-            default: rollout_steps<8>(Z, n, m, N, p.roll_g, lane, GL(rp.A), GL(rp.B)); break;
+            case 1: rollout_steps<1>(Z, n, m, N, p.roll_g, lane, shc + SL.off_ab, shc + SL.off_ab + n * n); break;
+            case 2: rollout_steps<2>(Z, n, m, N, p.roll_g, lane, shc + SL.off_ab, shc + SL.off_ab + n * n); break;
+            case 4: rollout_steps<4>(Z, n, m, N, p.roll_g, lane, shc + SL.off_ab, shc + SL.off_ab + n * n); break;
+            default: rollout_steps<8>(Z, n, m, N, p.roll_g, lane, shc + SL.off_ab, shc + SL.off_ab + n * n); break;
         }
         ALMPC_STAMP(inst, 13);
         const int nx = n * (N + 1);
         const size_t xo = (size_t)inst * nx;
         for (int t = lane; t < nx; t += 64) {
             const double ev = Z[(size_t)(t / n) * C + t % n];
+            const double xr = xref_sh ? shc[SL.off_xref + t] : GL(rp.xref)[(size_t)inst * rp.xref_stride + t];
             GL(rp.ex)[xo + t] = ev;
-            GL(rp.x)[xo + t] = (t < n) ? GL(rp.x0)[(size_t)inst * n + t] : ev + GL(rp.xref)[(size_t)inst * rp.xref_stride + t];
+            GL(rp.x)[xo + t] = (t < n) ? x0r : ev + xr;  // t < n <= 64 happens in the first pass only, where t == lane
         }
         ALMPC_STAMP(inst, 14);
     }
