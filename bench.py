@@ -135,8 +135,8 @@ def main():
         except OSError:
             pass
         # k_admm, algorithmic flops per launch: per instance and iteration one nz x nz product (2 nz^2) plus ~10 nz of
-        # vector work; once per instance the gradient (2 nz n) and v0 = -G f' (2 nz^2)
-        flops = iters_total * (2 * NZ * NZ + 10 * NZ) + BATCH_PER_GPU * (2 * NZ * NX + 2 * NZ * NZ)
+        # vector work; once per instance the gradient f' = F' e0 and v0 = V e0 (2 nz n each)
+        flops = iters_total * (2 * NZ * NZ + 10 * NZ) + BATCH_PER_GPU * (2 * NZ * NX + 2 * NZ * NX)
         admm_tflops = flops / (stage_ms["admm_ms"] * 1e-3) / 1e12
         roof_admm = {"bound": "mfma", "kernel": "k_admm<8,30>", "achieved": admm_tflops, "peak": FP64_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": admm_tflops / FP64_PEAK_TFLOPS,
@@ -148,7 +148,7 @@ def main():
         pol_bytes = BATCH_PER_GPU * 8 * (3 * NZ + 2 * NZ + 2 * NX * (N_HORIZON + 1))
         pol_ms = stage_ms["polish_ms"] + stage_ms["rollout_ms"]
         pol_gbs = pol_bytes / (pol_ms * 1e-3) / 1e9
-        roof_polish = {"bound": "hbm", "kernel": "k_polish (active-set polish + fused rollout)", "achieved": pol_gbs,
+        roof_polish = {"bound": "hbm", "kernel": "k_polish<true> (active-set polish with G in LDS + fused rollout)", "achieved": pol_gbs,
                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": pol_gbs / HBM_PEAK_GBS,
                        "traffic": traffic.get("k_polish", {}).get("hbm_bytes_per_launch"), "avg_kernel_ms": pol_ms,
                        "algorithmic_bytes_per_launch": pol_bytes,
