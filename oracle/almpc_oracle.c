@@ -135,6 +135,31 @@ int almpc_oracle_polish(int nz, const double* G, const double* v0, const double*
         if (y[j] < 0.0 && w[j] <= lo[j]) ADD(j, -1, lo[j]);
         else if (y[j] > 0.0 && w[j] >= hi[j]) ADD(j, +1, hi[j]);
     }
+    /* One-shot purge (as in k_polish): if the multipliers of a guessed set of at most 32 rows come out with the wrong
+     * sign on two or more rows, those rows are dropped together and the inverse is rebuilt for the others. */
+    if (k > 0 && k <= 32) {
+        for (int i = 0; i < k; ++i) r[i] = v0[W[i]] - bnd[i];
+        double lmax = 0.0;
+        for (int i = 0; i < k; ++i) {
+            double s = 0.0;
+            for (int l = 0; l < k; ++l) s += S[(size_t)l * nz + i] * r[l];
+            lam[i] = s;
+            lmax = fmax(lmax, fabs(s));
+        }
+        int nb = 0;
+        for (int i = 0; i < k; ++i) nb += ((side[i] > 0 ? -lam[i] : lam[i]) > 1e-12 * fmax(1.0, lmax)) ? 1 : 0;
+        if (nb >= 2) {
+            int kr[32], ks[32], nk = 0;
+            double kb[32];
+            for (int i = 0; i < k; ++i) {
+                if ((side[i] > 0 ? -lam[i] : lam[i]) > 1e-12 * fmax(1.0, lmax)) pos[W[i]] = -1;
+                else { kr[nk] = W[i]; ks[nk] = side[i]; kb[nk] = bnd[i]; ++nk; }
+            }
+            k = 0;
+            for (int i = 0; i < nk; ++i) ADD(kr[i], ks[i], kb[i]);
+            it += nb;
+        }
+    }
     while (it < max_iter) {
         ++it;
         for (int i = 0; i < k; ++i) r[i] = v0[W[i]] - bnd[i];

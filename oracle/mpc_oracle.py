@@ -760,7 +760,21 @@ def polish_active_set(G, v0, lo, hi, z, y, max_iter=None, refine=True):
             add(j, -1)
         elif y[j] > 0 and w[j] >= hi[j]:
             add(j, +1)
-    n_add = n_rem = 0
+    n_add = n_rem = n_purged = 0
+    # One-shot purge (as in k_polish and almpc_oracle.c): two or more wrong-sign multipliers on a guessed set of at
+    # most 32 rows -> drop those rows together and rebuild the inverse for the others.
+    if 0 < len(W) <= 32:
+        b = np.array([hi[j] if side[j] > 0 else lo[j] for j in W])
+        lam = Sinv @ (v0[W] - b)
+        viol = np.array([-lam[i] if side[W[i]] > 0 else lam[i] for i in range(len(W))])
+        bad = viol > 1e-12 * max(1.0, float(np.max(np.abs(lam))))
+        if bad.sum() >= 2:
+            kept = [(W[i], side[W[i]]) for i in range(len(W)) if not bad[i]]
+            n_rem += int(bad.sum())
+            n_purged = int(bad.sum())
+            W, side, Sinv = [], {}, np.zeros((0, 0))
+            for j, sd in kept:
+                add(j, sd)
     it = 0
     for it in range(1, max_iter + 1):
         if W:
@@ -801,7 +815,7 @@ def polish_active_set(G, v0, lo, hi, z, y, max_iter=None, refine=True):
             break
         remove(i)
         n_rem += 1
-    return dict(w=np.clip(w, lo, hi), iters=it, n_add=n_add, n_remove=n_rem, n_active=len(W))
+    return dict(w=np.clip(w, lo, hi), iters=it + n_purged, n_add=n_add, n_remove=n_rem, n_active=len(W))
 
 
 def design_shared(p: MPCProblem, rho=0.1, sigma=1e-6, rho_profile="scalar"):

@@ -583,3 +583,30 @@ def test_repeatability(capi, mo):
     b = step(capi, p, X0)
     for k in ("u", "x", "iters", "polish_iters"):
         assert np.array_equal(a[k], b[k])
+
+
+def test_polish_through_l2_build_matches_lds_build(capi, mo, monkeypatch):
+    """k_polish<false> (G read through L2, 4 waves per workgroup) is what shapes whose G does not fit LDS run; forced
+    here on the benchmark shape (ALMPC_POLISH_NO_GLDS=1 is read by almpc_create) it must give the results of the
+    default k_polish<true> build: same status, same iteration counts, u equal to rounding."""
+    p = mo.quadrotor()
+    X0 = np.concatenate([mo.quadrotor_x0_batch(64, a, first_instance=64 * k) for k, a in enumerate((0.3, 1.0, 3.0, 6.0))])
+    def run():
+        s = capi.Solver(p.n, p.m, p.N, len(X0))
+        s.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max, rho=30.0, rho_profile="stiffness")
+        s.set_reference(p.x_ref, p.u_ref)
+        s.update_initialization(X0)
+        s.calculate(capi.default_opts(rho=30.0, max_iter=8, check_every=8))
+        r = s.get_results()
+        s.close()
+        return r
+
+    a = run()
+    monkeypatch.setenv("ALMPC_POLISH_NO_GLDS", "1")
+    b = run()
+    assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["polish_iters"], b["polish_iters"])
+    assert np.abs(a["u"] - b["u"]).max() <= 1e-12 and np.abs(a["x"] - b["x"]).max() <= 1e-10
+    ok = a["status"] == 0
+    for i in np.nonzero(ok)[0][::7]:
+        e = mo.solve_mpc_exact(p, X0[i])
+        assert np.abs(a["u"][i] - e["u"]).max() <= U_TOL
