@@ -56,6 +56,10 @@ def load():
     L.almpc_last_error.argtypes = [_hp]
     L.almpc_last_error.restype = ctypes.c_char_p
     L.almpc_design_shared.argtypes = [_hp] + [_dp] * 10 + [ctypes.c_double, ctypes.c_double]
+    L.almpc_design_batched.argtypes = [_hp] + [_dp] * 6 + [ctypes.c_int, _dp, _dp, ctypes.c_double, ctypes.c_double]
+    L.almpc_design_batched.restype = ctypes.c_int
+    L.almpc_get_design_instance.argtypes = [_hp, ctypes.c_int, _dp, _dp, _dp]
+    L.almpc_get_design_instance.restype = ctypes.c_int
     L.almpc_set_reference.argtypes = [_hp, _dp, _dp, ctypes.c_int]
     L.almpc_set_terminal_equality.argtypes = [_hp, ctypes.c_int]
     L.almpc_set_rho_profile.argtypes = [_hp, ctypes.c_int]
@@ -190,6 +194,35 @@ class Solver:
         xmax = None if xmax is None else np.ascontiguousarray(xmax, dtype=np.float64).reshape(n)
         self._check(self.L.almpc_design_shared(self.h, _ptr(A), _ptr(B), _ptr(Q), _ptr(R), _ptr(S), _ptr(P), _ptr(umin),
                                                _ptr(umax), _ptr(xmin), _ptr(xmax), float(rho), float(sigma)))
+
+    def design_batched(self, A_batch, B_batch, Q, R, S=None, P=None, umin=None, umax=None, rho=0.1, sigma=1e-6,
+                       rho_profile="scalar"):
+        """One model per instance: A_batch (batch, n, n), B_batch (batch, n, m).  P: None (DARE per instance), (n, n) shared
+        or (batch, n, n)."""
+        n, m, b = self.n, self.m, self.batch
+        self._check(self.L.almpc_set_terminal_equality(self.h, 0))
+        self._check(self.L.almpc_set_rho_profile(self.h, {"scalar": 0, "stiffness": 1}[rho_profile]))
+        A = np.ascontiguousarray(np.asarray(A_batch, dtype=np.float64).reshape(b, n, n).transpose(0, 2, 1))  # column-major blocks
+        B = np.ascontiguousarray(np.asarray(B_batch, dtype=np.float64).reshape(b, n, m).transpose(0, 2, 1))
+        Q, R = _colmajor(Q, (n, n)), _colmajor(R, (m, m))
+        S = None if S is None else _colmajor(S, (m, m))
+        p_inst = 0
+        if P is not None:
+            P = np.asarray(P, dtype=np.float64)
+            if P.ndim == 3:
+                P = np.ascontiguousarray(P.reshape(b, n, n).transpose(0, 2, 1)); p_inst = 1
+            else:
+                P = _colmajor(P, (n, n))
+        umin = np.ascontiguousarray(umin, dtype=np.float64).reshape(m)
+        umax = np.ascontiguousarray(umax, dtype=np.float64).reshape(m)
+        self._check(self.L.almpc_design_batched(self.h, _ptr(A), _ptr(B), _ptr(Q), _ptr(R), _ptr(S), _ptr(P), p_inst, _ptr(umin),
+                                                _ptr(umax), float(rho), float(sigma)))
+
+    def get_design_instance(self, i):
+        n, nz = self.n, self.nz
+        H = np.empty((nz, nz), order="F"); F = np.empty((nz, n), order="F"); d = np.empty(nz)
+        self._check(self.L.almpc_get_design_instance(self.h, int(i), _ptr(H), _ptr(F), _ptr(d)))
+        return dict(H=H, F=F, d=d)
 
     def set_reference(self, x_ref, u_ref, per_instance=False):
         """x_ref (n, N+1) / u_ref (m, N), or with per_instance (batch, n, N+1) / (batch, m, N)."""

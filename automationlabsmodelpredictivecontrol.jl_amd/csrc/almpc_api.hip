@@ -8,6 +8,7 @@
 #include "almpc_design.hip.h"
 #include "almpc_polish_gen.hip.h"
 #include "almpc_fnn.hip.h"
+#include "almpc_instance.hip.h"
 #include "almpc_host_math.h"
 #include "../../include/almpc.h"
 
@@ -46,6 +47,14 @@ struct almpc_handle {
     int terminal_eq = 0, has_box = 0, mc = 0, R = 0, Rs = 0, np_pairs = 0;
     double *dGhat = nullptr, *dGnorm = nullptr, *dXmin = nullptr, *dXmax = nullptr;
     int *dRowTraj = nullptr, *dRowEq = nullptr, *dRowXidx = nullptr, *dRowState = nullptr;
+    // per-instance models (almpc_design_batched): persistent per-instance operands ...
+    bool batched = false;
+    double *bA = nullptr, *bB = nullptr, *bMinv = nullptr, *bG = nullptr, *bHs = nullptr, *bFs = nullptr, *bVs = nullptr,
+           *bD = nullptr, *bRho = nullptr, *bH = nullptr, *bF = nullptr;
+    // ... and design temporaries kept for the next re-design (a per-step re-linearisation designs every step)
+    double *bPhi = nullptr, *bGk = nullptr, *bGam = nullptr, *bW = nullptr, *bWP = nullptr, *bP = nullptr;
+    int* bFlag = nullptr;
+    bool batched_alloc = false;
     // timing (ALMPC_FLAG_TIMING): one set of 4 events per step since the last almpc_timing_reset
     std::vector<hipEvent_t> ev;  // 4 per step
     size_t ev_used = 0;          // steps recorded
@@ -99,7 +108,8 @@ void free_all(almpc_handle* h) {
     void* ptrs[] = {h->dMinvFrag, h->dVFrag, h->dHFrag, h->dFFrag, h->dG, h->dD, h->dUmin, h->dUmax, h->dA, h->dB,
                     h->dXref, h->dUref, h->dFS, h->dV0S, h->dRho, h->dX0, h->dXs, h->dZs, h->dYs, h->dV0, h->dW, h->dX, h->dEx,
                     h->dU, h->dEu, h->dStatus, h->dIters, h->dPiters, h->dOverflow, h->dPerm, h->dSglobal, h->dGhat, h->dGnorm, h->dXmin,
-                    h->dXmax, h->dRowTraj, h->dRowEq, h->dRowXidx, h->dRowState};
+                    h->dXmax, h->dRowTraj, h->dRowEq, h->dRowXidx, h->dRowState, h->bA, h->bB, h->bMinv, h->bG, h->bHs, h->bFs,
+                    h->bVs, h->bD, h->bRho, h->bH, h->bF, h->bPhi, h->bGk, h->bGam, h->bW, h->bWP, h->bP, h->bFlag};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& e : h->ev)
@@ -177,6 +187,7 @@ int almpc_create(almpc_handle** out, int n, int m, int N, int batch, int device_
     TRY(dalloc(&h->dU, b * h->nz)); TRY(dalloc(&h->dEu, b * h->nz));
     TRY(dalloc(&h->dSglobal, b * POLISH_GLB_PER_INST));
     TRY(dalloc(&h->dPerm, ((b + 15) / 16) * 16));
+    TRY(hipMemset(h->dPerm, 0xFF, ((b + 15) / 16) * 16 * sizeof(int32_t)));
     TRY(dalloc(&h->dStatus, b)); TRY(dalloc(&h->dIters, b)); TRY(dalloc(&h->dPiters, b)); TRY(dalloc(&h->dOverflow, b));
     TRY(hipMemset(h->dXs, 0, b * h->nzs * sizeof(double)));
     TRY(hipMemset(h->dZs, 0, b * h->nzs * sizeof(double)));
@@ -285,9 +296,158 @@ int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const
     HIP_TRY(h, hipMemcpy(h->dA, A, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->dB, B, (size_t)n * m * sizeof(double), hipMemcpyHostToDevice));
     h->designed = true;
+    h->batched = false;
     // default references: zeros, shared
     std::vector<double> xr((size_t)n * (N + 1), 0.0), ur((size_t)nz, 0.0);
     return almpc_set_reference(h, xr.data(), ur.data(), 0);
+}
+
+// Per-instance models: every instance gets its own condensed QP from (A_i, B_i).  The design kernels of
+// almpc_design.hip.h run with blockIdx.y = instance; the per-step path is k_admm_inst + k_polish<false> with strides.
+int almpc_design_batched(almpc_handle* h, const double* A_batch, const double* B_batch, const double* Q, const double* R,
+                         const double* S, const double* P, int P_per_instance, const double* umin, const double* umax,
+                         double rho, double sigma) {
+    if (!h) return ALMPC_ERR_INVALID;
+    if (!A_batch || !B_batch || !Q || !R || !umin || !umax) return fail(h, ALMPC_ERR_INVALID, "design_batched: null matrix pointer");
+    if (!(rho > 0.0) || !(sigma >= 0.0)) return fail(h, ALMPC_ERR_INVALID, "design_batched: rho must be > 0 and sigma >= 0");
+    if (h->terminal_eq) return fail(h, ALMPC_ERR_UNSUPPORTED, "design_batched: state rows (terminal equality) need a shared model");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int n = h->n, m = h->m, N = h->N, nz = h->nz, nzs = h->nzs, nrb = h->nrb;
+    const size_t b = (size_t)h->batch;
+    for (int i = 0; i < m; ++i)
+        if (!(umin[i] <= umax[i])) return fail(h, ALMPC_ERR_INVALID, "design_batched: umin > umax");
+    const size_t lds_admm = ((size_t)nz * nzs + 4 * (size_t)nzs + 32 + n) * sizeof(double);
+    if (lds_admm > 160 * 1024) return fail(h, ALMPC_ERR_UNSUPPORTED, "design_batched: the instance's KKT inverse does not fit LDS");
+    hm::mat Qm(Q, Q + (size_t)n * n), Rm(R, R + (size_t)m * m);
+    hm::mat Sm = S ? hm::mat(S, S + (size_t)m * m) : hm::mat((size_t)m * m, 0.0);
+    auto symmetrise = [](hm::mat& M, int k) {
+        for (int j = 0; j < k; ++j)
+            for (int i = 0; i < j; ++i) {
+                const double v = 0.5 * (M[(size_t)j * k + i] + M[(size_t)i * k + j]);
+                M[(size_t)j * k + i] = M[(size_t)i * k + j] = v;
+            }
+    };
+    symmetrise(Qm, n); symmetrise(Rm, m); symmetrise(Sm, m);
+    // terminal weight: given (shared or per instance), else DARE of every instance's model (src/sub/design_mpc.jl:327)
+    const bool p_inst = P ? (P_per_instance != 0) : true;
+    hm::mat Pall;
+    if (P) Pall.assign(P, P + (p_inst ? b : 1) * (size_t)n * n);
+    else {
+        Pall.resize(b * (size_t)n * n);
+        for (size_t i = 0; i < b; ++i) {
+            hm::mat Am(A_batch + i * n * n, A_batch + (i + 1) * n * n), Bm(B_batch + i * n * m, B_batch + (i + 1) * n * m), Pm;
+            if (!hm::dare(Am, Bm, Qm, Rm, n, m, Pm)) return fail(h, ALMPC_ERR_NUMERIC, "design_batched: DARE did not converge for instance " + std::to_string(i));
+            std::copy(Pm.begin(), Pm.end(), Pall.begin() + i * n * n);
+        }
+    }
+    for (size_t i = 0; i < (p_inst ? b : 1); ++i) {
+        hm::mat Pm(Pall.begin() + i * n * n, Pall.begin() + (i + 1) * n * n);
+        symmetrise(Pm, n);
+        std::copy(Pm.begin(), Pm.end(), Pall.begin() + i * n * n);
+    }
+    h->P.assign(Pall.begin(), Pall.begin() + (size_t)n * n);
+    h->hS = Sm;
+    h->rho = rho; h->sigma = sigma;
+    h->has_box = 0; h->mc = 0; h->R = nz; h->np_pairs = 1; h->Rs = 128;
+    const int useR = Rm[0] != 0.0, useS = useR && Sm[0] != 0.0;
+    const int njf = (n + 15) / 16, ps = 16 * njf, gs = nzs;
+    const int kr = ((n * N + HESS_KC - 1) / HESS_KC) * HESS_KC;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (!h->batched_alloc) {
+        HIP_TRY(h, dalloc(&h->bA, b * n * n)); HIP_TRY(h, dalloc(&h->bB, b * n * m));
+        HIP_TRY(h, dalloc(&h->bMinv, b * nz * nzs)); HIP_TRY(h, dalloc(&h->bG, b * nz * nzs)); HIP_TRY(h, dalloc(&h->bHs, b * nz * nzs));
+        HIP_TRY(h, dalloc(&h->bFs, b * n * nzs)); HIP_TRY(h, dalloc(&h->bVs, b * n * nzs));
+        HIP_TRY(h, dalloc(&h->bD, b * nzs)); HIP_TRY(h, dalloc(&h->bRho, b * nzs));
+        HIP_TRY(h, dalloc(&h->bH, b * nz * nz)); HIP_TRY(h, dalloc(&h->bF, b * nz * n));
+        HIP_TRY(h, dalloc(&h->bPhi, b * N * n * n)); HIP_TRY(h, dalloc(&h->bGk, b * N * n * m));
+        HIP_TRY(h, dalloc(&h->bGam, b * kr * gs)); HIP_TRY(h, dalloc(&h->bW, b * kr * gs)); HIP_TRY(h, dalloc(&h->bWP, b * kr * ps));
+        HIP_TRY(h, dalloc(&h->bP, b * n * n));
+        HIP_TRY(h, dalloc(&h->bFlag, b));
+        // padding rows / columns of the row-major panels stay zero for the lifetime of the handle
+        HIP_TRY(h, hipMemset(h->bGam, 0, b * kr * gs * sizeof(double)));
+        HIP_TRY(h, hipMemset(h->bW, 0, b * kr * gs * sizeof(double)));
+        HIP_TRY(h, hipMemset(h->bWP, 0, b * kr * ps * sizeof(double)));
+        HIP_TRY(h, hipMemset(h->bHs, 0, b * nz * nzs * sizeof(double)));
+        HIP_TRY(h, hipMemset(h->bFs, 0, b * n * nzs * sizeof(double)));
+        HIP_TRY(h, hipMemset(h->bVs, 0, b * n * nzs * sizeof(double)));
+        HIP_TRY(h, hipMemset(h->bMinv, 0, b * nz * nzs * sizeof(double)));
+        HIP_TRY(h, hipMemset(h->bG, 0, b * nz * nzs * sizeof(double)));
+        h->batched_alloc = true;
+    }
+    hipStream_t st = h->stream;
+    double *dQ = nullptr, *dR = nullptr, *dS = nullptr;
+    HIP_TRY(h, dalloc(&dQ, (size_t)n * n)); HIP_TRY(h, dalloc(&dR, (size_t)m * m)); HIP_TRY(h, dalloc(&dS, (size_t)m * m));
+    auto release = [&]() { (void)hipFree(dQ); (void)hipFree(dR); (void)hipFree(dS); };
+#define BTRY(call)                                                                                                  \
+    do {                                                                                                            \
+        hipError_t e_ = (call);                                                                                     \
+        if (e_ != hipSuccess) { release(); return fail(h, ALMPC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } \
+    } while (0)
+    BTRY(hipMemcpyAsync(h->bA, A_batch, b * n * n * sizeof(double), hipMemcpyHostToDevice, st));
+    BTRY(hipMemcpyAsync(h->bB, B_batch, b * n * m * sizeof(double), hipMemcpyHostToDevice, st));
+    BTRY(hipMemcpyAsync(h->bP, Pall.data(), Pall.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    BTRY(hipMemcpyAsync(dQ, Qm.data(), Qm.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    BTRY(hipMemcpyAsync(dR, Rm.data(), Rm.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    BTRY(hipMemcpyAsync(dS, Sm.data(), Sm.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    BTRY(hipMemsetAsync(h->bFlag, 0, b * sizeof(int), st));
+    DesignStrides ds;
+    ds.A = (long)n * n; ds.B = (long)n * m; ds.P = p_inst ? (long)n * n : 0; ds.Phi = (long)N * n * n; ds.Gk = (long)N * n * m;
+    ds.Gam = (long)kr * gs; ds.WP = (long)kr * ps; ds.H = (long)nz * nz; ds.F = (long)nz * n; ds.d = nzs; ds.Hs = (long)nz * nzs;
+    ds.Fs = (long)n * nzs; ds.G = (long)nz * nzs; ds.Minv = (long)nz * nzs; ds.rho = nzs; ds.flag = 1;
+    const unsigned gb = (unsigned)b;
+    hipLaunchKernelGGL(k_design_blocks, dim3(1, gb), dim3(256), (size_t)(3 * n * n + n * m) * sizeof(double), st, n, m, N,
+                       h->bA, h->bB, h->bPhi, h->bGk, ds);
+    hipLaunchKernelGGL(k_design_gamma, dim3(N, gb), dim3(256), 0, st, n, m, N, dQ, h->bP, h->bPhi, h->bGk, h->bGam, h->bW, h->bWP, gs, ps, ds);
+    HessParams hp;
+    hp.n = n; hp.m = m; hp.N = N; hp.nz = nz; hp.nrb = nrb; hp.njf = njf; hp.kr = kr;
+    hp.Gam = h->bGam; hp.W = h->bW; hp.WP = h->bWP; hp.gs = gs; hp.ps = ps; hp.R = dR; hp.S = dS; hp.useR = useR; hp.useS = useS;
+    hp.H = h->bH; hp.F = h->bF; hp.st = ds;
+    const size_t hess_lds = (size_t)HESS_KC * (16 + (gs + 16) + (ps + 16)) * sizeof(double);
+    hipLaunchKernelGGL(k_design_hessian, dim3(nrb, gb), dim3(64 * (nrb + njf)), hess_lds, st, hp);
+    hipLaunchKernelGGL(k_design_scale, dim3(1, gb), dim3(256), 0, st, nz, nzs, n, h->bH, h->bF, h->bD, h->bHs, h->bFs, h->bFlag, ds);
+    BTRY(hipGetLastError());
+    const size_t inv_lds = ((size_t)nz * (nz + 1) + nz + 2) * sizeof(double);
+    BTRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_design_inverse), hipFuncAttributeMaxDynamicSharedMemorySize, (int)inv_lds));
+    hipLaunchKernelGGL(k_design_inverse, dim3(1, gb), dim3(512), inv_lds, st, nz, nzs, h->bHs, 0.0, (const double*)nullptr, h->bG, h->bFlag,
+                       ds.Hs, 0L, ds.G, 1L);
+    hipLaunchKernelGGL(k_design_rho, dim3(1, gb), dim3(256), 0, st, nz, nzs, h->rho_mode, rho, h->bG, h->bRho, ds.G, ds.rho);
+    hipLaunchKernelGGL(k_design_inverse, dim3(1, gb), dim3(512), inv_lds, st, nz, nzs, h->bHs, sigma, (const double*)h->bRho, h->bMinv,
+                       h->bFlag, ds.Hs, ds.rho, ds.Minv, 1L);
+    hipLaunchKernelGGL(k_neg_gm, dim3(4, gb), dim3(256), 0, st, nz, nzs, n, nzs, h->bG, h->bFs, h->bVs, ds.G, ds.Fs);
+    BTRY(hipGetLastError());
+    std::vector<int> flags(b, 0);
+    BTRY(hipMemcpyAsync(flags.data(), h->bFlag, b * sizeof(int), hipMemcpyDeviceToHost, st));
+    // host copies of instance 0 for almpc_get_design (every instance: almpc_get_design_instance)
+    h->H.assign((size_t)nz * nz, 0.0); h->F.assign((size_t)nz * n, 0.0); h->d.assign((size_t)nzs, 0.0);
+    BTRY(hipMemcpyAsync(h->H.data(), h->bH, h->H.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    BTRY(hipMemcpyAsync(h->F.data(), h->bF, h->F.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    BTRY(hipMemcpyAsync(h->d.data(), h->bD, h->d.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    BTRY(hipStreamSynchronize(st));
+#undef BTRY
+    release();
+    for (size_t i = 0; i < b; ++i)
+        if (flags[i] != 0)
+            return fail(h, ALMPC_ERR_NUMERIC, "design_batched: instance " + std::to_string(i) +
+                        (flags[i] == 1 ? ": condensed Hessian has a non-positive diagonal" : ": Cholesky pivot not positive"));
+    HIP_TRY(h, hipMemcpy(h->dUmin, umin, m * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->dUmax, umax, m * sizeof(double), hipMemcpyHostToDevice));
+    h->designed = true;
+    h->batched = true;
+    std::vector<double> xr((size_t)n * (N + 1), 0.0), ur((size_t)nz, 0.0);
+    return almpc_set_reference(h, xr.data(), ur.data(), 0);
+}
+
+int almpc_get_design_instance(almpc_handle* h, int instance, double* H, double* F, double* d) {
+    if (!h) return ALMPC_ERR_INVALID;
+    if (!h->designed || !h->batched) return fail(h, ALMPC_ERR_NOT_DESIGNED, "get_design_instance needs almpc_design_batched");
+    if (instance < 0 || instance >= h->batch) return fail(h, ALMPC_ERR_INVALID, "get_design_instance: instance out of range");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const size_t nz = h->nz, n = h->n, i = (size_t)instance;
+    if (H) HIP_TRY(h, hipMemcpy(H, h->bH + i * nz * nz, nz * nz * sizeof(double), hipMemcpyDeviceToHost));
+    if (F) HIP_TRY(h, hipMemcpy(F, h->bF + i * nz * n, nz * n * sizeof(double), hipMemcpyDeviceToHost));
+    if (d) HIP_TRY(h, hipMemcpy(d, h->bD + i * h->nzs, nz * sizeof(double), hipMemcpyDeviceToHost));
+    return ALMPC_OK;
 }
 
 int almpc_set_reference(almpc_handle* h, const double* xref, const double* uref, int per_instance) {
@@ -305,8 +465,9 @@ int almpc_set_reference(almpc_handle* h, const double* xref, const double* uref,
     if (h->dV0S) { (void)hipFree(h->dV0S); h->dV0S = nullptr; }
     HIP_TRY(h, dalloc(&h->dXref, cnt * xs));
     HIP_TRY(h, dalloc(&h->dUref, cnt * us));
-    HIP_TRY(h, dalloc(&h->dFS, cnt * us));
-    HIP_TRY(h, dalloc(&h->dV0S, cnt * us));
+    const size_t fcnt = h->batched ? (size_t)h->batch : cnt;  // per-instance models: fS depends on d_i
+    HIP_TRY(h, dalloc(&h->dFS, fcnt * us));
+    HIP_TRY(h, dalloc(&h->dV0S, fcnt * us));
     HIP_TRY(h, hipMemcpy(h->dXref, xref, cnt * xs * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->dUref, uref, cnt * us * sizeof(double), hipMemcpyHostToDevice));
     // fS = d .* (2 D'Sbar D u_ref): the input-rate cost is on u, not e_u (src/sub/design_mpc.jl:423-446)
@@ -322,21 +483,38 @@ int almpc_set_reference(almpc_handle* h, const double* xref, const double* uref,
                     f[i * m + a] += 2.0 * sd;
                     f[(i + 1) * m + a] -= 2.0 * sd;
                 }
-            for (int r = 0; r < nz; ++r) f[r] *= h->d[r];
+            if (!h->batched)
+                for (int r = 0; r < nz; ++r) f[r] *= h->d[r];
         }
     }
+    if (h->batched) {  // fS_i = d_i .* g and v0S_i = -G_i fS_i on the device, one vector per instance
+        double* dGs = nullptr;
+        HIP_TRY(h, dalloc(&dGs, cnt * us));
+        hipError_t e = hipMemcpy(dGs, fS.data(), cnt * us * sizeof(double), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_fs_scale, dim3(256), dim3(256), 0, h->stream, h->batch, nz, h->nzs, dGs, per_instance ? (long)us : 0L,
+                               h->bD, h->dFS);
+            hipLaunchKernelGGL(k_neg_gm, dim3(1, (unsigned)h->batch), dim3(256), 0, h->stream, nz, h->nzs, 1, (int)us, h->bG, h->dFS,
+                               h->dV0S, (long)nz * h->nzs, (long)us);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        }
+        (void)hipFree(dGs);
+        if (e != hipSuccess) return fail(h, ALMPC_ERR_HIP, std::string("set_reference (batched): ") + hipGetErrorString(e));
+    } else {
     HIP_TRY(h, hipMemcpy(h->dFS, fS.data(), cnt * us * sizeof(double), hipMemcpyHostToDevice));
     // v0S = -G fS: constant part of the polish's unconstrained minimiser (k_admm adds the part linear in e0)
     {
         const size_t blocks = (cnt * us + 255) / 256;
         hipLaunchKernelGGL(k_neg_gm, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, h->stream, nz, h->nzs,
-                           (int)cnt, (int)us, h->dG, h->dFS, h->dV0S);
+                           (int)cnt, (int)us, h->dG, h->dFS, h->dV0S, 0L, 0L);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
+    }
     h->xref_stride = per_instance ? (long)xs : 0;
     h->uref_stride = per_instance ? (long)us : 0;
-    h->fS_stride = per_instance ? (long)us : 0;
+    h->fS_stride = (per_instance || h->batched) ? (long)us : 0;
     return ALMPC_OK;
 }
 
@@ -381,6 +559,22 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         HIP_TRY(h, hipEventRecord(ev[0], st));
     }
 
+    if (h->batched) {  // per-instance models: one workgroup per instance, KKT inverse in LDS
+        AdmmInstParams ip;
+        ip.nz = h->nz; ip.n = h->n; ip.m = h->m; ip.batch = h->batch; ip.nzs = h->nzs;
+        ip.Minv = h->bMinv; ip.Hs = h->bHs; ip.Fs = h->bFs; ip.Vs = h->bVs; ip.dvec = h->bD; ip.rhovec = h->bRho;
+        ip.fS = h->dFS; ip.v0S = h->dV0S; ip.umin = h->dUmin; ip.umax = h->dUmax;
+        ip.uref = h->dUref; ip.uref_stride = h->uref_stride; ip.xref = h->dXref; ip.xref_stride = h->xref_stride; ip.x0 = h->dX0;
+        ip.xs = h->dXs; ip.zs = h->dZs; ip.ys = h->dYs; ip.v0 = h->dV0; ip.status = h->dStatus; ip.iters = h->dIters;
+        ip.piters = h->dPiters; ip.overflow = h->dOverflow; ip.perm = h->dPerm;
+        ip.sigma = o.sigma; ip.alpha = o.alpha; ip.eps_abs = o.eps_abs; ip.eps_rel = o.eps_rel;
+        ip.max_iter = o.max_iter; ip.check_every = o.check_every; ip.warm = o.warm_start ? 1 : 0;
+        const size_t l = ((size_t)h->nz * h->nzs + 4 * (size_t)h->nzs + 32 + h->n) * sizeof(double);
+        if (l > 64 * 1024)
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_admm_inst), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l));
+        hipLaunchKernelGGL(k_admm_inst, dim3(h->batch), dim3(ADMM_INST_THREADS), l, st, ip);
+        HIP_TRY(h, hipGetLastError());
+    } else {
     AdmmParams ap;
     ap.nz = h->nz; ap.n = h->n; ap.m = h->m; ap.batch = h->batch; ap.nzs = h->nzs;
     ap.MinvFrag = h->dMinvFrag; ap.VFrag = h->dVFrag; ap.v0S = h->dV0S; ap.v0S_stride = h->fS_stride; ap.HFrag = h->dHFrag; ap.FFrag = h->dFFrag; ap.ksf = h->ksf;
@@ -395,10 +589,11 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
     const int grid = (h->batch + TILE - 1) / TILE;
     const size_t lds = ((size_t)2 * h->nzs * TILE + (size_t)h->nrb * 8 * TILE + (size_t)4 * h->ksf * TILE) * sizeof(double);
     HIP_TRY(h, launch_admm(h->nrb, h->ks, ap, grid, lds, st));
+    }
     if (timing) HIP_TRY(h, hipEventRecord(ev[1], st));
 
     RolloutParams rp;
-    rp.n = h->n; rp.m = h->m; rp.N = h->N; rp.batch = h->batch; rp.nzs = h->nzs; rp.A = h->dA; rp.B = h->dB;
+    rp.n = h->n; rp.m = h->m; rp.N = h->N; rp.batch = h->batch; rp.nzs = h->nzs; rp.A = h->batched ? h->bA : h->dA; rp.B = h->batched ? h->bB : h->dB;
     rp.dvec = h->dD; rp.w = h->dZs; rp.x0 = h->dX0; rp.xref = h->dXref; rp.xref_stride = h->xref_stride;
     rp.uref = h->dUref; rp.uref_stride = h->uref_stride; rp.umin = h->dUmin; rp.umax = h->dUmax; rp.x = h->dX; rp.ex = h->dEx; rp.u = h->dU; rp.eu = h->dEu;
     bool fused = false;
@@ -432,7 +627,11 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         fused = true;
     } else if (o.polish) {
         PolishParams pp;
-        pp.nz = h->nz; pp.m = h->m; pp.batch = h->batch; pp.nzs = h->nzs; pp.G = h->dG; pp.dvec = h->dD;
+        pp.nz = h->nz; pp.m = h->m; pp.batch = h->batch; pp.nzs = h->nzs;
+        pp.G = h->batched ? h->bG : h->dG; pp.dvec = h->batched ? h->bD : h->dD;
+        pp.G_stride = h->batched ? (long)h->nz * h->nzs : 0; pp.d_stride = h->batched ? (long)h->nzs : 0;
+        pp.A_stride = h->batched ? (long)h->n * h->n : 0; pp.B_stride = h->batched ? (long)h->n * h->m : 0;
+        pp.wave_const_off = -1;
         pp.umin = h->dUmin; pp.umax = h->dUmax; pp.uref = h->dUref; pp.uref_stride = h->uref_stride;
         pp.zs = h->dZs; pp.ys = h->dYs; pp.v0 = h->dV0; pp.w = h->dW; pp.status = h->dStatus; pp.piters = h->dPiters;
         pp.sglobal = h->dSglobal; pp.perm = h->dPerm; pp.ntiles = (h->batch + 15) / 16;
@@ -443,11 +642,16 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         int per_wave = POLISH_LDS_MIN_PER_WAVE;
         if (fused && (h->N + 1) * (h->n + h->m) > per_wave) per_wave = (h->N + 1) * (h->n + h->m);
         per_wave = (per_wave + 1) & ~1;
+        if (h->batched) {  // the wave's private copy of d_i | [A_i B_i] sits behind its buffers
+            if (!fused) return fail(h, ALMPC_ERR_UNSUPPORTED, "calculate: per-instance models need the fused rollout (n + m <= 8 * lanes-per-row)");
+            pp.wave_const_off = per_wave;
+            per_wave += (h->nzs + h->n * (h->n + h->m) + 1) & ~1;
+        }
         pp.lds_per_wave = per_wave;
         // G in LDS when it fits beside the buffers of 8 waves (gfx950: 160 KB per workgroup)
         const PolishShared SL = polish_shared_layout(h->n, h->m, h->N, h->nz, h->nzs, fused ? 1 : 0);
         const size_t l_glds = ((size_t)h->nz * h->nzs + SL.total + (size_t)POLISH_WAVES_GLDS * per_wave + 2) * sizeof(double);
-        if (l_glds <= 160 * 1024 && !h->polish_no_glds) {
+        if (l_glds <= 160 * 1024 && !h->polish_no_glds && !h->batched) {
             if (h->polish_glds_bytes != l_glds) {
                 HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_polish<true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)l_glds));
@@ -467,7 +671,8 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
 
     if (!fused) {
         const size_t per_wave = (size_t)h->n * (h->N + 1) + h->nz, shared = (size_t)h->n * h->n + (size_t)h->n * h->m;
-        if ((shared + 4 * per_wave) * sizeof(double) <= 60 * 1024) {
+        if (h->batched) { rp.A_stride = (long)h->n * h->n; rp.B_stride = (long)h->n * h->m; rp.d_stride = h->nzs; rp.dvec = h->bD; }
+        if (!h->batched && (shared + 4 * per_wave) * sizeof(double) <= 60 * 1024) {
             const size_t l = (shared + 4 * per_wave) * sizeof(double);
             hipLaunchKernelGGL((k_rollout<4>), dim3((h->batch + 3) / 4), dim3(256), l, st, rp);
         } else {  // long horizons with many states: one instance per workgroup, LDS beyond the 64 KiB default
@@ -656,6 +861,7 @@ int almpc_fnn_linearize(int device_id, int n, int m, int H, int L, int activatio
 int almpc_advance_plant(almpc_handle* h) {
     if (!h) return ALMPC_ERR_INVALID;
     if (!h->designed) return fail(h, ALMPC_ERR_NOT_DESIGNED, "advance_plant before design");
+    if (h->batched) return fail(h, ALMPC_ERR_UNSUPPORTED, "advance_plant: per-instance models have no shared plant (advance the states on the caller's side)");
     HIP_TRY(h, hipSetDevice(h->device));
     const int per_block = 256 / h->n;
     hipLaunchKernelGGL(k_advance_plant, dim3((h->batch + per_block - 1) / per_block), dim3(256), (size_t)per_block * h->n * sizeof(double),

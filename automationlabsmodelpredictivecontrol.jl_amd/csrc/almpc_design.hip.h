@@ -20,11 +20,19 @@
 
 namespace almpc {
 
+// Every design kernel takes the instance number from blockIdx.y and per-instance strides (in doubles) for its operands:
+// all zero with gridDim.y = 1 for the shared-model design, the per-instance sizes for almpc_design_batched.
+struct DesignStrides {
+    long A = 0, B = 0, P = 0, Phi = 0, Gk = 0, Gam = 0, WP = 0, H = 0, F = 0, d = 0, Hs = 0, Fs = 0, G = 0, Minv = 0, rho = 0,
+         flag = 0;
+};
+
 // ---- K1/K2 -------------------------------------------------------------------------------------
 // One workgroup.  Phi[k] (n x n, column-major) = A^(k+1); Gk[k] (n x m, column-major) = A^k B.
 __global__ __launch_bounds__(256) void k_design_blocks(int n, int m, int N, const double* A, const double* B,
-                                                       double* Phi, double* Gk) {
+                                                       double* Phi, double* Gk, DesignStrides st) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    A += blockIdx.y * st.A; B += blockIdx.y * st.B; Phi += blockIdx.y * st.Phi; Gk += blockIdx.y * st.Gk;
     double* As = smem;           // n*n
     double* Bs = As + n * n;     // n*m
     double* cur = Bs + n * m;    // n*n  = A^k
@@ -59,8 +67,10 @@ __global__ __launch_bounds__(256) void k_design_blocks(int n, int m, int N, cons
 // zero-initialised by the host so padding rows/columns stay zero.
 __global__ __launch_bounds__(256) void k_design_gamma(int n, int m, int N, const double* Q, const double* P,
                                                       const double* Phi, const double* Gk, double* Gam, double* W,
-                                                      double* WP, int gs, int ps) {
+                                                      double* WP, int gs, int ps, DesignStrides st) {
     const int k = blockIdx.x;
+    P += blockIdx.y * st.P; Phi += blockIdx.y * st.Phi; Gk += blockIdx.y * st.Gk;
+    Gam += blockIdx.y * st.Gam; W += blockIdx.y * st.Gam; WP += blockIdx.y * st.WP;
     const double* Qk = (k == N - 1) ? P : Q;  // stage N+1 carries only P (src/sub/design_mpc.jl:448-456)
     const int nz = m * N;
     for (int t = threadIdx.x; t < n * nz; t += blockDim.x) {
@@ -96,12 +106,15 @@ struct HessParams {
     int useR, useS;
     double* H;  // column-major nz x nz
     double* F;  // column-major nz x n
+    DesignStrides st;
 };
 
 constexpr int HESS_KC = 32;
 
 __global__ __launch_bounds__(768) void k_design_hessian(HessParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    p.Gam += blockIdx.y * p.st.Gam; p.W += blockIdx.y * p.st.Gam; p.WP += blockIdx.y * p.st.WP;
+    p.H += blockIdx.y * p.st.H; p.F += blockIdx.y * p.st.F;
     const int ws = p.gs + 16, pps = p.ps + 16;  // padded LDS strides: the 4 k-groups of a B read hit different banks
     double* GI = smem;                       // [KC][16]
     double* Wc = GI + HESS_KC * 16;          // [KC][ws]
@@ -165,7 +178,9 @@ __global__ __launch_bounds__(768) void k_design_hessian(HessParams p) {
 // d = diag(H)^-1/2 (pad rows 1), Hs (ld = nzs, symmetrised) = D H D, Fs (ld = nzs) = D F.  flag[0] != 0 on a
 // non-positive diagonal.
 __global__ __launch_bounds__(256) void k_design_scale(int nz, int nzs, int n, const double* H, const double* F,
-                                                      double* d, double* Hs, double* Fs, int* flag) {
+                                                      double* d, double* Hs, double* Fs, int* flag, DesignStrides st) {
+    H += blockIdx.y * st.H; F += blockIdx.y * st.F; d += blockIdx.y * st.d; Hs += blockIdx.y * st.Hs; Fs += blockIdx.y * st.Fs;
+    flag += blockIdx.y * st.flag;
     for (int t = threadIdx.x; t < nzs; t += blockDim.x) {
         double v = 1.0;
         if (t < nz) {
@@ -191,8 +206,10 @@ __global__ __launch_bounds__(256) void k_design_scale(int nz, int nzs, int n, co
 // One workgroup, matrix in LDS (ld = nz+1 to spread banks).  Cholesky (right-looking), in-place inverse of
 // the triangular factor, then X'X.  flag[0] != 0 if a pivot is not positive.
 __global__ __launch_bounds__(512) void k_design_inverse(int nz, int nzs, const double* Hs, double cshift, const double* dshift,
-                                                        double* Out, int* flag) {
+                                                        double* Out, int* flag, long sHs, long sShift, long sOut, long sFlag) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    Hs += blockIdx.y * sHs; Out += blockIdx.y * sOut; flag += blockIdx.y * sFlag;
+    if (dshift) dshift += blockIdx.y * sShift;
     const int ld = nz + 1;
     double* L = smem;         // [nz][ld], element (i,j) at L[j*ld + i]
     double* xo = L + (size_t)nz * ld;  // [nz] scratch column
@@ -244,7 +261,9 @@ __global__ __launch_bounds__(512) void k_design_inverse(int nz, int nzs, const d
 }
 
 // ---- ADMM penalty per row: scalar rho (OSQP), or the stiffness profile rho_i = rho / G_ii (G = H'^-1), pad rows 1
-__global__ __launch_bounds__(256) void k_design_rho(int nz, int nzs, int mode, double rho, const double* G, double* rhovec) {
+__global__ __launch_bounds__(256) void k_design_rho(int nz, int nzs, int mode, double rho, const double* G, double* rhovec,
+                                                    long sG, long sRho) {
+    G += blockIdx.y * sG; rhovec += blockIdx.y * sRho;
     for (int t = threadIdx.x; t < nzs; t += blockDim.x)
         rhovec[t] = (t < nz) ? (mode == 1 ? rho / G[(size_t)t * nzs + t] : rho) : 1.0;
 }
@@ -264,7 +283,9 @@ __global__ __launch_bounds__(256) void k_pack_frags(const double* M, int rows, i
 // ---- Out[:, c] = -G M[:, c] for a few columns (leading dimension ld for M and Out; G dense symmetric, leading dimension nzs).
 // Design-time / set_reference-time helper for the polish's unconstrained minimiser v0 = -G f' = (-G F') e0 + (-G fS):
 // with V = -G F' packed like F', k_admm gets v0 from n columns instead of a second nz x nz product per step.
-__global__ __launch_bounds__(256) void k_neg_gm(int nz, int nzs, int ncols, int ld, const double* G, const double* M, double* Out) {
+__global__ __launch_bounds__(256) void k_neg_gm(int nz, int nzs, int ncols, int ld, const double* G, const double* M, double* Out,
+                                                long sG, long sM) {
+    G += blockIdx.y * sG; M += blockIdx.y * sM; Out += blockIdx.y * sM;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < (long)ncols * nz; t += (long)gridDim.x * blockDim.x) {
         const int c = (int)(t / nz), r = (int)(t % nz);
         const double* g = G + (size_t)r * nzs;
@@ -369,9 +390,9 @@ inline int design_shared_device(hipStream_t stream, int n, int m, int N, int nzs
     DTRY(hipMemcpyAsync(dP, P.data(), P.size() * sizeof(double), hipMemcpyHostToDevice, stream));
 
     hipLaunchKernelGGL(k_design_blocks, dim3(1), dim3(256), (size_t)(3 * n * n + n * m) * sizeof(double), stream, n, m, N,
-                       dA, dB, dPhi, dGk);
+                       dA, dB, dPhi, dGk, DesignStrides());
     DTRY(hipGetLastError());
-    hipLaunchKernelGGL(k_design_gamma, dim3(N), dim3(256), 0, stream, n, m, N, dQ, dP, dPhi, dGk, dGam, dW, dWP, gs, ps);
+    hipLaunchKernelGGL(k_design_gamma, dim3(N), dim3(256), 0, stream, n, m, N, dQ, dP, dPhi, dGk, dGam, dW, dWP, gs, ps, DesignStrides());
     DTRY(hipGetLastError());
     HessParams hp;
     hp.n = n; hp.m = m; hp.N = N; hp.nz = nz; hp.nrb = nrb; hp.njf = njf; hp.kr = kr;
@@ -380,19 +401,19 @@ inline int design_shared_device(hipStream_t stream, int n, int m, int N, int nzs
     const size_t hess_lds = (size_t)HESS_KC * (16 + (gs + 16) + (ps + 16)) * sizeof(double);
     hipLaunchKernelGGL(k_design_hessian, dim3(nrb), dim3(64 * (nrb + njf)), hess_lds, stream, hp);
     DTRY(hipGetLastError());
-    hipLaunchKernelGGL(k_design_scale, dim3(1), dim3(256), 0, stream, nz, nzs, n, dH, dF, dD, dHs, dFs, dFlag);
+    hipLaunchKernelGGL(k_design_scale, dim3(1), dim3(256), 0, stream, nz, nzs, n, dH, dF, dD, dHs, dFs, dFlag, DesignStrides());
     DTRY(hipGetLastError());
     const size_t inv_lds = ((size_t)nz * (nz + 1) + nz + 2) * sizeof(double);
     DTRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_design_inverse), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)inv_lds));
     // G = H'^-1 first: the stiffness profile of the ADMM penalty (rho_i = rho / G_ii) is read off its diagonal
-    hipLaunchKernelGGL(k_design_inverse, dim3(1), dim3(512), inv_lds, stream, nz, nzs, dHs, 0.0, (const double*)nullptr, dG, dFlag);
+    hipLaunchKernelGGL(k_design_inverse, dim3(1), dim3(512), inv_lds, stream, nz, nzs, dHs, 0.0, (const double*)nullptr, dG, dFlag, 0L, 0L, 0L, 0L);
     DTRY(hipGetLastError());
-    hipLaunchKernelGGL(k_design_rho, dim3(1), dim3(256), 0, stream, nz, nzs, rho_mode, rho, dG, dRho);
-    hipLaunchKernelGGL(k_design_inverse, dim3(1), dim3(512), inv_lds, stream, nz, nzs, dHs, sigma, (const double*)dRho, dMinv, dFlag);
+    hipLaunchKernelGGL(k_design_rho, dim3(1), dim3(256), 0, stream, nz, nzs, rho_mode, rho, dG, dRho, 0L, 0L);
+    hipLaunchKernelGGL(k_design_inverse, dim3(1), dim3(512), inv_lds, stream, nz, nzs, dHs, sigma, (const double*)dRho, dMinv, dFlag, 0L, 0L, 0L, 0L);
     DTRY(hipGetLastError());
     hipLaunchKernelGGL(k_pack_frags, dim3(32), dim3(256), 0, stream, dMinv, nz, nz, nzs, nrb, ks, dMinvFrag);
-    hipLaunchKernelGGL(k_neg_gm, dim3(32), dim3(256), 0, stream, nz, nzs, n, nzs, dG, dFs, dVs);
+    hipLaunchKernelGGL(k_neg_gm, dim3(32), dim3(256), 0, stream, nz, nzs, n, nzs, dG, dFs, dVs, 0L, 0L);
     hipLaunchKernelGGL(k_pack_frags, dim3(32), dim3(256), 0, stream, dVs, nz, n, nzs, nrb, ksf, dVFrag);
     hipLaunchKernelGGL(k_pack_frags, dim3(32), dim3(256), 0, stream, dHs, nz, nz, nzs, nrb, ks, dHFrag);
     hipLaunchKernelGGL(k_pack_frags, dim3(32), dim3(256), 0, stream, dFs, nz, n, nzs, nrb, ksf, dFFrag);

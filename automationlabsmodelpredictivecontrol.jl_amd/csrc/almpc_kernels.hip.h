@@ -379,6 +379,7 @@ struct RolloutParams {
     int n, m, N, batch, nzs;
     const double* A;  // n*n column-major
     const double* B;  // n*m column-major
+    long A_stride = 0, B_stride = 0, d_stride = 0;  // per-instance models: doubles between instances (k_rollout<1> only); 0 = shared
     const double* dvec;
     const double* w;  // scaled solution [batch][nzs]
     const double* x0;
@@ -412,6 +413,10 @@ struct PolishParams {
     const int32_t* perm; // [ntiles*16] per-tile processing order written by k_admm (hard instances first, -1 = pad)
     int ntiles;          // ADMM tiles (16 instances each)
     int lds_per_wave;    // doubles of LDS per wave (>= POLISH_LDS_MIN_PER_WAVE and >= the rollout trajectory buffer)
+    // per-instance models (almpc_design_batched): strides in doubles of G, d, A, B per instance (0 = shared), and the
+    // offset inside the wave's LDS slot of its private copy of d_i | [A_i B_i] (which replace the workgroup-shared ones)
+    long G_stride, d_stride, A_stride, B_stride;
+    int wave_const_off;
     int max_iter;
     int fuse_rollout;    // 1: this kernel also produces u, e_u, x, e_x (roll.*), no separate k_rollout launch
     int roll_g, roll_cpl; // rollout lane decomposition: roll_g lanes per state row, roll_cpl columns of [A B] per lane
@@ -593,16 +598,23 @@ void k_polish(PolishParams p_arg) {
     double* wave_lds = shc + SL.total + (size_t)wv * p.lds_per_wave;
     int* qcnt = nullptr;
     const bool uref_sh = p.uref_stride == 0, xref_sh = p.roll.xref_stride == 0;
+    const bool per_inst = p.G_stride != 0;  // host: only with GLDS = false
+    double* cd = shc + SL.off_d;    // d and [A B] as the waves read them: workgroup-shared, or the wave's own copy
+    double* cab = shc + SL.off_ab;
+    if (per_inst) { cd = wave_lds + p.wave_const_off; cab = cd + nzs; }
     {
         constexpr int TPB = 64 * (GLDS ? POLISH_WAVES_GLDS : POLISH_WAVES);
         const int n = p.roll.n, m = p.m, N = p.roll.N;
-        for (int t = threadIdx.x; t < nzs; t += TPB) shc[SL.off_d + t] = p.dvec[t];
+        if (!per_inst)
+            for (int t = threadIdx.x; t < nzs; t += TPB) shc[SL.off_d + t] = p.dvec[t];
         for (int t = threadIdx.x; t < m; t += TPB) { shc[SL.off_umin + t] = p.umin[t]; shc[SL.off_umax + t] = p.umax[t]; }
         if (uref_sh)
             for (int t = threadIdx.x; t < nz; t += TPB) shc[SL.off_uref + t] = p.uref[t];
         if (p.fuse_rollout) {
-            for (int t = threadIdx.x; t < n * n; t += TPB) shc[SL.off_ab + t] = p.roll.A[t];
-            for (int t = threadIdx.x; t < n * m; t += TPB) shc[SL.off_ab + n * n + t] = p.roll.B[t];
+            if (!per_inst) {
+                for (int t = threadIdx.x; t < n * n; t += TPB) shc[SL.off_ab + t] = p.roll.A[t];
+                for (int t = threadIdx.x; t < n * m; t += TPB) shc[SL.off_ab + n * n + t] = p.roll.B[t];
+            }
             if (xref_sh)
                 for (int t = threadIdx.x; t < (N + 1) * n; t += TPB) shc[SL.off_xref + t] = p.roll.xref[t];
         }
@@ -642,6 +654,18 @@ void k_polish(PolishParams p_arg) {
     int lane = lane_k;
     asm volatile("" : "+v"(lane));  // same reason: masks and constants derived from the lane number stay inside the instance
     ALMPC_STAMP(inst, 8);
+    if constexpr (!GLDS) {
+        if (per_inst) {  // this instance's G, d, [A B]
+            Gp = GL(p.G) + (size_t)inst * p.G_stride;
+            const int n_ = p.roll.n, m_ = p.m;
+            for (int t = lane; t < nzs; t += 64) cd[t] = GL(p.dvec)[(size_t)inst * p.d_stride + t];
+            if (p.fuse_rollout) {
+                for (int t = lane; t < n_ * n_; t += 64) cab[t] = GL(p.roll.A)[(size_t)inst * p.A_stride + t];
+                for (int t = lane; t < n_ * m_; t += 64) cab[n_ * n_ + t] = GL(p.roll.B)[(size_t)inst * p.B_stride + t];
+            }
+            wave_fence_lds();
+        }
+    }
     const int st_in = GL(p.status)[inst];
     const size_t base = (size_t)inst * nzs;
     // row-distributed vectors: lane l owns the two consecutive rows 2l, 2l+1 (one 16-byte access per vector)
@@ -662,7 +686,7 @@ void k_polish(PolishParams p_arg) {
     double x0r = 0.0;
     if (p.fuse_rollout && lane < p.roll.n) x0r = GL(p.roll.x0)[(size_t)inst * p.roll.n + lane];
     {
-        const d2 dv = *reinterpret_cast<const d2*>(shc + SL.off_d + rc);
+        const d2 dv = *reinterpret_cast<const d2*>(cd + rc);
         const d2 vv = *reinterpret_cast<const d2*>(GL(p.v0) + base + rc);
         const d2 yy = *reinterpret_cast<const d2*>(GL(p.ys) + base + rc);
         const d2 zz = *reinterpret_cast<const d2*>(GL(p.zs) + base + rc);
@@ -1193,7 +1217,7 @@ void k_polish(PolishParams p_arg) {
         const RolloutParams& rp = p.roll;
         const int n = rp.n, m = rp.m, N = rp.N, C = n + m;
         double* Z = wave_lds;  // (N+1) x C trajectory buffer over the (now dead) active-set buffers; sized by the host
-        const d2 dvp = *reinterpret_cast<const d2*>(shc + SL.off_d + rc);
+        const d2 dvp = *reinterpret_cast<const d2*>(cd + rc);
         if (in0) {
             const double ur = uref_sh ? shc[SL.off_uref + r0] : GL(rp.uref)[(size_t)inst * rp.uref_stride + r0];
             const double uu = fmin(fmax(wout[0] * dvp[0] + ur, shc[SL.off_umin + r0 % m]), shc[SL.off_umax + r0 % m]);
@@ -1212,10 +1236,10 @@ void k_polish(PolishParams p_arg) {
         wave_fence_lds();
         ALMPC_STAMP(inst, 12);
         switch (p.roll_cpl) {
-            case 1: rollout_steps<1>(Z, n, m, N, p.roll_g, lane, shc + SL.off_ab, shc + SL.off_ab + n * n); break;
-            case 2: rollout_steps<2>(Z, n, m, N, p.roll_g, lane, shc + SL.off_ab, shc + SL.off_ab + n * n); break;
-            case 4: rollout_steps<4>(Z, n, m, N, p.roll_g, lane, shc + SL.off_ab, shc + SL.off_ab + n * n); break;
-            default: rollout_steps<8>(Z, n, m, N, p.roll_g, lane, shc + SL.off_ab, shc + SL.off_ab + n * n); break;
+            case 1: rollout_steps<1>(Z, n, m, N, p.roll_g, lane, cab, cab + n * n); break;
+            case 2: rollout_steps<2>(Z, n, m, N, p.roll_g, lane, cab, cab + n * n); break;
+            case 4: rollout_steps<4>(Z, n, m, N, p.roll_g, lane, cab, cab + n * n); break;
+            default: rollout_steps<8>(Z, n, m, N, p.roll_g, lane, cab, cab + n * n); break;
         }
         ALMPC_STAMP(inst, 13);
         const int nx = n * (N + 1);
@@ -1280,8 +1304,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_rollout(RolloutParams p) {
     double* Bs = As + n * n;           // [m][n]
     double* wbuf = Bs + n * m;         // per wave: e_x trajectory (nx) + e_u (nz)
     ALMPC_STAMP(blockIdx.x * WAVES + (threadIdx.x >> 6), 4);
-    for (int t = threadIdx.x; t < n * n; t += blockDim.x) As[t] = p.A[t];
-    for (int t = threadIdx.x; t < n * m; t += blockDim.x) Bs[t] = p.B[t];
+    // per-instance models: one instance per workgroup (WAVES = 1), so the workgroup's model is instance blockIdx.x's
+    const double* Ag = p.A + (size_t)blockIdx.x * WAVES * p.A_stride;
+    const double* Bg = p.B + (size_t)blockIdx.x * WAVES * p.B_stride;
+    for (int t = threadIdx.x; t < n * n; t += blockDim.x) As[t] = Ag[t];
+    for (int t = threadIdx.x; t < n * m; t += blockDim.x) Bs[t] = Bg[t];
     __syncthreads();
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int inst = blockIdx.x * WAVES + wv;
@@ -1292,7 +1319,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_rollout(RolloutParams p) {
     // inputs: u, e_u (contiguous per instance: coalesced)
     for (int r = lane; r < nz; r += 64) {
         const double ur = p.uref[(size_t)inst * p.uref_stride + r];
-        const double uu = fmin(fmax(p.w[(size_t)inst * p.nzs + r] * p.dvec[r] + ur, p.umin[r % m]), p.umax[r % m]);
+        const double uu = fmin(fmax(p.w[(size_t)inst * p.nzs + r] * p.dvec[(size_t)inst * p.d_stride + r] + ur, p.umin[r % m]), p.umax[r % m]);
         const double ev = uu - ur;
         v[r] = ev;
         p.eu[(size_t)inst * nz + r] = ev;

@@ -128,6 +128,26 @@ int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const
                         double sigma);
 
 /*
+ * Design with a model PER INSTANCE: A_batch [batch][n*n], B_batch [batch][n*m] (each block column-major).  This is the
+ * linear-programming design of the reference applied to the linearisation of a black-box model at every instance's own
+ * point (the reference linearises once, at the first reference, src/sub/model_modeler_implementation/fnn/
+ * mpc_modeler_implementation_fnn.jl:38-46, and then builds the QP of ..linear.jl:48-100 from (A, B): given (A_i, B_i)
+ * the QP of instance i is that QP; BASELINE.json configs[3] re-linearises every step, SURVEY.md section 8b
+ * `almpc_design_batched`).  Q, R, S, umin, umax as in almpc_design_shared.  P: NULL -> DARE(A_i, B_i, Q, R) per instance
+ * (host, src/sub/design_mpc.jl:327); else one n*n matrix (P_per_instance = 0) or [batch][n*n] (P_per_instance = 1).
+ * Prediction matrices, condensed Hessian (FP64 MFMA contraction), scaling and both inverses are built on the device for
+ * every instance; the step then runs one workgroup per instance with the instance's KKT inverse in LDS.  Not available
+ * with per-instance models: state rows (state box, terminal equality), almpc_advance_plant.  A later
+ * almpc_design_shared switches the handle back to the shared-model path.
+ */
+int almpc_design_batched(almpc_handle* h, const double* A_batch, const double* B_batch, const double* Q,
+                         const double* R, const double* S, const double* P, int P_per_instance,
+                         const double* umin, const double* umax, double rho, double sigma);
+
+/* H (nz*nz), F (nz*n), d (nz) of one instance after almpc_design_batched (any pointer may be NULL). */
+int almpc_get_design_instance(almpc_handle* h, int instance, double* H, double* F, double* d);
+
+/*
  * References (replaces _design_reference_mpc, src/main/main_mpc.jl:105-117, and the JuMP.fix of
  * x_reference/u_reference, ...linear.jl:90-100).  per_instance = 0: xref n*(N+1), uref m*N shared
  * by all instances.  per_instance = 1: xref [batch][N+1][n], uref [batch][N][m].

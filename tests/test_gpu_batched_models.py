@@ -1,0 +1,198 @@
+"""GPU parity tests for per-instance models (almpc_design_batched): every instance has its own (A_i, B_i).  The oracle builds
+one MPCProblem per instance (the reference's QP for given (A, B)) and solves it exactly."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+U_TOL = 1e-5   # BASELINE.json: |u - u*|_inf <= 1e-5
+X_TOL = 1e-4
+
+
+def quad_family(mo, batch, seed=7, spread=0.25):
+    """Quadrotors with per-instance mass and inertia (within +-spread of the nominal) -> per-instance (A_i, B_i)."""
+    rng = np.random.default_rng(seed)
+    As, Bs = [], []
+    for _ in range(batch):
+        f = 1.0 + spread * (2.0 * rng.random(4) - 1.0)
+        A, B = mo.quadrotor_model(mass=0.5 * f[0], J=(4e-3 * f[1], 4e-3 * f[2], 8e-3 * f[3]))
+        As.append(A); Bs.append(B)
+    return np.stack(As), np.stack(Bs)
+
+
+def random_family(n, m, batch, seed):
+    rng = np.random.default_rng(seed)
+    As, Bs = [], []
+    for _ in range(batch):
+        A = rng.standard_normal((n, n))
+        A *= (0.6 + 0.5 * rng.random()) / max(1e-9, np.max(np.abs(np.linalg.eigvals(A))))  # spectral radius 0.6 .. 1.1
+        As.append(A); Bs.append(rng.standard_normal((n, m)))
+    return np.stack(As), np.stack(Bs)
+
+
+def solve_batched(capi, As, Bs, N, umin, umax, X0, opts=None, x_ref=None, u_ref=None, q=100.0, r=0.1, s=0.0, P=None, **design_kw):
+    b, n, m = As.shape[0], As.shape[1], Bs.shape[2]
+    sv = capi.Solver(n, m, N, b)
+    sv.design_batched(As, Bs, q * np.eye(n), r * np.eye(m), s * np.eye(m), P, umin, umax, **design_kw)
+    if x_ref is not None:
+        sv.set_reference(x_ref, u_ref)
+    sv.update_initialization(X0)
+    sv.calculate(opts)
+    res = sv.get_results()
+    return sv, res
+
+
+def test_design_batched_matches_oracle(capi, mo):
+    As, Bs = quad_family(mo, 6)
+    sv = capi.Solver(12, 4, 30, 6)
+    sv.design_batched(As, Bs, 100 * np.eye(12), 0.1 * np.eye(4), None, None, [-2, -.05, -.05, -.02], [3, .05, .05, .02])
+    for i in range(6):
+        p = mo.make_problem(As[i], Bs[i], 30, [-2, -.05, -.05, -.02], [3, .05, .05, .02])
+        _, _, H, F = mo.condense(p)
+        g = sv.get_design_instance(i)
+        assert np.abs(g["H"] - H).max() <= 1e-11 * np.abs(H).max()
+        assert np.abs(g["F"] - F).max() <= 1e-11 * np.abs(F).max()
+        assert np.abs(g["d"] - mo.jacobi_scaling(H)).max() <= 1e-12 * np.abs(g["d"]).max()
+    sv.close()
+
+
+@pytest.mark.parametrize("amp", [0.5, 2.0])
+def test_quadrotor_family_vs_exact_oracle(capi, mo, amp):
+    b = 40
+    As, Bs = quad_family(mo, b)
+    X0 = mo.quadrotor_x0_batch(b, amp, first_instance=5000)
+    umin, umax = [-2, -.05, -.05, -.02], [3, .05, .05, .02]
+    sv, r = solve_batched(capi, As, Bs, 30, umin, umax, X0)
+    sv.close()
+    assert np.all(r["status"] == 0)
+    nact = 0
+    for i in range(b):
+        p = mo.make_problem(As[i], Bs[i], 30, umin, umax)
+        e = mo.solve_mpc_exact(p, X0[i])
+        assert np.abs(r["u"][i] - e["u"]).max() <= U_TOL
+        assert np.abs(r["x"][i] - e["x"]).max() <= X_TOL
+        nact += (np.isclose(e["u"], p.u_min[:, None]) | np.isclose(e["u"], p.u_max[:, None])).sum()
+    if amp >= 2.0:
+        assert nact > 50, "test input leaves the bounds inactive"
+
+
+def test_admm_iterate_matches_oracle_per_instance(capi, mo):
+    """polish = 0: the ADMM iterate of k_admm_inst (LDS-resident KKT inverse, column walk) is the oracle's iterate."""
+    b = 12
+    As, Bs = quad_family(mo, b, seed=11)
+    X0 = mo.quadrotor_x0_batch(b, 1.5, first_instance=77)
+    umin, umax = [-2, -.05, -.05, -.02], [3, .05, .05, .02]
+    for kw, prof in ((dict(rho=0.1), "scalar"), (dict(rho=30.0), "stiffness")):
+        sv, r = solve_batched(capi, As, Bs, 30, umin, umax, X0, capi.default_opts(max_iter=10, check_every=10, polish=0, **kw),
+                              rho_profile=prof, **kw)
+        sv.close()
+        for i in range(b):
+            p = mo.make_problem(As[i], Bs[i], 30, umin, umax)
+            des = mo.design_shared(p, rho=kw["rho"], rho_profile=prof)
+            fs = des["Fs"] @ (X0[i] - p.x_ref[:, 0]) + des["fS"]
+            a = mo.admm_box(des["Hs"], fs, des["lo"], des["hi"], rho=des["rho_vec"], sigma=des["sigma"], max_iter=10, check_every=10,
+                            Minv=des["Minv"], unscale=des["d"])
+            v = np.clip(a["z"] * des["d"], des["lo"] * des["d"], des["hi"] * des["d"])
+            assert r["iters"][i] == a["iters"] and r["status"][i] == a["status"]
+            assert np.abs(r["e_u"][i].T.reshape(-1) - v).max() <= 1e-9 * max(1.0, np.abs(v).max())
+
+
+@pytest.mark.parametrize("n,m,N", [(1, 1, 1), (2, 1, 12), (3, 2, 7), (5, 3, 9), (4, 2, 20), (7, 5, 25), (2, 1, 128), (16, 8, 16)])
+def test_random_plant_families_of_many_shapes(capi, mo, n, m, N):
+    b = 17
+    As, Bs = random_family(n, m, b, seed=1000 * n + 10 * m + N)
+    rng = np.random.default_rng(5)
+    X0 = rng.standard_normal((b, n)) * 2.0
+    umin, umax = -np.ones(m), np.ones(m)
+    sv, r = solve_batched(capi, As, Bs, N, umin, umax, X0)
+    sv.close()
+    for i in range(b):
+        p = mo.make_problem(As[i], Bs[i], N, umin, umax)
+        e = mo.solve_mpc_exact(p, X0[i])
+        if r["status"][i] == 0:
+            assert np.abs(r["u"][i] - e["u"]).max() <= U_TOL * max(1.0, np.abs(e["x"]).max())
+    assert (r["status"] == 0).mean() >= 0.9
+
+
+def test_identical_models_reproduce_the_shared_path(capi, mo):
+    p = mo.quadrotor()
+    b = 48
+    X0 = mo.quadrotor_x0_batch(b, 2.0, first_instance=321)
+    As, Bs = np.repeat(p.A[None], b, 0), np.repeat(p.B[None], b, 0)
+    sv, r = solve_batched(capi, As, Bs, 30, p.u_min, p.u_max, X0, P=p.P)
+    # same handle back on the shared-model path
+    sv.design_shared(p.A, p.B, p.Q, p.R, p.S, p.P, p.u_min, p.u_max)
+    sv.set_reference(p.x_ref, p.u_ref)
+    sv.update_initialization(X0)
+    sv.calculate()
+    s = sv.get_results()
+    sv.close()
+    assert np.array_equal(r["status"], s["status"])
+    assert np.abs(r["u"] - s["u"]).max() <= 1e-9 and np.abs(r["x"] - s["x"]).max() <= 1e-7
+
+
+def test_references_rate_weight_and_terminal_weight_options(capi, mo):
+    """Non-zero references, S != 0 (f_S term scaled per instance), shared P and per-instance P."""
+    b, n, m, N = 9, 4, 2, 15
+    As, Bs = random_family(n, m, b, seed=3)
+    As *= 0.9
+    rng = np.random.default_rng(1)
+    X0 = rng.standard_normal((b, n))
+    x_ref = 0.3 * np.ones((n, N + 1)); u_ref = np.tile(np.linspace(-0.3, 0.3, N), (m, 1))
+    umin, umax = -np.ones(m), np.ones(m)
+    Pshared = 50.0 * np.eye(n)
+    for P in (None, Pshared, np.stack([(40.0 + i) * np.eye(n) for i in range(b)])):
+        sv, r = solve_batched(capi, As, Bs, N, umin, umax, X0, x_ref=x_ref, u_ref=u_ref, s=0.7, P=P)
+        sv.close()
+        for i in range(b):
+            Pi = None if P is None else (P if P.ndim == 2 else P[i])
+            p = mo.make_problem(As[i], Bs[i], N, umin, umax, x_ref=x_ref, u_ref=u_ref, s=0.7, P=Pi)
+            e = mo.solve_mpc_exact(p, X0[i])
+            assert r["status"][i] == 0 and np.abs(r["u"][i] - e["u"]).max() <= U_TOL
+
+
+def test_config4_relinearised_fnn_per_instance(capi, mo):
+    """BASELINE configs[3] as an extension of the reference: the Fnn model is linearised at every instance's own
+    (x0_i, u_ref) by the Jacobian kernel, and each instance gets the reference's QP for its (A_i, B_i); N = 20, batch = 1024."""
+    f = mo.synthetic_fnn()
+    batch, N = 1024, 20
+    x_ref, u_ref = np.array([0.2, -0.1, 0.05, 0.0]), np.array([0.1, -0.2])
+    X0 = x_ref[None, :] + mo.splitmix_normal(0x5EED0004, 0, batch, 4) * 2.0
+    A, B = capi.fnn_linearize(f.W_in, f.W_h, f.b_h, f.W_out, X0, np.repeat(u_ref[None], batch, 0), act=f.act)
+    sv, r = solve_batched(capi, A, B, N, [-1, -1], [1, 1], X0, x_ref=x_ref[:, None] * np.ones((4, N + 1)),
+                          u_ref=u_ref[:, None] * np.ones((2, N)))
+    sv.close()
+    assert (r["status"] == 0).mean() >= 0.99
+    nact = 0
+    for i in range(0, batch, 16):
+        Ai, Bi = f.jacobian(X0[i], u_ref)
+        p = mo.make_problem(Ai, Bi, N, [-1, -1], [1, 1], x_ref=x_ref, u_ref=u_ref)
+        e = mo.solve_mpc_exact(p, X0[i])
+        if r["status"][i] == 0:
+            assert np.abs(r["u"][i] - e["u"]).max() <= U_TOL and np.abs(r["x"][i] - e["x"]).max() <= X_TOL
+        nact += ((e["u"] <= -1) | (e["u"] >= 1)).sum()
+    assert nact > 50
+
+
+def test_batched_error_behaviour(capi, mo):
+    p = mo.double_integrator()
+    sv = capi.Solver(2, 1, 10, 4)
+    A, B = np.repeat(p.A[None], 4, 0), np.repeat(p.B[None], 4, 0)
+    with pytest.raises(capi.AlmpcError) as ei:   # get_design_instance before a batched design
+        sv.get_design_instance(0)
+    assert ei.value.code == -5
+    sv.design_batched(A, B, p.Q, p.R, None, None, p.u_min, p.u_max)
+    with pytest.raises(capi.AlmpcError) as ei:
+        sv.advance_plant()
+    assert ei.value.code == -4
+    with pytest.raises(capi.AlmpcError) as ei:
+        sv.get_design_instance(4)
+    assert ei.value.code == -1
+    Abad = A.copy(); Abad[2, 0, 0] = np.nan   # a broken model: the numeric error names the instance
+    with pytest.raises(capi.AlmpcError) as ei:
+        sv.design_batched(Abad, B, p.Q, p.R, None, None, p.u_min, p.u_max)
+    assert ei.value.code == -6 and "instance 2" in str(ei.value)
+    with pytest.raises(capi.AlmpcError) as ei:   # the same with a given P: caught by the device-side pivot checks
+        sv.design_batched(Abad, B, p.Q, p.R, None, p.P, p.u_min, p.u_max)
+    assert ei.value.code == -6 and "instance 2" in str(ei.value)
+    sv.close()
