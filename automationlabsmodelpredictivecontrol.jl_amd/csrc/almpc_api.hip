@@ -316,8 +316,6 @@ int almpc_design_batched(almpc_handle* h, const double* A_batch, const double* B
     const size_t b = (size_t)h->batch;
     for (int i = 0; i < m; ++i)
         if (!(umin[i] <= umax[i])) return fail(h, ALMPC_ERR_INVALID, "design_batched: umin > umax");
-    const size_t lds_admm = ((size_t)nz * nzs + 4 * (size_t)nzs + 32 + n) * sizeof(double);
-    if (lds_admm > 160 * 1024) return fail(h, ALMPC_ERR_UNSUPPORTED, "design_batched: the instance's KKT inverse does not fit LDS");
     hm::mat Qm(Q, Q + (size_t)n * n), Rm(R, R + (size_t)m * m);
     hm::mat Sm = S ? hm::mat(S, S + (size_t)m * m) : hm::mat((size_t)m * m, 0.0);
     auto symmetrise = [](hm::mat& M, int k) {
@@ -569,10 +567,14 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         ip.piters = h->dPiters; ip.overflow = h->dOverflow; ip.perm = h->dPerm;
         ip.sigma = o.sigma; ip.alpha = o.alpha; ip.eps_abs = o.eps_abs; ip.eps_rel = o.eps_rel;
         ip.max_iter = o.max_iter; ip.check_every = o.check_every; ip.warm = o.warm_start ? 1 : 0;
-        const size_t l = ((size_t)h->nz * h->nzs + 4 * (size_t)h->nzs + 32 + h->n) * sizeof(double);
+        const size_t l = (12 * (size_t)h->nzs + 64 + 2 * (size_t)h->m) * sizeof(double);
         if (l > 64 * 1024)
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_admm_inst), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l));
-        hipLaunchKernelGGL(k_admm_inst, dim3(h->batch), dim3(ADMM_INST_THREADS), l, st, ip);
+        // persistent grid: as many workgroups as fit the CUs at once (LDS bound; 512 threads each, at most 4 per CU)
+        const int per_cu = 2;  // register bound: 2 x 256 threads at up to 256 VGPRs each fill the CU's register file
+        int wgs = h->num_cus * per_cu;
+        if (wgs > h->batch) wgs = h->batch;
+        hipLaunchKernelGGL(k_admm_inst, dim3(wgs), dim3(ADMM_INST_THREADS), l, st, ip);
         HIP_TRY(h, hipGetLastError());
     } else {
     AdmmParams ap;
@@ -635,7 +637,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         pp.umin = h->dUmin; pp.umax = h->dUmax; pp.uref = h->dUref; pp.uref_stride = h->uref_stride;
         pp.zs = h->dZs; pp.ys = h->dYs; pp.v0 = h->dV0; pp.w = h->dW; pp.status = h->dStatus; pp.piters = h->dPiters;
         pp.sglobal = h->dSglobal; pp.perm = h->dPerm; pp.ntiles = (h->batch + 15) / 16;
-        pp.max_iter = o.polish_max_iter > 0 ? o.polish_max_iter : 20 * h->nz + 50;
+        pp.max_iter = o.polish_max_iter > 0 ? o.polish_max_iter : 4 * h->nz + 50;
         // rollout fused into the tail of the polish when its trajectory buffer fits the wave's LDS slot
         fused = roll_fits;
         pp.fuse_rollout = fused ? 1 : 0; pp.roll_g = roll_g; pp.roll_cpl = roll_cpl; pp.roll = rp;

@@ -5,10 +5,11 @@
 // the same, only nothing is shared across the batch any more, so there is no 16-instance MFMA tile with a common A operand.
 //
 //   design : the kernels of almpc_design.hip.h with blockIdx.y = instance (MFMA contraction Gamma' Qbar Gamma per instance)
-//   k_admm_inst : ONE WORKGROUP PER INSTANCE.  The instance's KKT inverse M_i^-1 (nz x nzs doubles, 115 KB for nz = 120) is
-//            copied to LDS once and all K iterations run out of LDS: HBM traffic per instance-step is one read of M_i^-1
-//            (+ F'_i, V_i) instead of K reads.  The symmetric matrix is walked by columns (lane r reads M[c][r]: consecutive
-//            lanes, consecutive addresses, no bank conflict), the right-hand side is a broadcast read.
+//   k_admm_inst : ONE WORKGROUP PER INSTANCE AT A TIME (persistent workgroups).  The instance's KKT inverse M_i^-1 (nz x nzs
+//            doubles, 115 KB for nz = 120) is streamed from HBM once, straight into the registers of the workgroup's 512
+//            threads, and all K iterations run from there: HBM traffic per instance-step is one read of M_i^-1
+//            (+ F'_i, V_i) instead of K reads, and the stream of the next instance overlaps the iterations of the
+//            current one (second register set).
 //   polish / rollout : k_polish<false> with per-instance strides for G, d, A, B (almpc_kernels.hip.h).
 // Iteration formulas, termination test and outputs are those of k_admm (OSQP Algorithm 1, box form).
 #pragma once
@@ -36,162 +37,274 @@ struct AdmmInstParams {
     int max_iter, check_every, warm;
 };
 
-constexpr int ADMM_INST_THREADS = 256;  // two column halves x 128 rows
+#ifdef ALMPC_STAMPS
+#define ISTAMP(K) do { const int ord_ = (inst - (int)blockIdx.x) / (int)gridDim.x; if (ord_ >= 1 && ord_ < 3 && wv == 0) ALMPC_STAMP(blockIdx.x, (ord_ - 1) * 8 + (K)); } while (0)
+#else
+#define ISTAMP(K) do { } while (0)
+#endif
+constexpr int ADMM_INST_THREADS = 256;  // 4 waves, one per SIMD
+constexpr int ADMM_INST_PPW = 16;       // column PAIRS per wave, compile-time bound: nz <= 128 -> 64 pairs over 4 waves
 
-__global__ __launch_bounds__(ADMM_INST_THREADS) void k_admm_inst(AdmmInstParams p) {
+// Persistent workgroups, TWO per CU: workgroup b solves instances b, b + gridDim.x, ...
+// The KKT inverse of an instance never touches LDS.  Lane l owns the row pair (2l, 2l+1) and wave w the column pairs
+// (2j, 2j+1), j = w, w + 4, ...: the 30 x 16 bytes a thread needs are exactly what coalesced 16-byte-per-lane loads deliver
+// (1 KB per wave instruction), so the matrix streams HBM -> registers and stays there for all K iterations.  Issuing that
+// stream blocks the issuing waves for about as long as HBM takes to deliver it (the vector-memory queues fill up), so a
+// workgroup cannot overlap its own stream with its own iterations; the SECOND workgroup on the CU does: while one streams,
+// the other iterates.  Every wave carries the whole iterate redundantly (two rows per lane), so the right-hand side
+// entries of column pair j are two v_readlane pairs from lane j; only the 4 partial vectors of a product cross waves
+// (LDS, double buffered: ONE barrier per iteration).
+__global__ __launch_bounds__(ADMM_INST_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_admm_inst(AdmmInstParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int nz = p.nz, nzs = p.nzs, n = p.n;
-    const int inst = blockIdx.x;
-    double* M = smem;                       // [nz][nzs]
-    double* rhs0 = M + (size_t)nz * nzs;    // [nzs]
-    double* rhs1 = rhs0 + nzs;              // [nzs]
-    double* part = rhs1 + nzs;              // [2][nzs] partial products of the two column halves
-    double* red = part + 2 * nzs;           // [4 waves][8]
-    double* e0s = red + 32;                 // [n]
-    const int tid = threadIdx.x, r = tid & 127, half = tid >> 7, wv = tid >> 6;
-    const bool own = half == 0 && r < nz;   // this thread carries row r of the iterate
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, and the compiler knows it: column offsets stay scalar
+    constexpr int NW = ADMM_INST_THREADS / 64;  // 4 waves
+    constexpr int PPW = ADMM_INST_PPW;
+    constexpr int PFC = 4;                  // columns of F'_i / V_i per wave loaded with the matrix (n <= 16; more: separate loop)
+    double* part0 = smem;                   // [4][nzs] partial products of the waves (two buffers)
+    double* part1 = part0 + NW * nzs;
+    double* partv = part1 + NW * nzs;       // [4][nzs] V e0 partials (beside F' e0 in part0) at the start of an instance
+    double* e0s = partv + NW * nzs;         // [n <= 64]
+    double* bnd = e0s + 64;                 // [2 m] umin | umax
+    const int r0 = 2 * lane, r1 = 2 * lane + 1;
+    const bool inpair = r0 < nzs;           // nzs is even: both rows of the pair are inside the padded vector or neither
+    const int rc = inpair ? r0 : 0;
+    const bool own0 = r0 < nz, own1 = r1 < nz;
+    const int npairs = (nz + 1) / 2;
 
-    // ---- M_i^-1 -> LDS (16-byte copies, 8 in flight per thread)
-    {
-        const d2* src = reinterpret_cast<const d2*>(p.Minv + (size_t)inst * nz * nzs);
-        d2* dst = reinterpret_cast<d2*>(M);
-        const int cnt2 = nz * nzs / 2;
-        for (int i0 = tid; i0 < cnt2; i0 += ADMM_INST_THREADS * 8) {
-            d2 v[8];
+    for (int t = tid; t < p.m; t += ADMM_INST_THREADS) { bnd[t] = p.umin[t]; bnd[p.m + t] = p.umax[t]; }
+
+    for (int inst = blockIdx.x; inst < p.batch; inst += gridDim.x) {
+        // parameters re-read through an opaque kernarg pointer per instance: otherwise every instance-independent load is
+        // hoisted out of the persistent loop and the kernel spills (same measure as in k_polish)
+        auto ka_ = __builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka_));
+        const AdmmInstParams& q = *(const AdmmInstParams*)ka_;
+        ISTAMP(0);
+        // ---- one batch of loads: this wave's column pairs of M_i^-1, its columns of F'_i and V_i, the row constants, e0
+        d2 mcol[2 * PPW];
+        {
+            const double* Mi = GL(q.Minv) + (size_t)inst * nz * nzs;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int i = i0 + u * ADMM_INST_THREADS; v[u] = src[i < cnt2 ? i : 0]; }
+            for (int u = 0; u < PPW; ++u) {
+                const int j = wv + NW * u;                  // column pair (2j, 2j+1)
+                const int c0 = 2 * j < nz ? 2 * j : 0, c1 = 2 * j + 1 < nz ? 2 * j + 1 : 0;
+                mcol[2 * u] = *reinterpret_cast<const d2*>(Mi + (size_t)c0 * nzs + rc);
+                mcol[2 * u + 1] = *reinterpret_cast<const d2*>(Mi + (size_t)c1 * nzs + rc);
+            }
+        }
+        d2 cf[PFC], cv[PFC];
+        {
+            const double* Fi = GL(q.Fs) + (size_t)inst * n * nzs;
+            const double* Vi = GL(q.Vs) + (size_t)inst * n * nzs;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int i = i0 + u * ADMM_INST_THREADS; if (i < cnt2) dst[i] = v[u]; }
-        }
-    }
-    if (tid < n) e0s[tid] = p.x0[(size_t)inst * n + tid] - p.xref[(size_t)inst * p.xref_stride + tid];
-    __syncthreads();
-
-    // ---- per-row constants, f' = F' e0 + fS, v0 = V e0 + v0S
-    double dv = 1.0, dinv = 1.0, lo = 0.0, hi = 0.0, fs = 0.0, v0 = 0.0, rho = 1.0;
-    if (own) {
-        dv = p.dvec[(size_t)inst * nzs + r];
-        dinv = 1.0 / dv;
-        rho = p.rhovec[(size_t)inst * nzs + r];
-        const double ur = p.uref[(size_t)inst * p.uref_stride + r];
-        lo = (p.umin[r % p.m] - ur) * dinv;
-        hi = (p.umax[r % p.m] - ur) * dinv;
-        const double* Fi = p.Fs + (size_t)inst * n * nzs;
-        const double* Vi = p.Vs + (size_t)inst * n * nzs;
-        double af = p.fS[(size_t)inst * nz + r], av = p.v0S[(size_t)inst * nz + r];
-        for (int c = 0; c < n; ++c) {
-            const double e = e0s[c];
-            af += Fi[(size_t)c * nzs + r] * e;
-            av += Vi[(size_t)c * nzs + r] * e;
-        }
-        fs = af; v0 = av;
-    }
-    // |f/d|_inf (constant part of the dual tolerance)
-    auto block_max = [&](double v, int slot) -> double {
-        v = wave_max(v);
-        if ((tid & 63) == 0) red[wv * 8 + slot] = v;
-        __syncthreads();
-        const double o = fmax(fmax(red[0 * 8 + slot], red[1 * 8 + slot]), fmax(red[2 * 8 + slot], red[3 * 8 + slot]));
-        __syncthreads();
-        return o;
-    };
-    const double nf = block_max(own ? fabs(fs * dinv) : 0.0, 0);
-
-    // ---- initial iterate (yt = y / rho_r)
-    double x = 0.0, z = 0.0, yt = 0.0, px = 0.0;
-    const double sigma = p.sigma, alpha = p.alpha;
-    if (p.warm) {
-        if (own) {
-            const size_t o = (size_t)inst * nzs + r;
-            x = p.xs[o];
-            yt = p.ys[o] / rho;
-            z = fmin(fmax(p.zs[o], lo), hi);
-        }
-        if (half == 0) rhs0[r] = own ? x : 0.0;
-        __syncthreads();
-        if (own) {  // px = H'_i x: one product with the instance's scaled Hessian, read by columns from global memory
-            const double* Hi = p.Hs + (size_t)inst * nz * nzs;
-            double a = 0.0;
-            for (int c = 0; c < nz; ++c) a += Hi[(size_t)c * nzs + r] * rhs0[c];
-            px = a;
-        }
-        __syncthreads();
-    }
-    double rown = sigma * x - fs + rho * (z - yt);
-    if (half == 0 && r < nzs) rhs0[r] = own ? rown : 0.0;
-    __syncthreads();
-
-    bool active = true;
-    int my_iters = p.max_iter, my_status = 1;
-    double* cur = rhs0;
-    double* nxt = rhs1;
-    const int c_lo = half == 0 ? 0 : nz / 2, c_hi = half == 0 ? nz / 2 : nz;
-    const int rr = r < nzs ? r : 0;
-    for (int it = 1; it <= p.max_iter; ++it) {
-        {   // this half's share of row r of M_i^-1 rhs (M symmetric: column walk)
-            double a0 = 0.0, a1 = 0.0;
-            int c = c_lo;
-            for (; c + 1 < c_hi; c += 2) {
-                a0 += M[(size_t)c * nzs + rr] * cur[c];
-                a1 += M[(size_t)(c + 1) * nzs + rr] * cur[c + 1];
+            for (int u = 0; u < PFC; ++u) {
+                const int c = wv + NW * u;
+                const int cc = c < n ? c : 0;
+                cf[u] = *reinterpret_cast<const d2*>(Fi + (size_t)cc * nzs + rc);
+                cv[u] = *reinterpret_cast<const d2*>(Vi + (size_t)cc * nzs + rc);
             }
-            if (c < c_hi) a0 += M[(size_t)c * nzs + rr] * cur[c];
-            if (r < nzs) part[half * nzs + r] = a0 + a1;
         }
-        __syncthreads();
-        if (own) {
-            const double xt = part[r] + part[nzs + r];
-            if (active) {
-                const double hxt = rown - (sigma + rho) * xt;  // H' xt, from the KKT identity
-                px = alpha * hxt + (1.0 - alpha) * px;
-                x = alpha * xt + (1.0 - alpha) * x;
-                const double w = alpha * xt + (1.0 - alpha) * z + yt;
-                const double zn = fmin(fmax(w, lo), hi);
-                yt = w - zn;
-                z = zn;
-                rown = sigma * x - fs + rho * (z - yt);
-            }
-            nxt[r] = rown;
+        const int ra = own0 ? r0 : 0, rb = own1 ? r1 : 0;
+        const d2 pdd = *reinterpret_cast<const d2*>(GL(q.dvec) + (size_t)inst * nzs + rc);
+        const d2 prh = *reinterpret_cast<const d2*>(GL(q.rhovec) + (size_t)inst * nzs + rc);
+        const double ur0 = GL(q.uref)[(size_t)inst * q.uref_stride + ra], ur1 = GL(q.uref)[(size_t)inst * q.uref_stride + rb];
+        const double fS0 = GL(q.fS)[(size_t)inst * nz + ra], fS1 = GL(q.fS)[(size_t)inst * nz + rb];
+        const double vS0 = GL(q.v0S)[(size_t)inst * nz + ra], vS1 = GL(q.v0S)[(size_t)inst * nz + rb];
+        lds_barrier();  // the previous instance is done with the LDS vectors
+        if (tid < n) e0s[tid] = GL(q.x0)[(size_t)inst * n + tid] - GL(q.xref)[(size_t)inst * q.xref_stride + tid];
+        double dv[2], lo[2], hi[2], fs[2], v0[2], rho[2];
+        {
+            const double di0 = 1.0 / (own0 ? pdd[0] : 1.0), di1 = 1.0 / (own1 ? pdd[1] : 1.0);
+            dv[0] = own0 ? pdd[0] : 1.0; dv[1] = own1 ? pdd[1] : 1.0;
+            rho[0] = own0 ? prh[0] : 1.0; rho[1] = own1 ? prh[1] : 1.0;
+            lo[0] = own0 ? (bnd[ra % q.m] - ur0) * di0 : 0.0; hi[0] = own0 ? (bnd[q.m + ra % q.m] - ur0) * di0 : 0.0;
+            lo[1] = own1 ? (bnd[rb % q.m] - ur1) * di1 : 0.0; hi[1] = own1 ? (bnd[q.m + rb % q.m] - ur1) * di1 : 0.0;
+            fs[0] = own0 ? fS0 : 0.0; fs[1] = own1 ? fS1 : 0.0;   // + F' e0 below
+            v0[0] = own0 ? vS0 : 0.0; v0[1] = own1 ? vS1 : 0.0;   // + V e0 below
         }
-        const bool check = (it % p.check_every == 0) || (it == p.max_iter);
-        if (check) {  // block-uniform branch
-            const double yi = rho * yt;
-            const double rp = block_max(own ? fabs(dv * (x - z)) : 0.0, 0);
-            const double nx = block_max(own ? fabs(dv * x) : 0.0, 1);
-            const double nzn = block_max(own ? fabs(dv * z) : 0.0, 2);
-            const double rd = block_max(own ? fabs((px + fs + yi) * dinv) : 0.0, 3);
-            const double nhx = block_max(own ? fabs(px * dinv) : 0.0, 4);
-            const double ny = block_max(own ? fabs(yi * dinv) : 0.0, 5);
-            const double s = x + yi + px;
-            const double bad = block_max((own && !(fabs(s) <= 1.79e308)) ? 1.0 : 0.0, 6);
-            if (active) {
-                const bool conv = (rp <= p.eps_abs + p.eps_rel * fmax(nx, nzn)) &&
-                                  (rd <= p.eps_abs + p.eps_rel * fmax(fmax(nhx, ny), nf));
-                if (bad > 0.0) { active = false; my_iters = it; my_status = 2; }
-                else if (conv) { active = false; my_iters = it; my_status = 0; }
-            }
-            if (!active) break;  // block-uniform: every thread saw the same reduced values
-        } else {
-            __syncthreads();
-        }
-        double* t = cur; cur = nxt; nxt = t;
-    }
+        lds_barrier();
+        ISTAMP(1);
 
-    // ---- hand-off to the polish: same arrays as k_admm
-    if (tid == 0) {
-        p.iters[inst] = my_iters;
-        p.status[inst] = my_status;
-        p.piters[inst] = 0;
-        p.overflow[inst] = 0;
-        p.perm[inst] = inst;  // no ranking across instances here: processing order = instance order
+        // ---- f' = F' e0 + fS, v0 = V e0 + v0S: wave w multiplies columns w, w + 4, ...
+        {
+            d2 af = {0.0, 0.0}, av = {0.0, 0.0};
+#pragma unroll
+            for (int u = 0; u < PFC; ++u)
+                if (wv + NW * u < n) { const double e = e0s[wv + NW * u]; af += cf[u] * e; av += cv[u] * e; }
+            if (n > PFC * NW) {  // wide state vectors: the remaining columns
+                const double* Fi = GL(q.Fs) + (size_t)inst * n * nzs;
+                const double* Vi = GL(q.Vs) + (size_t)inst * n * nzs;
+                for (int c = wv + PFC * NW; c < n; c += NW) {
+                    const double e = e0s[c];
+                    af += *reinterpret_cast<const d2*>(Fi + (size_t)c * nzs + rc) * e;
+                    av += *reinterpret_cast<const d2*>(Vi + (size_t)c * nzs + rc) * e;
+                }
+            }
+            if (inpair) {
+                *reinterpret_cast<d2*>(part0 + wv * nzs + rc) = af;
+                *reinterpret_cast<d2*>(partv + wv * nzs + rc) = av;
+            }
+        }
+        lds_barrier();
+        {
+            d2 af = {0.0, 0.0}, av = {0.0, 0.0};
+            if (inpair) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    af += *reinterpret_cast<const d2*>(part0 + w * nzs + rc);
+                    av += *reinterpret_cast<const d2*>(partv + w * nzs + rc);
+                }
+            }
+            if (own0) { fs[0] += af[0]; v0[0] += av[0]; }
+            if (own1) { fs[1] += af[1]; v0[1] += av[1]; }
+        }
+        ISTAMP(2);
+        const double nf = wave_max(fmax(fabs(fs[0] / dv[0]), fabs(fs[1] / dv[1])));  // |f/d|_inf (pad rows contribute 0)
+
+        // ---- initial iterate (yt = y / rho_r); every wave holds all of it
+        double x[2] = {0, 0}, z[2] = {0, 0}, yt[2] = {0, 0}, px[2] = {0, 0}, rown[2];
+        const double sigma = q.sigma, alpha = q.alpha;
+        if (q.warm) {
+            if (inpair) {
+                const size_t o = (size_t)inst * nzs + rc;
+                const d2 xx = *reinterpret_cast<const d2*>(GL(q.xs) + o), yy = *reinterpret_cast<const d2*>(GL(q.ys) + o),
+                         zz = *reinterpret_cast<const d2*>(GL(q.zs) + o);
+                if (own0) { x[0] = xx[0]; yt[0] = yy[0] / rho[0]; z[0] = fmin(fmax(zz[0], lo[0]), hi[0]); }
+                if (own1) { x[1] = xx[1]; yt[1] = yy[1] / rho[1]; z[1] = fmin(fmax(zz[1], lo[1]), hi[1]); }
+            }
+            // px = H'_i x: one product with the instance's scaled Hessian (global memory, this wave's column pairs), summed
+            // like the iteration's product below
+            d2 a = {0.0, 0.0};
+            const double* Hi = GL(q.Hs) + (size_t)inst * nz * nzs;
+            for (int j = wv; j < npairs; j += NW) {
+                const double s0 = readlane_d(x[0], j), s1 = readlane_d(x[1], j);
+                a += *reinterpret_cast<const d2*>(Hi + (size_t)(2 * j) * nzs + rc) * s0;
+                if (2 * j + 1 < nz) a += *reinterpret_cast<const d2*>(Hi + (size_t)(2 * j + 1) * nzs + rc) * s1;
+            }
+            lds_barrier();  // part0 was read above
+            if (inpair) *reinterpret_cast<d2*>(part0 + wv * nzs + rc) = a;
+            lds_barrier();
+            d2 sum = {0.0, 0.0};
+            if (inpair) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) sum += *reinterpret_cast<const d2*>(part0 + w * nzs + rc);
+            }
+            px[0] = own0 ? sum[0] : 0.0; px[1] = own1 ? sum[1] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) rown[j] = sigma * x[j] - fs[j] + rho[j] * (z[j] - yt[j]);  // pad rows: 0
+        lds_barrier();  // the partial buffers are free again
+        ISTAMP(3);
+        ISTAMP(4);
+        bool active = true;
+        int my_iters = q.max_iter, my_status = 1;
+        double* pc = part0;
+        double* pn = part1;
+#pragma unroll 1
+        for (int it = 1; it <= q.max_iter; ++it) {
+            {   // wave w: column pairs j = w, w + 4, ... of M_i^-1 (registers) times (rhs[2j], rhs[2j+1]) = the two components of lane j
+                d2 acc0 = {0.0, 0.0}, acc1 = {0.0, 0.0};
+#pragma unroll
+                for (int u = 0; u < PPW; ++u) {
+                    const int j = wv + NW * u;
+                    if (j < npairs) {  // wave-uniform
+                        const double s0 = readlane_d(rown[0], j), s1 = readlane_d(rown[1], j);  // rhs of a pad row is 0
+                        acc0 += mcol[2 * u] * s0;
+                        acc1 += mcol[2 * u + 1] * s1;
+                    }
+                }
+                if (inpair) *reinterpret_cast<d2*>(pc + wv * nzs + rc) = acc0 + acc1;
+            }
+            lds_barrier();
+            {
+                d2 xt2 = {0.0, 0.0};
+                if (inpair) {
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) xt2 += *reinterpret_cast<const d2*>(pc + w * nzs + rc);
+                }
+                if (active) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const double xt = xt2[j];
+                        const double hxt = rown[j] - (sigma + rho[j]) * xt;  // H' xt, from the KKT identity
+                        px[j] = alpha * hxt + (1.0 - alpha) * px[j];
+                        x[j] = alpha * xt + (1.0 - alpha) * x[j];
+                        const double w = alpha * xt + (1.0 - alpha) * z[j] + yt[j];
+                        const double zn = fmin(fmax(w, lo[j]), hi[j]);
+                        yt[j] = w - zn;
+                        z[j] = zn;
+                        const bool own = j == 0 ? own0 : own1;
+                        rown[j] = own ? sigma * x[j] - fs[j] + rho[j] * (z[j] - yt[j]) : 0.0;
+                    }
+                }
+            }
+            { double* t = pc; pc = pn; pn = t; }
+            const bool check = (it % q.check_every == 0) || (it == q.max_iter);
+            if (check) {  // every wave holds the whole iterate: wave-local reductions, no LDS
+                double t_rp = 0, t_x = 0, t_z = 0, t_rd = 0, t_hx = 0, t_y = 0, t_bad = 0;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bool own = j == 0 ? own0 : own1;
+                    if (!own) continue;
+                    const double yi = rho[j] * yt[j], di = 1.0 / dv[j];
+                    t_rp = fmax(t_rp, fabs(dv[j] * (x[j] - z[j])));
+                    t_x = fmax(t_x, fabs(dv[j] * x[j]));
+                    t_z = fmax(t_z, fabs(dv[j] * z[j]));
+                    t_rd = fmax(t_rd, fabs((px[j] + fs[j] + yi) * di));
+                    t_hx = fmax(t_hx, fabs(px[j] * di));
+                    t_y = fmax(t_y, fabs(yi * di));
+                    const double s = x[j] + yi + px[j];
+                    if (!(fabs(s) <= 1.79e308)) t_bad = 1.0;
+                }
+                const double rp = wave_max(t_rp);
+                __builtin_amdgcn_sched_barrier(0);  // one DPP chain after the other: interleaved they cost ~50 registers
+                const double nx = wave_max(t_x);
+                __builtin_amdgcn_sched_barrier(0);
+                const double nzn = wave_max(t_z);
+                __builtin_amdgcn_sched_barrier(0);
+                const double rd = wave_max(t_rd);
+                __builtin_amdgcn_sched_barrier(0);
+                const double nhx = wave_max(t_hx);
+                __builtin_amdgcn_sched_barrier(0);
+                const double ny = wave_max(t_y);
+                __builtin_amdgcn_sched_barrier(0);
+                const double bad = wave_max(t_bad);
+                if (active) {
+                    const bool conv = (rp <= q.eps_abs + q.eps_rel * fmax(nx, nzn)) &&
+                                      (rd <= q.eps_abs + q.eps_rel * fmax(fmax(nhx, ny), nf));
+                    if (bad > 0.0) { active = false; my_iters = it; my_status = 2; }
+                    else if (conv) { active = false; my_iters = it; my_status = 0; }
+                }
+                if (!active) break;  // identical in every wave: all of them reduced the same values in the same order
+            }
+        }
+
+        ISTAMP(5);
+        // ---- hand-off to the polish: same arrays as k_admm (wave 0 writes)
+        if (tid == 0) {
+            GL(q.iters)[inst] = my_iters;
+            GL(q.status)[inst] = my_status;
+            GL(q.piters)[inst] = 0;
+            GL(q.overflow)[inst] = 0;
+            GL(q.perm)[inst] = inst;  // no ranking across instances here: processing order = instance order
+        }
+        if (wv == 0 && inpair) {
+            const size_t o = (size_t)inst * nzs + rc;
+            d2 a, b, c, d;
+            a[0] = own0 ? x[0] : 0.0; a[1] = own1 ? x[1] : 0.0;
+            b[0] = own0 ? z[0] : 0.0; b[1] = own1 ? z[1] : 0.0;
+            c[0] = own0 ? rho[0] * yt[0] : 0.0; c[1] = own1 ? rho[1] * yt[1] : 0.0;
+            d[0] = own0 ? v0[0] : 0.0; d[1] = own1 ? v0[1] : 0.0;
+            *reinterpret_cast<d2*>(GL(q.xs) + o) = a;
+            *reinterpret_cast<d2*>(GL(q.zs) + o) = b;
+            *reinterpret_cast<d2*>(GL(q.ys) + o) = c;
+            *reinterpret_cast<d2*>(GL(q.v0) + o) = d;
+        }
+        ISTAMP(6);
     }
-    if (half == 0 && r < nzs) {
-        const size_t o = (size_t)inst * nzs + r;
-        p.xs[o] = own ? x : 0.0;
-        p.zs[o] = own ? z : 0.0;
-        p.ys[o] = own ? rho * yt : 0.0;
-        p.v0[o] = own ? v0 : 0.0;
-    }
+#undef ISTAMP
 }
 
 // fS_i = d_i .* g: the constant part of the scaled gradient (g = 2 D'Sbar D u_ref, shared or per instance) for every instance

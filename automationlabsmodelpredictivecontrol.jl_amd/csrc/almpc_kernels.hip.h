@@ -472,6 +472,14 @@ __device__ __forceinline__ double half_sum(double v) {
     return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
 }
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding GLOBAL load (vmcnt(0)),
+// which would make a barrier in a compute phase wait for data that was deliberately requested early.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // generic -> global -> generic: tells the optimiser that a pointer it cannot trace back to the kernel arguments is a
 // global one (global_load instead of flat_load, which would also tie up the LDS wait counter)
 template <class T>
