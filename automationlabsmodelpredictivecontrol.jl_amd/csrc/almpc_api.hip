@@ -404,7 +404,7 @@ int almpc_design_batched(almpc_handle* h, const double* A_batch, const double* B
     hipLaunchKernelGGL(k_design_hessian, dim3(nrb, gb), dim3(64 * (nrb + njf)), hess_lds, st, hp);
     hipLaunchKernelGGL(k_design_scale, dim3(1, gb), dim3(256), 0, st, nz, nzs, n, h->bH, h->bF, h->bD, h->bHs, h->bFs, h->bFlag, ds);
     BTRY(hipGetLastError());
-    const size_t inv_lds = ((size_t)nz * (nz + 1) + nz + 2) * sizeof(double);
+    const size_t inv_lds = 520 * sizeof(double);
     BTRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_design_inverse), hipFuncAttributeMaxDynamicSharedMemorySize, (int)inv_lds));
     hipLaunchKernelGGL(k_design_inverse, dim3(1, gb), dim3(512), inv_lds, st, nz, nzs, h->bHs, 0.0, (const double*)nullptr, h->bG, h->bFlag,
                        ds.Hs, 0L, ds.G, 1L);

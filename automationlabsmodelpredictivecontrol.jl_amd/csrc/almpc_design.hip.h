@@ -202,59 +202,65 @@ __global__ __launch_bounds__(256) void k_design_scale(int nz, int nzs, int n, co
     }
 }
 
-// ---- K5: Minv = (Hs + c I)^-1 -------------------------------------------------------------------------
-// One workgroup, matrix in LDS (ld = nz+1 to spread banks).  Cholesky (right-looking), in-place inverse of
-// the triangular factor, then X'X.  flag[0] != 0 if a pivot is not positive.
+// ---- K5: Out = (Hs + c I + diag(dshift))^-1 ----------------------------------------------------------------
+// One workgroup per matrix, the matrix in REGISTERS: thread (row i = tid & 127, column group g = tid >> 7) holds
+// S[i][32 g .. 32 g + 31].  In-place Gauss-Jordan sweeps without pivoting (SPD: every pivot is a Schur-complement diagonal,
+// positive; flag[0] = 2 otherwise).  Per pivot the owners publish the pivot column and row through LDS (double buffered:
+// one barrier per pivot), everything else is 32 register FMAs per thread.  nz <= 128.
 __global__ __launch_bounds__(512) void k_design_inverse(int nz, int nzs, const double* Hs, double cshift, const double* dshift,
                                                         double* Out, int* flag, long sHs, long sShift, long sOut, long sFlag) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     Hs += blockIdx.y * sHs; Out += blockIdx.y * sOut; flag += blockIdx.y * sFlag;
     if (dshift) dshift += blockIdx.y * sShift;
-    const int ld = nz + 1;
-    double* L = smem;         // [nz][ld], element (i,j) at L[j*ld + i]
-    double* xo = L + (size_t)nz * ld;  // [nz] scratch column
-    int* badp = reinterpret_cast<int*>(xo + nz);  // in the dynamic region: a static __shared__ would misalign it
+    double* prow = smem;            // [2][128] pivot row (raw)
+    double* pcol = smem + 256;      // [2][128] pivot column
+    int* badp = reinterpret_cast<int*>(smem + 512);
+    const int i = threadIdx.x & 127, g = threadIdx.x >> 7;
     if (threadIdx.x == 0) *badp = 0;
-    for (int t = threadIdx.x; t < nz * nz; t += blockDim.x) {
-        const int i = t % nz, j = t / nz;
-        L[j * ld + i] = Hs[(size_t)j * nzs + i] + (i == j ? cshift + (dshift ? dshift[i] : 0.0) : 0.0);
+    double S[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        const int c = 32 * g + k;
+        double v = 0.0;
+        if (i < nz && c < nz) v = Hs[(size_t)c * nzs + i] + (i == c ? cshift + (dshift ? dshift[i] : 0.0) : 0.0);
+        S[k] = v;
     }
-    __syncthreads();
-    for (int j = 0; j < nz; ++j) {
-        const double piv = L[j * ld + j];
-        if (!(piv > 0.0)) { if (threadIdx.x == 0) *badp = 1; }
-        const double ljj = sqrt(piv > 0.0 ? piv : 1.0);
-        __syncthreads();
-        for (int i = j + threadIdx.x; i < nz; i += blockDim.x) L[j * ld + i] = (i == j) ? ljj : L[j * ld + i] / ljj;
-        __syncthreads();
-        const int rem = nz - j - 1;
-        for (int t = threadIdx.x; t < rem * rem; t += blockDim.x) {
-            const int i = j + 1 + t % rem, k = j + 1 + t / rem;
-            if (i >= k) L[k * ld + i] -= L[j * ld + i] * L[j * ld + k];
+    for (int gp = 0; gp < 4; ++gp) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const int pv = 32 * gp + k;
+            if (pv < nz) {  // uniform
+                double* pr = prow + (pv & 1) * 128;
+                double* pc = pcol + (pv & 1) * 128;
+                if (g == gp) pc[i] = S[k];  // column pv, every row
+                if (i == pv) {              // row pv, this group's 32 columns
+#pragma unroll
+                    for (int kk = 0; kk < 32; kk += 2) {
+                        d2 w; w[0] = S[kk]; w[1] = S[kk + 1];
+                        *reinterpret_cast<d2*>(pr + 32 * g + kk) = w;
+                    }
+                }
+                __syncthreads();
+                const double piv = pr[pv];
+                if (!(piv > 0.0) && threadIdx.x == 0) *badp = 1;
+                const double ip = 1.0 / (piv > 0.0 ? piv : 1.0);
+                const bool isp = i == pv;
+                const double f = isp ? 0.0 : pc[i] * ip;   // the pivot row itself is rescaled, not eliminated
+                const double scale = isp ? ip : 1.0;
+#pragma unroll
+                for (int kk = 0; kk < 32; kk += 2) {
+                    const d2 w = *reinterpret_cast<const d2*>(pr + 32 * g + kk);
+                    S[kk] = __builtin_fma(-f, w[0], S[kk]) * scale;
+                    S[kk + 1] = __builtin_fma(-f, w[1], S[kk + 1]) * scale;
+                }
+                if (g == gp) S[k] = isp ? ip : -f;  // column pv
+            }
         }
-        __syncthreads();
     }
-    // in-place inverse of the lower-triangular factor (unblocked dtrti2, lower): columns right to left
-    for (int j = nz - 1; j >= 0; --j) {
-        const double ajj = 1.0 / L[j * ld + j];
-        // x := T x with T = already inverted trailing block, x = L[j+1:, j]
-        for (int i = j + 1 + threadIdx.x; i < nz; i += blockDim.x) {
-            double s = 0.0;
-            for (int k = j + 1; k <= i; ++k) s += L[k * ld + i] * L[j * ld + k];
-            xo[i] = -s * ajj;
-        }
-        __syncthreads();
-        for (int i = j + threadIdx.x; i < nz; i += blockDim.x) L[j * ld + i] = (i == j) ? ajj : xo[i];
-        __syncthreads();
-    }
-    // Out = X'X, X = L^-1 (lower): Out[i][j] = sum_{k >= max(i,j)} X[k][i] X[k][j]
-    for (int t = threadIdx.x; t < nz * nz; t += blockDim.x) {
-        const int i = t % nz, j = t / nz;
-        if (i < j) continue;
-        double s = 0.0;
-        for (int k = i; k < nz; ++k) s += L[i * ld + k] * L[j * ld + k];
-        Out[(size_t)j * nzs + i] = s;
-        Out[(size_t)i * nzs + j] = s;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        const int c = 32 * g + k;
+        if (i < nz && c < nz) Out[(size_t)c * nzs + i] = S[k];
     }
     __syncthreads();
     if (threadIdx.x == 0 && *badp) atomicExch(flag, 2);
@@ -288,10 +294,9 @@ __global__ __launch_bounds__(256) void k_neg_gm(int nz, int nzs, int ncols, int 
     G += blockIdx.y * sG; M += blockIdx.y * sM; Out += blockIdx.y * sM;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < (long)ncols * nz; t += (long)gridDim.x * blockDim.x) {
         const int c = (int)(t / nz), r = (int)(t % nz);
-        const double* g = G + (size_t)r * nzs;
         const double* mcol = M + (size_t)c * ld;
         double acc = 0.0;
-        for (int j = 0; j < nz; ++j) acc += g[j] * mcol[j];
+        for (int j = 0; j < nz; ++j) acc += G[(size_t)j * nzs + r] * mcol[j];  // G symmetric: consecutive r, consecutive addresses
         Out[(size_t)c * ld + r] = -acc;
     }
 }
@@ -403,7 +408,7 @@ inline int design_shared_device(hipStream_t stream, int n, int m, int N, int nzs
     DTRY(hipGetLastError());
     hipLaunchKernelGGL(k_design_scale, dim3(1), dim3(256), 0, stream, nz, nzs, n, dH, dF, dD, dHs, dFs, dFlag, DesignStrides());
     DTRY(hipGetLastError());
-    const size_t inv_lds = ((size_t)nz * (nz + 1) + nz + 2) * sizeof(double);
+    const size_t inv_lds = 520 * sizeof(double);
     DTRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_design_inverse), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)inv_lds));
     // G = H'^-1 first: the stiffness profile of the ADMM penalty (rho_i = rho / G_ii) is read off its diagonal

@@ -169,7 +169,13 @@ def test_config4_relinearised_fnn_per_instance(capi, mo):
         p = mo.make_problem(Ai, Bi, N, [-1, -1], [1, 1], x_ref=x_ref, u_ref=u_ref)
         e = mo.solve_mpc_exact(p, X0[i])
         if r["status"][i] == 0:
-            assert np.abs(r["u"][i] - e["u"]).max() <= U_TOL and np.abs(r["x"][i] - e["x"]).max() <= X_TOL
+            assert np.abs(r["u"][i] - e["u"]).max() <= U_TOL
+            # x is the rollout of u through (A_i, B_i): compared directly where the linearisation is stable; an unstable one
+            # amplifies a 1e-7 difference in u by rho(A_i)^N, so there the rollout identity is checked on the GPU's own u
+            if np.max(np.abs(np.linalg.eigvals(Ai))) <= 1.0:
+                assert np.abs(r["x"][i] - e["x"]).max() <= X_TOL
+            ex = mo.rollout(p, X0[i], (r["u"][i] - p.u_ref).T.reshape(-1))["x"]
+            assert np.abs(r["x"][i] - ex).max() <= 1e-9 * max(1.0, np.abs(ex).max())
         nact += ((e["u"] <= -1) | (e["u"] >= 1)).sum()
     assert nact > 50
 
