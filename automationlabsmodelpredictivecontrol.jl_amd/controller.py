@@ -165,6 +165,7 @@ class HipModeler:
 
     def __init__(self, solver: _capi.Solver, opts: _capi.almpc_opts, batch: int):
         self.solver, self.opts, self.batch = solver, opts, batch
+        self.relinearize = None  # dict for mpc_linearization='step' (black-box models), see _design_blackbox
 
 
 def _design_reference_mpc(state_reference, input_reference, horizon: int) -> ReferencesStateInput:
@@ -205,8 +206,16 @@ def _design_blackbox(system: ConstrainedBlackBoxControlDiscreteSystem, horizon: 
                      references: ReferencesStateInput, **kws_):
     """Black-box (Fnn) model, LinearProgramming branch (src/sub/design_mpc.jl:143-225 ->
     .../fnn/mpc_modeler_implementation_fnn.jl:23-58): dynamics linearised at the FIRST reference, terminal weight
-    P = DARE at the linearisation about the LAST reference (src/sub/design_mpc.jl:312-327), then the linear path."""
+    P = DARE at the linearisation about the LAST reference (src/sub/design_mpc.jl:312-327), then the linear path.
+
+    Extension of this build (BASELINE.json configs[3]), kw mpc_linearization = "step": the dynamics are re-linearised at every
+    instance's own current state (and the first input reference) in update_initialization!, each instance gets the
+    reference's QP for its own (A_i, B_i) (almpc_design_batched); P stays the design-time terminal weight.  The default
+    "reference" is the reference's behaviour: one linearisation at design time, shared by the batch."""
     kws = _kws(kws_)
+    lin_mode = kws.get("mpc_linearization", "reference")
+    if lin_mode not in ("reference", "step"):
+        raise ValueError("mpc_linearization must be 'reference' or 'step'")
     if not isinstance(system.f, Fnn):
         raise NotImplementedError("only the Fnn model family is built (SURVEY.md section 2, components 8-14 are out of scope)")
     dev = int(kws.get("mpc_device", 0))
@@ -217,6 +226,14 @@ def _design_blackbox(system: ConstrainedBlackBoxControlDiscreteSystem, horizon: 
     P = _capi.dare(lin_last.A, lin_last.B, weights.Q, weights.R)
     C = _design_linear(lin_first, horizon, sample_time, references, kws=kws, _terminal_P=P)
     C.system = system
+    if lin_mode == "step":
+        if "mpc_state_constraint" in kws or kws.get("mpc_terminal_ingredient", "none") == "equality":
+            raise NotImplementedError("mpc_linearization='step' (per-instance models) has no state rows")
+        mod = C.tuning.modeler
+        sopt = dict(kws.get("mpc_solver_options", {}))
+        mod.relinearize = dict(system=system, device=dev, weights=weights, P=np.array(P), references=references,
+                               rho=float(sopt.get("rho", 0.1)), sigma=float(sopt.get("sigma", 1e-6)),
+                               rho_profile=kws.get("mpc_rho_profile", "scalar"))
     return C
 
 
@@ -262,7 +279,8 @@ def _design_linear(system: ConstrainedLinearControlDiscreteSystem, horizon: int,
     # (..linear.jl:34-38); P = DARE at the (linear) system (src/sub/design_mpc.jl:327), computed in the library.
     solver.design_shared(system.A, system.B, weights.Q, weights.R, weights.S, _terminal_P, system.U.low, system.U.high,
                          xmin=system.X.low if state_box else None, xmax=system.X.high if state_box else None,
-                         rho=rho, sigma=sigma, terminal="equality" if terminal == "equality" else "none")
+                         rho=rho, sigma=sigma, terminal="equality" if terminal == "equality" else "none",
+                         rho_profile=kws.get("mpc_rho_profile", "scalar"))
     solver.set_reference(x_ref, u_ref)
     P = solver.get_design()["P"]
     opts = _capi.default_opts(**sopt)
@@ -282,6 +300,15 @@ def update_initialization(C: ModelPredictiveControlController, initialization) -
     if x0.size != mod.batch * n:
         raise ValueError(f"initialization must hold {mod.batch} x {n} values")
     C.initialization = x0.reshape((n,) if mod.batch == 1 else (mod.batch, n)).copy()
+    rl = getattr(mod, "relinearize", None)
+    if rl is not None:  # mpc_linearization='step': Jacobians at (x0_i, u_ref[:,1]) -> one QP design per instance
+        f = rl["system"].f
+        u0 = np.repeat(np.asarray(rl["references"].u, dtype=np.float64)[:, 0][None, :], mod.batch, 0)
+        A, B = _capi.fnn_linearize(f.W_in, f.W_h, f.b_h, f.W_out, x0.reshape(mod.batch, n), u0, act=f.act, device=rl["device"])
+        w = rl["weights"]
+        mod.solver.design_batched(A, B, w.Q, w.R, w.S, rl["P"], rl["system"].U.low, rl["system"].U.high,
+                                  rho=rl["rho"], sigma=rl["sigma"], rho_profile=rl["rho_profile"])
+        mod.solver.set_reference(rl["references"].x, rl["references"].u)
     mod.solver.update_initialization(x0.reshape(mod.batch, n))
 
 

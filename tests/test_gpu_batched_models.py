@@ -202,3 +202,29 @@ def test_batched_error_behaviour(capi, mo):
         sv.design_batched(Abad, B, p.Q, p.R, None, p.P, p.u_min, p.u_max)
     assert ei.value.code == -6 and "instance 2" in str(ei.value)
     sv.close()
+
+
+def test_mirror_relinearises_every_step(pkg, capi, mo):
+    """Host mirror, kw mpc_linearization='step': update_initialization! re-linearises the Fnn model at every instance's own state,
+    calculate! solves each instance's own QP.  The default ('reference') stays the reference's single linearisation."""
+    f = mo.synthetic_fnn()
+    sys_ = pkg.ConstrainedBlackBoxControlDiscreteSystem(pkg.Fnn(f.W_in, f.W_h, f.b_h, f.W_out, f.act), 4, 2,
+                                                        pkg.Hyperrectangle([-10] * 4, [10] * 4), pkg.Hyperrectangle([-1, -1], [1, 1]))
+    x_ref, u_ref = [0.2, -0.1, 0.05, 0.0], [0.1, -0.2]
+    batch, N = 64, 20
+    C = pkg.proceed_controller(sys_, "model_predictive_control", N, 1, x_ref, u_ref, mpc_batch=batch, mpc_linearization="step")
+    P = C.tuning.terminal_ingredient.P
+    X0 = np.asarray(x_ref)[None, :] + mo.splitmix_normal(0x5EED0004, 100, batch, 4)
+    for step in range(2):   # two consecutive steps from different states: a new design each time
+        res = pkg._model_predictive_control_computation(C, X0 * (1.0 + 0.5 * step))
+        st = C.tuning.modeler.last_status
+        for i in range(0, batch, 5):
+            Ai, Bi = f.jacobian(X0[i] * (1.0 + 0.5 * step), np.asarray(u_ref))
+            p = mo.make_problem(Ai, Bi, N, [-1, -1], [1, 1], x_ref=np.asarray(x_ref), u_ref=np.asarray(u_ref), P=P)
+            e = mo.solve_mpc_exact(p, X0[i] * (1.0 + 0.5 * step))
+            if st[i] == 0:
+                assert np.abs(res.u[i] - e["u"]).max() <= U_TOL
+        assert (st == 0).mean() >= 0.95
+    C.tuning.modeler.solver.close()
+    with pytest.raises(ValueError):
+        pkg.proceed_controller(sys_, "model_predictive_control", N, 1, x_ref, u_ref, mpc_linearization="sometimes")
