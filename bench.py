@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--no-classes", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true")
     ap.add_argument("--no-closed-loop", action="store_true")
+    ap.add_argument("--no-batched-models", action="store_true", help="skip the secondary per-instance-model figure")
     args = ap.parse_args()
 
     import almpc_loader
@@ -235,6 +236,47 @@ def main():
             el = max_over_ranks(time_steps(solver, opts, k, barrier))
             cls[str(s_)] = world * k / el
         out["classes"] = {"unit": "batch-steps/s", **cls}
+
+    if rank == 0 and world == 1 and not args.no_batched_models:
+        # Secondary figure: the per-instance-model regime (SURVEY.md section 8d "per-instance-model regime", BASELINE configs[3]
+        # at the headline shape): every instance has its own (A_i, B_i) -> its own KKT inverse, which k_admm_inst streams from
+        # HBM once per step.  This is the regime where the HBM roofline is the binding one.
+        rng = np.random.default_rng(0)
+        Ab = np.repeat(p.A[None], BATCH_PER_GPU, 0)
+        Bb = np.repeat(p.B[None], BATCH_PER_GPU, 0) * (1.0 + 0.05 * rng.standard_normal((BATCH_PER_GPU, 1, 1)))
+        sb = capi.Solver(NX, NU, N_HORIZON, BATCH_PER_GPU, device=dev_index, timing=True)
+        t0 = time.perf_counter()
+        sb.design_batched(Ab, Bb, p.Q, p.R, p.S, p.P, p.u_min, p.u_max, **design_kw)
+        t_design = time.perf_counter() - t0
+        sb.set_reference(p.x_ref, p.u_ref)
+        sb.update_initialization(X0)
+        for _ in range(5):
+            sb.calculate(opts)
+        kb = 50
+        sb.timing_reset(kb)
+        t0 = time.perf_counter()
+        for _ in range(kb):
+            sb.calculate(opts, sync=False)
+        sb.synchronize()
+        elb = time.perf_counter() - t0
+        tb = sb.timing_summary()
+        rb = sb.get_results(want=("status",))
+        nzs_ = 16 * ((NZ + 15) // 16)
+        # k_admm_inst, algorithmic bytes per instance: M_i^-1 (nz x nzs), F'_i and V_i (n x nzs each), d, rho, fS, v0S, x0 in;
+        # x, z, y, v0 out
+        admm_bytes = BATCH_PER_GPU * 8 * (NZ * nzs_ + 2 * NX * nzs_ + 2 * nzs_ + 2 * NZ + NX + 4 * nzs_)
+        admm_ms_b = tb["admm_ms"] / max(1, tb["steps"])
+        out["per_instance_models"] = {
+            "value": kb / elb, "unit": "batch-steps/s (4096 instances, one model per instance)", "ms_per_step": 1e3 * elb / kb,
+            "design_ms": 1e3 * t_design, "status_counts": np.bincount(rb["status"], minlength=3).tolist(),
+            "stage_ms": {k: tb[k] / max(1, tb["steps"]) for k in ("admm_ms", "polish_ms", "total_ms")},
+            "roofline": {"bound": "hbm", "kernel": "k_admm_inst (KKT inverse streamed HBM -> registers once per instance-step)",
+                         "achieved": admm_bytes / (admm_ms_b * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": admm_bytes / (admm_ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic": traffic.get("k_admm_inst", {}).get("hbm_bytes_per_launch") if rank == 0 else None,
+                         "avg_kernel_ms": admm_ms_b, "algorithmic_bytes_per_launch": admm_bytes},
+            "note": "models = the benchmark plant with B scaled per instance (+-5 %), shared P, same x0 and options as the headline run"}
+        sb.close()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # ---- CPU baseline (kind "port": oracle/almpc_oracle.c, OpenMP over instances, all host cores) on a bounded
