@@ -7,7 +7,7 @@
 # solver tag "hip" next to osqp/scip/ipopt/auto (src/sub/solver_selection.jl:9-14).
 module AlmpcHIP
 
-export hip_solver_def, HipModeler, design_hip, update_initialization!, calculate!,
+export hip_solver_def, HipModeler, design_hip, design_batched!, update_initialization!, calculate!,
        _model_predictive_control_computation
 
 const libalmpc = get(ENV, "ALMPC_LIB", "libalmpc.so")
@@ -66,6 +66,29 @@ function design_hip(A::Matrix{Float64}, B::Matrix{Float64}, Q::Matrix{Float64}, 
                    h, x_ref, u_ref, 0))
     mod = HipModeler(h, n, m, N, batch, opts)
     finalizer(x -> ccall((:almpc_destroy, libalmpc), Cvoid, (Ptr{Cvoid},), x.handle), mod)
+    return mod
+end
+
+"""
+    design_batched!(mod, A_batch, B_batch, Q, R, S, P, umin, umax; x_ref, u_ref)
+
+One model per instance (`A_batch` n x n x batch, `B_batch` n x m x batch: Julia's column-major 3-arrays are the ABI's
+[batch][n*n] / [batch][n*m] blocks): the linear-programming design of the reference for the linearisation of a black-box model at
+every instance's own point (src/sub/model_modeler_implementation/fnn/mpc_modeler_implementation_fnn.jl:38-46 linearises once; the
+per-step re-linearisation is BASELINE configs[3]).  `P` = nothing (DARE per instance), an n x n matrix, or n x n x batch.
+"""
+function design_batched!(mod::HipModeler, A_batch::Array{Float64,3}, B_batch::Array{Float64,3}, Q::Matrix{Float64},
+                         R::Matrix{Float64}, S::Matrix{Float64}, P, umin::Vector{Float64}, umax::Vector{Float64};
+                         x_ref::Matrix{Float64}, u_ref::Matrix{Float64})
+    size(A_batch, 3) == mod.batch && size(B_batch, 3) == mod.batch || throw(DimensionMismatch("one model per instance"))
+    pptr = P === nothing ? Ptr{Float64}(C_NULL) : pointer(P)
+    pinst = (P !== nothing && ndims(P) == 3) ? 1 : 0
+    GC.@preserve P check(mod.handle, ccall((:almpc_design_batched, libalmpc), Cint,
+                   (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint,
+                    Ptr{Float64}, Ptr{Float64}, Cdouble, Cdouble),
+                   mod.handle, A_batch, B_batch, Q, R, S, pptr, pinst, umin, umax, mod.opts.rho, mod.opts.sigma))
+    check(mod.handle, ccall((:almpc_set_reference, libalmpc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Cint),
+                            mod.handle, x_ref, u_ref, 0))
     return mod
 end
 
