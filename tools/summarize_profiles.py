@@ -1,6 +1,6 @@
 """Turn the raw rocprofv3 output directories of one round into the small summaries kept under profiles/.
 
-    python tools/summarize_profiles.py <tag> <kernel_trace_dir> <pmc_fetch_dir> <pmc_write_dir>
+    python tools/summarize_profiles.py <tag> <kernel_trace_dir> <pmc_fetch_dir> <pmc_write_dir> [<more pmc dirs> ...]
 
 writes  profiles/<tag>_bench_kernel_stats.csv   (copy of the --stats kernel summary)
         profiles/<tag>_pmc_summary.csv          (per kernel / counter: dispatches, mean, min, max)
@@ -51,6 +51,18 @@ def main():
                                if fetch_mult == 2.0 else
                                "FETCH_SIZE raw (8-B-per-lane reads: uncalibrated width), WRITE_SIZE exact (16-B-per-lane stores)"),
             }
+    # optional further --pmc passes (e.g. MfmaUtil MfmaFlopsF64 / SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE): per-kernel means
+    extra = defaultdict(list)
+    for d in sys.argv[5:]:
+        with open(find(d, "*counter_collection.csv")) as f:
+            for r in csv.DictReader(f):
+                if "almpc::" in r["Kernel_Name"] and "design" not in r["Kernel_Name"] and "pack" not in r["Kernel_Name"]:
+                    extra[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
+    if extra:
+        with open(os.path.join(out, f"{tag}_pmc_mfma_lds.csv"), "w") as f:
+            f.write("Kernel_Name,Counter,Dispatches,Mean,Min,Max\n")
+            for (k, c), v in sorted(extra.items()):
+                f.write(f"\"{k}\",{c},{len(v)},{sum(v) / len(v)},{min(v)},{max(v)}\n")
     traffic["command"] = ("rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py "
                           "--steps 20 --warmup 5 --no-cpu-baseline --no-classes --no-pipelined --no-closed-loop")
     traffic["workload"] = "bench.py defaults: 4096 quadrotor instances, mixed amplitudes, stiffness rho profile (30), ADMM max_iter 8, polish on"
