@@ -38,7 +38,7 @@ struct almpc_handle {
     // device: per-instance state and results
     double *dX0 = nullptr, *dXs = nullptr, *dZs = nullptr, *dYs = nullptr, *dV0 = nullptr, *dW = nullptr;
     double *dX = nullptr, *dEx = nullptr, *dU = nullptr, *dEu = nullptr;
-    int32_t *dStatus = nullptr, *dIters = nullptr, *dPiters = nullptr, *dOverflow = nullptr, *dPerm = nullptr;
+    int32_t *dStatus = nullptr, *dIters = nullptr, *dPiters = nullptr, *dPerm = nullptr;
     int num_cus = 256;            // persistent-grid size of k_polish<true>
     size_t polish_glds_bytes = 0; // dynamic-LDS attribute last set on k_polish<true>
     int polish_no_glds = 0;       // diagnostic: force the G-through-L2 build (ALMPC_POLISH_NO_GLDS=1)
@@ -107,7 +107,7 @@ hipError_t launch_admm(int nrb, int ks, const AdmmParams& p, int grid, size_t ld
 void free_all(almpc_handle* h) {
     void* ptrs[] = {h->dMinvFrag, h->dVFrag, h->dHFrag, h->dFFrag, h->dG, h->dD, h->dUmin, h->dUmax, h->dA, h->dB,
                     h->dXref, h->dUref, h->dFS, h->dV0S, h->dRho, h->dX0, h->dXs, h->dZs, h->dYs, h->dV0, h->dW, h->dX, h->dEx,
-                    h->dU, h->dEu, h->dStatus, h->dIters, h->dPiters, h->dOverflow, h->dPerm, h->dSglobal, h->dGhat, h->dGnorm, h->dXmin,
+                    h->dU, h->dEu, h->dStatus, h->dIters, h->dPiters, h->dPerm, h->dSglobal, h->dGhat, h->dGnorm, h->dXmin,
                     h->dXmax, h->dRowTraj, h->dRowEq, h->dRowXidx, h->dRowState, h->bA, h->bB, h->bMinv, h->bG, h->bHs, h->bFs,
                     h->bVs, h->bD, h->bRho, h->bH, h->bF, h->bPhi, h->bGk, h->bGam, h->bW, h->bWP, h->bP, h->bFlag};
     for (void* p : ptrs)
@@ -188,7 +188,7 @@ int almpc_create(almpc_handle** out, int n, int m, int N, int batch, int device_
     TRY(dalloc(&h->dSglobal, b * POLISH_GLB_PER_INST));
     TRY(dalloc(&h->dPerm, ((b + 15) / 16) * 16));
     TRY(hipMemset(h->dPerm, 0xFF, ((b + 15) / 16) * 16 * sizeof(int32_t)));
-    TRY(dalloc(&h->dStatus, b)); TRY(dalloc(&h->dIters, b)); TRY(dalloc(&h->dPiters, b)); TRY(dalloc(&h->dOverflow, b));
+    TRY(dalloc(&h->dStatus, b)); TRY(dalloc(&h->dIters, b)); TRY(dalloc(&h->dPiters, b));
     TRY(hipMemset(h->dXs, 0, b * h->nzs * sizeof(double)));
     TRY(hipMemset(h->dZs, 0, b * h->nzs * sizeof(double)));
     TRY(hipMemset(h->dYs, 0, b * h->nzs * sizeof(double)));
@@ -564,7 +564,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         ip.fS = h->dFS; ip.v0S = h->dV0S; ip.umin = h->dUmin; ip.umax = h->dUmax;
         ip.uref = h->dUref; ip.uref_stride = h->uref_stride; ip.xref = h->dXref; ip.xref_stride = h->xref_stride; ip.x0 = h->dX0;
         ip.xs = h->dXs; ip.zs = h->dZs; ip.ys = h->dYs; ip.v0 = h->dV0; ip.status = h->dStatus; ip.iters = h->dIters;
-        ip.piters = h->dPiters; ip.overflow = h->dOverflow; ip.perm = h->dPerm;
+        ip.piters = h->dPiters; ip.perm = h->dPerm;
         ip.sigma = o.sigma; ip.alpha = o.alpha; ip.eps_abs = o.eps_abs; ip.eps_rel = o.eps_rel;
         ip.max_iter = o.max_iter; ip.check_every = o.check_every; ip.warm = o.warm_start ? 1 : 0;
         const size_t l = (12 * (size_t)h->nzs + 64 + 2 * (size_t)h->m) * sizeof(double);
@@ -584,7 +584,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
     ap.uref = h->dUref; ap.uref_stride = h->uref_stride; ap.xref = h->dXref; ap.xref_stride = h->xref_stride;
     ap.fS = h->dFS; ap.fS_stride = h->fS_stride; ap.x0 = h->dX0;
     ap.xs = h->dXs; ap.zs = h->dZs; ap.ys = h->dYs; ap.v0 = h->dV0; ap.status = h->dStatus; ap.iters = h->dIters;
-    ap.piters = h->dPiters; ap.overflow = h->dOverflow;
+    ap.piters = h->dPiters;
     ap.perm = h->dPerm;
     ap.rho = o.rho; ap.sigma = o.sigma; ap.alpha = o.alpha; ap.eps_abs = o.eps_abs; ap.eps_rel = o.eps_rel;
     ap.max_iter = o.max_iter; ap.check_every = o.check_every; ap.warm = o.warm_start ? 1 : 0;

@@ -32,7 +32,7 @@ struct AdmmInstParams {
     const double* xref; long xref_stride;
     const double* x0;
     double* xs; double* zs; double* ys; double* v0;
-    int32_t* status; int32_t* iters; int32_t* piters; int32_t* overflow; int32_t* perm;
+    int32_t* status; int32_t* iters; int32_t* piters; int32_t* perm;
     double sigma, alpha, eps_abs, eps_rel;
     int max_iter, check_every, warm;
 };
@@ -287,7 +287,6 @@ __global__ __launch_bounds__(ADMM_INST_THREADS) __attribute__((amdgpu_waves_per_
             GL(q.iters)[inst] = my_iters;
             GL(q.status)[inst] = my_status;
             GL(q.piters)[inst] = 0;
-            GL(q.overflow)[inst] = 0;
             GL(q.perm)[inst] = inst;  // no ranking across instances here: processing order = instance order
         }
         if (wv == 0 && inpair) {

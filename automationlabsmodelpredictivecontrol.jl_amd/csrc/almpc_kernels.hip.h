@@ -102,7 +102,6 @@ struct AdmmParams {
     int32_t* status;
     int32_t* iters;
     int32_t* piters;    // zeroed here so that the step needs no memset nodes
-    int32_t* overflow;
     int32_t* perm;      // [tiles*16] polish processing order inside each tile: large active-set guess first (see k_polish)
     double rho, sigma, alpha, eps_abs, eps_rel;
     int max_iter, check_every, warm;
@@ -309,7 +308,6 @@ __global__ __launch_bounds__(64 * NRB) void k_admm(AdmmParams p) {
         p.iters[inst] = my_iters;
         p.status[inst] = my_status;
         p.piters[inst] = 0;
-        p.overflow[inst] = 0;
     }
     // ---- polish order: the polish is bound by its slowest instances, so within every tile the instances are ranked by the
     // size of their active-set guess (a proxy for a long active-set chain): perm[tile*16 + rank] = instance (-1: pad column).
