@@ -141,13 +141,14 @@ __global__ __launch_bounds__(64 * NRB) void k_admm(AdmmParams p) {
     for (int ks = 0; ks < KSF_MAX; ++ks)
         af[ks] = (ks < p.ksf) ? p.FFrag[((size_t)(wv * p.ksf + ks)) * 64 + lane] : 0.0;
     int row[4];
-    double dv[4], dinv[4], lo[4], hi[4], fs[4];
+    double dv[4], dinv[4], lo[4], hi[4], fs[4], rho[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         row[i] = wv * 16 + q + 4 * i;
         const bool in = row[i] < p.nz;
         const int r = in ? row[i] : 0;
         dv[i] = in ? p.dvec[r] : 1.0;
+        rho[i] = p.rhovec[r];  // per-row penalty, requested with the rest of the prologue's loads
         const double ur = p.uref[(size_t)instc * p.uref_stride + r];
         lo[i] = p.umin[r % p.m] - ur;   // scaled below
         hi[i] = p.umax[r % p.m] - ur;
@@ -183,10 +184,8 @@ __global__ __launch_bounds__(64 * NRB) void k_admm(AdmmParams p) {
 
     // ---- initial iterate
     // y is carried in scaled form yt = y / rho_i (the update needs no 1/rho then); rho_i is per row
-    double x[4], z[4], yt[4], px[4], rown[4], rho[4];
+    double x[4], z[4], yt[4], px[4], rown[4];
     const double sigma = p.sigma, alpha = p.alpha;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) rho[i] = p.rhovec[row[i] < p.nz ? row[i] : 0];
     if (p.warm) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
