@@ -128,11 +128,6 @@ __global__ __launch_bounds__(64 * NRB) void k_admm(AdmmParams p) {
     const int instc = valid ? inst : p.batch - 1;  // clamp: pad columns recompute the last instance, never stored
     ALMPC_STAMP(blockIdx.x * NRB + wv, 0);
 
-    // ---- shared KKT inverse -> registers (A fragments), coalesced 512 B per wave-instruction
-    double a[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) a[ks] = p.MinvFrag[((size_t)(wv * KS + ks)) * 64 + lane];
-
     // ---- every other global load of the prologue is requested up front as well (one exposed latency, not five):
     // F' fragments, the row constants, and x0 / x_ref for e0
     constexpr int KSF_MAX = 16;  // n <= 64
@@ -164,7 +159,15 @@ __global__ __launch_bounds__(64 * NRB) void k_admm(AdmmParams p) {
         if (k < p.n) v = p.x0[(size_t)ii * p.n + k] - p.xref[(size_t)ii * p.xref_stride + k];
         e0s[t] = v;
     }
+    // ---- shared KKT inverse -> registers (A fragments), coalesced 512 B per wave-instruction.  Requested LAST: loads return
+    // in order, and these 30 fragments (115 KB per workgroup) are not needed before the first iteration, while everything
+    // above is needed by the prologue, which now runs under this stream instead of behind it.
+    double a[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) a[ks] = p.MinvFrag[((size_t)(wv * KS + ks)) * 64 + lane];
+    ALMPC_STAMP(blockIdx.x * NRB + wv, 5);
     __syncthreads();
+    ALMPC_STAMP(blockIdx.x * NRB + wv, 6);
 
     // ---- per-row constants and f' = F' e0 + fS
     {
@@ -182,6 +185,7 @@ __global__ __launch_bounds__(64 * NRB) void k_admm(AdmmParams p) {
         }
     }
 
+    ALMPC_STAMP(blockIdx.x * NRB + wv, 7);
     // ---- initial iterate
     // y is carried in scaled form yt = y / rho_i (the update needs no 1/rho then); rho_i is per row
     double x[4], z[4], yt[4], px[4], rown[4];

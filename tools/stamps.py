@@ -32,6 +32,8 @@ da = np.diff(out[ok2][:, [0, 1, 2, 3, 4]], axis=1)
 for i, nm in enumerate(["admm prologue", "admm loop", "admm v0 product", "admm result flush"]):
     v = da[:, i]
     print(f"{nm:28s} cycles: median {int(np.median(v)):7d}  p90 {int(np.percentile(v,90)):7d}  max {v.max():7d}")
+ex = out[ok2]
+print("admm prologue split: start->e0 written", int(np.median(ex[:,5]-ex[:,0])), " barrier", int(np.median(ex[:,6]-ex[:,5])), " f' + constants", int(np.median(ex[:,7]-ex[:,6])), " init + nf reduce", int(np.median(ex[:,1]-ex[:,7])))
 print("admm loop cycles / iteration:", np.median(da[:, 1]) / opts.max_iter)
 tot = out[ok][:, 14] - out[ok][:, 8]
 print("total per wave: median", int(np.median(tot)), "p90", int(np.percentile(tot, 90)), "max", tot.max(), " (2.4 GHz: max = %.1f us)" % (tot.max() / 2400.0))
