@@ -64,6 +64,8 @@ def load():
     L.almpc_set_terminal_equality.argtypes = [_hp, ctypes.c_int]
     L.almpc_set_rho_profile.argtypes = [_hp, ctypes.c_int]
     L.almpc_set_rho_profile.restype = ctypes.c_int
+    L.almpc_set_step_fusion.argtypes = [_hp, ctypes.c_int]
+    L.almpc_set_step_fusion.restype = ctypes.c_int
     L.almpc_set_terminal_equality.restype = ctypes.c_int
     L.almpc_update_initialization.argtypes = [_hp, _dp]
     L.almpc_update_initialization_device.argtypes = [_hp, ctypes.c_void_p]
@@ -223,6 +225,10 @@ class Solver:
         H = np.empty((nz, nz), order="F"); F = np.empty((nz, n), order="F"); d = np.empty(nz)
         self._check(self.L.almpc_get_design_instance(self.h, int(i), _ptr(H), _ptr(F), _ptr(d)))
         return dict(H=H, F=F, d=d)
+
+    def set_step_fusion(self, on: bool):
+        """One kernel per step (default) or the two-kernel path whose stage times can be told apart."""
+        self._check(self.L.almpc_set_step_fusion(self.h, 1 if on else 0))
 
     def set_reference(self, x_ref, u_ref, per_instance=False):
         """x_ref (n, N+1) / u_ref (m, N), or with per_instance (batch, n, N+1) / (batch, m, N)."""

@@ -42,6 +42,8 @@ struct almpc_handle {
     int num_cus = 256;            // persistent-grid size of k_polish<true>
     size_t polish_glds_bytes = 0; // dynamic-LDS attribute last set on k_polish<true>
     int polish_no_glds = 0;       // diagnostic: force the G-through-L2 build (ALMPC_POLISH_NO_GLDS=1)
+    int fuse_step = 1;            // one kernel per step when the shape allows (almpc_set_step_fusion / ALMPC_NO_FUSED_STEP=1)
+    size_t step_lds_bytes = 0;
     double* dSglobal = nullptr;  // polish scratch for working sets beyond 32 rows
     // state rows (state box / terminal equality): constraint-space data for k_polish_gen
     int terminal_eq = 0, has_box = 0, mc = 0, R = 0, Rs = 0, np_pairs = 0;
@@ -173,6 +175,8 @@ int almpc_create(almpc_handle** out, int n, int m, int N, int batch, int device_
         if (cus > 0) h->num_cus = cus;
         const char* e = getenv("ALMPC_POLISH_NO_GLDS");
         h->polish_no_glds = (e && e[0] == '1') ? 1 : 0;
+        const char* e2 = getenv("ALMPC_NO_FUSED_STEP");
+        h->fuse_step = (e2 && e2[0] == '1') ? 0 : 1;
     }
     const size_t fr = (size_t)h->nrb * h->ks * 64, b = (size_t)batch;
     TRY(dalloc(&h->dMinvFrag, fr)); TRY(dalloc(&h->dVFrag, (size_t)h->nrb * h->ksf * 64)); TRY(dalloc(&h->dHFrag, fr));
@@ -211,6 +215,12 @@ int almpc_set_rho_profile(almpc_handle* h, int mode) {
     if (mode != 0 && mode != 1) return fail(h, ALMPC_ERR_INVALID, "rho profile: 0 (scalar) or 1 (stiffness)");
     h->rho_mode = mode;
     h->designed = false;  // takes effect at the next design
+    return ALMPC_OK;
+}
+
+int almpc_set_step_fusion(almpc_handle* h, int on) {
+    if (!h) return ALMPC_ERR_INVALID;
+    h->fuse_step = on ? 1 : 0;
     return ALMPC_OK;
 }
 
@@ -576,8 +586,12 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         if (wgs > h->batch) wgs = h->batch;
         hipLaunchKernelGGL(k_admm_inst, dim3(wgs), dim3(ADMM_INST_THREADS), l, st, ip);
         HIP_TRY(h, hipGetLastError());
-    } else {
+    }
     AdmmParams ap;
+    bool admm_pending = false;  // shared-model ADMM not launched yet: it may go out fused with the polish (k_step_fused)
+    const int admm_grid = (h->batch + TILE - 1) / TILE;
+    const size_t admm_lds = ((size_t)2 * h->nzs * TILE + (size_t)h->nrb * 8 * TILE + (size_t)4 * h->ksf * TILE) * sizeof(double);
+    if (!h->batched) {
     ap.nz = h->nz; ap.n = h->n; ap.m = h->m; ap.batch = h->batch; ap.nzs = h->nzs;
     ap.MinvFrag = h->dMinvFrag; ap.VFrag = h->dVFrag; ap.v0S = h->dV0S; ap.v0S_stride = h->fS_stride; ap.HFrag = h->dHFrag; ap.FFrag = h->dFFrag; ap.ksf = h->ksf;
     ap.dvec = h->dD; ap.rhovec = h->dRho; ap.umin = h->dUmin; ap.umax = h->dUmax;
@@ -588,11 +602,16 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
     ap.perm = h->dPerm;
     ap.rho = o.rho; ap.sigma = o.sigma; ap.alpha = o.alpha; ap.eps_abs = o.eps_abs; ap.eps_rel = o.eps_rel;
     ap.max_iter = o.max_iter; ap.check_every = o.check_every; ap.warm = o.warm_start ? 1 : 0;
-    const int grid = (h->batch + TILE - 1) / TILE;
-    const size_t lds = ((size_t)2 * h->nzs * TILE + (size_t)h->nrb * 8 * TILE + (size_t)4 * h->ksf * TILE) * sizeof(double);
-    HIP_TRY(h, launch_admm(h->nrb, h->ks, ap, grid, lds, st));
+    admm_pending = true;
     }
-    if (timing) HIP_TRY(h, hipEventRecord(ev[1], st));
+    auto flush_admm = [&]() -> int {  // the two-kernel path: ADMM on its own
+        if (admm_pending) {
+            admm_pending = false;
+            HIP_TRY(h, launch_admm(h->nrb, h->ks, ap, admm_grid, admm_lds, st));
+        }
+        if (timing) HIP_TRY(h, hipEventRecord(ev[1], st));
+        return ALMPC_OK;
+    };
 
     RolloutParams rp;
     rp.n = h->n; rp.m = h->m; rp.N = h->N; rp.batch = h->batch; rp.nzs = h->nzs; rp.A = h->batched ? h->bA : h->dA; rp.B = h->batched ? h->bB : h->dB;
@@ -609,6 +628,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
     roll_cpl = roll_cpl <= 1 ? 1 : (roll_cpl <= 2 ? 2 : (roll_cpl <= 4 ? 4 : 8));
     if (h->mc > 0) {
         if (!roll_fits) return fail(h, ALMPC_ERR_UNSUPPORTED, "calculate: state rows need the fused rollout (n + m <= 8 * lanes-per-row)");
+        { const int rc_ = flush_admm(); if (rc_ != ALMPC_OK) return rc_; }
         PolishGenParams gp;
         gp.nz = h->nz; gp.mc = h->mc; gp.R = h->R; gp.Rs = h->Rs; gp.m = h->m; gp.n = h->n; gp.N = h->N; gp.batch = h->batch; gp.nzs = h->nzs;
         gp.Ghat = h->dGhat; gp.gnorm = h->dGnorm; gp.row_traj = h->dRowTraj; gp.row_eq = h->dRowEq; gp.row_xidx = h->dRowXidx;
@@ -652,7 +672,27 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         pp.lds_per_wave = per_wave;
         // G in LDS when it fits beside the buffers of 8 waves (gfx950: 160 KB per workgroup)
         const PolishShared SL = polish_shared_layout(h->n, h->m, h->N, h->nz, h->nzs, fused ? 1 : 0);
-        const size_t l_glds = ((size_t)h->nz * h->nzs + SL.total + (size_t)POLISH_WAVES_GLDS * per_wave + 2) * sizeof(double);
+        const size_t g_lds = (size_t)h->nz * ((h->nz + 1) & ~1);  // doubles: rows of G packed to an even stride
+        const size_t l_glds = (g_lds + SL.total + (size_t)POLISH_WAVES_GLDS * per_wave + 2) * sizeof(double);
+        // one kernel for the whole step when the tile is 8 waves and [G | union(ADMM buffers, polish buffers)] fits LDS
+        size_t l_step = l_glds - g_lds * sizeof(double);
+        if (admm_lds > l_step) l_step = admm_lds;
+        l_step += g_lds * sizeof(double);
+        const bool step_fused = admm_pending && h->fuse_step && !h->polish_no_glds && h->nrb == 8 && (h->ks == 30 || h->ks == 32) &&
+                                fused && l_step <= 160 * 1024;
+        if (step_fused) {
+            admm_pending = false;
+            if (timing) HIP_TRY(h, hipEventRecord(ev[1], st));  // no boundary between the phases to time: admm_ms reads 0
+            if (h->ks == 30) {
+                if (h->step_lds_bytes != l_step) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_fused<8, 30>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l_step));
+                hipLaunchKernelGGL((k_step_fused<8, 30>), dim3(pp.ntiles), dim3(512), l_step, st, ap, pp);
+            } else {
+                if (h->step_lds_bytes != l_step) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_fused<8, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l_step));
+                hipLaunchKernelGGL((k_step_fused<8, 32>), dim3(pp.ntiles), dim3(512), l_step, st, ap, pp);
+            }
+            h->step_lds_bytes = l_step;
+        } else {
+        { const int rc_ = flush_admm(); if (rc_ != ALMPC_OK) return rc_; }
         if (l_glds <= 160 * 1024 && !h->polish_no_glds && !h->batched) {
             if (h->polish_glds_bytes != l_glds) {
                 HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_polish<true>),
@@ -666,8 +706,12 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
             const size_t l = ((size_t)SL.total + (size_t)POLISH_WAVES * per_wave) * sizeof(double);
             hipLaunchKernelGGL((k_polish<false>), dim3((pp.ntiles * 16 + POLISH_WAVES - 1) / POLISH_WAVES), dim3(64 * POLISH_WAVES), l, st, pp);
         }
+        }
         HIP_TRY(h, hipGetLastError());
         rp.w = h->dW;
+    } else {
+        const int rc_ = flush_admm();
+        if (rc_ != ALMPC_OK) return rc_;
     }
     if (timing) HIP_TRY(h, hipEventRecord(ev[2], st));
 

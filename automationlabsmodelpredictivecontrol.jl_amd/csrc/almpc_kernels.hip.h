@@ -112,10 +112,9 @@ struct AdmmParams {
 // i = 0..3, of instance col -- so the whole ADMM vector update is register-local and only the
 // right-hand side travels through LDS (double-buffered, one barrier per iteration).
 template <int NRB, int KS>
-__global__ __launch_bounds__(64 * NRB) void k_admm(AdmmParams p) {
+__device__ __forceinline__ void admm_body(const AdmmParams& p, double* smem) {
     constexpr int RP = 16 * NRB;  // padded rows
     static_assert(4 * KS <= RP, "K padding must fit the row padding");
-    extern __shared__ __attribute__((aligned(16))) double smem[];
     double* rhs0 = smem;                    // [RP][16]
     double* rhs1 = smem + RP * TILE;        // [RP][16]
     double* red = smem + 2 * RP * TILE;     // [NRB][8][16]
@@ -373,6 +372,12 @@ __global__ __launch_bounds__(64 * NRB) void k_admm(AdmmParams p) {
     ALMPC_STAMP(blockIdx.x * NRB + wv, 4);
 }
 
+template <int NRB, int KS>
+__global__ __launch_bounds__(64 * NRB) void k_admm(AdmmParams p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    admm_body<NRB, KS>(p, smem);
+}
+
 // ------------------------------------------------------------------------------------------------
 // polish: primal active-set finish with the shared inverse G = H'^-1 (oracle: polish_active_set)
 // ------------------------------------------------------------------------------------------------
@@ -593,17 +598,18 @@ constexpr int POLISH_GLB_PER_INST = 64 * 64;        // doubles of global scratch
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-template <bool GLDS>
-__global__ __launch_bounds__(64 * (GLDS ? POLISH_WAVES_GLDS : POLISH_WAVES)) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_polish(PolishParams p_arg) {
+// GLDS: G in LDS (persistent 8-wave workgroups, tile-local queue); GPRE: it is there already (fused step kernel: requested
+// before the ADMM phase).  KOFF: byte offset of the PolishParams inside the kernel-argument segment.
+template <bool GLDS, bool GPRE, int KOFF>
+__device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* smem) {
     const PolishParams& p = p_arg;
-    constexpr int CH = 16;  // positions per chunk of G rows
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int CH = GLDS ? 8 : 16;  // positions per chunk of G rows (LDS latency needs fewer loads in flight than L2 latency)
     const int wv = threadIdx.x >> 6, lane_k = threadIdx.x & 63;
     const int nz = p.nz, nzs = p.nzs;
     const double* Gp = p.G;
+    const int gs = GLDS ? ((nz + 1) & ~1) : nzs;  // row stride of G as the waves read it: compact in LDS, nzs in global memory
     const PolishShared SL = polish_shared_layout(p.roll.n, p.m, p.roll.N, nz, nzs, p.fuse_rollout);
-    double* shc = smem + (GLDS ? (size_t)nz * nzs : 0);  // workgroup-shared constants
+    double* shc = smem + (GLDS ? (size_t)nz * gs : 0);  // workgroup-shared constants
     double* wave_lds = shc + SL.total + (size_t)wv * p.lds_per_wave;
     int* qcnt = nullptr;
     const bool uref_sh = p.uref_stride == 0, xref_sh = p.roll.xref_stride == 0;
@@ -629,25 +635,27 @@ void k_polish(PolishParams p_arg) {
         }
     }
     ALMPC_STAMP(8192 + blockIdx.x * 8 + wv, 0);
-    if constexpr (GLDS) {
-        const int cnt2 = nz * nzs / 2;  // nzs is even
-        const d2* src = reinterpret_cast<const d2*>(p.G);
-        d2* dst = reinterpret_cast<d2*>(smem);
-        // 8 independent 16-byte loads per thread in flight per round (a plain copy loop pays one L2 round trip per trip)
-        constexpr int TPB = 64 * POLISH_WAVES_GLDS, UNR = 8;
-        for (int i0 = threadIdx.x; i0 < cnt2; i0 += TPB * UNR) {
-            d2 v[UNR];
+    if constexpr (GLDS && !GPRE) {
+        // G -> LDS, rows packed to stride gs: wave w copies rows w, w + 8, ...; lane l the 16-byte pair l of a row; 8 rows in
+        // flight per wave and round (a plain copy loop pays one L2 round trip per row)
+        const int hs = gs / 2;
+        const bool lane_in = lane_k < hs;
+        const int lq = lane_in ? lane_k : 0;
+        for (int r0_ = wv; r0_ < nz; r0_ += POLISH_WAVES_GLDS * 8) {
+            d2 v[8];
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int i = i0 + u * TPB;
-                v[u] = src[i < cnt2 ? i : 0];
+            for (int u = 0; u < 8; ++u) {
+                const int r = r0_ + u * POLISH_WAVES_GLDS;
+                v[u] = *reinterpret_cast<const d2*>(p.G + (size_t)(r < nz ? r : 0) * nzs + 2 * lq);
             }
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int i = i0 + u * TPB;
-                if (i < cnt2) dst[i] = v[u];
+            for (int u = 0; u < 8; ++u) {
+                const int r = r0_ + u * POLISH_WAVES_GLDS;
+                if (r < nz && lane_in) *reinterpret_cast<d2*>(smem + (size_t)r * gs + 2 * lq) = v[u];
             }
         }
+    }
+    if constexpr (GLDS) {
         qcnt = reinterpret_cast<int*>(shc + SL.total + (size_t)POLISH_WAVES_GLDS * p.lds_per_wave);
         if (threadIdx.x == 0) *qcnt = POLISH_WAVES_GLDS;
         Gp = smem;
@@ -659,7 +667,7 @@ void k_polish(PolishParams p_arg) {
     // loop and the kernel spills hundreds of registers
     auto ka_ = __builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(ka_));
-    const PolishParams& p = *(const PolishParams*)ka_;
+    const PolishParams& p = *(const PolishParams*)((const char*)ka_ + KOFF);
     int lane = lane_k;
     asm volatile("" : "+v"(lane));  // same reason: masks and constants derived from the lane number stay inside the instance
     ALMPC_STAMP(inst, 8);
@@ -815,7 +823,7 @@ void k_polish(PolishParams p_arg) {
     // round trip can be started before the LDS work that produces the weights.
     auto g_load = [&](int l0, d2 (&g)[CH]) {
 #pragma unroll
-        for (int t = 0; t < CH; ++t) g[t] = *reinterpret_cast<const d2*>(Gp + (wrow_s[l0 + t] * nzs + rc));  // 32-bit index math
+        for (int t = 0; t < CH; ++t) g[t] = *reinterpret_cast<const d2*>(Gp + (wrow_s[l0 + t] * gs + rc));  // 32-bit index math
     };
     auto g_fma = [&](int l0, const double* ab, const d2 (&g)[CH], double& q0, double& q1) {
         double av[CH];
@@ -857,12 +865,12 @@ void k_polish(PolishParams p_arg) {
         const int pos = M::half ? (lane & 31) : lane;
         const bool lowhalf = M::half ? (lane < 32) : true;
         ALMPC_ACC_START;
-        const d2 gj = *reinterpret_cast<const d2*>(Gp + (j * nzs + rc));  // row j = column j
+        const d2 gj = *reinterpret_cast<const d2*>(Gp + (j * gs + rc));  // row j = column j
         d2 g[CH];
         g_load(0, g);  // rows of positions 0..CH-1: in flight while Sinv c is formed
         // c = G[W, j] = G[j, W] (symmetric) gathered straight from row j, beside the load of the row itself
-        const double cv = Gp[j * nzs + wrow];  // wrow is always a valid row index
-        const double gjj = Gp[j * nzs + j];
+        const double cv = Gp[j * gs + wrow];  // wrow is always a valid row index
+        const double gjj = Gp[j * gs + j];
         const double c = (pos < k) ? cv : 0.0;
         const double tj = readlane_d((j & 1) ? t1 : t0, j >> 1);
         ALMPC_ACC(0);
@@ -1116,7 +1124,7 @@ void k_polish(PolishParams p_arg) {
         {
             double gv[16];
 #pragma unroll
-            for (int t = 0; t < 16; ++t) gv[t] = Gp[wrow_s[16 * hhf + t] * nzs + wrow];
+            for (int t = 0; t < 16; ++t) gv[t] = Gp[wrow_s[16 * hhf + t] * gs + wrow];
 #pragma unroll
             for (int t = 0; t < 16; ++t) Sr[t] = (16 * hhf + t < k && pos < k) ? gv[t] : 0.0;
         }
@@ -1296,6 +1304,42 @@ void k_polish(PolishParams p_arg) {
             if (inst >= 0) process(inst);
         }
     }
+}
+
+template <bool GLDS>
+__global__ __launch_bounds__(64 * (GLDS ? POLISH_WAVES_GLDS : POLISH_WAVES)) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_polish(PolishParams p_arg) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    polish_body<GLDS, false, 0>(p_arg, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// One kernel per step for shapes whose tile is 8 waves (nz in 113..128): workgroup b first runs the ADMM of tile b, then
+// polishes the 16 instances of that tile with the tile-local queue of k_polish<true> -- the two kernels already pair up
+// workgroup b with tile b.  What the fusion buys: one launch instead of two, and the copy of G into LDS is requested
+// BEFORE the ADMM phase with direct global -> LDS loads (global_load_lds_dwordx4: no registers, 1 KB per wave instruction),
+// so it is there when the polish starts.  LDS: [G | union(ADMM buffers, polish buffers)].
+// ------------------------------------------------------------------------------------------------
+constexpr int STEP_KOFF = (int)((sizeof(AdmmParams) + 7) & ~size_t(7));  // PolishParams follows AdmmParams in the kernarg segment
+
+template <int NRB, int KS>
+__global__ __launch_bounds__(64 * NRB) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_step_fused(AdmmParams ap, PolishParams pp) {
+    static_assert(NRB == POLISH_WAVES_GLDS, "the polish queue is written for 8 waves");
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int gs = (pp.nz + 1) & ~1, hs = gs / 2;  // rows of G packed to stride gs in LDS (as polish_body<true, ...> reads them)
+    for (int r = wv; r < pp.nz; r += NRB) {
+        if (lane < hs) {  // one row per wave instruction: hs lanes x 16 bytes
+            const char* src = reinterpret_cast<const char*>(pp.G + (size_t)r * pp.nzs) + lane * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(smem + (size_t)r * gs), 16, 0, 0);
+        }
+    }
+    admm_body<NRB, KS>(ap, smem + (size_t)pp.nz * gs);
+    __builtin_amdgcn_s_waitcnt(0);  // this wave's pieces of G have landed
+    __syncthreads();                // ... and everybody's; the ADMM results of the tile are visible to the whole workgroup
+    polish_body<true, true, STEP_KOFF>(pp, smem);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -122,6 +122,14 @@ int almpc_set_terminal_equality(almpc_handle* h, int on);
  */
 int almpc_set_rho_profile(almpc_handle* h, int mode);
 
+/*
+ * Step fusion (default on): when the tile of 16 instances is 8 waves (nz in 113..128), polish = 1, no state rows and the
+ * buffers fit LDS, a step is ONE kernel (ADMM phase, then the polish of the same 16 instances by the same workgroup).
+ * 0 restores the two-kernel path (k_admm, k_polish), whose stage times the timing entry points can then separate.
+ * Results are identical.  May be changed at any time.
+ */
+int almpc_set_step_fusion(almpc_handle* h, int on);
+
 int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const double* Q,
                         const double* R, const double* S, const double* P, const double* umin,
                         const double* umax, const double* xmin, const double* xmax, double rho,
