@@ -35,14 +35,14 @@ def main():
         for (k, c, wg, g), v in sorted(rows.items()):
             f.write(f"\"{k}\",{c},{wg},{g},{len(v)},{sum(v) / len(v)},{min(v)},{max(v)}\n")
     traffic = {}
-    for short, pat in (("k_admm", "k_admm<"), ("k_polish", "k_polish<true>"), ("k_admm_inst", "k_admm_inst")):
+    for short, pat in (("k_admm", "k_admm<"), ("k_polish", "k_polish<true>"), ("k_admm_inst", "k_admm_inst"), ("k_step_fused", "k_step_fused")):
         ent = {}
         for (k, c, wg, g), v in rows.items():
             if pat in k:
                 ent[c] = (sum(v) / len(v), len(v))
         if "FETCH_SIZE" in ent and "WRITE_SIZE" in ent:
             fkb, fn = ent["FETCH_SIZE"]; wkb, wn = ent["WRITE_SIZE"]
-            fetch_mult = 2.0 if short in ("k_polish", "k_admm_inst") else 1.0
+            fetch_mult = 2.0 if short in ("k_polish", "k_admm_inst", "k_step_fused") else 1.0
             traffic[short] = {
                 "FETCH_SIZE_KB_per_launch": fkb, "launches_FETCH_SIZE": fn,
                 "WRITE_SIZE_KB_per_launch": wkb, "launches_WRITE_SIZE": wn,
