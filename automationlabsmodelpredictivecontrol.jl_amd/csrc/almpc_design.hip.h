@@ -266,6 +266,66 @@ __global__ __launch_bounds__(512) void k_design_inverse(int nz, int nzs, const d
     if (threadIdx.x == 0 && *badp) atomicExch(flag, 2);
 }
 
+// ---- K5 (shared-model design): Out = (Hs + c I + diag(dshift))^-1 by Cholesky -----------------------------
+// The shared design runs once, so it takes the more accurate route (relative error ~ eps cond instead of the
+// Gauss-Jordan kernel's few-times-larger constant: 4.5e-12 against 2.9e-10 in bench.py's u_err_inf).
+// One workgroup, matrix in LDS (ld = nz+1 to spread banks).  Cholesky (right-looking), in-place inverse of
+// the triangular factor, then X'X.  flag[0] != 0 if a pivot is not positive.
+__global__ __launch_bounds__(512) void k_design_inverse_chol(int nz, int nzs, const double* Hs, double cshift, const double* dshift,
+                                                        double* Out, int* flag, long sHs, long sShift, long sOut, long sFlag) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    Hs += blockIdx.y * sHs; Out += blockIdx.y * sOut; flag += blockIdx.y * sFlag;
+    if (dshift) dshift += blockIdx.y * sShift;
+    const int ld = nz + 1;
+    double* L = smem;         // [nz][ld], element (i,j) at L[j*ld + i]
+    double* xo = L + (size_t)nz * ld;  // [nz] scratch column
+    int* badp = reinterpret_cast<int*>(xo + nz);  // in the dynamic region: a static __shared__ would misalign it
+    if (threadIdx.x == 0) *badp = 0;
+    for (int t = threadIdx.x; t < nz * nz; t += blockDim.x) {
+        const int i = t % nz, j = t / nz;
+        L[j * ld + i] = Hs[(size_t)j * nzs + i] + (i == j ? cshift + (dshift ? dshift[i] : 0.0) : 0.0);
+    }
+    __syncthreads();
+    for (int j = 0; j < nz; ++j) {
+        const double piv = L[j * ld + j];
+        if (!(piv > 0.0)) { if (threadIdx.x == 0) *badp = 1; }
+        const double ljj = sqrt(piv > 0.0 ? piv : 1.0);
+        __syncthreads();
+        for (int i = j + threadIdx.x; i < nz; i += blockDim.x) L[j * ld + i] = (i == j) ? ljj : L[j * ld + i] / ljj;
+        __syncthreads();
+        const int rem = nz - j - 1;
+        for (int t = threadIdx.x; t < rem * rem; t += blockDim.x) {
+            const int i = j + 1 + t % rem, k = j + 1 + t / rem;
+            if (i >= k) L[k * ld + i] -= L[j * ld + i] * L[j * ld + k];
+        }
+        __syncthreads();
+    }
+    // in-place inverse of the lower-triangular factor (unblocked dtrti2, lower): columns right to left
+    for (int j = nz - 1; j >= 0; --j) {
+        const double ajj = 1.0 / L[j * ld + j];
+        // x := T x with T = already inverted trailing block, x = L[j+1:, j]
+        for (int i = j + 1 + threadIdx.x; i < nz; i += blockDim.x) {
+            double s = 0.0;
+            for (int k = j + 1; k <= i; ++k) s += L[k * ld + i] * L[j * ld + k];
+            xo[i] = -s * ajj;
+        }
+        __syncthreads();
+        for (int i = j + threadIdx.x; i < nz; i += blockDim.x) L[j * ld + i] = (i == j) ? ajj : xo[i];
+        __syncthreads();
+    }
+    // Out = X'X, X = L^-1 (lower): Out[i][j] = sum_{k >= max(i,j)} X[k][i] X[k][j]
+    for (int t = threadIdx.x; t < nz * nz; t += blockDim.x) {
+        const int i = t % nz, j = t / nz;
+        if (i < j) continue;
+        double s = 0.0;
+        for (int k = i; k < nz; ++k) s += L[i * ld + k] * L[j * ld + k];
+        Out[(size_t)j * nzs + i] = s;
+        Out[(size_t)i * nzs + j] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && *badp) atomicExch(flag, 2);
+}
+
 // ---- ADMM penalty per row: scalar rho (OSQP), or the stiffness profile rho_i = rho / G_ii (G = H'^-1), pad rows 1
 __global__ __launch_bounds__(256) void k_design_rho(int nz, int nzs, int mode, double rho, const double* G, double* rhovec,
                                                     long sG, long sRho) {
@@ -408,14 +468,14 @@ inline int design_shared_device(hipStream_t stream, int n, int m, int N, int nzs
     DTRY(hipGetLastError());
     hipLaunchKernelGGL(k_design_scale, dim3(1), dim3(256), 0, stream, nz, nzs, n, dH, dF, dD, dHs, dFs, dFlag, DesignStrides());
     DTRY(hipGetLastError());
-    const size_t inv_lds = 520 * sizeof(double);
-    DTRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_design_inverse), hipFuncAttributeMaxDynamicSharedMemorySize,
+    const size_t inv_lds = ((size_t)nz * (nz + 1) + nz + 2) * sizeof(double);
+    DTRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_design_inverse_chol), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)inv_lds));
     // G = H'^-1 first: the stiffness profile of the ADMM penalty (rho_i = rho / G_ii) is read off its diagonal
-    hipLaunchKernelGGL(k_design_inverse, dim3(1), dim3(512), inv_lds, stream, nz, nzs, dHs, 0.0, (const double*)nullptr, dG, dFlag, 0L, 0L, 0L, 0L);
+    hipLaunchKernelGGL(k_design_inverse_chol, dim3(1), dim3(512), inv_lds, stream, nz, nzs, dHs, 0.0, (const double*)nullptr, dG, dFlag, 0L, 0L, 0L, 0L);
     DTRY(hipGetLastError());
     hipLaunchKernelGGL(k_design_rho, dim3(1), dim3(256), 0, stream, nz, nzs, rho_mode, rho, dG, dRho, 0L, 0L);
-    hipLaunchKernelGGL(k_design_inverse, dim3(1), dim3(512), inv_lds, stream, nz, nzs, dHs, sigma, (const double*)dRho, dMinv, dFlag, 0L, 0L, 0L, 0L);
+    hipLaunchKernelGGL(k_design_inverse_chol, dim3(1), dim3(512), inv_lds, stream, nz, nzs, dHs, sigma, (const double*)dRho, dMinv, dFlag, 0L, 0L, 0L, 0L);
     DTRY(hipGetLastError());
     hipLaunchKernelGGL(k_pack_frags, dim3(32), dim3(256), 0, stream, dMinv, nz, nz, nzs, nrb, ks, dMinvFrag);
     hipLaunchKernelGGL(k_neg_gm, dim3(32), dim3(256), 0, stream, nz, nzs, n, nzs, dG, dFs, dVs, 0L, 0L);
