@@ -610,3 +610,29 @@ def test_polish_through_l2_build_matches_lds_build(capi, mo, monkeypatch):
     for i in np.nonzero(ok)[0][::7]:
         e = mo.solve_mpc_exact(p, X0[i])
         assert np.abs(a["u"][i] - e["u"]).max() <= U_TOL
+
+
+def test_fused_step_kernel_equals_two_kernel_path(capi, mo):
+    """k_step_fused (one kernel per step: ADMM phase + polish of the same tile) and the two-kernel path (k_admm, k_polish<true>) run the
+    same device functions: identical status, iteration counts and results, cold and warm, also for a partial last tile."""
+    p = mo.quadrotor()
+    X0 = np.concatenate([mo.quadrotor_x0_batch(50, a, first_instance=70 * k) for k, a in enumerate((0.3, 1.0, 3.0, 6.0))])  # 200 = 12.5 tiles
+    s = capi.Solver(p.n, p.m, p.N, len(X0))
+    s.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max, rho=30.0, rho_profile="stiffness")
+    s.set_reference(p.x_ref, p.u_ref)
+    out = {}
+    for fused in (True, False):
+        s.set_step_fusion(fused)
+        s.update_initialization(X0)
+        s.calculate(capi.default_opts(rho=30.0, max_iter=8, check_every=8))
+        a = s.get_results()
+        s.update_initialization(X0 * 0.9)
+        s.calculate(capi.default_opts(rho=30.0, max_iter=8, check_every=8, warm_start=1))
+        out[fused] = (a, s.get_results())
+    s.close()
+    for k in (0, 1):
+        f, t = out[True][k], out[False][k]
+        for key in ("status", "iters", "polish_iters", "u", "x", "e_u", "e_x"):
+            assert np.array_equal(f[key], t[key]), key
+    e = mo.solve_mpc_exact(p, X0[7])
+    assert np.abs(out[True][0]["u"][7] - e["u"]).max() <= U_TOL
