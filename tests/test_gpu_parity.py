@@ -636,3 +636,20 @@ def test_fused_step_kernel_equals_two_kernel_path(capi, mo):
             assert np.array_equal(f[key], t[key]), key
     e = mo.solve_mpc_exact(p, X0[7])
     assert np.abs(out[True][0]["u"][7] - e["u"]).max() <= U_TOL
+
+
+def test_config3_shards_reassemble_the_batch(pkg, capi, mo):
+    """BASELINE configs[2] in miniature: a batch seeded with 0x5EED0003 split into 8 contiguous shards (sharding.shard_range, one
+    handle per shard as one process per GPU would hold it) gives, shard by shard, exactly the results of the unsharded batch --
+    instances never interact, there is no data-path collective."""
+    p = mo.quadrotor()
+    batch, world = 8 * 40 + 5, 8  # ragged: shards of 41 / 40 instances, none a multiple of the 16-instance tile
+    X0 = mo.quadrotor_x0_batch(batch, 1.5, seed=0x5EED0003)
+    whole = step(capi, p, X0)
+    for rank in range(world):
+        lo, hi = pkg.sharding.shard_range(batch, rank, world)
+        part = step(capi, p, X0[lo:hi])
+        for key in ("status", "iters", "polish_iters", "u", "x"):
+            assert np.array_equal(part[key], whole[key][lo:hi]), (rank, key)
+    assert np.all(whole["status"] == 0)
+    assert np.abs(whole["u"][batch - 1] - mo.solve_mpc_exact(p, X0[batch - 1])["u"]).max() <= U_TOL

@@ -61,3 +61,8 @@ if okw.any():
     print("persistent waves:", int(okw.sum()), " G load cycles median", int(np.median(gl)), "max", int(gl.max()),
           " total cycles median", int(np.median(tt)), "max", int(tt.max()), " instances per wave min/median/max", int(cnt.min()), int(np.median(cnt)), int(cnt.max()))
     print("kernel span over all waves (if clocks comparable):", int(tl[okw, 2].max() - tl[okw, 0].min()))
+if okw.any():
+    # per workgroup (8 waves): when does its last wave finish the polish phase, relative to the phase start of that workgroup
+    t0 = tl[okw, 1].reshape(-1, 8).min(axis=1); t1 = tl[okw, 2].reshape(-1, 8).max(axis=1)
+    dur = t1 - t0
+    print("polish phase per workgroup (cycles): min", int(dur.min()), "median", int(np.median(dur)), "p90", int(np.percentile(dur, 90)), "max", int(dur.max()))
