@@ -367,14 +367,16 @@ int almpc_design_batched(almpc_handle* h, const double* A_batch, const double* B
         HIP_TRY(h, dalloc(&h->bFs, b * n * nzs)); HIP_TRY(h, dalloc(&h->bVs, b * n * nzs));
         HIP_TRY(h, dalloc(&h->bD, b * nzs)); HIP_TRY(h, dalloc(&h->bRho, b * nzs));
         HIP_TRY(h, dalloc(&h->bH, b * nz * nz)); HIP_TRY(h, dalloc(&h->bF, b * nz * n));
-        HIP_TRY(h, dalloc(&h->bPhi, b * N * n * n)); HIP_TRY(h, dalloc(&h->bGk, b * N * n * m));
-        HIP_TRY(h, dalloc(&h->bGam, b * kr * gs)); HIP_TRY(h, dalloc(&h->bW, b * kr * gs)); HIP_TRY(h, dalloc(&h->bWP, b * kr * ps));
+        if (design_instance_lds_doubles(n, m, N) * sizeof(double) > 160 * 1024) {  // dense route only: Gamma panels in HBM
+            HIP_TRY(h, dalloc(&h->bPhi, b * N * n * n)); HIP_TRY(h, dalloc(&h->bGk, b * N * n * m));
+            HIP_TRY(h, dalloc(&h->bGam, b * kr * gs)); HIP_TRY(h, dalloc(&h->bW, b * kr * gs)); HIP_TRY(h, dalloc(&h->bWP, b * kr * ps));
+            // padding rows / columns of the row-major panels stay zero for the lifetime of the handle
+            HIP_TRY(h, hipMemset(h->bGam, 0, b * kr * gs * sizeof(double)));
+            HIP_TRY(h, hipMemset(h->bW, 0, b * kr * gs * sizeof(double)));
+            HIP_TRY(h, hipMemset(h->bWP, 0, b * kr * ps * sizeof(double)));
+        }
         HIP_TRY(h, dalloc(&h->bP, b * n * n));
         HIP_TRY(h, dalloc(&h->bFlag, b));
-        // padding rows / columns of the row-major panels stay zero for the lifetime of the handle
-        HIP_TRY(h, hipMemset(h->bGam, 0, b * kr * gs * sizeof(double)));
-        HIP_TRY(h, hipMemset(h->bW, 0, b * kr * gs * sizeof(double)));
-        HIP_TRY(h, hipMemset(h->bWP, 0, b * kr * ps * sizeof(double)));
         HIP_TRY(h, hipMemset(h->bHs, 0, b * nz * nzs * sizeof(double)));
         HIP_TRY(h, hipMemset(h->bFs, 0, b * n * nzs * sizeof(double)));
         HIP_TRY(h, hipMemset(h->bVs, 0, b * n * nzs * sizeof(double)));
@@ -403,6 +405,16 @@ int almpc_design_batched(almpc_handle* h, const double* A_batch, const double* B
     ds.Gam = (long)kr * gs; ds.WP = (long)kr * ps; ds.H = (long)nz * nz; ds.F = (long)nz * n; ds.d = nzs; ds.Hs = (long)nz * nzs;
     ds.Fs = (long)n * nzs; ds.G = (long)nz * nzs; ds.Minv = (long)nz * nzs; ds.rho = nzs; ds.flag = 1;
     const unsigned gb = (unsigned)b;
+    const size_t inst_lds = design_instance_lds_doubles(n, m, N) * sizeof(double);
+    if (inst_lds <= 160 * 1024) {  // structured route: H_i, F_i from the Toeplitz blocks in LDS, no Gamma panels in HBM
+        DesignInstParams dp;
+        dp.n = n; dp.m = m; dp.N = N; dp.nz = nz; dp.useR = useR; dp.useS = useS;
+        dp.A = h->bA; dp.B = h->bB; dp.P = h->bP; dp.sA = ds.A; dp.sB = ds.B; dp.sP = ds.P;
+        dp.Q = dQ; dp.R = dR; dp.S = dS; dp.H = h->bH; dp.F = h->bF; dp.sH = ds.H; dp.sF = ds.F;
+        if (inst_lds > 64 * 1024)
+            BTRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_design_instance), hipFuncAttributeMaxDynamicSharedMemorySize, (int)inst_lds));
+        hipLaunchKernelGGL(k_design_instance, dim3(gb), dim3(256), inst_lds, st, dp);
+    } else {
     hipLaunchKernelGGL(k_design_blocks, dim3(1, gb), dim3(256), (size_t)(3 * n * n + n * m) * sizeof(double), st, n, m, N,
                        h->bA, h->bB, h->bPhi, h->bGk, ds);
     hipLaunchKernelGGL(k_design_gamma, dim3(N, gb), dim3(256), 0, st, n, m, N, dQ, h->bP, h->bPhi, h->bGk, h->bGam, h->bW, h->bWP, gs, ps, ds);
@@ -412,6 +424,7 @@ int almpc_design_batched(almpc_handle* h, const double* A_batch, const double* B
     hp.H = h->bH; hp.F = h->bF; hp.st = ds;
     const size_t hess_lds = (size_t)HESS_KC * (16 + (gs + 16) + (ps + 16)) * sizeof(double);
     hipLaunchKernelGGL(k_design_hessian, dim3(nrb, gb), dim3(64 * (nrb + njf)), hess_lds, st, hp);
+    }
     hipLaunchKernelGGL(k_design_scale, dim3(1, gb), dim3(256), 0, st, nz, nzs, n, h->bH, h->bF, h->bD, h->bHs, h->bFs, h->bFlag, ds);
     BTRY(hipGetLastError());
     const size_t inv_lds = 520 * sizeof(double);

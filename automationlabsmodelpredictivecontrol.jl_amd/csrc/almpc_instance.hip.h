@@ -306,6 +306,135 @@ __global__ __launch_bounds__(ADMM_INST_THREADS) __attribute__((amdgpu_waves_per_
 #undef ISTAMP
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_design_instance: condensed Hessian and gradient matrix of ONE instance per workgroup, entirely in LDS.
+// The dense route (k_design_gamma + k_design_hessian) materialises Gamma_i and Qbar Gamma_i in HBM (2 x 393 KB per quadrotor-size
+// instance) and contracts them with MFMA; for a batch of instances that traffic, not the flops, is the cost.  Gamma is block
+// lower-triangular Toeplitz with blocks G_k = A^k B, so with Q G_k, P G_k, Phi_k = A^k in LDS
+//     H_ij = 2 [ sum_{a=0}^{N-2-i} G_a' (Q G_{a+d}) + G_{N-1-i}' (P G_{N-1-i+d}) ],  d = i - j >= 0      (m x m blocks)
+//     F_i  = 2 [ sum_{a=0}^{N-2-i} E_a + E^P_{N-1-i} ] Phi_{i+1},   E_a = G_a' Q A^a,  E^P_a = G_a' P A^a   (m x n blocks)
+// i.e. prefix sums along the block diagonals: O(N^2 m^2 n) flops instead of O(N^3 m^2 n), nothing but A_i, B_i, P_i read and
+// H_i, F_i written.  Same H and F as k_design_hessian up to summation order (R, S terms as there: src/sub/design_mpc.jl:405-468).
+// Q and P symmetric (the host symmetrises them).  LDS: (N+1) n^2 + 5 N n m + 4 n^2 + ... doubles; the host falls back to the
+// dense route when that does not fit.
+// ------------------------------------------------------------------------------------------------
+struct DesignInstParams {
+    int n, m, N, nz, useR, useS;
+    const double* A; const double* B; const double* P; long sA, sB, sP;   // per instance
+    const double* Q; const double* R; const double* S;                     // shared
+    double* H; double* F; long sH, sF;                                     // column-major nz x nz, nz x n
+};
+
+__host__ __device__ inline size_t design_instance_lds_doubles(int n, int m, int N) {
+    return (size_t)4 * n * n + (size_t)n * m + (size_t)(N + 1) * n * n + (size_t)5 * N * n * m;
+}
+
+__global__ __launch_bounds__(256) void k_design_instance(DesignInstParams p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int n = p.n, m = p.m, N = p.N, nz = p.nz;
+    const int nn = n * n, nm = n * m;
+    const double* A = p.A + blockIdx.x * p.sA;
+    const double* B = p.B + blockIdx.x * p.sB;
+    const double* P = p.P + blockIdx.x * p.sP;
+    double* H = p.H + blockIdx.x * p.sH;
+    double* F = p.F + blockIdx.x * p.sF;
+    double* As = smem;             // [n][n] column-major: As[j*n+i] = A_ij
+    double* Qs = As + nn;
+    double* Ps = Qs + nn;
+    double* tmp = Ps + nn;         // [n][n] scratch
+    double* Bs = tmp + nn;         // [n][m] column-major
+    double* Phi = Bs + nm;         // [N+1][n*n]: Phi[k] = A^k
+    double* Gk = Phi + (size_t)(N + 1) * nn;   // [N][n*m]: G_k = A^k B
+    double* QG = Gk + (size_t)N * nm;          // Q G_k
+    double* PG = QG + (size_t)N * nm;          // P G_k
+    double* E = PG + (size_t)N * nm;           // [N][m*n]: E_a (then prefix sums), element (p, j) at [j*m + p]
+    double* EP = E + (size_t)N * nm;           // E^P_a
+    const int T = blockDim.x;
+    for (int t = threadIdx.x; t < nn; t += T) { As[t] = A[t]; Qs[t] = p.Q[t]; Ps[t] = P[t]; Phi[t] = (t % n == t / n) ? 1.0 : 0.0; }
+    for (int t = threadIdx.x; t < nm; t += T) Bs[t] = B[t];
+    __syncthreads();
+    for (int k = 1; k <= N; ++k) {  // Phi[k] = A Phi[k-1]
+        const double* prev = Phi + (size_t)(k - 1) * nn;
+        double* cur = Phi + (size_t)k * nn;
+        for (int t = threadIdx.x; t < nn; t += T) {
+            const int i = t % n, j = t / n;
+            double s = 0.0;
+            for (int l = 0; l < n; ++l) s += As[l * n + i] * prev[j * n + l];
+            cur[t] = s;
+        }
+        __syncthreads();
+    }
+    for (int t = threadIdx.x; t < N * nm; t += T) {  // G_k = Phi[k] B
+        const int k = t / nm, e = t % nm, i = e % n, j = e / n;
+        const double* ph = Phi + (size_t)k * nn;
+        double s = 0.0;
+        for (int l = 0; l < n; ++l) s += ph[l * n + i] * Bs[j * n + l];
+        Gk[t] = s;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < N * nm; t += T) {  // Q G_k, P G_k
+        const int k = t / nm, e = t % nm, i = e % n, j = e / n;
+        const double* g = Gk + (size_t)k * nm + (size_t)j * n;
+        double sq = 0.0, sp = 0.0;
+        for (int l = 0; l < n; ++l) { sq += Qs[l * n + i] * g[l]; sp += Ps[l * n + i] * g[l]; }
+        QG[t] = sq; PG[t] = sp;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < N * nm; t += T) {  // E_a[p][j] = sum_s (Q G_a)[s][p] Phi[a][s][j]  (Q symmetric)
+        const int a = t / nm, e = t % nm, pp = e % m, j = e / m;
+        const double* ph = Phi + (size_t)a * nn + (size_t)j * n;
+        const double* qg = QG + (size_t)a * nm + (size_t)pp * n;
+        const double* pg = PG + (size_t)a * nm + (size_t)pp * n;
+        double sq = 0.0, sp = 0.0;
+        for (int l = 0; l < n; ++l) { sq += qg[l] * ph[l]; sp += pg[l] * ph[l]; }
+        E[t] = sq; EP[t] = sp;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < nm; e += T)  // prefix sums over a
+        for (int a = 1; a < N; ++a) E[(size_t)a * nm + e] += E[(size_t)(a - 1) * nm + e];
+    __syncthreads();
+    // F_i = 2 (SE[N-2-i] + EP[N-1-i]) Phi[i+1]
+    for (int t = threadIdx.x; t < N * nm; t += T) {
+        const int i = t / nm, e = t % nm, pp = e % m, j = e / m;
+        const double* ph = Phi + (size_t)(i + 1) * nn + (size_t)j * n;
+        const double* se = (i <= N - 2) ? E + (size_t)(N - 2 - i) * nm : nullptr;
+        const double* ep = EP + (size_t)(N - 1 - i) * nm;
+        double s = 0.0;
+        for (int l = 0; l < n; ++l) s += ((se ? se[l * m + pp] : 0.0) + ep[l * m + pp]) * ph[l];
+        F[(size_t)j * nz + i * m + pp] = 2.0 * s;
+    }
+    // H: thread (d, p, q) walks block diagonal d from the last block row up, carrying the prefix sum of the Q terms
+    const int mm = m * m;
+    for (int t = threadIdx.x; t < N * mm; t += T) {
+        const int d = t / mm, e = t % mm, pp = e % m, qq = e / m;
+        double C = 0.0;
+        for (int i = N - 1; i >= d; --i) {
+            if (i < N - 1) {
+                const int a = N - 2 - i;
+                const double* g = Gk + (size_t)a * nm + (size_t)pp * n;
+                const double* qg = QG + (size_t)(a + d) * nm + (size_t)qq * n;
+                double s = 0.0;
+                for (int l = 0; l < n; ++l) s += g[l] * qg[l];
+                C += s;
+            }
+            const double* g = Gk + (size_t)(N - 1 - i) * nm + (size_t)pp * n;
+            const double* pg = PG + (size_t)(N - 1 - i + d) * nm + (size_t)qq * n;
+            double sp = 0.0;
+            for (int l = 0; l < n; ++l) sp += g[l] * pg[l];
+            double v = 2.0 * (C + sp);
+            const int j = i - d;
+            if (p.useR && d == 0) v += 2.0 * p.R[(size_t)qq * m + pp];
+            if (p.useS) {  // delta_u[:,i] = u[:,i] - u[:,i+1], i = 1..N-1 (src/sub/design_mpc.jl:429-431)
+                if (d == 0) v += 2.0 * ((i <= N - 2 ? 1 : 0) + (i >= 1 ? 1 : 0)) * p.S[(size_t)qq * m + pp];
+                else if (d == 1) v -= 2.0 * p.S[(size_t)qq * m + pp];
+            }
+            const int row = i * m + pp, col = j * m + qq;
+            H[(size_t)col * nz + row] = v;
+            if (d > 0) H[(size_t)row * nz + col] = v;
+        }
+    }
+}
+
 // fS_i = d_i .* g: the constant part of the scaled gradient (g = 2 D'Sbar D u_ref, shared or per instance) for every instance
 __global__ __launch_bounds__(256) void k_fs_scale(int batch, int nz, int nzs, const double* g, long g_stride, const double* d,
                                                   double* fS) {
