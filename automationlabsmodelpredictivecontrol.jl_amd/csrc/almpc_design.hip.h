@@ -246,12 +246,15 @@ __global__ __launch_bounds__(512) void k_design_inverse(int nz, int nzs, const d
                 const double ip = 1.0 / (piv > 0.0 ? piv : 1.0);
                 const bool isp = i == pv;
                 const double f = isp ? 0.0 : pc[i] * ip;   // the pivot row itself is rescaled, not eliminated
-                const double scale = isp ? ip : 1.0;
 #pragma unroll
                 for (int kk = 0; kk < 32; kk += 2) {
                     const d2 w = *reinterpret_cast<const d2*>(pr + 32 * g + kk);
-                    S[kk] = __builtin_fma(-f, w[0], S[kk]) * scale;
-                    S[kk + 1] = __builtin_fma(-f, w[1], S[kk + 1]) * scale;
+                    S[kk] = __builtin_fma(-f, w[0], S[kk]);
+                    S[kk + 1] = __builtin_fma(-f, w[1], S[kk + 1]);
+                }
+                if (isp) {  // one lane per column group: the other waves skip these 32 multiplications
+#pragma unroll
+                    for (int kk = 0; kk < 32; ++kk) S[kk] *= ip;
                 }
                 if (g == gp) S[k] = isp ? ip : -f;  // column pv
             }
