@@ -1275,7 +1275,7 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
         // work queue: slots are handed out in the order k_admm wrote them (hard instances first); every wave leaves once
         // the counter has passed the batch, so the grid always drains
         ALMPC_STAMP(8192 + blockIdx.x * 8 + wv, 1);
-        int nproc = 0;
+        [[maybe_unused]] int nproc = 0;  // read by the diagnostic (ALMPC_STAMPS) build only
         // work queue of this workgroup: it owns the ADMM tiles blockIdx.x, blockIdx.x + gridDim.x, ... (workgroup b of
         // k_admm and of this kernel land on the same XCD, so the iterates it reads are still in that L2) and walks their
         // instances in the per-tile order k_admm left (hardest first); wave w takes i = w, afterwards the waves pull
