@@ -56,7 +56,7 @@ def main():
     for d in sys.argv[5:]:
         with open(find(d, "*counter_collection.csv")) as f:
             for r in csv.DictReader(f):
-                if "almpc::" in r["Kernel_Name"] and "design" not in r["Kernel_Name"] and "pack" not in r["Kernel_Name"]:
+                if "almpc::" in r["Kernel_Name"]:
                     extra[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
     if extra:
         with open(os.path.join(out, f"{tag}_pmc_mfma_lds.csv"), "w") as f:
