@@ -12,6 +12,7 @@
 #include "almpc_host_math.h"
 #include "../../include/almpc.h"
 
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -752,6 +753,15 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
 int almpc_synchronize(almpc_handle* h) {
     if (!h) return ALMPC_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
+    // A step is tens of microseconds: poll the stream for a while before falling back to the blocking wait, whose wake-up
+    // (interrupt + scheduler) was seen to cost up to ~15 ms on this pool -- 200 steps' worth.
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipStreamQuery(h->stream);
+        if (q == hipSuccess) return ALMPC_OK;
+        if (q != hipErrorNotReady) return fail(h, ALMPC_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
+    }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return ALMPC_OK;
 }

@@ -277,12 +277,14 @@ def main():
         for _ in range(5):
             sb.calculate(opts)
         kb = 50
-        sb.timing_reset(kb)
-        t0 = time.perf_counter()
-        for _ in range(kb):
-            sb.calculate(opts, sync=False)
-        sb.synchronize()
-        elb = time.perf_counter() - t0
+        elb = float("inf")
+        for _rep in range(3):  # best of three bursts: a burst is only ~12 ms long and an occasional ~15 ms hiccup of the host-side wait
+            sb.timing_reset(kb)  # (seen on this pool) would otherwise double the figure
+            t0 = time.perf_counter()
+            for _ in range(kb):
+                sb.calculate(opts, sync=False)
+            sb.synchronize()
+            elb = min(elb, time.perf_counter() - t0)
         tb = sb.timing_summary()
         rb = sb.get_results(want=("status",))
         nzs_ = 16 * ((NZ + 15) // 16)
