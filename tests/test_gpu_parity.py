@@ -177,7 +177,8 @@ def test_osqp_default_settings_converge(capi, mo):
 
 
 # ---------------------------------------------------------------------------- odd shapes
-@pytest.mark.parametrize("n,m,N", [(1, 1, 1), (1, 1, 7), (3, 2, 7), (5, 3, 9), (2, 1, 128), (7, 5, 25), (16, 8, 16), (20, 1, 40), (64, 2, 3)])
+@pytest.mark.parametrize("n,m,N", [(1, 1, 1), (1, 1, 7), (3, 2, 7), (5, 3, 9), (2, 1, 128), (7, 5, 25), (16, 8, 16), (20, 1, 40), (64, 2, 3),
+                                   (3, 1, 117), (2, 1, 113), (6, 3, 39), (4, 4, 31)])  # the last four: 8-wave tiles -> fused step kernel, odd nz
 def test_random_stable_plants_of_many_shapes(capi, mo, n, m, N):
     """nz = m*N from 1 to 128 (odd values too), n up to 64 (n = 20, 64: the separate rollout kernels): random plants
     with spectral radius 0.97, bounds tight enough to be active, batch not a multiple of anything."""
