@@ -59,6 +59,10 @@ def load():
     L.almpc_design_batched.argtypes = [_hp] + [_dp] * 6 + [ctypes.c_int, _dp, _dp, ctypes.c_double, ctypes.c_double]
     L.almpc_design_batched.restype = ctypes.c_int
     L.almpc_get_design_instance.argtypes = [_hp, ctypes.c_int, _dp, _dp, _dp]
+    L.almpc_design_ltv.argtypes = [_hp] + [_dp] * 11 + [ctypes.c_int, _dp, _dp, ctypes.c_double, ctypes.c_double]
+    L.almpc_design_ltv.restype = ctypes.c_int
+    L.almpc_get_gradient_instance.argtypes = [_hp, ctypes.c_int, _dp]
+    L.almpc_get_gradient_instance.restype = ctypes.c_int
     L.almpc_get_design_instance.restype = ctypes.c_int
     L.almpc_set_reference.argtypes = [_hp, _dp, _dp, ctypes.c_int]
     L.almpc_set_terminal_equality.argtypes = [_hp, ctypes.c_int]
@@ -131,6 +135,9 @@ def dare(A, B, Q, R):
     return P
 
 
+FNN_ACTIVATIONS = {"identity": 0, "relu": 1, "tanh": 2, "sigmoid": 3, "swish": 4}
+
+
 def fnn_linearize(W_in, W_h, b_h, W_out, x, u, act="relu", device=0, want_f=False):
     """Batched Jacobians of an Fnn model on the GPU: x (batch, n), u (batch, m) -> A (batch, n, n), B (batch, n, m)."""
     L = load()
@@ -145,7 +152,7 @@ def fnn_linearize(W_in, W_h, b_h, W_out, x, u, act="relu", device=0, want_f=Fals
     u = np.ascontiguousarray(np.atleast_2d(u), dtype=np.float64)
     batch = x.shape[0]
     A = np.empty((batch, n, n)); B = np.empty((batch, m, n)); f = np.empty((batch, n)) if want_f else None
-    rc = L.almpc_fnn_linearize(int(device), n, m, H, nl, {"identity": 0, "relu": 1}[act], _ptr(W_in), _ptr(Wh), _ptr(bh), _ptr(W_out),
+    rc = L.almpc_fnn_linearize(int(device), n, m, H, nl, FNN_ACTIVATIONS[act], _ptr(W_in), _ptr(Wh), _ptr(bh), _ptr(W_out),
                                batch, _ptr(x), _ptr(u), _ptr(A), _ptr(B), _ptr(f))
     if rc != ALMPC_OK:
         raise AlmpcError(rc, "almpc_fnn_linearize")
@@ -219,6 +226,38 @@ class Solver:
         umax = np.ascontiguousarray(umax, dtype=np.float64).reshape(m)
         self._check(self.L.almpc_design_batched(self.h, _ptr(A), _ptr(B), _ptr(Q), _ptr(R), _ptr(S), _ptr(P), p_inst, _ptr(umin),
                                                 _ptr(umax), float(rho), float(sigma)))
+
+    def design_ltv(self, A_all, B_all, c_all, xbar, ubar, x_ref, u_ref, Q, R, S=None, P=None, umin=None, umax=None, rho=0.1, sigma=1e-6,
+                   rho_profile="scalar"):
+        """Time-varying models: A_all (batch, N, n, n), B_all (batch, N, n, m), c_all (batch, N, n) or None, xbar (batch, n, N+1),
+        ubar (batch, m, N), x_ref (n, N+1) / u_ref (m, N) or None, P (n, n) or (batch, n, n).  The QP variable is v = u - ubar."""
+        n, m, N, b = self.n, self.m, self.N, self.batch
+        self._check(self.L.almpc_set_terminal_equality(self.h, 0))
+        self._check(self.L.almpc_set_rho_profile(self.h, {"scalar": 0, "stiffness": 1}[rho_profile]))
+        A = np.ascontiguousarray(np.asarray(A_all, dtype=np.float64).reshape(b, N, n, n).transpose(0, 1, 3, 2))
+        B = np.ascontiguousarray(np.asarray(B_all, dtype=np.float64).reshape(b, N, n, m).transpose(0, 1, 3, 2))
+        c = None if c_all is None else np.ascontiguousarray(np.asarray(c_all, dtype=np.float64).reshape(b, N, n))
+        xb = np.ascontiguousarray(np.asarray(xbar, dtype=np.float64).reshape(b, n, N + 1).transpose(0, 2, 1))
+        ub = np.ascontiguousarray(np.asarray(ubar, dtype=np.float64).reshape(b, m, N).transpose(0, 2, 1))
+        xr = None if x_ref is None else np.ascontiguousarray(np.asarray(x_ref, dtype=np.float64).reshape(n, N + 1).T)
+        ur = None if u_ref is None else np.ascontiguousarray(np.asarray(u_ref, dtype=np.float64).reshape(m, N).T)
+        Q, R = _colmajor(Q, (n, n)), _colmajor(R, (m, m))
+        S = None if S is None else _colmajor(S, (m, m))
+        P = np.asarray(P, dtype=np.float64)
+        p_inst = 0
+        if P.ndim == 3:
+            P = np.ascontiguousarray(P.reshape(b, n, n).transpose(0, 2, 1)); p_inst = 1
+        else:
+            P = _colmajor(P, (n, n))
+        umin = np.ascontiguousarray(umin, dtype=np.float64).reshape(m)
+        umax = np.ascontiguousarray(umax, dtype=np.float64).reshape(m)
+        self._check(self.L.almpc_design_ltv(self.h, _ptr(A), _ptr(B), _ptr(c), _ptr(xb), _ptr(ub), _ptr(xr), _ptr(ur), _ptr(Q), _ptr(R),
+                                            _ptr(S), _ptr(P), p_inst, _ptr(umin), _ptr(umax), float(rho), float(sigma)))
+
+    def get_gradient_instance(self, i):
+        q = np.empty(self.nz)
+        self._check(self.L.almpc_get_gradient_instance(self.h, int(i), _ptr(q)))
+        return q
 
     def get_design_instance(self, i):
         n, nz = self.n, self.nz

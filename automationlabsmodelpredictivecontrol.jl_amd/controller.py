@@ -70,7 +70,7 @@ class ConstrainedLinearControlDiscreteSystem:
 class Fnn:
     """Feed-forward network in the layout the reference reads from Flux.params
     (src/sub/model_modeler_implementation/fnn/mpc_modeler_implementation_fnn.jl:88-107): W_in H x (n+m) (no bias, no
-    activation), hidden layers (W_h[l], b_h[l]) with activation `act` ("relu" | "identity"), W_out n x H (no bias).
+    activation), hidden layers (W_h[l], b_h[l]) with activation `act` ("identity" | "relu" | "tanh" | "sigmoid" | "swish"), W_out n x H (no bias).
     Also the model tag AutomationLabsSystems.Fnn() of src/sub/design_mpc.jl:176."""
     W_in: np.ndarray
     W_h: list

@@ -52,6 +52,8 @@ struct almpc_handle {
     int *dRowTraj = nullptr, *dRowEq = nullptr, *dRowXidx = nullptr, *dRowState = nullptr;
     // per-instance models (almpc_design_batched): persistent per-instance operands ...
     bool batched = false;
+    bool ltv = false;             // almpc_design_ltv: references and gradient are part of the design
+    double* bQ = nullptr;         // [batch][nz] explicit gradient of an LTV design (unscaled)
     double *bA = nullptr, *bB = nullptr, *bMinv = nullptr, *bG = nullptr, *bHs = nullptr, *bFs = nullptr, *bVs = nullptr,
            *bD = nullptr, *bRho = nullptr, *bH = nullptr, *bF = nullptr;
     // ... and design temporaries kept for the next re-design (a per-step re-linearisation designs every step)
@@ -112,7 +114,7 @@ void free_all(almpc_handle* h) {
                     h->dXref, h->dUref, h->dFS, h->dV0S, h->dRho, h->dX0, h->dXs, h->dZs, h->dYs, h->dV0, h->dW, h->dX, h->dEx,
                     h->dU, h->dEu, h->dStatus, h->dIters, h->dPiters, h->dPerm, h->dSglobal, h->dGhat, h->dGnorm, h->dXmin,
                     h->dXmax, h->dRowTraj, h->dRowEq, h->dRowXidx, h->dRowState, h->bA, h->bB, h->bMinv, h->bG, h->bHs, h->bFs,
-                    h->bVs, h->bD, h->bRho, h->bH, h->bF, h->bPhi, h->bGk, h->bGam, h->bW, h->bWP, h->bP, h->bFlag};
+                    h->bVs, h->bD, h->bRho, h->bH, h->bF, h->bPhi, h->bGk, h->bGam, h->bW, h->bWP, h->bP, h->bFlag, h->bQ};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& e : h->ev)
@@ -308,6 +310,7 @@ int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const
     HIP_TRY(h, hipMemcpy(h->dB, B, (size_t)n * m * sizeof(double), hipMemcpyHostToDevice));
     h->designed = true;
     h->batched = false;
+    h->ltv = false;
     // default references: zeros, shared
     std::vector<double> xr((size_t)n * (N + 1), 0.0), ur((size_t)nz, 0.0);
     return almpc_set_reference(h, xr.data(), ur.data(), 0);
@@ -315,9 +318,23 @@ int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const
 
 // Per-instance models: every instance gets its own condensed QP from (A_i, B_i).  The design kernels of
 // almpc_design.hip.h run with blockIdx.y = instance; the per-step path is k_admm_inst + k_polish<false> with strides.
-int almpc_design_batched(almpc_handle* h, const double* A_batch, const double* B_batch, const double* Q, const double* R,
-                         const double* S, const double* P, int P_per_instance, const double* umin, const double* umax,
-                         double rho, double sigma) {
+}  // extern "C"
+
+namespace {
+// Time-varying inputs of almpc_design_ltv (host pointers); nullptr for the time-invariant almpc_design_batched.
+struct LtvInputs {
+    const double* A_all;   // [batch][N][n*n]
+    const double* B_all;   // [batch][N][n*m]
+    const double* c_all;   // [batch][N][n] or null
+    const double* ebar;    // [batch][N][n]  xbar_{k+1} - x_ref_{k+1}
+    const double* qadd;    // [batch][nz]    input part of the gradient
+    const double* ubar;    // [batch][nz]    linearisation inputs (become the per-instance input reference)
+    const double* xbar;    // [batch][(N+1)*n]
+};
+
+int design_batched_common(almpc_handle* h, const double* A_batch, const double* B_batch, const double* Q, const double* R,
+                          const double* S, const double* P, int P_per_instance, const double* umin, const double* umax,
+                          double rho, double sigma, const LtvInputs* ltv) {
     if (!h) return ALMPC_ERR_INVALID;
     if (!A_batch || !B_batch || !Q || !R || !umin || !umax) return fail(h, ALMPC_ERR_INVALID, "design_batched: null matrix pointer");
     if (!(rho > 0.0) || !(sigma >= 0.0)) return fail(h, ALMPC_ERR_INVALID, "design_batched: rho must be > 0 and sigma >= 0");
@@ -407,7 +424,35 @@ int almpc_design_batched(almpc_handle* h, const double* A_batch, const double* B
     ds.Fs = (long)n * nzs; ds.G = (long)nz * nzs; ds.Minv = (long)nz * nzs; ds.rho = nzs; ds.flag = 1;
     const unsigned gb = (unsigned)b;
     const size_t inst_lds = design_instance_lds_doubles(n, m, N) * sizeof(double);
-    if (inst_lds <= 160 * 1024) {  // structured route: H_i, F_i from the Toeplitz blocks in LDS, no Gamma panels in HBM
+    double *dAll = nullptr, *dBll = nullptr, *dC = nullptr, *dE = nullptr, *dQa = nullptr;  // LTV staging (freed below)
+    if (ltv) {
+        auto upl = [&](double** d, const double* src, size_t cnt) -> hipError_t {
+            hipError_t e = dalloc(d, cnt);
+            if (e == hipSuccess) e = hipMemcpyAsync(*d, src, cnt * sizeof(double), hipMemcpyHostToDevice, st);
+            return e;
+        };
+        hipError_t e = upl(&dAll, ltv->A_all, b * N * n * n);
+        if (e == hipSuccess) e = upl(&dBll, ltv->B_all, b * N * n * m);
+        if (e == hipSuccess && ltv->c_all) e = upl(&dC, ltv->c_all, b * N * n);
+        if (e == hipSuccess) e = upl(&dE, ltv->ebar, b * N * n);
+        if (e == hipSuccess) e = upl(&dQa, ltv->qadd, b * nz);
+        if (e == hipSuccess && !h->bQ) e = dalloc(&h->bQ, b * nz);
+        if (e == hipSuccess) e = hipMemsetAsync(h->bF, 0, b * nz * n * sizeof(double), st);
+        const size_t ltv_lds = design_ltv_lds_doubles(n, m, N) * sizeof(double);
+        if (e == hipSuccess && ltv_lds > 64 * 1024)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_design_ltv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ltv_lds);
+        if (e == hipSuccess) {
+            DesignLtvParams lp;
+            lp.n = n; lp.m = m; lp.N = N; lp.nz = nz; lp.useR = useR; lp.useS = useS;
+            lp.A = dAll; lp.B = dBll; lp.c = dC; lp.ebar = dE; lp.P = h->bP; lp.sP = ds.P; lp.Q = dQ; lp.R = dR; lp.S = dS;
+            lp.qadd = dQa; lp.H = h->bH; lp.q = h->bQ;
+            hipLaunchKernelGGL(k_design_ltv, dim3(gb), dim3(256), ltv_lds, st, lp);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);  // the staging buffers are released right away
+        (void)hipFree(dAll); (void)hipFree(dBll); (void)hipFree(dC); (void)hipFree(dE); (void)hipFree(dQa);
+        if (e != hipSuccess) { release(); return fail(h, ALMPC_ERR_HIP, std::string("design_ltv: ") + hipGetErrorString(e)); }
+    } else if (inst_lds <= 160 * 1024) {  // structured route: H_i, F_i from the Toeplitz blocks in LDS, no Gamma panels in HBM
         DesignInstParams dp;
         dp.n = n; dp.m = m; dp.N = N; dp.nz = nz; dp.useR = useR; dp.useS = useS;
         dp.A = h->bA; dp.B = h->bB; dp.P = h->bP; dp.sA = ds.A; dp.sB = ds.B; dp.sP = ds.P;
@@ -455,8 +500,87 @@ int almpc_design_batched(almpc_handle* h, const double* A_batch, const double* B
     HIP_TRY(h, hipMemcpy(h->dUmax, umax, m * sizeof(double), hipMemcpyHostToDevice));
     h->designed = true;
     h->batched = true;
-    std::vector<double> xr((size_t)n * (N + 1), 0.0), ur((size_t)nz, 0.0);
-    return almpc_set_reference(h, xr.data(), ur.data(), 0);
+    h->ltv = false;
+    if (!ltv) {
+        std::vector<double> xr((size_t)n * (N + 1), 0.0), ur((size_t)nz, 0.0);
+        return almpc_set_reference(h, xr.data(), ur.data(), 0);
+    }
+    // LTV: the QP variable is v = u - ubar, so ubar takes the place of the input reference (bounds umin - ubar <= v, u = v + ubar);
+    // the gradient is the explicit vector q_i (F'_i = V_i = 0: the step kernels add nothing for e0)
+    {
+        const int rc = almpc_set_reference(h, ltv->xbar, ltv->ubar, 1);
+        if (rc != ALMPC_OK) return rc;
+    }
+    hipLaunchKernelGGL(k_fs_scale, dim3(256), dim3(256), 0, h->stream, h->batch, nz, nzs, h->bQ, (long)nz, h->bD, h->dFS);
+    hipLaunchKernelGGL(k_neg_gm, dim3(1, (unsigned)h->batch), dim3(256), 0, h->stream, nz, nzs, 1, nz, h->bG, h->dFS, h->dV0S,
+                       (long)nz * nzs, (long)nz);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->ltv = true;
+    return ALMPC_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int almpc_design_batched(almpc_handle* h, const double* A_batch, const double* B_batch, const double* Q, const double* R,
+                         const double* S, const double* P, int P_per_instance, const double* umin, const double* umax,
+                         double rho, double sigma) {
+    return design_batched_common(h, A_batch, B_batch, Q, R, S, P, P_per_instance, umin, umax, rho, sigma, nullptr);
+}
+
+// Time-varying models: see include/almpc.h.  The host prepares ebar = xbar - x_ref (stages 1..N), the input part of the
+// gradient 2 Rbar (ubar - u_ref) + 2 D'Sbar D ubar, and hands stage 0's (A, B) to the time-invariant slots (they only feed
+// the rollout outputs x / e_x, which are not defined for an LTV design).
+int almpc_design_ltv(almpc_handle* h, const double* A_all, const double* B_all, const double* c_all, const double* xbar,
+                     const double* ubar, const double* xref, const double* uref, const double* Q, const double* R, const double* S,
+                     const double* P, int P_per_instance, const double* umin, const double* umax, double rho, double sigma) {
+    if (!h) return ALMPC_ERR_INVALID;
+    if (!A_all || !B_all || !xbar || !ubar || !Q || !R || !P || !umin || !umax)
+        return fail(h, ALMPC_ERR_INVALID, "design_ltv: null pointer (P must be given: there is no single model to take a DARE of)");
+    const int n = h->n, m = h->m, N = h->N, nz = h->nz;
+    const size_t b = (size_t)h->batch;
+    if (design_ltv_lds_doubles(n, m, N) * sizeof(double) > 160 * 1024)
+        return fail(h, ALMPC_ERR_UNSUPPORTED, "design_ltv: nz^2 + 3 n nz doubles must fit the 160 KB of LDS");
+    std::vector<double> A0(b * n * n), B0(b * n * m), ebar(b * N * n), qadd(b * nz, 0.0);
+    for (size_t i = 0; i < b; ++i) {
+        std::copy(A_all + i * N * n * n, A_all + i * N * n * n + (size_t)n * n, A0.begin() + i * n * n);
+        std::copy(B_all + i * N * n * m, B_all + i * N * n * m + (size_t)n * m, B0.begin() + i * n * m);
+        for (int k = 0; k < N; ++k)
+            for (int j = 0; j < n; ++j)
+                ebar[(i * N + k) * n + j] = xbar[i * (size_t)(N + 1) * n + (size_t)(k + 1) * n + j] - (xref ? xref[(size_t)(k + 1) * n + j] : 0.0);
+    }
+    const bool useR = R[0] != 0.0, useS = useR && S && S[0] != 0.0;
+    for (size_t i = 0; i < b; ++i) {
+        const double* ub = ubar + i * nz;
+        double* qa = qadd.data() + i * nz;
+        if (useR)
+            for (int k = 0; k < N; ++k)
+                for (int a = 0; a < m; ++a) {
+                    double sr = 0.0;
+                    for (int c2 = 0; c2 < m; ++c2) sr += 0.5 * (R[(size_t)c2 * m + a] + R[(size_t)a * m + c2]) * (ub[k * m + c2] - (uref ? uref[k * m + c2] : 0.0));
+                    qa[k * m + a] += 2.0 * sr;
+                }
+        if (useS)  // the input-rate cost is on u itself (src/sub/design_mpc.jl:423-446): 2 D'Sbar D ubar
+            for (int k = 0; k + 1 < N; ++k)
+                for (int a = 0; a < m; ++a) {
+                    double sd = 0.0;
+                    for (int c2 = 0; c2 < m; ++c2) sd += 0.5 * (S[(size_t)c2 * m + a] + S[(size_t)a * m + c2]) * (ub[k * m + c2] - ub[(k + 1) * m + c2]);
+                    qa[k * m + a] += 2.0 * sd;
+                    qa[(k + 1) * m + a] -= 2.0 * sd;
+                }
+    }
+    LtvInputs in{A_all, B_all, c_all, ebar.data(), qadd.data(), ubar, xbar};
+    return design_batched_common(h, A0.data(), B0.data(), Q, R, S, P, P_per_instance, umin, umax, rho, sigma, &in);
+}
+
+int almpc_get_gradient_instance(almpc_handle* h, int instance, double* q) {
+    if (!h || !q) return ALMPC_ERR_INVALID;
+    if (!h->designed || !h->ltv) return fail(h, ALMPC_ERR_NOT_DESIGNED, "get_gradient_instance needs almpc_design_ltv");
+    if (instance < 0 || instance >= h->batch) return fail(h, ALMPC_ERR_INVALID, "get_gradient_instance: instance out of range");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpy(q, h->bQ + (size_t)instance * h->nz, (size_t)h->nz * sizeof(double), hipMemcpyDeviceToHost));
+    return ALMPC_OK;
 }
 
 int almpc_get_design_instance(almpc_handle* h, int instance, double* H, double* F, double* d) {
@@ -475,6 +599,7 @@ int almpc_get_design_instance(almpc_handle* h, int instance, double* H, double* 
 int almpc_set_reference(almpc_handle* h, const double* xref, const double* uref, int per_instance) {
     if (!h) return ALMPC_ERR_INVALID;
     if (!h->designed) return fail(h, ALMPC_ERR_NOT_DESIGNED, "set_reference before design");
+    if (h->ltv) return fail(h, ALMPC_ERR_INVALID, "set_reference: the references of an LTV design are arguments of almpc_design_ltv");
     if (!xref || !uref) return fail(h, ALMPC_ERR_INVALID, "set_reference: null pointer");
     HIP_TRY(h, hipSetDevice(h->device));
     const int n = h->n, m = h->m, N = h->N, nz = h->nz;
@@ -886,7 +1011,7 @@ int almpc_fnn_linearize(int device_id, int n, int m, int H, int L, int activatio
                         double* B, double* f) {
     if (n < 1 || m < 1 || H < 1 || L < 0 || batch < 1 || !W_in || !W_out || !x || !u || !A || !B || (L > 0 && (!W_h || !b_h)))
         return ALMPC_ERR_INVALID;
-    if (activation != 0 && activation != 1) return ALMPC_ERR_UNSUPPORTED;
+    if (activation < 0 || activation > 4) return ALMPC_ERR_UNSUPPORTED;
     const size_t nin = (size_t)n + m;
     const size_t lds = (2 * (size_t)H + 2 * (size_t)H * nin + nin) * sizeof(double);
     if (lds > 160 * 1024) return ALMPC_ERR_UNSUPPORTED;

@@ -11,7 +11,7 @@
 namespace almpc {
 
 struct FnnParams {
-    int n, m, H, L, act;  // act: 0 identity, 1 relu
+    int n, m, H, L, act;  // act: 0 identity, 1 relu, 2 tanh, 3 sigmoid, 4 swish (x*sigmoid(x)): NNlib's names
     const double* W_in;   // H x (n+m) column-major
     const double* W_h;    // [L] H x H column-major
     const double* b_h;    // [L] H
@@ -23,6 +23,17 @@ struct FnnParams {
     double* B;            // [batch] n x m column-major
     double* f;            // [batch][n] or null
 };
+
+// activation value and derivative at pre-activation a
+__device__ __forceinline__ void fnn_act(int act, double a, double& val, double& der) {
+    switch (act) {
+        case 1: val = fmax(a, 0.0); der = a > 0.0 ? 1.0 : 0.0; break;
+        case 2: { const double t = tanh(a); val = t; der = 1.0 - t * t; break; }
+        case 3: { const double s = 1.0 / (1.0 + exp(-a)); val = s; der = s * (1.0 - s); break; }
+        case 4: { const double s = 1.0 / (1.0 + exp(-a)); val = a * s; der = s * (1.0 + a * (1.0 - s)); break; }
+        default: val = a; der = 1.0; break;
+    }
+}
 
 __global__ __launch_bounds__(256) void k_fnn_jacobian(FnnParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -55,10 +66,16 @@ __global__ __launch_bounds__(256) void k_fnn_jacobian(FnnParams p) {
             const int i = t / nin, c = t % nin;
             double s = 0.0;
             for (int j = 0; j < H; ++j) s += W[(size_t)j * H + i] * J[(size_t)j * nin + c];
-            Jn[t] = (p.act == 1 && !(yn[i] > 0.0)) ? 0.0 : s;
+            double val, der;
+            fnn_act(p.act, yn[i], val, der);
+            Jn[t] = der == 0.0 ? 0.0 : der * s;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < H; i += blockDim.x) y[i] = (p.act == 1) ? fmax(yn[i], 0.0) : yn[i];
+        for (int i = threadIdx.x; i < H; i += blockDim.x) {
+            double val, der;
+            fnn_act(p.act, yn[i], val, der);
+            y[i] = val;
+        }
         for (int t = threadIdx.x; t < H * nin; t += blockDim.x) J[t] = Jn[t];
         __syncthreads();
     }

@@ -435,6 +435,115 @@ __global__ __launch_bounds__(256) void k_design_instance(DesignInstParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_design_ltv: time-varying models (SQP / multiple shooting around the QP engine, BASELINE.json configs[4]): stage k of instance
+// i has its own (A_ik, B_ik) and a defect c_ik, so with dx_0 = 0
+//     dx_{k+1} = A_k dx_k + B_k v_k + c_k   =>   dX = Gamma~ v + g~,   Gamma~ block (k, j) = A_{k-1} ... A_{j+1} B_j,  j < k.
+// The QP in v has H = 2 (Gamma~' Qbar Gamma~ + Rbar + D'Sbar D) and state part of the gradient q = 2 Gamma~' Qbar (g~ + ebar),
+// ebar_k = xbar_k - x_ref_k.  Gamma~ is not Toeplitz, but only its CURRENT row block (n x nz) is ever needed: one workgroup
+// per instance walks the stages, propagates the row block and g~ (one n x n product each) and accumulates H and q in LDS:
+// O(nz^2 n N / 3) flops, H_i and q_i are the only things written.  The R, S part of the gradient is added from qadd.
+// ------------------------------------------------------------------------------------------------
+struct DesignLtvParams {
+    int n, m, N, nz, useR, useS;
+    const double* A; const double* B;        // [batch][N][n*n], [batch][N][n*m]  (column-major blocks)
+    const double* c; const double* ebar;     // [batch][N][n] defects / state errors at the linearisation (stages 1..N); nullable
+    const double* P; long sP;                // terminal weight, shared (sP = 0) or per instance
+    const double* Q; const double* R; const double* S;
+    const double* qadd;                      // [batch][nz] input part of the gradient (host), nullable
+    double* H; double* q;                    // [batch][nz*nz] column-major, [batch][nz]
+};
+
+__host__ __device__ inline size_t design_ltv_lds_doubles(int n, int m, int N) {
+    const size_t nz = (size_t)m * N;
+    return nz * nz + 3 * (size_t)n * nz + 4 * (size_t)n * n + (size_t)n * m + 3 * (size_t)n + nz;
+}
+
+__global__ __launch_bounds__(256) void k_design_ltv(DesignLtvParams p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int n = p.n, m = p.m, N = p.N, nz = p.nz, nn = n * n, nm = n * m;
+    const size_t inst = blockIdx.x;
+    double* Hs = smem;                 // [nz][nz] column-major accumulator
+    double* Gc = Hs + (size_t)nz * nz; // [nz][n]: current row block of Gamma~, element (p, c) at c*n + p
+    double* Gn = Gc + (size_t)n * nz;
+    double* T = Gn + (size_t)n * nz;   // Q_k times the row block
+    double* Ak = T + (size_t)n * nz;
+    double* Qs = Ak + nn;
+    double* Ps = Qs + nn;
+    double* Bk = Ps + nn;
+    double* gk = Bk + nm;              // g~_k
+    double* gn = gk + n;
+    double* rv = gn + n;               // g~ + ebar of the current stage
+    double* qs = rv + n;               // [nz]
+    const int T_ = blockDim.x;
+    for (int t = threadIdx.x; t < nz * nz; t += T_) Hs[t] = 0.0;
+    for (int t = threadIdx.x; t < n * nz; t += T_) { Gc[t] = 0.0; Gn[t] = 0.0; }
+    for (int t = threadIdx.x; t < nz; t += T_) qs[t] = 0.0;
+    for (int t = threadIdx.x; t < nn; t += T_) { Qs[t] = p.Q[t]; Ps[t] = p.P[inst * p.sP + t]; }
+    for (int t = threadIdx.x; t < n; t += T_) gk[t] = 0.0;
+    __syncthreads();
+    for (int k = 0; k < N; ++k) {
+        const double* Ag = p.A + (inst * N + k) * nn;
+        const double* Bg = p.B + (inst * N + k) * nm;
+        for (int t = threadIdx.x; t < nn; t += T_) Ak[t] = Ag[t];
+        for (int t = threadIdx.x; t < nm; t += T_) Bk[t] = Bg[t];
+        __syncthreads();
+        const int wcols = (k + 1) * m;  // columns of the row block that are non-zero after this stage
+        for (int t = threadIdx.x; t < n * wcols; t += T_) {
+            const int pr = t % n, c = t / n;
+            double v;
+            if (c >= k * m) v = Bk[(c - k * m) * n + pr];
+            else {
+                v = 0.0;
+                for (int l = 0; l < n; ++l) v += Ak[l * n + pr] * Gc[c * n + l];
+            }
+            Gn[t] = v;
+        }
+        for (int pr = threadIdx.x; pr < n; pr += T_) {
+            double v = p.c ? p.c[(inst * N + k) * n + pr] : 0.0;
+            for (int l = 0; l < n; ++l) v += Ak[l * n + pr] * gk[l];
+            gn[pr] = v;
+        }
+        __syncthreads();
+        { double* t = Gc; Gc = Gn; Gn = t; }
+        { double* t = gk; gk = gn; gn = t; }
+        const double* Qk = (k == N - 1) ? Ps : Qs;  // stage N+1 carries only P (src/sub/design_mpc.jl:448-456)
+        for (int t = threadIdx.x; t < n * wcols; t += T_) {
+            const int pr = t % n, c = t / n;
+            double v = 0.0;
+            for (int l = 0; l < n; ++l) v += Qk[l * n + pr] * Gc[c * n + l];
+            T[t] = v;
+        }
+        for (int pr = threadIdx.x; pr < n; pr += T_) rv[pr] = gk[pr] + (p.ebar ? p.ebar[(inst * N + k) * n + pr] : 0.0);
+        __syncthreads();
+        for (int t = threadIdx.x; t < wcols * wcols; t += T_) {
+            const int c1 = t % wcols, c2 = t / wcols;
+            double v = 0.0;
+            for (int l = 0; l < n; ++l) v += Gc[c1 * n + l] * T[c2 * n + l];
+            Hs[(size_t)c2 * nz + c1] += v;
+        }
+        for (int c = threadIdx.x; c < wcols; c += T_) {
+            double v = 0.0;
+            for (int l = 0; l < n; ++l) v += T[c * n + l] * rv[l];
+            qs[c] += v;
+        }
+        __syncthreads();
+    }
+    double* H = p.H + inst * (size_t)nz * nz;
+    for (int t = threadIdx.x; t < nz * nz; t += T_) {
+        const int r = t % nz, c = t / nz;
+        double v = 2.0 * Hs[t];
+        const int ir = r / m, ar = r % m, ic = c / m, ac = c % m;
+        if (p.useR && ir == ic) v += 2.0 * p.R[(size_t)ac * m + ar];
+        if (p.useS) {  // delta_u[:,i] = u[:,i] - u[:,i+1], i = 1..N-1 (src/sub/design_mpc.jl:429-431)
+            if (ir == ic) v += 2.0 * ((ir <= N - 2 ? 1 : 0) + (ir >= 1 ? 1 : 0)) * p.S[(size_t)ac * m + ar];
+            else if (ir - ic == 1 || ic - ir == 1) v -= 2.0 * p.S[(size_t)ac * m + ar];
+        }
+        H[t] = v;
+    }
+    for (int t = threadIdx.x; t < nz; t += T_) p.q[inst * nz + t] = 2.0 * qs[t] + (p.qadd ? p.qadd[inst * nz + t] : 0.0);
+}
+
 // fS_i = d_i .* g: the constant part of the scaled gradient (g = 2 D'Sbar D u_ref, shared or per instance) for every instance
 __global__ __launch_bounds__(256) void k_fs_scale(int batch, int nz, int nzs, const double* g, long g_stride, const double* d,
                                                   double* fS) {

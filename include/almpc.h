@@ -152,6 +152,28 @@ int almpc_design_batched(almpc_handle* h, const double* A_batch, const double* B
                          const double* R, const double* S, const double* P, int P_per_instance,
                          const double* umin, const double* umax, double rho, double sigma);
 
+/*
+ * Design with TIME-VARYING models per instance: the QP of one SQP / multiple-shooting iteration around the trajectory
+ * (xbar, ubar) of every instance (BASELINE.json configs[4]: SQP outer loop around the condensed-QP kernel; the reference has no
+ * such path -- its NLP methods were removed, CHANGELOG.md:5 -- so only the QP itself has a reference meaning: with
+ * A_k = A, B_k = B, c = 0 it is the QP of almpc_design_batched written in v = u - ubar).
+ *   A_all [batch][N][n*n], B_all [batch][N][n*m]: Jacobians of x+ = f(x, u) at (xbar_k, ubar_k), k = 0..N-1 (column-major blocks);
+ *   c_all [batch][N][n] or NULL: defects f(xbar_k, ubar_k) - xbar_{k+1};  xbar [batch][N+1][n] (xbar_0 = x0), ubar [batch][N][m];
+ *   xref [N+1][n] / uref [N][m] or NULL (zeros): references of the tracking cost, shared;  Q, R, S, umin, umax as in
+ *   almpc_design_shared;  P: terminal weight, n*n (P_per_instance = 0) or [batch][n*n] (required).
+ * Linearised dynamics dx_{k+1} = A_k dx_k + B_k v_k + c_k, dx_0 = 0, cost of src/sub/design_mpc.jl:405-468 in (xbar + dx, ubar + v),
+ * bounds umin <= ubar + v <= umax.  almpc_calculate then solves for v; almpc_get_results returns u = ubar + v and e_u = v
+ * (x / e_x are not defined for an LTV design: roll the nonlinear model out on the caller's side).  almpc_set_reference is
+ * not used with this design.  Needs nz^2 + 3 n nz + 4 n^2 + ... doubles <= 160 KB of LDS (nz <= ~120 for n = 12).
+ */
+int almpc_design_ltv(almpc_handle* h, const double* A_all, const double* B_all, const double* c_all, const double* xbar,
+                     const double* ubar, const double* xref, const double* uref, const double* Q, const double* R,
+                     const double* S, const double* P, int P_per_instance, const double* umin, const double* umax,
+                     double rho, double sigma);
+
+/* Gradient q (nz, unscaled, in v) of one instance's QP after almpc_design_ltv (parity hook; H: almpc_get_design_instance). */
+int almpc_get_gradient_instance(almpc_handle* h, int instance, double* q);
+
 /* H (nz*nz), F (nz*n), d (nz) of one instance after almpc_design_batched (any pointer may be NULL). */
 int almpc_get_design_instance(almpc_handle* h, int instance, double* H, double* F, double* d);
 
@@ -237,7 +259,8 @@ int almpc_dare(int n, int m, const double* A, const double* B, const double* Q, 
  * A_i = df/dx (n x n), B_i = df/du (n x m), both column-major, and optionally f_i = f(x_i, u_i).  Stands in for
  * AutomationLabsSystems.proceed_system_linearization (.../fnn/mpc_modeler_implementation_fnn.jl:42-46).  Layout as the
  * reference reads it from Flux.params (.../fnn/...:88-107): W_in H x (n+m) without bias or activation, L hidden layers
- * (W_h[l] H x H, b_h[l] H) with `activation` (0 identity, 1 relu), W_out n x H without bias; all column-major.
+ * (W_h[l] H x H, b_h[l] H) with `activation` (0 identity, 1 relu, 2 tanh, 3 sigmoid, 4 swish; the
+ * reference takes whatever NNlib function sits at f[2][1].sigma, src/sub/design_mpc.jl:472-483), W_out n x H without bias; all column-major.
  * Host pointers; synchronous.
  */
 int almpc_fnn_linearize(int device_id, int n, int m, int H, int L, int activation, const double* W_in,

@@ -211,6 +211,55 @@ def s_rate_gradient(p: MPCProblem):
     return 2.0 * D.T @ np.kron(np.eye(N - 1), p.S) @ D @ p.u_ref.T.reshape(-1)
 
 
+def ltv_qp(A_list, B_list, c_list, xbar, ubar, x_ref, u_ref, Q, R, S, P, u_min, u_max):
+    """QP of one SQP / multiple-shooting iteration around the trajectory (xbar n x (N+1), ubar m x N), in v = u - ubar
+    (almpc_design_ltv; BASELINE.json configs[4] -- the reference has no such path, only the QP is reference-shaped):
+        dx_{k+1} = A_k dx_k + B_k v_k + c_k, dx_0 = 0   =>   dX = Gam v + g
+        cost of src/sub/design_mpc.jl:405-468 evaluated at (xbar + dx, ubar + v), with the same R / S branch rules and the
+        S term on u itself,  bounds u_min <= ubar + v <= u_max.
+    Returns H, q, lo, hi of  min 1/2 v'Hv + q'v."""
+    N = len(A_list)
+    n, m = np.asarray(B_list[0]).shape
+    nz = m * N
+    Gam = np.zeros((n * N, nz))
+    g = np.zeros(n * N)
+    row = np.zeros((n, nz))
+    gk = np.zeros(n)
+    for k in range(N):
+        A, B = np.asarray(A_list[k], dtype=np.float64), np.asarray(B_list[k], dtype=np.float64)
+        row = A @ row
+        row[:, k * m:(k + 1) * m] = B
+        gk = A @ gk + (0.0 if c_list is None else np.asarray(c_list[k], dtype=np.float64))
+        Gam[k * n:(k + 1) * n] = row
+        g[k * n:(k + 1) * n] = gk
+    Qbar = np.zeros((n * N, n * N))
+    for k in range(N):
+        Qbar[k * n:(k + 1) * n, k * n:(k + 1) * n] = P if k == N - 1 else Q
+    xr = np.zeros((n, N + 1)) if x_ref is None else np.asarray(x_ref, dtype=np.float64)
+    ur = np.zeros((m, N)) if u_ref is None else np.asarray(u_ref, dtype=np.float64)
+    ebar = (np.asarray(xbar, dtype=np.float64)[:, 1:] - xr[:, 1:]).T.reshape(-1)
+    ub = np.asarray(ubar, dtype=np.float64).T.reshape(-1)
+    H = Gam.T @ Qbar @ Gam
+    q = Gam.T @ Qbar @ (g + ebar)
+    if R[0, 0] != 0.0:
+        H = H + np.kron(np.eye(N), R)
+        q = q + np.kron(np.eye(N), R) @ (ub - ur.T.reshape(-1))
+        if S[0, 0] != 0.0:
+            D = np.zeros((m * (N - 1), m * N))
+            for i in range(N - 1):
+                D[i * m:(i + 1) * m, i * m:(i + 1) * m] = np.eye(m)
+                D[i * m:(i + 1) * m, (i + 1) * m:(i + 2) * m] = -np.eye(m)
+            DSD = D.T @ np.kron(np.eye(N - 1), S) @ D
+            H = H + DSD
+            q = q + DSD @ ub
+    H = 2.0 * H
+    H = 0.5 * (H + H.T)
+    q = 2.0 * q
+    lo = (np.asarray(u_min, dtype=np.float64)[:, None] - np.asarray(ubar)).T.reshape(-1)
+    hi = (np.asarray(u_max, dtype=np.float64)[:, None] - np.asarray(ubar)).T.reshape(-1)
+    return H, q, lo, hi
+
+
 def condensed_qp(p: MPCProblem, x0):
     """(H, f, lo, hi) of  min 1/2 v'Hv + f'v  s.t. lo <= v <= hi  for initial state x0."""
     Phi, Gam, H, F = condense(p)
@@ -875,18 +924,32 @@ class FnnModel:
         y1 = W_in [x;u]                      (no bias, no activation)
         yj = act(W_h[j-2] y(j-1) + b_h[j-2]) j = 2..L+1
         x+ = W_out y(L+1)                    (no bias)
-    act in {"relu", "identity"} (the activation found at f[2][1].sigma, src/sub/design_mpc.jl:472-483)."""
+    act in {"identity", "relu", "tanh", "sigmoid", "swish"} (NNlib names; the activation found at f[2][1].sigma,
+    src/sub/design_mpc.jl:472-483; the NLP branch registers it as a JuMP function, .../fnn/...:120-122)."""
     W_in: np.ndarray          # H x (n+m)
     W_h: list                 # L matrices H x H
     b_h: list                 # L vectors H
     W_out: np.ndarray         # n x H
     act: str = "relu"
 
+    def _act(self, a):
+        """activation value and derivative"""
+        if self.act == "relu":
+            return np.maximum(a, 0.0), (a > 0).astype(np.float64)
+        if self.act == "tanh":
+            t = np.tanh(a)
+            return t, 1.0 - t * t
+        if self.act in ("sigmoid", "swish"):
+            s = 1.0 / (1.0 + np.exp(-a))
+            return (s, s * (1.0 - s)) if self.act == "sigmoid" else (a * s, s * (1.0 + a * (1.0 - s)))
+        if self.act == "identity":
+            return a, np.ones_like(a)
+        raise ValueError(self.act)
+
     def forward(self, x, u):
         y = self.W_in @ np.concatenate([x, u])
         for W, b in zip(self.W_h, self.b_h):
-            pre = W @ y + b
-            y = np.maximum(pre, 0.0) if self.act == "relu" else pre
+            y = self._act(W @ y + b)[0]
         return self.W_out @ y
 
     def jacobian(self, x, u):
@@ -896,14 +959,8 @@ class FnnModel:
         y = self.W_in @ np.concatenate([x, u])
         J = self.W_in.copy()
         for W, b in zip(self.W_h, self.b_h):
-            pre = W @ y + b
-            if self.act == "relu":
-                mask = (pre > 0).astype(np.float64)
-                y = np.maximum(pre, 0.0)
-                J = (W @ J) * mask[:, None]
-            else:
-                y = pre
-                J = W @ J
+            y, der = self._act(W @ y + b)
+            J = (W @ J) * der[:, None]
         J = self.W_out @ J
         n = self.W_out.shape[0]
         return J[:, :n].copy(), J[:, n:].copy()

@@ -447,16 +447,17 @@ def test_state_constraint_mirror(pkg, mo):
 # ---------------------------------------------------------------------------- black-box (Fnn) models: BASELINE config 4
 def test_fnn_jacobian_kernel_vs_oracle(capi, mo):
     """Batched linearisation on the GPU (stand-in for AutomationLabsSystems.proceed_system_linearization) vs the numpy
-    restatement, at random points on both sides of the relu kinks, for relu and identity activations."""
-    for act in ("relu", "identity"):
+    restatement, at random points on both sides of the relu kinks, for every supported activation (device tanh/exp vs
+    libm: a few ulp through two hidden layers)."""
+    for act in ("relu", "identity", "tanh", "sigmoid", "swish"):
         f = mo.synthetic_fnn(act=act)
         X = mo.splitmix_normal(0x5EED0004, 0, 200, 4) * 2.0
         U = mo.splitmix_normal(0x5EED0005, 0, 200, 2)
         A, B, fx = capi.fnn_linearize(f.W_in, f.W_h, f.b_h, f.W_out, X, U, act=act, want_f=True)
         for i in range(0, 200, 3):
             Ao, Bo = f.jacobian(X[i], U[i])
-            assert np.abs(A[i] - Ao).max() <= 1e-13 and np.abs(B[i] - Bo).max() <= 1e-13
-            assert np.abs(fx[i] - f.forward(X[i], U[i])).max() <= 1e-13
+            assert np.abs(A[i] - Ao).max() <= 1e-13 and np.abs(B[i] - Bo).max() <= 1e-13, act
+            assert np.abs(fx[i] - f.forward(X[i], U[i])).max() <= 1e-13, act
     # deeper / wider network, no hidden layer edge case
     f = mo.synthetic_fnn(n=3, m=1, H=40, L=4)
     A, B = capi.fnn_linearize(f.W_in, f.W_h, f.b_h, f.W_out, np.ones((2, 3)) * 0.3, np.ones((2, 1)) * -0.2)

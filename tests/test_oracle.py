@@ -179,7 +179,7 @@ def test_state_box_inactive_equals_box_only(mo):
 
 
 def test_fnn_jacobian_matches_finite_differences(mo):
-    for act in ("relu", "identity"):
+    for act in ("relu", "identity", "tanh", "sigmoid", "swish"):
         f = mo.synthetic_fnn(act=act)
         x, u = np.array([0.3, -0.2, 0.1, 0.4]), np.array([0.2, -0.5])
         A, B = f.jacobian(x, u)
