@@ -63,6 +63,15 @@ def load():
     L.almpc_design_ltv.restype = ctypes.c_int
     L.almpc_get_gradient_instance.argtypes = [_hp, ctypes.c_int, _dp]
     L.almpc_get_gradient_instance.restype = ctypes.c_int
+    L.almpc_sqp_fnn_setup.argtypes = [_hp, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [_dp] * 10 + [ctypes.c_int, _dp, _dp,
+                                                                                                     ctypes.c_double, ctypes.c_double]
+    L.almpc_sqp_fnn_setup.restype = ctypes.c_int
+    L.almpc_sqp_fnn_start.argtypes = [_hp, _dp, _dp]
+    L.almpc_sqp_fnn_start.restype = ctypes.c_int
+    L.almpc_sqp_fnn_iterate.argtypes = [_hp, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, _dp, _dp]
+    L.almpc_sqp_fnn_iterate.restype = ctypes.c_int
+    L.almpc_sqp_fnn_skipped.argtypes = [_hp, _ip]
+    L.almpc_sqp_fnn_skipped.restype = ctypes.c_int
     L.almpc_get_design_instance.restype = ctypes.c_int
     L.almpc_set_reference.argtypes = [_hp, _dp, _dp, ctypes.c_int]
     L.almpc_set_terminal_equality.argtypes = [_hp, ctypes.c_int]
@@ -253,6 +262,54 @@ class Solver:
         umax = np.ascontiguousarray(umax, dtype=np.float64).reshape(m)
         self._check(self.L.almpc_design_ltv(self.h, _ptr(A), _ptr(B), _ptr(c), _ptr(xb), _ptr(ub), _ptr(xr), _ptr(ur), _ptr(Q), _ptr(R),
                                             _ptr(S), _ptr(P), p_inst, _ptr(umin), _ptr(umax), float(rho), float(sigma)))
+
+    def sqp_fnn_setup(self, W_in, W_h, b_h, W_out, x_ref, u_ref, Q, R, S=None, P=None, umin=None, umax=None, act="relu", rho=0.1,
+                      sigma=1e-6, rho_profile="scalar"):
+        """SQP outer loop for an Fnn model (almpc_sqp_fnn_*): network as in fnn_linearize, x_ref (n, N+1) / u_ref (m, N) or None,
+        P (n, n) or (batch, n, n)."""
+        n, m, N, b = self.n, self.m, self.N, self.batch
+        self._check(self.L.almpc_set_terminal_equality(self.h, 0))
+        self._check(self.L.almpc_set_rho_profile(self.h, {"scalar": 0, "stiffness": 1}[rho_profile]))
+        W_in, W_out = np.asfortranarray(W_in, dtype=np.float64), np.asfortranarray(W_out, dtype=np.float64)
+        H = W_in.shape[0]
+        nl = len(W_h)
+        Wh = np.ascontiguousarray(np.stack([np.asfortranarray(W, dtype=np.float64).T for W in W_h])) if nl else np.zeros((1, 1, 1))
+        bh = np.ascontiguousarray(np.stack([np.asarray(v, dtype=np.float64) for v in b_h])) if nl else np.zeros((1, 1))
+        xr = None if x_ref is None else np.ascontiguousarray(np.asarray(x_ref, dtype=np.float64).reshape(n, N + 1).T)
+        ur = None if u_ref is None else np.ascontiguousarray(np.asarray(u_ref, dtype=np.float64).reshape(m, N).T)
+        Q, R = _colmajor(Q, (n, n)), _colmajor(R, (m, m))
+        S = None if S is None else _colmajor(S, (m, m))
+        P = np.asarray(P, dtype=np.float64)
+        p_inst = 0
+        if P.ndim == 3:
+            P = np.ascontiguousarray(P.reshape(b, n, n).transpose(0, 2, 1)); p_inst = 1
+        else:
+            P = _colmajor(P, (n, n))
+        umin = np.ascontiguousarray(umin, dtype=np.float64).reshape(m)
+        umax = np.ascontiguousarray(umax, dtype=np.float64).reshape(m)
+        self._check(self.L.almpc_sqp_fnn_setup(self.h, H, nl, FNN_ACTIVATIONS[act], _ptr(W_in), _ptr(Wh), _ptr(bh), _ptr(W_out), _ptr(xr),
+                                               _ptr(ur), _ptr(Q), _ptr(R), _ptr(S), _ptr(P), p_inst, _ptr(umin), _ptr(umax), float(rho),
+                                               float(sigma)))
+
+    def sqp_fnn_start(self, x0, u_guess=None):
+        """x0 (batch, n); u_guess (batch, m, N) or None."""
+        x0 = np.ascontiguousarray(np.asarray(x0, dtype=np.float64).reshape(self.batch, self.n))
+        ug = None if u_guess is None else np.ascontiguousarray(np.asarray(u_guess, dtype=np.float64).reshape(self.batch, self.m, self.N).transpose(0, 2, 1))
+        self._check(self.L.almpc_sqp_fnn_start(self.h, _ptr(x0), _ptr(ug)))
+
+    def sqp_fnn_iterate(self, iters, step_scale=1.0, opts=None):
+        """-> (step_inf[iters], defect_inf[iters]); raises AlmpcError(ALMPC_ERR_NUMERIC) when an instance had to skip an iteration
+        (the histories are still filled: see .sqp_last)."""
+        st, de = np.zeros(int(iters)), np.zeros(int(iters))
+        self.sqp_last = (st, de)
+        self._check(self.L.almpc_sqp_fnn_iterate(self.h, int(iters), float(step_scale), ctypes.byref(opts) if opts is not None else None,
+                                                 _ptr(st), _ptr(de)))
+        return st, de
+
+    def sqp_fnn_skipped(self):
+        out = np.zeros(self.batch, dtype=np.int32)
+        self._check(self.L.almpc_sqp_fnn_skipped(self.h, out.ctypes.data_as(_ip)))
+        return out
 
     def get_gradient_instance(self, i):
         q = np.empty(self.nz)

@@ -9,9 +9,11 @@
 #include "almpc_polish_gen.hip.h"
 #include "almpc_fnn.hip.h"
 #include "almpc_instance.hip.h"
+#include "almpc_sqp.hip.h"
 #include "almpc_host_math.h"
 #include "../../include/almpc.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -60,6 +62,18 @@ struct almpc_handle {
     double *bPhi = nullptr, *bGk = nullptr, *bGam = nullptr, *bW = nullptr, *bWP = nullptr, *bP = nullptr;
     int* bFlag = nullptr;
     bool batched_alloc = false;
+    // SQP outer loop for a black-box Fnn model (almpc_sqp_fnn_*): the network, the stage data of the current linearisation
+    struct Sqp {
+        bool ready = false, started = false;
+        int H = 0, L = 0, act = 0, useR = 0, useS = 0;
+        long sP = 0;
+        double *W_in = nullptr, *W_h = nullptr, *b_h = nullptr, *W_out = nullptr;
+        double *A = nullptr, *B = nullptr, *c = nullptr, *fval = nullptr, *ebar = nullptr, *qadd = nullptr;
+        double *xref = nullptr, *uref = nullptr, *Q = nullptr, *R = nullptr, *S = nullptr;
+        int* bad = nullptr;
+        unsigned long long* stats = nullptr;  // [iters][2]
+        int stats_cap = 0;
+    } sqp;
     // timing (ALMPC_FLAG_TIMING): one set of 4 events per step since the last almpc_timing_reset
     std::vector<hipEvent_t> ev;  // 4 per step
     size_t ev_used = 0;          // steps recorded
@@ -114,7 +128,9 @@ void free_all(almpc_handle* h) {
                     h->dXref, h->dUref, h->dFS, h->dV0S, h->dRho, h->dX0, h->dXs, h->dZs, h->dYs, h->dV0, h->dW, h->dX, h->dEx,
                     h->dU, h->dEu, h->dStatus, h->dIters, h->dPiters, h->dPerm, h->dSglobal, h->dGhat, h->dGnorm, h->dXmin,
                     h->dXmax, h->dRowTraj, h->dRowEq, h->dRowXidx, h->dRowState, h->bA, h->bB, h->bMinv, h->bG, h->bHs, h->bFs,
-                    h->bVs, h->bD, h->bRho, h->bH, h->bF, h->bPhi, h->bGk, h->bGam, h->bW, h->bWP, h->bP, h->bFlag, h->bQ};
+                    h->bVs, h->bD, h->bRho, h->bH, h->bF, h->bPhi, h->bGk, h->bGam, h->bW, h->bWP, h->bP, h->bFlag, h->bQ,
+                    h->sqp.W_in, h->sqp.W_h, h->sqp.b_h, h->sqp.W_out, h->sqp.A, h->sqp.B, h->sqp.c, h->sqp.fval, h->sqp.ebar,
+                    h->sqp.qadd, h->sqp.xref, h->sqp.uref, h->sqp.Q, h->sqp.R, h->sqp.S, h->sqp.bad, h->sqp.stats};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& e : h->ev)
@@ -332,6 +348,62 @@ struct LtvInputs {
     const double* xbar;    // [batch][(N+1)*n]
 };
 
+// Persistent per-instance operands of the batched / LTV / SQP designs (allocated once per handle).
+int ensure_batched_alloc(almpc_handle* h) {
+    const int n = h->n, m = h->m, N = h->N, nz = h->nz, nzs = h->nzs;
+    const size_t b = (size_t)h->batch;
+    const int njf = (n + 15) / 16, ps = 16 * njf, gs = nzs;
+    const int kr = ((n * N + HESS_KC - 1) / HESS_KC) * HESS_KC;
+    if (!h->batched_alloc) {
+        HIP_TRY(h, dalloc(&h->bA, b * n * n)); HIP_TRY(h, dalloc(&h->bB, b * n * m));
+        HIP_TRY(h, dalloc(&h->bMinv, b * nz * nzs)); HIP_TRY(h, dalloc(&h->bG, b * nz * nzs)); HIP_TRY(h, dalloc(&h->bHs, b * nz * nzs));
+        HIP_TRY(h, dalloc(&h->bFs, b * n * nzs)); HIP_TRY(h, dalloc(&h->bVs, b * n * nzs));
+        HIP_TRY(h, dalloc(&h->bD, b * nzs)); HIP_TRY(h, dalloc(&h->bRho, b * nzs));
+        HIP_TRY(h, dalloc(&h->bH, b * nz * nz)); HIP_TRY(h, dalloc(&h->bF, b * nz * n));
+        if (design_instance_lds_doubles(n, m, N) * sizeof(double) > 160 * 1024) {  // dense route only: Gamma panels in HBM
+            HIP_TRY(h, dalloc(&h->bPhi, b * N * n * n)); HIP_TRY(h, dalloc(&h->bGk, b * N * n * m));
+            HIP_TRY(h, dalloc(&h->bGam, b * kr * gs)); HIP_TRY(h, dalloc(&h->bW, b * kr * gs)); HIP_TRY(h, dalloc(&h->bWP, b * kr * ps));
+            // padding rows / columns of the row-major panels stay zero for the lifetime of the handle
+            HIP_TRY(h, hipMemset(h->bGam, 0, b * kr * gs * sizeof(double)));
+            HIP_TRY(h, hipMemset(h->bW, 0, b * kr * gs * sizeof(double)));
+            HIP_TRY(h, hipMemset(h->bWP, 0, b * kr * ps * sizeof(double)));
+        }
+        HIP_TRY(h, dalloc(&h->bP, b * n * n));
+        HIP_TRY(h, dalloc(&h->bFlag, b));
+        HIP_TRY(h, hipMemset(h->bHs, 0, b * nz * nzs * sizeof(double)));
+        HIP_TRY(h, hipMemset(h->bFs, 0, b * n * nzs * sizeof(double)));
+        HIP_TRY(h, hipMemset(h->bVs, 0, b * n * nzs * sizeof(double)));
+        HIP_TRY(h, hipMemset(h->bMinv, 0, b * nz * nzs * sizeof(double)));
+        HIP_TRY(h, hipMemset(h->bG, 0, b * nz * nzs * sizeof(double)));
+        h->batched_alloc = true;
+    }
+    return ALMPC_OK;
+}
+
+// H_i (column-major, in bH) -> Jacobi scaling d_i, H'_i, F'_i, G_i = H'_i^-1, rho_i, Minv_i = (H'_i + sigma I + diag(rho_i))^-1
+void launch_batched_factor(almpc_handle* h, const DesignStrides& ds, double rho, double sigma, hipStream_t st) {
+    const int n = h->n, nz = h->nz, nzs = h->nzs;
+    const unsigned gb = (unsigned)h->batch;
+    hipLaunchKernelGGL(k_design_scale, dim3(1, gb), dim3(256), 0, st, nz, nzs, n, h->bH, h->bF, h->bD, h->bHs, h->bFs, h->bFlag, ds);
+    const size_t inv_lds = 520 * sizeof(double);
+    hipLaunchKernelGGL(k_design_inverse, dim3(1, gb), dim3(512), inv_lds, st, nz, nzs, h->bHs, 0.0, (const double*)nullptr, h->bG, h->bFlag,
+                       ds.Hs, 0L, ds.G, 1L);
+    hipLaunchKernelGGL(k_design_rho, dim3(1, gb), dim3(256), 0, st, nz, nzs, h->rho_mode, rho, h->bG, h->bRho, ds.G, ds.rho);
+    hipLaunchKernelGGL(k_design_inverse, dim3(1, gb), dim3(512), inv_lds, st, nz, nzs, h->bHs, sigma, (const double*)h->bRho, h->bMinv,
+                       h->bFlag, ds.Hs, ds.rho, ds.Minv, 1L);
+}
+
+DesignStrides batched_strides(const almpc_handle* h, bool p_inst) {
+    const int n = h->n, m = h->m, N = h->N, nz = h->nz, nzs = h->nzs;
+    const int njf = (n + 15) / 16, ps = 16 * njf, gs = nzs;
+    const int kr = ((n * N + HESS_KC - 1) / HESS_KC) * HESS_KC;
+    DesignStrides ds;
+    ds.A = (long)n * n; ds.B = (long)n * m; ds.P = p_inst ? (long)n * n : 0; ds.Phi = (long)N * n * n; ds.Gk = (long)N * n * m;
+    ds.Gam = (long)kr * gs; ds.WP = (long)kr * ps; ds.H = (long)nz * nz; ds.F = (long)nz * n; ds.d = nzs; ds.Hs = (long)nz * nzs;
+    ds.Fs = (long)n * nzs; ds.G = (long)nz * nzs; ds.Minv = (long)nz * nzs; ds.rho = nzs; ds.flag = 1;
+    return ds;
+}
+
 int design_batched_common(almpc_handle* h, const double* A_batch, const double* B_batch, const double* Q, const double* R,
                           const double* S, const double* P, int P_per_instance, const double* umin, const double* umax,
                           double rho, double sigma, const LtvInputs* ltv) {
@@ -379,29 +451,7 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
     const int njf = (n + 15) / 16, ps = 16 * njf, gs = nzs;
     const int kr = ((n * N + HESS_KC - 1) / HESS_KC) * HESS_KC;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    if (!h->batched_alloc) {
-        HIP_TRY(h, dalloc(&h->bA, b * n * n)); HIP_TRY(h, dalloc(&h->bB, b * n * m));
-        HIP_TRY(h, dalloc(&h->bMinv, b * nz * nzs)); HIP_TRY(h, dalloc(&h->bG, b * nz * nzs)); HIP_TRY(h, dalloc(&h->bHs, b * nz * nzs));
-        HIP_TRY(h, dalloc(&h->bFs, b * n * nzs)); HIP_TRY(h, dalloc(&h->bVs, b * n * nzs));
-        HIP_TRY(h, dalloc(&h->bD, b * nzs)); HIP_TRY(h, dalloc(&h->bRho, b * nzs));
-        HIP_TRY(h, dalloc(&h->bH, b * nz * nz)); HIP_TRY(h, dalloc(&h->bF, b * nz * n));
-        if (design_instance_lds_doubles(n, m, N) * sizeof(double) > 160 * 1024) {  // dense route only: Gamma panels in HBM
-            HIP_TRY(h, dalloc(&h->bPhi, b * N * n * n)); HIP_TRY(h, dalloc(&h->bGk, b * N * n * m));
-            HIP_TRY(h, dalloc(&h->bGam, b * kr * gs)); HIP_TRY(h, dalloc(&h->bW, b * kr * gs)); HIP_TRY(h, dalloc(&h->bWP, b * kr * ps));
-            // padding rows / columns of the row-major panels stay zero for the lifetime of the handle
-            HIP_TRY(h, hipMemset(h->bGam, 0, b * kr * gs * sizeof(double)));
-            HIP_TRY(h, hipMemset(h->bW, 0, b * kr * gs * sizeof(double)));
-            HIP_TRY(h, hipMemset(h->bWP, 0, b * kr * ps * sizeof(double)));
-        }
-        HIP_TRY(h, dalloc(&h->bP, b * n * n));
-        HIP_TRY(h, dalloc(&h->bFlag, b));
-        HIP_TRY(h, hipMemset(h->bHs, 0, b * nz * nzs * sizeof(double)));
-        HIP_TRY(h, hipMemset(h->bFs, 0, b * n * nzs * sizeof(double)));
-        HIP_TRY(h, hipMemset(h->bVs, 0, b * n * nzs * sizeof(double)));
-        HIP_TRY(h, hipMemset(h->bMinv, 0, b * nz * nzs * sizeof(double)));
-        HIP_TRY(h, hipMemset(h->bG, 0, b * nz * nzs * sizeof(double)));
-        h->batched_alloc = true;
-    }
+    { const int rc_ = ensure_batched_alloc(h); if (rc_ != ALMPC_OK) return rc_; }
     hipStream_t st = h->stream;
     double *dQ = nullptr, *dR = nullptr, *dS = nullptr;
     HIP_TRY(h, dalloc(&dQ, (size_t)n * n)); HIP_TRY(h, dalloc(&dR, (size_t)m * m)); HIP_TRY(h, dalloc(&dS, (size_t)m * m));
@@ -418,10 +468,7 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
     BTRY(hipMemcpyAsync(dR, Rm.data(), Rm.size() * sizeof(double), hipMemcpyHostToDevice, st));
     BTRY(hipMemcpyAsync(dS, Sm.data(), Sm.size() * sizeof(double), hipMemcpyHostToDevice, st));
     BTRY(hipMemsetAsync(h->bFlag, 0, b * sizeof(int), st));
-    DesignStrides ds;
-    ds.A = (long)n * n; ds.B = (long)n * m; ds.P = p_inst ? (long)n * n : 0; ds.Phi = (long)N * n * n; ds.Gk = (long)N * n * m;
-    ds.Gam = (long)kr * gs; ds.WP = (long)kr * ps; ds.H = (long)nz * nz; ds.F = (long)nz * n; ds.d = nzs; ds.Hs = (long)nz * nzs;
-    ds.Fs = (long)n * nzs; ds.G = (long)nz * nzs; ds.Minv = (long)nz * nzs; ds.rho = nzs; ds.flag = 1;
+    const DesignStrides ds = batched_strides(h, p_inst);
     const unsigned gb = (unsigned)b;
     const size_t inst_lds = design_instance_lds_doubles(n, m, N) * sizeof(double);
     double *dAll = nullptr, *dBll = nullptr, *dC = nullptr, *dE = nullptr, *dQa = nullptr;  // LTV staging (freed below)
@@ -471,15 +518,9 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
     const size_t hess_lds = (size_t)HESS_KC * (16 + (gs + 16) + (ps + 16)) * sizeof(double);
     hipLaunchKernelGGL(k_design_hessian, dim3(nrb, gb), dim3(64 * (nrb + njf)), hess_lds, st, hp);
     }
-    hipLaunchKernelGGL(k_design_scale, dim3(1, gb), dim3(256), 0, st, nz, nzs, n, h->bH, h->bF, h->bD, h->bHs, h->bFs, h->bFlag, ds);
     BTRY(hipGetLastError());
-    const size_t inv_lds = 520 * sizeof(double);
-    BTRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_design_inverse), hipFuncAttributeMaxDynamicSharedMemorySize, (int)inv_lds));
-    hipLaunchKernelGGL(k_design_inverse, dim3(1, gb), dim3(512), inv_lds, st, nz, nzs, h->bHs, 0.0, (const double*)nullptr, h->bG, h->bFlag,
-                       ds.Hs, 0L, ds.G, 1L);
-    hipLaunchKernelGGL(k_design_rho, dim3(1, gb), dim3(256), 0, st, nz, nzs, h->rho_mode, rho, h->bG, h->bRho, ds.G, ds.rho);
-    hipLaunchKernelGGL(k_design_inverse, dim3(1, gb), dim3(512), inv_lds, st, nz, nzs, h->bHs, sigma, (const double*)h->bRho, h->bMinv,
-                       h->bFlag, ds.Hs, ds.rho, ds.Minv, 1L);
+    BTRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_design_inverse), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(520 * sizeof(double))));
+    launch_batched_factor(h, ds, rho, sigma, st);
     hipLaunchKernelGGL(k_neg_gm, dim3(4, gb), dim3(256), 0, st, nz, nzs, n, nzs, h->bG, h->bFs, h->bVs, ds.G, ds.Fs);
     BTRY(hipGetLastError());
     std::vector<int> flags(b, 0);
@@ -583,6 +624,208 @@ int almpc_get_gradient_instance(almpc_handle* h, int instance, double* q) {
     return ALMPC_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// SQP outer loop for a black-box Fnn model, resident on the device (see almpc_sqp.hip.h and include/almpc.h).
+int almpc_sqp_fnn_setup(almpc_handle* h, int H, int L, int activation, const double* W_in, const double* W_h, const double* b_h,
+                        const double* W_out, const double* xref, const double* uref, const double* Q, const double* R,
+                        const double* S, const double* P, int P_per_instance, const double* umin, const double* umax, double rho,
+                        double sigma) {
+    if (!h) return ALMPC_ERR_INVALID;
+    if (H < 1 || L < 0 || !W_in || !W_out || (L > 0 && (!W_h || !b_h)) || !Q || !R || !P || !umin || !umax)
+        return fail(h, ALMPC_ERR_INVALID, "sqp_fnn_setup: null pointer or bad network shape (P must be given)");
+    if (activation < 0 || activation > 4) return fail(h, ALMPC_ERR_UNSUPPORTED, "sqp_fnn_setup: activation must be 0..4");
+    if (!(rho > 0.0) || !(sigma >= 0.0)) return fail(h, ALMPC_ERR_INVALID, "sqp_fnn_setup: rho must be > 0 and sigma >= 0");
+    if (h->terminal_eq) return fail(h, ALMPC_ERR_UNSUPPORTED, "sqp_fnn_setup: state rows (terminal equality) need a shared model");
+    const int n = h->n, m = h->m, N = h->N, nz = h->nz, nzs = h->nzs;
+    const size_t b = (size_t)h->batch, nin = (size_t)n + m;
+    if (n > 64) return fail(h, ALMPC_ERR_UNSUPPORTED, "sqp_fnn_setup: n <= 64 (one lane per state in the update kernel)");
+    if (design_ltv_lds_doubles(n, m, N) * sizeof(double) > 160 * 1024)
+        return fail(h, ALMPC_ERR_UNSUPPORTED, "sqp_fnn_setup: nz^2 + 3 n nz doubles must fit the 160 KB of LDS");
+    if ((2 * (size_t)H + 2 * (size_t)H * nin + nin) * sizeof(double) > 160 * 1024)
+        return fail(h, ALMPC_ERR_UNSUPPORTED, "sqp_fnn_setup: the network's forward-mode Jacobian must fit the 160 KB of LDS");
+    for (int i = 0; i < m; ++i)
+        if (!(umin[i] <= umax[i])) return fail(h, ALMPC_ERR_INVALID, "sqp_fnn_setup: umin > umax");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    auto sym = [](const double* M, int k) {
+        hm::mat o((size_t)k * k, 0.0);
+        if (M)
+            for (int j = 0; j < k; ++j)
+                for (int i = 0; i < k; ++i) o[(size_t)j * k + i] = 0.5 * (M[(size_t)j * k + i] + M[(size_t)i * k + j]);
+        return o;
+    };
+    const hm::mat Qm = sym(Q, n), Rm = sym(R, m), Sm = sym(S, m);
+    const bool p_inst = P_per_instance != 0;
+    hm::mat Pall((p_inst ? b : 1) * (size_t)n * n);
+    for (size_t i = 0; i < (p_inst ? b : 1); ++i) {
+        const hm::mat Pm = sym(P + i * n * n, n);
+        std::copy(Pm.begin(), Pm.end(), Pall.begin() + i * n * n);
+    }
+    { const int rc_ = ensure_batched_alloc(h); if (rc_ != ALMPC_OK) return rc_; }
+    almpc_handle::Sqp& q = h->sqp;
+    void* old[] = {q.W_in, q.W_h, q.b_h, q.W_out, q.A, q.B, q.c, q.fval, q.ebar, q.qadd, q.xref, q.uref, q.Q, q.R, q.S, q.bad, q.stats,
+                   h->dXref, h->dUref, h->dFS, h->dV0S};
+    for (void* p_ : old)
+        if (p_) (void)hipFree(p_);
+    q = almpc_handle::Sqp();
+    h->dXref = h->dUref = h->dFS = h->dV0S = nullptr;
+    auto up = [&](double** d, const double* src, size_t cnt) -> hipError_t {
+        hipError_t e = dalloc(d, cnt ? cnt : 1);
+        if (e == hipSuccess && src && cnt) e = hipMemcpy(*d, src, cnt * sizeof(double), hipMemcpyHostToDevice);
+        return e;
+    };
+    std::vector<double> xr((size_t)n * (N + 1), 0.0), ur((size_t)nz, 0.0);
+    if (xref) xr.assign(xref, xref + xr.size());
+    if (uref) ur.assign(uref, uref + ur.size());
+    HIP_TRY(h, up(&q.W_in, W_in, (size_t)H * nin)); HIP_TRY(h, up(&q.W_h, W_h, (size_t)L * H * H)); HIP_TRY(h, up(&q.b_h, b_h, (size_t)L * H));
+    HIP_TRY(h, up(&q.W_out, W_out, (size_t)n * H));
+    HIP_TRY(h, up(&q.A, nullptr, b * N * n * n)); HIP_TRY(h, up(&q.B, nullptr, b * N * n * m)); HIP_TRY(h, up(&q.c, nullptr, b * N * n));
+    HIP_TRY(h, up(&q.fval, nullptr, b * N * n)); HIP_TRY(h, up(&q.ebar, nullptr, b * N * n)); HIP_TRY(h, up(&q.qadd, nullptr, b * nz));
+    HIP_TRY(h, up(&q.xref, xr.data(), xr.size())); HIP_TRY(h, up(&q.uref, ur.data(), ur.size()));
+    HIP_TRY(h, up(&q.Q, Qm.data(), Qm.size())); HIP_TRY(h, up(&q.R, Rm.data(), Rm.size())); HIP_TRY(h, up(&q.S, Sm.data(), Sm.size()));
+    HIP_TRY(h, dalloc(&q.bad, b));
+    HIP_TRY(h, hipMemset(q.bad, 0, b * sizeof(int)));
+    if (!h->bQ) HIP_TRY(h, dalloc(&h->bQ, b * nz));
+    HIP_TRY(h, dalloc(&h->dXref, b * (size_t)n * (N + 1))); HIP_TRY(h, dalloc(&h->dUref, b * nz));
+    HIP_TRY(h, dalloc(&h->dFS, b * nz)); HIP_TRY(h, dalloc(&h->dV0S, b * nz));
+    HIP_TRY(h, hipMemcpy(h->bP, Pall.data(), Pall.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->dUmin, umin, m * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->dUmax, umax, m * sizeof(double), hipMemcpyHostToDevice));
+    // F_i = 0 for an LTV design (the gradient is explicit), so F'_i and V_i stay zero; stage-0 model slots are unused but read
+    HIP_TRY(h, hipMemset(h->bF, 0, b * nz * n * sizeof(double)));
+    HIP_TRY(h, hipMemset(h->bFs, 0, b * n * nzs * sizeof(double)));
+    HIP_TRY(h, hipMemset(h->bVs, 0, b * n * nzs * sizeof(double)));
+    HIP_TRY(h, hipMemset(h->bA, 0, b * n * n * sizeof(double)));
+    HIP_TRY(h, hipMemset(h->bB, 0, b * n * m * sizeof(double)));
+    q.H = H; q.L = L; q.act = activation; q.useR = Rm[0] != 0.0; q.useS = q.useR && Sm[0] != 0.0; q.sP = p_inst ? (long)n * n : 0;
+    h->P.assign(Pall.begin(), Pall.begin() + (size_t)n * n);
+    h->hS = Sm;
+    h->rho = rho; h->sigma = sigma;
+    h->has_box = 0; h->mc = 0; h->R = nz; h->np_pairs = 1; h->Rs = 128;
+    h->xref_stride = (long)n * (N + 1); h->uref_stride = nz; h->fS_stride = nz;
+    h->designed = false;  // becomes true with the first iteration's design
+    h->batched = true; h->ltv = true;
+    q.ready = true; q.started = false;
+    return ALMPC_OK;
+}
+
+int almpc_sqp_fnn_start(almpc_handle* h, const double* x0, const double* u_guess) {
+    if (!h || !x0) return h ? fail(h, ALMPC_ERR_INVALID, "sqp_fnn_start: null x0") : ALMPC_ERR_INVALID;
+    almpc_handle::Sqp& q = h->sqp;
+    if (!q.ready) return fail(h, ALMPC_ERR_NOT_DESIGNED, "sqp_fnn_start before sqp_fnn_setup");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int n = h->n, m = h->m, N = h->N, nz = h->nz;
+    const size_t b = (size_t)h->batch;
+    hipStream_t st = h->stream;
+    HIP_TRY(h, hipStreamSynchronize(st));
+    HIP_TRY(h, hipMemcpy(h->dX0, x0, b * n * sizeof(double), hipMemcpyHostToDevice));
+    if (u_guess) {
+        std::vector<double> ug(u_guess, u_guess + b * nz), lo(m), hi(m);
+        HIP_TRY(h, hipMemcpy(lo.data(), h->dUmin, m * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(hi.data(), h->dUmax, m * sizeof(double), hipMemcpyDeviceToHost));
+        for (size_t t = 0; t < ug.size(); ++t) ug[t] = std::min(std::max(ug[t], lo[t % m]), hi[t % m]);
+        HIP_TRY(h, hipMemcpy(h->dUref, ug.data(), ug.size() * sizeof(double), hipMemcpyHostToDevice));
+    } else {  // the input reference, clipped to the box
+        std::vector<double> ur(nz), lo(m), hi(m), ug(b * nz);
+        HIP_TRY(h, hipMemcpy(ur.data(), q.uref, nz * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(lo.data(), h->dUmin, m * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(hi.data(), h->dUmax, m * sizeof(double), hipMemcpyDeviceToHost));
+        for (size_t t = 0; t < ug.size(); ++t) ug[t] = std::min(std::max(ur[t % nz], lo[t % m]), hi[t % m]);
+        HIP_TRY(h, hipMemcpy(h->dUref, ug.data(), ug.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    FnnRolloutParams rp;
+    rp.n = n; rp.m = m; rp.H = q.H; rp.L = q.L; rp.act = q.act; rp.N = N;
+    rp.W_in = q.W_in; rp.W_h = q.W_h; rp.b_h = q.b_h; rp.W_out = q.W_out; rp.x0 = h->dX0; rp.ubar = h->dUref; rp.xbar = h->dXref;
+    const size_t l = (2 * (size_t)q.H + n + m) * sizeof(double);
+    if (l > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_fnn_rollout), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l));
+    hipLaunchKernelGGL(k_fnn_rollout, dim3((unsigned)b), dim3(256), l, st, rp);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemsetAsync(q.bad, 0, b * sizeof(int), st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    q.started = true;
+    return ALMPC_OK;
+}
+
+int almpc_sqp_fnn_iterate(almpc_handle* h, int iters, double step_scale, const almpc_opts* opts, double* step_inf, double* defect_inf) {
+    if (!h) return ALMPC_ERR_INVALID;
+    almpc_handle::Sqp& q = h->sqp;
+    if (!q.ready || !q.started) return fail(h, ALMPC_ERR_NOT_DESIGNED, "sqp_fnn_iterate needs sqp_fnn_setup and sqp_fnn_start");
+    if (iters < 1 || !(step_scale > 0.0 && step_scale <= 1.0)) return fail(h, ALMPC_ERR_INVALID, "sqp_fnn_iterate: iters >= 1, 0 < step_scale <= 1");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int n = h->n, m = h->m, N = h->N, nz = h->nz, nzs = h->nzs;
+    const size_t b = (size_t)h->batch, nin = (size_t)n + m;
+    hipStream_t st = h->stream;
+    if (q.stats_cap < iters) {
+        if (q.stats) { HIP_TRY(h, hipStreamSynchronize(st)); (void)hipFree(q.stats); q.stats = nullptr; }
+        HIP_TRY(h, dalloc(&q.stats, (size_t)2 * iters));
+        q.stats_cap = iters;
+    }
+    HIP_TRY(h, hipMemsetAsync(q.stats, 0, (size_t)2 * iters * sizeof(unsigned long long), st));
+    const size_t fnn_lds = (2 * (size_t)q.H + 2 * (size_t)q.H * nin + nin) * sizeof(double);
+    const size_t ltv_lds = design_ltv_lds_doubles(n, m, N) * sizeof(double);
+    if (fnn_lds > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_fnn_jacobian), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fnn_lds));
+    if (ltv_lds > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_design_ltv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ltv_lds));
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_design_inverse), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(520 * sizeof(double))));
+    const DesignStrides ds = batched_strides(h, q.sP != 0);
+    FnnParams fp;
+    fp.n = n; fp.m = m; fp.H = q.H; fp.L = q.L; fp.act = q.act; fp.batch = (int)(b * N);
+    fp.W_in = q.W_in; fp.W_h = q.W_h; fp.b_h = q.b_h; fp.W_out = q.W_out;
+    fp.x = h->dXref; fp.u = h->dUref; fp.ppi = N; fp.xs_group = (long)n * (N + 1); fp.us_group = nz;
+    fp.A = q.A; fp.B = q.B; fp.f = q.fval;
+    SqpParams sp;
+    sp.n = n; sp.m = m; sp.N = N; sp.nz = nz; sp.batch = h->batch; sp.useR = q.useR; sp.useS = q.useS;
+    sp.xref = q.xref; sp.uref = q.uref; sp.R = q.R; sp.S = q.S; sp.umin = h->dUmin; sp.umax = h->dUmax;
+    sp.xbar = h->dXref; sp.ubar = h->dUref; sp.fval = q.fval; sp.A = q.A; sp.B = q.B; sp.c = q.c; sp.ebar = q.ebar; sp.qadd = q.qadd;
+    sp.v = h->dEu; sp.flag = h->bFlag; sp.status = h->dStatus; sp.bad = q.bad; sp.stats = q.stats; sp.step_scale = step_scale;
+    sp.x = h->dX; sp.ex = h->dEx; sp.u = h->dU; sp.eu = h->dEu;
+    DesignLtvParams lp;
+    lp.n = n; lp.m = m; lp.N = N; lp.nz = nz; lp.useR = q.useR; lp.useS = q.useS;
+    lp.A = q.A; lp.B = q.B; lp.c = q.c; lp.ebar = q.ebar; lp.P = h->bP; lp.sP = q.sP; lp.Q = q.Q; lp.R = q.R; lp.S = q.S;
+    lp.qadd = q.qadd; lp.H = h->bH; lp.q = h->bQ;
+    for (int it = 0; it < iters; ++it) {
+        hipLaunchKernelGGL(k_fnn_jacobian, dim3((unsigned)(b * N)), dim3(256), fnn_lds, st, fp);
+        hipLaunchKernelGGL(k_sqp_prepare, dim3((unsigned)b), dim3(256), 0, st, sp);
+        HIP_TRY(h, hipMemsetAsync(h->bFlag, 0, b * sizeof(int), st));
+        hipLaunchKernelGGL(k_design_ltv, dim3((unsigned)b), dim3(256), ltv_lds, st, lp);
+        launch_batched_factor(h, ds, h->rho, h->sigma, st);
+        hipLaunchKernelGGL(k_fs_scale, dim3(256), dim3(256), 0, st, h->batch, nz, nzs, h->bQ, (long)nz, h->bD, h->dFS);
+        hipLaunchKernelGGL(k_neg_gm, dim3(1, (unsigned)b), dim3(256), 0, st, nz, nzs, 1, nz, h->bG, h->dFS, h->dV0S, (long)nz * nzs, (long)nz);
+        HIP_TRY(h, hipGetLastError());
+        h->designed = true;
+        const int rc = almpc_calculate_async(h, opts);
+        if (rc != ALMPC_OK) return rc;
+        sp.stats = q.stats + 2 * it;
+        hipLaunchKernelGGL(k_sqp_step, dim3((unsigned)b), dim3(64), 0, st, sp);
+        HIP_TRY(h, hipGetLastError());
+    }
+    std::vector<unsigned long long> stats((size_t)2 * iters);
+    std::vector<int> bad(b);
+    HIP_TRY(h, hipMemcpyAsync(stats.data(), q.stats, stats.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(bad.data(), q.bad, b * sizeof(int), hipMemcpyDeviceToHost, st));
+    { const int rc = almpc_synchronize(h); if (rc != ALMPC_OK) return rc; }
+    for (int it = 0; it < iters; ++it) {
+        double a, c2;
+        std::memcpy(&a, &stats[2 * it], 8); std::memcpy(&c2, &stats[2 * it + 1], 8);
+        if (step_inf) step_inf[it] = a;
+        if (defect_inf) defect_inf[it] = c2;
+    }
+    for (size_t i = 0; i < b; ++i)
+        if (bad[i])
+            return fail(h, ALMPC_ERR_NUMERIC, "sqp_fnn_iterate: instance " + std::to_string(i) +
+                        ": an iteration was skipped (condensed Hessian not positive definite to working precision, or a non-finite QP "
+                        "solution); its iterate is the last good one, the other instances are unaffected");
+    return ALMPC_OK;
+}
+
+int almpc_sqp_fnn_skipped(almpc_handle* h, int32_t* skipped) {
+    if (!h || !skipped) return ALMPC_ERR_INVALID;
+    if (!h->sqp.ready) return fail(h, ALMPC_ERR_NOT_DESIGNED, "sqp_fnn_skipped before sqp_fnn_setup");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(skipped, h->sqp.bad, (size_t)h->batch * sizeof(int), hipMemcpyDeviceToHost));
+    return ALMPC_OK;
+}
+
 int almpc_get_design_instance(almpc_handle* h, int instance, double* H, double* F, double* d) {
     if (!h) return ALMPC_ERR_INVALID;
     if (!h->designed || !h->batched) return fail(h, ALMPC_ERR_NOT_DESIGNED, "get_design_instance needs almpc_design_batched");
@@ -606,6 +849,7 @@ int almpc_set_reference(almpc_handle* h, const double* xref, const double* uref,
     const size_t cnt = per_instance ? (size_t)h->batch : 1;
     const size_t xs = (size_t)n * (N + 1), us = (size_t)nz;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->sqp.ready = h->sqp.started = false;  // the SQP iterate lived in the reference buffers released here
     if (h->dXref) { (void)hipFree(h->dXref); h->dXref = nullptr; }
     if (h->dUref) { (void)hipFree(h->dUref); h->dUref = nullptr; }
     if (h->dFS) { (void)hipFree(h->dFS); h->dFS = nullptr; }
@@ -1029,6 +1273,7 @@ int almpc_fnn_linearize(int device_id, int n, int m, int H, int L, int activatio
     };
     FnnParams p;
     p.n = n; p.m = m; p.H = H; p.L = L; p.act = activation; p.batch = batch;
+    p.ppi = 1; p.xs_group = n; p.us_group = m;
     p.W_in = up(W_in, (size_t)H * nin); p.W_h = up(W_h, (size_t)L * H * H); p.b_h = up(b_h, (size_t)L * H);
     p.W_out = up(W_out, (size_t)n * H); p.x = up(x, (size_t)batch * n); p.u = up(u, (size_t)batch * m);
     p.A = up(nullptr, (size_t)batch * n * n); p.B = up(nullptr, (size_t)batch * n * m); p.f = f ? up(nullptr, (size_t)batch * n) : nullptr;

@@ -17,8 +17,9 @@ struct FnnParams {
     const double* b_h;    // [L] H
     const double* W_out;  // n x H column-major
     int batch;
-    const double* x;      // [batch][n]
-    const double* u;      // [batch][m]
+    const double* x;      // point t = (g, k), g = t / ppi, k = t % ppi:  x + g * xs_group + k * n   (ppi = 1, xs_group = n: [batch][n])
+    const double* u;      //                                               u + g * us_group + k * m
+    int ppi; long xs_group, us_group;  // points per group and group strides: the stages of one trajectory [ (N+1) n | N m ]
     double* A;            // [batch] n x n column-major
     double* B;            // [batch] n x m column-major
     double* f;            // [batch][n] or null
@@ -44,7 +45,9 @@ __global__ __launch_bounds__(256) void k_fnn_jacobian(FnnParams p) {
     double* Jn = J + (size_t)H * nin;
     double* z = Jn + (size_t)H * nin;  // [nin]
     const int inst = blockIdx.x;
-    for (int t = threadIdx.x; t < nin; t += blockDim.x) z[t] = t < n ? p.x[(size_t)inst * n + t] : p.u[(size_t)inst * m + (t - n)];
+    const double* xp = p.x + (size_t)(inst / p.ppi) * p.xs_group + (size_t)(inst % p.ppi) * n;
+    const double* up = p.u + (size_t)(inst / p.ppi) * p.us_group + (size_t)(inst % p.ppi) * m;
+    for (int t = threadIdx.x; t < nin; t += blockDim.x) z[t] = t < n ? xp[t] : up[t - n];
     __syncthreads();
     for (int i = threadIdx.x; i < H; i += blockDim.x) {
         double s = 0.0;

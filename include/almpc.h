@@ -174,6 +174,35 @@ int almpc_design_ltv(almpc_handle* h, const double* A_all, const double* B_all, 
 /* Gradient q (nz, unscaled, in v) of one instance's QP after almpc_design_ltv (parity hook; H: almpc_get_design_instance). */
 int almpc_get_gradient_instance(almpc_handle* h, int instance, double* q);
 
+/*
+ * SQP outer loop for a black-box Fnn model, resident on the device (BASELINE configs[4]).  The problem is the reference's
+ * NonLinearProgramming branch for Fnn models (.../fnn/mpc_modeler_implementation_fnn.jl:73-189): the quadratic cost of
+ * _create_quadratic_cost_function (src/sub/design_mpc.jl:405-468) subject to x[:,k+1] = fnn(x[:,k], u[:,k]) and the input box,
+ * which the reference hands to Ipopt (src/sub/solver_selection.jl:100-104).  Here: Gauss-Newton SQP with multiple shooting and
+ * steps of length `step_scale`; every iteration = k_fnn_jacobian along the trajectory, the time-varying condensed QP of
+ * almpc_design_ltv, the per-instance step kernels, and the trajectory update -- all on the handle's stream, no host round trip.
+ * A fixed point (step and defects zero) is a KKT point of the NLP: the QP gradient is the exact NLP gradient.
+ *
+ *   setup    network in the layout of almpc_fnn_linearize, shared references xref n*(N+1) / uref m*N (NULL: zeros), weights,
+ *            P (required; shared or per instance), input box, ADMM rho/sigma.  Replaces any earlier design of the handle.
+ *   start    x0 [batch][n]; u_guess [batch][N][m] or NULL (the input reference); both clipped to the box.  The state
+ *            trajectory starts as the network's own rollout from x0 (zero defects).
+ *   iterate  `iters` iterations with QP options `opts` (NULL: defaults).  step_inf[it] / defect_inf[it] (nullable, length
+ *            iters): max over the batch of |v|_inf and of |f(xbar,ubar) - xbar+|_inf BEFORE iteration it's update.
+ *            Afterwards almpc_get_results returns the iterate: x, u, e_x = x - xref, e_u = u - uref, status/iters of the last QP.
+ *            An instance whose condensed Hessian is not positive definite to working precision (open-loop unstable
+ *            linearisation over a long horizon) or whose QP solution is non-finite keeps its last good iterate; the call then
+ *            returns ALMPC_ERR_NUMERIC after finishing all other instances; almpc_sqp_fnn_skipped tells which.
+ */
+int almpc_sqp_fnn_setup(almpc_handle* h, int H, int L, int activation, const double* W_in, const double* W_h, const double* b_h,
+                        const double* W_out, const double* xref, const double* uref, const double* Q, const double* R,
+                        const double* S, const double* P, int P_per_instance, const double* umin, const double* umax, double rho,
+                        double sigma);
+int almpc_sqp_fnn_start(almpc_handle* h, const double* x0, const double* u_guess);
+int almpc_sqp_fnn_iterate(almpc_handle* h, int iters, double step_scale, const almpc_opts* opts, double* step_inf,
+                          double* defect_inf);
+int almpc_sqp_fnn_skipped(almpc_handle* h, int32_t* skipped /* [batch], 1 = some iteration was skipped */);
+
 /* H (nz*nz), F (nz*n), d (nz) of one instance after almpc_design_batched (any pointer may be NULL). */
 int almpc_get_design_instance(almpc_handle* h, int instance, double* H, double* F, double* d);
 

@@ -1007,6 +1007,85 @@ def fnn_linear_problem(model: FnnModel, N, u_min, u_max, x_ref, u_ref, **kw):
 
 
 # --------------------------------------------------------------------------------------
+# NLP branch for black-box models: the problem the reference hands to Ipopt
+# (.../fnn/mpc_modeler_implementation_fnn.jl:73-189 + src/sub/design_mpc.jl:405-468)
+# --------------------------------------------------------------------------------------
+def fnn_rollout(model: FnnModel, x0, U):
+    """x (n, N+1) of the network driven by U (m, N) from x0."""
+    N = U.shape[1]
+    X = np.empty((x0.size, N + 1))
+    X[:, 0] = x0
+    for k in range(N):
+        X[:, k + 1] = model.forward(X[:, k], U[:, k])
+    return X
+
+
+def nlp_cost_and_gradient(model: FnnModel, x0, U, x_ref, u_ref, Q, R, S, P):
+    """Single-shooting statement of the reference's NLP (states eliminated through the network): the cost of
+    src/sub/design_mpc.jl:405-468 -- sum_{i=1..N} e_x_i'Q e_x_i + e_u_i'R e_u_i, terminal e_x_{N+1}'P e_x_{N+1}, rate term
+    sum_{i<N} (u_i - u_{i+1})'S(u_i - u_{i+1}) on u itself -- and its exact gradient in U by the adjoint recursion.
+    The R/S branch rules (only element [1,1] is tested, :423-465) are the caller's business: pass zeros to switch a term off."""
+    n, N = x0.size, U.shape[1]
+    X = fnn_rollout(model, x0, U)
+    EX, EU = X - x_ref, U - u_ref
+    J = float(EX[:, N] @ P @ EX[:, N])
+    for k in range(N):
+        J += float(EX[:, k] @ Q @ EX[:, k] + EU[:, k] @ R @ EU[:, k])
+    for k in range(N - 1):
+        du = U[:, k] - U[:, k + 1]
+        J += float(du @ S @ du)
+    G = np.zeros_like(U)
+    lam = 2.0 * (0.5 * (P + P.T)) @ EX[:, N]
+    Qs, Rs, Ss = 0.5 * (Q + Q.T), 0.5 * (R + R.T), 0.5 * (S + S.T)
+    for k in range(N - 1, -1, -1):
+        A, B = model.jacobian(X[:, k], U[:, k])
+        G[:, k] = 2.0 * Rs @ EU[:, k] + B.T @ lam
+        lam = A.T @ lam + (2.0 * Qs @ EX[:, k] if k > 0 else 0.0)
+    for k in range(N - 1):
+        du = 2.0 * Ss @ (U[:, k] - U[:, k + 1])
+        G[:, k] += du
+        G[:, k + 1] -= du
+    return J, G, X
+
+
+def nlp_kkt_residual(model: FnnModel, x0, U, x_ref, u_ref, Q, R, S, P, u_min, u_max):
+    """Method-independent first-order certificate of a candidate U (m, N) for the box-constrained NLP: the projected-gradient
+    residual |U - clip(U - D^2 G)|_inf in Jacobi-scaled coordinates (D^2 = 1 / diag of the Gauss-Newton Hessian would need the
+    QP; the plain gradient scaled by 1/(2 R_aa) is used), zero exactly at KKT points."""
+    _, G, _ = nlp_cost_and_gradient(model, x0, U, x_ref, u_ref, Q, R, S, P)
+    sc = 1.0 / np.maximum(2.0 * np.diag(R), 1e-12)
+    T = np.clip(U - sc[:, None] * G, u_min[:, None], u_max[:, None])
+    return float(np.abs(U - T).max())
+
+
+def sqp_fnn(model: FnnModel, x0, x_ref, u_ref, Q, R, S, P, u_min, u_max, iters, u_guess=None, step_scale=1.0):
+    """CPU restatement of the device loop almpc_sqp_fnn_*: Gauss-Newton SQP with multiple shooting, every QP solved exactly
+    (solve_box_qp_exact).  Returns X (n, N+1), U (m, N) and the per-iteration (|v|_inf, |defect|_inf) history."""
+    m, N = u_ref.shape
+    U = np.clip(u_ref if u_guess is None else u_guess, u_min[:, None], u_max[:, None]).astype(np.float64)
+    X = fnn_rollout(model, x0, U)
+    hist = []
+    useR = R[0, 0] != 0.0
+    Rz = R if useR else 0.0 * R
+    Sz = S if (useR and S[0, 0] != 0.0) else 0.0 * S
+    for _ in range(iters):
+        A, B, c = [], [], []
+        for k in range(N):
+            a, b = model.jacobian(X[:, k], U[:, k])
+            A.append(a); B.append(b); c.append(model.forward(X[:, k], U[:, k]) - X[:, k + 1])
+        H, q, lo, hi = ltv_qp(A, B, c, X, U, x_ref, u_ref, Q, Rz, Sz, P, u_min, u_max)
+        v = solve_box_qp_exact(H, q, lo, hi).reshape(N, m).T
+        hist.append((float(np.abs(v).max()), float(np.abs(np.array(c)).max())))
+        dx = np.zeros(x0.size)
+        Xn = X.copy()
+        for k in range(N):
+            dx = A[k] @ dx + B[k] @ v[:, k] + c[k]
+            Xn[:, k + 1] = X[:, k + 1] + step_scale * dx
+        X, U = Xn, np.clip(U + step_scale * v, u_min[:, None], u_max[:, None])
+    return X, U, hist
+
+
+# --------------------------------------------------------------------------------------
 # fixtures and synthetic configurations (SURVEY.md section 8c / 8d)
 # --------------------------------------------------------------------------------------
 def decode_linear_regressor_fixture(blob: bytes):

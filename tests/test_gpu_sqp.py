@@ -1,0 +1,138 @@
+"""GPU tests of the device-resident SQP loop for black-box Fnn models (almpc_sqp_fnn_*; BASELINE.json configs[4]).  The problem is
+the reference's NonLinearProgramming branch for Fnn (.../fnn/mpc_modeler_implementation_fnn.jl:73-189), which it gives to Ipopt;
+neither is runnable here, so the checks are (i) the numpy restatement of the same loop with exact QP solves, iteration by
+iteration, and (ii) a method-independent first-order certificate of the NLP itself (adjoint gradient, projected)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+U_TOL = 1e-5
+
+
+def _setup(capi, mo, b, N, act="tanh", S=None, amp=0.6):
+    f = mo.synthetic_fnn(act=act)
+    n, m = 4, 2
+    x_ref = np.tile(np.array([0.2, -0.1, 0.05, 0.0])[:, None], (1, N + 1)); u_ref = np.tile(np.array([0.1, -0.2])[:, None], (1, N))
+    X0 = x_ref[:, 0][None, :] + amp * mo.splitmix_normal(0x5EED0005, 0, b, n)
+    Q, R, P = 100.0 * np.eye(n), 0.1 * np.eye(m), 150.0 * np.eye(n)
+    S = np.zeros((m, m)) if S is None else S
+    umin, umax = -np.ones(m), np.ones(m)
+    s = capi.Solver(n, m, N, b)
+    s.sqp_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, x_ref, u_ref, Q, R, S, P, umin, umax, act=act)
+    return f, s, dict(x_ref=x_ref, u_ref=u_ref, Q=Q, R=R, S=S, P=P, u_min=umin, u_max=umax), X0
+
+
+def test_config5_sqp_vs_restatement_and_nlp_certificate(capi, mo):
+    """N = 50, Fnn 4-2-16x2 (tanh), 32 instances: 30 full-step iterations on the device."""
+    b, N, iters = 32, 50, 30
+    f, s, kw, X0 = _setup(capi, mo, b, N)
+    s.sqp_fnn_start(X0)
+    st, de = s.sqp_fnn_iterate(iters)
+    r = s.get_results()
+    s.close()
+    assert np.all(r["status"] == 0)
+    assert st[0] > 1e-2 and st[-1] <= 1e-7 and de[-1] <= 1e-12, (st, de)
+    for i in (0, 7, 19, 31):
+        X, U, hist = mo.sqp_fnn(f, X0[i], kw["x_ref"], kw["u_ref"], kw["Q"], kw["R"], kw["S"], kw["P"], kw["u_min"], kw["u_max"], iters)
+        assert np.abs(r["u"][i] - U).max() <= U_TOL
+        assert np.abs(r["x"][i] - X).max() <= 1e-5
+    for i in range(b):   # every instance: KKT point of the NLP, trajectory consistent with the network
+        U = r["u"][i]
+        assert np.abs(r["x"][i] - mo.fnn_rollout(f, X0[i], U)).max() <= 1e-9
+        assert mo.nlp_kkt_residual(f, X0[i], U, kw["x_ref"], kw["u_ref"], kw["Q"], kw["R"], kw["S"], kw["P"], kw["u_min"], kw["u_max"]) <= 1e-5
+        assert np.all(U <= 1.0) and np.all(U >= -1.0)
+    assert np.abs(r["e_u"] - (r["u"] - kw["u_ref"][None])).max() <= 1e-15
+    assert np.abs(r["e_x"] - (r["x"] - kw["x_ref"][None])).max() <= 1e-15
+
+
+def test_sqp_histories_match_the_restatement_per_iteration(capi, mo):
+    """Batch of one... of three: the device's per-iteration step / defect norms are maxima over the batch of the restatement's."""
+    b, N, iters = 3, 20, 6
+    f, s, kw, X0 = _setup(capi, mo, b, N, S=0.2 * np.eye(2))
+    ug = 0.4 * mo.splitmix_normal(0x5EED0008, 0, b, 2 * N).reshape(b, 2, N)
+    s.sqp_fnn_start(X0, ug)
+    st, de = s.sqp_fnn_iterate(iters, step_scale=0.75)
+    r = s.get_results(want=("u", "x"))
+    s.close()
+    H = []
+    for i in range(b):
+        X, U, hist = mo.sqp_fnn(f, X0[i], kw["x_ref"], kw["u_ref"], kw["Q"], kw["R"], kw["S"], kw["P"], kw["u_min"], kw["u_max"], iters,
+                                u_guess=ug[i], step_scale=0.75)
+        H.append(hist)
+        assert np.abs(r["u"][i] - U).max() <= U_TOL and np.abs(r["x"][i] - X).max() <= 1e-5
+    H = np.array(H)   # (b, iters, 2)
+    np.testing.assert_allclose(st, H[:, :, 0].max(axis=0), rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(de, H[:, :, 1].max(axis=0), rtol=1e-4, atol=1e-9)
+
+
+def test_sqp_continues_across_calls_and_restarts(capi, mo):
+    b, N = 8, 20
+    f, s, kw, X0 = _setup(capi, mo, b, N)
+    s.sqp_fnn_start(X0)
+    s.sqp_fnn_iterate(5)
+    s.sqp_fnn_iterate(7)
+    u12 = s.get_results(want=("u",))["u"].copy()
+    s.sqp_fnn_start(X0)
+    s.sqp_fnn_iterate(12)
+    u12b = s.get_results(want=("u",))["u"]
+    assert np.abs(u12 - u12b).max() == 0.0     # same kernels, same inputs: bit-identical
+    s.close()
+
+
+def test_sqp_error_behaviour(capi, mo):
+    f = mo.synthetic_fnn(act="tanh")
+    s = capi.Solver(4, 2, 10, 4)
+    with pytest.raises(capi.AlmpcError) as ei:
+        s.sqp_fnn_start(np.zeros((4, 4)))
+    assert ei.value.code == -5
+    with pytest.raises(capi.AlmpcError) as ei:
+        s.sqp_fnn_iterate(1)
+    assert ei.value.code == -5
+    s.close()
+    f2, s, kw, X0 = _setup(capi, mo, 4, 10)
+    with pytest.raises(capi.AlmpcError):
+        s.sqp_fnn_iterate(1)                    # not started
+    s.sqp_fnn_start(X0)
+    with pytest.raises(capi.AlmpcError):
+        s.sqp_fnn_iterate(0)
+    with pytest.raises(capi.AlmpcError):
+        s.sqp_fnn_iterate(1, step_scale=1.5)
+    with pytest.raises(capi.AlmpcError):
+        s.set_reference(kw["x_ref"], kw["u_ref"])   # references are part of the SQP set-up
+    # a later shared design takes the handle back; the SQP state is gone
+    p = mo.make_problem(np.eye(4) * 0.9, np.ones((4, 2)) * 0.1, 10, -np.ones(2), np.ones(2))
+    s.design_shared(p.A, p.B, p.Q, p.R, None, None, p.u_min, p.u_max)
+    with pytest.raises(capi.AlmpcError) as ei:
+        s.sqp_fnn_start(X0)
+    assert ei.value.code == -5
+    s.close()
+
+
+def test_sqp_indefinite_instance_is_contained(capi, mo):
+    """One instance whose condensed Hessian is not positive definite (here through an indefinite terminal weight; in practice an
+    open-loop unstable linearisation over a long horizon, cond(H) beyond 1e16) keeps its start and is reported; the other
+    instances are bit-identical to a clean run."""
+    b, N = 8, 20
+    f, s, kw, X0 = _setup(capi, mo, b, N)
+    s.sqp_fnn_start(X0)
+    s.sqp_fnn_iterate(4)
+    clean = s.get_results(want=("u", "x"))
+    assert s.sqp_fnn_skipped().sum() == 0
+    P = np.repeat(kw["P"][None], b, axis=0).copy()
+    P[3] = -1e4 * np.eye(4)
+    s.sqp_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, kw["x_ref"], kw["u_ref"], kw["Q"], kw["R"], kw["S"], P, kw["u_min"], kw["u_max"], act="tanh")
+    s.sqp_fnn_start(X0)
+    start_u = np.clip(kw["u_ref"], -1, 1)
+    with pytest.raises(capi.AlmpcError) as ei:
+        s.sqp_fnn_iterate(4)
+    assert ei.value.code == -6 and "instance 3" in str(ei.value)
+    sk = s.sqp_fnn_skipped()
+    r = s.get_results(want=("u", "x"))
+    st, de = s.sqp_last
+    s.close()
+    assert list(sk) == [0, 0, 0, 1, 0, 0, 0, 0]
+    keep = [i for i in range(b) if i != 3]
+    assert np.abs(r["u"][keep] - clean["u"][keep]).max() == 0.0 and np.abs(r["x"][keep] - clean["x"][keep]).max() == 0.0
+    assert np.abs(r["u"][3] - start_u).max() == 0.0
+    assert np.abs(r["x"][3] - mo.fnn_rollout(f, X0[3], start_u)).max() <= 1e-12
+    assert np.all(np.isfinite(st)) and np.all(np.isfinite(de)) and st[0] > 0

@@ -262,3 +262,40 @@ def test_quadrotor_model_is_exact_zoh(mo):
     np.testing.assert_allclose(B[2, 0], 0.5 * 0.1 ** 2 / 0.5)
     # torque -> angle -> velocity -> position chain: tau_y moves x by g*Ts^4/(24 J)
     np.testing.assert_allclose(B[0, 2], 9.81 * 0.1 ** 4 / 24 / 4e-3, rtol=1e-12)
+
+
+# ---------------------------------------------------------------------------- NLP branch (SQP restatement)
+def test_nlp_gradient_matches_finite_differences(mo):
+    f = mo.synthetic_fnn(act="tanh")
+    n, m, N = 4, 2, 6
+    x_ref = np.tile(np.array([0.2, -0.1, 0.05, 0.0])[:, None], (1, N + 1)); u_ref = np.tile(np.array([0.1, -0.2])[:, None], (1, N))
+    Q, R, S, P = 100.0 * np.eye(n), 0.1 * np.eye(m), 0.3 * np.eye(m), 150.0 * np.eye(n)
+    x0 = np.array([0.5, -0.3, 0.2, 0.1])
+    U = 0.3 * mo.splitmix_normal(0x5EED0006, 0, m, N)
+    J, G, _ = mo.nlp_cost_and_gradient(f, x0, U, x_ref, u_ref, Q, R, S, P)
+    eps = 1e-6
+    for a in range(m):
+        for k in range(N):
+            Up, Um = U.copy(), U.copy()
+            Up[a, k] += eps; Um[a, k] -= eps
+            fd = (mo.nlp_cost_and_gradient(f, x0, Up, x_ref, u_ref, Q, R, S, P)[0] - mo.nlp_cost_and_gradient(f, x0, Um, x_ref, u_ref, Q, R, S, P)[0]) / (2 * eps)
+            assert abs(fd - G[a, k]) <= 1e-6 * max(1.0, abs(G[a, k]))
+
+
+def test_sqp_restatement_reaches_a_kkt_point_of_the_nlp(mo):
+    f = mo.synthetic_fnn(act="tanh")
+    n, m, N = 4, 2, 12
+    x_ref = np.tile(np.array([0.2, -0.1, 0.05, 0.0])[:, None], (1, N + 1)); u_ref = np.tile(np.array([0.1, -0.2])[:, None], (1, N))
+    Q, R, S, P = 100.0 * np.eye(n), 0.1 * np.eye(m), 0.0 * np.eye(m), 150.0 * np.eye(n)
+    umin, umax = -np.ones(m), np.ones(m)
+    x0 = x_ref[:, 0] + np.array([0.5, -0.4, 0.3, 0.2])
+    X, U, hist = mo.sqp_fnn(f, x0, x_ref, u_ref, Q, R, S, P, umin, umax, iters=40)
+    assert hist[-1][0] <= 1e-9 and hist[-1][1] <= 1e-12, hist[-3:]
+    assert np.abs(X - mo.fnn_rollout(f, x0, U)).max() <= 1e-10          # multiple shooting closed the defects
+    assert mo.nlp_kkt_residual(f, x0, U, x_ref, u_ref, Q, R, S, P, umin, umax) <= 1e-8
+    assert np.any(U >= 1 - 1e-12) or np.any(U <= -1 + 1e-12)            # the box is active somewhere
+    # and it is a minimiser, not just a stationary point: random feasible perturbations do not decrease the cost
+    J0 = mo.nlp_cost_and_gradient(f, x0, U, x_ref, u_ref, Q, R, S, P)[0]
+    for s in range(5):
+        Up = np.clip(U + 1e-3 * mo.splitmix_normal(0x5EED0007, s, m, N), umin[:, None], umax[:, None])
+        assert mo.nlp_cost_and_gradient(f, x0, Up, x_ref, u_ref, Q, R, S, P)[0] >= J0 - 1e-12
