@@ -166,6 +166,7 @@ class HipModeler:
     def __init__(self, solver: _capi.Solver, opts: _capi.almpc_opts, batch: int):
         self.solver, self.opts, self.batch = solver, opts, batch
         self.relinearize = None  # dict for mpc_linearization='step' (black-box models), see _design_blackbox
+        self.sqp = None          # dict for mpc_programming_type='non_linear', see _design_blackbox_nonlinear
 
 
 def _design_reference_mpc(state_reference, input_reference, horizon: int) -> ReferencesStateInput:
@@ -224,6 +225,8 @@ def _design_blackbox(system: ConstrainedBlackBoxControlDiscreteSystem, horizon: 
     lin_last = proceed_system_linearization(system, x_ref[:, -1], u_ref[:, -1], device=dev)
     weights = _create_weights_coefficients(lin_first, kws=kws)
     P = _capi.dare(lin_last.A, lin_last.B, weights.Q, weights.R)
+    if kws.get("mpc_programming_type", "linear") == "non_linear":
+        return _design_blackbox_nonlinear(system, horizon, sample_time, references, weights, P, kws)
     C = _design_linear(lin_first, horizon, sample_time, references, kws=kws, _terminal_P=P)
     C.system = system
     if lin_mode == "step":
@@ -235,6 +238,43 @@ def _design_blackbox(system: ConstrainedBlackBoxControlDiscreteSystem, horizon: 
                                rho=float(sopt.get("rho", 0.1)), sigma=float(sopt.get("sigma", 1e-6)),
                                rho_profile=kws.get("mpc_rho_profile", "scalar"))
     return C
+
+
+def _design_blackbox_nonlinear(system, horizon, sample_time, references, weights, P, kws):
+    """Black-box (Fnn) model, NonLinearProgramming branch (.../fnn/mpc_modeler_implementation_fnn.jl:73-189): the network itself
+    is the equality constraint x[:,k+1] = fnn(x[:,k], u[:,k]) and the reference gives the NLP to Ipopt
+    (src/sub/solver_selection.jl:100-104).  Here the same NLP goes through the device-resident SQP loop (almpc_sqp_fnn_*).
+    Keys of this build: mpc_sqp_iterations (outer iterations per calculate!, default 10), mpc_sqp_step (step length, default 1),
+    mpc_sqp_warm_start (start each calculate! from the previous inputs shifted by one stage, default True)."""
+    D = _DEFAULT_PARAMETERS_MODEL_PREDICTIVE_CONTROL
+    solver_name = kws.get("mpc_solver", D["mpc_solver"])
+    if solver_name not in _IMPLEMENTATION_SOLVER_LIST:
+        raise KeyError(solver_name)
+    if solver_name in ("osqp", "scip", "ipopt"):
+        raise NotImplementedError(f"mpc_solver={solver_name!r} is the reference's CPU path; this build provides 'hip' (and 'auto' -> 'hip')")
+    terminal = kws.get("mpc_terminal_ingredient", D["mpc_terminal_ingredient"])
+    if terminal in ("equality", "contractive") or "mpc_state_constraint" in kws:
+        raise NotImplementedError("non_linear programming on the device: input box only (no state rows, no terminal constraint)")
+    f = system.f
+    n, m = system.statedim, system.inputdim
+    batch = int(kws.get("mpc_batch", 1))
+    x_ref, u_ref = np.asarray(references.x, dtype=np.float64), np.asarray(references.u, dtype=np.float64)
+    if x_ref.shape != (n, horizon + 1) or u_ref.shape != (m, horizon):
+        raise ValueError("references must be n x (N+1) and m x N")
+    sopt = dict(kws.get("mpc_solver_options", {}))
+    solver = _capi.Solver(n, m, horizon, batch, device=int(kws.get("mpc_device", 0)), timing=bool(kws.get("mpc_timing", False)))
+    solver.sqp_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, x_ref, u_ref, weights.Q, weights.R, weights.S, P, system.U.low, system.U.high,
+                         act=f.act, rho=float(sopt.get("rho", 0.1)), sigma=float(sopt.get("sigma", 1e-6)),
+                         rho_profile=kws.get("mpc_rho_profile", "scalar"))
+    mod = HipModeler(solver, _capi.default_opts(**sopt), batch)
+    mod.sqp = dict(iterations=int(kws.get("mpc_sqp_iterations", 10)), step=float(kws.get("mpc_sqp_step", 1.0)),
+                   warm_start=bool(kws.get("mpc_sqp_warm_start", True)), u_prev=None)
+    tuning = ModelPredictiveControlTuning(mod, references, horizon, weights, TerminalIngredient(terminal, np.array(P)),
+                                          float(sample_time), int(kws.get("mpc_max_time", D["mpc_max_time"])))
+    shape = (lambda *s: s) if batch == 1 else (lambda *s: (batch, *s))
+    results = ModelPredictiveControlResults(np.empty(shape(n, horizon + 1)), np.empty(shape(n, horizon + 1)),
+                                            np.empty(shape(m, horizon)), np.empty(shape(m, horizon)))
+    return ModelPredictiveControlController(system, tuning, np.empty(shape(n)), results)
 
 
 def _design_linear(system: ConstrainedLinearControlDiscreteSystem, horizon: int, sample_time: int,
@@ -300,6 +340,11 @@ def update_initialization(C: ModelPredictiveControlController, initialization) -
     if x0.size != mod.batch * n:
         raise ValueError(f"initialization must hold {mod.batch} x {n} values")
     C.initialization = x0.reshape((n,) if mod.batch == 1 else (mod.batch, n)).copy()
+    if getattr(mod, "sqp", None) is not None:  # non_linear: the SQP iterate restarts from the network's own rollout
+        up = mod.sqp["u_prev"] if mod.sqp["warm_start"] else None
+        ug = None if up is None else np.concatenate([up[:, :, 1:], up[:, :, -1:]], axis=2)
+        mod.solver.sqp_fnn_start(x0.reshape(mod.batch, n), ug)
+        return
     rl = getattr(mod, "relinearize", None)
     if rl is not None:  # mpc_linearization='step': Jacobians at (x0_i, u_ref[:,1]) -> one QP design per instance
         f = rl["system"].f
@@ -317,7 +362,10 @@ def calculate(C: ModelPredictiveControlController) -> None:
     check the solver status and lets JuMP.value throw when no solution exists; here a non-finite instance
     raises ArithmeticError, and per-instance status/iterations are kept on the modeler."""
     mod: HipModeler = C.tuning.modeler
-    mod.solver.calculate(mod.opts)
+    if getattr(mod, "sqp", None) is not None:
+        mod.last_sqp_history = mod.solver.sqp_fnn_iterate(mod.sqp["iterations"], mod.sqp["step"], mod.opts)
+    else:
+        mod.solver.calculate(mod.opts)
     r = mod.solver.get_results()
     mod.last_status, mod.last_iters, mod.last_polish_iters = r["status"], r["iters"], r["polish_iters"]
     if np.any(r["status"] == _capi.NON_FINITE):
@@ -327,6 +375,8 @@ def calculate(C: ModelPredictiveControlController) -> None:
     res = C.computation_results
     for k in ("x", "e_x", "u", "e_u"):
         getattr(res, k)[...] = r[k][0] if mod.batch == 1 else r[k]
+    if getattr(mod, "sqp", None) is not None:
+        mod.sqp["u_prev"] = r["u"].copy()
 
 
 def _model_predictive_control_computation(C: ModelPredictiveControlController, X0):

@@ -7,7 +7,8 @@
 # solver tag "hip" next to osqp/scip/ipopt/auto (src/sub/solver_selection.jl:9-14).
 module AlmpcHIP
 
-export hip_solver_def, HipModeler, design_hip, design_batched!, update_initialization!, calculate!,
+export hip_solver_def, HipModeler, design_hip, design_batched!, design_sqp_fnn!, sqp_start!, sqp_iterate!,
+       update_initialization!, calculate!,
        _model_predictive_control_computation
 
 const libalmpc = get(ENV, "ALMPC_LIB", "libalmpc.so")
@@ -90,6 +91,36 @@ function design_batched!(mod::HipModeler, A_batch::Array{Float64,3}, B_batch::Ar
     check(mod.handle, ccall((:almpc_set_reference, libalmpc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Cint),
                             mod.handle, x_ref, u_ref, 0))
     return mod
+end
+
+"""
+    design_sqp_fnn!(mod, W_in, W_h, b_h, W_out, activation, Q, R, S, P, umin, umax; x_ref, u_ref)
+
+NonLinearProgramming branch for an Fnn model (src/sub/model_modeler_implementation/fnn/mpc_modeler_implementation_fnn.jl:73-189,
+which the reference solves with Ipopt): the same NLP by Gauss-Newton SQP on the device.  `W_in` H x (n+m), `W_h` H x H x L,
+`b_h` H x L, `W_out` n x H as read from Flux.params (:88-107); `activation` 0 identity, 1 relu, 2 tanh, 3 sigmoid, 4 swish.
+Then per step:  `sqp_start!(mod, x0)`;  `sqp_iterate!(mod, iters)`;  results through `calculate!`'s readers (`almpc_get_results`).
+"""
+function design_sqp_fnn!(mod::HipModeler, W_in::Matrix{Float64}, W_h::Array{Float64,3}, b_h::Matrix{Float64}, W_out::Matrix{Float64},
+                         activation::Integer, Q::Matrix{Float64}, R::Matrix{Float64}, S::Matrix{Float64}, P::Matrix{Float64},
+                         umin::Vector{Float64}, umax::Vector{Float64}; x_ref::Matrix{Float64}, u_ref::Matrix{Float64})
+    check(mod.handle, ccall((:almpc_sqp_fnn_setup, libalmpc), Cint,
+                   (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                    Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint, Ptr{Float64}, Ptr{Float64}, Cdouble, Cdouble),
+                   mod.handle, size(W_in, 1), size(W_h, 3), activation, W_in, W_h, b_h, W_out, x_ref, u_ref, Q, R, S, P, 0, umin, umax,
+                   mod.opts.rho, mod.opts.sigma))
+    return mod
+end
+
+sqp_start!(mod::HipModeler, x0::VecOrMat{Float64}) =
+    check(mod.handle, ccall((:almpc_sqp_fnn_start, libalmpc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), mod.handle, x0, C_NULL))
+
+function sqp_iterate!(mod::HipModeler, iters::Integer; step::Float64 = 1.0)
+    st, de = zeros(iters), zeros(iters)
+    o = Ref(mod.opts)
+    check(mod.handle, ccall((:almpc_sqp_fnn_iterate, libalmpc), Cint, (Ptr{Cvoid}, Cint, Cdouble, Ref{AlmpcOpts}, Ptr{Float64}, Ptr{Float64}),
+                            mod.handle, iters, step, o, st, de))
+    return st, de
 end
 
 # update_initialization!(C, x0): x0 is a Vector (batch 1) or an n x batch Matrix (src/main/computation_mpc.jl:17-29)

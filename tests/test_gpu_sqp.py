@@ -136,3 +136,35 @@ def test_sqp_indefinite_instance_is_contained(capi, mo):
     assert np.abs(r["u"][3] - start_u).max() == 0.0
     assert np.abs(r["x"][3] - mo.fnn_rollout(f, X0[3], start_u)).max() <= 1e-12
     assert np.all(np.isfinite(st)) and np.all(np.isfinite(de)) and st[0] > 0
+
+
+def test_mirror_non_linear_programming_type(pkg, mo):
+    """proceed_controller(...; mpc_programming_type = "non_linear") for an Fnn system: the reference builds the NLP of
+    .../fnn/...:73-189 for Ipopt; the mirror runs the device SQP loop on the same problem (P = DARE at the last reference)."""
+    f = mo.synthetic_fnn(act="tanh")
+    sys_ = pkg.ConstrainedBlackBoxControlDiscreteSystem(pkg.Fnn(f.W_in, f.W_h, f.b_h, f.W_out, f.act), 4, 2,
+                                                        pkg.Hyperrectangle([-10] * 4, [10] * 4), pkg.Hyperrectangle([-1, -1], [1, 1]))
+    x_ref, u_ref = [0.2, -0.1, 0.05, 0.0], [0.1, -0.2]
+    N, batch = 20, 16
+    C = pkg.proceed_controller(sys_, "model_predictive_control", N, 1, x_ref, u_ref, mpc_batch=batch, mpc_programming_type="non_linear",
+                               mpc_sqp_iterations=25)
+    Al, Bl = f.jacobian(np.array(x_ref), np.array(u_ref))
+    P = mo.dare(Al, Bl, 100 * np.eye(4), 0.1 * np.eye(2))
+    assert np.abs(C.tuning.terminal_ingredient.P - P).max() <= 1e-9 * np.abs(P).max()
+    X0 = np.asarray(x_ref)[None, :] + 0.6 * mo.splitmix_normal(0x5EED0009, 0, batch, 4)
+    res = pkg._model_predictive_control_computation(C, X0)
+    assert res.u.shape == (batch, 2, N) and res.x.shape == (batch, 4, N + 1)
+    xr, ur = np.tile(np.array(x_ref)[:, None], (1, N + 1)), np.tile(np.array(u_ref)[:, None], (1, N))
+    for i in range(batch):
+        assert mo.nlp_kkt_residual(f, X0[i], res.u[i], xr, ur, 100 * np.eye(4), 0.1 * np.eye(2), np.zeros((2, 2)), P, -np.ones(2), np.ones(2)) <= 1e-5
+        assert np.abs(res.x[i] - mo.fnn_rollout(f, X0[i], res.u[i])).max() <= 1e-8
+    # closed loop: plant = the network; the shifted warm start needs fewer iterations to the same tolerance
+    C.tuning.modeler.sqp["iterations"] = 8
+    X1 = np.stack([f.forward(X0[i], res.u[i][:, 0]) for i in range(batch)])
+    res = pkg._model_predictive_control_computation(C, X1)
+    st, de = C.tuning.modeler.last_sqp_history
+    assert st[-1] <= 1e-3 and de[-1] <= 1e-8
+    with pytest.raises(NotImplementedError):
+        pkg.proceed_controller(sys_, "model_predictive_control", N, 1, x_ref, u_ref, mpc_programming_type="non_linear",
+                               mpc_terminal_ingredient="equality")
+    C.tuning.modeler.solver.close()

@@ -1,0 +1,29 @@
+"""SQP iterations of BASELINE configs[4] alone, for rocprofv3 --kernel-trace --stats (see tools/README.md)."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import almpc_loader
+pkg = almpc_loader.load_package()
+capi = pkg._capi
+import mpc_oracle as mo
+
+bq = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+Nq = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+its = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+f = mo.synthetic_fnn(act="tanh")
+nq, mq = 4, 2
+xr = np.tile(np.array([0.2, -0.1, 0.05, 0.0])[:, None], (1, Nq + 1)); ur = np.tile(np.array([0.1, -0.2])[:, None], (1, Nq))
+X0 = xr[:, 0][None, :] + 0.6 * mo.splitmix_normal(0x5EED0005, 0, bq, nq)
+Al, Bl = f.jacobian(xr[:, -1], ur[:, -1])
+P = mo.dare(Al, Bl, 100.0 * np.eye(nq), 0.1 * np.eye(mq))
+s = capi.Solver(nq, mq, Nq, bq)
+s.sqp_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, xr, ur, 100.0 * np.eye(nq), 0.1 * np.eye(mq), None, P, -np.ones(mq), np.ones(mq), act="tanh")
+import time
+for rep in range(3):
+    s.sqp_fnn_start(X0)
+    t0 = time.perf_counter()
+    st, de = s.sqp_fnn_iterate(its)
+    print(f"rep {rep}: {1e3 * (time.perf_counter() - t0) / its:.3f} ms / iteration; step {st[-1]:.2e} defect {de[-1]:.2e}")
+print("steps", np.array2string(st, precision=2))
+s.close()
