@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -386,10 +387,10 @@ void launch_batched_factor(almpc_handle* h, const DesignStrides& ds, double rho,
     const unsigned gb = (unsigned)h->batch;
     hipLaunchKernelGGL(k_design_scale, dim3(1, gb), dim3(256), 0, st, nz, nzs, n, h->bH, h->bF, h->bD, h->bHs, h->bFs, h->bFlag, ds);
     const size_t inv_lds = 520 * sizeof(double);
-    hipLaunchKernelGGL(k_design_inverse, dim3(1, gb), dim3(512), inv_lds, st, nz, nzs, h->bHs, 0.0, (const double*)nullptr, h->bG, h->bFlag,
+    hipLaunchKernelGGL(k_design_inverse, dim3(1, gb), dim3(DESIGN_INVERSE_THREADS), inv_lds, st, nz, nzs, h->bHs, 0.0, (const double*)nullptr, h->bG, h->bFlag,
                        ds.Hs, 0L, ds.G, 1L);
     hipLaunchKernelGGL(k_design_rho, dim3(1, gb), dim3(256), 0, st, nz, nzs, h->rho_mode, rho, h->bG, h->bRho, ds.G, ds.rho);
-    hipLaunchKernelGGL(k_design_inverse, dim3(1, gb), dim3(512), inv_lds, st, nz, nzs, h->bHs, sigma, (const double*)h->bRho, h->bMinv,
+    hipLaunchKernelGGL(k_design_inverse, dim3(1, gb), dim3(DESIGN_INVERSE_THREADS), inv_lds, st, nz, nzs, h->bHs, sigma, (const double*)h->bRho, h->bMinv,
                        h->bFlag, ds.Hs, ds.rho, ds.Minv, 1L);
 }
 
@@ -402,6 +403,52 @@ DesignStrides batched_strides(const almpc_handle* h, bool p_inst) {
     ds.Gam = (long)kr * gs; ds.WP = (long)kr * ps; ds.H = (long)nz * nz; ds.F = (long)nz * n; ds.d = nzs; ds.Hs = (long)nz * nzs;
     ds.Fs = (long)n * nzs; ds.G = (long)nz * nzs; ds.Minv = (long)nz * nzs; ds.rho = nzs; ds.flag = 1;
     return ds;
+}
+
+// Jacobians of an Fnn at p.batch points: wave-per-point build when weights + 4 waves' buffers fit 64 KB of LDS, else one workgroup
+// per point.
+hipError_t launch_fnn_jacobian(const FnnParams& p, int num_cus, hipStream_t st) {
+    const size_t nin = (size_t)p.n + p.m;
+    const size_t lw = fnn_w_lds_doubles(p.n, p.m, p.H, p.L) * sizeof(double);
+    if (lw <= 64 * 1024 && !getenv("ALMPC_FNN_WG")) {
+        int wgs = (p.batch + FNN_W_WAVES - 1) / FNN_W_WAVES;
+        const int cap = num_cus * 4;  // 16 waves per CU
+        if (wgs > cap) wgs = cap;
+        hipLaunchKernelGGL(k_fnn_jacobian_w, dim3(wgs), dim3(64 * FNN_W_WAVES), lw, st, p);
+        return hipGetLastError();
+    }
+    const size_t lds = (2 * (size_t)p.H + 2 * (size_t)p.H * nin + nin) * sizeof(double);
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fnn_jacobian), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_fnn_jacobian, dim3(p.batch), dim3(256), lds, st, p);
+    return hipGetLastError();
+}
+
+// k_design_ltv: accumulators in registers when the shape allows (nz <= 128, one thread per element of (A, B)), else in LDS
+bool ltv_reg_path(const almpc_handle* h) {
+    const int n = h->n, m = h->m;
+    return h->nz <= LTV_REG_NZ && n * n + n * m <= 1024 - n && design_ltv_reg_lds_doubles(n, m, h->N) * sizeof(double) <= 160 * 1024 &&
+           !getenv("ALMPC_LTV_LDS");
+}
+
+bool ltv_supported(const almpc_handle* h) {
+    return ltv_reg_path(h) || design_ltv_lds_doubles(h->n, h->m, h->N) * sizeof(double) <= 160 * 1024;
+}
+
+hipError_t launch_design_ltv(almpc_handle* h, const DesignLtvParams& lp, hipStream_t st) {
+    const int n = h->n, m = h->m;
+    const bool reg = ltv_reg_path(h);
+    const size_t lds = (reg ? design_ltv_reg_lds_doubles(n, m, h->N) : design_ltv_lds_doubles(n, m, h->N)) * sizeof(double);
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reg ? reinterpret_cast<const void*>(k_design_ltv_reg) : reinterpret_cast<const void*>(k_design_ltv),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    if (reg) hipLaunchKernelGGL(k_design_ltv_reg, dim3((unsigned)h->batch), dim3(1024), lds, st, lp);
+    else hipLaunchKernelGGL(k_design_ltv, dim3((unsigned)h->batch), dim3(256), lds, st, lp);
+    return hipGetLastError();
 }
 
 int design_batched_common(almpc_handle* h, const double* A_batch, const double* B_batch, const double* Q, const double* R,
@@ -485,16 +532,12 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
         if (e == hipSuccess) e = upl(&dQa, ltv->qadd, b * nz);
         if (e == hipSuccess && !h->bQ) e = dalloc(&h->bQ, b * nz);
         if (e == hipSuccess) e = hipMemsetAsync(h->bF, 0, b * nz * n * sizeof(double), st);
-        const size_t ltv_lds = design_ltv_lds_doubles(n, m, N) * sizeof(double);
-        if (e == hipSuccess && ltv_lds > 64 * 1024)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_design_ltv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ltv_lds);
         if (e == hipSuccess) {
             DesignLtvParams lp;
             lp.n = n; lp.m = m; lp.N = N; lp.nz = nz; lp.useR = useR; lp.useS = useS;
             lp.A = dAll; lp.B = dBll; lp.c = dC; lp.ebar = dE; lp.P = h->bP; lp.sP = ds.P; lp.Q = dQ; lp.R = dR; lp.S = dS;
             lp.qadd = dQa; lp.H = h->bH; lp.q = h->bQ;
-            hipLaunchKernelGGL(k_design_ltv, dim3(gb), dim3(256), ltv_lds, st, lp);
-            e = hipGetLastError();
+            e = launch_design_ltv(h, lp, st);
         }
         if (e == hipSuccess) e = hipStreamSynchronize(st);  // the staging buffers are released right away
         (void)hipFree(dAll); (void)hipFree(dBll); (void)hipFree(dC); (void)hipFree(dE); (void)hipFree(dQa);
@@ -581,8 +624,8 @@ int almpc_design_ltv(almpc_handle* h, const double* A_all, const double* B_all, 
         return fail(h, ALMPC_ERR_INVALID, "design_ltv: null pointer (P must be given: there is no single model to take a DARE of)");
     const int n = h->n, m = h->m, N = h->N, nz = h->nz;
     const size_t b = (size_t)h->batch;
-    if (design_ltv_lds_doubles(n, m, N) * sizeof(double) > 160 * 1024)
-        return fail(h, ALMPC_ERR_UNSUPPORTED, "design_ltv: nz^2 + 3 n nz doubles must fit the 160 KB of LDS");
+    if (!ltv_supported(h))
+        return fail(h, ALMPC_ERR_UNSUPPORTED, "design_ltv: nz <= 128, or nz^2 + 3 n nz doubles must fit the 160 KB of LDS");
     std::vector<double> A0(b * n * n), B0(b * n * m), ebar(b * N * n), qadd(b * nz, 0.0);
     for (size_t i = 0; i < b; ++i) {
         std::copy(A_all + i * N * n * n, A_all + i * N * n * n + (size_t)n * n, A0.begin() + i * n * n);
@@ -638,9 +681,10 @@ int almpc_sqp_fnn_setup(almpc_handle* h, int H, int L, int activation, const dou
     if (h->terminal_eq) return fail(h, ALMPC_ERR_UNSUPPORTED, "sqp_fnn_setup: state rows (terminal equality) need a shared model");
     const int n = h->n, m = h->m, N = h->N, nz = h->nz, nzs = h->nzs;
     const size_t b = (size_t)h->batch, nin = (size_t)n + m;
-    if (n > 64) return fail(h, ALMPC_ERR_UNSUPPORTED, "sqp_fnn_setup: n <= 64 (one lane per state in the update kernel)");
-    if (design_ltv_lds_doubles(n, m, N) * sizeof(double) > 160 * 1024)
-        return fail(h, ALMPC_ERR_UNSUPPORTED, "sqp_fnn_setup: nz^2 + 3 n nz doubles must fit the 160 KB of LDS");
+    if (n > 64 || sqp_step_lds_doubles(n, m, N) * sizeof(double) > 160 * 1024)
+        return fail(h, ALMPC_ERR_UNSUPPORTED, "sqp_fnn_setup: n <= 64 (one lane per state in the update kernel) and its stage buffers must fit LDS");
+    if (!ltv_supported(h))
+        return fail(h, ALMPC_ERR_UNSUPPORTED, "sqp_fnn_setup: nz <= 128, or nz^2 + 3 n nz doubles must fit the 160 KB of LDS");
     if ((2 * (size_t)H + 2 * (size_t)H * nin + nin) * sizeof(double) > 160 * 1024)
         return fail(h, ALMPC_ERR_UNSUPPORTED, "sqp_fnn_setup: the network's forward-mode Jacobian must fit the 160 KB of LDS");
     for (int i = 0; i < m; ++i)
@@ -753,7 +797,7 @@ int almpc_sqp_fnn_iterate(almpc_handle* h, int iters, double step_scale, const a
     if (iters < 1 || !(step_scale > 0.0 && step_scale <= 1.0)) return fail(h, ALMPC_ERR_INVALID, "sqp_fnn_iterate: iters >= 1, 0 < step_scale <= 1");
     HIP_TRY(h, hipSetDevice(h->device));
     const int n = h->n, m = h->m, N = h->N, nz = h->nz, nzs = h->nzs;
-    const size_t b = (size_t)h->batch, nin = (size_t)n + m;
+    const size_t b = (size_t)h->batch;
     hipStream_t st = h->stream;
     if (q.stats_cap < iters) {
         if (q.stats) { HIP_TRY(h, hipStreamSynchronize(st)); (void)hipFree(q.stats); q.stats = nullptr; }
@@ -761,12 +805,10 @@ int almpc_sqp_fnn_iterate(almpc_handle* h, int iters, double step_scale, const a
         q.stats_cap = iters;
     }
     HIP_TRY(h, hipMemsetAsync(q.stats, 0, (size_t)2 * iters * sizeof(unsigned long long), st));
-    const size_t fnn_lds = (2 * (size_t)q.H + 2 * (size_t)q.H * nin + nin) * sizeof(double);
-    const size_t ltv_lds = design_ltv_lds_doubles(n, m, N) * sizeof(double);
-    if (fnn_lds > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_fnn_jacobian), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fnn_lds));
-    if (ltv_lds > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_design_ltv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ltv_lds));
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_design_inverse), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(520 * sizeof(double))));
     const DesignStrides ds = batched_strides(h, q.sP != 0);
+    const size_t step_lds = sqp_step_lds_doubles(n, m, N) * sizeof(double);
+    if (step_lds > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sqp_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds));
     FnnParams fp;
     fp.n = n; fp.m = m; fp.H = q.H; fp.L = q.L; fp.act = q.act; fp.batch = (int)(b * N);
     fp.W_in = q.W_in; fp.W_h = q.W_h; fp.b_h = q.b_h; fp.W_out = q.W_out;
@@ -783,10 +825,10 @@ int almpc_sqp_fnn_iterate(almpc_handle* h, int iters, double step_scale, const a
     lp.A = q.A; lp.B = q.B; lp.c = q.c; lp.ebar = q.ebar; lp.P = h->bP; lp.sP = q.sP; lp.Q = q.Q; lp.R = q.R; lp.S = q.S;
     lp.qadd = q.qadd; lp.H = h->bH; lp.q = h->bQ;
     for (int it = 0; it < iters; ++it) {
-        hipLaunchKernelGGL(k_fnn_jacobian, dim3((unsigned)(b * N)), dim3(256), fnn_lds, st, fp);
+        HIP_TRY(h, launch_fnn_jacobian(fp, h->num_cus, st));
         hipLaunchKernelGGL(k_sqp_prepare, dim3((unsigned)b), dim3(256), 0, st, sp);
         HIP_TRY(h, hipMemsetAsync(h->bFlag, 0, b * sizeof(int), st));
-        hipLaunchKernelGGL(k_design_ltv, dim3((unsigned)b), dim3(256), ltv_lds, st, lp);
+        HIP_TRY(h, launch_design_ltv(h, lp, st));
         launch_batched_factor(h, ds, h->rho, h->sigma, st);
         hipLaunchKernelGGL(k_fs_scale, dim3(256), dim3(256), 0, st, h->batch, nz, nzs, h->bQ, (long)nz, h->bD, h->dFS);
         hipLaunchKernelGGL(k_neg_gm, dim3(1, (unsigned)b), dim3(256), 0, st, nz, nzs, 1, nz, h->bG, h->dFS, h->dV0S, (long)nz * nzs, (long)nz);
@@ -795,7 +837,7 @@ int almpc_sqp_fnn_iterate(almpc_handle* h, int iters, double step_scale, const a
         const int rc = almpc_calculate_async(h, opts);
         if (rc != ALMPC_OK) return rc;
         sp.stats = q.stats + 2 * it;
-        hipLaunchKernelGGL(k_sqp_step, dim3((unsigned)b), dim3(64), 0, st, sp);
+        hipLaunchKernelGGL(k_sqp_step, dim3((unsigned)b), dim3(256), step_lds, st, sp);
         HIP_TRY(h, hipGetLastError());
     }
     std::vector<unsigned long long> stats((size_t)2 * iters);
@@ -1043,7 +1085,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         pp.max_iter = o.polish_max_iter > 0 ? o.polish_max_iter : 4 * h->nz + 50;
         // rollout fused into the tail of the polish when its trajectory buffer fits the wave's LDS slot
         fused = roll_fits;
-        pp.fuse_rollout = fused ? 1 : 0; pp.roll_g = roll_g; pp.roll_cpl = roll_cpl; pp.roll = rp;
+        pp.fuse_rollout = fused ? (h->ltv ? 2 : 1) : 0; pp.roll_g = roll_g; pp.roll_cpl = roll_cpl; pp.roll = rp;
         int per_wave = POLISH_LDS_MIN_PER_WAVE;
         if (fused && (h->N + 1) * (h->n + h->m) > per_wave) per_wave = (h->N + 1) * (h->n + h->m);
         per_wave = (per_wave + 1) & ~1;
@@ -1280,12 +1322,9 @@ int almpc_fnn_linearize(int device_id, int n, int m, int H, int L, int activatio
     int rc = ALMPC_OK;
     if (!p.W_in || !p.W_h || !p.b_h || !p.W_out || !p.x || !p.u || !p.A || !p.B || (f && !p.f)) rc = ALMPC_ERR_HIP;
     if (rc == ALMPC_OK) {
-        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k_fnn_jacobian),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) rc = ALMPC_ERR_HIP;
-    }
-    if (rc == ALMPC_OK) {
-        hipLaunchKernelGGL(k_fnn_jacobian, dim3(batch), dim3(256), lds, 0, p);
-        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = ALMPC_ERR_HIP;
+        hipDeviceProp_t prop;
+        const int cus = hipGetDeviceProperties(&prop, device_id) == hipSuccess ? prop.multiProcessorCount : 256;
+        if (launch_fnn_jacobian(p, cus, 0) != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = ALMPC_ERR_HIP;
     }
     if (rc == ALMPC_OK) {
         if (hipMemcpy(A, p.A, (size_t)batch * n * n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||

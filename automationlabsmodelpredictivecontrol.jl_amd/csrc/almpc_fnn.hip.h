@@ -97,4 +97,90 @@ __global__ __launch_bounds__(256) void k_fnn_jacobian(FnnParams p) {
         }
 }
 
+// Wave-per-point build for small networks (the SQP loop linearises batch x N points per iteration): the weights are staged in
+// LDS once per workgroup and shared by its 4 waves, every wave walks its own points with wave-local LDS buffers and no
+// workgroup barrier inside the loop.  Same arithmetic, same summation order as k_fnn_jacobian (bit-identical results).
+constexpr int FNN_W_WAVES = 4;
+
+__host__ __device__ inline size_t fnn_w_lds_doubles(int n, int m, int H, int L) {
+    const size_t nin = (size_t)n + m;
+    const size_t weights = (size_t)H * nin + (size_t)L * H * H + (size_t)L * H + (size_t)n * H;
+    const size_t per_wave = 2 * (size_t)H + 2 * (size_t)H * nin + nin;
+    return weights + FNN_W_WAVES * per_wave;
+}
+
+__global__ __launch_bounds__(64 * FNN_W_WAVES) void k_fnn_jacobian_w(FnnParams p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int n = p.n, m = p.m, H = p.H, L = p.L, nin = n + m;
+    double* Win = smem;                               // H x nin column-major
+    double* Wh = Win + (size_t)H * nin;               // [L] H x H column-major
+    double* bh = Wh + (size_t)L * H * H;              // [L] H
+    double* Wout = bh + (size_t)L * H;                // n x H column-major
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double* y = Wout + (size_t)n * H + (size_t)wv * (2 * (size_t)H + 2 * (size_t)H * nin + nin);
+    double* yn = y + H;
+    double* J = yn + H;                               // [H][nin] row-major
+    double* Jn = J + (size_t)H * nin;
+    double* z = Jn + (size_t)H * nin;
+    for (int t = threadIdx.x; t < H * nin; t += blockDim.x) Win[t] = p.W_in[t];
+    for (int t = threadIdx.x; t < L * H * H; t += blockDim.x) Wh[t] = p.W_h[t];
+    for (int t = threadIdx.x; t < L * H; t += blockDim.x) bh[t] = p.b_h[t];
+    for (int t = threadIdx.x; t < n * H; t += blockDim.x) Wout[t] = p.W_out[t];
+    __syncthreads();
+    auto wsync = []() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    for (int inst = blockIdx.x * FNN_W_WAVES + wv; inst < p.batch; inst += gridDim.x * FNN_W_WAVES) {
+        const double* xp = p.x + (size_t)(inst / p.ppi) * p.xs_group + (size_t)(inst % p.ppi) * n;
+        const double* up = p.u + (size_t)(inst / p.ppi) * p.us_group + (size_t)(inst % p.ppi) * m;
+        for (int t = lane; t < nin; t += 64) z[t] = t < n ? xp[t] : up[t - n];
+        wsync();
+        for (int i = lane; i < H; i += 64) {
+            double s = 0.0;
+            for (int c = 0; c < nin; ++c) s += Win[(size_t)c * H + i] * z[c];
+            y[i] = s;
+        }
+        for (int t = lane; t < H * nin; t += 64) J[t] = Win[(size_t)(t % nin) * H + t / nin];
+        wsync();
+        for (int l = 0; l < L; ++l) {
+            const double* W = Wh + (size_t)l * H * H;
+            const double* b = bh + (size_t)l * H;
+            for (int i = lane; i < H; i += 64) {
+                double s = b[i];
+                for (int j = 0; j < H; ++j) s += W[(size_t)j * H + i] * y[j];
+                yn[i] = s;  // pre-activation
+            }
+            wsync();
+            for (int t = lane; t < H * nin; t += 64) {
+                const int i = t / nin, c = t % nin;
+                double s = 0.0;
+                for (int j = 0; j < H; ++j) s += W[(size_t)j * H + i] * J[(size_t)j * nin + c];
+                double val, der;
+                fnn_act(p.act, yn[i], val, der);
+                Jn[t] = der == 0.0 ? 0.0 : der * s;
+            }
+            wsync();
+            for (int i = lane; i < H; i += 64) {
+                double val, der;
+                fnn_act(p.act, yn[i], val, der);
+                y[i] = val;
+            }
+            for (int t = lane; t < H * nin; t += 64) J[t] = Jn[t];
+            wsync();
+        }
+        for (int t = lane; t < n * nin; t += 64) {
+            const int i = t % n, c = t / n;
+            double s = 0.0;
+            for (int j = 0; j < H; ++j) s += Wout[(size_t)j * n + i] * J[(size_t)j * nin + c];
+            if (c < n) p.A[(size_t)inst * n * n + (size_t)c * n + i] = s;
+            else p.B[(size_t)inst * n * m + (size_t)(c - n) * n + i] = s;
+        }
+        if (p.f)
+            for (int i = lane; i < n; i += 64) {
+                double s = 0.0;
+                for (int j = 0; j < H; ++j) s += Wout[(size_t)j * n + i] * y[j];
+                p.f[(size_t)inst * n + i] = s;
+            }
+        wsync();  // the next point overwrites z, y, J
+    }
+}
+
 }  // namespace almpc

@@ -544,6 +544,137 @@ __global__ __launch_bounds__(256) void k_design_ltv(DesignLtvParams p) {
     for (int t = threadIdx.x; t < nz; t += T_) p.q[inst * nz + t] = 2.0 * qs[t] + (p.qadd ? p.qadd[inst * nz + t] : 0.0);
 }
 
+// Register-accumulator build of the same design for nz <= 128: 1024 threads, thread (tx, ty) keeps the 4 x 4 strided tile
+// H[tx + 32 i][ty + 32 j] in registers for the whole walk, so a stage costs 8 n LDS reads per thread instead of a read-modify-write
+// of LDS per element (the LDS build above spends 85 % of its time there), the row blocks are stored stage-row-major ([l][c]:
+// lanes read consecutive addresses), q sits in the registers of threads c < nz, the next stage's (A, B) are fetched one stage
+// two stages ahead (a stage is shorter than an HBM round trip), defects and state errors are staged in LDS once, and a stage
+// needs two barriers.  LDS: 3 n 128 + 4 n^2 + 2 n m + 4 n + 2 N n doubles (16 KB for n = 4, N = 50).
+constexpr int LTV_REG_NZ = 128;
+
+__host__ __device__ inline size_t design_ltv_reg_lds_doubles(int n, int m, int N) {
+    return 3 * (size_t)n * LTV_REG_NZ + 4 * (size_t)n * n + 2 * (size_t)n * m + 4 * (size_t)n + 2 * (size_t)N * n;
+}
+
+__global__ __launch_bounds__(1024) void k_design_ltv_reg(DesignLtvParams p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int NZP = LTV_REG_NZ;
+    const int n = p.n, m = p.m, N = p.N, nz = p.nz, nn = n * n, nm = n * m, nab = nn + nm;
+    const size_t inst = blockIdx.x;
+    double* Gc = smem;                    // [n][NZP] current row block of Gamma~ (row l of the block, column c)
+    double* Gn = Gc + (size_t)n * NZP;
+    double* T = Gn + (size_t)n * NZP;     // Q_k times the row block
+    double* AB = T + (size_t)n * NZP;     // [2][nn + nm]: (A_k, B_k) of the current and of the next stage
+    double* Qs = AB + 2 * nab;
+    double* Ps = Qs + nn;
+    double* gk = Ps + nn;
+    double* gn = gk + n;
+    double* rv2 = gn + n;                 // [2][n]: g~ + ebar of the current stage, double buffered over the stages
+    double* cs = rv2 + 2 * n;             // [N][n] defects
+    double* es = cs + (size_t)N * n;      // [N][n] state errors
+    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5, T_ = 1024;
+    double acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    double qacc = 0.0;
+    // (A, B) of the stages are contiguous per instance: [N][nn] and [N][nm]; element e < nab of stage k
+    const double* Ag = p.A + inst * N * (size_t)nn;
+    const double* Bg = p.B + inst * N * (size_t)nm;
+    auto ab_load = [&](int k) -> double { return tid < nn ? Ag[(size_t)k * nn + tid] : Bg[(size_t)k * nm + tid - nn]; };
+    double pre = 0.0;  // stage k + 2's element, in flight for a whole stage before it is written to LDS
+    if (tid < nab) {
+        AB[tid] = ab_load(0);
+        if (N > 1) AB[nab + tid] = ab_load(1);
+        if (N > 2) pre = ab_load(2);
+    }
+    for (int t = tid; t < 3 * n * NZP; t += T_) Gc[t] = 0.0;  // Gc, Gn, T
+    for (int t = tid; t < nn; t += T_) { Qs[t] = p.Q[t]; Ps[t] = p.P[inst * p.sP + t]; }
+    for (int t = tid; t < n; t += T_) gk[t] = 0.0;
+    for (int t = tid; t < N * n; t += T_) {
+        cs[t] = p.c ? p.c[inst * N * n + t] : 0.0;
+        es[t] = p.ebar ? p.ebar[inst * N * n + t] : 0.0;
+    }
+    __syncthreads();
+    for (int k = 0; k < N; ++k) {
+        const double* Ak = AB + (k & 1) * nab;
+        const double* Bk = Ak + nn;
+        const int wcols = (k + 1) * m;  // columns of the row block that are non-zero after this stage
+        for (int t = tid; t < n * wcols; t += T_) {
+            const int c = t % wcols, pr = t / wcols;
+            double v;
+            if (c >= k * m) v = Bk[(c - k * m) * n + pr];
+            else {
+                v = 0.0;
+                for (int l = 0; l < n; ++l) v += Ak[l * n + pr] * Gc[l * NZP + c];
+            }
+            Gn[pr * NZP + c] = v;
+        }
+        if (tid >= T_ - n) {  // the last n threads (they have no share of the row block as long as n * wcols <= 1024 - n)
+            const int pr = tid - (T_ - n);
+            double v = cs[k * n + pr];
+            for (int l = 0; l < n; ++l) v += Ak[l * n + pr] * gk[l];
+            gn[pr] = v;
+            rv2[(k & 1) * n + pr] = v + es[k * n + pr];
+        }
+        __syncthreads();
+        { double* t = Gc; Gc = Gn; Gn = t; }
+        { double* t = gk; gk = gn; gn = t; }
+        const double* Qk = (k == N - 1) ? Ps : Qs;  // stage N+1 carries only P (src/sub/design_mpc.jl:448-456)
+        const double* rv = rv2 + (k & 1) * n;
+        for (int t = tid; t < n * wcols; t += T_) {
+            const int c = t % wcols, pr = t / wcols;
+            double v = 0.0;
+            for (int l = 0; l < n; ++l) v += Qk[l * n + pr] * Gc[l * NZP + c];
+            T[pr * NZP + c] = v;
+        }
+        if (tid < nab) {  // this stage's (A, B) slot is free (last read before the barrier above): it takes stage k + 2
+            if (k + 2 < N) AB[(k & 1) * nab + tid] = pre;
+            if (k + 3 < N) pre = ab_load(k + 3);
+        }
+        __syncthreads();
+        const int ni = (wcols + 31) >> 5;  // 32-column groups that hold non-zeros
+        for (int l = 0; l < n; ++l) {
+            double a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = i < ni ? Gc[l * NZP + tx + 32 * i] : 0.0;
+                b[i] = i < ni ? T[l * NZP + ty + 32 * i] : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+        }
+        if (tid < wcols) {
+            double v = 0.0;
+            for (int l = 0; l < n; ++l) v += T[l * NZP + tid] * rv[l];
+            qacc += v;
+        }
+        // no barrier here: before its first barrier the next stage writes only the other row-block buffer, the other g~ and the
+        // other rv; T and the (A, B) slot are rewritten after that barrier, i.e. after every thread has finished the reads above
+    }
+    double* H = p.H + inst * (size_t)nz * nz;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = tx + 32 * i, c = ty + 32 * j;
+            if (r < nz && c < nz) {
+                double v = 2.0 * acc[i][j];
+                const int ir = r / m, ar = r % m, ic = c / m, ac = c % m;
+                if (p.useR && ir == ic) v += 2.0 * p.R[(size_t)ac * m + ar];
+                if (p.useS) {
+                    if (ir == ic) v += 2.0 * ((ir <= N - 2 ? 1 : 0) + (ir >= 1 ? 1 : 0)) * p.S[(size_t)ac * m + ar];
+                    else if (ir - ic == 1 || ic - ir == 1) v -= 2.0 * p.S[(size_t)ac * m + ar];
+                }
+                H[(size_t)c * nz + r] = v;
+            }
+        }
+    if (tid < nz) p.q[inst * nz + tid] = 2.0 * qacc + (p.qadd ? p.qadd[inst * nz + tid] : 0.0);
+}
+
 // fS_i = d_i .* g: the constant part of the scaled gradient (g = 2 D'Sbar D u_ref, shared or per instance) for every instance
 __global__ __launch_bounds__(256) void k_fs_scale(int batch, int nz, int nzs, const double* g, long g_stride, const double* d,
                                                   double* fS) {

@@ -424,7 +424,7 @@ struct PolishParams {
     long G_stride, d_stride, A_stride, B_stride;
     int wave_const_off;
     int max_iter;
-    int fuse_rollout;    // 1: this kernel also produces u, e_u, x, e_x (roll.*), no separate k_rollout launch
+    int fuse_rollout;    // 1: this kernel also produces u, e_u, x, e_x (roll.*), no separate k_rollout launch; 2: u, e_u only
     int roll_g, roll_cpl; // rollout lane decomposition: roll_g lanes per state row, roll_cpl columns of [A B] per lane
     RolloutParams roll;
 };
@@ -1249,6 +1249,7 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
             GL(rp.eu)[(size_t)inst * nz + r1] = uu - ur;
             Z[(size_t)(r1 / m) * C + n + r1 % m] = uu - ur;
         }
+        if (p.fuse_rollout == 2) return;  // time-varying models: inputs only (there is no single (A, B) to roll out; x is the caller's)
         if (lane < n) Z[lane] = x0r - (xref_sh ? shc[SL.off_xref + lane] : GL(rp.xref)[(size_t)inst * rp.xref_stride + lane]);
         wave_fence_lds();
         ALMPC_STAMP(inst, 12);

@@ -68,72 +68,108 @@ __global__ __launch_bounds__(256) void k_sqp_prepare(SqpParams p) {
     }
 }
 
-// After the QP: dx_{k+1} = A_k dx_k + B_k v_k + c_k (dx_0 = 0), xbar += s dx, ubar += s v; one wave per instance.
-// Lane j < n owns component j of dx; the previous dx is exchanged through LDS.
-__global__ __launch_bounds__(64) void k_sqp_step(SqpParams p) {
-    __shared__ double dxs[2][64];
+// After the QP: dx_{k+1} = A_k dx_k + B_k v_k + c_k (dx_0 = 0), xbar += s dx, ubar += s v; one workgroup per instance.
+// The recursion is a dependent chain of N small products.  All of its operands are staged in LDS first -- [A_k | B_k | c_k] of
+// `chunk` stages at a time with the whole workgroup (one HBM round trip per chunk; the host sizes the chunk, normally all N
+// stages), v once -- and wave 0 then walks the stages on its own: lane j < n owns dx_j, the previous dx comes from the lanes
+// themselves (v_readlane), so a stage is n + m FMAs deep with no barrier.  Trajectory update, results and the batch maxima
+// are done by all threads around it.
+__host__ __device__ inline int sqp_step_chunk(int n, int m, int N) {
+    const long E = (long)n * n + (long)n * m + n, fixed = (long)(N + 1) * n + (long)m * N + 16;
+    long ch = (12288 - fixed) / E;  // 96 KB of doubles
+    return (int)(ch < 1 ? 1 : (ch > N ? N : ch));
+}
+__host__ __device__ inline size_t sqp_step_lds_doubles(int n, int m, int N) {
+    return (size_t)sqp_step_chunk(n, m, N) * ((size_t)n * n + (size_t)n * m + n) + (size_t)(N + 1) * n + (size_t)m * N + 16;
+}
+
+__global__ __launch_bounds__(256) void k_sqp_step(SqpParams p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int skip;
-    const int n = p.n, m = p.m, N = p.N, nz = p.nz, lane = threadIdx.x;
+    const int n = p.n, m = p.m, N = p.N, nz = p.nz, tid = threadIdx.x, nn = n * n, nm = n * m, E = nn + nm + n;
+    const int CH = sqp_step_chunk(n, m, N);
+    double* stage = smem;                       // [CH][E]
+    double* dxa = stage + (size_t)CH * E;       // [(N+1)][n]: dx_0 = 0, dx_1, ...
+    double* vs = dxa + (size_t)(N + 1) * n;     // [nz]
+    double* red = vs + nz;                      // [16]
     const size_t i = blockIdx.x;
     const double* v = p.v + i * (size_t)nz;
+    const double* cg = p.c + i * (size_t)N * n;
     double* xb = p.xbar + i * (size_t)(N + 1) * n;
     double* ub = p.ubar + i * (size_t)nz;
+    const double* Ag = p.A + i * N * (size_t)nn;
+    const double* Bg = p.B + i * N * (size_t)nm;
     // largest step / defect of this instance, and the finite check
     double vmax = 0.0, cmax = 0.0;
     int finite = 1;
-    for (int t = lane; t < nz; t += 64) {
-        const double a = fabs(v[t]);
-        finite &= (a <= 1.79e308) ? 1 : 0;
-        vmax = fmax(vmax, a);
+    for (int t = tid; t < nz; t += 256) {
+        const double a = v[t];
+        vs[t] = a;
+        finite &= (fabs(a) <= 1.79e308) ? 1 : 0;
+        vmax = fmax(vmax, fabs(a));
     }
-    for (int t = lane; t < N * n; t += 64) {
-        const double a = fabs(p.c[i * (size_t)N * n + t]);
+    for (int t = tid; t < N * n; t += 256) {
+        const double a = fabs(cg[t]);
         finite &= (a <= 1.79e308) ? 1 : 0;
         cmax = fmax(cmax, a);
     }
+    if (tid < n) dxa[tid] = 0.0;
+    vmax = wave_max(vmax);
+    cmax = wave_max(cmax);
     finite = __all(finite);
-    if (lane == 0) {
-        const int s = (!finite || p.flag[i] != 0 || p.status[i] == 2) ? 1 : 0;
-        skip = s;
-        if (s) p.bad[i] = 1;
+    if ((tid & 63) == 0) {
+        red[tid >> 6] = vmax; red[4 + (tid >> 6)] = cmax; red[8 + (tid >> 6)] = finite ? 0.0 : 1.0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int bad = (red[8] + red[9] + red[10] + red[11] != 0.0) || p.flag[i] != 0 || p.status[i] == 2;
+        skip = bad;
+        if (bad) p.bad[i] = 1;
+        else {
+            atomicMax(p.stats + 0, (unsigned long long)__double_as_longlong(fmax(fmax(red[0], red[1]), fmax(red[2], red[3]))));
+            atomicMax(p.stats + 1, (unsigned long long)__double_as_longlong(fmax(fmax(red[4], red[5]), fmax(red[6], red[7]))));
+        }
     }
     __syncthreads();
     if (!skip) {
-        vmax = wave_max(vmax);
-        cmax = wave_max(cmax);
-        if (lane == 0) {
-            atomicMax(p.stats + 0, (unsigned long long)__double_as_longlong(vmax));
-            atomicMax(p.stats + 1, (unsigned long long)__double_as_longlong(cmax));
-        }
-        if (lane < n) dxs[0][lane] = 0.0;
-        __syncthreads();
-        for (int k = 0; k < N; ++k) {
-            const double* A = p.A + (i * N + k) * (size_t)n * n;
-            const double* B = p.B + (i * N + k) * (size_t)n * m;
-            const double* dxp = dxs[k & 1];
-            if (lane < n) {
-                double s = p.c[(i * N + k) * (size_t)n + lane];
-                for (int c2 = 0; c2 < n; ++c2) s += A[(size_t)c2 * n + lane] * dxp[c2];
-                for (int c2 = 0; c2 < m; ++c2) s += B[(size_t)c2 * n + lane] * v[k * m + c2];
-                dxs[(k + 1) & 1][lane] = s;
-                xb[(size_t)(k + 1) * n + lane] += p.step_scale * s;
+        double dxr = 0.0;                       // wave 0, lane j < n: dx_j of the current stage
+        const int lj = tid < n ? tid : 0;
+        for (int k0 = 0; k0 < N; k0 += CH) {
+            const int cnt = (N - k0 < CH) ? N - k0 : CH;
+            if (k0 > 0) __syncthreads();        // the previous chunk has been consumed
+            for (int t = tid; t < cnt * E; t += 256) {
+                const int k = k0 + t / E, e = t % E;
+                stage[t] = e < nn ? Ag[(size_t)k * nn + e] : (e < nn + nm ? Bg[(size_t)k * nm + e - nn] : cg[(size_t)k * n + e - nn - nm]);
             }
             __syncthreads();
-        }
-        for (int t = lane; t < nz; t += 64) {
-            const int a = t % m;
-            ub[t] = fmin(fmax(ub[t] + p.step_scale * v[t], p.umin[a]), p.umax[a]);  // v is feasible: the clip only removes rounding
+            if (tid < 64) {
+                for (int kk = 0; kk < cnt; ++kk) {
+                    const double* A = stage + (size_t)kk * E;
+                    const double* B = A + nn;
+                    double s = A[nn + nm + lj];
+                    for (int c2 = 0; c2 < n; ++c2) s += A[c2 * n + lj] * readlane_d(dxr, c2);
+                    for (int c2 = 0; c2 < m; ++c2) s += B[c2 * n + lj] * vs[(k0 + kk) * m + c2];
+                    dxr = s;
+                    if (tid < n) dxa[(size_t)(k0 + kk + 1) * n + tid] = s;
+                }
+            }
         }
         __syncthreads();
     }
-    // results: the iterate itself (also for a skipped instance: its last good iterate)
-    for (int t = lane; t < (N + 1) * n; t += 64) {
-        const double xv = xb[t];
+    // trajectory update and results: the iterate itself (for a skipped instance: its last good iterate)
+    for (int t = tid; t < (N + 1) * n; t += 256) {
+        double xv = xb[t];
+        if (!skip && t >= n) { xv += p.step_scale * dxa[t]; xb[t] = xv; }
         p.x[i * (size_t)(N + 1) * n + t] = xv;
         p.ex[i * (size_t)(N + 1) * n + t] = xv - p.xref[t];
     }
-    for (int t = lane; t < nz; t += 64) {
-        const double uv = ub[t];
+    for (int t = tid; t < nz; t += 256) {
+        double uv = ub[t];
+        if (!skip) {
+            const int a = t % m;
+            uv = fmin(fmax(uv + p.step_scale * vs[t], p.umin[a]), p.umax[a]);  // v is feasible: the clip only removes rounding
+            ub[t] = uv;
+        }
         p.u[i * (size_t)nz + t] = uv;
         p.eu[i * (size_t)nz + t] = uv - p.uref[t];
     }

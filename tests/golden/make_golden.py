@@ -35,7 +35,36 @@ def case(p, X0, name, extra=None):
     print(name, len(out), "cases")
 
 
+def sqp_case(name="fnn_sqp"):
+    """NLP branch (Fnn as equality constraints): converged Gauss-Newton SQP of the restatement, certified by the NLP's own
+    projected-gradient residual."""
+    f = mo.synthetic_fnn(act="tanh")
+    n, m, N = 4, 2, 20
+    x_ref = np.tile(np.array([0.2, -0.1, 0.05, 0.0])[:, None], (1, N + 1)); u_ref = np.tile(np.array([0.1, -0.2])[:, None], (1, N))
+    Al, Bl = f.jacobian(x_ref[:, -1], u_ref[:, -1])
+    Q, R, S = 100.0 * np.eye(n), 0.1 * np.eye(m), np.zeros((m, m))
+    P = mo.dare(Al, Bl, Q, R)
+    umin, umax = -np.ones(m), np.ones(m)
+    X0 = x_ref[:, 0][None, :] + 0.6 * mo.splitmix_normal(0x5EED000A, 0, 4, n)
+    out = []
+    for x0 in X0:
+        X, U, hist = mo.sqp_fnn(f, x0, x_ref, u_ref, Q, R, S, P, umin, umax, iters=60)
+        res = mo.nlp_kkt_residual(f, x0, U, x_ref, u_ref, Q, R, S, P, umin, umax)
+        assert res <= 1e-9 and hist[-1][0] <= 1e-9, (res, hist[-1])
+        out.append(dict(x0=x0.tolist(), u=U.tolist(), x=X.tolist(), kkt=res, n_active=int(((U <= -1) | (U >= 1)).sum()),
+                        cost=mo.nlp_cost_and_gradient(f, x0, U, x_ref, u_ref, Q, R, S, P)[0]))
+    d = dict(name=name, source="oracle/mpc_oracle.py::sqp_fnn (60 iterations, exact QP solves), certified by nlp_kkt_residual; "
+                               "NOT reference output (the reference gives this NLP to Ipopt)",
+             n=n, m=m, N=N, act="tanh", W_in=f.W_in.tolist(), W_h=[w.tolist() for w in f.W_h], b_h=[b.tolist() for b in f.b_h],
+             W_out=f.W_out.tolist(), q=100.0, r=0.1, s=0.0, P=P.tolist(), u_min=umin.tolist(), u_max=umax.tolist(),
+             x_ref=x_ref[:, 0].tolist(), u_ref=u_ref[:, 0].tolist(), cases=out)
+    with open(os.path.join(HERE, name + ".json"), "w") as fh:
+        json.dump(d, fh)
+    print(name, len(out), "cases, active bounds:", [c["n_active"] for c in out])
+
+
 if __name__ == "__main__":
+    sqp_case()
     case(mo.double_integrator(), np.array([[1.0, 0.0], [5.0, 0.0], [-3.0, 1.0], [0.0, 0.0]]), "double_integrator")
     with open(os.path.join(HERE, "linear_regressor_train_result.jls"), "rb") as f:
         A, B = mo.decode_linear_regressor_fixture(f.read())

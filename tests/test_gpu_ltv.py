@@ -133,9 +133,40 @@ def test_ltv_error_behaviour(capi, mo):
     s.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max)   # back to the shared path: references work again
     s.set_reference(p.x_ref, p.u_ref)
     s.close()
-    big = capi.Solver(12, 4, 32, 2)   # nz = 128: the accumulators do not fit LDS
+    big = capi.Solver(40, 3, 40, 2)   # 1720 elements of (A, B) per stage: beyond the register build; LDS build: 280 KB of accumulators
     with pytest.raises(capi.AlmpcError) as ei:
-        big.design_ltv(np.zeros((2, 32, 12, 12)), np.zeros((2, 32, 12, 4)), None, np.zeros((2, 12, 33)), np.zeros((2, 4, 32)), None, None,
-                       np.eye(12), np.eye(4), None, np.eye(12), -np.ones(4), np.ones(4))
+        big.design_ltv(np.zeros((2, 40, 40, 40)), np.zeros((2, 40, 40, 3)), None, np.zeros((2, 40, 41)), np.zeros((2, 3, 40)), None, None,
+                       np.eye(40), np.eye(3), None, np.eye(40), -np.ones(3), np.ones(3))
     assert ei.value.code == -4
     big.close()
+
+
+@pytest.mark.parametrize("path", ["registers", "lds"])
+@pytest.mark.parametrize("shape", [(12, 4, 32), (3, 1, 37), (6, 3, 20)])
+def test_ltv_design_kernels_both_builds(capi, mo, path, shape, monkeypatch):
+    """k_design_ltv_reg (accumulators in registers, nz <= 128; (12, 4, 32) is its largest quadrotor-like shape) and the LDS build
+    it replaced (still the route for larger nz; forced here through ALMPC_LTV_LDS) against the numpy restatement: H, q and u*."""
+    n, m, N = shape
+    if path == "lds":
+        if ((m * N) ** 2 + 3 * n * m * N + 4 * n * n + n * m + 3 * n + m * N) * 8 > 160 * 1024:
+            pytest.skip("LDS build: nz^2 + 3 n nz doubles do not fit 160 KB")
+        monkeypatch.setenv("ALMPC_LTV_LDS", "1")
+    rng = np.random.default_rng(n * 100 + N)
+    b = 5
+    A_all = np.stack([[0.85 * np.eye(n) + 0.1 * rng.standard_normal((n, n)) / np.sqrt(n) for _ in range(N)] for _ in range(b)])
+    B_all = rng.standard_normal((b, N, n, m))
+    c_all = 0.05 * rng.standard_normal((b, N, n))
+    xbar = rng.standard_normal((b, n, N + 1)); ubar = 0.2 * rng.standard_normal((b, m, N))
+    x_ref = 0.2 * rng.standard_normal((n, N + 1)); u_ref = 0.1 * rng.standard_normal((m, N))
+    Q, R, S, P = 10.0 * np.eye(n), 1.0 * np.eye(m), 0.3 * np.eye(m), 25.0 * np.eye(n) + 0.2 * np.ones((n, n))
+    umin, umax = -0.5 * np.ones(m), 0.6 * np.ones(m)
+    s, r = solve_ltv(capi, A_all, B_all, c_all, xbar, ubar, x_ref, u_ref, Q, R, S, P, umin, umax)
+    assert np.all(r["status"] == 0)
+    for i in range(b):
+        H, q, lo, hi = mo.ltv_qp(A_all[i], B_all[i], c_all[i], xbar[i], ubar[i], x_ref, u_ref, Q, R, S, P, umin, umax)
+        Hd = s.get_design_instance(i)["H"]
+        assert np.abs(Hd - H).max() <= 1e-11 * np.abs(H).max()
+        assert np.abs(s.get_gradient_instance(i) - q).max() <= 1e-11 * max(1.0, np.abs(q).max())
+        v = mo.solve_box_qp_exact(H, q, lo, hi)
+        assert np.abs(r["e_u"][i].T.reshape(-1) - v).max() <= U_TOL
+    s.close()

@@ -445,10 +445,13 @@ def test_state_constraint_mirror(pkg, mo):
 
 
 # ---------------------------------------------------------------------------- black-box (Fnn) models: BASELINE config 4
-def test_fnn_jacobian_kernel_vs_oracle(capi, mo):
+@pytest.mark.parametrize("build", ["wave_per_point", "workgroup_per_point"])
+def test_fnn_jacobian_kernel_vs_oracle(capi, mo, build, monkeypatch):
     """Batched linearisation on the GPU (stand-in for AutomationLabsSystems.proceed_system_linearization) vs the numpy
     restatement, at random points on both sides of the relu kinks, for every supported activation (device tanh/exp vs
-    libm: a few ulp through two hidden layers)."""
+    libm: a few ulp through two hidden layers); both kernel builds (small networks: one wave per point, weights in LDS)."""
+    if build == "workgroup_per_point":
+        monkeypatch.setenv("ALMPC_FNN_WG", "1")
     for act in ("relu", "identity", "tanh", "sigmoid", "swish"):
         f = mo.synthetic_fnn(act=act)
         X = mo.splitmix_normal(0x5EED0004, 0, 200, 4) * 2.0

@@ -168,3 +168,25 @@ def test_mirror_non_linear_programming_type(pkg, mo):
         pkg.proceed_controller(sys_, "model_predictive_control", N, 1, x_ref, u_ref, mpc_programming_type="non_linear",
                                mpc_terminal_ingredient="equality")
     C.tuning.modeler.solver.close()
+
+
+def test_golden_sqp_vectors_through_the_c_abi(capi, mo):
+    """tests/golden/fnn_sqp.json (certified KKT points of the NLP): 60 device iterations from the same start reach them."""
+    import json, os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fnn_sqp.json")) as fh:
+        g = json.load(fh)
+    n, m, N = g["n"], g["m"], g["N"]
+    X0 = np.array([c["x0"] for c in g["cases"]])
+    xr = np.tile(np.array(g["x_ref"])[:, None], (1, N + 1)); ur = np.tile(np.array(g["u_ref"])[:, None], (1, N))
+    s = capi.Solver(n, m, N, len(X0))
+    s.sqp_fnn_setup(np.array(g["W_in"]), [np.array(w) for w in g["W_h"]], [np.array(b) for b in g["b_h"]], np.array(g["W_out"]), xr, ur,
+                    g["q"] * np.eye(n), g["r"] * np.eye(m), g["s"] * np.eye(m), np.array(g["P"]), np.array(g["u_min"]), np.array(g["u_max"]),
+                    act=g["act"])
+    s.sqp_fnn_start(X0)
+    st, de = s.sqp_fnn_iterate(60)
+    r = s.get_results(want=("u", "x", "status"))
+    s.close()
+    assert np.all(r["status"] == 0) and st[-1] <= 1e-8
+    for i, c in enumerate(g["cases"]):
+        assert np.abs(r["u"][i] - np.array(c["u"])).max() <= U_TOL
+        assert np.abs(r["x"][i] - np.array(c["x"])).max() <= 1e-5

@@ -299,3 +299,29 @@ def test_sqp_restatement_reaches_a_kkt_point_of_the_nlp(mo):
     for s in range(5):
         Up = np.clip(U + 1e-3 * mo.splitmix_normal(0x5EED0007, s, m, N), umin[:, None], umax[:, None])
         assert mo.nlp_cost_and_gradient(f, x0, Up, x_ref, u_ref, Q, R, S, P)[0] >= J0 - 1e-12
+
+
+def _sqp_golden(mo):
+    g = _load("fnn_sqp")
+    f = mo.FnnModel(np.array(g["W_in"]), [np.array(w) for w in g["W_h"]], [np.array(b) for b in g["b_h"]], np.array(g["W_out"]), g["act"])
+    n, m, N = g["n"], g["m"], g["N"]
+    kw = dict(x_ref=np.tile(np.array(g["x_ref"])[:, None], (1, N + 1)), u_ref=np.tile(np.array(g["u_ref"])[:, None], (1, N)),
+              Q=g["q"] * np.eye(n), R=g["r"] * np.eye(m), S=g["s"] * np.eye(m), P=np.array(g["P"]),
+              u_min=np.array(g["u_min"]), u_max=np.array(g["u_max"]))
+    return g, f, kw
+
+
+def test_golden_sqp_vectors(mo):
+    """The committed NLP-branch vectors: the stored inputs are certified KKT points of the stored problem (independent of how
+    they were found), and the SQP restatement reproduces them."""
+    g, f, kw = _sqp_golden(mo)
+    f0 = mo.synthetic_fnn(act="tanh")
+    assert np.abs(f.W_out - f0.W_out).max() == 0.0 and np.abs(f.W_h[1] - f0.W_h[1]).max() == 0.0   # same generator as the GPU tests use
+    for c in g["cases"]:
+        x0, U = np.array(c["x0"]), np.array(c["u"])
+        assert mo.nlp_kkt_residual(f, x0, U, **kw) <= 1e-9
+        assert np.abs(np.array(c["x"]) - mo.fnn_rollout(f, x0, U)).max() <= 1e-10
+        assert c["n_active"] >= 10
+    c = g["cases"][1]
+    X, U, _ = mo.sqp_fnn(f, np.array(c["x0"]), kw["x_ref"], kw["u_ref"], kw["Q"], kw["R"], kw["S"], kw["P"], kw["u_min"], kw["u_max"], iters=60)
+    assert np.abs(U - np.array(c["u"])).max() <= 1e-9

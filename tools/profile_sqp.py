@@ -11,6 +11,7 @@ import mpc_oracle as mo
 bq = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 Nq = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 its = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+max_iter = int(sys.argv[4]) if len(sys.argv) > 4 else 25
 f = mo.synthetic_fnn(act="tanh")
 nq, mq = 4, 2
 xr = np.tile(np.array([0.2, -0.1, 0.05, 0.0])[:, None], (1, Nq + 1)); ur = np.tile(np.array([0.1, -0.2])[:, None], (1, Nq))
@@ -23,7 +24,9 @@ import time
 for rep in range(3):
     s.sqp_fnn_start(X0)
     t0 = time.perf_counter()
-    st, de = s.sqp_fnn_iterate(its)
+    st, de = s.sqp_fnn_iterate(its, opts=capi.default_opts(max_iter=max_iter, check_every=max_iter))
+    r = s.get_results(want=('polish_iters', 'iters', 'status'))
+    print('polish iters mean/max', r['polish_iters'].mean(), r['polish_iters'].max(), 'admm iters', r['iters'].mean(), 'status', np.bincount(r['status']))
     print(f"rep {rep}: {1e3 * (time.perf_counter() - t0) / its:.3f} ms / iteration; step {st[-1]:.2e} defect {de[-1]:.2e}")
 print("steps", np.array2string(st, precision=2))
 s.close()
