@@ -437,17 +437,34 @@ bool ltv_supported(const almpc_handle* h) {
     return ltv_reg_path(h) || design_ltv_lds_doubles(h->n, h->m, h->N) * sizeof(double) <= 160 * 1024;
 }
 
-hipError_t launch_design_ltv(almpc_handle* h, const DesignLtvParams& lp, hipStream_t st) {
-    const int n = h->n, m = h->m;
-    const bool reg = ltv_reg_path(h);
-    const size_t lds = (reg ? design_ltv_reg_lds_doubles(n, m, h->N) : design_ltv_lds_doubles(n, m, h->N)) * sizeof(double);
+template <int NC>
+hipError_t launch_design_ltv_reg(almpc_handle* h, const DesignLtvParams& lp, size_t lds, hipStream_t st) {
     if (lds > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reg ? reinterpret_cast<const void*>(k_design_ltv_reg) : reinterpret_cast<const void*>(k_design_ltv),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_design_ltv_reg<NC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    if (reg) hipLaunchKernelGGL(k_design_ltv_reg, dim3((unsigned)h->batch), dim3(1024), lds, st, lp);
-    else hipLaunchKernelGGL(k_design_ltv, dim3((unsigned)h->batch), dim3(256), lds, st, lp);
+    hipLaunchKernelGGL((k_design_ltv_reg<NC>), dim3((unsigned)h->batch), dim3(1024), lds, st, lp);
+    return hipGetLastError();
+}
+
+hipError_t launch_design_ltv(almpc_handle* h, const DesignLtvParams& lp, hipStream_t st) {
+    const int n = h->n, m = h->m;
+    if (ltv_reg_path(h)) {
+        const size_t lds = design_ltv_reg_lds_doubles(n, m, h->N) * sizeof(double);
+        switch (n) {
+            case 2: return launch_design_ltv_reg<2>(h, lp, lds, st);
+            case 4: return launch_design_ltv_reg<4>(h, lp, lds, st);
+            case 6: return launch_design_ltv_reg<6>(h, lp, lds, st);
+            case 12: return launch_design_ltv_reg<12>(h, lp, lds, st);
+            default: return launch_design_ltv_reg<0>(h, lp, lds, st);
+        }
+    }
+    const size_t lds = design_ltv_lds_doubles(n, m, h->N) * sizeof(double);
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_design_ltv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_design_ltv, dim3((unsigned)h->batch), dim3(256), lds, st, lp);
     return hipGetLastError();
 }
 

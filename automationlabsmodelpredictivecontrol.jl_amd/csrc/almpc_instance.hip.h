@@ -550,16 +550,17 @@ __global__ __launch_bounds__(256) void k_design_ltv(DesignLtvParams p) {
 // lanes read consecutive addresses), q sits in the registers of threads c < nz, the next stage's (A, B) are fetched one stage
 // two stages ahead (a stage is shorter than an HBM round trip), defects and state errors are staged in LDS once, and a stage
 // needs two barriers.  LDS: 3 n 128 + 4 n^2 + 2 n m + 4 n + 2 N n doubles (16 KB for n = 4, N = 50).
-constexpr int LTV_REG_NZ = 128;
+constexpr int LTV_REG_NZ = 128;  // (the kernel uses t >> 7 and t & 127)
 
 __host__ __device__ inline size_t design_ltv_reg_lds_doubles(int n, int m, int N) {
     return 3 * (size_t)n * LTV_REG_NZ + 4 * (size_t)n * n + 2 * (size_t)n * m + 4 * (size_t)n + 2 * (size_t)N * n;
 }
 
+template <int NC>  // NC > 0: the state dimension at compile time (the stage loops unroll); 0: any n
 __global__ __launch_bounds__(1024) void k_design_ltv_reg(DesignLtvParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NZP = LTV_REG_NZ;
-    const int n = p.n, m = p.m, N = p.N, nz = p.nz, nn = n * n, nm = n * m, nab = nn + nm;
+    const int n = NC > 0 ? NC : p.n, m = p.m, N = p.N, nz = p.nz, nn = n * n, nm = n * m, nab = nn + nm;
     const size_t inst = blockIdx.x;
     double* Gc = smem;                    // [n][NZP] current row block of Gamma~ (row l of the block, column c)
     double* Gn = Gc + (size_t)n * NZP;
@@ -601,17 +602,19 @@ __global__ __launch_bounds__(1024) void k_design_ltv_reg(DesignLtvParams p) {
         const double* Ak = AB + (k & 1) * nab;
         const double* Bk = Ak + nn;
         const int wcols = (k + 1) * m;  // columns of the row block that are non-zero after this stage
-        for (int t = tid; t < n * wcols; t += T_) {
-            const int c = t % wcols, pr = t / wcols;
-            double v;
-            if (c >= k * m) v = Bk[(c - k * m) * n + pr];
-            else {
-                v = 0.0;
-                for (int l = 0; l < n; ++l) v += Ak[l * n + pr] * Gc[l * NZP + c];
+        for (int t = tid; t < n * NZP; t += T_) {   // element (pr, c) of the row block: c = t mod 128, no division
+            const int c = t & (NZP - 1), pr = t >> 7;
+            if (c < wcols) {
+                double v;
+                if (c >= k * m) v = Bk[(c - k * m) * n + pr];
+                else {
+                    v = 0.0;
+                    for (int l = 0; l < n; ++l) v += Ak[l * n + pr] * Gc[l * NZP + c];
+                }
+                Gn[t] = v;
             }
-            Gn[pr * NZP + c] = v;
         }
-        if (tid >= T_ - n) {  // the last n threads (they have no share of the row block as long as n * wcols <= 1024 - n)
+        if (tid >= T_ - n) {  // the last n threads (for n <= 7 they have no share of the row block)
             const int pr = tid - (T_ - n);
             double v = cs[k * n + pr];
             for (int l = 0; l < n; ++l) v += Ak[l * n + pr] * gk[l];
@@ -623,11 +626,13 @@ __global__ __launch_bounds__(1024) void k_design_ltv_reg(DesignLtvParams p) {
         { double* t = gk; gk = gn; gn = t; }
         const double* Qk = (k == N - 1) ? Ps : Qs;  // stage N+1 carries only P (src/sub/design_mpc.jl:448-456)
         const double* rv = rv2 + (k & 1) * n;
-        for (int t = tid; t < n * wcols; t += T_) {
-            const int c = t % wcols, pr = t / wcols;
-            double v = 0.0;
-            for (int l = 0; l < n; ++l) v += Qk[l * n + pr] * Gc[l * NZP + c];
-            T[pr * NZP + c] = v;
+        for (int t = tid; t < n * NZP; t += T_) {
+            const int c = t & (NZP - 1), pr = t >> 7;
+            if (c < wcols) {
+                double v = 0.0;
+                for (int l = 0; l < n; ++l) v += Qk[l * n + pr] * Gc[l * NZP + c];
+                T[t] = v;
+            }
         }
         if (tid < nab) {  // this stage's (A, B) slot is free (last read before the barrier above): it takes stage k + 2
             if (k + 2 < N) AB[(k & 1) * nab + tid] = pre;

@@ -37,8 +37,11 @@ def main():
     traffic = {}
     for short, pat in (("k_admm", "k_admm<"), ("k_polish", "k_polish<true>"), ("k_admm_inst", "k_admm_inst"), ("k_step_fused", "k_step_fused")):
         ent = {}
+        # a kernel launched at several sizes (k_admm_inst: the 4096-instance secondary figure and the 256-instance SQP loop):
+        # the largest grid is the one the roofline entry is quoted on
+        gmax = max([int(g) for (k, c, wg, g) in rows if pat in k], default=0)
         for (k, c, wg, g), v in rows.items():
-            if pat in k:
+            if pat in k and int(g) == gmax:
                 ent[c] = (sum(v) / len(v), len(v))
         if "FETCH_SIZE" in ent and "WRITE_SIZE" in ent:
             fkb, fn = ent["FETCH_SIZE"]; wkb, wn = ent["WRITE_SIZE"]
