@@ -53,6 +53,8 @@ struct almpc_handle {
     int terminal_eq = 0, has_box = 0, mc = 0, R = 0, Rs = 0, np_pairs = 0;
     double *dGhat = nullptr, *dGnorm = nullptr, *dXmin = nullptr, *dXmax = nullptr;
     int *dRowTraj = nullptr, *dRowEq = nullptr, *dRowXidx = nullptr, *dRowState = nullptr;
+    int32_t* dOverflow = nullptr;  // [2 + batch] k_polish_gen: count, cursor and list of instances to redo with the 64-row build
+    int pgen64_attr[4] = {0, 0, 0, 0};
     // per-instance models (almpc_design_batched): persistent per-instance operands ...
     bool batched = false;
     bool ltv = false;             // almpc_design_ltv: references and gradient are part of the design
@@ -129,7 +131,7 @@ void free_all(almpc_handle* h) {
                     h->dXref, h->dUref, h->dFS, h->dV0S, h->dRho, h->dX0, h->dXs, h->dZs, h->dYs, h->dV0, h->dW, h->dX, h->dEx,
                     h->dU, h->dEu, h->dStatus, h->dIters, h->dPiters, h->dPerm, h->dSglobal, h->dGhat, h->dGnorm, h->dXmin,
                     h->dXmax, h->dRowTraj, h->dRowEq, h->dRowXidx, h->dRowState, h->bA, h->bB, h->bMinv, h->bG, h->bHs, h->bFs,
-                    h->bVs, h->bD, h->bRho, h->bH, h->bF, h->bPhi, h->bGk, h->bGam, h->bW, h->bWP, h->bP, h->bFlag, h->bQ,
+                    h->bVs, h->bD, h->bRho, h->bH, h->bF, h->bPhi, h->bGk, h->bGam, h->bW, h->bWP, h->bP, h->bFlag, h->bQ, h->dOverflow,
                     h->sqp.W_in, h->sqp.W_h, h->sqp.b_h, h->sqp.W_out, h->sqp.A, h->sqp.B, h->sqp.c, h->sqp.fval, h->sqp.ebar,
                     h->sqp.qadd, h->sqp.xref, h->sqp.uref, h->sqp.Q, h->sqp.R, h->sqp.S, h->sqp.bad, h->sqp.stats};
     for (void* p : ptrs)
@@ -1079,14 +1081,30 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         gp.zs = h->dZs; gp.ys = h->dYs; gp.v0 = h->dV0; gp.status = h->dStatus; gp.piters = h->dPiters;
         gp.max_iter = o.polish_max_iter > 0 ? o.polish_max_iter : 20 * h->R + 50;
         gp.roll_g = roll_g; gp.roll_cpl = roll_cpl; gp.roll = rp;
-        const size_t l = (size_t)PGEN_WAVES * PGEN_LDS_PER_WAVE * sizeof(double);
+        if (!h->dOverflow) HIP_TRY(h, dalloc(&h->dOverflow, (size_t)h->batch + 2));
+        HIP_TRY(h, hipMemsetAsync(h->dOverflow, 0, 2 * sizeof(int32_t), st));
+        gp.ovf = h->dOverflow;
         const dim3 grid((h->batch + PGEN_WAVES - 1) / PGEN_WAVES), block(64 * PGEN_WAVES);
+        // first launch: working sets up to 32 rows, every instance; second launch: the instances the first one flagged, up to 64 rows
+        const size_t l32 = (size_t)PGEN_WAVES * pgen_lds_per_wave(32) * sizeof(double);
+        const size_t l64 = (size_t)pgen_lds_per_wave(64) * sizeof(double);
+#define PGEN_LAUNCH(NP_)                                                                                                         \
+    do {                                                                                                                         \
+        hipLaunchKernelGGL((k_polish_gen<NP_>), grid, block, l32, st, gp);                                                       \
+        if (!h->pgen64_attr[NP_ - 1]) {                                                                                          \
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_polish_gen64<NP_>),                                   \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)l64));                               \
+            h->pgen64_attr[NP_ - 1] = 1;                                                                                         \
+        }                                                                                                                        \
+        hipLaunchKernelGGL((k_polish_gen64<NP_>), dim3(4 * h->num_cus < h->batch ? 4 * h->num_cus : h->batch), dim3(64), l64, st, gp); \
+    } while (0)
         switch (h->np_pairs) {
-            case 1: hipLaunchKernelGGL((k_polish_gen<1>), grid, block, l, st, gp); break;
-            case 2: hipLaunchKernelGGL((k_polish_gen<2>), grid, block, l, st, gp); break;
-            case 3: hipLaunchKernelGGL((k_polish_gen<3>), grid, block, l, st, gp); break;
-            default: hipLaunchKernelGGL((k_polish_gen<4>), grid, block, l, st, gp); break;
+            case 1: PGEN_LAUNCH(1); break;
+            case 2: PGEN_LAUNCH(2); break;
+            case 3: PGEN_LAUNCH(3); break;
+            default: PGEN_LAUNCH(4); break;
         }
+#undef PGEN_LAUNCH
         HIP_TRY(h, hipGetLastError());
         fused = true;
     } else if (o.polish) {

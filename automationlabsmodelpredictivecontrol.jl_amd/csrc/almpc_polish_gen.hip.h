@@ -15,8 +15,10 @@
 // multiplier (status ALMPC_INFEASIBLE).
 //
 // One wave per instance; lane l owns row pairs (2l, 2l+1) + 128 q, q < NP (R <= 128 NP).  Same machinery as
-// k_polish: Sinv = (Ghat_WW)^-1 in LDS (32 x 32, identity padded, both half-waves mirror the positions),
-// position-distributed data in registers, LDS broadcasts, DPP reductions, branch-free sweeps.
+// k_polish: Sinv = (Ghat_WW)^-1 in LDS (WL x WL, identity padded), position-distributed data in registers, LDS broadcasts,
+// DPP reductions, branch-free sweeps.  Two builds: WL = 32 (both half-waves mirror the 32 positions and split the columns of
+// every sweep; 9 KB of LDS per wave) runs on every instance; an instance whose working set outgrows 32 rows is flagged and
+// redone by the WL = 64 build (one position per lane, 38 KB per wave) in a second launch that every other wave leaves at once.
 #pragma once
 #include "almpc_kernels.hip.h"
 
@@ -37,34 +39,48 @@ struct PolishGenParams {
     const double* uref; long uref_stride;
     const double* zs; const double* ys; const double* v0;
     int32_t* status; int32_t* piters;
+    int32_t* ovf;         // [0] number of flagged instances (working set outgrew the 32-row build), [1] queue cursor of the
+                          // second launch, [2 ...] the flagged instances; [0] and [1] are zeroed before the first launch
     int max_iter;
     int roll_g, roll_cpl;
     RolloutParams roll;
 };
 
 constexpr int PGEN_WAVES = 4;
-// LDS per wave (doubles): Sinv 32x32 | rowbuf Rs(<=512) | pbufa 32 | pbufb 32 | wrow_s (32 ints) | Z trajectory shares Sinv
-constexpr int PGEN_LDS_PER_WAVE = 32 * 32 + 512 + 32 + 32 + 16;
+// LDS per wave (doubles): Sinv WL x WL | rowbuf Rs(<=512) | pbufa WL | pbufb WL | wrow_s (WL ints) | Z trajectory shares Sinv
+__host__ __device__ constexpr int pgen_lds_per_wave(int WL) { return WL * WL + 512 + WL + WL + WL / 2; }
 
-template <int NP>
-__global__ __launch_bounds__(64 * PGEN_WAVES) void k_polish_gen(PolishGenParams p) {
-    constexpr int WL = 32;
+template <int NP, int WL>
+__device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double* smem) {
+    static_assert(WL == 32 || WL == 64, "working-set capacity: 32 (mirrored half-waves) or 64 (one position per lane)");
+    constexpr int HS = 64 / WL;  // lanes per position: 2 = the half-waves split the columns of a sweep, 1 = no split
     constexpr int CH = 8;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr bool QUEUE = WL == 64;  // the 64-row build is the second launch: persistent waves pull flagged instances
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int inst = blockIdx.x * PGEN_WAVES + wv;
-    if (inst >= p.batch) return;
+  do {  // (one pass in the first launch)
+    int inst;
+    if (QUEUE) {
+        if (p.ovf[0] == 0) return;  // (nothing flagged: leave without touching the cursor)
+        int qi = 0;
+        if (lane == 0) qi = atomicAdd(p.ovf + 1, 1);
+        qi = __builtin_amdgcn_readfirstlane(qi);
+        if (qi >= p.ovf[0]) return;
+        inst = p.ovf[2 + qi];
+    } else {
+        inst = blockIdx.x * PGEN_WAVES + wv;
+        if (inst >= p.batch) return;
+    }
     const int st_in = p.status[inst];
     const int nz = p.nz, nzs = p.nzs, R = p.R, Rs = p.Rs;
     const size_t base = (size_t)inst * nzs;
-    const int pos = lane & 31, hf = lane >> 5;
-    const bool lowhalf = lane < 32;
+    const int pos = lane & (WL - 1), hf = (HS == 2) ? (lane >> 5) : 0;
+    const bool lowhalf = lane < WL;
 
-    double* Sl = smem + (size_t)wv * PGEN_LDS_PER_WAVE;
-    double* rowbuf = Sl + 32 * 32;  // [Rs]
+    double* Sl = smem + (size_t)wv * pgen_lds_per_wave(WL);
+    double* rowbuf = Sl + WL * WL;  // [Rs]
     double* pbufa = rowbuf + 512;
-    double* pbufb = pbufa + 32;
-    int* wrow_s = reinterpret_cast<int*>(pbufb + 32);
+    double* pbufb = pbufa + WL;
+    int* wrow_s = reinterpret_cast<int*>(pbufb + WL);
     const RolloutParams& rp = p.roll;
     const int n = p.n, m = p.m, N = p.N, C = n + m;
     double* Z = Sl;  // trajectory buffer (N+1) x C, first use (s0) and last use (outputs); Sinv lives here in between
@@ -133,8 +149,8 @@ __global__ __launch_bounds__(64 * PGEN_WAVES) void k_polish_gen(PolishGenParams 
     x0_bad = __any(x0_bad);
     wave_fence_lds();
     // ---- Sinv := identity (Z is dead now)
-#pragma unroll
-    for (int t = 0; t < 16; ++t) Sl[(2 * t + hf) * 32 + pos] = ((2 * t + hf) == pos) ? 1.0 : 0.0;
+#pragma unroll 8
+    for (int t = 0; t < WL / HS; ++t) Sl[(HS * t + hf) * WL + pos] = ((HS * t + hf) == pos) ? 1.0 : 0.0;
     wrow_s[pos] = 0;
     wave_fence_lds();
 
@@ -155,24 +171,24 @@ __global__ __launch_bounds__(64 * PGEN_WAVES) void k_polish_gen(PolishGenParams 
     };
     auto s_matvec = [&](const double* cb) __attribute__((always_inline)) -> double {
         double acc = 0.0;
-        for (int l0 = 0; l0 < k; l0 += 16) {
+        for (int l0 = 0; l0 < k; l0 += 8 * HS) {
             double a[8], c[8];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) { a[t] = Sl[(l0 + 2 * t + hf) * WL + pos]; c[t] = cb[l0 + 2 * t + hf]; }
+            for (int t = 0; t < 8; ++t) { a[t] = Sl[(l0 + HS * t + hf) * WL + pos]; c[t] = cb[l0 + HS * t + hf]; }
 #pragma unroll
             for (int t = 0; t < 8; ++t) acc += a[t] * c[t];
         }
-        acc += __shfl_xor(acc, 32);
+        if (HS == 2) acc += __shfl_xor(acc, 32);
         return acc;
     };
     auto s_rank1 = [&](double a, const double* ab, double scale) __attribute__((always_inline)) {
         const double as = a * scale;
-        for (int l0 = 0; l0 < k; l0 += 16) {
+        for (int l0 = 0; l0 < k; l0 += 8 * HS) {
             double cur[8], av[8];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) { cur[t] = Sl[(l0 + 2 * t + hf) * WL + pos]; av[t] = ab[l0 + 2 * t + hf]; }
+            for (int t = 0; t < 8; ++t) { cur[t] = Sl[(l0 + HS * t + hf) * WL + pos]; av[t] = ab[l0 + HS * t + hf]; }
 #pragma unroll
-            for (int t = 0; t < 8; ++t) Sl[(l0 + 2 * t + hf) * WL + pos] = cur[t] + as * av[t];
+            for (int t = 0; t < 8; ++t) Sl[(l0 + HS * t + hf) * WL + pos] = cur[t] + as * av[t];
         }
     };
     // q[.] = sum_{l<k} Ghat[W_l, rows] * a_l  (a in LDS buffer ab, zero beyond k)
@@ -302,6 +318,7 @@ __global__ __launch_bounds__(64 * PGEN_WAVES) void k_polish_gen(PolishGenParams 
 
     const bool skip = (st_in == 2) || x0_bad;
     bool give_up = skip;
+    bool overflow = false;  // the working set hit WL rows
     if (!skip) {
         // ---- initial working set: equality rows, then the input rows the ADMM multipliers flag (rows ascending)
         int flag[NP][2];
@@ -353,7 +370,7 @@ __global__ __launch_bounds__(64 * PGEN_WAVES) void k_polish_gen(PolishGenParams 
         // taken: a saturated guess can hold more rows than there are variables.
         const int ng = cnt < 64 ? cnt : 64;
         for (int gi = 0; gi < ng; ++gi) {
-            if (k == WL) { give_up = true; break; }
+            if (k == WL) { give_up = true; overflow = true; break; }
             const int j = __builtin_amdgcn_readlane(g_row, gi), sd = __builtin_amdgcn_readlane(g_sd, gi);
             double gj[NP][2], u, dp, gjj;
             dir_u(j, gj, u, dp, gjj);
@@ -409,7 +426,7 @@ __global__ __launch_bounds__(64 * PGEN_WAVES) void k_polish_gen(PolishGenParams 
             double lam_p = 0.0;
             bool added = false;
             while (it < max_iter) {
-                if (k == WL) { fin = 1; give_up = true; break; }
+                if (k == WL) { fin = 1; give_up = true; overflow = true; break; }
                 double u, dp, gjj, dv[NP][2], gj[NP][2];
                 dir_u(pr, gj, u, dp, gjj);
                 dir_d(gj, dv);
@@ -463,6 +480,7 @@ __global__ __launch_bounds__(64 * PGEN_WAVES) void k_polish_gen(PolishGenParams 
     if (lane == 0) {
         p.piters[inst] = it;
         p.status[inst] = (st_in == 2) ? 2 : ((fin == 0) ? 0 : (fin == 3 ? 3 : 1));
+        if (!QUEUE && overflow && fin != 3) p.ovf[2 + atomicAdd(p.ovf, 1)] = inst;
     }
     wave_fence_lds();
     {
@@ -499,6 +517,23 @@ __global__ __launch_bounds__(64 * PGEN_WAVES) void k_polish_gen(PolishGenParams 
             rp.x[xo + t] = (t < n) ? rp.x0[(size_t)inst * n + t] : ev + rp.xref[(size_t)inst * rp.xref_stride + t];
         }
     }
+    if (QUEUE) wave_fence_lds();  // the next instance reuses this wave's LDS slot
+  } while (QUEUE);
+}
+
+// first launch: one wave per instance, working sets up to 32 rows (two waves per SIMD: at most 256 registers)
+template <int NP>
+__global__ __launch_bounds__(64 * PGEN_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_polish_gen(PolishGenParams p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    polish_gen_body<NP, 32>(p, smem);
+}
+
+// second launch: the instances the first one flagged, working sets up to 64 rows; single-wave workgroups (38 KB of LDS each:
+// four per CU, and an empty queue costs a few microseconds -- 152 KB workgroups took 45 us to launch and leave)
+template <int NP>
+__global__ __launch_bounds__(64) void k_polish_gen64(PolishGenParams p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    polish_gen_body<NP, 64>(p, smem);
 }
 
 }  // namespace almpc

@@ -404,6 +404,35 @@ def test_state_rows_vs_exact_oracle(capi, mo, name):
     assert n_state_active > 0, "test inputs never activate a state row"
 
 
+def test_state_rows_working_sets_beyond_32_rows(capi, mo):
+    """Tight state box + terminal equality on the quadrotor: 12 equality rows are always in the working set, and several instances
+    end with 33..64 active rows.  Those outgrow the 32-row build of k_polish_gen, are flagged and redone by its 64-row build in a
+    second launch: every feasible instance must match the exact oracle, every infeasible one must be reported as such."""
+    q = mo.quadrotor()
+    xmax = np.array([1, 1, 1, .5, .5, .5, .1, .1, .1, .1, .1, .1]) * 3.0
+    p = mo.make_problem(q.A, q.B, 30, q.u_min, q.u_max, x_min=-xmax, x_max=xmax, terminal="equality")
+    X0 = np.clip(mo.quadrotor_x0_batch(32, 1.0, first_instance=900), -0.99 * xmax, 0.99 * xmax)
+    s = capi.Solver(p.n, p.m, p.N, len(X0))
+    s.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max, xmin=p.x_min, xmax=p.x_max, terminal="equality")
+    s.update_initialization(X0)
+    s.calculate()
+    r = s.get_results()
+    s.close()
+    big = 0
+    for i in range(len(X0)):
+        try:
+            e = mo.solve_mpc_exact(p, X0[i], return_info=True)
+        except ValueError:
+            assert r["status"][i] == 3
+            continue
+        assert r["status"][i] == 0, (i, r["status"][i])
+        assert np.abs(r["u"][i] - e["u"]).max() <= U_TOL and np.abs(r["x"][i] - e["x"]).max() <= X_TOL
+        assert np.abs(r["e_x"][i][:, -1]).max() <= 1e-9
+        na = int((np.isclose(e["u"], p.u_min[:, None]) | np.isclose(e["u"], p.u_max[:, None])).sum()) + e["info"]["n_active_state"]
+        big += na > 32
+    assert big >= 3, "test inputs do not reach the second tier"
+
+
 def test_state_rows_need_polish(capi, mo):
     p, X0 = _constrained_problems(mo)["di_box"]
     s = capi.Solver(2, 1, 10, len(X0))

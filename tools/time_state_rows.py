@@ -5,7 +5,10 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np, almpc_loader, mpc_oracle as mo, bench
 capi = almpc_loader.load_package()._capi
 p = mo.quadrotor(); b = 4096
-for amp, box in ((1.0, 3.0), (1.0, 1.0), (3.0, 3.0)):
+CASES = ((1.0, 3.0), (1.0, 1.0), (3.0, 3.0))
+if len(sys.argv) > 1:  # one case only (for rocprofv3): python tools/time_state_rows.py <case 0..2>
+    CASES = (CASES[int(sys.argv[1])],)
+for amp, box in CASES:
     X0 = mo.quadrotor_x0_batch(b, amp)
     xmax = box * np.array([1, 1, 1, .5, .5, .5, .1, .1, .1, .1, .1, .1]) * 3.0
     X0 = np.clip(X0, -0.99 * xmax, 0.99 * xmax)
