@@ -1235,22 +1235,37 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
         const int n = rp.n, m = rp.m, N = rp.N, C = n + m;
         double* Z = wave_lds;  // (N+1) x C trajectory buffer over the (now dead) active-set buffers; sized by the host
         const d2 dvp = *reinterpret_cast<const d2*>(cd + rc);
+        // references first, on separate code paths for their two homes (LDS copy of a shared reference / global memory): a
+        // select of the two addresses becomes a flat load that waits for every store in flight before it
+        double ur0 = 0.0, ur1 = 0.0;
+        if (uref_sh) {
+            ur0 = shc[SL.off_uref + (in0 ? r0 : 0)];
+            ur1 = shc[SL.off_uref + (in1 ? r1 : 0)];
+        } else {
+            const double* ug = GL(rp.uref) + (size_t)inst * rp.uref_stride;
+            ur0 = ug[in0 ? r0 : 0];
+            ur1 = ug[in1 ? r1 : 0];
+        }
+        const int m0 = r0 % m, m1 = (m0 + 1 == m) ? 0 : m0 + 1, k0s = r0 / m, k1s = (m0 + 1 == m) ? k0s + 1 : k0s;
         if (in0) {
-            const double ur = uref_sh ? shc[SL.off_uref + r0] : GL(rp.uref)[(size_t)inst * rp.uref_stride + r0];
-            const double uu = fmin(fmax(wout[0] * dvp[0] + ur, shc[SL.off_umin + r0 % m]), shc[SL.off_umax + r0 % m]);
+            const double uu = fmin(fmax(wout[0] * dvp[0] + ur0, shc[SL.off_umin + m0]), shc[SL.off_umax + m0]);
             GL(rp.u)[(size_t)inst * nz + r0] = uu;
-            GL(rp.eu)[(size_t)inst * nz + r0] = uu - ur;
-            Z[(size_t)(r0 / m) * C + n + r0 % m] = uu - ur;
+            GL(rp.eu)[(size_t)inst * nz + r0] = uu - ur0;
+            Z[(size_t)k0s * C + n + m0] = uu - ur0;
         }
         if (in1) {
-            const double ur = uref_sh ? shc[SL.off_uref + r1] : GL(rp.uref)[(size_t)inst * rp.uref_stride + r1];
-            const double uu = fmin(fmax(wout[1] * dvp[1] + ur, shc[SL.off_umin + r1 % m]), shc[SL.off_umax + r1 % m]);
+            const double uu = fmin(fmax(wout[1] * dvp[1] + ur1, shc[SL.off_umin + m1]), shc[SL.off_umax + m1]);
             GL(rp.u)[(size_t)inst * nz + r1] = uu;
-            GL(rp.eu)[(size_t)inst * nz + r1] = uu - ur;
-            Z[(size_t)(r1 / m) * C + n + r1 % m] = uu - ur;
+            GL(rp.eu)[(size_t)inst * nz + r1] = uu - ur1;
+            Z[(size_t)k1s * C + n + m1] = uu - ur1;
         }
         if (p.fuse_rollout == 2) return;  // time-varying models: inputs only (there is no single (A, B) to roll out; x is the caller's)
-        if (lane < n) Z[lane] = x0r - (xref_sh ? shc[SL.off_xref + lane] : GL(rp.xref)[(size_t)inst * rp.xref_stride + lane]);
+        if (lane < n) {
+            double xr0;
+            if (xref_sh) xr0 = shc[SL.off_xref + lane];
+            else xr0 = GL(rp.xref)[(size_t)inst * rp.xref_stride + lane];
+            Z[lane] = x0r - xr0;
+        }
         wave_fence_lds();
         ALMPC_STAMP(inst, 12);
         switch (p.roll_cpl) {
@@ -1262,11 +1277,34 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
         ALMPC_STAMP(inst, 13);
         const int nx = n * (N + 1);
         const size_t xo = (size_t)inst * nx;
-        for (int t = lane; t < nx; t += 64) {
-            const double ev = Z[(size_t)(t / n) * C + t % n];
-            const double xr = xref_sh ? shc[SL.off_xref + t] : GL(rp.xref)[(size_t)inst * rp.xref_stride + t];
-            GL(rp.ex)[xo + t] = ev;
-            GL(rp.x)[xo + t] = (t < n) ? x0r : ev + xr;  // t < n <= 64 happens in the first pass only, where t == lane
+        // all values first (LDS trajectory, references from their home -- two code paths, see above), then the stores back to back
+        const float inv_n = 1.0f / (float)n;   // t / n for t < 4096, n <= 64: (t + 0.5) / n is never within 1e-3 of an integer
+        for (int t0 = 0; t0 < nx; t0 += 4 * 64) {
+            double ev[4], xr[4];
+            int tt[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + 64 * u + lane;
+                tt[u] = t < nx ? t : nx - 1;
+                const int kq = (int)(((float)tt[u] + 0.5f) * inv_n);
+                ev[u] = Z[(size_t)tt[u] + (size_t)kq * m];   // (t / n) * C + t % n
+            }
+            if (xref_sh) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) xr[u] = shc[SL.off_xref + tt[u]];
+            } else {
+                const double* xg = GL(rp.xref) + (size_t)inst * rp.xref_stride;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) xr[u] = xg[tt[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + 64 * u + lane;
+                if (t < nx) {
+                    GL(rp.ex)[xo + t] = ev[u];
+                    GL(rp.x)[xo + t] = (t < n) ? x0r : ev[u] + xr[u];  // t < n <= 64 happens in the first pass only, where t == lane
+                }
+            }
         }
         ALMPC_STAMP(inst, 14);
     }
