@@ -709,12 +709,23 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
         const d2 zz = *reinterpret_cast<const d2*>(GL(p.zs) + base + rc);
         v00 = vv[0]; v01 = vv[1]; y0 = yy[0]; y1 = yy[1]; z0 = zz[0]; z1 = zz[1];
         // bounds exactly as k_admm forms them ((umin - uref) * (1/d)): its z sits ON these values when active
+        // (references: LDS copy of a shared one, or global per instance.  Two code paths kept apart by an empty asm: a select of the
+        // two addresses -- which is what the optimiser makes of a plain if/else as well -- is a flat load that waits for every
+        // store in flight, here the trajectory stores of the previous instance)
+        double urp0, urp1;
+        if (uref_sh) {
+            urp0 = shc[SL.off_uref + (in0 ? r0 : 0)]; urp1 = shc[SL.off_uref + (in1 ? r1 : 0)];
+            asm volatile("" : "+v"(urp0), "+v"(urp1));
+        } else {
+            const double* ug = GL(p.uref) + (size_t)inst * p.uref_stride;
+            urp0 = ug[in0 ? r0 : 0]; urp1 = ug[in1 ? r1 : 0];
+        }
         if (in0) {
-            const double di = 1.0 / dv[0], ur = uref_sh ? shc[SL.off_uref + r0] : GL(p.uref)[(size_t)inst * p.uref_stride + r0];
+            const double di = 1.0 / dv[0], ur = urp0;
             lo0 = (shc[SL.off_umin + r0 % p.m] - ur) * di; hi0 = (shc[SL.off_umax + r0 % p.m] - ur) * di; w0 = fmin(fmax(z0, lo0), hi0);
         } else { v00 = 0.0; y0 = 0.0; z0 = 0.0; }
         if (in1) {
-            const double di = 1.0 / dv[1], ur = uref_sh ? shc[SL.off_uref + r1] : GL(p.uref)[(size_t)inst * p.uref_stride + r1];
+            const double di = 1.0 / dv[1], ur = urp1;
             lo1 = (shc[SL.off_umin + r1 % p.m] - ur) * di; hi1 = (shc[SL.off_umax + r1 % p.m] - ur) * di; w1 = fmin(fmax(z1, lo1), hi1);
         } else { v01 = 0.0; y1 = 0.0; z1 = 0.0; }
     }
@@ -1241,6 +1252,7 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
         if (uref_sh) {
             ur0 = shc[SL.off_uref + (in0 ? r0 : 0)];
             ur1 = shc[SL.off_uref + (in1 ? r1 : 0)];
+            asm volatile("" : "+v"(ur0), "+v"(ur1));  // keeps the two paths apart (see the prologue)
         } else {
             const double* ug = GL(rp.uref) + (size_t)inst * rp.uref_stride;
             ur0 = ug[in0 ? r0 : 0];
@@ -1262,7 +1274,7 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
         if (p.fuse_rollout == 2) return;  // time-varying models: inputs only (there is no single (A, B) to roll out; x is the caller's)
         if (lane < n) {
             double xr0;
-            if (xref_sh) xr0 = shc[SL.off_xref + lane];
+            if (xref_sh) { xr0 = shc[SL.off_xref + lane]; asm volatile("" : "+v"(xr0)); }
             else xr0 = GL(rp.xref)[(size_t)inst * rp.xref_stride + lane];
             Z[lane] = x0r - xr0;
         }
@@ -1292,6 +1304,7 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
             if (xref_sh) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) xr[u] = shc[SL.off_xref + tt[u]];
+                asm volatile("" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]));
             } else {
                 const double* xg = GL(rp.xref) + (size_t)inst * rp.xref_stride;
 #pragma unroll
