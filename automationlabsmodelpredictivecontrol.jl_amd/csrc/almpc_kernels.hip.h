@@ -111,8 +111,10 @@ struct AdmmParams {
 // instance vector in the MFMA C/D layout: lane (q = l>>4, col = l&15) holds rows 16w + q + 4i,
 // i = 0..3, of instance col -- so the whole ADMM vector update is register-local and only the
 // right-hand side travels through LDS (double-buffered, one barrier per iteration).
-template <int NRB, int KS>
-__device__ __forceinline__ void admm_body(const AdmmParams& p, double* smem) {
+// `after_requests` runs right after the prologue's own global loads have been requested (the fused step kernel asks for G there:
+// loads return in order, so a stream requested first would hold up e0 and the fragments of the first iteration)
+template <int NRB, int KS, typename AfterRequests>
+__device__ __forceinline__ void admm_body(const AdmmParams& p, double* smem, AfterRequests after_requests) {
     constexpr int RP = 16 * NRB;  // padded rows
     static_assert(4 * KS <= RP, "K padding must fit the row padding");
     double* rhs0 = smem;                    // [RP][16]
@@ -164,6 +166,7 @@ __device__ __forceinline__ void admm_body(const AdmmParams& p, double* smem) {
     double a[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) a[ks] = p.MinvFrag[((size_t)(wv * KS + ks)) * 64 + lane];
+    after_requests();
     ALMPC_STAMP(blockIdx.x * NRB + wv, 5);
     __syncthreads();
     ALMPC_STAMP(blockIdx.x * NRB + wv, 6);
@@ -375,7 +378,7 @@ __device__ __forceinline__ void admm_body(const AdmmParams& p, double* smem) {
 template <int NRB, int KS>
 __global__ __launch_bounds__(64 * NRB) void k_admm(AdmmParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    admm_body<NRB, KS>(p, smem);
+    admm_body<NRB, KS>(p, smem, []() {});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1369,8 +1372,8 @@ void k_polish(PolishParams p_arg) {
 // One kernel per step for shapes whose tile is 8 waves (nz in 113..128): workgroup b first runs the ADMM of tile b, then
 // polishes the 16 instances of that tile with the tile-local queue of k_polish<true> -- the two kernels already pair up
 // workgroup b with tile b.  What the fusion buys: one launch instead of two, and the copy of G into LDS is requested
-// BEFORE the ADMM phase with direct global -> LDS loads (global_load_lds_dwordx4: no registers, 1 KB per wave instruction),
-// so it is there when the polish starts.  LDS: [G | union(ADMM buffers, polish buffers)].
+// under the ADMM phase (right after its prologue's own loads) with direct global -> LDS loads (global_load_lds_dwordx4: no
+// registers, 1 KB per wave instruction), so it is there when the polish starts.  LDS: [G | union(ADMM buffers, polish buffers)].
 // ------------------------------------------------------------------------------------------------
 constexpr int STEP_KOFF = (int)((sizeof(AdmmParams) + 7) & ~size_t(7));  // PolishParams follows AdmmParams in the kernarg segment
 
@@ -1381,14 +1384,16 @@ void k_step_fused(AdmmParams ap, PolishParams pp) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int gs = (pp.nz + 1) & ~1, hs = gs / 2;  // rows of G packed to stride gs in LDS (as polish_body<true, ...> reads them)
-    for (int r = wv; r < pp.nz; r += NRB) {
-        if (lane < hs) {  // one row per wave instruction: hs lanes x 16 bytes
-            const char* src = reinterpret_cast<const char*>(pp.G + (size_t)r * pp.nzs) + lane * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(smem + (size_t)r * gs), 16, 0, 0);
+    auto request_g = [&]() __attribute__((always_inline)) {
+        for (int r = wv; r < pp.nz; r += NRB) {
+            if (lane < hs) {  // one row per wave instruction: hs lanes x 16 bytes
+                const char* src = reinterpret_cast<const char*>(pp.G + (size_t)r * pp.nzs) + lane * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(smem + (size_t)r * gs), 16, 0, 0);
+            }
         }
-    }
-    admm_body<NRB, KS>(ap, smem + (size_t)pp.nz * gs);
+    };
+    admm_body<NRB, KS>(ap, smem + (size_t)pp.nz * gs, request_g);
     __builtin_amdgcn_s_waitcnt(0);  // this wave's pieces of G have landed
     __syncthreads();                // ... and everybody's; the ADMM results of the tile are visible to the whole workgroup
     polish_body<true, true, STEP_KOFF>(pp, smem);
