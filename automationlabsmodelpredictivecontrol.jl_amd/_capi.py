@@ -71,6 +71,8 @@ def load():
     L.almpc_sqp_fnn_iterate.argtypes = [_hp, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, _dp, _dp]
     L.almpc_sqp_fnn_iterate.restype = ctypes.c_int
     L.almpc_sqp_fnn_skipped.argtypes = [_hp, _ip]
+    L.almpc_sqp_fnn_set_step_rule.argtypes = [_hp, ctypes.c_int]
+    L.almpc_sqp_fnn_set_step_rule.restype = ctypes.c_int
     L.almpc_sqp_fnn_skipped.restype = ctypes.c_int
     L.almpc_get_design_instance.restype = ctypes.c_int
     L.almpc_set_reference.argtypes = [_hp, _dp, _dp, ctypes.c_int]
@@ -297,9 +299,10 @@ class Solver:
         ug = None if u_guess is None else np.ascontiguousarray(np.asarray(u_guess, dtype=np.float64).reshape(self.batch, self.m, self.N).transpose(0, 2, 1))
         self._check(self.L.almpc_sqp_fnn_start(self.h, _ptr(x0), _ptr(ug)))
 
-    def sqp_fnn_iterate(self, iters, step_scale=1.0, opts=None):
+    def sqp_fnn_iterate(self, iters, step_scale=1.0, opts=None, step_rule="fixed"):
         """-> (step_inf[iters], defect_inf[iters]); raises AlmpcError(ALMPC_ERR_NUMERIC) when an instance had to skip an iteration
-        (the histories are still filled: see .sqp_last)."""
+        (the histories are still filled: see .sqp_last).  step_rule: "fixed" | "merit" (l1 merit-function safeguard)."""
+        self._check(self.L.almpc_sqp_fnn_set_step_rule(self.h, {"fixed": 0, "merit": 1}[step_rule]))
         st, de = np.zeros(int(iters)), np.zeros(int(iters))
         self.sqp_last = (st, de)
         self._check(self.L.almpc_sqp_fnn_iterate(self.h, int(iters), float(step_scale), ctypes.byref(opts) if opts is not None else None,

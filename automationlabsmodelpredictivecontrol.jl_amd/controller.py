@@ -245,6 +245,7 @@ def _design_blackbox_nonlinear(system, horizon, sample_time, references, weights
     is the equality constraint x[:,k+1] = fnn(x[:,k], u[:,k]) and the reference gives the NLP to Ipopt
     (src/sub/solver_selection.jl:100-104).  Here the same NLP goes through the device-resident SQP loop (almpc_sqp_fnn_*).
     Keys of this build: mpc_sqp_iterations (outer iterations per calculate!, default 10), mpc_sqp_step (step length, default 1),
+    mpc_sqp_step_rule ("merit": steps safeguarded by the l1 merit function, default; "fixed"),
     mpc_sqp_warm_start (start each calculate! from the previous inputs shifted by one stage, default True)."""
     D = _DEFAULT_PARAMETERS_MODEL_PREDICTIVE_CONTROL
     solver_name = kws.get("mpc_solver", D["mpc_solver"])
@@ -268,7 +269,8 @@ def _design_blackbox_nonlinear(system, horizon, sample_time, references, weights
                          rho_profile=kws.get("mpc_rho_profile", "scalar"))
     mod = HipModeler(solver, _capi.default_opts(**sopt), batch)
     mod.sqp = dict(iterations=int(kws.get("mpc_sqp_iterations", 10)), step=float(kws.get("mpc_sqp_step", 1.0)),
-                   warm_start=bool(kws.get("mpc_sqp_warm_start", True)), u_prev=None)
+                   warm_start=bool(kws.get("mpc_sqp_warm_start", True)), u_prev=None,
+                   step_rule=kws.get("mpc_sqp_step_rule", "merit"))
     tuning = ModelPredictiveControlTuning(mod, references, horizon, weights, TerminalIngredient(terminal, np.array(P)),
                                           float(sample_time), int(kws.get("mpc_max_time", D["mpc_max_time"])))
     shape = (lambda *s: s) if batch == 1 else (lambda *s: (batch, *s))
@@ -363,7 +365,7 @@ def calculate(C: ModelPredictiveControlController) -> None:
     raises ArithmeticError, and per-instance status/iterations are kept on the modeler."""
     mod: HipModeler = C.tuning.modeler
     if getattr(mod, "sqp", None) is not None:
-        mod.last_sqp_history = mod.solver.sqp_fnn_iterate(mod.sqp["iterations"], mod.sqp["step"], mod.opts)
+        mod.last_sqp_history = mod.solver.sqp_fnn_iterate(mod.sqp["iterations"], mod.sqp["step"], mod.opts, step_rule=mod.sqp["step_rule"])
     else:
         mod.solver.calculate(mod.opts)
     r = mod.solver.get_results()

@@ -17,7 +17,9 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -74,6 +76,10 @@ struct almpc_handle {
         double *A = nullptr, *B = nullptr, *c = nullptr, *fval = nullptr, *ebar = nullptr, *qadd = nullptr;
         double *xref = nullptr, *uref = nullptr, *Q = nullptr, *R = nullptr, *S = nullptr;
         int* bad = nullptr;
+        double* mer = nullptr;    // [batch][4] step rule 1: step factor, merit of the last accepted point, redo flag
+        double *xback = nullptr, *uback = nullptr, *dxback = nullptr, *vback = nullptr;  // last accepted point and its step
+        double mu = 0.0;          // merit weight of the defects
+        int step_rule = 0;        // 0 fixed step, 1 merit-function safeguard (almpc_sqp_fnn_set_step_rule)
         unsigned long long* stats = nullptr;  // [iters][2]
         int stats_cap = 0;
     } sqp;
@@ -133,7 +139,7 @@ void free_all(almpc_handle* h) {
                     h->dXmax, h->dRowTraj, h->dRowEq, h->dRowXidx, h->dRowState, h->bA, h->bB, h->bMinv, h->bG, h->bHs, h->bFs,
                     h->bVs, h->bD, h->bRho, h->bH, h->bF, h->bPhi, h->bGk, h->bGam, h->bW, h->bWP, h->bP, h->bFlag, h->bQ, h->dOverflow,
                     h->sqp.W_in, h->sqp.W_h, h->sqp.b_h, h->sqp.W_out, h->sqp.A, h->sqp.B, h->sqp.c, h->sqp.fval, h->sqp.ebar,
-                    h->sqp.qadd, h->sqp.xref, h->sqp.uref, h->sqp.Q, h->sqp.R, h->sqp.S, h->sqp.bad, h->sqp.stats};
+                    h->sqp.qadd, h->sqp.xref, h->sqp.uref, h->sqp.Q, h->sqp.R, h->sqp.S, h->sqp.bad, h->sqp.stats, h->sqp.mer, h->sqp.xback, h->sqp.uback, h->sqp.dxback, h->sqp.vback};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& e : h->ev)
@@ -726,11 +732,13 @@ int almpc_sqp_fnn_setup(almpc_handle* h, int H, int L, int activation, const dou
     }
     { const int rc_ = ensure_batched_alloc(h); if (rc_ != ALMPC_OK) return rc_; }
     almpc_handle::Sqp& q = h->sqp;
-    void* old[] = {q.W_in, q.W_h, q.b_h, q.W_out, q.A, q.B, q.c, q.fval, q.ebar, q.qadd, q.xref, q.uref, q.Q, q.R, q.S, q.bad, q.stats,
+    const int keep_rule = q.step_rule;
+    void* old[] = {q.W_in, q.W_h, q.b_h, q.W_out, q.A, q.B, q.c, q.fval, q.ebar, q.qadd, q.xref, q.uref, q.Q, q.R, q.S, q.bad, q.stats, q.mer, q.xback, q.uback, q.dxback, q.vback,
                    h->dXref, h->dUref, h->dFS, h->dV0S};
     for (void* p_ : old)
         if (p_) (void)hipFree(p_);
     q = almpc_handle::Sqp();
+    q.step_rule = keep_rule;
     h->dXref = h->dUref = h->dFS = h->dV0S = nullptr;
     auto up = [&](double** d, const double* src, size_t cnt) -> hipError_t {
         hipError_t e = dalloc(d, cnt ? cnt : 1);
@@ -747,6 +755,16 @@ int almpc_sqp_fnn_setup(almpc_handle* h, int H, int L, int activation, const dou
     HIP_TRY(h, up(&q.xref, xr.data(), xr.size())); HIP_TRY(h, up(&q.uref, ur.data(), ur.size()));
     HIP_TRY(h, up(&q.Q, Qm.data(), Qm.size())); HIP_TRY(h, up(&q.R, Rm.data(), Rm.size())); HIP_TRY(h, up(&q.S, Sm.data(), Sm.size()));
     HIP_TRY(h, dalloc(&q.bad, b));
+    HIP_TRY(h, dalloc(&q.mer, 4 * b));
+    HIP_TRY(h, dalloc(&q.xback, b * (size_t)n * (N + 1))); HIP_TRY(h, dalloc(&q.dxback, b * (size_t)n * (N + 1)));
+    HIP_TRY(h, dalloc(&q.uback, b * nz)); HIP_TRY(h, dalloc(&q.vback, b * nz));
+    {
+        double pm = 0.0;
+        for (double v : Pall) pm = std::max(pm, std::fabs(v));
+        for (double v : Qm) pm = std::max(pm, std::fabs(v));
+        q.mu = 2.0 * pm;  // the multipliers of the dynamics are ~ 2 |P e|: exact for errors up to order one.  Measured on the benchmark
+                          // set: 0.2 |P| rejects good steps near the solution, 10 |P| rejects every full step of some instances
+    }
     HIP_TRY(h, hipMemset(q.bad, 0, b * sizeof(int)));
     if (!h->bQ) HIP_TRY(h, dalloc(&h->bQ, b * nz));
     HIP_TRY(h, dalloc(&h->dXref, b * (size_t)n * (N + 1))); HIP_TRY(h, dalloc(&h->dUref, b * nz));
@@ -804,7 +822,12 @@ int almpc_sqp_fnn_start(almpc_handle* h, const double* x0, const double* u_guess
     hipLaunchKernelGGL(k_fnn_rollout, dim3((unsigned)b), dim3(256), l, st, rp);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemsetAsync(q.bad, 0, b * sizeof(int), st));
-    HIP_TRY(h, hipStreamSynchronize(st));
+    {
+        std::vector<double> d0(4 * b, 0.0);
+        for (size_t i = 0; i < b; ++i) { d0[4 * i] = 1.0; d0[4 * i + 1] = std::numeric_limits<double>::infinity(); }
+        HIP_TRY(h, hipMemcpyAsync(q.mer, d0.data(), d0.size() * sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_TRY(h, hipStreamSynchronize(st));
+    }
     q.started = true;
     return ALMPC_OK;
 }
@@ -838,7 +861,8 @@ int almpc_sqp_fnn_iterate(almpc_handle* h, int iters, double step_scale, const a
     sp.xref = q.xref; sp.uref = q.uref; sp.R = q.R; sp.S = q.S; sp.umin = h->dUmin; sp.umax = h->dUmax;
     sp.xbar = h->dXref; sp.ubar = h->dUref; sp.fval = q.fval; sp.A = q.A; sp.B = q.B; sp.c = q.c; sp.ebar = q.ebar; sp.qadd = q.qadd;
     sp.v = h->dEu; sp.flag = h->bFlag; sp.status = h->dStatus; sp.bad = q.bad; sp.stats = q.stats; sp.step_scale = step_scale;
-    sp.x = h->dX; sp.ex = h->dEx; sp.u = h->dU; sp.eu = h->dEu;
+    sp.x = h->dX; sp.ex = h->dEx; sp.u = h->dU; sp.eu = h->dEu; sp.adaptive = q.step_rule; sp.mu = q.mu; sp.Q = q.Q; sp.P = h->bP; sp.sP = q.sP; sp.mer = q.mer;
+    sp.xback = q.xback; sp.uback = q.uback; sp.dxback = q.dxback; sp.vback = q.vback;
     DesignLtvParams lp;
     lp.n = n; lp.m = m; lp.N = N; lp.nz = nz; lp.useR = q.useR; lp.useS = q.useS;
     lp.A = q.A; lp.B = q.B; lp.c = q.c; lp.ebar = q.ebar; lp.P = h->bP; lp.sP = q.sP; lp.Q = q.Q; lp.R = q.R; lp.S = q.S;
@@ -875,6 +899,13 @@ int almpc_sqp_fnn_iterate(almpc_handle* h, int iters, double step_scale, const a
             return fail(h, ALMPC_ERR_NUMERIC, "sqp_fnn_iterate: instance " + std::to_string(i) +
                         ": an iteration was skipped (condensed Hessian not positive definite to working precision, or a non-finite QP "
                         "solution); its iterate is the last good one, the other instances are unaffected");
+    return ALMPC_OK;
+}
+
+int almpc_sqp_fnn_set_step_rule(almpc_handle* h, int rule) {
+    if (!h) return ALMPC_ERR_INVALID;
+    if (rule != 0 && rule != 1) return fail(h, ALMPC_ERR_INVALID, "sqp_fnn_set_step_rule: 0 (fixed step) or 1 (merit-function safeguard)");
+    h->sqp.step_rule = rule;
     return ALMPC_OK;
 }
 

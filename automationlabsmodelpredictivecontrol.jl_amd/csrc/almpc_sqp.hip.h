@@ -33,15 +33,83 @@ struct SqpParams {
     int* bad;             // [batch] sticky: some iteration of this instance was skipped
     unsigned long long* stats;  // [2]: bit patterns of max |v| and max |c| over the batch (non-negative doubles order like integers)
     double step_scale;
+    // step rule 1 (merit-function safeguard): see k_sqp_prepare
+    int adaptive;
+    double mu;            // weight of the defects in the merit function J + mu |defects|_1
+    const double* Q; const double* P; long sP;   // cost weights for J (P shared or per instance)
+    double* mer;          // [batch][4]: step factor a, merit of the last accepted point, redo flag (1: this iteration is void), spare
+    double* xback; double* uback;   // [batch][(N+1) n], [batch][nz]: last accepted point
+    double* dxback; double* vback;  // its step (dx of every stage, v), so that a rejected trial can be re-taken shorter
     double *x, *ex, *u, *eu;    // result buffers: the iterate after the update
 };
 
 // Before the QP: defects, state errors and the input part of the gradient, one workgroup per instance.
+// Step rule 1.  Full Gauss-Newton steps are not globally convergent (3 of the 256 benchmark instances end in a cycle), and
+// heuristics on |v| alone misfire in the first iterations, where growing steps are normal.  The safeguard is the classical l1
+// merit function phi = J(x, u) + mu |f(x, u) - x+|_1, evaluated a posteriori: the network outputs at the point reached by the last
+// step are computed by THIS iteration's linearisation anyway, so the test costs one reduction.  If phi did not decrease, the
+// point is rejected: the iterate goes back to the last accepted point plus HALF the step (both kept), this iteration's QP -- built
+// at the rejected point -- is void for the instance (redo flag: k_sqp_step leaves it alone), and the next iteration tests the
+// shorter step.  Accepted steps double the factor back up to 1; at 1/64 a step is accepted regardless.
 __global__ __launch_bounds__(256) void k_sqp_prepare(SqpParams p) {
     const int n = p.n, m = p.m, N = p.N, nz = p.nz;
     const size_t i = blockIdx.x;
-    const double* xb = p.xbar + i * (size_t)(N + 1) * n;
-    const double* ub = p.ubar + i * (size_t)nz;
+    double* xbw = p.xbar + i * (size_t)(N + 1) * n;
+    double* ubw = p.ubar + i * (size_t)nz;
+    if (p.adaptive) {
+        __shared__ double red[8];
+        __shared__ int reject;
+        double part = 0.0;
+        const double* Pm = p.P + i * p.sP;
+        for (int t = threadIdx.x; t < (N + 1) * n; t += blockDim.x) {   // e_x' W e_x, W = Q for stages 1..N, P for N+1
+            const int k = t / n, r = t % n;
+            const double* W = (k == N) ? Pm : p.Q;
+            double sdot = 0.0;
+            for (int j = 0; j < n; ++j) sdot += W[(size_t)j * n + r] * (xbw[k * n + j] - p.xref[k * n + j]);
+            part += (xbw[t] - p.xref[t]) * sdot;
+        }
+        for (int t = threadIdx.x; t < nz; t += blockDim.x) {
+            const int k = t / m, a = t % m;
+            if (p.useR) {
+                double sdot = 0.0;
+                for (int c2 = 0; c2 < m; ++c2) sdot += p.R[(size_t)c2 * m + a] * (ubw[k * m + c2] - p.uref[k * m + c2]);
+                part += (ubw[t] - p.uref[t]) * sdot;
+            }
+            if (p.useS && k + 1 < N) {
+                double sdot = 0.0;
+                for (int c2 = 0; c2 < m; ++c2) sdot += p.S[(size_t)c2 * m + a] * (ubw[k * m + c2] - ubw[(k + 1) * m + c2]);
+                part += (ubw[t] - ubw[t + m]) * sdot;
+            }
+        }
+        for (int t = threadIdx.x; t < N * n; t += blockDim.x) part += p.mu * fabs(p.fval[i * (size_t)N * n + t] - xbw[n + t]);
+        part = wave_sum(part);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double phi = (red[0] + red[1]) + (red[2] + red[3]);
+            double a = p.mer[4 * i], ref = p.mer[4 * i + 1];
+            // (a non-finite phi is rejected like an increase; the first iteration after `start` has ref = +inf)
+            const bool ok = (phi <= ref + 1e-12 * fabs(ref) + 1e-300) || a <= 1.0 / 64.0;
+            if (ok) { ref = phi; a = fmin(1.0, 2.0 * a); }
+            else a *= 0.5;
+            p.mer[4 * i] = a; p.mer[4 * i + 1] = ref; p.mer[4 * i + 2] = ok ? 0.0 : 1.0;
+            red[4] = a;
+            reject = ok ? 0 : 1;
+        }
+        __syncthreads();
+        if (reject) {  // back to the last accepted point plus the shorter step
+            const double a = red[4];
+            for (int t = threadIdx.x; t < (N + 1) * n; t += blockDim.x)
+                xbw[t] = p.xback[i * (size_t)(N + 1) * n + t] + a * p.dxback[i * (size_t)(N + 1) * n + t];
+            for (int t = threadIdx.x; t < nz; t += blockDim.x) {
+                const int am = t % m;
+                ubw[t] = fmin(fmax(p.uback[i * (size_t)nz + t] + a * p.vback[i * (size_t)nz + t], p.umin[am]), p.umax[am]);
+            }
+            __syncthreads();
+        }
+    }
+    const double* xb = xbw;
+    const double* ub = ubw;
     for (int t = threadIdx.x; t < N * n; t += blockDim.x) {
         const double xn = xb[n + t];  // stage k+1, component j  (t = k*n + j)
         p.c[i * (size_t)N * n + t] = p.fval[i * (size_t)N * n + t] - xn;
@@ -122,15 +190,20 @@ __global__ __launch_bounds__(256) void k_sqp_step(SqpParams p) {
     }
     __syncthreads();
     if (tid == 0) {
-        const int bad = (red[8] + red[9] + red[10] + red[11] != 0.0) || p.flag[i] != 0 || p.status[i] == 2;
-        skip = bad;
+        const int redo_ = p.adaptive && p.mer[4 * i + 2] != 0.0;   // trial point rejected in k_sqp_prepare: this QP is void
+        const int bad = !redo_ && ((red[8] + red[9] + red[10] + red[11] != 0.0) || p.flag[i] != 0 || p.status[i] == 2);
+        skip = bad || redo_;
         if (bad) p.bad[i] = 1;
-        else {
+        else if (!redo_) {
             atomicMax(p.stats + 0, (unsigned long long)__double_as_longlong(fmax(fmax(red[0], red[1]), fmax(red[2], red[3]))));
             atomicMax(p.stats + 1, (unsigned long long)__double_as_longlong(fmax(fmax(red[4], red[5]), fmax(red[6], red[7]))));
         }
     }
     __syncthreads();
+    // Step length: `step_scale`, times the instance's own factor under step rule 1 (k_sqp_prepare).  An instance whose last
+    // trial point was just rejected there sits on a new, shorter trial: its QP of this iteration is void.
+    double scale = p.step_scale;
+    if (p.adaptive) scale *= p.mer[4 * i];  // the factor in force for the step taken now (k_sqp_prepare has just updated it)
     if (!skip) {
         double dxr = 0.0;                       // wave 0, lane j < n: dx_j of the current stage
         const int lj = tid < n ? tid : 0;
@@ -157,9 +230,19 @@ __global__ __launch_bounds__(256) void k_sqp_step(SqpParams p) {
         __syncthreads();
     }
     // trajectory update and results: the iterate itself (for a skipped instance: its last good iterate)
+    if (p.adaptive && !skip) {  // remember the point this step leaves and the (full) step itself
+        for (int t = tid; t < (N + 1) * n; t += 256) {
+            p.xback[i * (size_t)(N + 1) * n + t] = xb[t];
+            p.dxback[i * (size_t)(N + 1) * n + t] = p.step_scale * dxa[t];
+        }
+        for (int t = tid; t < nz; t += 256) {
+            p.uback[i * (size_t)nz + t] = ub[t];
+            p.vback[i * (size_t)nz + t] = p.step_scale * vs[t];
+        }
+    }
     for (int t = tid; t < (N + 1) * n; t += 256) {
         double xv = xb[t];
-        if (!skip && t >= n) { xv += p.step_scale * dxa[t]; xb[t] = xv; }
+        if (!skip && t >= n) { xv += scale * dxa[t]; xb[t] = xv; }
         p.x[i * (size_t)(N + 1) * n + t] = xv;
         p.ex[i * (size_t)(N + 1) * n + t] = xv - p.xref[t];
     }
@@ -167,7 +250,7 @@ __global__ __launch_bounds__(256) void k_sqp_step(SqpParams p) {
         double uv = ub[t];
         if (!skip) {
             const int a = t % m;
-            uv = fmin(fmax(uv + p.step_scale * vs[t], p.umin[a]), p.umax[a]);  // v is feasible: the clip only removes rounding
+            uv = fmin(fmax(uv + scale * vs[t], p.umin[a]), p.umax[a]);  // v is feasible: the clip only removes rounding
             ub[t] = uv;
         }
         p.u[i * (size_t)nz + t] = uv;

@@ -202,6 +202,13 @@ int almpc_sqp_fnn_start(almpc_handle* h, const double* x0, const double* u_guess
 int almpc_sqp_fnn_iterate(almpc_handle* h, int iters, double step_scale, const almpc_opts* opts, double* step_inf,
                           double* defect_inf);
 int almpc_sqp_fnn_skipped(almpc_handle* h, int32_t* skipped /* [batch], 1 = some iteration was skipped */);
+/* Step rule of almpc_sqp_fnn_iterate.  0 (default): every instance takes steps of length `step_scale` (full Gauss-Newton steps
+ * are not globally convergent: they can end in a cycle when the tracking residual is large).  1: safeguarded by the l1 merit
+ * function phi = J + mu |f(x,u) - x+|_1 (mu = 2 max(|P|, |Q|)), tested a posteriori with the network outputs the next
+ * linearisation computes anyway: a step after which phi did not decrease is taken back and re-taken at half the length (that
+ * iteration's QP is void for the instance), accepted steps double the factor back up to 1, and at 1/64 a step is accepted
+ * regardless.  step_inf / defect_inf then cover the instances whose QP counted.  The factor restarts at 1 in `start`. */
+int almpc_sqp_fnn_set_step_rule(almpc_handle* h, int rule);
 
 /* H (nz*nz), F (nz*n), d (nz) of one instance after almpc_design_batched (any pointer may be NULL). */
 int almpc_get_design_instance(almpc_handle* h, int instance, double* H, double* F, double* d);

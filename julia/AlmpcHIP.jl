@@ -115,7 +115,8 @@ end
 sqp_start!(mod::HipModeler, x0::VecOrMat{Float64}) =
     check(mod.handle, ccall((:almpc_sqp_fnn_start, libalmpc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), mod.handle, x0, C_NULL))
 
-function sqp_iterate!(mod::HipModeler, iters::Integer; step::Float64 = 1.0)
+function sqp_iterate!(mod::HipModeler, iters::Integer; step::Float64 = 1.0, merit_safeguard::Bool = true)
+    check(mod.handle, ccall((:almpc_sqp_fnn_set_step_rule, libalmpc), Cint, (Ptr{Cvoid}, Cint), mod.handle, merit_safeguard ? 1 : 0))
     st, de = zeros(iters), zeros(iters)
     o = Ref(mod.opts)
     check(mod.handle, ccall((:almpc_sqp_fnn_iterate, libalmpc), Cint, (Ptr{Cvoid}, Cint, Cdouble, Ref{AlmpcOpts}, Ptr{Float64}, Ptr{Float64}),

@@ -1058,9 +1058,14 @@ def nlp_kkt_residual(model: FnnModel, x0, U, x_ref, u_ref, Q, R, S, P, u_min, u_
     return float(np.abs(U - T).max())
 
 
-def sqp_fnn(model: FnnModel, x0, x_ref, u_ref, Q, R, S, P, u_min, u_max, iters, u_guess=None, step_scale=1.0):
+def sqp_fnn(model: FnnModel, x0, x_ref, u_ref, Q, R, S, P, u_min, u_max, iters, u_guess=None, step_scale=1.0, adaptive=False,
+            merit_mu=None):
     """CPU restatement of the device loop almpc_sqp_fnn_*: Gauss-Newton SQP with multiple shooting, every QP solved exactly
-    (solve_box_qp_exact).  Returns X (n, N+1), U (m, N) and the per-iteration (|v|_inf, |defect|_inf) history."""
+    (solve_box_qp_exact).  Returns X (n, N+1), U (m, N) and the per-iteration (|v|_inf, |defect|_inf) history (None for an
+    iteration whose QP was void).
+    adaptive: step rule 1 of almpc_sqp_fnn_set_step_rule -- l1 merit function phi = J + mu |defects|_1, mu = 2 max(|P|, |Q|),
+    tested a posteriori at the top of the next iteration: if phi did not decrease the iterate returns to the last accepted point
+    plus half the step and the iteration's QP is void; accepted steps double the factor back up to 1; at 1/64 accept anyway."""
     m, N = u_ref.shape
     U = np.clip(u_ref if u_guess is None else u_guess, u_min[:, None], u_max[:, None]).astype(np.float64)
     X = fnn_rollout(model, x0, U)
@@ -1068,20 +1073,45 @@ def sqp_fnn(model: FnnModel, x0, x_ref, u_ref, Q, R, S, P, u_min, u_max, iters, 
     useR = R[0, 0] != 0.0
     Rz = R if useR else 0.0 * R
     Sz = S if (useR and S[0, 0] != 0.0) else 0.0 * S
+    mu = 2.0 * max(np.abs(P).max(), np.abs(Q).max()) if merit_mu is None else float(merit_mu)
+    a, ref = 1.0, np.inf
+    Xb = Ub = dXb = Vb = None
+
+    def merit(X, U, fv):
+        EX, EU = X - x_ref, U - u_ref
+        J = float(EX[:, N] @ P @ EX[:, N]) + sum(float(EX[:, k] @ Q @ EX[:, k] + EU[:, k] @ Rz @ EU[:, k]) for k in range(N))
+        J += sum(float((U[:, k] - U[:, k + 1]) @ Sz @ (U[:, k] - U[:, k + 1])) for k in range(N - 1))
+        return J + mu * float(np.abs(fv - X[:, 1:]).sum())
+
     for _ in range(iters):
+        fv = np.stack([model.forward(X[:, k], U[:, k]) for k in range(N)], axis=1)
+        if adaptive:
+            phi = merit(X, U, fv)
+            ok = (phi <= ref + 1e-12 * abs(ref) + 1e-300) or a <= 1.0 / 64.0
+            if ok:
+                ref, a = phi, min(1.0, 2.0 * a)
+            else:
+                a *= 0.5
+                X = Xb + a * dXb
+                U = np.clip(Ub + a * Vb, u_min[:, None], u_max[:, None])
+                hist.append(None)
+                continue
         A, B, c = [], [], []
         for k in range(N):
-            a, b = model.jacobian(X[:, k], U[:, k])
-            A.append(a); B.append(b); c.append(model.forward(X[:, k], U[:, k]) - X[:, k + 1])
+            Ak, Bk = model.jacobian(X[:, k], U[:, k])
+            A.append(Ak); B.append(Bk); c.append(fv[:, k] - X[:, k + 1])
         H, q, lo, hi = ltv_qp(A, B, c, X, U, x_ref, u_ref, Q, Rz, Sz, P, u_min, u_max)
         v = solve_box_qp_exact(H, q, lo, hi).reshape(N, m).T
         hist.append((float(np.abs(v).max()), float(np.abs(np.array(c)).max())))
+        dX = np.zeros_like(X)
         dx = np.zeros(x0.size)
-        Xn = X.copy()
         for k in range(N):
             dx = A[k] @ dx + B[k] @ v[:, k] + c[k]
-            Xn[:, k + 1] = X[:, k + 1] + step_scale * dx
-        X, U = Xn, np.clip(U + step_scale * v, u_min[:, None], u_max[:, None])
+            dX[:, k + 1] = dx
+        if adaptive:
+            Xb, Ub, dXb, Vb = X.copy(), U.copy(), step_scale * dX, step_scale * v
+        sc = step_scale * (a if adaptive else 1.0)
+        X, U = X + sc * dX, np.clip(U + sc * v, u_min[:, None], u_max[:, None])
     return X, U, hist
 
 

@@ -190,3 +190,37 @@ def test_golden_sqp_vectors_through_the_c_abi(capi, mo):
     for i, c in enumerate(g["cases"]):
         assert np.abs(r["u"][i] - np.array(c["u"])).max() <= U_TOL
         assert np.abs(r["x"][i] - np.array(c["x"])).max() <= 1e-5
+
+
+def test_merit_safeguard_breaks_the_cycle(capi, mo):
+    """Instances 42, 50 and 115 of the benchmark set (N = 50) never settle with full steps -- 115 sits in a two-cycle with
+    |v|_inf = 0.0666 -- and converge under step rule 1 (l1 merit function, almpc_sqp_fnn_set_step_rule); instances 0, 35 and 69
+    converge either way (35 and 69 slowly: the rule must not hold them back).  Device loop against the restatement with the same
+    rule, then the NLP certificate."""
+    N, iters = 50, 60
+    f = mo.synthetic_fnn(act="tanh")
+    n, m = 4, 2
+    x_ref = np.tile(np.array([0.2, -0.1, 0.05, 0.0])[:, None], (1, N + 1)); u_ref = np.tile(np.array([0.1, -0.2])[:, None], (1, N))
+    X0all = x_ref[:, 0][None, :] + 0.6 * mo.splitmix_normal(0x5EED0005, 0, 256, n)
+    pick = [0, 35, 42, 50, 69, 115]
+    X0 = X0all[pick]
+    Al, Bl = f.jacobian(x_ref[:, -1], u_ref[:, -1])
+    Q, R, S = 100.0 * np.eye(n), 0.1 * np.eye(m), np.zeros((m, m))
+    P = mo.dare(Al, Bl, Q, R)
+    umin, umax = -np.ones(m), np.ones(m)
+    s = capi.Solver(n, m, N, len(pick))
+    s.sqp_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, x_ref, u_ref, Q, R, S, P, umin, umax, act="tanh")
+    s.sqp_fnn_start(X0)
+    st_full, _ = s.sqp_fnn_iterate(iters)
+    assert st_full[-1] > 1e-2                     # the cycle
+    s.sqp_fnn_start(X0)
+    st, de = s.sqp_fnn_iterate(iters, step_rule="merit")
+    r = s.get_results(want=("u", "x", "status"))
+    s.close()
+    # no cycle left: the batch maximum keeps falling (instance 42 converges at a linear rate of 0.9: 8e-4 after 60 iterations)
+    assert st[-1] <= 2e-3 and de[-1] <= 1e-7 and np.all(st[-10:] < st[-11:-1]), (st[-12:], de[-5:])
+    for j, i in enumerate(pick):
+        X, U, hist = mo.sqp_fnn(f, X0all[i], x_ref, u_ref, Q, R, S, P, umin, umax, iters, adaptive=True)
+        assert np.abs(r["u"][j] - U).max() <= U_TOL and np.abs(r["x"][j] - X).max() <= 1e-5, i
+        if i in (0, 35, 69, 115):
+            assert mo.nlp_kkt_residual(f, X0all[i], r["u"][j], x_ref, u_ref, Q, R, S, P, umin, umax) <= 1e-3, i
