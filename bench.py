@@ -256,9 +256,11 @@ def main():
         for s_ in AMPLITUDES:
             solver.update_initialization(make_x0(mo, first, BATCH_PER_GPU, amplitude=s_))
             k = max(20, args.steps // 5)
-            solver.timing_reset(k + args.warmup)  # no event creation inside the timed loop
+            solver.timing_reset(3 * k + args.warmup)  # no event creation inside the timed loop
             time_steps(solver, opts, max(5, args.warmup // 5), barrier)
-            el = max_over_ranks(time_steps(solver, opts, k, barrier))
+            # best of three bursts: a burst is a few milliseconds long, and an occasional ~15-30 ms hiccup of the host-side wait
+            # (seen on this pool) would otherwise swallow the figure
+            el = min(max_over_ranks(time_steps(solver, opts, k, barrier)) for _ in range(3))
             cls[str(s_)] = world * k / el
         out["classes"] = {"unit": "batch-steps/s", **cls}
 
