@@ -28,7 +28,7 @@ def run(name, As, Bs, N, umin, umax, X0, P, K=8, reps=20):
     byt = b * 8 * (2 * nz * (16 * ((nz + 15) // 16)))  # Minv_i + (rows of) G_i upper bound
     print(f"{name}: batch {b} n {n} m {m} N {N}: design first {1e3*t_first:.2f} ms, re-design {1e3*t_design:.2f} ms, step {1e6*t_step:.1f} us "
           f"(admm {1e3*ts['admm_ms']/ts['steps']:.1f} us, polish {1e3*ts['polish_ms']/ts['steps']:.1f} us) -> {b/t_step/1e6:.2f} M instance-steps/s, "
-          f"Minv+G bytes/step {byt/1e6:.0f} MB = {byt/t_step/1e9:.0f} GB/s; status {np.bincount(r['status']).tolist()} polish its mean {r['polish_iters'].mean():.2f}")
+          f"Minv+G bytes/step {byt/1e6:.0f} MB = {byt/t_step/1e9:.0f} GB/s; status {np.bincount(r['status']).tolist()} polish its mean {r['polish_iters'].mean():.2f} max {r['polish_iters'].max()} top5 {np.sort(r['polish_iters'])[-5:].tolist()}")
     s.close()
 
 
