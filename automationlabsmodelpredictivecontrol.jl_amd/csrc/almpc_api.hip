@@ -1148,7 +1148,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         pp.umin = h->dUmin; pp.umax = h->dUmax; pp.uref = h->dUref; pp.uref_stride = h->uref_stride;
         pp.zs = h->dZs; pp.ys = h->dYs; pp.v0 = h->dV0; pp.w = h->dW; pp.status = h->dStatus; pp.piters = h->dPiters;
         pp.sglobal = h->dSglobal; pp.perm = h->dPerm; pp.ntiles = (h->batch + 15) / 16;
-        pp.max_iter = o.polish_max_iter > 0 ? o.polish_max_iter : 4 * h->nz + 50;
+        pp.max_iter = o.polish_max_iter > 0 ? o.polish_max_iter : 2 * h->nz + 50;
         // rollout fused into the tail of the polish when its trajectory buffer fits the wave's LDS slot
         fused = roll_fits;
         pp.fuse_rollout = fused ? (h->ltv ? 2 : 1) : 0; pp.roll_g = roll_g; pp.roll_cpl = roll_cpl; pp.roll = rp;

@@ -77,7 +77,7 @@ typedef struct almpc_opts {
     int32_t max_iter;
     int32_t check_every;
     int32_t polish;           /* 0 off, 1 on                                                   */
-    int32_t polish_max_iter;  /* cap on active-set changes per instance; <=0 -> 4*nz+50        */
+    int32_t polish_max_iter;  /* cap on active-set changes per instance; <=0 -> 2*nz+50        */
     int32_t warm_start;       /* 1: start ADMM from the previous step's (x, z, y) of each instance */
     int32_t reserved[3];
 } almpc_opts;

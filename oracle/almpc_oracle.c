@@ -268,7 +268,7 @@ int almpc_oracle_step_batch(int n, int m, int N, int batch, const double* A, con
 #else
     (void)threads;
 #endif
-    if (polish_max_iter <= 0) polish_max_iter = 4 * nz + 50;
+    if (polish_max_iter <= 0) polish_max_iter = 2 * nz + 50;
 #pragma omp parallel num_threads(used)
     {
         double* work = (double*)malloc(sizeof(double) * ((size_t)nz * nz + 20 * (size_t)nz + n));

@@ -778,7 +778,7 @@ def polish_active_set(G, v0, lo, hi, z, y, max_iter=None, refine=True):
     Returns dict(w, iters, n_add, n_remove, n_active).
     """
     nz = v0.size
-    max_iter = 4 * nz + 50 if max_iter is None else max_iter
+    max_iter = 2 * nz + 50 if max_iter is None else max_iter
     W, side = [], {}
     Sinv = np.zeros((0, 0))
 
