@@ -36,6 +36,9 @@ def pkg():
 
 @pytest.fixture(scope="session")
 def capi(pkg):
+    if not os.path.exists(pkg._capi.LIB_PATH):  # fresh checkout (the .so is not in git): build it once, as the driver's build() does
+        import __graft_entry__
+        __graft_entry__.build()
     pkg._capi.load()
     return pkg._capi
 
