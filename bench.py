@@ -62,12 +62,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--max-iter", type=int, default=8,
-                    help="ADMM iterations before the polish (= check interval); 8 is the tuned value for this workload, "
-                         "the library default is 25")
+    ap.add_argument("--max-iter", type=int, default=6,
+                    help="ADMM iterations before the polish (= check interval); 6 is the tuned value for this workload "
+                         "(sweep in DESIGN.md section 4), the library default is 25")
     ap.add_argument("--rho-profile", default="stiffness", choices=("scalar", "stiffness"),
                     help="ADMM penalty: OSQP's scalar rho, or rho_i = rho / (H'^-1)_ii (almpc_set_rho_profile)")
-    ap.add_argument("--rho", type=float, default=None, help="rho (default 30 for the stiffness profile, 0.1 for scalar)")
+    ap.add_argument("--rho", type=float, default=None, help="rho (default 45 for the stiffness profile, 0.1 for scalar)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-classes", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true")
@@ -92,7 +92,7 @@ def main():
     ndev = int(os.environ.get("ALMPC_NUM_DEVICES", "0"))  # test hook: fold ranks onto fewer devices (with ALMPC_DIST_BACKEND=gloo)
     dev_index = (local_rank % ndev) if ndev > 0 else local_rank
     solver = capi.Solver(NX, NU, N_HORIZON, BATCH_PER_GPU, device=dev_index, timing=True)
-    rho = args.rho if args.rho is not None else (30.0 if args.rho_profile == "stiffness" else 0.1)
+    rho = args.rho if args.rho is not None else (45.0 if args.rho_profile == "stiffness" else 0.1)
     design_kw = dict(rho=rho, rho_profile=args.rho_profile)
     solver.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max, **design_kw)
     solver.set_reference(p.x_ref, p.u_ref)

@@ -68,7 +68,7 @@ def main():
                 f.write(f"\"{k}\",{c},{len(v)},{sum(v) / len(v)},{min(v)},{max(v)}\n")
     traffic["command"] = ("rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py "
                           "--steps 20 --warmup 5 --no-cpu-baseline --no-classes --no-pipelined --no-closed-loop")
-    traffic["workload"] = "bench.py defaults: 4096 quadrotor instances, mixed amplitudes, stiffness rho profile (30), ADMM max_iter 8, polish on"
+    traffic["workload"] = "bench.py defaults: 4096 quadrotor instances, mixed amplitudes, stiffness rho profile (45), ADMM max_iter 6, polish on"
     with open(os.path.join(out, f"{tag}_hbm_traffic.json"), "w") as f:
         json.dump(traffic, f, indent=1)
     print(json.dumps(traffic, indent=1))
