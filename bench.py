@@ -363,6 +363,12 @@ def main():
                                "sample": f"{reps} passes over the same 4096 instances of this run ({cpu_el:.1f} s wall), oracle/almpc_oracle.c "
                                          f"(gcc -O3 -march=native, OpenMP): same ADMM+polish+rollout as the HIP path",
                                "instance_steps_per_s": reps * BATCH_PER_GPU / cpu_el}
+        # secondary: single-thread latency of the exact active-set oracle (numpy), the truth the parity
+        # tests use, on 12 instances of the same batch
+        t0 = time.perf_counter()
+        for i_ in range(0, 12 * 300, 300):
+            mo.solve_mpc_exact(p, X0[i_])
+        out["cpu_baseline"]["exact_oracle_ms_per_solve_1_thread"] = 1e3 * (time.perf_counter() - t0) / 12
     solver.close()
     if solver2 is not None:
         solver2.close()  # (freed only now: a large hipFree in the middle slows the launches that follow it)
