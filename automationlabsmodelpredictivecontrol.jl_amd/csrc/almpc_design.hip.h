@@ -181,6 +181,7 @@ __global__ __launch_bounds__(256) void k_design_scale(int nz, int nzs, int n, co
                                                       double* d, double* Hs, double* Fs, int* flag, DesignStrides st) {
     H += blockIdx.y * st.H; F += blockIdx.y * st.F; d += blockIdx.y * st.d; Hs += blockIdx.y * st.Hs; Fs += blockIdx.y * st.Fs;
     flag += blockIdx.y * st.flag;
+    __shared__ double ds[128];  // nz <= 128 (almpc_create); the scaling is read nz^2 times
     for (int t = threadIdx.x; t < nzs; t += blockDim.x) {
         double v = 1.0;
         if (t < nz) {
@@ -189,16 +190,27 @@ __global__ __launch_bounds__(256) void k_design_scale(int nz, int nzs, int n, co
             else v = 1.0 / sqrt(h);
         }
         d[t] = v;
+        if (t < 128) ds[t] = v;
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < nz * nz; t += blockDim.x) {
-        const int r = t % nz, c = t / nz;
-        const double h = 0.5 * (H[(size_t)c * nz + r] + H[(size_t)r * nz + c]);
-        Hs[(size_t)c * nzs + r] = d[r] * h * d[c];
+    // four elements per thread and pass: eight loads in flight instead of two behind an integer division
+    for (int t0 = 4 * threadIdx.x; t0 < nz * nz; t0 += 4 * blockDim.x) {
+        double ha[4], hb[4];
+        int rr[4], cc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + u < nz * nz ? t0 + u : nz * nz - 1;
+            cc[u] = t / nz; rr[u] = t - cc[u] * nz;
+            ha[u] = H[(size_t)cc[u] * nz + rr[u]];
+            hb[u] = H[(size_t)rr[u] * nz + cc[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (t0 + u < nz * nz) Hs[(size_t)cc[u] * nzs + rr[u]] = ds[rr[u]] * (0.5 * (ha[u] + hb[u])) * ds[cc[u]];
     }
     for (int t = threadIdx.x; t < nz * n; t += blockDim.x) {
         const int r = t % nz, c = t / nz;
-        Fs[(size_t)c * nzs + r] = d[r] * F[(size_t)c * nz + r];
+        Fs[(size_t)c * nzs + r] = ds[r] * F[(size_t)c * nz + r];
     }
 }
 
