@@ -48,6 +48,7 @@ struct almpc_handle {
     int num_cus = 256;            // persistent-grid size of k_polish<true>
     size_t polish_glds_bytes = 0; // dynamic-LDS attribute last set on k_polish<true>
     int polish_no_glds = 0;       // diagnostic: force the G-through-L2 build (ALMPC_POLISH_NO_GLDS=1)
+    int skip_admm = 0;            // transient (SQP iterations after the first): guess from the iterate, no ADMM phase, no KKT inverse
     int fuse_step = 1;            // one kernel per step when the shape allows (almpc_set_step_fusion / ALMPC_NO_FUSED_STEP=1)
     size_t step_lds_bytes = 0;
     double* dSglobal = nullptr;  // polish scratch for working sets beyond 32 rows
@@ -80,6 +81,8 @@ struct almpc_handle {
         double *xback = nullptr, *uback = nullptr, *dxback = nullptr, *vback = nullptr;  // last accepted point and its step
         double mu = 0.0;          // merit weight of the defects
         int step_rule = 0;        // 0 fixed step, 1 merit-function safeguard (almpc_sqp_fnn_set_step_rule)
+        long since_start = 0;     // iterations since almpc_sqp_fnn_start: the first one gets its guess from ADMM, the others from the iterate
+        int guess_from_iterate = 1;  // diagnostic: ALMPC_SQP_ADMM_ALWAYS=1 keeps the ADMM phase in every iteration
         unsigned long long* stats = nullptr;  // [iters][2]
         int stats_cap = 0;
     } sqp;
@@ -397,6 +400,7 @@ void launch_batched_factor(almpc_handle* h, const DesignStrides& ds, double rho,
     const size_t inv_lds = 520 * sizeof(double);
     hipLaunchKernelGGL(k_design_inverse, dim3(1, gb), dim3(DESIGN_INVERSE_THREADS), inv_lds, st, nz, nzs, h->bHs, 0.0, (const double*)nullptr, h->bG, h->bFlag,
                        ds.Hs, 0L, ds.G, 1L);
+    if (h->skip_admm) return;  // no ADMM phase in this solve: its KKT inverse is not needed
     hipLaunchKernelGGL(k_design_rho, dim3(1, gb), dim3(256), 0, st, nz, nzs, h->rho_mode, rho, h->bG, h->bRho, ds.G, ds.rho);
     hipLaunchKernelGGL(k_design_inverse, dim3(1, gb), dim3(DESIGN_INVERSE_THREADS), inv_lds, st, nz, nzs, h->bHs, sigma, (const double*)h->bRho, h->bMinv,
                        h->bFlag, ds.Hs, ds.rho, ds.Minv, 1L);
@@ -829,6 +833,8 @@ int almpc_sqp_fnn_start(almpc_handle* h, const double* x0, const double* u_guess
         HIP_TRY(h, hipStreamSynchronize(st));
     }
     q.started = true;
+    q.since_start = 0;
+    { const char* e = getenv("ALMPC_SQP_ADMM_ALWAYS"); q.guess_from_iterate = (e && e[0] == '1') ? 0 : 1; }
     return ALMPC_OK;
 }
 
@@ -872,13 +878,16 @@ int almpc_sqp_fnn_iterate(almpc_handle* h, int iters, double step_scale, const a
         hipLaunchKernelGGL(k_sqp_prepare, dim3((unsigned)b), dim3(256), 0, st, sp);
         HIP_TRY(h, hipMemsetAsync(h->bFlag, 0, b * sizeof(int), st));
         HIP_TRY(h, launch_design_ltv(h, lp, st));
+        h->skip_admm = (q.guess_from_iterate && q.since_start > 0) ? 1 : 0;
         launch_batched_factor(h, ds, h->rho, h->sigma, st);
         hipLaunchKernelGGL(k_fs_scale, dim3(256), dim3(256), 0, st, h->batch, nz, nzs, h->bQ, (long)nz, h->bD, h->dFS);
         hipLaunchKernelGGL(k_neg_gm, dim3(1, (unsigned)b), dim3(256), 0, st, nz, nzs, 1, nz, h->bG, h->dFS, h->dV0S, (long)nz * nzs, (long)nz);
         HIP_TRY(h, hipGetLastError());
         h->designed = true;
         const int rc = almpc_calculate_async(h, opts);
+        h->skip_admm = 0;
         if (rc != ALMPC_OK) return rc;
+        q.since_start += 1;
         sp.stats = q.stats + 2 * it;
         hipLaunchKernelGGL(k_sqp_step, dim3((unsigned)b), dim3(256), step_lds, st, sp);
         HIP_TRY(h, hipGetLastError());
@@ -1052,6 +1061,11 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         ip.piters = h->dPiters; ip.perm = h->dPerm;
         ip.sigma = o.sigma; ip.alpha = o.alpha; ip.eps_abs = o.eps_abs; ip.eps_rel = o.eps_rel;
         ip.max_iter = o.max_iter; ip.check_every = o.check_every; ip.warm = o.warm_start ? 1 : 0;
+        if (h->skip_admm) {
+            if (!o.polish) return fail(h, ALMPC_ERR_INVALID, "calculate: the SQP loop needs opts.polish = 1");
+            hipLaunchKernelGGL(k_guess_iterate, dim3((h->batch + 3) / 4), dim3(256), 0, st, ip);
+            HIP_TRY(h, hipGetLastError());
+        } else {
         const size_t l = (12 * (size_t)h->nzs + 64 + 2 * (size_t)h->m) * sizeof(double);
         if (l > 64 * 1024)
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_admm_inst), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l));
@@ -1061,6 +1075,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         if (wgs > h->batch) wgs = h->batch;
         hipLaunchKernelGGL(k_admm_inst, dim3(wgs), dim3(ADMM_INST_THREADS), l, st, ip);
         HIP_TRY(h, hipGetLastError());
+        }
     }
     AdmmParams ap;
     bool admm_pending = false;  // shared-model ADMM not launched yet: it may go out fused with the polish (k_step_fused)

@@ -307,6 +307,43 @@ __global__ __launch_bounds__(ADMM_INST_THREADS) __attribute__((amdgpu_waves_per_
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_guess_iterate: hand-off to the active-set finish for an SQP iteration after the first one, instead of an ADMM phase.
+// The QP variable is v = u - ubar around the current iterate, so v = 0 is feasible, and the rows that are active at the
+// solution of this QP are, up to a few changes, the inputs that already sit ON a bound: the previous QP put them there and the
+// update clamps exactly.  Guess: z = 0, working set = rows with ubar on a bound, multiplier sign = the side (the rule the finish
+// reads: y > 0 on the upper bound, y < 0 on the lower).  The finish is an exact primal active-set method whatever its start, so
+// the result is the same as with the ADMM guess; what goes away is the ADMM phase AND the KKT inverse it needs -- one of the two
+// n_z x n_z inverses of every iteration.  One wave per instance, same output arrays as k_admm_inst.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_guess_iterate(AdmmInstParams p) {
+    const int nz = p.nz, nzs = p.nzs, n = p.n, lane = threadIdx.x & 63;
+    const int inst = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (inst >= p.batch) return;
+    const double* Vi = p.Vs + (size_t)inst * n * nzs;
+    const double* dv = p.dvec + (size_t)inst * nzs;
+    const size_t o = (size_t)inst * nzs;
+    for (int r = lane; r < nzs; r += 64) {
+        double v = 0.0, z = 0.0, y = 0.0;
+        if (r < nz) {
+            v = p.v0S[(size_t)inst * nz + r];
+            for (int c = 0; c < n; ++c)
+                v += Vi[(size_t)c * nzs + r] * (p.x0[(size_t)inst * n + c] - p.xref[(size_t)inst * p.xref_stride + c]);
+            const double ur = p.uref[(size_t)inst * p.uref_stride + r], di = 1.0 / dv[r];
+            const double lo = (p.umin[r % p.m] - ur) * di, hi = (p.umax[r % p.m] - ur) * di;  // as k_admm_inst forms them
+            z = fmin(fmax(0.0, lo), hi);
+            y = (hi <= 0.0) ? 1.0 : ((lo >= 0.0) ? -1.0 : 0.0);
+        }
+        p.xs[o + r] = z; p.zs[o + r] = z; p.ys[o + r] = y; p.v0[o + r] = v;
+    }
+    if (lane == 0) {
+        p.iters[inst] = 0;
+        p.status[inst] = 1;   // "not converged": the finish sets 0 when it certifies the optimum
+        p.piters[inst] = 0;
+        p.perm[inst] = inst;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_design_instance: condensed Hessian and gradient matrix of ONE instance per workgroup, entirely in LDS.
 // The dense route (k_design_gamma + k_design_hessian) materialises Gamma_i and Qbar Gamma_i in HBM (2 x 393 KB per quadrotor-size
 // instance) and contracts them with MFMA; for a batch of instances that traffic, not the flops, is the cost.  Gamma is block

@@ -182,6 +182,8 @@ int almpc_get_gradient_instance(almpc_handle* h, int instance, double* q);
  * steps of length `step_scale`; every iteration = k_fnn_jacobian along the trajectory, the time-varying condensed QP of
  * almpc_design_ltv, the per-instance step kernels, and the trajectory update -- all on the handle's stream, no host round trip.
  * A fixed point (step and defects zero) is a KKT point of the NLP: the QP gradient is the exact NLP gradient.
+ * The first iteration after `start` finds its working-set guess by ADMM, the following ones take it from the iterate (inputs
+ * that sit on a bound) and skip the ADMM phase and its KKT inverse; the exact finish makes the two equivalent.
  *
  *   setup    network in the layout of almpc_fnn_linearize, shared references xref n*(N+1) / uref m*N (NULL: zeros), weights,
  *            P (required; shared or per instance), input box, ADMM rho/sigma.  Replaces any earlier design of the handle.
