@@ -48,6 +48,7 @@ struct almpc_handle {
     int num_cus = 256;            // persistent-grid size of k_polish<true>
     size_t polish_glds_bytes = 0; // dynamic-LDS attribute last set on k_polish<true>
     int polish_no_glds = 0;       // diagnostic: force the G-through-L2 build (ALMPC_POLISH_NO_GLDS=1)
+    int polish_sgl_attr = 0;
     int skip_admm = 0;            // transient (SQP iterations after the first): guess from the iterate, no ADMM phase, no KKT inverse
     int fuse_step = 1;            // one kernel per step when the shape allows (almpc_set_step_fusion / ALMPC_NO_FUSED_STEP=1)
     size_t step_lds_bytes = 0;
@@ -1159,7 +1160,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         pp.G = h->batched ? h->bG : h->dG; pp.dvec = h->batched ? h->bD : h->dD;
         pp.G_stride = h->batched ? (long)h->nz * h->nzs : 0; pp.d_stride = h->batched ? (long)h->nzs : 0;
         pp.A_stride = h->batched ? (long)h->n * h->n : 0; pp.B_stride = h->batched ? (long)h->n * h->m : 0;
-        pp.wave_const_off = -1;
+        pp.wave_const_off = -1; pp.sg_off = 0; pp.g_off = 0;
         pp.umin = h->dUmin; pp.umax = h->dUmax; pp.uref = h->dUref; pp.uref_stride = h->uref_stride;
         pp.zs = h->dZs; pp.ys = h->dYs; pp.v0 = h->dV0; pp.w = h->dW; pp.status = h->dStatus; pp.piters = h->dPiters;
         pp.sglobal = h->dSglobal; pp.perm = h->dPerm; pp.ntiles = (h->batch + 15) / 16;
@@ -1210,6 +1211,19 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
             hipLaunchKernelGGL((k_polish<true>), dim3(wgs), dim3(64 * POLISH_WAVES_GLDS), l_glds, st, pp);
         } else {
             const size_t l = ((size_t)SL.total + (size_t)POLISH_WAVES * per_wave) * sizeof(double);
+            // small batches of per-instance models: single-wave workgroups with G_i and the second-tier Sinv in LDS
+            const size_t sgl_wave = (size_t)per_wave + POLISH_GLB_PER_INST + (size_t)h->nz * h->nzs;
+            const size_t l_sgl = ((size_t)SL.total + sgl_wave) * sizeof(double);
+            if (h->batched && h->batch <= 2 * h->num_cus && l_sgl <= 160 * 1024 && !getenv("ALMPC_POLISH_SG_GLOBAL")) {
+                pp.sg_off = per_wave;
+                pp.g_off = per_wave + POLISH_GLB_PER_INST;
+                pp.lds_per_wave = (int)sgl_wave;
+                if (!h->polish_sgl_attr) {
+                    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_polish_sgl), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l_sgl));
+                    h->polish_sgl_attr = 1;
+                }
+                hipLaunchKernelGGL(k_polish_sgl, dim3(pp.ntiles * 16), dim3(64), l_sgl, st, pp);
+            } else
             hipLaunchKernelGGL((k_polish<false>), dim3((pp.ntiles * 16 + POLISH_WAVES - 1) / POLISH_WAVES), dim3(64 * POLISH_WAVES), l, st, pp);
         }
         }

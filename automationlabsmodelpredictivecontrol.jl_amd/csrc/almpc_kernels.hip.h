@@ -426,6 +426,8 @@ struct PolishParams {
     // offset inside the wave's LDS slot of its private copy of d_i | [A_i B_i] (which replace the workgroup-shared ones)
     long G_stride, d_stride, A_stride, B_stride;
     int wave_const_off;
+    int sg_off;          // k_polish_sgl: offset inside the wave's LDS slot of its 64 x 64 Sinv (working sets beyond 32 rows)
+    int g_off;           // k_polish_sgl: offset of the wave's copy of its instance's G_i (nz rows of nzs doubles)
     int max_iter;
     int fuse_rollout;    // 1: this kernel also produces u, e_u, x, e_x (roll.*), no separate k_rollout launch; 2: u, e_u only
     int roll_g, roll_cpl; // rollout lane decomposition: roll_g lanes per state row, roll_cpl columns of [A B] per lane
@@ -603,10 +605,15 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 // GLDS: G in LDS (persistent 8-wave workgroups, tile-local queue); GPRE: it is there already (fused step kernel: requested
 // before the ADMM phase).  KOFF: byte offset of the PolishParams inside the kernel-argument segment.
-template <bool GLDS, bool GPRE, int KOFF>
+// SGL (per-instance models, small batches, e.g. the SQP loop where every instance has about 50 active rows): single-wave
+// workgroups whose LDS holds the instance's own G_i (requested with direct global -> LDS loads at the start of the instance) and
+// the 64 x 64 Sinv of a working set beyond 32 rows -- a bordering step beyond 32 rows is then two sweeps over LDS instead of
+// one over global scratch and one over rows of G_i in L2.
+template <bool GLDS, bool GPRE, int KOFF, bool SGL = false>
 __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* smem) {
     const PolishParams& p = p_arg;
-    constexpr int CH = GLDS ? 8 : 16;  // positions per chunk of G rows (LDS latency needs fewer loads in flight than L2 latency)
+    constexpr int CH = (GLDS || SGL) ? 8 : 16;  // positions per chunk of G rows (LDS latency needs fewer loads in flight than L2 latency)
+    constexpr int NWV = GLDS ? POLISH_WAVES_GLDS : (SGL ? 1 : POLISH_WAVES);  // waves per workgroup
     const int wv = threadIdx.x >> 6, lane_k = threadIdx.x & 63;
     const int nz = p.nz, nzs = p.nzs;
     const double* Gp = p.G;
@@ -621,7 +628,7 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
     double* cab = shc + SL.off_ab;
     if (per_inst) { cd = wave_lds + p.wave_const_off; cab = cd + nzs; }
     {
-        constexpr int TPB = 64 * (GLDS ? POLISH_WAVES_GLDS : POLISH_WAVES);
+        constexpr int TPB = 64 * NWV;
         const int n = p.roll.n, m = p.m, N = p.roll.N;
         if (!per_inst)
             for (int t = threadIdx.x; t < nzs; t += TPB) shc[SL.off_d + t] = p.dvec[t];
@@ -676,6 +683,16 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
     ALMPC_STAMP(inst, 8);
     if constexpr (!GLDS) {
         if (per_inst) {  // this instance's G, d, [A B]
+            if constexpr (SGL) {
+                // G_i -> LDS, one row per wave instruction (lanes x 16 bytes), no registers: everything is in flight at once
+                double* gl = wave_lds + p.g_off;
+                const char* src = reinterpret_cast<const char*>(GL(p.G) + (size_t)inst * p.G_stride) + lane * 16;
+                if (lane < nzs / 2)
+                    for (int r = 0; r < nz; ++r)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)r * nzs * 8),
+                                                         (__attribute__((address_space(3))) void*)(gl + (size_t)r * nzs), 16, 0, 0);
+                Gp = gl;
+            } else
             Gp = GL(p.G) + (size_t)inst * p.G_stride;
             const int n_ = p.roll.n, m_ = p.m;
             for (int t = lane; t < nzs; t += 64) cd[t] = GL(p.dvec)[(size_t)inst * p.d_stride + t];
@@ -683,6 +700,7 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
                 for (int t = lane; t < n_ * n_; t += 64) cab[t] = GL(p.roll.A)[(size_t)inst * p.A_stride + t];
                 for (int t = lane; t < n_ * m_; t += 64) cab[n_ * n_ + t] = GL(p.roll.B)[(size_t)inst * p.B_stride + t];
             }
+            if constexpr (SGL) __builtin_amdgcn_s_waitcnt(0);  // the copy of G_i has landed (vmcnt and lgkmcnt zero)
             wave_fence_lds();
         }
     }
@@ -699,7 +717,9 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
     double* pbufa = rowbuf + 128;      // [64]  one position-distributed vector, for broadcasts by position
     double* pbufb = pbufa + 64;        // [64]  a second one
     int* wrow_s = reinterpret_cast<int*>(pbufb + 64);  // [64] row index of each position (copy of wrow)
-    double* Sg = GL(p.sglobal) + (size_t)inst * POLISH_GLB_PER_INST;
+    double* Sg;
+    if constexpr (SGL) Sg = wave_lds + p.sg_off;
+    else Sg = GL(p.sglobal) + (size_t)inst * POLISH_GLB_PER_INST;
 
     double lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0, v00, v01, w0 = 0, w1 = 0, y0, y1, z0, z1;
     // x0 of this instance for the fused rollout (n <= 64: one state per lane), requested with the other prologue loads
@@ -774,7 +794,7 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
     // Broadcasts of a position-distributed vector go through a 64-entry LDS buffer (one uniform-address read per
     // element, pipelined with the Sinv reads) rather than through v_readlane pairs.
     auto sync_s = [&](auto m) {  // order this wave's writes to Sinv before its later reads
-        if constexpr (decltype(m)::glb) {
+        if constexpr (decltype(m)::glb && !SGL) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1353,7 +1373,7 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
 #endif
     } else {
         // slot s -> (tile s % ntiles, rank s / ntiles): the dispatch order starts with the hardest instance of every tile
-        const int slot = blockIdx.x * POLISH_WAVES + wv;
+        const int slot = blockIdx.x * NWV + wv;
         if (slot < p.ntiles * 16) {
             const int inst = p.perm[(slot % p.ntiles) * 16 + slot / p.ntiles];
             if (inst >= 0) process(inst);
@@ -1366,6 +1386,12 @@ __global__ __launch_bounds__(64 * (GLDS ? POLISH_WAVES_GLDS : POLISH_WAVES)) __a
 void k_polish(PolishParams p_arg) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     polish_body<GLDS, false, 0>(p_arg, smem);
+}
+
+// per-instance models, small batches: single-wave workgroups, G_i and the second-tier Sinv in LDS (one workgroup per CU)
+__global__ __launch_bounds__(64) void k_polish_sgl(PolishParams p_arg) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    polish_body<false, false, 0, true>(p_arg, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
