@@ -109,7 +109,8 @@ const char* almpc_last_error(const almpc_handle* h);
 /*
  * Terminal constraint e_x[:,N+1] == 0 (mpc_terminal_ingredient = "equality", src/sub/design_mpc.jl:330-331):
  * call with 1 BEFORE almpc_design_shared.  Problems with state rows (state box and/or terminal equality) are
- * finished by a dual active-set method in constraint space (k_polish_gen); they require opts.polish = 1.
+ * finished by a dual active-set method in constraint space (k_polish_gen, working sets up to 32 rows; instances beyond that are
+ * redone by k_polish_gen64, up to 64 rows; beyond 64 the instance is reported as ALMPC_MAX_ITER); they require opts.polish = 1.
  */
 int almpc_set_terminal_equality(almpc_handle* h, int on);
 
@@ -118,7 +119,7 @@ int almpc_set_terminal_equality(almpc_handle* h, int on);
  * inequality rows.  1: stiffness-matched rho_i = rho / G_ii with G = H'^-1 (a diagonal preconditioning of the
  * constraint rows, the role OSQP's Ruiz scaling E plays): rows in soft directions of the Hessian get a small penalty.
  * On the benchmark plant this cuts the active-set work after 10 ADMM iterations by ~3x; `rho` of
- * almpc_design_shared is then the numerator (10 is the tuned value).
+ * almpc_design_shared is then the numerator (the benchmark uses 45 with 6 iterations: sweep in DESIGN.md section 4).
  */
 int almpc_set_rho_profile(almpc_handle* h, int mode);
 
