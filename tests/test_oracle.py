@@ -325,3 +325,35 @@ def test_golden_sqp_vectors(mo):
     c = g["cases"][1]
     X, U, _ = mo.sqp_fnn(f, np.array(c["x0"]), kw["x_ref"], kw["u_ref"], kw["Q"], kw["R"], kw["S"], kw["P"], kw["u_min"], kw["u_max"], iters=60)
     assert np.abs(U - np.array(c["u"])).max() <= 1e-9
+
+
+def test_ltv_qp_reduces_to_the_condensed_qp_and_to_finite_differences(mo):
+    """ltv_qp (the QP of one SQP iteration) pinned from two sides: with time-invariant stages, zero defects and the linearisation
+    trajectory generated by the same model it is the condensed QP of the linear path shifted to v = u - ubar (same minimiser u);
+    and for a nonlinear model its gradient at v = 0 is the exact gradient of the NLP cost along the linearised dynamics."""
+    # (the reference pair must be an equilibrium of the model: the reference's deviation dynamics drop f(x_ref, u_ref) - x_ref,
+    # SURVEY.md section 8a-1, the LTV statement keeps the true dynamics)
+    p = mo.make_problem([[1.0, 1.0], [0.0, 1.0]], [[0.5], [1.0]], 8, [-1.0], [1.0], x_ref=[0.3, 0.0], u_ref=[0.0], s=0.7)
+    x0 = np.array([2.0, -0.5])
+    rng = np.random.default_rng(5)
+    ubar = np.clip(0.3 * rng.standard_normal((1, p.N)), -1, 1)
+    xbar = np.empty((2, p.N + 1)); xbar[:, 0] = x0
+    for k in range(p.N):
+        xbar[:, k + 1] = p.A @ xbar[:, k] + p.B @ ubar[:, k]
+    H, q, lo, hi = mo.ltv_qp([p.A] * p.N, [p.B] * p.N, None, xbar, ubar, p.x_ref, p.u_ref, p.Q, p.R, p.S, p.P, p.u_min, p.u_max)
+    v = mo.solve_box_qp_exact(H, q, lo, hi)
+    e = mo.solve_mpc_exact(p, x0)
+    assert np.abs((ubar + v.reshape(p.N, 1).T) - e["u"]).max() <= 1e-9
+    # nonlinear model: q = dJ/du of the single-shooting cost at ubar when the trajectory is the model's own rollout
+    f = mo.synthetic_fnn(act="tanh")
+    n, m, N = 4, 2, 7
+    x_ref = np.tile(np.array([0.2, -0.1, 0.05, 0.0])[:, None], (1, N + 1)); u_ref = np.tile(np.array([0.1, -0.2])[:, None], (1, N))
+    Q, R, S, P = 100.0 * np.eye(n), 0.1 * np.eye(m), 0.3 * np.eye(m), 150.0 * np.eye(n)
+    U = 0.3 * mo.splitmix_normal(0x5EED000B, 0, m, N)
+    x0 = np.array([0.5, -0.3, 0.2, 0.1])
+    X = mo.fnn_rollout(f, x0, U)
+    A, B = zip(*[f.jacobian(X[:, k], U[:, k]) for k in range(N)])
+    H, q, lo, hi = mo.ltv_qp(list(A), list(B), None, X, U, x_ref, u_ref, Q, R, S, P, -np.ones(m), np.ones(m))
+    _, G, _ = mo.nlp_cost_and_gradient(f, x0, U, x_ref, u_ref, Q, R, S, P)
+    assert np.abs(q - G.T.reshape(-1)).max() <= 1e-9 * max(1.0, np.abs(q).max())
+    assert np.allclose(H, H.T) and np.linalg.eigvalsh(H).min() > 0
