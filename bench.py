@@ -37,9 +37,9 @@ ALG_BYTES_PER_INSTANCE_STEP = 11808
 AMPLITUDES = (0.3, 1.0, 3.0)
 
 
-def make_x0(mo, first_instance, count, amplitude=None, seed=0x5EED0002):
+def make_x0(wl, first_instance, count, amplitude=None, seed=0x5EED0002):
     """x0 of instances [first, first+count): amplitude class by instance index unless one is forced."""
-    xi = mo.splitmix_normal(seed, first_instance, count, NX) * mo.QUADROTOR_X0_SCALE[None, :]
+    xi = wl.splitmix_normal(seed, first_instance, count, NX) * wl.QUADROTOR_X0_SCALE[None, :]
     if amplitude is None:
         amp = np.array(AMPLITUDES)[(np.arange(first_instance, first_instance + count) % 3)]
         return np.ascontiguousarray(xi * amp[:, None])
@@ -77,18 +77,22 @@ def main():
     args = ap.parse_args()
 
     import almpc_loader
-    import mpc_oracle as mo
+    import importlib
     pkg = almpc_loader.load_package()
     capi = pkg._capi
+    wl = importlib.import_module(pkg.__name__ + ".workloads")  # synthetic inputs (product side)
+    # oracle/ is test infrastructure: it is imported only by the checker legs below (u_err_inf, the NLP certificate) and by the
+    # cpu_baseline leg, never for the inputs and never on the measured path
+    mo = None
     ranks = pkg.sharding.Ranks(backend="nccl")  # one process per GPU; RCCL only for barrier / max-reduce
     rank, local_rank, world = ranks.rank, ranks.local_rank, ranks.world
     if world > 1 and args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     barrier, max_over_ranks = ranks.barrier, ranks.max_over_ranks
 
-    p = mo.quadrotor(N_HORIZON)
+    p = wl.quadrotor(N_HORIZON)
     first, _ = pkg.sharding.shard_range(world * BATCH_PER_GPU, rank, world)
-    X0 = make_x0(mo, first, BATCH_PER_GPU)
+    X0 = make_x0(wl, first, BATCH_PER_GPU)
     ndev = int(os.environ.get("ALMPC_NUM_DEVICES", "0"))  # test hook: fold ranks onto fewer devices (with ALMPC_DIST_BACKEND=gloo)
     dev_index = (local_rank % ndev) if ndev > 0 else local_rank
     solver = capi.Solver(NX, NU, N_HORIZON, BATCH_PER_GPU, device=dev_index, timing=True)
@@ -192,14 +196,16 @@ def main():
                          "admm_iters_mean": float(res["iters"].mean()), "polish_iters_mean": float(res["polish_iters"].mean()),
                          "polish_iters_max": int(res["polish_iters"].max())}
         # ---- parity on a sample of this very run: exact (KKT-certified) optimum from the oracle
+        import mpc_oracle as mo
+        po = mo.make_problem(p.A, p.B, N_HORIZON, p.u_min, p.u_max)   # the oracle's statement of the same problem (P = its own DARE)
         nchk = 96
         err = 0.0
         for i in range(nchk):
-            e = mo.solve_mpc_exact(p, X0[i])
+            e = mo.solve_mpc_exact(po, X0[i])
             err = max(err, float(np.abs(res["u"][i] - e["u"]).max()))
         out["u_err_inf"] = err
         out["u_err_sample"] = f"first {nchk} instances of rank 0 vs oracle exact optimum"
-        _, _, Hq, _ = mo.condense(p)
+        _, _, Hq, _ = mo.condense(po)
         out["cond_H"] = float(np.linalg.cond(Hq))
 
     solver2 = None
@@ -210,7 +216,7 @@ def main():
         solver2 = capi.Solver(NX, NU, N_HORIZON, BATCH_PER_GPU, device=dev_index)
         solver2.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max, **design_kw)
         solver2.set_reference(p.x_ref, p.u_ref)
-        solver2.update_initialization(make_x0(mo, first + world * BATCH_PER_GPU, BATCH_PER_GPU))
+        solver2.update_initialization(make_x0(wl, first + world * BATCH_PER_GPU, BATCH_PER_GPU))
         pair = (solver, solver2)
         solver.timing_reset(args.steps + args.warmup)
         for i in range(2 * max(5, args.warmup // 5)):
@@ -254,7 +260,7 @@ def main():
         # per-class rates (each class alone on the whole batch), short runs
         cls = {}
         for s_ in AMPLITUDES:
-            solver.update_initialization(make_x0(mo, first, BATCH_PER_GPU, amplitude=s_))
+            solver.update_initialization(make_x0(wl, first, BATCH_PER_GPU, amplitude=s_))
             k = max(20, args.steps // 5)
             solver.timing_reset(3 * k + args.warmup)  # no event creation inside the timed loop
             time_steps(solver, opts, max(5, args.warmup // 5), barrier)
@@ -273,7 +279,8 @@ def main():
         Bb = np.repeat(p.B[None], BATCH_PER_GPU, 0) * (1.0 + 0.05 * rng.standard_normal((BATCH_PER_GPU, 1, 1)))
         sb = capi.Solver(NX, NU, N_HORIZON, BATCH_PER_GPU, device=dev_index, timing=True)
         t0 = time.perf_counter()
-        sb.design_batched(Ab, Bb, p.Q, p.R, p.S, p.P, p.u_min, p.u_max, **design_kw)
+        P_lib = solver.get_design()["P"]   # the library's DARE of the nominal model, shared by the perturbed ones
+        sb.design_batched(Ab, Bb, p.Q, p.R, p.S, P_lib, p.u_min, p.u_max, **design_kw)
         t_design = time.perf_counter() - t0
         sb.set_reference(p.x_ref, p.u_ref)
         sb.update_initialization(X0)
@@ -311,12 +318,15 @@ def main():
         # Secondary figure: BASELINE configs[4] -- the NLP of the reference's NonLinearProgramming branch for an Fnn model
         # (N = 50, batch = 256) through the device-resident SQP loop: one iteration = Jacobians of 256 x 50 stages, the LTV
         # condensed QP (H_i in LDS, two 100 x 100 inverses), ADMM + polish per instance, trajectory update.
-        f = mo.synthetic_fnn(act="tanh")
         bq, nq, mq, Nq = 256, 4, 2, 50
+        W_in, W_h, b_h, W_out = wl.synthetic_fnn_weights(nq, mq)
+        A0, _ = capi.fnn_linearize(W_in, W_h, b_h, W_out, np.zeros((1, nq)), np.zeros((1, mq)), act="tanh", device=dev_index)
+        W_out = wl.scale_to_radius(W_out, A0[0])   # spectral radius 0.95 at the origin
+        f = pkg.Fnn(W_in, W_h, b_h, W_out, "tanh")
         xr = np.tile(np.array([0.2, -0.1, 0.05, 0.0])[:, None], (1, Nq + 1)); ur = np.tile(np.array([0.1, -0.2])[:, None], (1, Nq))
-        X0q = xr[:, 0][None, :] + 0.6 * mo.splitmix_normal(0x5EED0005, 0, bq, nq)
-        Al, Bl = f.jacobian(xr[:, -1], ur[:, -1])
-        Pq = mo.dare(Al, Bl, 100.0 * np.eye(nq), 0.1 * np.eye(mq))
+        X0q = xr[:, 0][None, :] + 0.6 * wl.splitmix_normal(0x5EED0005, 0, bq, nq)
+        Al, Bl = capi.fnn_linearize(W_in, W_h, b_h, W_out, xr[:, -1][None, :], ur[:, -1][None, :], act="tanh", device=dev_index)
+        Pq = capi.dare(Al[0], Bl[0], 100.0 * np.eye(nq), 0.1 * np.eye(mq))   # terminal weight as the reference takes it (last reference)
         sq = capi.Solver(nq, mq, Nq, bq, device=dev_index)
         sq.sqp_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, xr, ur, 100.0 * np.eye(nq), 0.1 * np.eye(mq), None, Pq, -np.ones(mq), np.ones(mq),
                          act="tanh")
@@ -330,7 +340,9 @@ def main():
             best = min(best, time.perf_counter() - t0)
         st2_, de2_ = sq.sqp_fnn_iterate(its, step_rule="merit")   # 20 more from there: where the loop ends up
         rq = sq.get_results(want=("status", "u"))
-        kkt = max(mo.nlp_kkt_residual(f, X0q[i], rq["u"][i], xr, ur, 100.0 * np.eye(nq), 0.1 * np.eye(mq), np.zeros((mq, mq)), Pq,
+        import mpc_oracle as mo   # checker: first-order certificate of the NLP itself
+        fo = mo.FnnModel(W_in, W_h, b_h, W_out, "tanh")
+        kkt = max(mo.nlp_kkt_residual(fo, X0q[i], rq["u"][i], xr, ur, 100.0 * np.eye(nq), 0.1 * np.eye(mq), np.zeros((mq, mq)), Pq,
                                       -np.ones(mq), np.ones(mq)) for i in range(0, bq, 32))
         out["sqp_fnn"] = {"value": its / best, "unit": "SQP iterations/s (256 instances, Fnn 4-2-16x2 tanh, N=50)",
                           "ms_per_iteration": 1e3 * best / its, "instance_iterations_per_s": its * bq / best,
@@ -346,13 +358,15 @@ def main():
         # ---- CPU baseline (kind "port": oracle/almpc_oracle.c, OpenMP over instances, all host cores) on a bounded
         # sample of the same workload: the same 4096 x0, same options, repeated until ~10 s of wall time
         import c_oracle
-        des = mo.design_shared(p, rho=opts.rho, sigma=opts.sigma, rho_profile=args.rho_profile)
+        import mpc_oracle as mo
+        po = mo.make_problem(p.A, p.B, N_HORIZON, p.u_min, p.u_max)
+        des = mo.design_shared(po, rho=opts.rho, sigma=opts.sigma, rho_profile=args.rho_profile)
         kw = dict(alpha=opts.alpha, eps_abs=opts.eps_abs, eps_rel=opts.eps_rel, max_iter=int(opts.max_iter),
                   check_every=int(opts.check_every), polish=bool(opts.polish), threads=pkg.sharding.host_cpu_share())
-        c_oracle.step_batch(p, des, X0[:256], **kw)  # warm
+        c_oracle.step_batch(po, des, X0[:256], **kw)  # warm
         reps, t0, used = 0, time.perf_counter(), 1
         while True:
-            r = c_oracle.step_batch(p, des, X0, **kw)
+            r = c_oracle.step_batch(po, des, X0, **kw)
             used = r["threads"]
             reps += 1
             if time.perf_counter() - t0 > 12.0 or reps >= 100000:
@@ -367,7 +381,7 @@ def main():
         # tests use, on 12 instances of the same batch
         t0 = time.perf_counter()
         for i_ in range(0, 12 * 300, 300):
-            mo.solve_mpc_exact(p, X0[i_])
+            mo.solve_mpc_exact(po, X0[i_])
         out["cpu_baseline"]["exact_oracle_ms_per_solve_1_thread"] = 1e3 * (time.perf_counter() - t0) / 12
     solver.close()
     if solver2 is not None:

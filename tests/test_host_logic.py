@@ -69,3 +69,23 @@ def test_shard_range_partitions(pkg, batch, world):
 
 def test_aggregate_rate(pkg):
     assert pkg.sharding.aggregate_rate(4096, 10, 2.0, 8) == 8 * 4096 * 10 / 2.0
+
+
+def test_workloads_module_matches_the_oracle_generators(pkg, mo):
+    """bench.py takes its synthetic inputs from the product-side workloads module (it may not route inputs through oracle/);
+    the oracle keeps its own copies for the tests: the two must produce identical arrays."""
+    import importlib
+    wl = importlib.import_module(pkg.__name__ + ".workloads")
+    assert np.array_equal(wl.splitmix_normal(0x5EED0002, 5, 9, 12), mo.splitmix_normal(0x5EED0002, 5, 9, 12))
+    assert np.array_equal(wl.quadrotor_x0_batch(7, 3.0, first_instance=11), mo.quadrotor_x0_batch(7, 3.0, first_instance=11))
+    A, B = wl.quadrotor_model()
+    Ao, Bo = mo.quadrotor_model()
+    assert np.array_equal(A, Ao) and np.array_equal(B, Bo)
+    q, qo = wl.quadrotor(30), mo.quadrotor(30)
+    for k in ("Q", "R", "S", "u_min", "u_max", "x_ref", "u_ref"):
+        assert np.array_equal(getattr(q, k), getattr(qo, k)), k
+    W_in, W_h, b_h, W_out = wl.synthetic_fnn_weights()
+    fo = mo.synthetic_fnn(act="tanh")
+    A0, _ = mo.FnnModel(W_in, W_h, b_h, W_out, "tanh").jacobian(np.zeros(4), np.zeros(2))
+    assert np.array_equal(W_in, fo.W_in) and np.array_equal(W_h[1], fo.W_h[1]) and np.array_equal(b_h[0], fo.b_h[0])
+    assert np.array_equal(wl.scale_to_radius(W_out, A0), fo.W_out)
