@@ -40,25 +40,22 @@ struct almpc_handle {
     double *dXref = nullptr, *dUref = nullptr, *dFS = nullptr, *dV0S = nullptr, *dRho = nullptr;
     int rho_mode = 0;  // 0 scalar rho (OSQP), 1 stiffness profile rho / G_ii
     long xref_stride = 0, uref_stride = 0, fS_stride = 0;
-    std::vector<double> hS;  // S weight (for fS with per-instance references)
+    std::vector<double> hS;  // S weight, symmetrised (for fS with per-instance references)
+    int useS = 0;            // the input-rate term is part of the cost: R[1,1] != 0 and S[1,1] != 0 (src/sub/design_mpc.jl:423-466)
     // device: per-instance state and results
     double *dX0 = nullptr, *dXs = nullptr, *dZs = nullptr, *dYs = nullptr, *dV0 = nullptr, *dW = nullptr;
     double *dX = nullptr, *dEx = nullptr, *dU = nullptr, *dEu = nullptr;
     int32_t *dStatus = nullptr, *dIters = nullptr, *dPiters = nullptr, *dPerm = nullptr;
     int num_cus = 256;            // persistent-grid size of k_polish<true>
-    size_t polish_glds_bytes = 0; // dynamic-LDS attribute last set on k_polish<true>
     int polish_no_glds = 0;       // diagnostic: force the G-through-L2 build (ALMPC_POLISH_NO_GLDS=1)
-    int polish_sgl_attr = 0;
     int skip_admm = 0;            // transient (SQP iterations after the first): guess from the iterate, no ADMM phase, no KKT inverse
     int fuse_step = 1;            // one kernel per step when the shape allows (almpc_set_step_fusion / ALMPC_NO_FUSED_STEP=1)
-    size_t step_lds_bytes = 0;
     double* dSglobal = nullptr;  // polish scratch for working sets beyond 32 rows
     // state rows (state box / terminal equality): constraint-space data for k_polish_gen
     int terminal_eq = 0, has_box = 0, mc = 0, R = 0, Rs = 0, np_pairs = 0;
     double *dGhat = nullptr, *dGnorm = nullptr, *dXmin = nullptr, *dXmax = nullptr;
     int *dRowTraj = nullptr, *dRowEq = nullptr, *dRowXidx = nullptr, *dRowState = nullptr;
     int32_t* dOverflow = nullptr;  // [2 + batch] k_polish_gen: count, cursor and list of instances to redo with the 64-row build
-    int pgen64_attr[4] = {0, 0, 0, 0};
     // per-instance models (almpc_design_batched): persistent per-instance operands ...
     bool batched = false;
     bool ltv = false;             // almpc_design_ltv: references and gradient are part of the design
@@ -270,6 +267,9 @@ int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const
     if (!A || !B || !Q || !R || !umin || !umax) return fail(h, ALMPC_ERR_INVALID, "design: null matrix pointer");
     if ((xmin == nullptr) != (xmax == nullptr)) return fail(h, ALMPC_ERR_INVALID, "design: give both xmin and xmax or neither");
     if (!(rho > 0.0) || !(sigma >= 0.0)) return fail(h, ALMPC_ERR_INVALID, "design: rho must be > 0 and sigma >= 0");
+    // from here on the handle's previous design is being overwritten: it counts as designed again only after the last step below
+    h->designed = false;
+    h->sqp.ready = h->sqp.started = false;
     HIP_TRY(h, hipSetDevice(h->device));
     const int n = h->n, m = h->m, N = h->N, nz = h->nz;
     for (int i = 0; i < m; ++i)
@@ -280,7 +280,13 @@ int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const
     if (P) Pm.assign(P, P + (size_t)n * n);
     else if (!hm::dare(Am, Bm, Qm, Rm, n, m, Pm)) return fail(h, ALMPC_ERR_NUMERIC, "design: DARE did not converge");
     h->P = Pm;
+    for (int j = 0; j < m; ++j)  // S enters the cost as a quadratic form: only its symmetric part counts
+        for (int i = 0; i < j; ++i) {
+            const double v = 0.5 * (Sm[(size_t)j * m + i] + Sm[(size_t)i * m + j]);
+            Sm[(size_t)j * m + i] = Sm[(size_t)i * m + j] = v;
+        }
     h->hS = Sm;
+    h->useS = (Rm[0] != 0.0 && Sm[0] != 0.0) ? 1 : 0;  // the reference drops the S term together with R (src/sub/design_mpc.jl:423-466)
     h->rho = rho; h->sigma = sigma;
 
     // ---- state rows: the state box for stages 2..N+1 (stage 1 is x0 itself, checked per instance) and/or the terminal
@@ -342,7 +348,9 @@ int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const
     h->ltv = false;
     // default references: zeros, shared
     std::vector<double> xr((size_t)n * (N + 1), 0.0), ur((size_t)nz, 0.0);
-    return almpc_set_reference(h, xr.data(), ur.data(), 0);
+    const int rc_ref = almpc_set_reference(h, xr.data(), ur.data(), 0);
+    if (rc_ref != ALMPC_OK) h->designed = false;
+    return rc_ref;
 }
 
 // Per-instance models: every instance gets its own condensed QP from (A_i, B_i).  The design kernels of
@@ -432,7 +440,7 @@ hipError_t launch_fnn_jacobian(const FnnParams& p, int num_cus, hipStream_t st) 
     }
     const size_t lds = (2 * (size_t)p.H + 2 * (size_t)p.H * nin + nin) * sizeof(double);
     if (lds > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fnn_jacobian), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(k_fnn_jacobian), (size_t)(lds));
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_fnn_jacobian, dim3(p.batch), dim3(256), lds, st, p);
@@ -453,7 +461,7 @@ bool ltv_supported(const almpc_handle* h) {
 template <int NC>
 hipError_t launch_design_ltv_reg(almpc_handle* h, const DesignLtvParams& lp, size_t lds, hipStream_t st) {
     if (lds > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_design_ltv_reg<NC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(k_design_ltv_reg<NC>), (size_t)(lds));
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL((k_design_ltv_reg<NC>), dim3((unsigned)h->batch), dim3(1024), lds, st, lp);
@@ -474,7 +482,7 @@ hipError_t launch_design_ltv(almpc_handle* h, const DesignLtvParams& lp, hipStre
     }
     const size_t lds = design_ltv_lds_doubles(n, m, h->N) * sizeof(double);
     if (lds > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_design_ltv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(k_design_ltv), (size_t)(lds));
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_design_ltv, dim3((unsigned)h->batch), dim3(256), lds, st, lp);
@@ -488,6 +496,8 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
     if (!A_batch || !B_batch || !Q || !R || !umin || !umax) return fail(h, ALMPC_ERR_INVALID, "design_batched: null matrix pointer");
     if (!(rho > 0.0) || !(sigma >= 0.0)) return fail(h, ALMPC_ERR_INVALID, "design_batched: rho must be > 0 and sigma >= 0");
     if (h->terminal_eq) return fail(h, ALMPC_ERR_UNSUPPORTED, "design_batched: state rows (terminal equality) need a shared model");
+    h->designed = false;  // the previous design is overwritten below; set again by the last statement on success
+    h->sqp.ready = h->sqp.started = false;
     HIP_TRY(h, hipSetDevice(h->device));
     const int n = h->n, m = h->m, N = h->N, nz = h->nz, nzs = h->nzs, nrb = h->nrb;
     const size_t b = (size_t)h->batch;
@@ -525,6 +535,7 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
     h->rho = rho; h->sigma = sigma;
     h->has_box = 0; h->mc = 0; h->R = nz; h->np_pairs = 1; h->Rs = 128;
     const int useR = Rm[0] != 0.0, useS = useR && Sm[0] != 0.0;
+    h->useS = useS;
     const int njf = (n + 15) / 16, ps = 16 * njf, gs = nzs;
     const int kr = ((n * N + HESS_KC - 1) / HESS_KC) * HESS_KC;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -578,7 +589,7 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
         dp.A = h->bA; dp.B = h->bB; dp.P = h->bP; dp.sA = ds.A; dp.sB = ds.B; dp.sP = ds.P;
         dp.Q = dQ; dp.R = dR; dp.S = dS; dp.H = h->bH; dp.F = h->bF; dp.sH = ds.H; dp.sF = ds.F;
         if (inst_lds > 64 * 1024)
-            BTRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_design_instance), hipFuncAttributeMaxDynamicSharedMemorySize, (int)inst_lds));
+            BTRY(ensure_dyn_lds(reinterpret_cast<const void*>(k_design_instance), (size_t)(inst_lds)));
         hipLaunchKernelGGL(k_design_instance, dim3(gb), dim3(256), inst_lds, st, dp);
     } else {
     hipLaunchKernelGGL(k_design_blocks, dim3(1, gb), dim3(256), (size_t)(3 * n * n + n * m) * sizeof(double), st, n, m, N,
@@ -592,7 +603,7 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
     hipLaunchKernelGGL(k_design_hessian, dim3(nrb, gb), dim3(64 * (nrb + njf)), hess_lds, st, hp);
     }
     BTRY(hipGetLastError());
-    BTRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_design_inverse), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(520 * sizeof(double))));
+    BTRY(ensure_dyn_lds(reinterpret_cast<const void*>(k_design_inverse), (size_t)((520 * sizeof(double)))));
     launch_batched_factor(h, ds, rho, sigma, st);
     hipLaunchKernelGGL(k_neg_gm, dim3(4, gb), dim3(256), 0, st, nz, nzs, n, nzs, h->bG, h->bFs, h->bVs, ds.G, ds.Fs);
     BTRY(hipGetLastError());
@@ -617,20 +628,24 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
     h->ltv = false;
     if (!ltv) {
         std::vector<double> xr((size_t)n * (N + 1), 0.0), ur((size_t)nz, 0.0);
-        return almpc_set_reference(h, xr.data(), ur.data(), 0);
+        const int rc = almpc_set_reference(h, xr.data(), ur.data(), 0);
+        if (rc != ALMPC_OK) h->designed = false;
+        return rc;
     }
     // LTV: the QP variable is v = u - ubar, so ubar takes the place of the input reference (bounds umin - ubar <= v, u = v + ubar);
     // the gradient is the explicit vector q_i (F'_i = V_i = 0: the step kernels add nothing for e0)
     {
         const int rc = almpc_set_reference(h, ltv->xbar, ltv->ubar, 1);
-        if (rc != ALMPC_OK) return rc;
+        if (rc != ALMPC_OK) { h->designed = false; return rc; }
     }
+    h->designed = false;  // until the explicit gradient below is in place
     hipLaunchKernelGGL(k_fs_scale, dim3(256), dim3(256), 0, h->stream, h->batch, nz, nzs, h->bQ, (long)nz, h->bD, h->dFS);
     hipLaunchKernelGGL(k_neg_gm, dim3(1, (unsigned)h->batch), dim3(256), 0, h->stream, nz, nzs, 1, nz, h->bG, h->dFS, h->dV0S,
                        (long)nz * nzs, (long)nz);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->ltv = true;
+    h->designed = true;
     return ALMPC_OK;
 }
 }  // namespace
@@ -719,6 +734,8 @@ int almpc_sqp_fnn_setup(almpc_handle* h, int H, int L, int activation, const dou
         return fail(h, ALMPC_ERR_UNSUPPORTED, "sqp_fnn_setup: the network's forward-mode Jacobian must fit the 160 KB of LDS");
     for (int i = 0; i < m; ++i)
         if (!(umin[i] <= umax[i])) return fail(h, ALMPC_ERR_INVALID, "sqp_fnn_setup: umin > umax");
+    h->designed = false;  // any earlier design of the handle is replaced (its reference buffers are released below)
+    h->sqp.ready = h->sqp.started = false;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     auto sym = [](const double* M, int k) {
@@ -786,6 +803,7 @@ int almpc_sqp_fnn_setup(almpc_handle* h, int H, int L, int activation, const dou
     q.H = H; q.L = L; q.act = activation; q.useR = Rm[0] != 0.0; q.useS = q.useR && Sm[0] != 0.0; q.sP = p_inst ? (long)n * n : 0;
     h->P.assign(Pall.begin(), Pall.begin() + (size_t)n * n);
     h->hS = Sm;
+    h->useS = q.useS;
     h->rho = rho; h->sigma = sigma;
     h->has_box = 0; h->mc = 0; h->R = nz; h->np_pairs = 1; h->Rs = 128;
     h->xref_stride = (long)n * (N + 1); h->uref_stride = nz; h->fS_stride = nz;
@@ -823,7 +841,7 @@ int almpc_sqp_fnn_start(almpc_handle* h, const double* x0, const double* u_guess
     rp.n = n; rp.m = m; rp.H = q.H; rp.L = q.L; rp.act = q.act; rp.N = N;
     rp.W_in = q.W_in; rp.W_h = q.W_h; rp.b_h = q.b_h; rp.W_out = q.W_out; rp.x0 = h->dX0; rp.ubar = h->dUref; rp.xbar = h->dXref;
     const size_t l = (2 * (size_t)q.H + n + m) * sizeof(double);
-    if (l > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_fnn_rollout), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l));
+    if (l > 64 * 1024) HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(k_fnn_rollout), (size_t)(l)));
     hipLaunchKernelGGL(k_fnn_rollout, dim3((unsigned)b), dim3(256), l, st, rp);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemsetAsync(q.bad, 0, b * sizeof(int), st));
@@ -854,10 +872,10 @@ int almpc_sqp_fnn_iterate(almpc_handle* h, int iters, double step_scale, const a
         q.stats_cap = iters;
     }
     HIP_TRY(h, hipMemsetAsync(q.stats, 0, (size_t)2 * iters * sizeof(unsigned long long), st));
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_design_inverse), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(520 * sizeof(double))));
+    HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(k_design_inverse), (size_t)((520 * sizeof(double)))));
     const DesignStrides ds = batched_strides(h, q.sP != 0);
     const size_t step_lds = sqp_step_lds_doubles(n, m, N) * sizeof(double);
-    if (step_lds > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sqp_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds));
+    if (step_lds > 64 * 1024) HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(k_sqp_step), (size_t)(step_lds)));
     FnnParams fp;
     fp.n = n; fp.m = m; fp.H = q.H; fp.L = q.L; fp.act = q.act; fp.batch = (int)(b * N);
     fp.W_in = q.W_in; fp.W_h = q.W_h; fp.b_h = q.b_h; fp.W_out = q.W_out;
@@ -952,6 +970,7 @@ int almpc_set_reference(almpc_handle* h, const double* xref, const double* uref,
     const size_t xs = (size_t)n * (N + 1), us = (size_t)nz;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->sqp.ready = h->sqp.started = false;  // the SQP iterate lived in the reference buffers released here
+    h->designed = false;                    // the reference buffers are replaced below: designed again on success only
     if (h->dXref) { (void)hipFree(h->dXref); h->dXref = nullptr; }
     if (h->dUref) { (void)hipFree(h->dUref); h->dUref = nullptr; }
     if (h->dFS) { (void)hipFree(h->dFS); h->dFS = nullptr; }
@@ -965,7 +984,7 @@ int almpc_set_reference(almpc_handle* h, const double* xref, const double* uref,
     HIP_TRY(h, hipMemcpy(h->dUref, uref, cnt * us * sizeof(double), hipMemcpyHostToDevice));
     // fS = d .* (2 D'Sbar D u_ref): the input-rate cost is on u, not e_u (src/sub/design_mpc.jl:423-446)
     std::vector<double> fS(cnt * us, 0.0);
-    if (h->hS[0] != 0.0) {
+    if (h->useS) {  // S counts only together with R (the reference's branch rule, src/sub/design_mpc.jl:423-466), as in the design kernels
         for (size_t c = 0; c < cnt; ++c) {
             const double* ur = uref + c * us;
             double* f = fS.data() + c * us;
@@ -1008,6 +1027,7 @@ int almpc_set_reference(almpc_handle* h, const double* xref, const double* uref,
     h->xref_stride = per_instance ? (long)xs : 0;
     h->uref_stride = per_instance ? (long)us : 0;
     h->fS_stride = (per_instance || h->batched) ? (long)us : 0;
+    h->designed = true;
     return ALMPC_OK;
 }
 
@@ -1069,7 +1089,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         } else {
         const size_t l = (12 * (size_t)h->nzs + 64 + 2 * (size_t)h->m) * sizeof(double);
         if (l > 64 * 1024)
-            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_admm_inst), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l));
+            HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(k_admm_inst), (size_t)(l)));
         // persistent grid: as many workgroups as fit the CUs at once (LDS bound; 512 threads each, at most 4 per CU)
         const int per_cu = 2;  // register bound: 2 x 256 threads at up to 256 VGPRs each fill the CU's register file
         int wgs = h->num_cus * per_cu;
@@ -1138,11 +1158,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
 #define PGEN_LAUNCH(NP_)                                                                                                         \
     do {                                                                                                                         \
         hipLaunchKernelGGL((k_polish_gen<NP_>), grid, block, l32, st, gp);                                                       \
-        if (!h->pgen64_attr[NP_ - 1]) {                                                                                          \
-            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_polish_gen64<NP_>),                                   \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)l64));                               \
-            h->pgen64_attr[NP_ - 1] = 1;                                                                                         \
-        }                                                                                                                        \
+        HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(k_polish_gen64<NP_>), l64));                                     \
         hipLaunchKernelGGL((k_polish_gen64<NP_>), dim3(4 * h->num_cus < h->batch ? 4 * h->num_cus : h->batch), dim3(64), l64, st, gp); \
     } while (0)
         switch (h->np_pairs) {
@@ -1191,21 +1207,16 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
             admm_pending = false;
             if (timing) HIP_TRY(h, hipEventRecord(ev[1], st));  // no boundary between the phases to time: admm_ms reads 0
             if (h->ks == 30) {
-                if (h->step_lds_bytes != l_step) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_fused<8, 30>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l_step));
+                HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(k_step_fused<8, 30>), (size_t)(l_step)));
                 hipLaunchKernelGGL((k_step_fused<8, 30>), dim3(pp.ntiles), dim3(512), l_step, st, ap, pp);
             } else {
-                if (h->step_lds_bytes != l_step) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_fused<8, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l_step));
+                HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(k_step_fused<8, 32>), (size_t)(l_step)));
                 hipLaunchKernelGGL((k_step_fused<8, 32>), dim3(pp.ntiles), dim3(512), l_step, st, ap, pp);
             }
-            h->step_lds_bytes = l_step;
-        } else {
+                } else {
         { const int rc_ = flush_admm(); if (rc_ != ALMPC_OK) return rc_; }
         if (l_glds <= 160 * 1024 && !h->polish_no_glds && !h->batched) {
-            if (h->polish_glds_bytes != l_glds) {
-                HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_polish<true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)l_glds));
-                h->polish_glds_bytes = l_glds;
-            }
+            HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(k_polish<true>), (size_t)(l_glds)));
             int wgs = pp.ntiles;  // one ADMM tile (16 instances) per workgroup and round
             if (wgs > h->num_cus) wgs = h->num_cus;
             hipLaunchKernelGGL((k_polish<true>), dim3(wgs), dim3(64 * POLISH_WAVES_GLDS), l_glds, st, pp);
@@ -1218,13 +1229,12 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
                 pp.sg_off = per_wave;
                 pp.g_off = per_wave + POLISH_GLB_PER_INST;
                 pp.lds_per_wave = (int)sgl_wave;
-                if (!h->polish_sgl_attr) {
-                    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_polish_sgl), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l_sgl));
-                    h->polish_sgl_attr = 1;
-                }
+                HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(k_polish_sgl), (size_t)(l_sgl)));
                 hipLaunchKernelGGL(k_polish_sgl, dim3(pp.ntiles * 16), dim3(64), l_sgl, st, pp);
-            } else
+            } else {
+            HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(k_polish<false>), l));
             hipLaunchKernelGGL((k_polish<false>), dim3((pp.ntiles * 16 + POLISH_WAVES - 1) / POLISH_WAVES), dim3(64 * POLISH_WAVES), l, st, pp);
+            }
         }
         }
         HIP_TRY(h, hipGetLastError());
@@ -1243,8 +1253,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
             hipLaunchKernelGGL((k_rollout<4>), dim3((h->batch + 3) / 4), dim3(256), l, st, rp);
         } else {  // long horizons with many states: one instance per workgroup, LDS beyond the 64 KiB default
             const size_t l = (shared + per_wave) * sizeof(double);
-            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout<1>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)l));
+            HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(k_rollout<1>), (size_t)(l)));
             hipLaunchKernelGGL((k_rollout<1>), dim3(h->batch), dim3(64), l, st, rp);
         }
         HIP_TRY(h, hipGetLastError());
@@ -1447,7 +1456,7 @@ int almpc_debug_poison_lds(almpc_handle* h) {
     if (!h) return ALMPC_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
     const int bytes = 160 * 1024;
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_poison_lds), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(k_poison_lds), (size_t)(bytes)));
     // one workgroup owns a whole CU's LDS; several waves of workgroups so that every CU is visited
     hipLaunchKernelGGL(k_poison_lds, dim3(1024), dim3(1024), bytes, h->stream, 0x7ff8dead0000beefULL, bytes / 8,
                        reinterpret_cast<unsigned long long*>(h->dSglobal));

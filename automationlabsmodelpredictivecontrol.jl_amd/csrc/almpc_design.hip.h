@@ -517,8 +517,7 @@ inline int design_shared_device(hipStream_t stream, int n, int m, int N, int nzs
     hipLaunchKernelGGL(k_design_scale, dim3(1), dim3(256), 0, stream, nz, nzs, n, dH, dF, dD, dHs, dFs, dFlag, DesignStrides());
     DTRY(hipGetLastError());
     const size_t inv_lds = ((size_t)nz * (nz + 1) + nz + 2) * sizeof(double);
-    DTRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_design_inverse_chol), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)inv_lds));
+    DTRY(ensure_dyn_lds(reinterpret_cast<const void*>(k_design_inverse_chol), (size_t)(inv_lds)));
     // G = H'^-1 first: the stiffness profile of the ADMM penalty (rho_i = rho / G_ii) is read off its diagonal
     hipLaunchKernelGGL(k_design_inverse_chol, dim3(1), dim3(512), inv_lds, stream, nz, nzs, dHs, 0.0, (const double*)nullptr, dG, dFlag, 0L, 0L, 0L, 0L);
     DTRY(hipGetLastError());

@@ -66,10 +66,10 @@ inline bool lu_solve(mat A, mat& B, int n, int c) {
     return true;
 }
 
-inline double fro(const mat& A) {
+inline double amax(const mat& A) {  // max-abs norm (no squares: a diverging iterate must not overflow the test that rejects it)
     double s = 0.0;
-    for (double v : A) s += v * v;
-    return std::sqrt(s);
+    for (double v : A) s = std::fmax(s, std::fabs(v));
+    return s;
 }
 
 // Stabilising solution of the discrete algebraic Riccati equation
@@ -81,7 +81,8 @@ inline bool dare(const mat& A, const mat& B, const mat& Q, const mat& R, int n, 
     if (!lu_solve(R, Rinv_Bt, m, n)) return false;
     mat Ak = A, Gk = mul(B, Rinv_Bt, n, m, n), Hk = Q;
     const mat I = eye(n);
-    for (int it = 0; it < 200; ++it) {
+    bool converged = false;
+    for (int it = 0; it < 200 && !converged; ++it) {
         mat W = mul(Gk, Hk, n, n, n);
         for (size_t i = 0; i < W.size(); ++i) W[i] += I[i];
         mat WinvA = Ak, WinvG = Gk;
@@ -101,12 +102,26 @@ inline bool dare(const mat& A, const mat& B, const mat& Q, const mat& R, int n, 
             }
         mat diff = H1;
         for (size_t i = 0; i < diff.size(); ++i) diff[i] -= Hk[i];
-        const bool done = fro(diff) <= 1e-13 * std::fmax(1.0, fro(H1));
+        const bool done = std::isfinite(amax(H1)) && amax(diff) <= 1e-13 * std::fmax(1.0, amax(H1));
         Ak.swap(A1); Gk.swap(G1); Hk.swap(H1);
-        if (done) break;
+        converged = done;
     }
+    if (!converged) return false;  // 200 doublings without a fixed point: no stabilising solution to working precision
     for (double v : Hk)
         if (!std::isfinite(v)) return false;
+    // accept only a P that satisfies the equation itself: residual of A'PA - P - A'PB (R + B'PB)^-1 B'PA + Q
+    {
+        const mat At = transpose(A, n, n), Bt = transpose(B, n, m);
+        const mat PA = mul(Hk, A, n, n, n), PB = mul(Hk, B, n, n, m);
+        mat S = mul(Bt, PB, m, n, m);
+        for (size_t i = 0; i < S.size(); ++i) S[i] += R[i];
+        mat K = mul(Bt, PA, m, n, n);  // B'PA, m x n
+        if (!lu_solve(S, K, m, n)) return false;
+        mat res = mul(At, PA, n, n, n);
+        const mat corr = mul(mul(At, PB, n, n, m), K, n, m, n);
+        for (size_t i = 0; i < res.size(); ++i) res[i] += Q[i] - Hk[i] - corr[i];
+        if (!(amax(res) <= 1e-7 * std::fmax(1.0, std::fmax(amax(Hk), amax(Q))))) return false;
+    }
     P = Hk;
     return true;
 }

@@ -19,7 +19,29 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 namespace almpc {
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-function, process-wide attribute (per device): keep the largest value ever
+// asked for per (device, kernel) and only ever raise it, so that handles of different shapes cannot lower each other's limit.
+inline hipError_t ensure_dyn_lds(const void* fn, size_t bytes) {
+    if (bytes <= 64 * 1024) return hipSuccess;  // within the default limit
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, size_t> cur;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& c = cur[std::make_pair(dev, fn)];
+    if (c >= bytes) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) c = bytes;
+    return e;
+}
+
 
 // Diagnostic build only (-DALMPC_STAMPS): lane 0 of every wave records the shader clock at phase boundaries into a
 // debug buffer of its own (never read by kernel code).  The shipped library has no stamps.

@@ -28,12 +28,14 @@ class Ranks:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.dist = None
         self.device = "cpu"
+        self.backend = "none"
         if self.world > 1:
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             import torch
             import torch.distributed as dist
             # ALMPC_DIST_BACKEND=gloo lets the multi-process plumbing be exercised on a box with fewer GPUs than ranks
             backend = os.environ.get("ALMPC_DIST_BACKEND") or backend or "nccl"
+            self.backend = backend
             if backend == "nccl":
                 idx = self.local_rank if device_index is None else device_index
                 torch.cuda.set_device(idx)

@@ -57,6 +57,32 @@ def time_steps(solver, opts, steps, barrier):
     return time.perf_counter() - t0
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` typed by hand (no launcher): start N ranks of this script under torch.distributed.run, one per
+    GPU, relay their output (rank 0 prints the JSON line) and return the launcher's exit code.  Runs before anything in this
+    process initialises HIP (counting devices does not); children are separate processes, nothing is exec'ed over this one."""
+    import socket
+    import subprocess
+    fold = int(os.environ.get("ALMPC_NUM_DEVICES", "0"))   # test hook: fold ranks onto fewer devices (needs ALMPC_DIST_BACKEND=gloo)
+    if fold <= 0:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write(f"bench.py: --gpus {n} but only {have} GPU(s) visible on this node; refusing to fold ranks onto fewer "
+                             f"devices (set ALMPC_NUM_DEVICES and ALMPC_DIST_BACKEND=gloo for a plumbing test)\n")
+            return 2
+    elif os.environ.get("ALMPC_DIST_BACKEND", "nccl") == "nccl":
+        sys.stderr.write("bench.py: ALMPC_NUM_DEVICES folds ranks onto shared devices, which RCCL refuses: set ALMPC_DIST_BACKEND=gloo\n")
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,7 +100,14 @@ def main():
     ap.add_argument("--no-closed-loop", action="store_true")
     ap.add_argument("--no-batched-models", action="store_true", help="skip the secondary per-instance-model figure")
     ap.add_argument("--no-sqp", action="store_true", help="skip the secondary SQP (BASELINE configs[4]) figure")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="plumbing check: spawn / rendezvous / barrier / reductions and the JSON line, no solver (value is null); "
+                         "the only mode that runs without a GPU")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))   # nothing in this process has touched the GPU
 
     import almpc_loader
     import importlib
@@ -89,10 +122,27 @@ def main():
     if world > 1 and args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     barrier, max_over_ranks = ranks.barrier, ranks.max_over_ranks
+    # ranks that actually joined the job, counted by an all-reduce over the process group (RCCL on the GPU box)
+    joined = int(round(ranks.sum_over_ranks(1.0)))
+    if joined != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but {joined} rank(s) joined the process group")
 
+    # configs[2]: 32,768 instances over 8 GPUs come from seed 0x5EED0003; every other world size shards the
+    # configs[1] stream (seed 0x5EED0002), 4096 instances per GPU either way
+    seed = 0x5EED0003 if world == 8 else 0x5EED0002
     p = wl.quadrotor(N_HORIZON)
-    first, _ = pkg.sharding.shard_range(world * BATCH_PER_GPU, rank, world)
-    X0 = make_x0(wl, first, BATCH_PER_GPU)
+    first, last = pkg.sharding.shard_range(world * BATCH_PER_GPU, rank, world)
+    assert last - first == BATCH_PER_GPU
+    if args.rendezvous_only:
+        barrier()
+        el = max_over_ranks(1.0 + rank)
+        if rank == 0:
+            print(json.dumps({"metric": "MPC steps/s (batch=4096, nx=12, nu=4, N=30)", "value": None, "n_gpus": world,
+                              "rccl_ranks": joined, "global_batch": world * BATCH_PER_GPU, "seed": hex(seed),
+                              "max_over_ranks_check": el, "backend": ranks.backend, "data": "none (rendezvous only)"}))
+        ranks.close()
+        return
+    X0 = make_x0(wl, first, BATCH_PER_GPU, seed=seed)
     ndev = int(os.environ.get("ALMPC_NUM_DEVICES", "0"))  # test hook: fold ranks onto fewer devices (with ALMPC_DIST_BACKEND=gloo)
     dev_index = (local_rank % ndev) if ndev > 0 else local_rank
     solver = capi.Solver(NX, NU, N_HORIZON, BATCH_PER_GPU, device=dev_index, timing=True)
@@ -129,13 +179,13 @@ def main():
         "value": inst_steps_per_s / BATCH_PER_GPU,
         "unit": "batch-steps/s (one step = 4096 instance QP solves)",
         "instance_steps_per_s": inst_steps_per_s,
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": world, "rccl_ranks": joined, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "configs[1]: hover-linearised quadrotor nx=12 nu=4 N=30, 4096 instances per GPU, shared model, "
                                "x0 amplitude classes 0.3/1.0/3.0 interleaved, cold start every step",
-                   "batch_per_gpu": BATCH_PER_GPU, "global_batch": world * BATCH_PER_GPU,
+                   "batch_per_gpu": BATCH_PER_GPU, "global_batch": world * BATCH_PER_GPU, "seed": hex(seed),
                    "admm_max_iter": int(opts.max_iter), "check_every": int(opts.check_every), "polish": int(opts.polish),
                    "rho": opts.rho, "rho_profile": args.rho_profile, "eps": opts.eps_abs, "parallelism": f"instances sharded over {world} GPU(s), 16-instance tile per workgroup"},
     }
@@ -216,7 +266,7 @@ def main():
         solver2 = capi.Solver(NX, NU, N_HORIZON, BATCH_PER_GPU, device=dev_index)
         solver2.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max, **design_kw)
         solver2.set_reference(p.x_ref, p.u_ref)
-        solver2.update_initialization(make_x0(wl, first + world * BATCH_PER_GPU, BATCH_PER_GPU))
+        solver2.update_initialization(make_x0(wl, first + world * BATCH_PER_GPU, BATCH_PER_GPU, seed=seed))
         pair = (solver, solver2)
         solver.timing_reset(args.steps + args.warmup)
         for i in range(2 * max(5, args.warmup // 5)):
@@ -260,7 +310,7 @@ def main():
         # per-class rates (each class alone on the whole batch), short runs
         cls = {}
         for s_ in AMPLITUDES:
-            solver.update_initialization(make_x0(wl, first, BATCH_PER_GPU, amplitude=s_))
+            solver.update_initialization(make_x0(wl, first, BATCH_PER_GPU, amplitude=s_, seed=seed))
             k = max(20, args.steps // 5)
             solver.timing_reset(3 * k + args.warmup)  # no event creation inside the timed loop
             time_steps(solver, opts, max(5, args.warmup // 5), barrier)

@@ -74,7 +74,7 @@ def test_product_never_imports_oracle():
     (doc comments may cite it)."""
     import re
     pkg = os.path.join(ROOT, "automationlabsmodelpredictivecontrol.jl_amd")
-    bad = re.compile(r"^\s*(from|import)\s+(mpc_oracle|c_oracle)|#\s*include[^\n]*oracle|dlopen|libalmpc_oracle|CDLL\([^)]*oracle", re.M)
+    bad = re.compile(r"^\s*(from|import)\s+(mpc_oracle|c_oracle)|#\s*include[^\n]*oracle|dlopen\([^)]*oracle|libalmpc_oracle|CDLL\([^)]*oracle", re.M)
     for dirpath, _, files in os.walk(pkg):
         for fn in files:
             if fn.endswith((".py", ".h", ".hip", ".cpp")):
@@ -83,3 +83,20 @@ def test_product_never_imports_oracle():
     mk = open(os.path.join(ROOT, "Makefile")).read()
     lib_rule = mk[mk.index("$(LIB):"):mk.index("$(ORACLE):")]
     assert "oracle" not in lib_rule
+
+
+def test_dare_is_host_math_and_rejects_what_has_no_stabilising_solution(capi, mo):
+    """almpc_dare (design-time host code, what ControlSystems.are does at src/sub/design_mpc.jl:327): agrees with scipy on the
+    reference-held QTP model and on the benchmark plant; a model whose unstable mode is uncontrollable has no stabilising
+    solution and must be an error, not a huge 'converged' P (the doubling iteration diverges there)."""
+    import numpy as np
+    import scipy.linalg as sla
+    p = mo.quadrotor()
+    P = capi.dare(p.A, p.B, p.Q, p.R)
+    ref = sla.solve_discrete_are(p.A, p.B, p.Q, p.R)
+    assert np.abs(P - ref).max() <= 1e-9 * np.abs(ref).max()
+    for A, B in ((np.array([[1.2, 0.0], [0.0, 0.5]]), np.array([[0.0], [1.0]])),     # unstable and uncontrollable
+                 (np.array([[1.0]]), np.array([[0.0]]))):                              # marginal and uncontrollable
+        with pytest.raises(capi.AlmpcError) as ei:
+            capi.dare(A, B, np.eye(len(A)), np.eye(1))
+        assert ei.value.code == -6

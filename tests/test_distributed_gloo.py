@@ -63,3 +63,38 @@ def test_two_rank_shards_reassemble_the_batch(mo, co):
     xi = mo.splitmix_normal(0x5EED0003, 0, batch, 2) * np.array([3.0, 1.0])
     full = co.step_batch(p, des, xi, threads=1)["u"][:, 0, 0]
     np.testing.assert_array_equal(np.array(got[0][3] + got[1][3]), full)
+
+
+def _bench(extra, env_extra):
+    import subprocess
+    env = dict(os.environ, **env_extra)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, text=True, timeout=600)
+
+
+@pytest.mark.timeout(900)
+def test_bench_gpus_2_starts_two_ranks_by_itself():
+    """`python bench.py --gpus 2` without a launcher starts two ranks, which rendezvous, all-reduce the rank count and the
+    max-over-ranks time, and rank 0 prints ONE line with n_gpus = 2 (--rendezvous-only: the solver needs a GPU, the plumbing does not)."""
+    import json
+    r = _bench(["--gpus", "2", "--rendezvous-only"], {"ALMPC_DIST_BACKEND": "gloo", "ALMPC_NUM_DEVICES": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["global_batch"] == 8192
+    assert out["max_over_ranks_check"] == 2.0 and out["value"] is None
+
+
+@pytest.mark.timeout(300)
+def test_bench_refuses_more_ranks_than_gpus():
+    """Fewer GPUs than --gpus (none at all in the build container): non-zero exit, a message, no JSON line -- never a silent
+    one-GPU number under an n_gpus it did not run."""
+    import torch
+    have = torch.cuda.device_count()
+    r = _bench(["--gpus", str(have + 2), "--steps", "1", "--warmup", "0"], {"ALMPC_NUM_DEVICES": "0"})
+    assert r.returncode != 0
+    assert "GPU(s) visible" in r.stderr
+    assert not any(ln.startswith("{") for ln in r.stdout.splitlines())

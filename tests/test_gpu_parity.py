@@ -280,6 +280,32 @@ def test_input_rate_weight_with_time_varying_reference(capi, mo):
         assert np.abs(r["u"][i] - mo.solve_mpc_exact(p, X0[i])["u"]).max() <= U_TOL
 
 
+def test_input_rate_weight_is_dropped_together_with_R(capi, mo):
+    """The reference's branch rule (src/sub/design_mpc.jl:423-466): with R[1,1] == 0 the objective has neither the input term nor the
+    input-rate term, whatever S is -- also not the linear term a time-varying u_ref would otherwise add (R = 0, S != 0, u_ref varying).
+    P is given: the DARE needs R > 0."""
+    ur = np.linspace(-0.3, 0.4, 8).reshape(1, 8)
+    P = np.array([[300.0, 40.0], [40.0, 150.0]])
+    A, B = [[0.9, 1.0], [0.0, 0.8]], [[0.5], [1.0]]
+    p = mo.make_problem(A, B, 8, [-1.0], [1.0], x_ref=np.zeros((2, 9)), u_ref=ur, r=0.0, s=2.0, P=P)
+    p_noS = mo.make_problem(A, B, 8, [-1.0], [1.0], x_ref=np.zeros((2, 9)), u_ref=ur, r=0.0, s=0.0, P=P)
+    X0 = np.array([[2.0, 0.5], [-1.0, 0.2], [0.3, -0.1]])
+    s = capi.Solver(2, 1, 8, len(X0))
+    s.design_shared(p.A, p.B, p.Q, p.R, p.S, P, p.u_min, p.u_max)
+    s.set_reference(p.x_ref, p.u_ref)
+    s.update_initialization(X0)
+    s.calculate()
+    r = s.get_results()
+    d = s.get_design()
+    s.close()
+    od = mo.design_shared(p_noS)
+    assert np.abs(d["H"] - od["H"]).max() <= 1e-10 * np.abs(od["H"]).max()
+    assert np.all(r["status"] == 0)
+    for i in range(len(X0)):
+        for q in (p, p_noS):  # the oracle applies the same rule: both statements have the same optimum
+            assert np.abs(r["u"][i] - mo.solve_mpc_exact(q, X0[i])["u"]).max() <= U_TOL
+
+
 def test_warm_start_closed_loop(capi, mo):
     """Receding horizon: 30 closed-loop steps with warm-started ADMM reach the reference and agree with the oracle."""
     p = mo.quadrotor()

@@ -1,0 +1,117 @@
+"""Full-size checks of the headline configurations on one MI355X (pytest -m gpu):
+  * the exact operating point bench.py runs (stiffness rho profile 45, 6 ADMM iterations) on all 4096 instances of configs[1];
+  * one whole per-GPU shard of configs[2] (rank 7 of 8: instances 28,672..32,767 of the 32,768-instance batch, seed 0x5EED0003);
+  * bench.py --gpus N: starts N ranks by itself, reports n_gpus = N, and refuses to run with fewer GPUs than ranks.
+Size-independent properties: KKT certificate of every instance in scaled coordinates, dynamics consistency of the rollout,
+box feasibility; agreement with the exact oracle (1e-6 on u, north_star: 1e-5) on a sample."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+U_TOL = 1e-6
+BENCH_RHO, BENCH_K = 45.0, 6   # bench.py defaults (--rho, --max-iter)
+
+
+def _bench_point_solver(capi, p, batch):
+    s = capi.Solver(p.n, p.m, p.N, batch, device=0)
+    s.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max, rho=BENCH_RHO, rho_profile="stiffness")
+    s.set_reference(p.x_ref, p.u_ref)
+    return s
+
+
+def _certify(mo, p, X0, r, sample):
+    batch = len(X0)
+    assert np.all(r["status"] == 0), np.bincount(r["status"])
+    des = mo.design_shared(p)
+    d = des["d"]
+    W = (r["e_u"].transpose(0, 2, 1).reshape(batch, -1)) / d[None]
+    Fs = X0 @ des["Fs"].T
+    Gd = W @ des["Hs"] + Fs                                    # gradient H'w + f' of every instance
+    kkt = np.abs(W - np.clip(W - Gd, des["lo"][None], des["hi"][None])).max(axis=1)
+    assert kkt.max() <= 1e-8 * max(1.0, np.abs(Fs).max())
+    ex, eu = r["e_x"], r["e_u"]
+    pred = np.einsum("ij,bjk->bik", p.A, ex[:, :, :-1]) + np.einsum("ij,bjk->bik", p.B, eu)
+    assert np.abs(pred - ex[:, :, 1:]).max() <= 1e-9 * max(1.0, np.abs(ex).max())   # ..linear.jl:58-60
+    assert np.all(r["u"] >= p.u_min[None, :, None]) and np.all(r["u"] <= p.u_max[None, :, None])
+    assert np.array_equal(r["x"][:, :, 0], X0)                                       # stage 1 is x0 itself
+    for i in sample:
+        assert np.abs(r["u"][i] - mo.solve_mpc_exact(p, X0[i])["u"]).max() <= U_TOL
+
+
+def test_bench_operating_point_full_batch(capi, mo):
+    """configs[1], the options of the headline run: every one of the 4096 instances is certified optimal."""
+    p = mo.quadrotor()
+    batch = 4096
+    amp = np.array([0.3, 1.0, 3.0])[np.arange(batch) % 3]
+    X0 = mo.splitmix_normal(0x5EED0002, 0, batch, 12) * mo.QUADROTOR_X0_SCALE[None] * amp[:, None]
+    s = _bench_point_solver(capi, p, batch)
+    s.update_initialization(X0)
+    s.calculate(capi.default_opts(rho=BENCH_RHO, max_iter=BENCH_K, check_every=BENCH_K))
+    r = s.get_results()
+    # the closed-loop leg of the bench: warm-started steps from the advanced plant stay certified
+    s.advance_plant()
+    s.calculate(capi.default_opts(rho=BENCH_RHO, max_iter=BENCH_K, check_every=BENCH_K, warm_start=1))
+    r2 = s.get_results(want=("status",))
+    s.close()
+    assert np.all(r["iters"] == BENCH_K)
+    _certify(mo, p, X0, r, range(0, batch, 97))
+    assert np.all(r2["status"] == 0)
+
+
+def test_config2_rank7_shard_full_size(pkg, capi, mo):
+    """configs[2]: rank 7's contiguous 4096-instance shard of the 32,768-instance batch (seed 0x5EED0003), generated from the
+    instance indices alone exactly as bench.py's rank 7 does, solved at the bench operating point."""
+    p = mo.quadrotor()
+    world, per = 8, 4096
+    lo, hi = pkg.sharding.shard_range(world * per, 7, world)
+    assert (lo, hi) == (28672, 32768)
+    amp = np.array([0.3, 1.0, 3.0])[np.arange(lo, hi) % 3]
+    X0 = mo.splitmix_normal(0x5EED0003, lo, per, 12) * mo.QUADROTOR_X0_SCALE[None] * amp[:, None]
+    # the shard is a slice of the global stream, not a fresh stream
+    glob = mo.splitmix_normal(0x5EED0003, lo - 3, 6, 12)
+    assert np.array_equal(glob[3:], mo.splitmix_normal(0x5EED0003, lo, 3, 12))
+    s = _bench_point_solver(capi, p, per)
+    s.update_initialization(X0)
+    s.calculate(capi.default_opts(rho=BENCH_RHO, max_iter=BENCH_K, check_every=BENCH_K))
+    r = s.get_results()
+    s.close()
+    _certify(mo, p, X0, r, range(5, per, 131))
+
+
+def _run_bench(extra, env_extra):
+    env = dict(os.environ, **env_extra)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, text=True, timeout=900)
+
+
+@pytest.mark.timeout(1200)
+def test_bench_gpus_2_spawns_two_ranks(capi):
+    """`python bench.py --gpus 2` with no launcher: two ranks (folded onto the one GPU of this box, gloo for the barrier) each solve
+    their own 4096-instance shard through the HIP library; the line says n_gpus 2 and carries a real throughput."""
+    r = _run_bench(["--gpus", "2", "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-classes", "--no-pipelined",
+                    "--no-closed-loop", "--no-batched-models", "--no-sqp"], {"ALMPC_DIST_BACKEND": "gloo", "ALMPC_NUM_DEVICES": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2
+    assert out["config"]["global_batch"] == 8192 and out["value"] > 0
+    assert out["solver"]["status_counts"][0] == 4096 and out["u_err_inf"] <= 1e-5
+
+
+@pytest.mark.timeout(600)
+def test_bench_refuses_more_ranks_than_gpus():
+    """On a box with fewer GPUs than --gpus the bench fails loudly instead of printing a one-GPU number."""
+    import torch
+    have = torch.cuda.device_count()
+    r = _run_bench(["--gpus", str(have + 1), "--steps", "2", "--warmup", "1"], {})
+    assert r.returncode != 0
+    assert "GPU(s) visible" in r.stderr and not any(ln.startswith("{") for ln in r.stdout.splitlines())
