@@ -112,9 +112,17 @@ def load():
     return L
 
 
+OPT_NO_WARM_STATE = 0x1  # almpc.h: ALMPC_OPT_NO_WARM_STATE (opts.reserved[0])
+
+
 def default_opts(**kw) -> almpc_opts:
+    """almpc_default_opts, then the given fields.  keep_warm_state=False sets ALMPC_OPT_NO_WARM_STATE (the step does not store the
+    ADMM state a later warm start would need)."""
     o = almpc_opts()
     load().almpc_default_opts(ctypes.byref(o))
+    if "keep_warm_state" in kw:
+        if not kw.pop("keep_warm_state"):
+            o.reserved[0] |= OPT_NO_WARM_STATE
     for k, v in kw.items():
         if not hasattr(o, k):
             raise TypeError(f"unknown solver option {k!r}")

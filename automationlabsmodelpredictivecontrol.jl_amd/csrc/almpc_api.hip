@@ -39,6 +39,9 @@ struct almpc_handle {
     double *dD = nullptr, *dUmin = nullptr, *dUmax = nullptr, *dA = nullptr, *dB = nullptr;
     double *dXref = nullptr, *dUref = nullptr, *dFS = nullptr, *dV0S = nullptr, *dRho = nullptr;
     int rho_mode = 0;  // 0 scalar rho (OSQP), 1 stiffness profile rho / G_ii
+    // blocked rollout of the shared model (rollout_blocked): [Gamma_s | Phi_s] rows per lane, built at design time
+    double* dRollM = nullptr;
+    int roll_s = 0, roll_nb = 0;  // roll_s == 0: shape not covered (n > ROLL_NX or m > ROLL_SMX), the stage-by-stage rollout is used
     long xref_stride = 0, uref_stride = 0, fS_stride = 0;
     std::vector<double> hS;  // S weight, symmetrised (for fS with per-instance references)
     int useS = 0;            // the input-rate term is part of the cost: R[1,1] != 0 and S[1,1] != 0 (src/sub/design_mpc.jl:423-466)
@@ -46,6 +49,8 @@ struct almpc_handle {
     double *dX0 = nullptr, *dXs = nullptr, *dZs = nullptr, *dYs = nullptr, *dV0 = nullptr, *dW = nullptr;
     double *dX = nullptr, *dEx = nullptr, *dU = nullptr, *dEu = nullptr;
     int32_t *dStatus = nullptr, *dIters = nullptr, *dPiters = nullptr, *dPerm = nullptr;
+    uint32_t* dYflags = nullptr;  // [batch][nrb] signs of the ADMM multipliers (steps run with ALMPC_OPT_NO_WARM_STATE)
+    bool state_valid = true;      // xs / ys hold the ADMM state of the last step (a warm start may use them)
     int num_cus = 256;            // persistent-grid size of k_polish<true>
     int polish_no_glds = 0;       // diagnostic: force the G-through-L2 build (ALMPC_POLISH_NO_GLDS=1)
     int skip_admm = 0;            // transient (SQP iterations after the first): guess from the iterate, no ADMM phase, no KKT inverse
@@ -135,8 +140,8 @@ hipError_t launch_admm(int nrb, int ks, const AdmmParams& p, int grid, size_t ld
 
 void free_all(almpc_handle* h) {
     void* ptrs[] = {h->dMinvFrag, h->dVFrag, h->dHFrag, h->dFFrag, h->dG, h->dD, h->dUmin, h->dUmax, h->dA, h->dB,
-                    h->dXref, h->dUref, h->dFS, h->dV0S, h->dRho, h->dX0, h->dXs, h->dZs, h->dYs, h->dV0, h->dW, h->dX, h->dEx,
-                    h->dU, h->dEu, h->dStatus, h->dIters, h->dPiters, h->dPerm, h->dSglobal, h->dGhat, h->dGnorm, h->dXmin,
+                    h->dXref, h->dUref, h->dFS, h->dV0S, h->dRho, h->dRollM, h->dX0, h->dXs, h->dZs, h->dYs, h->dV0, h->dW, h->dX, h->dEx,
+                    h->dU, h->dEu, h->dStatus, h->dIters, h->dPiters, h->dPerm, h->dYflags, h->dSglobal, h->dGhat, h->dGnorm, h->dXmin,
                     h->dXmax, h->dRowTraj, h->dRowEq, h->dRowXidx, h->dRowState, h->bA, h->bB, h->bMinv, h->bG, h->bHs, h->bFs,
                     h->bVs, h->bD, h->bRho, h->bH, h->bF, h->bPhi, h->bGk, h->bGam, h->bW, h->bWP, h->bP, h->bFlag, h->bQ, h->dOverflow,
                     h->sqp.W_in, h->sqp.W_h, h->sqp.b_h, h->sqp.W_out, h->sqp.A, h->sqp.B, h->sqp.c, h->sqp.fval, h->sqp.ebar,
@@ -222,6 +227,7 @@ int almpc_create(almpc_handle** out, int n, int m, int N, int batch, int device_
     TRY(dalloc(&h->dPerm, ((b + 15) / 16) * 16));
     TRY(hipMemset(h->dPerm, 0xFF, ((b + 15) / 16) * 16 * sizeof(int32_t)));
     TRY(dalloc(&h->dStatus, b)); TRY(dalloc(&h->dIters, b)); TRY(dalloc(&h->dPiters, b));
+    TRY(dalloc(&h->dYflags, b * h->nrb));
     TRY(hipMemset(h->dXs, 0, b * h->nzs * sizeof(double)));
     TRY(hipMemset(h->dZs, 0, b * h->nzs * sizeof(double)));
     TRY(hipMemset(h->dYs, 0, b * h->nzs * sizeof(double)));
@@ -343,6 +349,30 @@ int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const
     HIP_TRY(h, hipMemcpy(h->dUmax, umax, m * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->dA, A, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->dB, B, (size_t)n * m * sizeof(double), hipMemcpyHostToDevice));
+    {
+        // blocked rollout: s stages per block with one lane per (stage, state row); lane (j, i) holds row i of
+        // [A^j B, ..., A B, B (stages t = 0..j), 0 ... | A^(j+1)]  (design-time host math, n x n products)
+        int sblk = std::min(N, std::min(64 / n, ROLL_SMX / m));
+        h->roll_s = 0;
+        if (sblk >= 1 && n <= ROLL_NX && !getenv("ALMPC_ROLLOUT_STAGEWISE")) {
+            std::vector<double> M((size_t)(ROLL_SMX + ROLL_NX) * 64, 0.0);
+            std::vector<hm::mat> Apow(sblk + 1), ApB(sblk);  // A^j, A^j B
+            Apow[0] = hm::eye(n);
+            for (int j = 1; j <= sblk; ++j) Apow[j] = hm::mul(Am, Apow[j - 1], n, n, n);
+            for (int j = 0; j < sblk; ++j) ApB[j] = hm::mul(Apow[j], Bm, n, n, m);
+            for (int j = 0; j < sblk; ++j)
+                for (int i = 0; i < n; ++i) {
+                    const int lane = j * n + i;
+                    for (int t = 0; t <= j; ++t)
+                        for (int a = 0; a < m; ++a) M[(size_t)(t * m + a) * 64 + lane] = ApB[j - t][(size_t)a * n + i];
+                    for (int c = 0; c < n; ++c) M[(size_t)(ROLL_SMX + c) * 64 + lane] = Apow[j + 1][(size_t)c * n + i];
+                }
+            if (h->dRollM) { (void)hipFree(h->dRollM); h->dRollM = nullptr; }
+            HIP_TRY(h, dalloc(&h->dRollM, M.size()));
+            HIP_TRY(h, hipMemcpy(h->dRollM, M.data(), M.size() * sizeof(double), hipMemcpyHostToDevice));
+            h->roll_s = sblk; h->roll_nb = (N + sblk - 1) / sblk;
+        }
+    }
     h->designed = true;
     h->batched = false;
     h->ltv = false;
@@ -1058,6 +1088,11 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         return fail(h, ALMPC_ERR_INVALID, "calculate: rho/sigma differ from the design values (the shared KKT inverse is built for them)");
     if (o.max_iter < 1 || o.check_every < 1 || !(o.alpha > 0.0 && o.alpha < 2.0) || !(o.eps_abs >= 0.0) || !(o.eps_rel >= 0.0))
         return fail(h, ALMPC_ERR_INVALID, "calculate: bad options");
+    // ALMPC_OPT_NO_WARM_STATE: shared-model steps with the polish on (the polish needs only the signs of y); ignored elsewhere
+    const bool keep_state = !((o.reserved[0] & ALMPC_OPT_NO_WARM_STATE) && !h->batched && o.polish && h->mc == 0);
+    if (o.warm_start && !h->state_valid)
+        return fail(h, ALMPC_ERR_INVALID, "calculate: warm_start = 1, but the previous step ran with ALMPC_OPT_NO_WARM_STATE (no ADMM state was kept)");
+    h->state_valid = keep_state;
     HIP_TRY(h, hipSetDevice(h->device));
     const bool timing = (h->flags & ALMPC_FLAG_TIMING) != 0 && (h->step_count++ % (size_t)h->timing_stride) == 0;
     hipStream_t st = h->stream;
@@ -1113,6 +1148,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
     ap.perm = h->dPerm;
     ap.rho = o.rho; ap.sigma = o.sigma; ap.alpha = o.alpha; ap.eps_abs = o.eps_abs; ap.eps_rel = o.eps_rel;
     ap.max_iter = o.max_iter; ap.check_every = o.check_every; ap.warm = o.warm_start ? 1 : 0;
+    ap.keep_state = keep_state ? 1 : 0; ap.yflags = h->dYflags;
     admm_pending = true;
     }
     auto flush_admm = [&]() -> int {  // the two-kernel path: ADMM on its own
@@ -1176,16 +1212,20 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         pp.G = h->batched ? h->bG : h->dG; pp.dvec = h->batched ? h->bD : h->dD;
         pp.G_stride = h->batched ? (long)h->nz * h->nzs : 0; pp.d_stride = h->batched ? (long)h->nzs : 0;
         pp.A_stride = h->batched ? (long)h->n * h->n : 0; pp.B_stride = h->batched ? (long)h->n * h->m : 0;
-        pp.wave_const_off = -1; pp.sg_off = 0; pp.g_off = 0;
+        pp.wave_const_off = -1; pp.sg_off = 0; pp.g_off = 0; pp.sg_shared_off = -1;
         pp.umin = h->dUmin; pp.umax = h->dUmax; pp.uref = h->dUref; pp.uref_stride = h->uref_stride;
         pp.zs = h->dZs; pp.ys = h->dYs; pp.v0 = h->dV0; pp.w = h->dW; pp.status = h->dStatus; pp.piters = h->dPiters;
+        pp.yflags = keep_state ? nullptr : h->dYflags; pp.yflag_words = h->nrb;
         pp.sglobal = h->dSglobal; pp.perm = h->dPerm; pp.ntiles = (h->batch + 15) / 16;
         pp.max_iter = o.polish_max_iter > 0 ? o.polish_max_iter : 2 * h->nz + 50;
         // rollout fused into the tail of the polish when its trajectory buffer fits the wave's LDS slot
         fused = roll_fits;
-        pp.fuse_rollout = fused ? (h->ltv ? 2 : 1) : 0; pp.roll_g = roll_g; pp.roll_cpl = roll_cpl; pp.roll = rp;
+        const bool blocked = !h->batched && h->roll_s > 0;   // shared model: blocked rollout, no trajectory buffer
+        if (blocked) fused = true;
+        pp.fuse_rollout = fused ? (h->ltv ? 2 : (blocked ? 3 : 1)) : 0; pp.roll_g = roll_g; pp.roll_cpl = roll_cpl; pp.roll = rp;
+        pp.rollM = h->dRollM; pp.roll_s = h->roll_s; pp.roll_nb = h->roll_nb;
         int per_wave = POLISH_LDS_MIN_PER_WAVE;
-        if (fused && (h->N + 1) * (h->n + h->m) > per_wave) per_wave = (h->N + 1) * (h->n + h->m);
+        if (fused && !blocked && (h->N + 1) * (h->n + h->m) > per_wave) per_wave = (h->N + 1) * (h->n + h->m);
         per_wave = (per_wave + 1) & ~1;
         if (h->batched) {  // the wave's private copy of d_i | [A_i B_i] sits behind its buffers
             if (!fused) return fail(h, ALMPC_ERR_UNSUPPORTED, "calculate: per-instance models need the fused rollout (n + m <= 8 * lanes-per-row)");
@@ -1194,9 +1234,18 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         }
         pp.lds_per_wave = per_wave;
         // G in LDS when it fits beside the buffers of 8 waves (gfx950: 160 KB per workgroup)
-        const PolishShared SL = polish_shared_layout(h->n, h->m, h->N, h->nz, h->nzs, fused ? 1 : 0);
+        const PolishShared SL = polish_shared_layout(h->n, h->m, h->N, h->nz, h->nzs, pp.fuse_rollout);
         const size_t g_lds = (size_t)h->nz * ((h->nz + 1) & ~1);  // doubles: rows of G packed to an even stride
-        const size_t l_glds = (g_lds + SL.total + (size_t)POLISH_WAVES_GLDS * per_wave + 2) * sizeof(double);
+        size_t l_glds = (g_lds + SL.total + (size_t)POLISH_WAVES_GLDS * per_wave + 2) * sizeof(double);
+        // workgroup-shared second-tier slot (working sets beyond 32 rows) behind the queue words, if the 160 KB allow it
+        pp.sg_shared_off = -1;
+        {
+            const size_t slot = (size_t)POLISH_SG_SHARED_CAP * 64 * sizeof(double);
+            if (l_glds + slot <= 160 * 1024 && !h->batched && !getenv("ALMPC_POLISH_SG_GLOBAL")) {
+                pp.sg_shared_off = (int)(SL.total + (size_t)POLISH_WAVES_GLDS * per_wave + 2);
+                l_glds += slot;
+            }
+        }
         // one kernel for the whole step when the tile is 8 waves and [G | union(ADMM buffers, polish buffers)] fits LDS
         size_t l_step = l_glds - g_lds * sizeof(double);
         if (admm_lds > l_step) l_step = admm_lds;

@@ -127,6 +127,11 @@ struct AdmmParams {
     int32_t* perm;      // [tiles*16] polish processing order inside each tile: large active-set guess first (see k_polish)
     double rho, sigma, alpha, eps_abs, eps_rel;
     int max_iter, check_every, warm;
+    // keep_state = 0 (opts.reserved[0] & ALMPC_OPT_NO_WARM_STATE): the ADMM state is not kept for a warm start of the next step: x and y
+    // are not written at all; of y the polish needs only the signs, which go out as one 32-bit word per (instance, wave):
+    // yflags[inst * NRB + w], bit b: y < 0 on row 16 w + b, bit 16 + b: y > 0.
+    int keep_state;
+    uint32_t* yflags;
 };
 
 // One workgroup = NRB waves = one tile of 16 instances.  Wave w owns rows 16w..16w+15 of every
@@ -216,11 +221,16 @@ __device__ __forceinline__ void admm_body(const AdmmParams& p, double* smem, Aft
     const double sigma = p.sigma, alpha = p.alpha;
     if (p.warm) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4; ++i) {  // all twelve loads first (one exposed latency), then the arithmetic and the LDS writes
             const size_t o = (size_t)instc * p.nzs + row[i];
             x[i] = p.xs[o];
-            yt[i] = p.ys[o] / rho[i];
-            z[i] = fmin(fmax(p.zs[o], lo[i]), hi[i]);
+            yt[i] = p.ys[o];
+            z[i] = p.zs[o];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            yt[i] = yt[i] / rho[i];
+            z[i] = fmin(fmax(z[i], lo[i]), hi[i]);
             rhs0[row[i] * TILE + col] = x[i];
         }
         __syncthreads();
@@ -390,9 +400,22 @@ __device__ __forceinline__ void admm_body(const AdmmParams& p, double* smem, Aft
     double y[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) y[i] = rho[i] * yt[i];
-    flush(x, p.xs);
+    if (p.keep_state) {
+        flush(x, p.xs);
+        flush(y, p.ys);
+    } else {
+        uint32_t mk = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t b = (uint32_t)(q + 4 * i);
+            mk |= (yt[i] < 0.0 ? 1u : 0u) << b;
+            mk |= (yt[i] > 0.0 ? 1u : 0u) << (16u + b);
+        }
+        mk |= (uint32_t)__shfl_xor((int)mk, 16);
+        mk |= (uint32_t)__shfl_xor((int)mk, 32);
+        if (q == 0 && valid) p.yflags[(size_t)inst * NRB + wv] = mk;
+    }
     flush(z, p.zs);
-    flush(y, p.ys);
     flush(v0r, p.v0);
     ALMPC_STAMP(blockIdx.x * NRB + wv, 4);
 }
@@ -436,6 +459,8 @@ struct PolishParams {
     long uref_stride;
     const double* zs;    // ADMM z, y (scaled)
     const double* ys;
+    const uint32_t* yflags;  // non-null: the signs of y as AdmmParams::yflags (ys is then not read), yflag_words words per instance
+    int yflag_words;
     const double* v0;
     double* w;           // result (scaled), [batch][nzs]
     int32_t* status;     // in: ADMM status; out: final
@@ -449,10 +474,19 @@ struct PolishParams {
     long G_stride, d_stride, A_stride, B_stride;
     int wave_const_off;
     int sg_off;          // k_polish_sgl: offset inside the wave's LDS slot of its 64 x 64 Sinv (working sets beyond 32 rows)
+    int sg_shared_off;   // G-in-LDS builds: offset (doubles, from the shared constants) of ONE workgroup-shared second-tier slot of
+                         // POLISH_SG_SHARED_CAP columns x 64 rows, or < 0: a wave whose working set outgrows 32 rows claims it (LDS
+                         // word beside the queue counter) and otherwise falls back to the global scratch
     int g_off;           // k_polish_sgl: offset of the wave's copy of its instance's G_i (nz rows of nzs doubles)
     int max_iter;
-    int fuse_rollout;    // 1: this kernel also produces u, e_u, x, e_x (roll.*), no separate k_rollout launch; 2: u, e_u only
+    int fuse_rollout;    // 1: this kernel also produces u, e_u, x, e_x (roll.*), no separate k_rollout launch; 2: u, e_u only;
+                         // 3: as 1 with the blocked rollout (shared model: rollM)
     int roll_g, roll_cpl; // rollout lane decomposition: roll_g lanes per state row, roll_cpl columns of [A B] per lane
+    // blocked rollout (fuse_rollout == 3): roll_s stages per block, one lane per (stage in block, state row); rollM
+    // [ROLL_SMX + ROLL_NX][64] holds lane (j, i)'s row of [Gamma_s | Phi_s], zero padded: ROLL_SMX input columns (A^(j-t) B for
+    // t <= j), then ROLL_NX state columns (A^(j+1))
+    const double* rollM;
+    int roll_s, roll_nb;
     RolloutParams roll;
 };
 
@@ -594,6 +628,74 @@ __device__ __forceinline__ void rollout_steps(double* Z, int n, int m, int N, in
     }
 }
 
+// Blocked rollout of one instance by one wave (shared model).  The recursion e+ = A e + B v is a chain of N dependent steps, each an
+// LDS (or cross-lane) round trip; here s = floor(64 / n) stages advance at once: lane (j, i) owns row i of stage k0 + j + 1 and
+//   e_x[k0+j+1] = A^(j+1) e_x[k0] + sum_{t<=j} A^(j-t) B e_u[k0+t],
+// with its row of [Gamma_s | Phi_s] in registers (rollM, built at design time).  The input part does not depend on the chain and is
+// summed while the previous block's values leave; the block's start state reaches every lane through v_readlane (SGPR operands of
+// the FMAs): no LDS on the chain.  Values leave for HBM as they are produced (lane order = memory order of x and e_x), so there is
+// no trajectory buffer.  eub: LDS, e_u of the instance in stage order, ZERO beyond nz (256 doubles).
+constexpr int ROLL_SMX = 24, ROLL_NX = 16;  // blocked rollout: s*m <= ROLL_SMX input columns, n <= ROLL_NX state columns per lane
+// rollM is [ROLL_SMX + ROLL_NX][64], zero beyond the s*m input / n state columns in use and on lanes >= s*n: every loop below is
+// straight-line code of fixed length (no per-column branches, all LDS reads of a block in flight together).  <SMX, NX> are the
+// column counts the instantiation carries in registers (the benchmark shape has its exact fit <20, 12>).
+template <int SMX, int NX>
+__device__ __forceinline__ void roll_load(const double* M, int lane, double (&cu)[SMX], double (&cx)[NX]) {
+#pragma unroll
+    for (int c = 0; c < SMX; ++c) cu[c] = M[c * 64 + lane];
+#pragma unroll
+    for (int c = 0; c < NX; ++c) cx[c] = M[(ROLL_SMX + c) * 64 + lane];
+}
+template <int SMX, int NX>
+__device__ __forceinline__ void roll_run(const double (&cu)[SMX], const double (&cx)[NX], int n, int m, int N, int s, int nb, int lane,
+                                         const double* eub, double e0v, double x0r, const double* xref_lds, const double* xref_glb,
+                                         double* gx, double* gex) {
+    const int nx = n * (N + 1), sm = s * m;
+    if (lane < n) {  // stage 1 of the reference's numbering: x[:,1] = x0, e_x[:,1] = x0 - x_ref[:,1]
+        gex[lane] = e0v;
+        gx[lane] = x0r;
+    }
+    const bool mine = lane < s * n;
+    // input part of a block: independent of the chain, so the next block's is summed while this block's values leave
+    auto upart = [&](int b, double (&acc)[4]) {
+        const double* ub = eub + b * sm;
+        double uv[SMX];
+#pragma unroll
+        for (int c = 0; c < SMX; ++c) uv[c] = ub[c];   // zero padded: reads past the block's inputs meet zero coefficients
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = 0.0;
+#pragma unroll
+        for (int c = 0; c < SMX; ++c) acc[c & 3] = __builtin_fma(cu[c], uv[c], acc[c & 3]);
+    };
+    double acc[4];
+    upart(0, acc);
+    double prev = e0v;  // the block's start state: row i on lane src0 + i
+    int src0 = 0;
+#pragma unroll 1
+    for (int b = 0; b < nb; ++b) {
+        const int t = (b * s + 1) * n + lane;       // flat index of this lane's value in x / e_x
+        const bool ok = mine && t < nx;
+        const int tc = ok ? t : 0;
+        double xr;                                   // reference: LDS copy of a shared one, or global per instance
+        if (xref_lds) xr = xref_lds[tc];
+        else xr = xref_glb[tc];
+#pragma unroll
+        for (int c = 0; c < NX; ++c) {
+            const int sl = src0 + c;
+            acc[c & 3] = __builtin_fma(cx[c], readlane_d(prev, sl < 64 ? sl : 63), acc[c & 3]);  // columns >= n: zero coefficient
+        }
+        const double ev = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        prev = ev;
+        src0 = (s - 1) * n;
+        upart(b + 1, acc);                           // (one block past the end reads the zero padding)
+        if (xref_lds) asm volatile("" : "+v"(xr));   // keeps the two reference paths apart (a select of the addresses = flat loads)
+        if (ok) {
+            gex[t] = ev;
+            gx[t] = ev + xr;
+        }
+    }
+}
+
 // Two builds of the polish.  k_polish<false>: 4 waves per workgroup, one instance per wave, G read through L2.
 // k_polish<true>: ONE persistent workgroup of 8 waves per CU that first copies the shared G = H'^-1 into LDS (115 KB
 // for nz = 120: it fits beside the waves' small buffers in the 160 KB of a gfx950 CU) and then lets each wave pull
@@ -617,11 +719,12 @@ __host__ __device__ inline PolishShared polish_shared_layout(int n, int m, int N
     L.off_umax = L.off_umin + m;
     L.off_uref = L.off_umax + m;
     L.off_ab = L.off_uref + nz;
-    L.off_xref = L.off_ab + (fused ? n * (n + m) : 0);
+    L.off_xref = L.off_ab + ((fused && fused != 3) ? n * (n + m) : 0);   // the blocked rollout (3) has no use for [A B]
     L.total = (L.off_xref + (fused ? (N + 1) * n : 0) + 1) & ~1;
     return L;
 }
 constexpr int POLISH_GLB_PER_INST = 64 * 64;        // doubles of global scratch per instance
+constexpr int POLISH_SG_SHARED_CAP = 48;            // capacity (positions) of the workgroup-shared second-tier slot in LDS
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
@@ -658,7 +761,7 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
         if (uref_sh)
             for (int t = threadIdx.x; t < nz; t += TPB) shc[SL.off_uref + t] = p.uref[t];
         if (p.fuse_rollout) {
-            if (!per_inst) {
+            if (!per_inst && p.fuse_rollout != 3) {
                 for (int t = threadIdx.x; t < n * n; t += TPB) shc[SL.off_ab + t] = p.roll.A[t];
                 for (int t = threadIdx.x; t < n * m; t += TPB) shc[SL.off_ab + n * n + t] = p.roll.B[t];
             }
@@ -689,7 +792,7 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
     }
     if constexpr (GLDS) {
         qcnt = reinterpret_cast<int*>(shc + SL.total + (size_t)POLISH_WAVES_GLDS * p.lds_per_wave);
-        if (threadIdx.x == 0) *qcnt = POLISH_WAVES_GLDS;
+        if (threadIdx.x == 0) { qcnt[0] = POLISH_WAVES_GLDS; qcnt[1] = -1; }  // queue counter | owner of the shared second-tier slot
         Gp = smem;
     }
     __syncthreads();
@@ -739,7 +842,12 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
     double* pbufa = rowbuf + 128;      // [64]  one position-distributed vector, for broadcasts by position
     double* pbufb = pbufa + 64;        // [64]  a second one
     int* wrow_s = reinterpret_cast<int*>(pbufb + 64);  // [64] row index of each position (copy of wrow)
+    // second tier (working sets beyond 32 rows): Sinv in memory, leading dimension 64, capacity cap2.  Its home is the wave's own
+    // LDS (SGL), the workgroup-shared LDS slot if this wave gets it (G-in-LDS builds; chosen when the tier is entered), or the
+    // instance's global scratch.  In the G-in-LDS builds the pointer is a generic one (flat accesses): the tier is rare there.
     double* Sg;
+    int cap2 = 64;
+    bool own_slot = false;
     if constexpr (SGL) Sg = wave_lds + p.sg_off;
     else Sg = GL(p.sglobal) + (size_t)inst * POLISH_GLB_PER_INST;
 
@@ -750,7 +858,15 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
     {
         const d2 dv = *reinterpret_cast<const d2*>(cd + rc);
         const d2 vv = *reinterpret_cast<const d2*>(GL(p.v0) + base + rc);
-        const d2 yy = *reinterpret_cast<const d2*>(GL(p.ys) + base + rc);
+        d2 yy;
+        if (p.yflags) {  // only the signs of y are needed (the guess below): +-1 / 0 from the flag word of this row pair
+            const uint32_t wd = GL(p.yflags)[(size_t)inst * p.yflag_words + (rc >> 4)];
+            const uint32_t b = (uint32_t)(rc & 15);
+            yy[0] = (double)(int)((wd >> (16u + b)) & 1u) - (double)(int)((wd >> b) & 1u);
+            yy[1] = (double)(int)((wd >> (17u + b)) & 1u) - (double)(int)((wd >> (b + 1u)) & 1u);
+        } else {
+            yy = *reinterpret_cast<const d2*>(GL(p.ys) + base + rc);
+        }
         const d2 zz = *reinterpret_cast<const d2*>(GL(p.zs) + base + rc);
         v00 = vv[0]; v01 = vv[1]; y0 = yy[0]; y1 = yy[1]; z0 = zz[0]; z1 = zz[1];
         // bounds exactly as k_admm forms them ((umin - uref) * (1/d)): its z sits ON these values when active
@@ -969,7 +1085,7 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
             // border: new column k and new row k (u is zero beyond k, so the padding stays zero)
             const double bv = (pos == k) ? isc : -u * isc;
             S[k * M::WL + pos] = bv;
-            S[pos * M::WL + k] = bv;
+            if (pos < cap2) S[pos * M::WL + k] = bv;
         }
         if (pos == k) { wrow = j; wsd = sd; wbnd = bval; lam = mu; }
         if (lane == 0) wrow_s[k] = j;
@@ -1039,7 +1155,7 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
                 const double corner = readlane_d(colv, last);
                 const double nv = (pos == rp) ? corner : ((pos == last) ? 0.0 : colv);
                 S[rp * M::WL + pos] = nv;
-                S[pos * M::WL + rp] = nv;
+                if (pos < cap2) S[pos * M::WL + rp] = nv;
                 const int lrow = __builtin_amdgcn_readlane(wrow, last), lsd = __builtin_amdgcn_readlane(wsd, last);
                 const double lbv = readlane_d(wbnd, last), llam = readlane_d(lam, last);
                 if (pos == rp) { wrow = lrow; wsd = lsd; wbnd = lbv; lam = llam; }
@@ -1048,7 +1164,7 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
             {   // position `last` returns to the identity padding
                 const double iv = (pos == last) ? 1.0 : 0.0;
                 S[last * M::WL + pos] = iv;
-                S[pos * M::WL + last] = iv;
+                if (pos < cap2) S[pos * M::WL + last] = iv;
             }
         }
         if (pos == last) lam = 0.0;
@@ -1086,7 +1202,7 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
             }
             const double rmin = wave_min(rr);
             if (rmin < 1.0) {
-                if (k == M::WL) { --it; overflow = true; return; }  // redo this pass in the next mode
+                if (k == (M::glb ? cap2 : M::WL)) { --it; overflow = true; return; }  // redo this pass in the next mode
                 const int owner = __builtin_ctzll(__ballot(rr == rmin));  // smallest lane = smallest row among ties
                 const int jmin = 2 * owner + (__builtin_amdgcn_readlane(second ? 1 : 0, owner));
                 const double tt = fmax(rmin, 0.0);
@@ -1127,15 +1243,43 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
             fresh = false;
         }
     };
-    auto to_global = [&]() {  // carry Sinv (k = 32 positions) over to the global slot: leading dimension 64, identity padded
+    // entering the second tier with `need` positions wanted right away: pick its home
+    auto tier2_home = [&](int need) {
+        if constexpr (GLDS) {
+            if (p.sg_shared_off >= 0 && need <= POLISH_SG_SHARED_CAP) {
+                int got = 0;
+                if (lane == 0) got = (atomicCAS(qcnt + 1, -1, wv) == -1) ? 1 : 0;
+                got = __builtin_amdgcn_readfirstlane(got);
+                if (got) { own_slot = true; cap2 = POLISH_SG_SHARED_CAP; Sg = shc + p.sg_shared_off; }
+            }
+        }
+    };
+    // the shared slot is full (cap2 positions): carry on in the global scratch (capacity 64)
+    auto slot_to_global = [&]() {
+        double* Gs = GL(p.sglobal) + (size_t)inst * POLISH_GLB_PER_INST;
+        for (int c = 0; c < POLISH_SG_SHARED_CAP; c += 8) {
+            double v[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = Sg[(c + t) * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) Gs[(c + t) * 64 + lane] = v[t];
+        }
+        for (int c = POLISH_SG_SHARED_CAP; c < 64; ++c) Gs[c * 64 + lane] = (c == lane) ? 1.0 : 0.0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (lane == 0) atomicExch(qcnt + 1, -1);
+        own_slot = false; cap2 = 64; Sg = Gs;
+    };
+    auto to_global = [&]() {  // carry Sinv (k = 32 positions) over to the second tier: leading dimension 64, identity padded
 #pragma unroll
         for (int t = 0; t < 16; ++t) {  // Sinv is symmetric: lane (hpos, hhf) writes its piece of columns 16 hhf + t
             Sg[(16 * hhf + t) * 64 + hpos] = Sr[t];
             Sg[(16 * hhf + t) * 64 + 32 + hpos] = 0.0;
         }
 #pragma unroll 4
-        for (int c = 32; c < 64; ++c) Sg[c * 64 + lane] = 0.0;
-        if (lane >= 32) Sg[lane * 64 + lane] = 1.0;  // same lane as the zero above: program order
+        for (int c = 32; c < cap2; ++c) Sg[c * 64 + lane] = 0.0;
+        if (lane >= 32 && lane < cap2) Sg[lane * 64 + lane] = 1.0;  // same lane as the zero above: program order
         if (lane >= 32) lam = 0.0;  // lanes 32..63 stop mirroring positions 0..31: they are positions 32..63 now
         sync_s(PolishMode<true>{});
     };
@@ -1246,6 +1390,7 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
         }
         }  // pass
         if (k0 > 32) {
+            tier2_home(k0);
             to_global();
             for (int q = 32; q < k0; ++q)
                 add_row(PolishMode<true>{}, __builtin_amdgcn_readlane(pend_row, q), readlane_d(pend_bnd, q),
@@ -1258,12 +1403,23 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
     if (!give_up) {
         if (!overflow) {
             run(PolishMode<false>{});
-            if (overflow) to_global();
+            if (overflow) { tier2_home(33); to_global(); }
         }
         if (overflow) {
             overflow = false;
             run(PolishMode<true>{});
+            if (overflow && own_slot) {  // outgrew the shared slot: continue in the global scratch
+                slot_to_global();
+                overflow = false;
+                run(PolishMode<true>{});
+            }
             give_up = overflow;  // outgrew 64
+        }
+    }
+    if constexpr (GLDS) {
+        if (own_slot) {  // done with Sinv: hand the shared slot back
+            if (lane == 0) atomicExch(qcnt + 1, -1);
+            own_slot = false;
         }
     }
 
@@ -1302,6 +1458,71 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
             const double* ug = GL(rp.uref) + (size_t)inst * rp.uref_stride;
             ur0 = ug[in0 ? r0 : 0];
             ur1 = ug[in1 ? r1 : 0];
+        }
+        if (p.fuse_rollout == 3) {
+            const bool exact = p.roll_s * m <= 20 && n <= 12;   // the benchmark shape's exact fit
+            double cu[ROLL_SMX], cx[ROLL_NX];
+            // coefficients first: their L2 round trip runs under the u / e_u code below
+            if (exact) {
+                double cu2[20], cx2[12];
+                roll_load<20, 12>(GL(p.rollM), lane, cu2, cx2);
+#pragma unroll
+                for (int c = 0; c < ROLL_SMX; ++c) cu[c] = c < 20 ? cu2[c] : 0.0;
+#pragma unroll
+                for (int c = 0; c < ROLL_NX; ++c) cx[c] = c < 12 ? cx2[c] : 0.0;
+            } else {
+                roll_load<ROLL_SMX, ROLL_NX>(GL(p.rollM), lane, cu, cx);
+            }
+            // blocked rollout: e_u goes to LDS in stage order (= row order), zero padded to whole blocks
+            const int m0 = r0 % m, m1 = (m0 + 1 == m) ? 0 : m0 + 1;
+            double e0 = 0.0, e1 = 0.0;
+            if (in0) {
+                const double uu = fmin(fmax(wout[0] * dvp[0] + ur0, shc[SL.off_umin + m0]), shc[SL.off_umax + m0]);
+                e0 = uu - ur0;
+                GL(rp.u)[(size_t)inst * nz + r0] = uu;
+                GL(rp.eu)[(size_t)inst * nz + r0] = e0;
+            }
+            if (in1) {
+                const double uu = fmin(fmax(wout[1] * dvp[1] + ur1, shc[SL.off_umin + m1]), shc[SL.off_umax + m1]);
+                e1 = uu - ur1;
+                GL(rp.u)[(size_t)inst * nz + r1] = uu;
+                GL(rp.eu)[(size_t)inst * nz + r1] = e1;
+            }
+            double* eub = wave_lds;  // 256 doubles: rowbuf | pbufa | pbufb (the active-set state is dead)
+            {
+                d2 ev; ev[0] = e0; ev[1] = e1;
+                *reinterpret_cast<d2*>(eub + 2 * lane) = ev;
+                d2 zz; zz[0] = 0.0; zz[1] = 0.0;
+                *reinterpret_cast<d2*>(eub + 128 + 2 * lane) = zz;
+            }
+            double e0v = 0.0;
+            const double* xg = nullptr;
+            if (lane < n) {
+                double xr0;
+                if (xref_sh) { xr0 = shc[SL.off_xref + lane]; asm volatile("" : "+v"(xr0)); }
+                else xr0 = GL(rp.xref)[(size_t)inst * rp.xref_stride + lane];
+                e0v = x0r - xr0;
+            }
+            if (!xref_sh) xg = GL(rp.xref) + (size_t)inst * rp.xref_stride;
+            wave_fence_lds();
+            ALMPC_STAMP(inst, 12);
+            const size_t xo3 = (size_t)inst * n * (N + 1);
+            double* gx = GL(rp.x) + xo3;
+            double* gex = GL(rp.ex) + xo3;
+            const double* xl = xref_sh ? (shc + SL.off_xref) : nullptr;
+            if (exact) {
+                double cu2[20], cx2[12];
+#pragma unroll
+                for (int c = 0; c < 20; ++c) cu2[c] = cu[c];
+#pragma unroll
+                for (int c = 0; c < 12; ++c) cx2[c] = cx[c];
+                roll_run<20, 12>(cu2, cx2, n, m, N, p.roll_s, p.roll_nb, lane, eub, e0v, x0r, xl, xg, gx, gex);
+            } else {
+                roll_run<ROLL_SMX, ROLL_NX>(cu, cx, n, m, N, p.roll_s, p.roll_nb, lane, eub, e0v, x0r, xl, xg, gx, gex);
+            }
+            ALMPC_STAMP(inst, 13);
+            ALMPC_STAMP(inst, 14);
+            return;
         }
         const int m0 = r0 % m, m1 = (m0 + 1 == m) ? 0 : m0 + 1, k0s = r0 / m, k1s = (m0 + 1 == m) ? k0s + 1 : k0s;
         if (in0) {

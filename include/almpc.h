@@ -79,8 +79,15 @@ typedef struct almpc_opts {
     int32_t polish;           /* 0 off, 1 on                                                   */
     int32_t polish_max_iter;  /* cap on active-set changes per instance; <=0 -> 2*nz+50        */
     int32_t warm_start;       /* 1: start ADMM from the previous step's (x, z, y) of each instance */
-    int32_t reserved[3];
+    int32_t reserved[3];      /* reserved[0]: flag bits ALMPC_OPT_*; the others must be 0            */
 } almpc_opts;
+
+/* opts.reserved[0] bits */
+/* The ADMM state (x, y) of this step is NOT kept for a warm start of the next one (a cold-start-every-step caller, e.g. a Monte-Carlo
+ * sweep, saves their 2 * nz doubles of HBM writes per instance; the polish gets the signs of y as 4 bytes per 16 rows).  Results
+ * are identical.  The next almpc_calculate on the handle must then not ask for warm_start (ALMPC_ERR_INVALID).  Shared-model
+ * steps with polish = 1 only; ignored otherwise. */
+#define ALMPC_OPT_NO_WARM_STATE 0x1
 
 void almpc_default_opts(almpc_opts* opts);
 

@@ -698,6 +698,34 @@ def test_fused_step_kernel_equals_two_kernel_path(capi, mo):
     assert np.abs(out[True][0]["u"][7] - e["u"]).max() <= U_TOL
 
 
+def test_step_without_warm_state_gives_identical_results(capi, mo):
+    """ALMPC_OPT_NO_WARM_STATE (opts.reserved[0]): the step skips the stores of the ADMM x and y (the polish gets the signs of y as
+    flag words): bit-identical results on both kernel paths, and a warm start right after such a step is refused."""
+    p = mo.quadrotor()
+    X0 = np.concatenate([mo.quadrotor_x0_batch(50, a, first_instance=90 * k) for k, a in enumerate((0.3, 1.0, 3.0, 6.0))])  # partial last tile
+    s = capi.Solver(p.n, p.m, p.N, len(X0))
+    s.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max, rho=45.0, rho_profile="stiffness")
+    s.set_reference(p.x_ref, p.u_ref)
+    s.update_initialization(X0)
+    out = {}
+    for fused in (True, False):
+        s.set_step_fusion(fused)
+        for keep in (True, False):
+            s.calculate(capi.default_opts(rho=45.0, max_iter=6, check_every=6, keep_warm_state=keep))
+            out[fused, keep] = s.get_results()
+    for key in ("status", "iters", "polish_iters", "u", "x", "e_u", "e_x"):
+        for k in out:
+            assert np.array_equal(out[k][key], out[True, True][key]), (k, key)
+    with pytest.raises(capi.AlmpcError) as ei:   # the last step kept no state
+        s.calculate(capi.default_opts(rho=45.0, max_iter=6, check_every=6, warm_start=1))
+    assert ei.value.code == -1
+    s.calculate(capi.default_opts(rho=45.0, max_iter=6, check_every=6))              # a step that keeps it ...
+    s.calculate(capi.default_opts(rho=45.0, max_iter=6, check_every=6, warm_start=1))  # ... makes the warm start legal again
+    assert np.all(s.get_results(want=("status",))["status"] == 0)
+    s.close()
+    assert np.all(out[True, True]["status"] == 0)
+
+
 def test_config3_shards_reassemble_the_batch(pkg, capi, mo):
     """BASELINE configs[2] in miniature: a batch seeded with 0x5EED0003 split into 8 contiguous shards (sharding.shard_range, one
     handle per shard as one process per GPU would hold it) gives, shard by shard, exactly the results of the unsharded batch --
