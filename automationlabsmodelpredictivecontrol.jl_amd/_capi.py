@@ -99,6 +99,11 @@ def load():
     L.almpc_advance_plant.restype = ctypes.c_int
     L.almpc_dare.argtypes = [ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, _dp]
     L.almpc_dare.restype = ctypes.c_int
+    L.almpc_relin_fnn_setup.argtypes = [_hp, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [_dp] * 12 + [ctypes.c_double, ctypes.c_double]
+    L.almpc_relin_fnn_setup.restype = ctypes.c_int
+    L.almpc_relin_fnn_step.argtypes = [_hp, ctypes.POINTER(almpc_opts)]
+    L.almpc_relin_fnn_step_async.argtypes = [_hp, ctypes.POINTER(almpc_opts)]
+    L.almpc_relin_fnn_timing.argtypes = [_hp, _fp, _fp, _fp]
     L.almpc_fnn_linearize.argtypes = [ctypes.c_int] * 6 + [_dp] * 4 + [ctypes.c_int] + [_dp] * 5
     L.almpc_fnn_linearize.restype = ctypes.c_int
     L.almpc_debug_poison_lds.restype = ctypes.c_int
@@ -300,6 +305,38 @@ class Solver:
         self._check(self.L.almpc_sqp_fnn_setup(self.h, H, nl, FNN_ACTIVATIONS[act], _ptr(W_in), _ptr(Wh), _ptr(bh), _ptr(W_out), _ptr(xr),
                                                _ptr(ur), _ptr(Q), _ptr(R), _ptr(S), _ptr(P), p_inst, _ptr(umin), _ptr(umax), float(rho),
                                                float(sigma)))
+
+    def relin_fnn_setup(self, W_in, W_h, b_h, W_out, x_ref, u_ref, Q, R, S=None, P=None, umin=None, umax=None, act="relu", rho=0.1,
+                        sigma=1e-6, rho_profile="scalar"):
+        """Device-resident per-step re-linearisation of an Fnn model (almpc_relin_fnn_*, BASELINE configs[3]): network as in
+        fnn_linearize, shared x_ref (n, N+1) / u_ref (m, N) or None, shared P (n, n)."""
+        n, m, N = self.n, self.m, self.N
+        self._check(self.L.almpc_set_terminal_equality(self.h, 0))
+        self._check(self.L.almpc_set_rho_profile(self.h, {"scalar": 0, "stiffness": 1}[rho_profile]))
+        W_in, W_out = np.asfortranarray(W_in, dtype=np.float64), np.asfortranarray(W_out, dtype=np.float64)
+        H = W_in.shape[0]
+        nl = len(W_h)
+        Wh = np.ascontiguousarray(np.stack([np.asfortranarray(W, dtype=np.float64).T for W in W_h])) if nl else np.zeros((1, 1, 1))
+        bh = np.ascontiguousarray(np.stack([np.asarray(v, dtype=np.float64) for v in b_h])) if nl else np.zeros((1, 1))
+        xr = None if x_ref is None else np.ascontiguousarray(np.asarray(x_ref, dtype=np.float64).reshape(n, N + 1).T)
+        ur = None if u_ref is None else np.ascontiguousarray(np.asarray(u_ref, dtype=np.float64).reshape(m, N).T)
+        Q, R = _colmajor(Q, (n, n)), _colmajor(R, (m, m))
+        S = None if S is None else _colmajor(S, (m, m))
+        P = _colmajor(P, (n, n))
+        umin = np.ascontiguousarray(umin, dtype=np.float64).reshape(m)
+        umax = np.ascontiguousarray(umax, dtype=np.float64).reshape(m)
+        self._check(self.L.almpc_relin_fnn_setup(self.h, H, nl, FNN_ACTIVATIONS[act], _ptr(W_in), _ptr(Wh), _ptr(bh), _ptr(W_out), _ptr(xr),
+                                                 _ptr(ur), _ptr(Q), _ptr(R), _ptr(S), _ptr(P), _ptr(umin), _ptr(umax), float(rho),
+                                                 float(sigma)))
+
+    def relin_fnn_step(self, opts: almpc_opts | None = None, sync=True):
+        fn = self.L.almpc_relin_fnn_step if sync else self.L.almpc_relin_fnn_step_async
+        self._check(fn(self.h, ctypes.byref(opts) if opts is not None else None))
+
+    def relin_fnn_timing(self):
+        a, d, s = ctypes.c_float(), ctypes.c_float(), ctypes.c_float()
+        self._check(self.L.almpc_relin_fnn_timing(self.h, ctypes.byref(a), ctypes.byref(d), ctypes.byref(s)))
+        return dict(jacobian_ms=a.value, design_ms=d.value, step_ms=s.value)
 
     def sqp_fnn_start(self, x0, u_guess=None):
         """x0 (batch, n); u_guess (batch, m, N) or None."""

@@ -234,9 +234,12 @@ def _design_blackbox(system: ConstrainedBlackBoxControlDiscreteSystem, horizon: 
             raise NotImplementedError("mpc_linearization='step' (per-instance models) has no state rows")
         mod = C.tuning.modeler
         sopt = dict(kws.get("mpc_solver_options", {}))
-        mod.relinearize = dict(system=system, device=dev, weights=weights, P=np.array(P), references=references,
-                               rho=float(sopt.get("rho", 0.1)), sigma=float(sopt.get("sigma", 1e-6)),
-                               rho_profile=kws.get("mpc_rho_profile", "scalar"))
+        f = system.f
+        # device-resident pipeline (almpc_relin_fnn_*): Jacobians -> per-instance designs -> step, no host pointers per step
+        mod.solver.relin_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, references.x, references.u, weights.Q, weights.R, weights.S, np.array(P),
+                                   system.U.low, system.U.high, act=f.act, rho=float(sopt.get("rho", 0.1)),
+                                   sigma=float(sopt.get("sigma", 1e-6)), rho_profile=kws.get("mpc_rho_profile", "scalar"))
+        mod.relinearize = dict(system=system, device=dev)
     return C
 
 
@@ -347,15 +350,7 @@ def update_initialization(C: ModelPredictiveControlController, initialization) -
         ug = None if up is None else np.concatenate([up[:, :, 1:], up[:, :, -1:]], axis=2)
         mod.solver.sqp_fnn_start(x0.reshape(mod.batch, n), ug)
         return
-    rl = getattr(mod, "relinearize", None)
-    if rl is not None:  # mpc_linearization='step': Jacobians at (x0_i, u_ref[:,1]) -> one QP design per instance
-        f = rl["system"].f
-        u0 = np.repeat(np.asarray(rl["references"].u, dtype=np.float64)[:, 0][None, :], mod.batch, 0)
-        A, B = _capi.fnn_linearize(f.W_in, f.W_h, f.b_h, f.W_out, x0.reshape(mod.batch, n), u0, act=f.act, device=rl["device"])
-        w = rl["weights"]
-        mod.solver.design_batched(A, B, w.Q, w.R, w.S, rl["P"], rl["system"].U.low, rl["system"].U.high,
-                                  rho=rl["rho"], sigma=rl["sigma"], rho_profile=rl["rho_profile"])
-        mod.solver.set_reference(rl["references"].x, rl["references"].u)
+    # mpc_linearization='step': the Jacobians at (x0_i, u_ref[:,1]) and the per-instance designs are part of calculate! (on the device)
     mod.solver.update_initialization(x0.reshape(mod.batch, n))
 
 
@@ -366,6 +361,8 @@ def calculate(C: ModelPredictiveControlController) -> None:
     mod: HipModeler = C.tuning.modeler
     if getattr(mod, "sqp", None) is not None:
         mod.last_sqp_history = mod.solver.sqp_fnn_iterate(mod.sqp["iterations"], mod.sqp["step"], mod.opts, step_rule=mod.sqp["step_rule"])
+    elif getattr(mod, "relinearize", None) is not None:
+        mod.solver.relin_fnn_step(mod.opts)
     else:
         mod.solver.calculate(mod.opts)
     r = mod.solver.get_results()

@@ -89,6 +89,17 @@ struct almpc_handle {
         unsigned long long* stats = nullptr;  // [iters][2]
         int stats_cap = 0;
     } sqp;
+    // per-step re-linearisation of a black-box Fnn model on the device (almpc_relin_fnn_*, BASELINE configs[3])
+    struct Relin {
+        bool ready = false;
+        int H = 0, L = 0, act = 0, useR = 0, useS = 0;
+        double *W_in = nullptr, *W_h = nullptr, *b_h = nullptr, *W_out = nullptr;
+        double *ulin = nullptr;   // [batch][m] linearisation input of every instance (the first input reference)
+        double *Q = nullptr, *R = nullptr, *S = nullptr;
+        double *gS = nullptr;     // [nz] unscaled input-rate gradient 2 D'Sbar D u_ref of the shared reference
+        float ms_jac = 0, ms_design = 0, ms_step = 0;  // last timed step (almpc_relin_fnn_step with timing)
+        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    } relin;
     // timing (ALMPC_FLAG_TIMING): one set of 4 events per step since the last almpc_timing_reset
     std::vector<hipEvent_t> ev;  // 4 per step
     size_t ev_used = 0;          // steps recorded
@@ -148,6 +159,11 @@ void free_all(almpc_handle* h) {
                     h->sqp.qadd, h->sqp.xref, h->sqp.uref, h->sqp.Q, h->sqp.R, h->sqp.S, h->sqp.bad, h->sqp.stats, h->sqp.mer, h->sqp.xback, h->sqp.uback, h->sqp.dxback, h->sqp.vback};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    for (void* p : {(void*)h->relin.W_in, (void*)h->relin.W_h, (void*)h->relin.b_h, (void*)h->relin.W_out, (void*)h->relin.ulin,
+                    (void*)h->relin.Q, (void*)h->relin.R, (void*)h->relin.S, (void*)h->relin.gS})
+        if (p) (void)hipFree(p);
+    for (auto& e : h->relin.ev)
+        if (e) (void)hipEventDestroy(e);
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
     h->ev.clear();
@@ -276,6 +292,7 @@ int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const
     // from here on the handle's previous design is being overwritten: it counts as designed again only after the last step below
     h->designed = false;
     h->sqp.ready = h->sqp.started = false;
+    h->relin.ready = false;
     HIP_TRY(h, hipSetDevice(h->device));
     const int n = h->n, m = h->m, N = h->N, nz = h->nz;
     for (int i = 0; i < m; ++i)
@@ -519,6 +536,46 @@ hipError_t launch_design_ltv(almpc_handle* h, const DesignLtvParams& lp, hipStre
     return hipGetLastError();
 }
 
+// The per-instance design from DEVICE-resident operands (bA, bB, bP; weights dQ, dR, dS): prediction matrices, H_i and F_i,
+// scaling, both inverses, V_i.  Launches only (handle's stream); the caller checks bFlag.
+hipError_t launch_batched_design(almpc_handle* h, const DesignStrides& ds, int useR, int useS, const double* dQ, const double* dR,
+                                 const double* dS, double rho, double sigma) {
+    const int n = h->n, m = h->m, N = h->N, nz = h->nz, nzs = h->nzs, nrb = h->nrb;
+    const int njf = (n + 15) / 16, ps = 16 * njf, gs = nzs;
+    const int kr = ((n * N + HESS_KC - 1) / HESS_KC) * HESS_KC;
+    const unsigned gb = (unsigned)h->batch;
+    hipStream_t st = h->stream;
+    const size_t inst_lds = design_instance_lds_doubles(n, m, N) * sizeof(double);
+    hipError_t e = hipMemsetAsync(h->bFlag, 0, (size_t)h->batch * sizeof(int), st);
+    if (e != hipSuccess) return e;
+    if (inst_lds <= 160 * 1024) {  // structured route: H_i, F_i from the Toeplitz blocks in LDS, no Gamma panels in HBM
+        DesignInstParams dp;
+        dp.n = n; dp.m = m; dp.N = N; dp.nz = nz; dp.useR = useR; dp.useS = useS;
+        dp.A = h->bA; dp.B = h->bB; dp.P = h->bP; dp.sA = ds.A; dp.sB = ds.B; dp.sP = ds.P;
+        dp.Q = dQ; dp.R = dR; dp.S = dS; dp.H = h->bH; dp.F = h->bF; dp.sH = ds.H; dp.sF = ds.F;
+        e = ensure_dyn_lds(reinterpret_cast<const void*>(k_design_instance), inst_lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_design_instance, dim3(gb), dim3(256), inst_lds, st, dp);
+    } else {
+        hipLaunchKernelGGL(k_design_blocks, dim3(1, gb), dim3(256), (size_t)(3 * n * n + n * m) * sizeof(double), st, n, m, N,
+                           h->bA, h->bB, h->bPhi, h->bGk, ds);
+        hipLaunchKernelGGL(k_design_gamma, dim3(N, gb), dim3(256), 0, st, n, m, N, dQ, h->bP, h->bPhi, h->bGk, h->bGam, h->bW, h->bWP, gs, ps, ds);
+        HessParams hp;
+        hp.n = n; hp.m = m; hp.N = N; hp.nz = nz; hp.nrb = nrb; hp.njf = njf; hp.kr = kr;
+        hp.Gam = h->bGam; hp.W = h->bW; hp.WP = h->bWP; hp.gs = gs; hp.ps = ps; hp.R = dR; hp.S = dS; hp.useR = useR; hp.useS = useS;
+        hp.H = h->bH; hp.F = h->bF; hp.st = ds;
+        const size_t hess_lds = (size_t)HESS_KC * (16 + (gs + 16) + (ps + 16)) * sizeof(double);
+        hipLaunchKernelGGL(k_design_hessian, dim3(nrb, gb), dim3(64 * (nrb + njf)), hess_lds, st, hp);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = ensure_dyn_lds(reinterpret_cast<const void*>(k_design_inverse), 520 * sizeof(double));
+    if (e != hipSuccess) return e;
+    launch_batched_factor(h, ds, rho, sigma, st);
+    hipLaunchKernelGGL(k_neg_gm, dim3(4, gb), dim3(256), 0, st, nz, nzs, n, nzs, h->bG, h->bFs, h->bVs, ds.G, ds.Fs);
+    return hipGetLastError();
+}
+
 int design_batched_common(almpc_handle* h, const double* A_batch, const double* B_batch, const double* Q, const double* R,
                           const double* S, const double* P, int P_per_instance, const double* umin, const double* umax,
                           double rho, double sigma, const LtvInputs* ltv) {
@@ -528,8 +585,9 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
     if (h->terminal_eq) return fail(h, ALMPC_ERR_UNSUPPORTED, "design_batched: state rows (terminal equality) need a shared model");
     h->designed = false;  // the previous design is overwritten below; set again by the last statement on success
     h->sqp.ready = h->sqp.started = false;
+    h->relin.ready = false;
     HIP_TRY(h, hipSetDevice(h->device));
-    const int n = h->n, m = h->m, N = h->N, nz = h->nz, nzs = h->nzs, nrb = h->nrb;
+    const int n = h->n, m = h->m, N = h->N, nz = h->nz, nzs = h->nzs;
     const size_t b = (size_t)h->batch;
     for (int i = 0; i < m; ++i)
         if (!(umin[i] <= umax[i])) return fail(h, ALMPC_ERR_INVALID, "design_batched: umin > umax");
@@ -566,8 +624,6 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
     h->has_box = 0; h->mc = 0; h->R = nz; h->np_pairs = 1; h->Rs = 128;
     const int useR = Rm[0] != 0.0, useS = useR && Sm[0] != 0.0;
     h->useS = useS;
-    const int njf = (n + 15) / 16, ps = 16 * njf, gs = nzs;
-    const int kr = ((n * N + HESS_KC - 1) / HESS_KC) * HESS_KC;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     { const int rc_ = ensure_batched_alloc(h); if (rc_ != ALMPC_OK) return rc_; }
     hipStream_t st = h->stream;
@@ -588,7 +644,6 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
     BTRY(hipMemsetAsync(h->bFlag, 0, b * sizeof(int), st));
     const DesignStrides ds = batched_strides(h, p_inst);
     const unsigned gb = (unsigned)b;
-    const size_t inst_lds = design_instance_lds_doubles(n, m, N) * sizeof(double);
     double *dAll = nullptr, *dBll = nullptr, *dC = nullptr, *dE = nullptr, *dQa = nullptr;  // LTV staging (freed below)
     if (ltv) {
         auto upl = [&](double** d, const double* src, size_t cnt) -> hipError_t {
@@ -613,30 +668,13 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
         if (e == hipSuccess) e = hipStreamSynchronize(st);  // the staging buffers are released right away
         (void)hipFree(dAll); (void)hipFree(dBll); (void)hipFree(dC); (void)hipFree(dE); (void)hipFree(dQa);
         if (e != hipSuccess) { release(); return fail(h, ALMPC_ERR_HIP, std::string("design_ltv: ") + hipGetErrorString(e)); }
-    } else if (inst_lds <= 160 * 1024) {  // structured route: H_i, F_i from the Toeplitz blocks in LDS, no Gamma panels in HBM
-        DesignInstParams dp;
-        dp.n = n; dp.m = m; dp.N = N; dp.nz = nz; dp.useR = useR; dp.useS = useS;
-        dp.A = h->bA; dp.B = h->bB; dp.P = h->bP; dp.sA = ds.A; dp.sB = ds.B; dp.sP = ds.P;
-        dp.Q = dQ; dp.R = dR; dp.S = dS; dp.H = h->bH; dp.F = h->bF; dp.sH = ds.H; dp.sF = ds.F;
-        if (inst_lds > 64 * 1024)
-            BTRY(ensure_dyn_lds(reinterpret_cast<const void*>(k_design_instance), (size_t)(inst_lds)));
-        hipLaunchKernelGGL(k_design_instance, dim3(gb), dim3(256), inst_lds, st, dp);
+        BTRY(ensure_dyn_lds(reinterpret_cast<const void*>(k_design_inverse), 520 * sizeof(double)));
+        launch_batched_factor(h, ds, rho, sigma, st);
+        hipLaunchKernelGGL(k_neg_gm, dim3(4, gb), dim3(256), 0, st, nz, nzs, n, nzs, h->bG, h->bFs, h->bVs, ds.G, ds.Fs);
+        BTRY(hipGetLastError());
     } else {
-    hipLaunchKernelGGL(k_design_blocks, dim3(1, gb), dim3(256), (size_t)(3 * n * n + n * m) * sizeof(double), st, n, m, N,
-                       h->bA, h->bB, h->bPhi, h->bGk, ds);
-    hipLaunchKernelGGL(k_design_gamma, dim3(N, gb), dim3(256), 0, st, n, m, N, dQ, h->bP, h->bPhi, h->bGk, h->bGam, h->bW, h->bWP, gs, ps, ds);
-    HessParams hp;
-    hp.n = n; hp.m = m; hp.N = N; hp.nz = nz; hp.nrb = nrb; hp.njf = njf; hp.kr = kr;
-    hp.Gam = h->bGam; hp.W = h->bW; hp.WP = h->bWP; hp.gs = gs; hp.ps = ps; hp.R = dR; hp.S = dS; hp.useR = useR; hp.useS = useS;
-    hp.H = h->bH; hp.F = h->bF; hp.st = ds;
-    const size_t hess_lds = (size_t)HESS_KC * (16 + (gs + 16) + (ps + 16)) * sizeof(double);
-    hipLaunchKernelGGL(k_design_hessian, dim3(nrb, gb), dim3(64 * (nrb + njf)), hess_lds, st, hp);
+        BTRY(launch_batched_design(h, ds, useR, useS, dQ, dR, dS, rho, sigma));
     }
-    BTRY(hipGetLastError());
-    BTRY(ensure_dyn_lds(reinterpret_cast<const void*>(k_design_inverse), (size_t)((520 * sizeof(double)))));
-    launch_batched_factor(h, ds, rho, sigma, st);
-    hipLaunchKernelGGL(k_neg_gm, dim3(4, gb), dim3(256), 0, st, nz, nzs, n, nzs, h->bG, h->bFs, h->bVs, ds.G, ds.Fs);
-    BTRY(hipGetLastError());
     std::vector<int> flags(b, 0);
     BTRY(hipMemcpyAsync(flags.data(), h->bFlag, b * sizeof(int), hipMemcpyDeviceToHost, st));
     // host copies of instance 0 for almpc_get_design (every instance: almpc_get_design_instance)
@@ -743,6 +781,148 @@ int almpc_get_gradient_instance(almpc_handle* h, int instance, double* q) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// Per-step re-linearisation of a black-box Fnn model, resident on the device (BASELINE configs[3]; include/almpc.h).
+int almpc_relin_fnn_setup(almpc_handle* h, int H, int L, int activation, const double* W_in, const double* W_h, const double* b_h,
+                          const double* W_out, const double* xref, const double* uref, const double* Q, const double* R,
+                          const double* S, const double* P, const double* umin, const double* umax, double rho, double sigma) {
+    if (!h) return ALMPC_ERR_INVALID;
+    if (H < 1 || L < 0 || !W_in || !W_out || (L > 0 && (!W_h || !b_h)) || !Q || !R || !P || !umin || !umax)
+        return fail(h, ALMPC_ERR_INVALID, "relin_fnn_setup: null pointer or bad network shape (P must be given: the terminal weight "
+                                          "comes from the linearisation at the last reference, src/sub/design_mpc.jl:312-327)");
+    if (activation < 0 || activation > 4) return fail(h, ALMPC_ERR_UNSUPPORTED, "relin_fnn_setup: activation must be 0..4");
+    if (!(rho > 0.0) || !(sigma >= 0.0)) return fail(h, ALMPC_ERR_INVALID, "relin_fnn_setup: rho must be > 0 and sigma >= 0");
+    if (h->terminal_eq) return fail(h, ALMPC_ERR_UNSUPPORTED, "relin_fnn_setup: state rows (terminal equality) need a shared model");
+    const int n = h->n, m = h->m, N = h->N, nz = h->nz;
+    const size_t b = (size_t)h->batch, nin = (size_t)n + m;
+    if ((2 * (size_t)H + 2 * (size_t)H * nin + nin) * sizeof(double) > 160 * 1024)
+        return fail(h, ALMPC_ERR_UNSUPPORTED, "relin_fnn_setup: the network's forward-mode Jacobian must fit the 160 KB of LDS");
+    for (int i = 0; i < m; ++i)
+        if (!(umin[i] <= umax[i])) return fail(h, ALMPC_ERR_INVALID, "relin_fnn_setup: umin > umax");
+    h->designed = false;
+    h->sqp.ready = h->sqp.started = false;
+    h->relin.ready = false;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    auto sym = [](const double* M, int k) {
+        hm::mat o((size_t)k * k, 0.0);
+        if (M)
+            for (int j = 0; j < k; ++j)
+                for (int i = 0; i < k; ++i) o[(size_t)j * k + i] = 0.5 * (M[(size_t)j * k + i] + M[(size_t)i * k + j]);
+        return o;
+    };
+    const hm::mat Qm = sym(Q, n), Rm = sym(R, m), Sm = sym(S, m), Pm = sym(P, n);
+    { const int rc_ = ensure_batched_alloc(h); if (rc_ != ALMPC_OK) return rc_; }
+    almpc_handle::Relin& q = h->relin;
+    for (void* p_ : {(void*)q.W_in, (void*)q.W_h, (void*)q.b_h, (void*)q.W_out, (void*)q.ulin, (void*)q.Q, (void*)q.R, (void*)q.S, (void*)q.gS})
+        if (p_) (void)hipFree(p_);
+    q.W_in = q.W_h = q.b_h = q.W_out = q.ulin = q.Q = q.R = q.S = q.gS = nullptr;
+    auto up = [&](double** d, const double* src, size_t cnt) -> hipError_t {
+        hipError_t e = dalloc(d, cnt ? cnt : 1);
+        if (e == hipSuccess && src && cnt) e = hipMemcpy(*d, src, cnt * sizeof(double), hipMemcpyHostToDevice);
+        return e;
+    };
+    std::vector<double> xr((size_t)n * (N + 1), 0.0), ur((size_t)nz, 0.0);
+    if (xref) xr.assign(xref, xref + xr.size());
+    if (uref) ur.assign(uref, uref + ur.size());
+    q.useR = Rm[0] != 0.0; q.useS = q.useR && Sm[0] != 0.0;
+    // unscaled input-rate gradient of the shared reference: 2 D'Sbar D u_ref (the rate cost is on u itself, src/sub/design_mpc.jl:423-446)
+    std::vector<double> gS((size_t)nz, 0.0);
+    if (q.useS)
+        for (int i = 0; i + 1 < N; ++i)
+            for (int a = 0; a < m; ++a) {
+                double sd = 0.0;
+                for (int c2 = 0; c2 < m; ++c2) sd += Sm[(size_t)c2 * m + a] * (ur[i * m + c2] - ur[(i + 1) * m + c2]);
+                gS[i * m + a] += 2.0 * sd;
+                gS[(i + 1) * m + a] -= 2.0 * sd;
+            }
+    std::vector<double> ul(b * m);
+    for (size_t i = 0; i < b; ++i)
+        for (int a = 0; a < m; ++a) ul[i * m + a] = ur[a];  // every instance linearises at the first input reference
+    HIP_TRY(h, up(&q.W_in, W_in, (size_t)H * nin)); HIP_TRY(h, up(&q.W_h, W_h, (size_t)L * H * H)); HIP_TRY(h, up(&q.b_h, b_h, (size_t)L * H));
+    HIP_TRY(h, up(&q.W_out, W_out, (size_t)n * H)); HIP_TRY(h, up(&q.ulin, ul.data(), ul.size()));
+    HIP_TRY(h, up(&q.Q, Qm.data(), Qm.size())); HIP_TRY(h, up(&q.R, Rm.data(), Rm.size())); HIP_TRY(h, up(&q.S, Sm.data(), Sm.size()));
+    HIP_TRY(h, up(&q.gS, gS.data(), gS.size()));
+    HIP_TRY(h, hipMemcpy(h->bP, Pm.data(), Pm.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->dUmin, umin, m * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->dUmax, umax, m * sizeof(double), hipMemcpyHostToDevice));
+    // shared references; the scaled input-rate gradient fS_i = d_i .* gS and v0S_i = -G_i fS_i are per instance (re-made every step)
+    for (double** pp_ : {&h->dXref, &h->dUref, &h->dFS, &h->dV0S})
+        if (*pp_) { (void)hipFree(*pp_); *pp_ = nullptr; }
+    HIP_TRY(h, up(&h->dXref, xr.data(), xr.size())); HIP_TRY(h, up(&h->dUref, ur.data(), ur.size()));
+    HIP_TRY(h, dalloc(&h->dFS, b * nz)); HIP_TRY(h, dalloc(&h->dV0S, b * nz));
+    HIP_TRY(h, hipMemset(h->dFS, 0, b * nz * sizeof(double))); HIP_TRY(h, hipMemset(h->dV0S, 0, b * nz * sizeof(double)));
+    h->xref_stride = 0; h->uref_stride = 0; h->fS_stride = nz;
+    for (auto& e : q.ev)
+        if (!e) HIP_TRY(h, hipEventCreate(&e));
+    q.H = H; q.L = L; q.act = activation;
+    h->P = Pm; h->hS = Sm; h->useS = q.useS;
+    h->rho = rho; h->sigma = sigma;
+    h->has_box = 0; h->mc = 0; h->R = nz; h->np_pairs = 1; h->Rs = 128;
+    h->batched = true; h->ltv = false;
+    h->state_valid = true;
+    q.ready = true;
+    return ALMPC_OK;
+}
+
+int almpc_relin_fnn_step_async(almpc_handle* h, const almpc_opts* opts) {
+    if (!h) return ALMPC_ERR_INVALID;
+    almpc_handle::Relin& q = h->relin;
+    if (!q.ready) return fail(h, ALMPC_ERR_NOT_DESIGNED, "relin_fnn_step before relin_fnn_setup");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int n = h->n, m = h->m, nz = h->nz, nzs = h->nzs;
+    hipStream_t st = h->stream;
+    const bool timing = (h->flags & ALMPC_FLAG_TIMING) != 0;
+    if (timing) HIP_TRY(h, hipEventRecord(q.ev[0], st));
+    // 1. Jacobians at (x0_i, u_ref[:,1]) straight into the handle's per-instance model slots
+    FnnParams fp;
+    fp.n = n; fp.m = m; fp.H = q.H; fp.L = q.L; fp.act = q.act; fp.batch = h->batch;
+    fp.W_in = q.W_in; fp.W_h = q.W_h; fp.b_h = q.b_h; fp.W_out = q.W_out;
+    fp.x = h->dX0; fp.u = q.ulin; fp.ppi = 1; fp.xs_group = n; fp.us_group = m;
+    fp.A = h->bA; fp.B = h->bB; fp.f = nullptr;
+    HIP_TRY(h, launch_fnn_jacobian(fp, h->num_cus, st));
+    if (timing) HIP_TRY(h, hipEventRecord(q.ev[1], st));
+    // 2. the reference's QP for every (A_i, B_i): H_i, F_i, scaling, inverses, V_i; reference-dependent vectors
+    const DesignStrides ds = batched_strides(h, false);
+    HIP_TRY(h, launch_batched_design(h, ds, q.useR, q.useS, q.Q, q.R, q.S, h->rho, h->sigma));
+    if (q.useS) {
+        hipLaunchKernelGGL(k_fs_scale, dim3(256), dim3(256), 0, st, h->batch, nz, nzs, q.gS, 0L, h->bD, h->dFS);
+        hipLaunchKernelGGL(k_neg_gm, dim3(1, (unsigned)h->batch), dim3(256), 0, st, nz, nzs, 1, nz, h->bG, h->dFS, h->dV0S,
+                           (long)nz * nzs, (long)nz);
+        HIP_TRY(h, hipGetLastError());
+    }
+    if (timing) HIP_TRY(h, hipEventRecord(q.ev[2], st));
+    // 3. the step itself
+    h->designed = true;
+    const int rc = almpc_calculate_async(h, opts);
+    if (rc != ALMPC_OK) return rc;
+    hipLaunchKernelGGL(k_flag_to_status, dim3((h->batch + 255) / 256), dim3(256), 0, st, h->batch, h->bFlag, h->dStatus);
+    HIP_TRY(h, hipGetLastError());
+    if (timing) HIP_TRY(h, hipEventRecord(q.ev[3], st));
+    return ALMPC_OK;
+}
+
+int almpc_relin_fnn_step(almpc_handle* h, const almpc_opts* opts) {
+    const int rc = almpc_relin_fnn_step_async(h, opts);
+    if (rc != ALMPC_OK) return rc;
+    return almpc_synchronize(h);
+}
+
+int almpc_relin_fnn_timing(almpc_handle* h, float* ms_jacobian, float* ms_design, float* ms_step) {
+    if (!h) return ALMPC_ERR_INVALID;
+    if (!(h->flags & ALMPC_FLAG_TIMING) || !h->relin.ready) return fail(h, ALMPC_ERR_INVALID, "relin_fnn_timing: needs ALMPC_FLAG_TIMING and a step");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipEventSynchronize(h->relin.ev[3]));
+    float a = 0, d = 0, s2 = 0;
+    HIP_TRY(h, hipEventElapsedTime(&a, h->relin.ev[0], h->relin.ev[1]));
+    HIP_TRY(h, hipEventElapsedTime(&d, h->relin.ev[1], h->relin.ev[2]));
+    HIP_TRY(h, hipEventElapsedTime(&s2, h->relin.ev[2], h->relin.ev[3]));
+    if (ms_jacobian) *ms_jacobian = a;
+    if (ms_design) *ms_design = d;
+    if (ms_step) *ms_step = s2;
+    return ALMPC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // SQP outer loop for a black-box Fnn model, resident on the device (see almpc_sqp.hip.h and include/almpc.h).
 int almpc_sqp_fnn_setup(almpc_handle* h, int H, int L, int activation, const double* W_in, const double* W_h, const double* b_h,
                         const double* W_out, const double* xref, const double* uref, const double* Q, const double* R,
@@ -766,6 +946,7 @@ int almpc_sqp_fnn_setup(almpc_handle* h, int H, int L, int activation, const dou
         if (!(umin[i] <= umax[i])) return fail(h, ALMPC_ERR_INVALID, "sqp_fnn_setup: umin > umax");
     h->designed = false;  // any earlier design of the handle is replaced (its reference buffers are released below)
     h->sqp.ready = h->sqp.started = false;
+    h->relin.ready = false;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     auto sym = [](const double* M, int k) {
@@ -1000,6 +1181,7 @@ int almpc_set_reference(almpc_handle* h, const double* xref, const double* uref,
     const size_t xs = (size_t)n * (N + 1), us = (size_t)nz;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->sqp.ready = h->sqp.started = false;  // the SQP iterate lived in the reference buffers released here
+    h->relin.ready = false;                 // ... and so did the re-linearisation pipeline's references
     h->designed = false;                    // the reference buffers are replaced below: designed again on success only
     if (h->dXref) { (void)hipFree(h->dXref); h->dXref = nullptr; }
     if (h->dUref) { (void)hipFree(h->dUref); h->dUref = nullptr; }

