@@ -104,6 +104,10 @@ def load():
     L.almpc_relin_fnn_step.argtypes = [_hp, ctypes.POINTER(almpc_opts)]
     L.almpc_relin_fnn_step_async.argtypes = [_hp, ctypes.POINTER(almpc_opts)]
     L.almpc_relin_fnn_timing.argtypes = [_hp, _fp, _fp, _fp]
+    L.almpc_comm_unique_id.argtypes = [ctypes.c_char_p]
+    L.almpc_comm_init.argtypes = [_hp, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+    L.almpc_comm_summary.argtypes = [_hp, ctypes.POINTER(ctypes.c_int64)]
+    L.almpc_comm_allgather_first_input.argtypes = [_hp, _dp, ctypes.POINTER(_dp)]
     L.almpc_fnn_linearize.argtypes = [ctypes.c_int] * 6 + [_dp] * 4 + [ctypes.c_int] + [_dp] * 5
     L.almpc_fnn_linearize.restype = ctypes.c_int
     L.almpc_debug_poison_lds.restype = ctypes.c_int
@@ -118,6 +122,15 @@ def load():
 
 
 OPT_NO_WARM_STATE = 0x1  # almpc.h: ALMPC_OPT_NO_WARM_STATE (opts.reserved[0])
+
+
+def comm_unique_id() -> bytes:
+    """128-byte RCCL id made by rank 0 (almpc_comm_unique_id); hand it to the other ranks by any channel."""
+    buf = ctypes.create_string_buffer(128)
+    rc = load().almpc_comm_unique_id(buf)
+    if rc != ALMPC_OK:
+        raise AlmpcError(rc, "almpc_comm_unique_id (librccl not loadable?)")
+    return buf.raw
 
 
 def default_opts(**kw) -> almpc_opts:
@@ -337,6 +350,24 @@ class Solver:
         a, d, s = ctypes.c_float(), ctypes.c_float(), ctypes.c_float()
         self._check(self.L.almpc_relin_fnn_timing(self.h, ctypes.byref(a), ctypes.byref(d), ctypes.byref(s)))
         return dict(jacobian_ms=a.value, design_ms=d.value, step_ms=s.value)
+
+    # ---- multi-GPU (RCCL inside the library): one process per GPU, one handle per process
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        if len(unique_id) != 128:
+            raise ValueError("the RCCL unique id is 128 bytes (comm_unique_id() on rank 0)")
+        self._check(self.L.almpc_comm_init(self.h, unique_id, int(rank), int(world)))
+        self._comm_world = int(world)
+
+    def comm_summary(self):
+        out = (ctypes.c_int64 * 4)()
+        self._check(self.L.almpc_comm_summary(self.h, out))
+        return dict(ranks=int(out[0]), unsolved=int(out[1]), admm_iters_max=int(out[2]), polish_iters_max=int(out[3]))
+
+    def comm_allgather_first_input(self):
+        """u[:, 1] of every instance of every rank: (world, batch, m)."""
+        out = np.empty((self._comm_world, self.batch, self.m))
+        self._check(self.L.almpc_comm_allgather_first_input(self.h, _ptr(out), None))
+        return out
 
     def sqp_fnn_start(self, x0, u_guess=None):
         """x0 (batch, n); u_guess (batch, m, N) or None."""

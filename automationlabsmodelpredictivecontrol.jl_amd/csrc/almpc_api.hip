@@ -10,6 +10,7 @@
 #include "almpc_fnn.hip.h"
 #include "almpc_instance.hip.h"
 #include "almpc_sqp.hip.h"
+#include "almpc_comm.hip.h"
 #include "almpc_host_math.h"
 #include "../../include/almpc.h"
 
@@ -100,6 +101,11 @@ struct almpc_handle {
         float ms_jac = 0, ms_design = 0, ms_step = 0;  // last timed step (almpc_relin_fnn_step with timing)
         hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     } relin;
+    // multi-GPU (almpc_comm_*): this handle's rank in an RCCL communicator of one process per GPU
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 0;
+    long long* dComm4 = nullptr;       // [4] summary words
+    double *dU0 = nullptr, *dU0all = nullptr;  // [batch][m] packed first inputs, [world][batch][m] gathered
     // timing (ALMPC_FLAG_TIMING): one set of 4 events per step since the last almpc_timing_reset
     std::vector<hipEvent_t> ev;  // 4 per step
     size_t ev_used = 0;          // steps recorded
@@ -164,6 +170,9 @@ void free_all(almpc_handle* h) {
         if (p) (void)hipFree(p);
     for (auto& e : h->relin.ev)
         if (e) (void)hipEventDestroy(e);
+    if (h->comm && rccl_api().ok) (void)rccl_api().CommDestroy(h->comm);
+    for (void* p : {(void*)h->dComm4, (void*)h->dU0, (void*)h->dU0all})
+        if (p) (void)hipFree(p);
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
     h->ev.clear();
@@ -1669,6 +1678,75 @@ int almpc_fnn_linearize(int device_id, int n, int m, int H, int L, int activatio
     }
     for (void* b : bufs) (void)hipFree(b);
     return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Multi-GPU: RCCL inside the library (see almpc_comm.hip.h and include/almpc.h)
+int almpc_comm_unique_id(char* id128) {
+    if (!id128) return ALMPC_ERR_INVALID;
+    RcclApi& r = rccl_api();
+    if (!r.ok) return ALMPC_ERR_UNSUPPORTED;
+    ncclUniqueId id;
+    if (r.GetUniqueId(&id) != ncclSuccess) return ALMPC_ERR_HIP;
+    std::memcpy(id128, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return ALMPC_OK;
+}
+
+int almpc_comm_init(almpc_handle* h, const char* id128, int rank, int world) {
+    if (!h || !id128) return ALMPC_ERR_INVALID;
+    if (world < 1 || rank < 0 || rank >= world) return fail(h, ALMPC_ERR_INVALID, "comm_init: need 0 <= rank < world");
+    RcclApi& r = rccl_api();
+    if (!r.ok) return fail(h, ALMPC_ERR_UNSUPPORTED, "comm_init: " + r.err);
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->comm) { (void)r.CommDestroy(h->comm); h->comm = nullptr; }
+    ncclUniqueId id;
+    std::memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+    const ncclResult_t rc = r.CommInitRank(&h->comm, world, id, rank);
+    if (rc != ncclSuccess) { h->comm = nullptr; return fail(h, ALMPC_ERR_HIP, std::string("ncclCommInitRank: ") + r.GetErrorString(rc)); }
+    h->comm_rank = rank; h->comm_world = world;
+    for (double** pp_ : {&h->dU0, &h->dU0all})
+        if (*pp_) { (void)hipFree(*pp_); *pp_ = nullptr; }
+    if (!h->dComm4) HIP_TRY(h, dalloc(&h->dComm4, 4));
+    HIP_TRY(h, dalloc(&h->dU0, (size_t)h->batch * h->m));
+    HIP_TRY(h, dalloc(&h->dU0all, (size_t)world * h->batch * h->m));
+    return ALMPC_OK;
+}
+
+int almpc_comm_summary(almpc_handle* h, int64_t* out4) {
+    if (!h || !out4) return ALMPC_ERR_INVALID;
+    if (!h->comm) return fail(h, ALMPC_ERR_NOT_DESIGNED, "comm_summary before comm_init");
+    if (!h->designed) return fail(h, ALMPC_ERR_NOT_DESIGNED, "comm_summary before a step");
+    RcclApi& r = rccl_api();
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_comm_summary, dim3(1), dim3(1024), 0, h->stream, h->batch, h->dStatus, h->dIters, h->dPiters, h->dComm4);
+    HIP_TRY(h, hipGetLastError());
+    ncclResult_t rc = r.AllReduce(h->dComm4, h->dComm4, 2, ncclInt64, ncclSum, h->comm, h->stream);
+    if (rc == ncclSuccess) rc = r.AllReduce(h->dComm4 + 2, h->dComm4 + 2, 2, ncclInt64, ncclMax, h->comm, h->stream);
+    if (rc != ncclSuccess) return fail(h, ALMPC_ERR_HIP, std::string("ncclAllReduce: ") + r.GetErrorString(rc));
+    long long host[4];
+    HIP_TRY(h, hipMemcpyAsync(host, h->dComm4, sizeof(host), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < 4; ++i) out4[i] = host[i];
+    return ALMPC_OK;
+}
+
+int almpc_comm_allgather_first_input(almpc_handle* h, double* u0_all, const double** d_u0_all) {
+    if (!h) return ALMPC_ERR_INVALID;
+    if (!h->comm) return fail(h, ALMPC_ERR_NOT_DESIGNED, "comm_allgather_first_input before comm_init");
+    if (!h->designed) return fail(h, ALMPC_ERR_NOT_DESIGNED, "comm_allgather_first_input before a step");
+    RcclApi& r = rccl_api();
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t cnt = (size_t)h->batch * h->m;
+    hipLaunchKernelGGL(k_pack_first_input, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, h->batch, h->m, h->N, h->dU, h->dU0);
+    HIP_TRY(h, hipGetLastError());
+    const ncclResult_t rc = r.AllGather(h->dU0, h->dU0all, cnt, ncclFloat64, h->comm, h->stream);
+    if (rc != ncclSuccess) return fail(h, ALMPC_ERR_HIP, std::string("ncclAllGather: ") + r.GetErrorString(rc));
+    if (u0_all) {
+        HIP_TRY(h, hipMemcpyAsync(u0_all, h->dU0all, cnt * h->comm_world * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    if (d_u0_all) *d_u0_all = h->dU0all;
+    return ALMPC_OK;
 }
 
 int almpc_advance_plant(almpc_handle* h) {

@@ -65,6 +65,14 @@ class Ranks:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
 
+    def broadcast_bytes(self, payload, root: int = 0) -> bytes:
+        """The bytes rank `root` holds, on every rank (used to hand the library's 128-byte RCCL id to the other ranks)."""
+        if self.dist is None:
+            return payload
+        box = [payload if self.rank == root else None]
+        self.dist.broadcast_object_list(box, src=root)
+        return box[0]
+
     def close(self):
         if self.dist is not None:
             self.dist.barrier()

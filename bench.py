@@ -57,6 +57,26 @@ def time_steps(solver, opts, steps, barrier):
     return time.perf_counter() - t0
 
 
+class c_stdout_to_stderr:
+    """librccl prints a version banner on C stdout when NCCL_DEBUG asks for it (the GPU pool sets NCCL_DEBUG=VERSION), from whichever
+    call first creates a communicator.  stdout of this job carries ONE JSON line: while communicators are made, file descriptor 1
+    points at stderr, and C stdio is flushed before it is put back."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` typed by hand (no launcher): start N ranks of this script under torch.distributed.run, one per
     GPU, relay their output (rank 0 prints the JSON line) and return the launcher's exit code.  Runs before anything in this
@@ -118,13 +138,14 @@ def main():
     # oracle/ is test infrastructure: it is imported only by the checker legs below (u_err_inf, the NLP certificate) and by the
     # cpu_baseline leg, never for the inputs and never on the measured path
     mo = None
-    ranks = pkg.sharding.Ranks(backend="nccl")  # one process per GPU; RCCL only for barrier / max-reduce
-    rank, local_rank, world = ranks.rank, ranks.local_rank, ranks.world
-    if world > 1 and args.gpus != world:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    barrier, max_over_ranks = ranks.barrier, ranks.max_over_ranks
-    # ranks that actually joined the job, counted by an all-reduce over the process group (RCCL on the GPU box)
-    joined = int(round(ranks.sum_over_ranks(1.0)))
+    with c_stdout_to_stderr():
+        ranks = pkg.sharding.Ranks(backend="nccl")  # one process per GPU; RCCL only for barrier / max-reduce
+        rank, local_rank, world = ranks.rank, ranks.local_rank, ranks.world
+        if world > 1 and args.gpus != world:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        barrier, max_over_ranks = ranks.barrier, ranks.max_over_ranks
+        # ranks that actually joined the job, counted by an all-reduce over the process group (RCCL on the GPU box)
+        joined = int(round(ranks.sum_over_ranks(1.0)))
     if joined != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but {joined} rank(s) joined the process group")
 
@@ -152,6 +173,18 @@ def main():
     solver.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max, **design_kw)
     solver.set_reference(p.x_ref, p.u_ref)
     solver.update_initialization(X0)  # x0 resident in HBM from here on
+    # the library's own RCCL communicator (almpc_comm_*: one rank per GPU; not possible when the test hook folds ranks onto one device)
+    lib_comm = None
+    if ranks.backend != "gloo":
+        with c_stdout_to_stderr():
+            try:
+                uid = ranks.broadcast_bytes(capi.comm_unique_id() if rank == 0 else None)
+                solver.comm_init(uid, rank, world)
+                lib_comm = True
+            except capi.AlmpcError as e:
+                if world > 1:
+                    raise
+                lib_comm = f"unavailable ({e})"
     # cold start every step (the headline workload): the ADMM state a warm start would need is not stored (ALMPC_OPT_NO_WARM_STATE);
     # the closed-loop leg below uses the default (state kept, warm_start = 1)
     opts = capi.default_opts(rho=rho, max_iter=args.max_iter, check_every=args.max_iter, keep_warm_state=False)
@@ -177,6 +210,15 @@ def main():
     solver.timing_set_stride(TIMING_STRIDE)
     solver.timing_reset(0)
 
+    comm_line = None
+    if lib_comm is True:   # collectives of the library itself, after the timed region: job-wide solve summary and the gathered first inputs
+        summ = solver.comm_summary()
+        u0_all = solver.comm_allgather_first_input()
+        mine = solver.get_results(want=("u",))["u"][:, :, 0]
+        comm_line = dict(summ, first_input_gather_shape=list(u0_all.shape),
+                         first_input_gather_matches_local=bool(np.array_equal(u0_all[rank], mine)))
+    elif lib_comm is not None:
+        comm_line = {"error": lib_comm}
     inst_steps_per_s = pkg.sharding.aggregate_rate(BATCH_PER_GPU, args.steps, elapsed, world)
     out = {
         "metric": "MPC steps/s (batch=4096, nx=12, nu=4, N=30)",
@@ -193,6 +235,8 @@ def main():
                    "admm_max_iter": int(opts.max_iter), "check_every": int(opts.check_every), "polish": int(opts.polish),
                    "rho": opts.rho, "rho_profile": args.rho_profile, "eps": opts.eps_abs, "warm_state_kept": False, "parallelism": f"instances sharded over {world} GPU(s), 16-instance tile per workgroup"},
     }
+    if comm_line is not None:
+        out["rccl_in_library"] = comm_line   # ranks / unsolved / max iterations all-reduced by libalmpc.so's own communicator
     if rank == 0:
         # ---- rooflines from the HIP events recorded inside the timed region (one event set per step on the stream the
         # kernels run on).  Two kernels per step: k_admm (FP64 MFMA bound) and k_polish (+ fused rollout; dependent

@@ -335,6 +335,25 @@ int almpc_fnn_linearize(int device_id, int n, int m, int H, int L, int activatio
                         const double* u, double* A, double* B, double* f);
 
 /*
+ * Multi-GPU: one process per GPU, each with its own handle on its contiguous shard of the batch; instances never interact, so no
+ * collective is on the data path of a step.  RCCL (over xGMI) runs inside the library (dlopen("librccl.so") at first use) for what a
+ * multi-GPU caller needs between steps:
+ *   almpc_comm_unique_id   rank 0 makes the 128-byte id and hands it to the other ranks by any channel (file, socket, MPI, ...)
+ *   almpc_comm_init        every rank, collectively: ncclCommInitRank on the handle's device
+ *   almpc_comm_summary     out4 = {ranks in the job, instances with status != 0 over all ranks (sums); max ADMM iterations, max
+ *                          polish iterations over all ranks (max)} of the last step; collective; synchronises the handle's stream
+ *   almpc_comm_allgather_first_input   u[:,1] of every instance of every rank: [world][batch][m] doubles (32 B per quadrotor instance,
+ *                          never the full trajectories); u0_all: host buffer or NULL; d_u0_all: receives the device pointer or NULL;
+ *                          collective, on the handle's stream (synchronous only when u0_all is given)
+ * ALMPC_ERR_UNSUPPORTED: librccl could not be loaded.
+ */
+#define ALMPC_COMM_ID_BYTES 128
+int almpc_comm_unique_id(char* id128);
+int almpc_comm_init(almpc_handle* h, const char* id128, int rank, int world);
+int almpc_comm_summary(almpc_handle* h, int64_t* out4);
+int almpc_comm_allgather_first_input(almpc_handle* h, double* u0_all, const double** d_u0_all);
+
+/*
  * Test hook: overwrite the LDS of every compute unit with NaN bit patterns (a kernel that reads LDS it has not written
  * then produces NaNs instead of passing on stale values).  Synchronous.  Not needed by callers.
  */

@@ -1,15 +1,16 @@
 # AlmpcHIP.jl -- thin Julia shim over libalmpc.so (include/almpc.h).
 #
 # NOT EXECUTED IN THIS REPOSITORY'S CI: the build image has no `julia`.  Every behaviour of the ABI is exercised
-# through the same entry points from Python (tests/test_gpu_parity.py); this file is the binding a maintainer of
-# AutomationLabsModelPredictiveControl.jl would add.  It keeps the reference's names and call shapes
+# through the same entry points from Python (tests/test_gpu_parity.py) and from C (tests/capi_harness.c, which passes
+# column-major arrays exactly as `ccall` does); this file is the binding a maintainer of
+# AutomationLabsModelPredictiveControl.jl would add, and julia/reference_hip.patch wires it into the reference.  It keeps the reference's names and call shapes
 # (src/main/main_mpc.jl:22-53, src/sub/design_mpc.jl:54-129, src/main/computation_mpc.jl:17-55) and adds the
 # solver tag "hip" next to osqp/scip/ipopt/auto (src/sub/solver_selection.jl:9-14).
 module AlmpcHIP
 
-export hip_solver_def, HipModeler, design_hip, design_batched!, design_sqp_fnn!, sqp_start!, sqp_iterate!,
-       update_initialization!, calculate!,
-       _model_predictive_control_computation
+export hip_solver_def, HipModeler, AlmpcOpts, design_hip, terminal_weight, design_batched!, design_sqp_fnn!, sqp_start!, sqp_iterate!,
+       design_relin_fnn!, relin_step!, update_initialization!, calculate!, read_results!,
+       _model_predictive_control_computation, comm_unique_id, comm_init!, comm_summary, comm_allgather_first_input
 
 const libalmpc = get(ENV, "ALMPC_LIB", "libalmpc.so")
 
@@ -42,32 +43,53 @@ function check(h, rc)
 end
 
 """
-    design_hip(A, B, Q, R, S, umin, umax, N; batch = 1, device = 0, x_ref, u_ref, opts)
+    design_hip(A, B, Q, R, S, umin, umax, N; batch = 1, device = 0, x_ref, u_ref, opts,
+               xmin = nothing, xmax = nothing, terminal = "none", rho_profile = "scalar", P = nothing)
 
 Design for `ConstrainedLinearControlDiscreteSystem` (replaces the JuMP model built at
 src/sub/model_modeler_implementation/linear/mpc_modeler_implementation_linear.jl:20-103 and the objective of
-src/sub/design_mpc.jl:405-468).  `P` is computed inside (DARE, src/sub/design_mpc.jl:327).
+src/sub/design_mpc.jl:405-468).  `P = nothing`: computed inside (DARE, src/sub/design_mpc.jl:327).
+`xmin`/`xmax`: the state box of kw `mpc_state_constraint` (..linear.jl:62-70, stages 1..N+1).  `terminal = "equality"`:
+`e_x[:, end] .== 0` (src/sub/design_mpc.jl:330-331); "none" / "neighborhood" add nothing, as in the reference; "contractive" is a
+quadratic constraint and is refused.  `rho_profile`: "scalar" (OSQP) or "stiffness" (`almpc_set_rho_profile`).
 """
 function design_hip(A::Matrix{Float64}, B::Matrix{Float64}, Q::Matrix{Float64}, R::Matrix{Float64},
                     S::Matrix{Float64}, umin::Vector{Float64}, umax::Vector{Float64}, N::Int;
                     batch::Int = 1, device::Int = 0, x_ref::Matrix{Float64}, u_ref::Matrix{Float64},
-                    opts::AlmpcOpts = AlmpcOpts())
+                    opts::AlmpcOpts = AlmpcOpts(), xmin::Union{Nothing,Vector{Float64}} = nothing,
+                    xmax::Union{Nothing,Vector{Float64}} = nothing, terminal::String = "none",
+                    rho_profile::String = "scalar", P::Union{Nothing,Matrix{Float64}} = nothing)
     n, m = size(B)
+    terminal == "contractive" && error("terminal ingredient \"contractive\" is a quadratic constraint (src/sub/design_mpc.jl:333-340), not a QP row")
+    (xmin === nothing) == (xmax === nothing) || error("give both xmin and xmax or neither")
     href = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:almpc_create, libalmpc), Cint, (Ref{Ptr{Cvoid}}, Cint, Cint, Cint, Cint, Cint, UInt32),
                href, n, m, N, batch, device, 0)
     rc == 0 || error("almpc_create failed ($rc): no gfx950 device? (there is no CPU fallback)")
     h = href[]
-    check(h, ccall((:almpc_design_shared, libalmpc), Cint,
+    mod = HipModeler(h, n, m, N, batch, opts)
+    finalizer(x -> ccall((:almpc_destroy, libalmpc), Cvoid, (Ptr{Cvoid},), x.handle), mod)
+    check(h, ccall((:almpc_set_terminal_equality, libalmpc), Cint, (Ptr{Cvoid}, Cint), h, terminal == "equality" ? 1 : 0))
+    check(h, ccall((:almpc_set_rho_profile, libalmpc), Cint, (Ptr{Cvoid}, Cint), h, rho_profile == "stiffness" ? 1 : 0))
+    pP = P === nothing ? Ptr{Float64}(C_NULL) : pointer(P)
+    pxmin = xmin === nothing ? Ptr{Float64}(C_NULL) : pointer(xmin)
+    pxmax = xmax === nothing ? Ptr{Float64}(C_NULL) : pointer(xmax)
+    GC.@preserve P xmin xmax check(h, ccall((:almpc_design_shared, libalmpc), Cint,
                    (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
                     Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cdouble, Cdouble),
-                   h, A, B, Q, R, S, C_NULL, umin, umax, C_NULL, C_NULL, opts.rho, opts.sigma))
+                   h, A, B, Q, R, S, pP, umin, umax, pxmin, pxmax, opts.rho, opts.sigma))
     # references: n x (N+1) and m x N Julia matrices are already the ABI's [N+1][n] / [N][m] memory
     check(h, ccall((:almpc_set_reference, libalmpc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Cint),
                    h, x_ref, u_ref, 0))
-    mod = HipModeler(h, n, m, N, batch, opts)
-    finalizer(x -> ccall((:almpc_destroy, libalmpc), Cvoid, (Ptr{Cvoid},), x.handle), mod)
     return mod
+end
+
+"terminal weight P (n x n) of the current design: what `_create_terminal_ingredient` returns as `P_cost` (src/sub/design_mpc.jl:327,393)"
+function terminal_weight(mod::HipModeler)
+    P = Matrix{Float64}(undef, mod.n, mod.n)
+    check(mod.handle, ccall((:almpc_get_design, libalmpc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                            mod.handle, C_NULL, C_NULL, P, C_NULL))
+    return P
 end
 
 """
@@ -138,8 +160,69 @@ function calculate!(mod::HipModeler, x::Array{Float64}, e_x::Array{Float64}, u::
     check(mod.handle, ccall((:almpc_get_results, libalmpc), Cint,
                             (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}),
                             mod.handle, x, e_x, u, e_u, status, C_NULL, C_NULL))
-    any(==(2), status) && error("calculate!: non-finite values in at least one instance")
+    # the reference never checks the solver status and lets JuMP.value throw when there is no primal (src/main/computation_mpc.jl:41-53)
+    any(==(2), status) && error("calculate!: non-finite values in at least one instance (no solution to read)")
+    any(==(3), status) && error("calculate!: infeasible problem in at least one instance (state box / terminal equality)")
     return status
+end
+
+"""
+    design_relin_fnn!(mod, W_in, W_h, b_h, W_out, activation, Q, R, S, P, umin, umax; x_ref, u_ref)
+
+BASELINE configs[3]: the black-box model is re-linearised at every instance's own state in every step, on the device
+(`almpc_relin_fnn_*`).  `P` as the reference takes it: DARE at the linearisation about the LAST reference
+(src/sub/design_mpc.jl:312-327).  Then per step: `update_initialization!(mod, X0)`; `relin_step!(mod)`; `read_results!`.
+"""
+function design_relin_fnn!(mod::HipModeler, W_in::Matrix{Float64}, W_h::Array{Float64,3}, b_h::Matrix{Float64}, W_out::Matrix{Float64},
+                           activation::Integer, Q::Matrix{Float64}, R::Matrix{Float64}, S::Matrix{Float64}, P::Matrix{Float64},
+                           umin::Vector{Float64}, umax::Vector{Float64}; x_ref::Matrix{Float64}, u_ref::Matrix{Float64})
+    check(mod.handle, ccall((:almpc_relin_fnn_setup, libalmpc), Cint,
+                   (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                    Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cdouble, Cdouble),
+                   mod.handle, size(W_in, 1), size(W_h, 3), activation, W_in, W_h, b_h, W_out, x_ref, u_ref, Q, R, S, P, umin, umax,
+                   mod.opts.rho, mod.opts.sigma))
+    return mod
+end
+
+function relin_step!(mod::HipModeler)
+    o = Ref(mod.opts)
+    check(mod.handle, ccall((:almpc_relin_fnn_step, libalmpc), Cint, (Ptr{Cvoid}, Ref{AlmpcOpts}), mod.handle, o))
+end
+
+"copy the results of the last step into caller-owned arrays (m x N x batch, n x (N+1) x batch); returns the per-instance status"
+function read_results!(mod::HipModeler, x::Array{Float64}, e_x::Array{Float64}, u::Array{Float64}, e_u::Array{Float64})
+    status = Vector{Int32}(undef, mod.batch)
+    check(mod.handle, ccall((:almpc_get_results, libalmpc), Cint,
+                            (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}),
+                            mod.handle, x, e_x, u, e_u, status, C_NULL, C_NULL))
+    return status
+end
+
+# ---- multi-GPU: one Julia process per GPU, each with its own handle on its shard of the batch; RCCL inside the library ----
+"rank 0 makes the id and hands the 128 bytes to the other ranks (MPI.jl, Distributed, a file: any channel)"
+function comm_unique_id()
+    id = Vector{UInt8}(undef, 128)
+    rc = ccall((:almpc_comm_unique_id, libalmpc), Cint, (Ptr{UInt8},), id)
+    rc == 0 || error("almpc_comm_unique_id failed ($rc): librccl not loadable?")
+    return id
+end
+
+comm_init!(mod::HipModeler, id::Vector{UInt8}, rank::Integer, world::Integer) =
+    check(mod.handle, ccall((:almpc_comm_init, libalmpc), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint), mod.handle, id, rank, world))
+
+"(ranks, unsolved instances over all ranks, max ADMM iterations, max polish iterations) of the last step, all-reduced over RCCL"
+function comm_summary(mod::HipModeler)
+    out = Vector{Int64}(undef, 4)
+    check(mod.handle, ccall((:almpc_comm_summary, libalmpc), Cint, (Ptr{Cvoid}, Ptr{Int64}), mod.handle, out))
+    return out
+end
+
+"u[:, 1] of every instance of every rank (m x batch x world), all-gathered over RCCL: what a plant simulator on any rank needs next"
+function comm_allgather_first_input(mod::HipModeler, world::Integer)
+    out = Array{Float64,3}(undef, mod.m, mod.batch, world)
+    check(mod.handle, ccall((:almpc_comm_allgather_first_input, libalmpc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Ptr{Float64}}),
+                            mod.handle, out, C_NULL))
+    return out
 end
 
 # the name BASELINE.json uses; absent from the reference (SURVEY.md section 0): one batched step

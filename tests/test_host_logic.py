@@ -1,6 +1,10 @@
 """Host-side mirror of the reference interface: argument handling and error behaviour (CPU only)."""
+import os
+
 import numpy as np
 import pytest
+
+from conftest import ROOT
 
 
 def test_design_reference_broadcast(pkg):
@@ -89,3 +93,34 @@ def test_workloads_module_matches_the_oracle_generators(pkg, mo):
     A0, _ = mo.FnnModel(W_in, W_h, b_h, W_out, "tanh").jacobian(np.zeros(4), np.zeros(2))
     assert np.array_equal(W_in, fo.W_in) and np.array_equal(W_h[1], fo.W_h[1]) and np.array_equal(b_h[0], fo.b_h[0])
     assert np.array_equal(wl.scale_to_radius(W_out, A0), fo.W_out)
+
+
+def test_reference_side_patch_applies_to_the_reference(tmp_path):
+    """julia/reference_hip.patch (the four reference-side edits of INTEGRATION.md as an actual diff: hip_solver_def tag, "hip" in
+    _IMPLEMENTATION_SOLVER_LIST, the design branch to AlmpcHIP.design_hip, the dispatch in update_initialization! / calculate!) applies
+    cleanly to the reference's own files.  Build container only: the GPU box has no /root/reference."""
+    import shutil
+    import subprocess
+    ref = "/root/reference"
+    if not os.path.isdir(ref):
+        pytest.skip("no reference checkout here")
+    files = ["src/types/types.jl", "src/sub/solver_selection.jl", "src/sub/design_mpc.jl", "src/main/computation_mpc.jl",
+             "src/AutomationLabsModelPredictiveControl.jl"]
+    for f in files:
+        os.makedirs(os.path.dirname(tmp_path / f), exist_ok=True)
+        shutil.copy(os.path.join(ref, f), tmp_path / f)
+    patch = os.path.join(ROOT, "julia", "reference_hip.patch")
+    touched = {ln.split(" b/")[1].strip() for ln in open(patch) if ln.startswith("diff --git")}
+    assert touched == set(files)
+    r = subprocess.run(["git", "apply", "--check", "--verbose", patch], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    subprocess.check_call(["git", "apply", patch], cwd=tmp_path)
+    sel = open(tmp_path / "src/sub/solver_selection.jl").read()
+    assert "hip = hip_solver_def()," in sel
+    assert "AlmpcHIP.design_hip(" in open(tmp_path / "src/sub/design_mpc.jl").read()
+    # every ccall in the shim names a symbol the header declares
+    import re
+    shim = open(os.path.join(ROOT, "julia", "AlmpcHIP.jl")).read()
+    hdr = open(os.path.join(ROOT, "include", "almpc.h")).read()
+    for sym in set(re.findall(r"ccall\(\(:(almpc_[a-z_]+), libalmpc\)", shim)):
+        assert re.search(r"\b" + sym + r"\s*\(", hdr), sym
