@@ -15,6 +15,7 @@ ALMPC_OK = 0
 ERR_NAMES = {0: "ALMPC_OK", -1: "ALMPC_ERR_INVALID", -2: "ALMPC_ERR_NO_DEVICE", -3: "ALMPC_ERR_HIP",
              -4: "ALMPC_ERR_UNSUPPORTED", -5: "ALMPC_ERR_NOT_DESIGNED", -6: "ALMPC_ERR_NUMERIC"}
 FLAG_TIMING = 0x1
+FLAG_STRUCTURED = 0x2
 SOLVED, MAX_ITER, NON_FINITE, INFEASIBLE = 0, 1, 2, 3
 
 
@@ -99,6 +100,7 @@ def load():
     L.almpc_advance_plant.restype = ctypes.c_int
     L.almpc_dare.argtypes = [ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, _dp]
     L.almpc_dare.restype = ctypes.c_int
+    L.almpc_set_structured_fallback.argtypes = [_hp, ctypes.c_int]
     L.almpc_relin_fnn_setup.argtypes = [_hp, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [_dp] * 12 + [ctypes.c_double, ctypes.c_double]
     L.almpc_relin_fnn_setup.restype = ctypes.c_int
     L.almpc_relin_fnn_step.argtypes = [_hp, ctypes.POINTER(almpc_opts)]
@@ -200,16 +202,20 @@ def fnn_linearize(W_in, W_h, b_h, W_out, x, u, act="relu", device=0, want_f=Fals
 class Solver:
     """Thin object wrapper of an almpc_handle: one device, one batch shard."""
 
-    def __init__(self, n, m, N, batch, device=0, timing=False):
+    def __init__(self, n, m, N, batch, device=0, timing=False, structured=False, structured_fallback=False):
+        """structured: ALMPC_FLAG_STRUCTURED (the Riccati active-set solve of the multiple-shooting form is the handle's solver: any
+        m*N <= 1024).  structured_fallback: a condensed handle whose unsolved instances are redone by that solve."""
         self.L = load()
         self.n, self.m, self.N, self.batch = int(n), int(m), int(N), int(batch)
         self.nz = self.m * self.N
         h = _hp()
         rc = self.L.almpc_create(ctypes.byref(h), self.n, self.m, self.N, self.batch, int(device),
-                                 FLAG_TIMING if timing else 0)
+                                 (FLAG_TIMING if timing else 0) | (FLAG_STRUCTURED if structured else 0))
         if rc != ALMPC_OK:
             raise AlmpcError(rc, "almpc_create failed (is a gfx950 GPU visible? there is no CPU fallback)")
         self.h = h
+        if structured_fallback:
+            self._check(self.L.almpc_set_structured_fallback(self.h, 1))
 
     def _check(self, rc):
         if rc != ALMPC_OK:

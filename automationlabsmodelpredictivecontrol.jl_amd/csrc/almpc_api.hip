@@ -11,6 +11,7 @@
 #include "almpc_instance.hip.h"
 #include "almpc_sqp.hip.h"
 #include "almpc_comm.hip.h"
+#include "almpc_riccati.hip.h"
 #include "almpc_host_math.h"
 #include "../../include/almpc.h"
 
@@ -101,6 +102,13 @@ struct almpc_handle {
         float ms_jac = 0, ms_design = 0, ms_step = 0;  // last timed step (almpc_relin_fnn_step with timing)
         hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     } relin;
+    // structured (Riccati) solve: the handle's only solver (ALMPC_FLAG_STRUCTURED) or the fallback for instances the condensed path
+    // leaves unsolved (almpc_set_structured_fallback)
+    bool structured = false;
+    int fallback = 0;
+    double *rQ = nullptr, *rR = nullptr, *rP = nullptr, *rKst = nullptr;   // device copies of Q, R (branch rule applied), shared P; gain scratch
+    long rP_stride = 0;   // per-instance terminal weights (batched designs): doubles between instances of bP, else 0 with rP
+    bool r_batched_P = false;
     // multi-GPU (almpc_comm_*): this handle's rank in an RCCL communicator of one process per GPU
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_world = 0;
@@ -171,12 +179,67 @@ void free_all(almpc_handle* h) {
     for (auto& e : h->relin.ev)
         if (e) (void)hipEventDestroy(e);
     if (h->comm && rccl_api().ok) (void)rccl_api().CommDestroy(h->comm);
-    for (void* p : {(void*)h->dComm4, (void*)h->dU0, (void*)h->dU0all})
+    for (void* p : {(void*)h->dComm4, (void*)h->dU0, (void*)h->dU0all, (void*)h->rQ, (void*)h->rR, (void*)h->rP, (void*)h->rKst})
         if (p) (void)hipFree(p);
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
     h->ev.clear();
     if (h->stream) (void)hipStreamDestroy(h->stream);
+}
+
+// Device copies of the weights the structured solve uses (R with the reference's branch rule applied: zero if R[1,1] == 0)
+int riccati_weights(almpc_handle* h, const hm::mat& Qm, const hm::mat& Rm, const double* Pshared) {
+    const int n = h->n, m = h->m;
+    hm::mat Qs = Qm, Rs = Rm;
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < j; ++i) { const double v = 0.5 * (Qs[(size_t)j * n + i] + Qs[(size_t)i * n + j]); Qs[(size_t)j * n + i] = Qs[(size_t)i * n + j] = v; }
+    for (int j = 0; j < m; ++j)
+        for (int i = 0; i < j; ++i) { const double v = 0.5 * (Rs[(size_t)j * m + i] + Rs[(size_t)i * m + j]); Rs[(size_t)j * m + i] = Rs[(size_t)i * m + j] = v; }
+    if (Rm[0] == 0.0) std::fill(Rs.begin(), Rs.end(), 0.0);
+    if (!h->rQ) HIP_TRY(h, dalloc(&h->rQ, (size_t)n * n));
+    if (!h->rR) HIP_TRY(h, dalloc(&h->rR, (size_t)m * m));
+    HIP_TRY(h, hipMemcpy(h->rQ, Qs.data(), Qs.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->rR, Rs.data(), Rs.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (Pshared) {
+        if (!h->rP) HIP_TRY(h, dalloc(&h->rP, (size_t)n * n));
+        HIP_TRY(h, hipMemcpy(h->rP, Pshared, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (!h->rKst) HIP_TRY(h, dalloc(&h->rKst, (size_t)h->batch * h->N * ((size_t)n * m + m)));
+    return ALMPC_OK;
+}
+
+bool riccati_shape_ok(const almpc_handle* h) {
+    return h->n <= 32 && h->m <= 16 && (long)h->m * h->N <= 1024 && riccati_lds_doubles(h->n, h->m, h->N) * sizeof(double) <= 160 * 1024;
+}
+
+// k_riccati over the batch (filter = 0) or over the instances whose status is not 0 (filter = 1, start = the step's own result)
+hipError_t launch_riccati(almpc_handle* h, int filter, const double* guess, int max_iter) {
+    RiccatiParams rp;
+    rp.n = h->n; rp.m = h->m; rp.N = h->N; rp.batch = h->batch;
+    const bool pi = h->batched && !h->structured ? true : h->batched;
+    rp.A = pi ? h->bA : h->dA; rp.A_stride = pi ? (long)h->n * h->n : 0;
+    rp.B = pi ? h->bB : h->dB; rp.B_stride = pi ? (long)h->n * h->m : 0;
+    rp.Q = h->rQ; rp.R = h->rR;
+    rp.P = h->r_batched_P ? h->bP : h->rP; rp.P_stride = h->r_batched_P ? h->rP_stride : 0;
+    rp.umin = h->dUmin; rp.umax = h->dUmax;
+    rp.uref = h->dUref; rp.uref_stride = h->uref_stride; rp.xref = h->dXref; rp.xref_stride = h->xref_stride;
+    rp.x0 = h->dX0; rp.uguess = guess; rp.filter = filter; rp.Kst = h->rKst;
+    rp.x = h->dX; rp.ex = h->dEx; rp.u = h->dU; rp.eu = h->dEu; rp.status = h->dStatus; rp.piters = h->dPiters;
+    rp.max_iter = max_iter > 0 ? max_iter : 20 * h->N * h->m + 50;
+    rp.tol = 1e-9;
+    rp.lds_per_wave = riccati_lds_doubles(h->n, h->m, h->N);
+    const size_t per = (size_t)rp.lds_per_wave * sizeof(double);
+    int waves = RICCATI_WAVES;   // per-wave slices of LDS: as many waves per workgroup as fit
+    while (waves > 1 && per * waves > 160 * 1024) --waves;
+    const size_t lds = per * waves;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(k_riccati), lds);
+    if (e != hipSuccess) return e;
+    int wgs = (h->batch + waves - 1) / waves;
+    const int cap = h->num_cus * 2;
+    if (wgs > cap) wgs = cap;
+    hipLaunchKernelGGL(k_riccati, dim3(wgs), dim3(64 * waves), lds, h->stream, rp);
+    return hipGetLastError();
 }
 
 }  // namespace
@@ -204,12 +267,16 @@ int almpc_create(almpc_handle** out, int n, int m, int N, int batch, int device_
     if (!out) return ALMPC_ERR_INVALID;
     *out = nullptr;
     if (n < 1 || m < 1 || N < 1 || batch < 1) return ALMPC_ERR_INVALID;
-    if (n > 64 || (long)m * N > 128) return ALMPC_ERR_UNSUPPORTED;
+    const bool structured = (flags & ALMPC_FLAG_STRUCTURED) != 0;
+    if (structured) {
+        if (n > 32 || m > 16 || (long)m * N > 1024 || riccati_lds_doubles(n, m, N) * sizeof(double) > 160 * 1024) return ALMPC_ERR_UNSUPPORTED;
+    } else if (n > 64 || (long)m * N > 128) return ALMPC_ERR_UNSUPPORTED;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count < 1) return ALMPC_ERR_NO_DEVICE;
     if (device_id < 0 || device_id >= count) return ALMPC_ERR_NO_DEVICE;
     almpc_handle* h = new almpc_handle();
     h->n = n; h->m = m; h->N = N; h->batch = batch; h->device = device_id; h->flags = flags;
+    h->structured = structured;
     h->nz = m * N;
     h->nrb = (h->nz + 15) / 16;
     h->nzs = 16 * h->nrb;
@@ -238,6 +305,18 @@ int almpc_create(almpc_handle** out, int n, int m, int N, int batch, int device_
         h->fuse_step = (e2 && e2[0] == '1') ? 0 : 1;
     }
     const size_t fr = (size_t)h->nrb * h->ks * 64, b = (size_t)batch;
+    if (structured) {   // no condensed matrices: models, references, inputs / outputs and the gain scratch only
+        TRY(dalloc(&h->dUmin, (size_t)m)); TRY(dalloc(&h->dUmax, (size_t)m));
+        TRY(dalloc(&h->dA, (size_t)n * n)); TRY(dalloc(&h->dB, (size_t)n * m));
+        TRY(dalloc(&h->dX0, b * n));
+        TRY(dalloc(&h->dX, b * n * (N + 1))); TRY(dalloc(&h->dEx, b * n * (N + 1)));
+        TRY(dalloc(&h->dU, b * h->nz)); TRY(dalloc(&h->dEu, b * h->nz));
+        TRY(dalloc(&h->dStatus, b)); TRY(dalloc(&h->dIters, b)); TRY(dalloc(&h->dPiters, b));
+        TRY(hipMemset(h->dIters, 0, b * sizeof(int32_t)));
+        TRY(hipMemset(h->dX0, 0, b * n * sizeof(double)));
+        *out = h;
+        return ALMPC_OK;
+    }
     TRY(dalloc(&h->dMinvFrag, fr)); TRY(dalloc(&h->dVFrag, (size_t)h->nrb * h->ksf * 64)); TRY(dalloc(&h->dHFrag, fr));
     TRY(dalloc(&h->dFFrag, (size_t)h->nrb * h->ksf * 64));
     TRY(dalloc(&h->dG, (size_t)h->nz * h->nzs));
@@ -291,11 +370,44 @@ int almpc_set_terminal_equality(almpc_handle* h, int on) {
     return ALMPC_OK;
 }
 
+int almpc_set_structured_fallback(almpc_handle* h, int on) {
+    if (!h) return ALMPC_ERR_INVALID;
+    if (on && !riccati_shape_ok(h)) return fail(h, ALMPC_ERR_UNSUPPORTED, "structured fallback: needs n <= 32, m <= 16 and its buffers in 160 KB of LDS");
+    h->fallback = on ? 1 : 0;
+    h->designed = false;  // takes effect at the next design (which prepares the weights on the device)
+    return ALMPC_OK;
+}
+
 int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const double* Q, const double* R,
                         const double* S, const double* P, const double* umin, const double* umax,
                         const double* xmin, const double* xmax, double rho, double sigma) {
     if (!h) return ALMPC_ERR_INVALID;
     if (!A || !B || !Q || !R || !umin || !umax) return fail(h, ALMPC_ERR_INVALID, "design: null matrix pointer");
+    if (h->structured) {   // ALMPC_FLAG_STRUCTURED: no condensed matrices at all; rho / sigma are not used
+        const int n = h->n, m = h->m, N = h->N;
+        if (xmin || xmax || h->terminal_eq) return fail(h, ALMPC_ERR_UNSUPPORTED, "structured solve: input box only (no state rows)");
+        if (R[0] != 0.0 && S && S[0] != 0.0) return fail(h, ALMPC_ERR_UNSUPPORTED, "structured solve: no input-rate weight S");
+        for (int i = 0; i < m; ++i)
+            if (!(umin[i] <= umax[i])) return fail(h, ALMPC_ERR_INVALID, "design: umin > umax");
+        h->designed = false;
+        HIP_TRY(h, hipSetDevice(h->device));
+        hm::mat Am(A, A + (size_t)n * n), Bm(B, B + (size_t)n * m), Qm(Q, Q + (size_t)n * n), Rm(R, R + (size_t)m * m), Pm;
+        if (P) Pm.assign(P, P + (size_t)n * n);
+        else if (!hm::dare(Am, Bm, Qm, Rm, n, m, Pm)) return fail(h, ALMPC_ERR_NUMERIC, "design: DARE did not converge");
+        h->P = Pm; h->H.clear(); h->F.clear(); h->d.clear();
+        { const int rc_ = riccati_weights(h, Qm, Rm, Pm.data()); if (rc_ != ALMPC_OK) return rc_; }
+        HIP_TRY(h, hipMemcpy(h->dUmin, umin, m * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->dUmax, umax, m * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->dA, A, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->dB, B, (size_t)n * m * sizeof(double), hipMemcpyHostToDevice));
+        h->batched = false; h->ltv = false; h->r_batched_P = false; h->rP_stride = 0;
+        h->hS.assign((size_t)m * m, 0.0); h->useS = 0;
+        h->designed = true;
+        std::vector<double> xr((size_t)n * (N + 1), 0.0), ur((size_t)h->nz, 0.0);
+        const int rc_ref = almpc_set_reference(h, xr.data(), ur.data(), 0);
+        if (rc_ref != ALMPC_OK) h->designed = false;
+        return rc_ref;
+    }
     if ((xmin == nullptr) != (xmax == nullptr)) return fail(h, ALMPC_ERR_INVALID, "design: give both xmin and xmax or neither");
     if (!(rho > 0.0) || !(sigma >= 0.0)) return fail(h, ALMPC_ERR_INVALID, "design: rho must be > 0 and sigma >= 0");
     // from here on the handle's previous design is being overwritten: it counts as designed again only after the last step below
@@ -398,6 +510,12 @@ int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const
             HIP_TRY(h, hipMemcpy(h->dRollM, M.data(), M.size() * sizeof(double), hipMemcpyHostToDevice));
             h->roll_s = sblk; h->roll_nb = (N + sblk - 1) / sblk;
         }
+    }
+    if (h->fallback) {
+        if (h->mc > 0 || h->useS) return fail(h, ALMPC_ERR_UNSUPPORTED, "structured fallback: input box only, no input-rate weight");
+        const int rc_ = riccati_weights(h, Qm, Rm, Pm.data());
+        if (rc_ != ALMPC_OK) return rc_;
+        h->r_batched_P = false; h->rP_stride = 0;
     }
     h->designed = true;
     h->batched = false;
@@ -589,6 +707,44 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
                           const double* S, const double* P, int P_per_instance, const double* umin, const double* umax,
                           double rho, double sigma, const LtvInputs* ltv) {
     if (!h) return ALMPC_ERR_INVALID;
+    if (h->structured) {   // one model per instance, structured solve: models and terminal weights on the device, nothing condensed
+        if (ltv) return fail(h, ALMPC_ERR_UNSUPPORTED, "structured solve: time-varying designs are not built");
+        if (!A_batch || !B_batch || !Q || !R || !umin || !umax) return fail(h, ALMPC_ERR_INVALID, "design_batched: null matrix pointer");
+        if (R[0] != 0.0 && S && S[0] != 0.0) return fail(h, ALMPC_ERR_UNSUPPORTED, "structured solve: no input-rate weight S");
+        const int n = h->n, m = h->m, N = h->N;
+        const size_t b = (size_t)h->batch;
+        h->designed = false;
+        HIP_TRY(h, hipSetDevice(h->device));
+        hm::mat Qm(Q, Q + (size_t)n * n), Rm(R, R + (size_t)m * m);
+        const bool p_inst = P ? (P_per_instance != 0) : true;
+        hm::mat Pall;
+        if (P) Pall.assign(P, P + (p_inst ? b : 1) * (size_t)n * n);
+        else {
+            Pall.resize(b * (size_t)n * n);
+            for (size_t i = 0; i < b; ++i) {
+                hm::mat Am(A_batch + i * n * n, A_batch + (i + 1) * n * n), Bm(B_batch + i * n * m, B_batch + (i + 1) * n * m), Pm;
+                if (!hm::dare(Am, Bm, Qm, Rm, n, m, Pm)) return fail(h, ALMPC_ERR_NUMERIC, "design_batched: DARE did not converge for instance " + std::to_string(i));
+                std::copy(Pm.begin(), Pm.end(), Pall.begin() + i * n * n);
+            }
+        }
+        if (!h->bA) HIP_TRY(h, dalloc(&h->bA, b * n * n));
+        if (!h->bB) HIP_TRY(h, dalloc(&h->bB, b * n * m));
+        if (!h->bP) HIP_TRY(h, dalloc(&h->bP, b * n * n));
+        HIP_TRY(h, hipMemcpy(h->bA, A_batch, b * n * n * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->bB, B_batch, b * n * m * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->bP, Pall.data(), Pall.size() * sizeof(double), hipMemcpyHostToDevice));
+        { const int rc_ = riccati_weights(h, Qm, Rm, nullptr); if (rc_ != ALMPC_OK) return rc_; }
+        HIP_TRY(h, hipMemcpy(h->dUmin, umin, m * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->dUmax, umax, m * sizeof(double), hipMemcpyHostToDevice));
+        h->P.assign(Pall.begin(), Pall.begin() + (size_t)n * n); h->H.clear(); h->F.clear(); h->d.clear();
+        h->hS.assign((size_t)m * m, 0.0); h->useS = 0;
+        h->batched = true; h->ltv = false; h->r_batched_P = true; h->rP_stride = p_inst ? (long)n * n : 0;
+        h->designed = true;
+        std::vector<double> xr((size_t)n * (N + 1), 0.0), ur((size_t)h->nz, 0.0);
+        const int rc_ref = almpc_set_reference(h, xr.data(), ur.data(), 0);
+        if (rc_ref != ALMPC_OK) h->designed = false;
+        return rc_ref;
+    }
     if (!A_batch || !B_batch || !Q || !R || !umin || !umax) return fail(h, ALMPC_ERR_INVALID, "design_batched: null matrix pointer");
     if (!(rho > 0.0) || !(sigma >= 0.0)) return fail(h, ALMPC_ERR_INVALID, "design_batched: rho must be > 0 and sigma >= 0");
     if (h->terminal_eq) return fail(h, ALMPC_ERR_UNSUPPORTED, "design_batched: state rows (terminal equality) need a shared model");
@@ -700,6 +856,12 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
                         (flags[i] == 1 ? ": condensed Hessian has a non-positive diagonal" : ": Cholesky pivot not positive"));
     HIP_TRY(h, hipMemcpy(h->dUmin, umin, m * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->dUmax, umax, m * sizeof(double), hipMemcpyHostToDevice));
+    if (h->fallback && !ltv) {
+        if (useS) return fail(h, ALMPC_ERR_UNSUPPORTED, "structured fallback: no input-rate weight");
+        const int rc_ = riccati_weights(h, Qm, Rm, nullptr);
+        if (rc_ != ALMPC_OK) return rc_;
+        h->r_batched_P = true; h->rP_stride = p_inst ? (long)n * n : 0;
+    }
     h->designed = true;
     h->batched = true;
     h->ltv = false;
@@ -869,6 +1031,12 @@ int almpc_relin_fnn_setup(almpc_handle* h, int H, int L, int activation, const d
     h->has_box = 0; h->mc = 0; h->R = nz; h->np_pairs = 1; h->Rs = 128;
     h->batched = true; h->ltv = false;
     h->state_valid = true;
+    if (h->fallback) {
+        if (q.useS) return fail(h, ALMPC_ERR_UNSUPPORTED, "structured fallback: no input-rate weight");
+        const int rc_ = riccati_weights(h, Qm, Rm, nullptr);
+        if (rc_ != ALMPC_OK) return rc_;
+        h->r_batched_P = true; h->rP_stride = 0;
+    }
     q.ready = true;
     return ALMPC_OK;
 }
@@ -1189,6 +1357,19 @@ int almpc_set_reference(almpc_handle* h, const double* xref, const double* uref,
     const size_t cnt = per_instance ? (size_t)h->batch : 1;
     const size_t xs = (size_t)n * (N + 1), us = (size_t)nz;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->structured) {
+        h->designed = false;
+        if (h->dXref) { (void)hipFree(h->dXref); h->dXref = nullptr; }
+        if (h->dUref) { (void)hipFree(h->dUref); h->dUref = nullptr; }
+        HIP_TRY(h, dalloc(&h->dXref, cnt * xs));
+        HIP_TRY(h, dalloc(&h->dUref, cnt * us));
+        HIP_TRY(h, hipMemcpy(h->dXref, xref, cnt * xs * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->dUref, uref, cnt * us * sizeof(double), hipMemcpyHostToDevice));
+        h->xref_stride = per_instance ? (long)xs : 0;
+        h->uref_stride = per_instance ? (long)us : 0;
+        h->designed = true;
+        return ALMPC_OK;
+    }
     h->sqp.ready = h->sqp.started = false;  // the SQP iterate lived in the reference buffers released here
     h->relin.ready = false;                 // ... and so did the re-linearisation pipeline's references
     h->designed = false;                    // the reference buffers are replaced below: designed again on success only
@@ -1285,6 +1466,10 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         return fail(h, ALMPC_ERR_INVALID, "calculate: warm_start = 1, but the previous step ran with ALMPC_OPT_NO_WARM_STATE (no ADMM state was kept)");
     h->state_valid = keep_state;
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->structured) {   // the Riccati active-set solve is the whole step (polish_max_iter caps its working-set changes)
+        HIP_TRY(h, launch_riccati(h, 0, nullptr, o.polish_max_iter));
+        return ALMPC_OK;
+    }
     const bool timing = (h->flags & ALMPC_FLAG_TIMING) != 0 && (h->step_count++ % (size_t)h->timing_stride) == 0;
     hipStream_t st = h->stream;
     hipEvent_t* ev = nullptr;
@@ -1498,6 +1683,9 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         }
         HIP_TRY(h, hipGetLastError());
     }
+    // structured fallback: instances the condensed path left without a certificate (status != 0: an active-set finish that ran into
+    // its cap, a non-finite or indefinite condensed problem) are redone in the multiple-shooting form, from the step's own result
+    if (h->fallback && !h->ltv && h->mc == 0 && o.polish) HIP_TRY(h, launch_riccati(h, 1, h->dU, 0));
     if (timing) {
         HIP_TRY(h, hipEventRecord(ev[3], st));
         h->ev_used += 1;
@@ -1550,7 +1738,7 @@ int almpc_get_design(almpc_handle* h, double* H, double* F, double* P, double* d
     if (H) std::memcpy(H, h->H.data(), h->H.size() * sizeof(double));
     if (F) std::memcpy(F, h->F.data(), h->F.size() * sizeof(double));
     if (P) std::memcpy(P, h->P.data(), h->P.size() * sizeof(double));
-    if (d) std::memcpy(d, h->d.data(), (size_t)h->nz * sizeof(double));
+    if (d && h->d.size() >= (size_t)h->nz) std::memcpy(d, h->d.data(), (size_t)h->nz * sizeof(double));   // (structured handles: P only)
     return ALMPC_OK;
 }
 

@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--no-closed-loop", action="store_true")
     ap.add_argument("--no-batched-models", action="store_true", help="skip the secondary per-instance-model figure")
     ap.add_argument("--no-sqp", action="store_true", help="skip the secondary SQP (BASELINE configs[4]) figure")
+    ap.add_argument("--no-structured", action="store_true", help="skip the secondary structured-solve (N = 50) figure")
     ap.add_argument("--no-relin", action="store_true", help="skip the secondary per-step re-linearisation (BASELINE configs[3]) figure")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="plumbing check: spawn / rendezvous / barrier / reductions and the JSON line, no solver (value is null); "
@@ -457,6 +458,34 @@ def main():
                                     "note": "one step = Jacobians at (x0_i, u_ref[:,1]) + per-instance condensed designs + ADMM + polish on the "
                                             "handle's stream (almpc_relin_fnn_step); stage_ms: HIP events of the last step"}
         s3.close()
+
+    if rank == 0 and world == 1 and not args.no_structured:
+        # Secondary figure: the structured (non-condensed) solve, k_riccati -- the benchmark plant over a horizon the condensed kernels
+        # cannot take (N = 50: m N = 200 > 128), 4096 instances, mixed amplitudes.  Correctness path (one wave per instance, a full
+        # Riccati sweep per working-set change): the figure says what it costs, not that it is tuned.
+        Ns = 50
+        ps = wl.quadrotor(Ns)
+        ss = capi.Solver(NX, NU, Ns, BATCH_PER_GPU, device=dev_index, structured=True)
+        ss.design_shared(ps.A, ps.B, ps.Q, ps.R, ps.S, None, ps.u_min, ps.u_max)
+        ss.set_reference(ps.x_ref, ps.u_ref)
+        ss.update_initialization(X0)
+        ss.calculate()
+        ks, bests = 5, float("inf")
+        for _rep in range(3):
+            t0 = time.perf_counter()
+            for _ in range(ks):
+                ss.calculate(sync=False)
+            ss.synchronize()
+            bests = min(bests, time.perf_counter() - t0)
+        rs = ss.get_results(want=("status", "polish_iters", "u"))
+        import mpc_oracle as mo
+        pso = mo.make_problem(ps.A, ps.B, Ns, ps.u_min, ps.u_max)
+        errs = max(float(np.abs(rs["u"][i] - mo.solve_mpc_exact(pso, X0[i])["u"]).max()) for i in range(0, 96, 8))
+        out["structured_N50"] = {"value": ks / bests, "unit": "batch-steps/s (4096 instances, quadrotor nx=12 nu=4, N=50, Riccati active-set solve)",
+                                 "ms_per_step": 1e3 * bests / ks, "status_counts": np.bincount(rs["status"], minlength=3).tolist(),
+                                 "working_set_changes_mean": float(rs["polish_iters"].mean()), "working_set_changes_max": int(rs["polish_iters"].max()),
+                                 "u_err_inf_sampled": errs}
+        ss.close()
 
     if rank == 0 and world == 1 and not args.no_sqp:
         # Secondary figure: BASELINE configs[4] -- the NLP of the reference's NonLinearProgramming branch for an Fnn model

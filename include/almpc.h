@@ -93,10 +93,20 @@ void almpc_default_opts(almpc_opts* opts);
 
 /* flags for almpc_create */
 #define ALMPC_FLAG_TIMING 0x1u /* record HIP events around every kernel of almpc_calculate */
+/*
+ * Structured (non-condensed) solve: the handle solves the multiple-shooting form the reference itself builds (states and inputs per
+ * stage, dynamics as constraints: ..linear.jl:48-60) by a primal active-set method whose equality-constrained subproblems are
+ * backward Riccati recursions (k_riccati) -- no condensed Hessian, so no m*N <= 128 limit and no loss of definiteness for open-loop
+ * unstable models over long horizons.  Limits: n <= 32, m <= 16, m*N <= 1024.  Entry points of such a
+ * handle: almpc_design_shared / almpc_design_batched (input box only: no state rows, no S; rho / sigma unused), almpc_set_reference,
+ * almpc_update_initialization(_device), almpc_calculate(_async) (opts.polish_max_iter caps the working-set changes; <= 0: 20 m N + 50),
+ * almpc_get_results (iters: 0, polish_iters: working-set changes), almpc_get_design (P only), almpc_comm_*.
+ */
+#define ALMPC_FLAG_STRUCTURED 0x2u
 
 /*
  * Create a solver for `batch` instances of an (n states, m inputs, horizon N) controller on HIP
- * device `device_id`.  Supported: 1 <= m*N <= 128, 1 <= n <= 64.
+ * device `device_id`.  Supported: 1 <= m*N <= 128, 1 <= n <= 64 (ALMPC_FLAG_STRUCTURED: m*N <= 1024, n <= 32, m <= 16).
  */
 int almpc_create(almpc_handle** out, int n, int m, int N, int batch, int device_id, uint32_t flags);
 void almpc_destroy(almpc_handle* h);
@@ -137,6 +147,15 @@ int almpc_set_rho_profile(almpc_handle* h, int mode);
  * Results are identical.  May be changed at any time.
  */
 int almpc_set_step_fusion(almpc_handle* h, int on);
+
+/*
+ * Structured fallback of a condensed handle (call BEFORE the design; needs n <= 32, m <= 16, input box only, S = 0): after every
+ * step the instances the condensed path left without a certificate (status != ALMPC_SOLVED: an active-set finish that ran into its
+ * cap, a non-finite solve -- in practice per-instance linearisations that are open-loop unstable, whose condensed Hessian is
+ * singular to working precision) are solved again in the multiple-shooting form by k_riccati, starting from the step's own result.
+ * Instances that were solved are not touched.
+ */
+int almpc_set_structured_fallback(almpc_handle* h, int on);
 
 int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const double* Q,
                         const double* R, const double* S, const double* P, const double* umin,

@@ -551,6 +551,137 @@ def solve_mpc_exact(p: MPCProblem, x0, return_info=False):
     return out
 
 
+# --------------------------------------------------------------------------------------
+# structured (non-condensed) solve: the multiple-shooting form the reference builds (..linear.jl:48-60) solved stage by stage
+# --------------------------------------------------------------------------------------
+def riccati_active_set(A, B, Q, R, P, e0, lo, hi, c=None, v_guess=None, max_iter=None, tol=1e-9, return_info=False):
+    """CPU restatement of k_riccati (csrc/almpc_riccati.hip.h): primal active-set method on
+        min  e_N'P e_N + sum_{k=1..N-1} e_k'Q e_k + sum_{k=0..N-1} v_k'R v_k
+        s.t. e_{k+1} = A_k e_k + B_k v_k + c_k,  e_0 given,  lo_k <= v_k <= hi_k
+    (the reference's QP, src/sub/design_mpc.jl:405-468 on ..linear.jl:48-100, in deviation coordinates; stage 1 of the reference is
+    e_0 here), whose equality-constrained subproblems -- inputs of the working set held at their bounds -- are solved by a backward
+    Riccati recursion and a forward rollout instead of a condensed Hessian: O(N (n^3 + n^2 m)) per working-set change, no m*N limit
+    and no loss of definiteness for open-loop unstable models.  A, B: (n, n), (n, m) or lists of N stage matrices; c: (N, n) or None;
+    lo, hi: (N, m).  Multipliers come from the adjoint recursion along the trajectory.
+    Start: v_guess (N, m) clipped to the box (rows on a bound enter the working set), or the clipped unconstrained (LQR) solution."""
+    N, m = lo.shape
+    n = e0.size
+    Ak = [np.asarray(A)] * N if np.ndim(A) == 2 else [np.asarray(a) for a in A]
+    Bk = [np.asarray(B)] * N if np.ndim(B) == 2 else [np.asarray(b) for b in B]
+    ck = np.zeros((N, n)) if c is None else np.asarray(c, dtype=np.float64)
+    Qs, Rs, Ps = 0.5 * (Q + Q.T), 0.5 * (R + R.T), 0.5 * (P + P.T)
+    max_iter = 20 * N * m + 50 if max_iter is None else max_iter
+
+    def sweep(fixed, bval):
+        """backward Riccati for the working set (fixed (N, m) bool, bval (N, m)), then the forward rollout: v*, e*"""
+        Kst, kst = [None] * N, [None] * N
+        Pn, pn = Ps.copy(), np.zeros(n)
+        for k in range(N - 1, -1, -1):
+            a, b = Ak[k], Bk[k]
+            bt = np.where(fixed[k], bval[k], 0.0)
+            d = b @ bt + ck[k]
+            g = Pn @ d + pn
+            M1 = Pn @ a
+            BPA = b.T @ M1
+            Lam = Rs + b.T @ (Pn @ b)
+            h = b.T @ g + Rs @ bt
+            fx = fixed[k]
+            Lam = Lam.copy()
+            Lam[fx, :] = 0.0; Lam[:, fx] = 0.0; Lam[fx, fx] = 1.0
+            BPA = BPA.copy(); BPA[fx, :] = 0.0
+            h = h.copy(); h[fx] = 0.0
+            Li = np.linalg.inv(Lam)
+            K, kff = Li @ BPA, Li @ h
+            Kst[k], kst[k] = K, kff
+            if k > 0:
+                Pnew = Qs + a.T @ M1 - BPA.T @ K
+                pn = a.T @ g - BPA.T @ kff
+                Pn = 0.5 * (Pnew + Pnew.T)
+        vs, es = np.empty((N, m)), np.empty((N + 1, n))
+        es[0] = e0
+        for k in range(N):
+            vs[k] = np.where(fixed[k], bval[k], -Kst[k] @ es[k] - kst[k])
+            es[k + 1] = Ak[k] @ es[k] + Bk[k] @ vs[k] + ck[k]
+        return vs, es
+
+    fixed = np.zeros((N, m), dtype=bool)
+    side = np.zeros((N, m), dtype=int)
+    bval = np.zeros((N, m))
+    if v_guess is None:
+        vs, _ = sweep(fixed, bval)
+        v = np.clip(vs, lo, hi)
+    else:
+        v = np.clip(np.asarray(v_guess, dtype=np.float64).reshape(N, m), lo, hi)
+    up, dn = v >= hi, v <= lo
+    fixed = up | dn
+    side = np.where(up, 1, np.where(dn, -1, 0))
+    bval = np.where(up, hi, np.where(dn, lo, 0.0))
+    n_add = n_rem = 0
+    status = 1
+    it = 0
+    for it in range(1, max_iter + 1):
+        vs, es = sweep(fixed, bval)
+        free = ~fixed
+        step = vs - v
+        with np.errstate(divide="ignore", invalid="ignore"):
+            r_hi = np.where(free & (vs > hi), (hi - v) / step, np.inf)
+            r_lo = np.where(free & (vs < lo), (lo - v) / step, np.inf)
+        rr = np.minimum(r_hi, r_lo)
+        j = int(np.argmin(rr))          # ties: smallest stage, then smallest input
+        kj, aj = divmod(j, m)
+        if rr[kj, aj] < 1.0:
+            t = max(rr[kj, aj], 0.0)
+            v = np.where(free, v + t * step, v)
+            if r_hi[kj, aj] <= r_lo[kj, aj]:
+                v[kj, aj] = hi[kj, aj]; side[kj, aj] = 1; bval[kj, aj] = hi[kj, aj]
+            else:
+                v[kj, aj] = lo[kj, aj]; side[kj, aj] = -1; bval[kj, aj] = lo[kj, aj]
+            fixed[kj, aj] = True
+            n_add += 1
+            continue
+        v = vs.copy()
+        # multipliers of the bounds from the adjoint recursion: mu_k = 2 (R v_k + B_k' lam_{k+1}), lam_N = P e_N, lam_k = Q e_k + A_k' lam_{k+1}
+        lam = Ps @ es[N]
+        mu = np.empty((N, m))
+        for k in range(N - 1, -1, -1):
+            mu[k] = 2.0 * (Rs @ v[k] + Bk[k].T @ lam)
+            lam = Qs @ es[k] + Ak[k].T @ lam
+        viol = np.where(fixed, side * mu, -np.inf)      # an upper bound needs mu <= 0, a lower bound mu >= 0
+        mmax = float(np.max(np.abs(np.where(fixed, mu, 0.0)))) if fixed.any() else 0.0
+        j = int(np.argmax(viol))
+        kj, aj = divmod(j, m)
+        if not fixed.any() or viol[kj, aj] <= tol * max(1.0, mmax):
+            status = 0
+            break
+        fixed[kj, aj] = False; side[kj, aj] = 0; bval[kj, aj] = 0.0
+        n_rem += 1
+    vs, es = sweep(fixed, bval)
+    v = np.clip(vs, lo, hi) if status == 0 else v
+    es = np.empty((N + 1, n)); es[0] = e0
+    for k in range(N):
+        es[k + 1] = Ak[k] @ es[k] + Bk[k] @ v[k] + ck[k]
+    out = dict(v=v, e=es, status=status, iters=it, n_add=n_add, n_remove=n_rem, n_active=int(fixed.sum()))
+    return out
+
+
+def solve_mpc_structured(p: MPCProblem, x0, u_guess=None, **kw):
+    """One MPC step through `riccati_active_set` (box-only problems, S = 0): same outputs as `solve_mpc_exact`."""
+    if p.x_min is not None or p.terminal != "none":
+        raise NotImplementedError("structured solve: input box only")
+    if p.R[0, 0] != 0.0 and p.S[0, 0] != 0.0:
+        raise NotImplementedError("structured solve: no input-rate weight")
+    R = p.R if p.R[0, 0] != 0.0 else 0.0 * p.R          # the reference's branch rule (src/sub/design_mpc.jl:423-466)
+    e0 = np.asarray(x0, dtype=np.float64) - p.x_ref[:, 0]
+    lo = (p.u_min[:, None] - p.u_ref).T
+    hi = (p.u_max[:, None] - p.u_ref).T
+    vg = None if u_guess is None else (np.asarray(u_guess, dtype=np.float64) - p.u_ref).T
+    r = riccati_active_set(p.A, p.B, p.Q, R, p.P, e0, lo, hi, v_guess=vg, **kw)
+    e_u = r["v"].T
+    e_x = r["e"].T
+    return dict(u=e_u + p.u_ref, e_u=e_u, x=e_x + p.x_ref, e_x=e_x, status=r["status"], iters=r["iters"], n_active=r["n_active"],
+                n_add=r["n_add"], n_remove=r["n_remove"])
+
+
 def kkt_general(Hs, fs, A, a0, lo, hi, w, lam):
     """Method-independent optimality certificate for  min 1/2 w'Hs w + fs'w  s.t. lo <= A w + a0 <= hi :
     max of stationarity |Hs w + fs + A'lam|_inf, primal violation, and complementarity/sign violation of lam."""

@@ -159,10 +159,16 @@ def test_config4_relinearised_fnn_per_instance(capi, mo):
     x_ref, u_ref = np.array([0.2, -0.1, 0.05, 0.0]), np.array([0.1, -0.2])
     X0 = x_ref[None, :] + mo.splitmix_normal(0x5EED0004, 0, batch, 4) * 2.0
     A, B = capi.fnn_linearize(f.W_in, f.W_h, f.b_h, f.W_out, X0, np.repeat(u_ref[None], batch, 0), act=f.act)
-    sv, r = solve_batched(capi, A, B, N, [-1, -1], [1, 1], X0, x_ref=x_ref[:, None] * np.ones((4, N + 1)),
-                          u_ref=u_ref[:, None] * np.ones((2, N)))
+    # (three of these linearisations are open-loop unstable, cond(H') up to 5e16: the condensed path leaves them unsolved and the
+    # structured fallback -- k_riccati on the multiple-shooting form -- solves them: tests/test_gpu_structured.py has the details)
+    sv = capi.Solver(4, 2, N, batch, structured_fallback=True)
+    sv.design_batched(A, B, 100.0 * np.eye(4), 0.1 * np.eye(2), None, None, [-1, -1], [1, 1])
+    sv.set_reference(x_ref[:, None] * np.ones((4, N + 1)), u_ref[:, None] * np.ones((2, N)))
+    sv.update_initialization(X0)
+    sv.calculate()
+    r = sv.get_results()
     sv.close()
-    assert (r["status"] == 0).mean() >= 0.99
+    assert np.all(r["status"] == 0)
     nact = 0
     for i in range(0, batch, 16):
         Ai, Bi = f.jacobian(X0[i], u_ref)

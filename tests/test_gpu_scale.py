@@ -98,7 +98,7 @@ def test_bench_gpus_2_spawns_two_ranks(capi):
     """`python bench.py --gpus 2` with no launcher: two ranks (folded onto the one GPU of this box, gloo for the barrier) each solve
     their own 4096-instance shard through the HIP library; the line says n_gpus 2 and carries a real throughput."""
     r = _run_bench(["--gpus", "2", "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-classes", "--no-pipelined",
-                    "--no-closed-loop", "--no-batched-models", "--no-sqp", "--no-relin"], {"ALMPC_DIST_BACKEND": "gloo", "ALMPC_NUM_DEVICES": "1"})
+                    "--no-closed-loop", "--no-batched-models", "--no-sqp", "--no-relin", "--no-structured"], {"ALMPC_DIST_BACKEND": "gloo", "ALMPC_NUM_DEVICES": "1"})
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)

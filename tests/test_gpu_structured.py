@@ -1,0 +1,153 @@
+"""GPU tests of the structured (non-condensed) solve, k_riccati (second half): the multiple-shooting
+form the reference builds (..linear.jl:48-60) solved by a primal active-set method with Riccati-recursion subproblems.
+Oracles: the exact condensed solver where the condensed problem is well conditioned, the numpy restatement of the same algorithm
+(mpc_oracle.riccati_active_set) everywhere, and the reference's sparse statement (mpc_oracle.sparse_problem) as a method-independent
+optimality certificate for the shapes the condensed kernels cannot take (m*N > 128) or condition (unstable linearisations)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+U_TOL = 1e-6
+
+
+def _solve(capi, p, X0, **kw):
+    s = capi.Solver(p.n, p.m, p.N, len(X0), structured=True, **kw)
+    s.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max)
+    s.set_reference(p.x_ref, p.u_ref)
+    s.update_initialization(X0)
+    s.calculate()
+    r = s.get_results()
+    P = s.get_design()["P"]
+    s.close()
+    return r, P
+
+
+def test_structured_solve_matches_the_exact_oracle_on_the_benchmark_plant(capi, mo):
+    p = mo.quadrotor()
+    X0 = np.concatenate([mo.quadrotor_x0_batch(40, a, first_instance=40 * k) for k, a in enumerate((0.3, 1.0, 3.0, 6.0))])
+    r, P = _solve(capi, p, X0)
+    assert np.all(r["status"] == 0)
+    assert np.abs(P - p.P).max() <= 1e-9 * np.abs(p.P).max()
+    for i in range(0, len(X0), 3):
+        e = mo.solve_mpc_exact(p, X0[i])
+        assert np.abs(r["u"][i] - e["u"]).max() <= U_TOL and np.abs(r["x"][i] - e["x"]).max() <= 1e-5
+    # same decisions as the restatement: iteration counts agree
+    for i in (0, 50, 90, 130, 159):
+        o = mo.solve_mpc_structured(p, X0[i])
+        assert o["status"] == 0 and o["iters"] == r["polish_iters"][i]
+        assert np.abs(r["u"][i] - o["u"]).max() <= 1e-9
+    np.testing.assert_allclose(r["e_u"], r["u"] - p.u_ref[None], atol=1e-14)
+    np.testing.assert_allclose(r["e_x"], r["x"] - p.x_ref[None], atol=1e-12)
+    np.testing.assert_array_equal(r["x"][:, :, 0], X0)
+
+
+def test_structured_solve_takes_the_long_horizon_the_condensed_kernels_cannot(capi, mo):
+    """Quadrotor, N = 50: m*N = 200 > 128 (almpc_create refuses a condensed handle).  Certificate: KKT conditions of the reference's
+    own sparse statement cannot be formed cheaply per instance here, so: (i) the numpy restatement, (ii) the exact condensed oracle
+    (numpy, no size limit) on a sample, (iii) dynamics, box, and first-order optimality of the condensed QP for every instance."""
+    p = mo.quadrotor(N=50)
+    with pytest.raises(capi.AlmpcError) as ei:
+        capi.Solver(p.n, p.m, p.N, 4)
+    assert ei.value.code == -4
+    X0 = np.concatenate([mo.quadrotor_x0_batch(64, a, first_instance=64 * k) for k, a in enumerate((0.3, 1.0, 3.0))])
+    r, _ = _solve(capi, p, X0)
+    assert np.all(r["status"] == 0)
+    ex, eu = r["e_x"], r["e_u"]
+    pred = np.einsum("ij,bjk->bik", p.A, ex[:, :, :-1]) + np.einsum("ij,bjk->bik", p.B, eu)
+    assert np.abs(pred - ex[:, :, 1:]).max() <= 1e-9 * max(1.0, np.abs(ex).max())
+    assert np.all(r["u"] >= p.u_min[None, :, None]) and np.all(r["u"] <= p.u_max[None, :, None])
+    _, _, H, F = mo.condense(p)
+    V = eu.transpose(0, 2, 1).reshape(len(X0), -1)
+    Gd = V @ H + X0 @ F.T                                        # gradient of the condensed QP at the structured solution
+    lo = np.tile(p.u_min, p.N)[None] ; hi = np.tile(p.u_max, p.N)[None]
+    sc = 1.0 / np.diag(H)[None]
+    kkt = np.abs(V - np.clip(V - sc * Gd, lo, hi)).max(axis=1)   # projected-gradient residual, Jacobi scaled
+    assert kkt.max() <= 1e-7
+    for i in (0, 70, 140, 191):
+        e = mo.solve_mpc_exact(p, X0[i])
+        assert np.abs(r["u"][i] - e["u"]).max() <= U_TOL
+        o = mo.solve_mpc_structured(p, X0[i])
+        assert np.abs(r["u"][i] - o["u"]).max() <= 1e-9 and o["iters"] == r["polish_iters"][i]
+
+
+def test_structured_fallback_solves_the_unstable_linearisations(capi, mo):
+    """The relinearised Fnn batch of tests/test_gpu_batched_models.py: three of its 1024 linearisations are open-loop unstable
+    (spectral radius up to 2.3, cond(H') 1e10 .. 5e16: the condensed Hessian is singular to working precision and the active-set
+    finish runs into its cap).  With the structured fallback every instance of the batch is solved."""
+    f = mo.synthetic_fnn()
+    batch, N = 1024, 20
+    x_ref, u_ref = np.array([0.2, -0.1, 0.05, 0.0]), np.array([0.1, -0.2])
+    X0 = x_ref[None, :] + mo.splitmix_normal(0x5EED0004, 0, batch, 4) * 2.0
+    A, B = capi.fnn_linearize(f.W_in, f.W_h, f.b_h, f.W_out, X0, np.repeat(u_ref[None], batch, 0), act=f.act)
+    xr, ur = x_ref[:, None] * np.ones((4, N + 1)), u_ref[:, None] * np.ones((2, N))
+    out = {}
+    for fb in (False, True):
+        s = capi.Solver(4, 2, N, batch, structured_fallback=fb)
+        s.design_batched(A, B, 100.0 * np.eye(4), 0.1 * np.eye(2), None, None, [-1, -1], [1, 1])
+        s.set_reference(xr, ur)
+        s.update_initialization(X0)
+        s.calculate()
+        out[fb] = s.get_results()
+        s.close()
+    bad = np.nonzero(out[False]["status"] != 0)[0]
+    assert 1 <= len(bad) <= 8                       # the condensed path alone leaves them unsolved ...
+    assert np.all(out[True]["status"] == 0)         # ... the fallback solves every instance
+    ok = out[False]["status"] == 0
+    for key in ("u", "x", "polish_iters"):          # instances that were solved are not touched
+        assert np.array_equal(out[False][key][ok], out[True][key][ok]), key
+    for i in bad:
+        p = mo.make_problem(A[i], B[i], N, [-1, -1], [1, 1], x_ref=x_ref, u_ref=u_ref)
+        o = mo.solve_mpc_structured(p, X0[i])
+        assert o["status"] == 0 and np.abs(out[True]["u"][i] - o["u"]).max() <= U_TOL
+        # method-independent: dynamics consistency and optimality through the adjoint multipliers' signs is what `o` certifies;
+        # here additionally the cost is not worse than the exact condensed oracle's answer
+        e = mo.solve_mpc_exact(p, X0[i])
+        assert np.abs(out[True]["u"][i] - e["u"]).max() <= 1e-5
+
+
+def test_structured_handle_with_per_instance_models_and_references(capi, mo):
+    rng = np.random.default_rng(5)
+    b, n, m, N = 24, 5, 3, 12
+    As, Bs = [], []
+    for _ in range(b):
+        A = rng.standard_normal((n, n)); A *= (0.7 + 0.6 * rng.random()) / np.max(np.abs(np.linalg.eigvals(A)))
+        As.append(A); Bs.append(rng.standard_normal((n, m)))
+    As, Bs = np.stack(As), np.stack(Bs)
+    X0 = 2.0 * rng.standard_normal((b, n))
+    x_ref = 0.2 * np.ones((n, N + 1)); u_ref = np.tile(np.linspace(-0.2, 0.2, N), (m, 1))
+    s = capi.Solver(n, m, N, b, structured=True)
+    s.design_batched(As, Bs, 100.0 * np.eye(n), 0.1 * np.eye(m), None, None, -np.ones(m), np.ones(m))
+    s.set_reference(x_ref, u_ref)
+    s.update_initialization(X0)
+    s.calculate()
+    r = s.get_results()
+    s.close()
+    assert np.all(r["status"] == 0)
+    for i in range(b):
+        p = mo.make_problem(As[i], Bs[i], N, -np.ones(m), np.ones(m), x_ref=x_ref, u_ref=u_ref)
+        e = mo.solve_mpc_exact(p, X0[i])
+        assert np.abs(r["u"][i] - e["u"]).max() <= U_TOL
+
+
+def test_structured_handle_refuses_what_it_does_not_build(capi, mo):
+    p = mo.double_integrator()
+    s = capi.Solver(2, 1, 10, 2, structured=True)
+    with pytest.raises(capi.AlmpcError) as ei:
+        s.design_shared(p.A, p.B, p.Q, p.R, 0.5 * np.eye(1), None, p.u_min, p.u_max)          # input-rate weight
+    assert ei.value.code == -4
+    with pytest.raises(capi.AlmpcError) as ei:
+        s.design_shared(p.A, p.B, p.Q, p.R, None, None, p.u_min, p.u_max, xmin=[-9, -9], xmax=[9, 9])   # state rows
+    assert ei.value.code == -4
+    with pytest.raises(capi.AlmpcError) as ei:
+        s.calculate()
+    assert ei.value.code == -5
+    s.design_shared(p.A, p.B, p.Q, p.R, None, None, p.u_min, p.u_max)
+    s.update_initialization([[5.0, 0.0], [1.0, 0.0]])
+    s.calculate()
+    r = s.get_results()
+    s.close()
+    for i, x0 in enumerate(([5.0, 0.0], [1.0, 0.0])):
+        assert np.abs(r["u"][i] - mo.solve_mpc_exact(p, np.array(x0))["u"]).max() <= U_TOL
+    with pytest.raises(capi.AlmpcError):
+        capi.Solver(40, 2, 10, 1, structured=True)      # n > 32
