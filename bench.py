@@ -248,7 +248,7 @@ def main():
         iters_total = int(res["iters"].astype(np.int64).sum())
         traffic = {}
         try:
-            with open(os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r2_hbm_traffic.json")) as f:
                 traffic = json.load(f)
         except OSError:
             pass
@@ -261,7 +261,7 @@ def main():
                      "traffic": traffic.get("k_admm", {}).get("hbm_bytes_per_launch"),
                      "avg_kernel_ms": stage_ms["admm_ms"], "admm_iters_per_launch": iters_total,
                      "note": "FP64 MFMA v_mfma_f64_16x16x4_f64; peak = public-spec FP64 78.6 TFLOP/s (71-76 measured with "
-                             "tools/microbench/f64_pipes.hip); traffic = PMC bytes per launch from profiles/r1_hbm_traffic.json"}
+                             "tools/microbench/f64_pipes.hip); traffic = PMC bytes per launch from profiles/r2_hbm_traffic.json"}
         # k_polish (+ rollout), algorithmic bytes per launch: z, y, v0 in (3 nz doubles), u, e_u, x, e_x out
         pol_bytes = BATCH_PER_GPU * 8 * (3 * NZ + 2 * NZ + 2 * NX * (N_HORIZON + 1))
         pol_ms = stage_ms["polish_ms"] + stage_ms["rollout_ms"]

@@ -405,3 +405,51 @@ def test_fnn_fixture_reference_assertions_lp_vs_nlp(mo):
     assert np.abs(lin["x"] - 0.65).max() <= 0.5                                                    # as :1053 asserts for the linear fixture
     assert np.abs(lin["u"][:, 0] - U[:, 0]).max() > 0.1                                            # `broken = true` in the reference
     assert np.all(U >= lo[:, None] - 1e-12) and np.all(U <= hi[:, None] + 1e-12)
+
+
+# ---------------------------------------------------------------------------- structured (Riccati) restatement
+def test_riccati_active_set_equals_the_exact_condensed_solver(mo):
+    """mpc_oracle.riccati_active_set (the restatement k_riccati follows) solves the reference's QP in its multiple-shooting form;
+    where the condensed problem is well conditioned it must land on the exact condensed optimum: double integrator, the QTP scenario
+    shape, the benchmark plant at N = 30 and at N = 50 (m N = 200, beyond the condensed kernels), from both kinds of start."""
+    p = mo.double_integrator()
+    for x0 in ([1.0, 0.0], [5.0, 0.0], [-8.0, 3.0]):
+        e = mo.solve_mpc_exact(p, np.array(x0))
+        s = mo.solve_mpc_structured(p, np.array(x0))
+        assert s["status"] == 0 and np.abs(s["u"] - e["u"]).max() <= 1e-9 and np.abs(s["x"] - e["x"]).max() <= 1e-8
+    for N in (30, 50):
+        p = mo.quadrotor(N=N)
+        for amp, first in ((0.3, 0), (1.0, 11), (3.0, 23)):
+            x0 = mo.quadrotor_x0_batch(1, amp, first_instance=first)[0]
+            e = mo.solve_mpc_exact(p, x0)
+            s = mo.solve_mpc_structured(p, x0)
+            assert s["status"] == 0 and np.abs(s["u"] - e["u"]).max() <= 1e-8
+            s2 = mo.solve_mpc_structured(p, x0, u_guess=np.clip(e["u"] + 0.01, p.u_min[:, None], p.u_max[:, None]))   # a warm guess
+            assert s2["status"] == 0 and np.abs(s2["u"] - e["u"]).max() <= 1e-8 and s2["iters"] <= s["iters"] + 8
+
+
+def test_riccati_active_set_on_an_open_loop_unstable_model(mo):
+    """Spectral radius 2.2 over 20 stages: cond of the condensed Hessian ~1e14.  The structured solve does not notice; the optimum is
+    certified by the KKT conditions of the reference's sparse statement (dynamics as constraints): zero defects, and the bound
+    multipliers from the adjoint recursion have the right signs (recomputed here independently)."""
+    rng = np.random.default_rng(3)
+    n, m, N = 4, 2, 20
+    A = rng.standard_normal((n, n)); A *= 2.2 / np.max(np.abs(np.linalg.eigvals(A)))
+    B = rng.standard_normal((n, m))
+    p = mo.make_problem(A, B, N, [-1, -1], [1, 1], P=200.0 * np.eye(n))
+    x0 = 0.05 * rng.standard_normal(n)
+    s = mo.solve_mpc_structured(p, x0)
+    assert s["status"] == 0
+    ex, eu = s["e_x"], s["e_u"]
+    assert np.abs(A @ ex[:, :-1] + B @ eu - ex[:, 1:]).max() <= 1e-9 * max(1.0, np.abs(ex).max())
+    lam = p.P @ ex[:, N]
+    for k in range(N - 1, -1, -1):
+        mu = 2.0 * (p.R @ eu[:, k] + B.T @ lam)
+        for a in range(m):
+            if eu[a, k] >= 1.0 - 1e-12:
+                assert mu[a] <= 1e-7 * max(1.0, np.abs(mu).max())
+            elif eu[a, k] <= -1.0 + 1e-12:
+                assert mu[a] >= -1e-7 * max(1.0, np.abs(mu).max())
+            else:
+                assert abs(mu[a]) <= 1e-6 * max(1.0, np.abs(lam).max())
+        lam = p.Q @ ex[:, k] + A.T @ lam
