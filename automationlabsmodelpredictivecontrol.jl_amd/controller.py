@@ -311,7 +311,9 @@ def _design_linear(system: ConstrainedLinearControlDiscreteSystem, horizon: int,
         import warnings
         warnings.warn("neighborhood terminal state constraint is not yet implemented")
     elif terminal not in ("none", "equality"):
-        terminal_constraint = "none"  # the reference's final `else`: no terminal constraint to add
+        # the reference's final `else` (src/sub/design_mpc.jl:389-391): an unknown string adds no terminal constraint; it is stored as given
+        # in TerminalIngredient.Xf there, and here
+        pass
     # the state box exists only if the kw is PRESENT (its value is never read), bounds come from system.X (..linear.jl:62-70)
     state_box = "mpc_state_constraint" in kws
     max_time = kws.get("mpc_max_time", D["mpc_max_time"])

@@ -1,0 +1,57 @@
+"""AddressSanitizer + UndefinedBehaviorSanitizer runs of the CPU-side C / C++ code (sanitizers on the CPU build
+only -- GPU sanitizers are not available on this pool): the oracle's C restatement on a quadrotor batch that exercises ADMM, the
+purge, adds and removes of the polish and the rollout, and the library's design-time host math (DARE).  The sanitized binaries must
+exit cleanly (-fno-sanitize-recover=all turns any report into a failure) and reproduce the regular build's numbers."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+SAN = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g", "-O1"]
+
+
+def _run(cmd, **kw):
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env, **kw)
+
+
+@pytest.mark.timeout(900)
+def test_oracle_c_restatement_under_asan_ubsan(tmp_path, mo, co):
+    exe = str(tmp_path / "oracle_san")
+    subprocess.check_call(["gcc", "-std=gnu11", "-Wall", "-Wno-unknown-pragmas"] + SAN + ["-o", exe, os.path.join(ROOT, "tests", "sanitize", "oracle_driver.c"), "-lm"])
+    p = mo.quadrotor()
+    des = mo.design_shared(p, rho=45.0, rho_profile="stiffness")
+    X0 = np.concatenate([mo.quadrotor_x0_batch(12, a, first_instance=20 * k) for k, a in enumerate((0.3, 1.0, 3.0, 6.0))])
+    f = lambda a: np.asfortranarray(a, dtype=np.float64).flatten(order="F")
+    hdr = np.array([p.n, p.m, p.N, len(X0), 6, des["sigma"], 0, 0], dtype=np.float64)
+    parts = [hdr, f(p.A), f(p.B), f(des["Minv"]), f(des["Hs"]), f(des["G"]), f(des["Fs"]), des["fS"], des["lo"], des["hi"], des["d"],
+             f(p.x_ref), f(p.u_ref), X0.flatten(), des["rho_vec"]]
+    np.concatenate([np.asarray(a, dtype=np.float64).ravel() for a in parts]).tofile(tmp_path / "in.bin")
+    r = _run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "ERROR" not in r.stderr and "runtime error" not in r.stderr
+    u = np.fromfile(tmp_path / "out.bin").reshape(len(X0), p.N, p.m).transpose(0, 2, 1)
+    ref = co.step_batch(p, des, X0, max_iter=6, check_every=6, threads=1)
+    assert np.abs(u - ref["u"]).max() <= 1e-9          # -O1 without -march=native vs -O3 -march=native: rounding (FMA contraction) times cond 6.5e6
+    assert f"instances {len(X0)} unsolved 0" in r.stdout
+
+
+@pytest.mark.timeout(600)
+def test_host_math_dare_under_asan_ubsan(tmp_path, mo):
+    exe = str(tmp_path / "host_math_san")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall"] + SAN + ["-o", exe, os.path.join(ROOT, "tests", "sanitize", "host_math_driver.cpp")])
+    p = mo.quadrotor()
+    with open(tmp_path / "in.txt", "w") as fo:
+        fo.write(f"{p.n} {p.m}\n")
+        for M in (p.A, p.B, p.Q, p.R):
+            fo.write(" ".join(repr(float(v)) for v in np.asarray(M).flatten(order="F")) + "\n")
+    r = _run([exe, str(tmp_path / "in.txt")])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "ERROR" not in r.stderr and "runtime error" not in r.stderr
+    vals = r.stdout.split()
+    assert vals[0] == "1"
+    P = np.array([float(v) for v in vals[1:]]).reshape(p.n, p.n, order="F")
+    assert np.abs(P - p.P).max() <= 1e-9 * np.abs(p.P).max()
