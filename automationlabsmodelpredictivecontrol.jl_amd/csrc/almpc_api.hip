@@ -228,6 +228,18 @@ hipError_t launch_riccati(almpc_handle* h, int filter, const double* guess, int 
     rp.max_iter = max_iter > 0 ? max_iter : 20 * h->N * h->m + 50;
     rp.tol = 1e-9;
     rp.lds_per_wave = riccati_lds_doubles(h->n, h->m, h->N);
+    rp.A_kstride = 0; rp.B_kstride = 0; rp.c = nullptr; rp.c_stride = 0; rp.ebar = nullptr; rp.ebar_stride = 0;
+    rp.qu = nullptr; rp.qu_stride = 0; rp.qu_scale = 1.0; rp.flag = nullptr; rp.v_only = 0;
+    if (h->sqp.ready && filter == 2) {   // the QP of the current SQP iteration: stage models, defects, state errors, input gradient
+        const almpc_handle::Sqp& q = h->sqp;
+        const long n = h->n, m = h->m, N = h->N;
+        rp.A = q.A; rp.A_stride = N * n * n; rp.A_kstride = n * n;
+        rp.B = q.B; rp.B_stride = N * n * m; rp.B_kstride = n * m;
+        rp.c = q.c; rp.c_stride = N * n; rp.ebar = q.ebar; rp.ebar_stride = N * n;
+        rp.qu = q.qadd; rp.qu_stride = N * m; rp.qu_scale = 0.5;
+        rp.P = h->bP; rp.P_stride = q.sP;
+        rp.x0 = nullptr; rp.flag = h->bFlag; rp.v_only = 1;
+    }
     const size_t per = (size_t)rp.lds_per_wave * sizeof(double);
     int waves = RICCATI_WAVES;   // per-wave slices of LDS: as many waves per workgroup as fit
     while (waves > 1 && per * waves > 160 * 1024) --waves;
@@ -1197,6 +1209,12 @@ int almpc_sqp_fnn_setup(almpc_handle* h, int H, int L, int activation, const dou
     h->xref_stride = (long)n * (N + 1); h->uref_stride = nz; h->fS_stride = nz;
     h->designed = false;  // becomes true with the first iteration's design
     h->batched = true; h->ltv = true;
+    if (h->fallback) {
+        if (q.useS) return fail(h, ALMPC_ERR_UNSUPPORTED, "structured fallback: no input-rate weight");
+        const int rc_ = riccati_weights(h, Qm, Rm, nullptr);
+        if (rc_ != ALMPC_OK) return rc_;
+        h->r_batched_P = true; h->rP_stride = q.sP;
+    }
     q.ready = true; q.started = false;
     return ALMPC_OK;
 }
@@ -1294,6 +1312,9 @@ int almpc_sqp_fnn_iterate(almpc_handle* h, int iters, double step_scale, const a
         const int rc = almpc_calculate_async(h, opts);
         h->skip_admm = 0;
         if (rc != ALMPC_OK) return rc;
+        // structured fallback: an instance whose condensed Hessian came out indefinite to working precision (open-loop unstable
+        // linearisation over the horizon) or whose QP was left unsolved gets this iteration's QP solved in its stage-wise form
+        if (h->fallback) HIP_TRY(h, launch_riccati(h, 2, nullptr, 0));
         q.since_start += 1;
         sp.stats = q.stats + 2 * it;
         hipLaunchKernelGGL(k_sqp_step, dim3((unsigned)b), dim3(256), step_lds, st, sp);

@@ -34,7 +34,17 @@ struct RiccatiParams {
     const double* xref; long xref_stride;     // [N+1][n]
     const double* x0;                          // [batch][n]
     const double* uguess;                      // [batch][N][m] start (e.g. the condensed path's result) or null: clipped LQR
-    int filter;                                // 1: only instances with status != 0 (fallback after the condensed path)
+    int filter;                                // 1: only instances with status != 0 (fallback after the condensed path);
+                                               // 2: only instances with flag != 0 or status != 0, flag cleared when solved (SQP loop)
+    // time-varying stage models (the QP of one SQP iteration, almpc_sqp.hip.h): A_k = A + inst * A_stride + k * A_kstride etc.;
+    // c [N][n] defects, ebar [N][n]: the cost is on e_{k+1} + ebar_k (state error of the linearisation point), qu [N][m]: linear
+    // input cost (J += 2 qu'v); e_0 = 0 when x0 is null.  All nullable / zero for the time-invariant MPC problem.
+    long A_kstride, B_kstride;
+    const double* c;    long c_stride;
+    const double* ebar; long ebar_stride;
+    const double* qu;   long qu_stride; double qu_scale;   // (J += 2 qu_scale qu'v: 0.5 for a plain gradient vector)
+    int* flag;                                 // [batch] (filter 2)
+    int v_only;                                // 1: write e_u (= v) and status / piters only (the SQP update does the rest)
     double* Kst;                               // scratch [batch][N][m*n + m]: K_k | kff_k
     double* x; double* ex; double* u; double* eu;   // results, layouts of almpc_get_results
     int32_t* status; int32_t* piters;
@@ -103,7 +113,8 @@ __global__ __launch_bounds__(64 * RICCATI_WAVES) void k_riccati(RiccatiParams p)
     const int wpb = (int)(blockDim.x >> 6);   // waves per workgroup: as many (<= RICCATI_WAVES) as have room for their LDS slice
     const int nwaves = gridDim.x * wpb;
     for (int inst = blockIdx.x * wpb + wv; inst < p.batch; inst += nwaves) {
-        if (p.filter && p.status[inst] == 0) continue;
+        if (p.filter == 1 && p.status[inst] == 0) continue;
+        if (p.filter == 2 && p.status[inst] == 0 && p.flag[inst] == 0) continue;
         const double* Ag = p.A + (size_t)inst * p.A_stride;
         const double* Bg = p.B + (size_t)inst * p.B_stride;
         const double* Pg = p.P + (size_t)inst * p.P_stride;
@@ -111,24 +122,41 @@ __global__ __launch_bounds__(64 * RICCATI_WAVES) void k_riccati(RiccatiParams p)
         const double* xrg = p.xref + (size_t)inst * p.xref_stride;
         double* Kg = p.Kst + (size_t)inst * N * (nm + m);
         double* exg = etraj;   // the trajectory stays in LDS (re-read across lanes by the adjoint pass); copied out at the end
+        const bool ltv = p.A_kstride != 0;
+        const double* cg = p.c ? p.c + (size_t)inst * p.c_stride : nullptr;
+        const double* ebg = p.ebar ? p.ebar + (size_t)inst * p.ebar_stride : nullptr;
+        const double* qug = p.qu ? p.qu + (size_t)inst * p.qu_stride : nullptr;
         for (int t = lane; t < nn; t += 64) { As[t] = Ag[t]; Qs[t] = p.Q[t]; }
         for (int t = lane; t < nm; t += 64) Bs[t] = Bg[t];
         for (int t = lane; t < mm; t += 64) Rs[t] = p.R[t];
         rw_fence();
+        auto load_stage = [&](int k) {   // time-varying models: (A_k, B_k) into the LDS slots of the stage loops
+            if (!ltv) return;
+            rw_fence();
+            for (int t = lane; t < nn; t += 64) As[t] = Ag[(size_t)k * p.A_kstride + t];
+            for (int t = lane; t < nm; t += 64) Bs[t] = Bg[(size_t)k * p.B_kstride + t];
+            rw_fence();
+        };
         auto lo_of = [&](int k, int a) { return p.umin[a] - urg[k * m + a]; };
         auto hi_of = [&](int k, int a) { return p.umax[a] - urg[k * m + a]; };
 
         // ---- backward Riccati sweep for the current working set, then the forward rollout: vstar, trajectory in exg
         auto sweep = [&]() {
             for (int t = lane; t < nn; t += 64) Pn[t] = 0.5 * (Pg[t] + Pg[(t % n) * n + t / n]);
-            for (int t = lane; t < n; t += 64) pn[t] = 0.0;
+            rw_fence();
+            for (int i = lane; i < n; i += 64) {   // p_N = P ebar_{N-1}: the terminal cost is on e_N + ebar_{N-1}
+                double s = 0.0;
+                if (ebg) for (int j = 0; j < n; ++j) s += Pn[i + j * n] * ebg[(size_t)(N - 1) * n + j];
+                pn[i] = s;
+            }
             rw_fence();
             for (int k = N - 1; k >= 0; --k) {
                 const uint32_t wk = wset[k];
+                load_stage(k);
                 for (int a = lane; a < m; a += 64) btv[a] = ((wk >> a) & 1u) ? bval[k * m + a] : 0.0;
                 rw_fence();
-                for (int i = lane; i < n; i += 64) {   // d = B bt
-                    double s = 0.0;
+                for (int i = lane; i < n; i += 64) {   // d = B bt + c_k
+                    double s = cg ? cg[(size_t)k * n + i] : 0.0;
                     for (int a = 0; a < m; ++a) s += Bs[i + a * n] * btv[a];
                     dv[i] = s;
                 }
@@ -148,8 +176,8 @@ __global__ __launch_bounds__(64 * RICCATI_WAVES) void k_riccati(RiccatiParams p)
                     const bool fi = (wk >> i) & 1u, fj = (wk >> j) & 1u;
                     Lam[t] = (fi || fj) ? (i == j ? 1.0 : 0.0) : Lam[t] + Rs[t];
                 }
-                for (int a = lane; a < m; a += 64) {           // h = B' g + R bt, zero on the fixed inputs
-                    double s = 0.0;
+                for (int a = lane; a < m; a += 64) {           // h = B' g + R bt + qu_k, zero on the fixed inputs
+                    double s = qug ? p.qu_scale * qug[(size_t)k * m + a] : 0.0;
                     for (int i = 0; i < n; ++i) s += Bs[i + a * n] * gv[i];
                     for (int b = 0; b < m; ++b) s += Rs[a + b * m] * btv[b];
                     hv[a] = ((wk >> a) & 1u) ? 0.0 : s;
@@ -197,6 +225,7 @@ __global__ __launch_bounds__(64 * RICCATI_WAVES) void k_riccati(RiccatiParams p)
                     double pv2 = 0.0;
                     if (lane < n) {
                         double s = 0.0;
+                        if (ebg) for (int j = 0; j < n; ++j) s += Qs[lane + j * n] * ebg[(size_t)(k - 1) * n + j];   // + Q ebar_{k-1}: cost on e_k + ebar_{k-1}
                         for (int l = 0; l < n; ++l) s += As[l + lane * n] * gv[l];
                         for (int a = 0; a < m; ++a) s -= BPA[a + lane * m] * kffv[a];
                         pv2 = s;
@@ -214,7 +243,7 @@ __global__ __launch_bounds__(64 * RICCATI_WAVES) void k_riccati(RiccatiParams p)
             // (the gains were stored by other lanes of this wave: made visible at device scope, read back past the L1 and one stage ahead)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __builtin_amdgcn_wave_barrier();
-            if (lane < n) { const double e0 = p.x0[(size_t)inst * n + lane] - xrg[lane]; ev[lane] = e0; exg[lane] = e0; }
+            if (lane < n) { const double e0 = p.x0 ? p.x0[(size_t)inst * n + lane] - xrg[lane] : 0.0; ev[lane] = e0; exg[lane] = e0; }
             double kreg[9];   // (n m + m) / 64 <= 9 for n <= 32, m <= 16
             auto kload = [&](int k) {
 #pragma unroll
@@ -234,6 +263,7 @@ __global__ __launch_bounds__(64 * RICCATI_WAVES) void k_riccati(RiccatiParams p)
                     else if (t < nm + m) kffv[t - nm] = kreg[c];
                 }
                 if (k + 1 < N) kload(k + 1);
+                load_stage(k);
                 rw_fence();
                 for (int a = lane; a < m; a += 64) {
                     double s = -kffv[a];
@@ -243,6 +273,7 @@ __global__ __launch_bounds__(64 * RICCATI_WAVES) void k_riccati(RiccatiParams p)
                 rw_fence();
                 double en = 0.0;
                 if (lane < n) {
+                    en = cg ? cg[(size_t)k * n + lane] : 0.0;
                     for (int j = 0; j < n; ++j) en += As[lane + j * n] * ev[j];
                     for (int a = 0; a < m; ++a) en += Bs[lane + a * n] * vstar[k * m + a];
                 }
@@ -253,11 +284,13 @@ __global__ __launch_bounds__(64 * RICCATI_WAVES) void k_riccati(RiccatiParams p)
         };
         // trajectory of vcur (after a partial step the stored one is vstar's)
         auto rollout_cur = [&]() {
-            if (lane < n) { const double e0 = p.x0[(size_t)inst * n + lane] - xrg[lane]; ev[lane] = e0; exg[lane] = e0; }
+            if (lane < n) { const double e0 = p.x0 ? p.x0[(size_t)inst * n + lane] - xrg[lane] : 0.0; ev[lane] = e0; exg[lane] = e0; }
             rw_fence();
             for (int k = 0; k < N; ++k) {
+                load_stage(k);
                 double en = 0.0;
                 if (lane < n) {
+                    en = cg ? cg[(size_t)k * n + lane] : 0.0;
                     for (int j = 0; j < n; ++j) en += As[lane + j * n] * ev[j];
                     for (int a = 0; a < m; ++a) en += Bs[lane + a * n] * vcur[k * m + a];
                 }
@@ -332,9 +365,10 @@ __global__ __launch_bounds__(64 * RICCATI_WAVES) void k_riccati(RiccatiParams p)
             for (int t = lane; t < N * m; t += 64) vcur[t] = vstar[t];
             rw_fence();
             // ---- multipliers of the fixed inputs by the adjoint recursion (the stored trajectory is vstar's = vcur's)
-            if (lane < n) {
+            if (lane < n) {   // lam_N = P (e_N + ebar_{N-1})
                 double s = 0.0;
-                for (int j = 0; j < n; ++j) s += 0.5 * (Pg[lane + j * n] + Pg[j + lane * n]) * exg[(size_t)N * n + j];
+                for (int j = 0; j < n; ++j)
+                    s += 0.5 * (Pg[lane + j * n] + Pg[j + lane * n]) * (exg[(size_t)N * n + j] + (ebg ? ebg[(size_t)(N - 1) * n + j] : 0.0));
                 lamv[lane] = s;
             }
             rw_fence();
@@ -342,8 +376,9 @@ __global__ __launch_bounds__(64 * RICCATI_WAVES) void k_riccati(RiccatiParams p)
             int tv = 0x7fffffff;
             for (int k = N - 1; k >= 0; --k) {
                 const uint32_t wk = wset[k];
+                load_stage(k);
                 if (lane < m) {
-                    double s = 0.0;
+                    double s = qug ? p.qu_scale * qug[(size_t)k * m + lane] : 0.0;
                     for (int b = 0; b < m; ++b) s += Rs[lane + b * m] * vcur[k * m + b];
                     for (int i = 0; i < n; ++i) s += Bs[i + lane * n] * lamv[i];
                     const double mu = 2.0 * s;
@@ -354,8 +389,9 @@ __global__ __launch_bounds__(64 * RICCATI_WAVES) void k_riccati(RiccatiParams p)
                     }
                 }
                 double ln = 0.0;
-                if (lane < n) {
-                    for (int j = 0; j < n; ++j) ln += Qs[lane + j * n] * exg[(size_t)k * n + j] + As[j + lane * n] * lamv[j];
+                if (lane < n && k > 0) {   // lam_k = Q (e_k + ebar_{k-1}) + A_k' lam_{k+1}  (stage 0 carries no cost)
+                    for (int j = 0; j < n; ++j)
+                        ln += Qs[lane + j * n] * (exg[(size_t)k * n + j] + (ebg ? ebg[(size_t)(k - 1) * n + j] : 0.0)) + As[j + lane * n] * lamv[j];
                 }
                 rw_fence();
                 if (lane < n) lamv[lane] = ln;
@@ -372,6 +408,20 @@ __global__ __launch_bounds__(64 * RICCATI_WAVES) void k_riccati(RiccatiParams p)
             rw_fence();
         }
         // ---- outputs: u = v + u_ref (clamped to the box), e_u, x = e_x + x_ref, e_x (trajectory of the final point)
+        if (p.v_only) {   // SQP loop: the QP's solution v (= e_u of the handle) is all the update kernel needs
+            for (int t = lane; t < N * m; t += 64) {
+                const int a = t % m;
+                const double ur = urg[t];
+                p.eu[(size_t)inst * N * m + t] = bad ? vcur[t] : fmin(fmax(vcur[t] + ur, p.umin[a]), p.umax[a]) - ur;
+            }
+            if (lane == 0) {
+                p.status[inst] = bad ? 2 : (fin == 0 ? 0 : 1);
+                p.piters[inst] = it;
+                if (p.filter == 2 && !bad && fin == 0) p.flag[inst] = 0;
+            }
+            rw_fence();
+            continue;
+        }
         if (fin != 0 && !bad) rollout_cur();
         for (int t = lane; t < N * m; t += 64) {
             const int a = t % m;

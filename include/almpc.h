@@ -153,7 +153,9 @@ int almpc_set_step_fusion(almpc_handle* h, int on);
  * step the instances the condensed path left without a certificate (status != ALMPC_SOLVED: an active-set finish that ran into its
  * cap, a non-finite solve -- in practice per-instance linearisations that are open-loop unstable, whose condensed Hessian is
  * singular to working precision) are solved again in the multiple-shooting form by k_riccati, starting from the step's own result.
- * Instances that were solved are not touched.
+ * Instances that were solved are not touched.  With the SQP loop (almpc_sqp_fnn_*) the fallback solves the QP of an iteration in its
+ * stage-wise form (time-varying models, defects) for the instances whose condensed Hessian came out indefinite to working precision,
+ * instead of skipping them.
  */
 int almpc_set_structured_fallback(almpc_handle* h, int on);
 

@@ -554,7 +554,7 @@ def solve_mpc_exact(p: MPCProblem, x0, return_info=False):
 # --------------------------------------------------------------------------------------
 # structured (non-condensed) solve: the multiple-shooting form the reference builds (..linear.jl:48-60) solved stage by stage
 # --------------------------------------------------------------------------------------
-def riccati_active_set(A, B, Q, R, P, e0, lo, hi, c=None, v_guess=None, max_iter=None, tol=1e-9, return_info=False):
+def riccati_active_set(A, B, Q, R, P, e0, lo, hi, c=None, v_guess=None, max_iter=None, tol=1e-9, return_info=False, ebar=None, qu=None):
     """CPU restatement of k_riccati (csrc/almpc_riccati.hip.h): primal active-set method on
         min  e_N'P e_N + sum_{k=1..N-1} e_k'Q e_k + sum_{k=0..N-1} v_k'R v_k
         s.t. e_{k+1} = A_k e_k + B_k v_k + c_k,  e_0 given,  lo_k <= v_k <= hi_k
@@ -563,19 +563,22 @@ def riccati_active_set(A, B, Q, R, P, e0, lo, hi, c=None, v_guess=None, max_iter
     Riccati recursion and a forward rollout instead of a condensed Hessian: O(N (n^3 + n^2 m)) per working-set change, no m*N limit
     and no loss of definiteness for open-loop unstable models.  A, B: (n, n), (n, m) or lists of N stage matrices; c: (N, n) or None;
     lo, hi: (N, m).  Multipliers come from the adjoint recursion along the trajectory.
-    Start: v_guess (N, m) clipped to the box (rows on a bound enter the working set), or the clipped unconstrained (LQR) solution."""
+    Start: v_guess (N, m) clipped to the box (rows on a bound enter the working set), or the clipped unconstrained (LQR) solution.
+    For the QP of an SQP iteration: ebar (N, n) -- the state cost is on e_{k+1} + ebar_k --, qu (N, m) -- J += 2 qu_k'v_k."""
     N, m = lo.shape
     n = e0.size
     Ak = [np.asarray(A)] * N if np.ndim(A) == 2 else [np.asarray(a) for a in A]
     Bk = [np.asarray(B)] * N if np.ndim(B) == 2 else [np.asarray(b) for b in B]
     ck = np.zeros((N, n)) if c is None else np.asarray(c, dtype=np.float64)
+    eb = np.zeros((N, n)) if ebar is None else np.asarray(ebar, dtype=np.float64)
+    quk = np.zeros((N, m)) if qu is None else np.asarray(qu, dtype=np.float64)
     Qs, Rs, Ps = 0.5 * (Q + Q.T), 0.5 * (R + R.T), 0.5 * (P + P.T)
     max_iter = 20 * N * m + 50 if max_iter is None else max_iter
 
     def sweep(fixed, bval):
         """backward Riccati for the working set (fixed (N, m) bool, bval (N, m)), then the forward rollout: v*, e*"""
         Kst, kst = [None] * N, [None] * N
-        Pn, pn = Ps.copy(), np.zeros(n)
+        Pn, pn = Ps.copy(), Ps @ eb[N - 1]
         for k in range(N - 1, -1, -1):
             a, b = Ak[k], Bk[k]
             bt = np.where(fixed[k], bval[k], 0.0)
@@ -584,7 +587,7 @@ def riccati_active_set(A, B, Q, R, P, e0, lo, hi, c=None, v_guess=None, max_iter
             M1 = Pn @ a
             BPA = b.T @ M1
             Lam = Rs + b.T @ (Pn @ b)
-            h = b.T @ g + Rs @ bt
+            h = b.T @ g + Rs @ bt + quk[k]
             fx = fixed[k]
             Lam = Lam.copy()
             Lam[fx, :] = 0.0; Lam[:, fx] = 0.0; Lam[fx, fx] = 1.0
@@ -595,7 +598,7 @@ def riccati_active_set(A, B, Q, R, P, e0, lo, hi, c=None, v_guess=None, max_iter
             Kst[k], kst[k] = K, kff
             if k > 0:
                 Pnew = Qs + a.T @ M1 - BPA.T @ K
-                pn = a.T @ g - BPA.T @ kff
+                pn = Qs @ eb[k - 1] + a.T @ g - BPA.T @ kff
                 Pn = 0.5 * (Pnew + Pnew.T)
         vs, es = np.empty((N, m)), np.empty((N + 1, n))
         es[0] = e0
@@ -641,11 +644,11 @@ def riccati_active_set(A, B, Q, R, P, e0, lo, hi, c=None, v_guess=None, max_iter
             continue
         v = vs.copy()
         # multipliers of the bounds from the adjoint recursion: mu_k = 2 (R v_k + B_k' lam_{k+1}), lam_N = P e_N, lam_k = Q e_k + A_k' lam_{k+1}
-        lam = Ps @ es[N]
+        lam = Ps @ (es[N] + eb[N - 1])
         mu = np.empty((N, m))
         for k in range(N - 1, -1, -1):
-            mu[k] = 2.0 * (Rs @ v[k] + Bk[k].T @ lam)
-            lam = Qs @ es[k] + Ak[k].T @ lam
+            mu[k] = 2.0 * (Rs @ v[k] + quk[k] + Bk[k].T @ lam)
+            lam = (Qs @ (es[k] + eb[k - 1]) if k > 0 else 0.0) + Ak[k].T @ lam
         viol = np.where(fixed, side * mu, -np.inf)      # an upper bound needs mu <= 0, a lower bound mu >= 0
         mmax = float(np.max(np.abs(np.where(fixed, mu, 0.0)))) if fixed.any() else 0.0
         j = int(np.argmax(viol))
@@ -1190,7 +1193,7 @@ def nlp_kkt_residual(model: FnnModel, x0, U, x_ref, u_ref, Q, R, S, P, u_min, u_
 
 
 def sqp_fnn(model: FnnModel, x0, x_ref, u_ref, Q, R, S, P, u_min, u_max, iters, u_guess=None, step_scale=1.0, adaptive=False,
-            merit_mu=None):
+            merit_mu=None, structured=False):
     """CPU restatement of the device loop almpc_sqp_fnn_*: Gauss-Newton SQP with multiple shooting, every QP solved exactly
     (solve_box_qp_exact).  Returns X (n, N+1), U (m, N) and the per-iteration (|v|_inf, |defect|_inf) history (None for an
     iteration whose QP was void).
@@ -1231,8 +1234,13 @@ def sqp_fnn(model: FnnModel, x0, x_ref, u_ref, Q, R, S, P, u_min, u_max, iters, 
         for k in range(N):
             Ak, Bk = model.jacobian(X[:, k], U[:, k])
             A.append(Ak); B.append(Bk); c.append(fv[:, k] - X[:, k + 1])
-        H, q, lo, hi = ltv_qp(A, B, c, X, U, x_ref, u_ref, Q, Rz, Sz, P, u_min, u_max)
-        v = solve_box_qp_exact(H, q, lo, hi).reshape(N, m).T
+        if structured:   # the QP in its stage-wise form (riccati_active_set): no condensed Hessian, also for unstable linearisations
+            rr = riccati_active_set(A, B, Q, Rz, P, np.zeros(x0.size), (u_min[:, None] - U).T, (u_max[:, None] - U).T, c=np.array(c),
+                                    ebar=(X[:, 1:] - x_ref[:, 1:]).T, qu=(Rz @ (U - u_ref)).T)
+            v = rr["v"].T
+        else:
+            H, q, lo, hi = ltv_qp(A, B, c, X, U, x_ref, u_ref, Q, Rz, Sz, P, u_min, u_max)
+            v = solve_box_qp_exact(H, q, lo, hi).reshape(N, m).T
         hist.append((float(np.abs(v).max()), float(np.abs(np.array(c)).max())))
         dX = np.zeros_like(X)
         dx = np.zeros(x0.size)

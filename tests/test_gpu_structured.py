@@ -153,3 +153,42 @@ def test_structured_handle_refuses_what_it_does_not_build(capi, mo):
         assert np.abs(r["u"][i] - mo.solve_mpc_exact(p, np.array(x0))["u"]).max() <= U_TOL
     with pytest.raises(capi.AlmpcError):
         capi.Solver(40, 2, 10, 1, structured=True)      # n > 32
+
+
+def test_sqp_loop_solves_an_indefinite_condensed_qp_through_the_stage_wise_form(capi, mo):
+    """An Fnn with identity activation and spectral radius 1.6 over N = 50 stages: the model is linear, so the NLP of the reference's
+    NonLinearProgramming branch is a convex QP -- but its condensed Hessian (cond ~ 1.6^100) is indefinite to working precision, the
+    design kernels flag every instance and the SQP loop can only contain them (ALMPC_ERR_NUMERIC, iterate kept).  With the structured
+    fallback the loop solves each iteration's QP in its stage-wise form (k_riccati with time-varying stage models, defects, state
+    errors and the input gradient) and lands on the optimum of the linear problem in one iteration."""
+    n, m, N, b = 4, 2, 50, 6
+    f = mo.synthetic_fnn(act="identity")
+    f.b_h = [0.0 * v for v in f.b_h]
+    A0, B0 = f.jacobian(np.zeros(n), np.zeros(m))
+    f.W_out = f.W_out * (1.6 / np.max(np.abs(np.linalg.eigvals(A0))))
+    A, B = f.jacobian(np.zeros(n), np.zeros(m))
+    x_ref, u_ref = np.zeros((n, N + 1)), np.zeros((m, N))
+    Q, R, P = 100.0 * np.eye(n), 0.1 * np.eye(m), 150.0 * np.eye(n)
+    X0 = 0.25 * mo.splitmix_normal(0x5EED0009, 0, b, n)
+    out = {}
+    for fb in (False, True):
+        s = capi.Solver(n, m, N, b, structured_fallback=fb)
+        s.sqp_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, x_ref, u_ref, Q, R, None, P, -np.ones(m), np.ones(m), act="identity")
+        s.sqp_fnn_start(X0)
+        if fb:
+            st, de = s.sqp_fnn_iterate(3)
+            assert s.sqp_fnn_skipped().sum() == 0
+            out["hist"] = (st, de)
+        else:
+            with pytest.raises(capi.AlmpcError) as ei:
+                s.sqp_fnn_iterate(3)
+            assert ei.value.code == -6 and s.sqp_fnn_skipped().sum() >= 1
+        out[fb] = s.get_results(want=("u", "x", "status"))
+        s.close()
+    st, de = out["hist"]
+    assert st[0] > 1e-3 and st[-1] <= 1e-9 and de[-1] <= 1e-9, (st, de)          # linear model: converged after the first iteration
+    p = mo.make_problem(A, B, N, -np.ones(m), np.ones(m), P=P)
+    for i in range(b):
+        o = mo.solve_mpc_structured(p, X0[i])
+        assert o["status"] == 0 and np.abs(out[True]["u"][i] - o["u"]).max() <= 1e-6
+    assert ((np.abs(out[True]["u"]) >= 1.0).sum()) >= 1                             # the box is active somewhere

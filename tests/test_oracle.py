@@ -453,3 +453,18 @@ def test_riccati_active_set_on_an_open_loop_unstable_model(mo):
             else:
                 assert abs(mu[a]) <= 1e-6 * max(1.0, np.abs(lam).max())
         lam = p.Q @ ex[:, k] + A.T @ lam
+
+
+def test_riccati_active_set_solves_the_qp_of_an_sqp_iteration(mo):
+    """Time-varying stage models, defects, state errors of the linearisation point and the input gradient (what k_riccati gets from the
+    SQP loop): the stage-wise solve equals the exact solve of the condensed LTV QP (mpc_oracle.ltv_qp), iteration by iteration."""
+    f = mo.synthetic_fnn(act="tanh")
+    n, m, N = 4, 2, 20
+    x_ref = np.tile(np.array([0.2, -0.1, 0.05, 0.0])[:, None], (1, N + 1)); u_ref = np.tile(np.array([0.1, -0.2])[:, None], (1, N))
+    Q, R, P, S = 100.0 * np.eye(n), 0.1 * np.eye(m), 150.0 * np.eye(n), np.zeros((m, m))
+    x0 = x_ref[:, 0] + 0.6 * mo.splitmix_normal(0x5EED0005, 3, 1, n)[0]
+    for it in (1, 3, 8):
+        Xa, Ua, ha = mo.sqp_fnn(f, x0, x_ref, u_ref, Q, R, S, P, -np.ones(m), np.ones(m), it)
+        Xb, Ub, hb = mo.sqp_fnn(f, x0, x_ref, u_ref, Q, R, S, P, -np.ones(m), np.ones(m), it, structured=True)
+        assert np.abs(Ua - Ub).max() <= 1e-10 and np.abs(Xa - Xb).max() <= 1e-10
+        assert abs(ha[-1][0] - hb[-1][0]) <= 1e-10 * max(1.0, ha[-1][0])
