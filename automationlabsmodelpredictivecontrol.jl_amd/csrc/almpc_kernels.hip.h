@@ -994,8 +994,10 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
     // is a valid address and its weight is zero).  Split in a load half and an FMA half so that the first chunk's L2
     // round trip can be started before the LDS work that produces the weights.
     auto g_load = [&](int l0, d2 (&g)[CH]) {
+        // row indices straight from the position-distributed register (v_readlane -> scalar address part): the LDS copy wrow_s cost a
+        // dependent LDS round trip per chunk before the rows of G could even be requested
 #pragma unroll
-        for (int t = 0; t < CH; ++t) g[t] = *reinterpret_cast<const d2*>(Gp + (wrow_s[l0 + t] * gs + rc));  // 32-bit index math
+        for (int t = 0; t < CH; ++t) g[t] = *reinterpret_cast<const d2*>(Gp + (__builtin_amdgcn_readlane(wrow, l0 + t) * gs + rc));
     };
     auto g_fma = [&](int l0, const double* ab, const d2 (&g)[CH], double& q0, double& q1) {
         double av[CH];
