@@ -106,7 +106,7 @@ struct almpc_handle {
     // leaves unsolved (almpc_set_structured_fallback)
     bool structured = false;
     int fallback = 0;
-    double *rQ = nullptr, *rR = nullptr, *rP = nullptr, *rKst = nullptr;   // device copies of Q, R (branch rule applied), shared P; gain scratch
+    double *rQ = nullptr, *rR = nullptr, *rP = nullptr, *rKst = nullptr, *rPst = nullptr;   // device copies of Q, R (branch rule applied), shared P; gain scratch
     long rP_stride = 0;   // per-instance terminal weights (batched designs): doubles between instances of bP, else 0 with rP
     bool r_batched_P = false;
     // multi-GPU (almpc_comm_*): this handle's rank in an RCCL communicator of one process per GPU
@@ -179,7 +179,7 @@ void free_all(almpc_handle* h) {
     for (auto& e : h->relin.ev)
         if (e) (void)hipEventDestroy(e);
     if (h->comm && rccl_api().ok) (void)rccl_api().CommDestroy(h->comm);
-    for (void* p : {(void*)h->dComm4, (void*)h->dU0, (void*)h->dU0all, (void*)h->rQ, (void*)h->rR, (void*)h->rP, (void*)h->rKst})
+    for (void* p : {(void*)h->dComm4, (void*)h->dU0, (void*)h->dU0all, (void*)h->rQ, (void*)h->rR, (void*)h->rP, (void*)h->rKst, (void*)h->rPst})
         if (p) (void)hipFree(p);
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
@@ -205,6 +205,8 @@ int riccati_weights(almpc_handle* h, const hm::mat& Qm, const hm::mat& Rm, const
         HIP_TRY(h, hipMemcpy(h->rP, Pshared, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice));
     }
     if (!h->rKst) HIP_TRY(h, dalloc(&h->rKst, (size_t)h->batch * h->N * ((size_t)n * m + m)));
+    if (!h->rPst && (size_t)h->batch * h->N * ((size_t)n * n + n) * sizeof(double) <= ((size_t)8 << 30))   // value functions of the last sweep
+        HIP_TRY(h, dalloc(&h->rPst, (size_t)h->batch * h->N * ((size_t)n * n + n)));
     return ALMPC_OK;
 }
 
@@ -223,7 +225,7 @@ hipError_t launch_riccati(almpc_handle* h, int filter, const double* guess, int 
     rp.P = h->r_batched_P ? h->bP : h->rP; rp.P_stride = h->r_batched_P ? h->rP_stride : 0;
     rp.umin = h->dUmin; rp.umax = h->dUmax;
     rp.uref = h->dUref; rp.uref_stride = h->uref_stride; rp.xref = h->dXref; rp.xref_stride = h->xref_stride;
-    rp.x0 = h->dX0; rp.uguess = guess; rp.filter = filter; rp.Kst = h->rKst;
+    rp.x0 = h->dX0; rp.uguess = guess; rp.filter = filter; rp.Kst = h->rKst; rp.Pst = h->rPst;
     rp.x = h->dX; rp.ex = h->dEx; rp.u = h->dU; rp.eu = h->dEu; rp.status = h->dStatus; rp.piters = h->dPiters;
     rp.max_iter = max_iter > 0 ? max_iter : 20 * h->N * h->m + 50;
     rp.tol = 1e-9;

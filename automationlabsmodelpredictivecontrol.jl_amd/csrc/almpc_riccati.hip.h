@@ -46,6 +46,9 @@ struct RiccatiParams {
     int* flag;                                 // [batch] (filter 2)
     int v_only;                                // 1: write e_u (= v) and status / piters only (the SQP update does the rest)
     double* Kst;                               // scratch [batch][N][m*n + m]: K_k | kff_k
+    double* Pst;                               // scratch [batch][N][n*n + n]: P_k | p_k of the last sweep (k = 1..N-1), or null: a working-set
+                                               // change at stage k leaves the recursion above k untouched, so the next backward sweep
+                                               // restarts from P_{k+1}, p_{k+1} instead of from the terminal weight
     double* x; double* ex; double* u; double* eu;   // results, layouts of almpc_get_results
     int32_t* status; int32_t* piters;
     int max_iter;
@@ -91,6 +94,7 @@ __device__ __forceinline__ int wave_min_i(int v) {
 }
 
 constexpr int RICCATI_WAVES = 4;
+constexpr int RICCATI_CLIP_START = 4;   // see the start of the active-set loop
 
 __global__ __launch_bounds__(64 * RICCATI_WAVES) void k_riccati(RiccatiParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -141,16 +145,24 @@ __global__ __launch_bounds__(64 * RICCATI_WAVES) void k_riccati(RiccatiParams p)
         auto hi_of = [&](int k, int a) { return p.umax[a] - urg[k * m + a]; };
 
         // ---- backward Riccati sweep for the current working set, then the forward rollout: vstar, trajectory in exg
-        auto sweep = [&]() {
-            for (int t = lane; t < nn; t += 64) Pn[t] = 0.5 * (Pg[t] + Pg[(t % n) * n + t / n]);
-            rw_fence();
-            for (int i = lane; i < n; i += 64) {   // p_N = P ebar_{N-1}: the terminal cost is on e_N + ebar_{N-1}
-                double s = 0.0;
-                if (ebg) for (int j = 0; j < n; ++j) s += Pn[i + j * n] * ebg[(size_t)(N - 1) * n + j];
-                pn[i] = s;
+        double* Pstg = p.Pst ? p.Pst + (size_t)inst * N * (nn + n) : nullptr;
+        auto sweep = [&](int kstart) {   // kstart: the highest stage whose working set changed since the last sweep (N - 1: all)
+            if (!Pstg || kstart >= N - 1) {
+                kstart = N - 1;
+                for (int t = lane; t < nn; t += 64) Pn[t] = 0.5 * (Pg[t] + Pg[(t % n) * n + t / n]);
+                rw_fence();
+                for (int i = lane; i < n; i += 64) {   // p_N = P ebar_{N-1}: the terminal cost is on e_N + ebar_{N-1}
+                    double s = 0.0;
+                    if (ebg) for (int j = 0; j < n; ++j) s += Pn[i + j * n] * ebg[(size_t)(N - 1) * n + j];
+                    pn[i] = s;
+                }
+            } else {   // P_{kstart+1}, p_{kstart+1} of the previous sweep (stored by other lanes of this wave: device-coherent loads)
+                const double* src = Pstg + (size_t)(kstart + 1) * (nn + n);
+                for (int t = lane; t < nn; t += 64) Pn[t] = __hip_atomic_load(src + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int t = lane; t < n; t += 64) pn[t] = __hip_atomic_load(src + nn + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             rw_fence();
-            for (int k = N - 1; k >= 0; --k) {
+            for (int k = kstart; k >= 0; --k) {
                 const uint32_t wk = wset[k];
                 load_stage(k);
                 for (int a = lane; a < m; a += 64) btv[a] = ((wk >> a) & 1u) ? bval[k * m + a] : 0.0;
@@ -235,7 +247,12 @@ __global__ __launch_bounds__(64 * RICCATI_WAVES) void k_riccati(RiccatiParams p)
                     for (int t = lane; t < nn; t += 64) M1[t] = pnew[cnt++];   // M1 is free now: holds the unsymmetrised P
                     if (lane < n) pn[lane] = pv2;
                     rw_fence();
-                    for (int t = lane; t < nn; t += 64) Pn[t] = 0.5 * (M1[t] + M1[(t % n) * n + t / n]);
+                    for (int t = lane; t < nn; t += 64) {
+                        const double v = 0.5 * (M1[t] + M1[(t % n) * n + t / n]);
+                        Pn[t] = v;
+                        if (Pstg) Pstg[(size_t)k * (nn + n) + t] = v;
+                    }
+                    if (Pstg && lane < n) Pstg[(size_t)k * (nn + n) + nn + lane] = pv2;
                     rw_fence();
                 }
             }
@@ -308,7 +325,21 @@ __global__ __launch_bounds__(64 * RICCATI_WAVES) void k_riccati(RiccatiParams p)
             for (int t = lane; t < N * m; t += 64) vstar[t] = p.uguess[(size_t)inst * N * m + t] - urg[t];
             rw_fence();
         } else {
-            sweep();
+            sweep(N - 1);
+            // the clipped unconstrained solution is a good start only when it clips few inputs: with many, most of the clipped rows are
+            // not active at the optimum and each costs a sweep to remove (measured on the quadrotor at N = 50: 339 changes against 60
+            // from the interior).  More than RICCATI_CLIP_START rows clipped: start from the reference input (v = 0) instead.
+            int nclip = 0;
+            for (int t = lane; t < N * m; t += 64) {
+                const int k = t / m, a = t % m;
+                nclip += (vstar[t] > hi_of(k, a) || vstar[t] < lo_of(k, a)) ? 1 : 0;
+            }
+            for (int o = 32; o > 0; o >>= 1) nclip += __shfl_xor(nclip, o);
+            if (nclip > RICCATI_CLIP_START) {
+                rw_fence();
+                for (int t = lane; t < N * m; t += 64) vstar[t] = 0.0;
+                rw_fence();
+            }
         }
         for (int t = lane; t < N * m; t += 64) {
             const int k = t / m, a = t % m;
@@ -324,9 +355,10 @@ __global__ __launch_bounds__(64 * RICCATI_WAVES) void k_riccati(RiccatiParams p)
 
         int it = 0, fin = 1;
         bool bad = false;
+        int kchg = N - 1;   // highest stage whose working set changed since the last sweep
         while (it < p.max_iter) {
             ++it;
-            sweep();
+            sweep(kchg);
             // ---- ratio test over the free inputs of all stages: first bound hit on the way from vcur to vstar
             double rmin = __builtin_inf();
             int tmin = 0x7fffffff;
@@ -359,6 +391,7 @@ __global__ __launch_bounds__(64 * RICCATI_WAVES) void k_riccati(RiccatiParams p)
                     vcur[tsel] = b; bval[tsel] = b;
                     wset[k] |= (1u << a) | (up ? (1u << (16 + a)) : 0u);
                 }
+                kchg = tsel / m;
                 rw_fence();
                 continue;
             }
@@ -405,6 +438,7 @@ __global__ __launch_bounds__(64 * RICCATI_WAVES) void k_riccati(RiccatiParams p)
                 wset[k] &= ~((1u << a) | (1u << (16 + a)));
                 bval[tsel] = 0.0;
             }
+            kchg = tsel / m;
             rw_fence();
         }
         // ---- outputs: u = v + u_ref (clamped to the box), e_u, x = e_x + x_ref, e_x (trajectory of the final point)

@@ -563,7 +563,8 @@ def riccati_active_set(A, B, Q, R, P, e0, lo, hi, c=None, v_guess=None, max_iter
     Riccati recursion and a forward rollout instead of a condensed Hessian: O(N (n^3 + n^2 m)) per working-set change, no m*N limit
     and no loss of definiteness for open-loop unstable models.  A, B: (n, n), (n, m) or lists of N stage matrices; c: (N, n) or None;
     lo, hi: (N, m).  Multipliers come from the adjoint recursion along the trajectory.
-    Start: v_guess (N, m) clipped to the box (rows on a bound enter the working set), or the clipped unconstrained (LQR) solution.
+    Start: v_guess (N, m) clipped to the box (rows on a bound enter the working set), or the clipped unconstrained (LQR) solution if
+    it clips at most 4 inputs, else the reference input (v = 0): most rows a heavily clipped LQR solution holds are not active at the optimum.
     For the QP of an SQP iteration: ebar (N, n) -- the state cost is on e_{k+1} + ebar_k --, qu (N, m) -- J += 2 qu_k'v_k."""
     N, m = lo.shape
     n = e0.size
@@ -612,6 +613,8 @@ def riccati_active_set(A, B, Q, R, P, e0, lo, hi, c=None, v_guess=None, max_iter
     bval = np.zeros((N, m))
     if v_guess is None:
         vs, _ = sweep(fixed, bval)
+        if int(((vs > hi) | (vs < lo)).sum()) > 4:   # k_riccati's RICCATI_CLIP_START: many clipped rows -> start from the reference input
+            vs = np.zeros((N, m))
         v = np.clip(vs, lo, hi)
     else:
         v = np.clip(np.asarray(v_guess, dtype=np.float64).reshape(N, m), lo, hi)
