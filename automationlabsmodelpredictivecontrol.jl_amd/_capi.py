@@ -106,6 +106,7 @@ def load():
     L.almpc_relin_fnn_step.argtypes = [_hp, ctypes.POINTER(almpc_opts)]
     L.almpc_relin_fnn_step_async.argtypes = [_hp, ctypes.POINTER(almpc_opts)]
     L.almpc_relin_fnn_timing.argtypes = [_hp, _fp, _fp, _fp]
+    L.almpc_relin_fnn_advance.argtypes = [_hp]
     L.almpc_comm_unique_id.argtypes = [ctypes.c_char_p]
     L.almpc_comm_init.argtypes = [_hp, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
     L.almpc_comm_summary.argtypes = [_hp, ctypes.POINTER(ctypes.c_int64)]
@@ -351,6 +352,10 @@ class Solver:
     def relin_fnn_step(self, opts: almpc_opts | None = None, sync=True):
         fn = self.L.almpc_relin_fnn_step if sync else self.L.almpc_relin_fnn_step_async
         self._check(fn(self.h, ctypes.byref(opts) if opts is not None else None))
+
+    def relin_fnn_advance(self):
+        """x0 <- fnn(x0, u[:,1]) on the device (closed loop of the black-box model)."""
+        self._check(self.L.almpc_relin_fnn_advance(self.h))
 
     def relin_fnn_timing(self):
         a, d, s = ctypes.c_float(), ctypes.c_float(), ctypes.c_float()

@@ -55,7 +55,8 @@ struct almpc_handle {
     bool state_valid = true;      // xs / ys hold the ADMM state of the last step (a warm start may use them)
     int num_cus = 256;            // persistent-grid size of k_polish<true>
     int polish_no_glds = 0;       // diagnostic: force the G-through-L2 build (ALMPC_POLISH_NO_GLDS=1)
-    int skip_admm = 0;            // transient (SQP iterations after the first): guess from the iterate, no ADMM phase, no KKT inverse
+    int skip_admm = 0;            // transient (SQP iterations after the first): guess from the iterate, no ADMM phase, no KKT inverse;
+                                  // 2 (re-linearisation pipeline, warm steps): guess = the previous step's inputs shifted by one stage
     int fuse_step = 1;            // one kernel per step when the shape allows (almpc_set_step_fusion / ALMPC_NO_FUSED_STEP=1)
     double* dSglobal = nullptr;  // polish scratch for working sets beyond 32 rows
     // state rows (state box / terminal equality): constraint-space data for k_polish_gen
@@ -99,6 +100,8 @@ struct almpc_handle {
         double *ulin = nullptr;   // [batch][m] linearisation input of every instance (the first input reference)
         double *Q = nullptr, *R = nullptr, *S = nullptr;
         double *gS = nullptr;     // [nz] unscaled input-rate gradient 2 D'Sbar D u_ref of the shared reference
+        bool have_prev = false;   // a step has been solved since setup: its inputs can seed the next step's working set
+        double *u0 = nullptr, *xnext = nullptr;   // [batch][m] applied inputs, [batch][n] next states (almpc_relin_fnn_advance)
         float ms_jac = 0, ms_design = 0, ms_step = 0;  // last timed step (almpc_relin_fnn_step with timing)
         hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     } relin;
@@ -174,7 +177,7 @@ void free_all(almpc_handle* h) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : {(void*)h->relin.W_in, (void*)h->relin.W_h, (void*)h->relin.b_h, (void*)h->relin.W_out, (void*)h->relin.ulin,
-                    (void*)h->relin.Q, (void*)h->relin.R, (void*)h->relin.S, (void*)h->relin.gS})
+                    (void*)h->relin.Q, (void*)h->relin.R, (void*)h->relin.S, (void*)h->relin.gS, (void*)h->relin.u0, (void*)h->relin.xnext})
         if (p) (void)hipFree(p);
     for (auto& e : h->relin.ev)
         if (e) (void)hipEventDestroy(e);
@@ -1039,7 +1042,9 @@ int almpc_relin_fnn_setup(almpc_handle* h, int H, int L, int activation, const d
     h->xref_stride = 0; h->uref_stride = 0; h->fS_stride = nz;
     for (auto& e : q.ev)
         if (!e) HIP_TRY(h, hipEventCreate(&e));
-    q.H = H; q.L = L; q.act = activation;
+    q.H = H; q.L = L; q.act = activation; q.have_prev = false;
+    if (!q.u0) HIP_TRY(h, dalloc(&q.u0, b * m));
+    if (!q.xnext) HIP_TRY(h, dalloc(&q.xnext, b * n));
     h->P = Pm; h->hS = Sm; h->useS = q.useS;
     h->rho = rho; h->sigma = sigma;
     h->has_box = 0; h->mc = 0; h->R = nz; h->np_pairs = 1; h->Rs = 128;
@@ -1072,9 +1077,16 @@ int almpc_relin_fnn_step_async(almpc_handle* h, const almpc_opts* opts) {
     fp.A = h->bA; fp.B = h->bB; fp.f = nullptr;
     HIP_TRY(h, launch_fnn_jacobian(fp, h->num_cus, st));
     if (timing) HIP_TRY(h, hipEventRecord(q.ev[1], st));
-    // 2. the reference's QP for every (A_i, B_i): H_i, F_i, scaling, inverses, V_i; reference-dependent vectors
+    // 2. the reference's QP for every (A_i, B_i): H_i, F_i, scaling, inverses, V_i; reference-dependent vectors.  A warm step
+    // (opts.warm_start = 1 after a solved step) takes its working-set guess from the previous step's inputs shifted by one stage
+    // instead of an ADMM phase, and the design then needs one inverse (G_i) instead of two
+    const bool warm = opts && opts->warm_start && q.have_prev && (!opts || opts->polish);
+    h->skip_admm = warm ? 2 : 0;
     const DesignStrides ds = batched_strides(h, false);
-    HIP_TRY(h, launch_batched_design(h, ds, q.useR, q.useS, q.Q, q.R, q.S, h->rho, h->sigma));
+    {
+        const hipError_t e_ = launch_batched_design(h, ds, q.useR, q.useS, q.Q, q.R, q.S, h->rho, h->sigma);
+        if (e_ != hipSuccess) { h->skip_admm = 0; return fail(h, ALMPC_ERR_HIP, std::string("relin design: ") + hipGetErrorString(e_)); }
+    }
     if (q.useS) {
         hipLaunchKernelGGL(k_fs_scale, dim3(256), dim3(256), 0, st, h->batch, nz, nzs, q.gS, 0L, h->bD, h->dFS);
         hipLaunchKernelGGL(k_neg_gm, dim3(1, (unsigned)h->batch), dim3(256), 0, st, nz, nzs, 1, nz, h->bG, h->dFS, h->dV0S,
@@ -1084,8 +1096,14 @@ int almpc_relin_fnn_step_async(almpc_handle* h, const almpc_opts* opts) {
     if (timing) HIP_TRY(h, hipEventRecord(q.ev[2], st));
     // 3. the step itself
     h->designed = true;
-    const int rc = almpc_calculate_async(h, opts);
+    almpc_opts o2;
+    almpc_default_opts(&o2);
+    if (opts) o2 = *opts;
+    o2.warm_start = 0;   // (the per-instance ADMM's own warm start is not what a warm step of this pipeline means)
+    const int rc = almpc_calculate_async(h, &o2);
+    h->skip_admm = 0;
     if (rc != ALMPC_OK) return rc;
+    q.have_prev = true;
     hipLaunchKernelGGL(k_flag_to_status, dim3((h->batch + 255) / 256), dim3(256), 0, st, h->batch, h->bFlag, h->dStatus);
     HIP_TRY(h, hipGetLastError());
     if (timing) HIP_TRY(h, hipEventRecord(q.ev[3], st));
@@ -1096,6 +1114,27 @@ int almpc_relin_fnn_step(almpc_handle* h, const almpc_opts* opts) {
     const int rc = almpc_relin_fnn_step_async(h, opts);
     if (rc != ALMPC_OK) return rc;
     return almpc_synchronize(h);
+}
+
+// x0 <- fnn(x0, u[:,1]) on the device: the closed loop of the black-box model itself (the plant a simulation study drives), no host
+// round trip.  Follow with almpc_relin_fnn_step(_async) -- typically with opts.warm_start = 1.
+int almpc_relin_fnn_advance(almpc_handle* h) {
+    if (!h) return ALMPC_ERR_INVALID;
+    almpc_handle::Relin& q = h->relin;
+    if (!q.ready || !q.have_prev) return fail(h, ALMPC_ERR_NOT_DESIGNED, "relin_fnn_advance needs a solved almpc_relin_fnn_step");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int n = h->n, m = h->m;
+    hipStream_t st = h->stream;
+    const size_t cnt = (size_t)h->batch * m;
+    hipLaunchKernelGGL(k_pack_first_input, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, h->batch, m, h->N, h->dU, q.u0);
+    FnnParams fp;
+    fp.n = n; fp.m = m; fp.H = q.H; fp.L = q.L; fp.act = q.act; fp.batch = h->batch;
+    fp.W_in = q.W_in; fp.W_h = q.W_h; fp.b_h = q.b_h; fp.W_out = q.W_out;
+    fp.x = h->dX0; fp.u = q.u0; fp.ppi = 1; fp.xs_group = n; fp.us_group = m;
+    fp.A = h->bA; fp.B = h->bB; fp.f = q.xnext;   // (the Jacobian slots are scratch here: the next step re-linearises at the new state)
+    HIP_TRY(h, launch_fnn_jacobian(fp, h->num_cus, st));
+    HIP_TRY(h, hipMemcpyAsync(h->dX0, q.xnext, (size_t)h->batch * n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    return ALMPC_OK;
 }
 
 int almpc_relin_fnn_timing(almpc_handle* h, float* ms_jacobian, float* ms_design, float* ms_step) {
@@ -1518,7 +1557,8 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         ip.max_iter = o.max_iter; ip.check_every = o.check_every; ip.warm = o.warm_start ? 1 : 0;
         if (h->skip_admm) {
             if (!o.polish) return fail(h, ALMPC_ERR_INVALID, "calculate: the SQP loop needs opts.polish = 1");
-            hipLaunchKernelGGL(k_guess_iterate, dim3((h->batch + 3) / 4), dim3(256), 0, st, ip);
+            if (h->skip_admm == 2) hipLaunchKernelGGL(k_guess_shift, dim3((h->batch + 3) / 4), dim3(256), 0, st, ip, (const double*)h->dU, h->N);
+            else hipLaunchKernelGGL(k_guess_iterate, dim3((h->batch + 3) / 4), dim3(256), 0, st, ip);
             HIP_TRY(h, hipGetLastError());
         } else {
         const size_t l = (12 * (size_t)h->nzs + 64 + 2 * (size_t)h->m) * sizeof(double);

@@ -343,6 +343,40 @@ __global__ __launch_bounds__(256) void k_guess_iterate(AdmmInstParams p) {
     }
 }
 
+// k_guess_shift: the same hand-off for a receding-horizon step with per-instance models (almpc_relin_fnn_step, warm_start = 1): the
+// guess is the previous step's input trajectory shifted by one stage (stage k <- stage k+1, the last stage repeated) -- the classic
+// MPC warm start.  z = that point in the new scaled coordinates, clipped to the box; working set = its rows on a bound.  The finish
+// is exact whatever its start; what goes away is the ADMM phase and the KKT inverse of the design.  uprev: [batch][N][m].
+__global__ __launch_bounds__(256) void k_guess_shift(AdmmInstParams p, const double* uprev, int N) {
+    const int nz = p.nz, nzs = p.nzs, n = p.n, m = p.m, lane = threadIdx.x & 63;
+    const int inst = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (inst >= p.batch) return;
+    const double* Vi = p.Vs + (size_t)inst * n * nzs;
+    const double* dv = p.dvec + (size_t)inst * nzs;
+    const size_t o = (size_t)inst * nzs;
+    for (int r = lane; r < nzs; r += 64) {
+        double v = 0.0, z = 0.0, y = 0.0;
+        if (r < nz) {
+            v = p.v0S[(size_t)inst * nz + r];
+            for (int c = 0; c < n; ++c)
+                v += Vi[(size_t)c * nzs + r] * (p.x0[(size_t)inst * n + c] - p.xref[(size_t)inst * p.xref_stride + c]);
+            const int k = r / m, a = r % m;
+            const double up = uprev[(size_t)inst * nz + (size_t)(k + 1 < N ? k + 1 : N - 1) * m + a];
+            const double ur = p.uref[(size_t)inst * p.uref_stride + r], di = 1.0 / dv[r];
+            const double lo = (p.umin[a] - ur) * di, hi = (p.umax[a] - ur) * di;  // as k_admm_inst forms them
+            z = fmin(fmax((up - ur) * di, lo), hi);
+            y = (z >= hi) ? 1.0 : ((z <= lo) ? -1.0 : 0.0);
+        }
+        p.xs[o + r] = z; p.zs[o + r] = z; p.ys[o + r] = y; p.v0[o + r] = v;
+    }
+    if (lane == 0) {
+        p.iters[inst] = 0;
+        p.status[inst] = 1;   // "not converged": the finish sets 0 when it certifies the optimum
+        p.piters[inst] = 0;
+        p.perm[inst] = inst;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_design_instance: condensed Hessian and gradient matrix of ONE instance per workgroup, entirely in LDS.
 // The dense route (k_design_gamma + k_design_hessian) materialises Gamma_i and Qbar Gamma_i in HBM (2 x 393 KB per quadrotor-size

@@ -448,6 +448,22 @@ def main():
             best3 = min(best3, time.perf_counter() - t0)
         t3 = s3.relin_fnn_timing()
         r3 = s3.get_results(want=("status", "u", "polish_iters"))
+        # the same pipeline in closed loop on the network itself (x0 <- fnn(x0, u[:,1]) on the device), warm steps: working-set guess
+        # from the previous inputs shifted one stage, no ADMM phase, one inverse per design.  40 steps from X03, best of 3.
+        o3w = capi.default_opts(warm_start=1)
+        kcl3, bestcl3, st_cl3 = 40, float("inf"), None
+        for _rep in range(3):
+            s3.update_initialization(X03)
+            s3.relin_fnn_step(o3)
+            s3.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(kcl3):
+                s3.relin_fnn_advance()
+                s3.relin_fnn_step(o3w, sync=False)
+            s3.synchronize()
+            bestcl3 = min(bestcl3, time.perf_counter() - t0)
+            st_cl3 = s3.get_results(want=("status",))["status"]
+        t3w = s3.relin_fnn_timing()
         import mpc_oracle as mo   # checker: exact optimum of sampled instances' own QPs
         fo3 = mo.FnnModel(W_in, W_h, b_h, W_out, "relu")
         err3 = 0.0
@@ -460,6 +476,10 @@ def main():
                                     "ms_per_step": 1e3 * best3 / k3, "instance_steps_per_s": k3 * b3 / best3,
                                     "stage_ms": t3, "status_counts": np.bincount(r3["status"], minlength=3).tolist(),
                                     "polish_iters_max": int(r3["polish_iters"].max()), "u_err_inf_sampled": err3,
+                                    "closed_loop_warm": {"value": kcl3 / bestcl3, "ms_per_step": 1e3 * bestcl3 / kcl3, "stage_ms": t3w,
+                                                         "status_counts_last": np.bincount(st_cl3, minlength=3).tolist(),
+                                                         "note": "plant = the network (almpc_relin_fnn_advance), opts.warm_start = 1: "
+                                                                 "shifted-previous-inputs guess, no ADMM phase, one inverse per design"},
                                     "note": "one step = Jacobians at (x0_i, u_ref[:,1]) + per-instance condensed designs + ADMM + polish on the "
                                             "handle's stream (almpc_relin_fnn_step); stage_ms: HIP events of the last step"}
         s3.close()

@@ -253,6 +253,10 @@ int almpc_sqp_fnn_set_step_rule(almpc_handle* h, int rule);
  *           almpc_fnn_linearize + almpc_dare); input box; rho, sigma.  Replaces any earlier design of the handle.
  *   step    opts as almpc_calculate.  An instance whose condensed Hessian comes out without a positive diagonal / pivot (flagged by
  *           the design kernels) gets status ALMPC_NON_FINITE instead of a host-side error.
+ *           opts->warm_start = 1 (after a solved step of this pipeline): the working-set guess is the previous step's input
+ *           trajectory shifted by one stage instead of an ADMM phase, and the design needs one inverse per instance instead of two
+ *           (the exact finish makes the two starts equivalent).
+ *   advance x0 <- fnn(x0, u[:,1]) on the device: the closed loop of the black-box model itself, no host round trip.
  *   timing  (ALMPC_FLAG_TIMING) milliseconds of the last step's three stages.
  */
 int almpc_relin_fnn_setup(almpc_handle* h, int H, int L, int activation, const double* W_in, const double* W_h, const double* b_h,
@@ -260,6 +264,7 @@ int almpc_relin_fnn_setup(almpc_handle* h, int H, int L, int activation, const d
                           const double* S, const double* P, const double* umin, const double* umax, double rho, double sigma);
 int almpc_relin_fnn_step(almpc_handle* h, const almpc_opts* opts);
 int almpc_relin_fnn_step_async(almpc_handle* h, const almpc_opts* opts);
+int almpc_relin_fnn_advance(almpc_handle* h);
 int almpc_relin_fnn_timing(almpc_handle* h, float* ms_jacobian, float* ms_design, float* ms_step);
 
 /* H (nz*nz), F (nz*n), d (nz) of one instance after almpc_design_batched (any pointer may be NULL). */

@@ -9,7 +9,7 @@
 module AlmpcHIP
 
 export hip_solver_def, HipModeler, AlmpcOpts, design_hip, terminal_weight, design_batched!, design_sqp_fnn!, sqp_start!, sqp_iterate!,
-       design_relin_fnn!, relin_step!, update_initialization!, calculate!, read_results!,
+       design_relin_fnn!, relin_step!, relin_advance!, update_initialization!, calculate!, read_results!,
        _model_predictive_control_computation, comm_unique_id, comm_init!, comm_summary, comm_allgather_first_input
 
 const libalmpc = get(ENV, "ALMPC_LIB", "libalmpc.so")
@@ -184,10 +184,16 @@ function design_relin_fnn!(mod::HipModeler, W_in::Matrix{Float64}, W_h::Array{Fl
     return mod
 end
 
-function relin_step!(mod::HipModeler)
-    o = Ref(mod.opts)
+"one step; `warm = true` after a solved step: working-set guess from the previous inputs shifted one stage, no ADMM phase"
+function relin_step!(mod::HipModeler; warm::Bool = false)
+    o0 = mod.opts
+    o = Ref(AlmpcOpts(o0.rho, o0.sigma, o0.alpha, o0.eps_abs, o0.eps_rel, o0.max_iter, o0.check_every, o0.polish, o0.polish_max_iter,
+                      Int32(warm), o0.reserved))
     check(mod.handle, ccall((:almpc_relin_fnn_step, libalmpc), Cint, (Ptr{Cvoid}, Ref{AlmpcOpts}), mod.handle, o))
 end
+
+"x0 <- fnn(x0, u[:,1]) on the device: the closed loop of the black-box model itself (simulation studies)"
+relin_advance!(mod::HipModeler) = check(mod.handle, ccall((:almpc_relin_fnn_advance, libalmpc), Cint, (Ptr{Cvoid},), mod.handle))
 
 "copy the results of the last step into caller-owned arrays (m x N x batch, n x (N+1) x batch); returns the per-instance status"
 function read_results!(mod::HipModeler, x::Array{Float64}, e_x::Array{Float64}, u::Array{Float64}, e_u::Array{Float64})

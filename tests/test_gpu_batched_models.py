@@ -276,3 +276,58 @@ def test_relin_pipeline_on_device_equals_host_path(capi, mo):
             if a["status"][i] == 0:
                 p = mo.make_problem(A[i], B[i], N, [-1, -1], [1, 1], x_ref=x_ref, u_ref=u_ref, s=0.0 if S is None else 0.3, P=P)
                 assert np.abs(b["u"][i] - mo.solve_mpc_exact(p, X0[i])["u"]).max() <= U_TOL
+
+
+def test_relin_closed_loop_warm_steps(capi, mo):
+    """Closed loop of the black-box model itself: step -> almpc_relin_fnn_advance (x0 <- fnn(x0, u[:,1]) on the device) -> step.
+    A warm step (opts.warm_start = 1: working-set guess = previous inputs shifted one stage, no ADMM phase, one inverse per design)
+    reaches the same optimum as a cold one, and both match the exact oracle on the instance's own linearisation."""
+    f = mo.synthetic_fnn()
+    batch, N, n, m = 256, 20, 4, 2
+    x_ref = np.array([0.2, -0.1, 0.05, 0.0])[:, None] * np.ones((n, N + 1))
+    u_ref = np.array([0.1, -0.2])[:, None] * np.ones((m, N))
+    Q, R = 100.0 * np.eye(n), 0.1 * np.eye(m)
+    Al, Bl = capi.fnn_linearize(f.W_in, f.W_h, f.b_h, f.W_out, x_ref[:, -1][None], u_ref[:, -1][None], act=f.act)
+    P = capi.dare(Al[0], Bl[0], Q, R)
+    X0 = x_ref[:, 0][None, :] + mo.splitmix_normal(0x5EED0004, 11, batch, n) * 1.5
+    sw = capi.Solver(n, m, N, batch, timing=True, structured_fallback=True)
+    sc = capi.Solver(n, m, N, batch, timing=True, structured_fallback=True)
+    for s in (sw, sc):
+        s.relin_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, x_ref, u_ref, Q, R, None, P, [-1, -1], [1, 1], act=f.act)
+        s.update_initialization(X0)
+    with pytest.raises(capi.AlmpcError):   # nothing solved yet: nothing to advance with
+        sw.relin_fnn_advance()
+    warm, cold = capi.default_opts(warm_start=1), capi.default_opts()
+    x = X0.copy()
+    nact = 0
+    for step in range(6):
+        sw.relin_fnn_step(warm)            # (step 0: no previous step, so it runs cold)
+        a = sw.get_results()
+        assert np.abs(a["x"][:, :, 0] - x).max() <= 1e-12   # the device's network step = the host's, to rounding
+        x = a["x"][:, :, 0].copy()
+        sc.update_initialization(x)
+        sc.relin_fnn_step(cold)
+        b = sc.get_results()
+        assert np.all(a["status"] == 0) and np.all(b["status"] == 0), (step, np.bincount(a["status"]), np.bincount(b["status"]))
+        # two routes to one optimum.  Compared where the problem means something: a linearisation with spectral radius > 2 sends the
+        # predicted states to 1e7 within the horizon, and an input then moves the cost by 1e-17 of its value
+        sane = (np.abs(a["e_x"]).reshape(batch, -1).max(axis=1) <= 1e3) & (np.abs(b["e_x"]).reshape(batch, -1).max(axis=1) <= 1e3)
+        assert sane.mean() >= 0.98
+        assert np.abs(a["u"][sane] - b["u"][sane]).max() <= U_TOL, step
+        if step > 0:
+            assert np.all(a["iters"] == 0)                  # no ADMM phase ran
+            tw, tc = sw.relin_fnn_timing(), sc.relin_fnn_timing()
+            assert tw["design_ms"] < tc["design_ms"]
+        for i in range(step, batch, 37):
+            if not sane[i]:
+                continue
+            Ai, Bi = f.jacobian(x[i], u_ref[:, 0])
+            p = mo.make_problem(Ai, Bi, N, [-1, -1], [1, 1], x_ref=x_ref, u_ref=u_ref, P=P)
+            e = mo.solve_mpc_exact(p, x[i])
+            assert np.abs(a["u"][i] - e["u"]).max() <= U_TOL
+            nact += ((e["u"] <= -1) | (e["u"] >= 1)).sum()
+        # the plant: the network itself, on the device (checked against the host's forward pass at the next step)
+        x = np.stack([f.forward(x[i], a["u"][i][:, 0]) for i in range(batch)])
+        sw.relin_fnn_advance()
+    assert nact > 20
+    sw.close(); sc.close()
