@@ -78,6 +78,8 @@ def load():
     L.almpc_get_design_instance.restype = ctypes.c_int
     L.almpc_set_reference.argtypes = [_hp, _dp, _dp, ctypes.c_int]
     L.almpc_set_terminal_equality.argtypes = [_hp, ctypes.c_int]
+    L.almpc_set_state_box.argtypes = [_hp, _dp, _dp]
+    L.almpc_set_state_box.restype = ctypes.c_int
     L.almpc_set_rho_profile.argtypes = [_hp, ctypes.c_int]
     L.almpc_set_rho_profile.restype = ctypes.c_int
     L.almpc_set_step_fusion.argtypes = [_hp, ctypes.c_int]
@@ -248,12 +250,24 @@ class Solver:
         self._check(self.L.almpc_design_shared(self.h, _ptr(A), _ptr(B), _ptr(Q), _ptr(R), _ptr(S), _ptr(P), _ptr(umin),
                                                _ptr(umax), _ptr(xmin), _ptr(xmax), float(rho), float(sigma)))
 
+    def _state_rows(self, xmin, xmax, terminal):
+        """State box / terminal equality of the designs without xmin / xmax arguments (almpc_set_state_box, almpc_set_terminal_equality)."""
+        if (xmin is None) != (xmax is None):
+            raise ValueError("give both xmin and xmax or neither")
+        self._check(self.L.almpc_set_terminal_equality(self.h, 1 if terminal == "equality" else 0))
+        if xmin is None:
+            self._check(self.L.almpc_set_state_box(self.h, None, None))
+        else:
+            lo = np.ascontiguousarray(xmin, dtype=np.float64).reshape(self.n)
+            hi = np.ascontiguousarray(xmax, dtype=np.float64).reshape(self.n)
+            self._check(self.L.almpc_set_state_box(self.h, _ptr(lo), _ptr(hi)))
+
     def design_batched(self, A_batch, B_batch, Q, R, S=None, P=None, umin=None, umax=None, rho=0.1, sigma=1e-6,
-                       rho_profile="scalar"):
+                       rho_profile="scalar", xmin=None, xmax=None, terminal="none"):
         """One model per instance: A_batch (batch, n, n), B_batch (batch, n, m).  P: None (DARE per instance), (n, n) shared
-        or (batch, n, n)."""
+        or (batch, n, n).  xmin / xmax: state box (stages 1..N+1); terminal = "equality": e_x[:, N+1] = 0."""
         n, m, b = self.n, self.m, self.batch
-        self._check(self.L.almpc_set_terminal_equality(self.h, 0))
+        self._state_rows(xmin, xmax, terminal)
         self._check(self.L.almpc_set_rho_profile(self.h, {"scalar": 0, "stiffness": 1}[rho_profile]))
         A = np.ascontiguousarray(np.asarray(A_batch, dtype=np.float64).reshape(b, n, n).transpose(0, 2, 1))  # column-major blocks
         B = np.ascontiguousarray(np.asarray(B_batch, dtype=np.float64).reshape(b, n, m).transpose(0, 2, 1))
@@ -276,7 +290,7 @@ class Solver:
         """Time-varying models: A_all (batch, N, n, n), B_all (batch, N, n, m), c_all (batch, N, n) or None, xbar (batch, n, N+1),
         ubar (batch, m, N), x_ref (n, N+1) / u_ref (m, N) or None, P (n, n) or (batch, n, n).  The QP variable is v = u - ubar."""
         n, m, N, b = self.n, self.m, self.N, self.batch
-        self._check(self.L.almpc_set_terminal_equality(self.h, 0))
+        self._state_rows(None, None, "none")
         self._check(self.L.almpc_set_rho_profile(self.h, {"scalar": 0, "stiffness": 1}[rho_profile]))
         A = np.ascontiguousarray(np.asarray(A_all, dtype=np.float64).reshape(b, N, n, n).transpose(0, 1, 3, 2))
         B = np.ascontiguousarray(np.asarray(B_all, dtype=np.float64).reshape(b, N, n, m).transpose(0, 1, 3, 2))
@@ -303,7 +317,7 @@ class Solver:
         """SQP outer loop for an Fnn model (almpc_sqp_fnn_*): network as in fnn_linearize, x_ref (n, N+1) / u_ref (m, N) or None,
         P (n, n) or (batch, n, n)."""
         n, m, N, b = self.n, self.m, self.N, self.batch
-        self._check(self.L.almpc_set_terminal_equality(self.h, 0))
+        self._state_rows(None, None, "none")
         self._check(self.L.almpc_set_rho_profile(self.h, {"scalar": 0, "stiffness": 1}[rho_profile]))
         W_in, W_out = np.asfortranarray(W_in, dtype=np.float64), np.asfortranarray(W_out, dtype=np.float64)
         H = W_in.shape[0]
@@ -327,11 +341,11 @@ class Solver:
                                                float(sigma)))
 
     def relin_fnn_setup(self, W_in, W_h, b_h, W_out, x_ref, u_ref, Q, R, S=None, P=None, umin=None, umax=None, act="relu", rho=0.1,
-                        sigma=1e-6, rho_profile="scalar"):
+                        sigma=1e-6, rho_profile="scalar", xmin=None, xmax=None, terminal="none"):
         """Device-resident per-step re-linearisation of an Fnn model (almpc_relin_fnn_*, BASELINE configs[3]): network as in
-        fnn_linearize, shared x_ref (n, N+1) / u_ref (m, N) or None, shared P (n, n)."""
+        fnn_linearize, shared x_ref (n, N+1) / u_ref (m, N) or None, shared P (n, n); xmin / xmax / terminal as in design_batched."""
         n, m, N = self.n, self.m, self.N
-        self._check(self.L.almpc_set_terminal_equality(self.h, 0))
+        self._state_rows(xmin, xmax, terminal)
         self._check(self.L.almpc_set_rho_profile(self.h, {"scalar": 0, "stiffness": 1}[rho_profile]))
         W_in, W_out = np.asfortranarray(W_in, dtype=np.float64), np.asfortranarray(W_out, dtype=np.float64)
         H = W_in.shape[0]

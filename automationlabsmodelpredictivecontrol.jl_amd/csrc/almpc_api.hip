@@ -64,6 +64,9 @@ struct almpc_handle {
     double *dGhat = nullptr, *dGnorm = nullptr, *dXmin = nullptr, *dXmax = nullptr;
     int *dRowTraj = nullptr, *dRowEq = nullptr, *dRowXidx = nullptr, *dRowState = nullptr;
     int32_t* dOverflow = nullptr;  // [2 + batch] k_polish_gen: count, cursor and list of instances to redo with the 64-row build
+    int* dRowMap = nullptr;        // [N*n] state (stage k+2, i) -> state-row index or -1 (k_ghat_inst)
+    bool ghat_inst = false;        // dGhat / dGnorm hold one constraint-space matrix PER INSTANCE ([batch][R][Rs], [batch][Rs])
+    std::vector<double> boxmin, boxmax;  // almpc_set_state_box: the state box of the per-instance / time-varying / SQP designs
     // per-instance models (almpc_design_batched): persistent per-instance operands ...
     bool batched = false;
     bool ltv = false;             // almpc_design_ltv: references and gradient are part of the design
@@ -170,7 +173,7 @@ void free_all(almpc_handle* h) {
     void* ptrs[] = {h->dMinvFrag, h->dVFrag, h->dHFrag, h->dFFrag, h->dG, h->dD, h->dUmin, h->dUmax, h->dA, h->dB,
                     h->dXref, h->dUref, h->dFS, h->dV0S, h->dRho, h->dRollM, h->dX0, h->dXs, h->dZs, h->dYs, h->dV0, h->dW, h->dX, h->dEx,
                     h->dU, h->dEu, h->dStatus, h->dIters, h->dPiters, h->dPerm, h->dYflags, h->dSglobal, h->dGhat, h->dGnorm, h->dXmin,
-                    h->dXmax, h->dRowTraj, h->dRowEq, h->dRowXidx, h->dRowState, h->bA, h->bB, h->bMinv, h->bG, h->bHs, h->bFs,
+                    h->dXmax, h->dRowTraj, h->dRowEq, h->dRowXidx, h->dRowState, h->dRowMap, h->bA, h->bB, h->bMinv, h->bG, h->bHs, h->bFs,
                     h->bVs, h->bD, h->bRho, h->bH, h->bF, h->bPhi, h->bGk, h->bGam, h->bW, h->bWP, h->bP, h->bFlag, h->bQ, h->dOverflow,
                     h->sqp.W_in, h->sqp.W_h, h->sqp.b_h, h->sqp.W_out, h->sqp.A, h->sqp.B, h->sqp.c, h->sqp.fval, h->sqp.ebar,
                     h->sqp.qadd, h->sqp.xref, h->sqp.uref, h->sqp.Q, h->sqp.R, h->sqp.S, h->sqp.bad, h->sqp.stats, h->sqp.mer, h->sqp.xback, h->sqp.uback, h->sqp.dxback, h->sqp.vback};
@@ -188,6 +191,83 @@ void free_all(almpc_handle* h) {
         if (e) (void)hipEventDestroy(e);
     h->ev.clear();
     if (h->stream) (void)hipStreamDestroy(h->stream);
+}
+
+// State rows of a design: the state box for stages 2..N+1 (stage 1 is x0 itself, checked per instance) and / or the terminal
+// equality on stage N+1 (which then replaces the box rows of that stage).  Fills the row tables and (re)allocates the
+// constraint-space matrix: one for the handle (shared model) or one per instance.  mc = 0 afterwards: no state rows.
+int setup_state_rows(almpc_handle* h, const double* xmin, const double* xmax, bool per_instance) {
+    const int n = h->n, m = h->m, N = h->N, nz = h->nz;
+    h->has_box = xmin ? 1 : 0;
+    std::vector<int> row_traj, row_eq, row_xidx, row_state, rowmap((size_t)N * n, -1);
+    if (h->has_box)
+        for (int i = 0; i < n; ++i)
+            if (!(xmin[i] <= xmax[i])) return fail(h, ALMPC_ERR_INVALID, "design: xmin > xmax");
+    for (int k = 0; k < N; ++k)
+        for (int i = 0; i < n; ++i) {
+            const bool is_eq = h->terminal_eq && k == N - 1;
+            if (!(h->has_box || is_eq)) continue;
+            rowmap[(size_t)k * n + i] = (int)row_traj.size();
+            row_traj.push_back((k + 1) * (n + m) + i);
+            row_eq.push_back(is_eq ? 1 : 0);
+            row_xidx.push_back((k + 1) * n + i);
+            row_state.push_back(i);
+        }
+    h->mc = (int)row_traj.size();
+    h->R = nz + h->mc;
+    h->np_pairs = (h->R + 127) / 128;
+    h->Rs = 128 * h->np_pairs;
+    for (void* q : {(void*)h->dGhat, (void*)h->dGnorm, (void*)h->dXmin, (void*)h->dXmax, (void*)h->dRowTraj, (void*)h->dRowEq,
+                    (void*)h->dRowXidx, (void*)h->dRowState, (void*)h->dRowMap})
+        if (q) (void)hipFree(q);
+    h->dGhat = h->dGnorm = h->dXmin = h->dXmax = nullptr;
+    h->dRowTraj = h->dRowEq = h->dRowXidx = h->dRowState = h->dRowMap = nullptr;
+    h->ghat_inst = false;
+    if (h->mc == 0) return ALMPC_OK;
+    if (h->np_pairs > 4) return fail(h, ALMPC_ERR_UNSUPPORTED, "design: state rows need n*N + m*N <= 512");
+    if ((size_t)(N + 1) * (n + m) > 32 * 32) return fail(h, ALMPC_ERR_UNSUPPORTED, "design: state rows need (N+1)*(n+m) <= 1024");
+    if (per_instance && n > 32) return fail(h, ALMPC_ERR_UNSUPPORTED, "design: state rows with per-instance models need n <= 32");
+    const size_t copies = per_instance ? (size_t)h->batch : 1;
+    HIP_TRY(h, dalloc(&h->dGhat, copies * h->R * h->Rs));
+    HIP_TRY(h, dalloc(&h->dGnorm, copies * h->Rs));
+    if (per_instance) HIP_TRY(h, hipMemset(h->dGhat, 0, copies * h->R * h->Rs * sizeof(double)));  // (the padding columns stay zero)
+    HIP_TRY(h, dalloc(&h->dXmin, (size_t)n)); HIP_TRY(h, dalloc(&h->dXmax, (size_t)n));
+    HIP_TRY(h, dalloc(&h->dRowTraj, (size_t)h->Rs)); HIP_TRY(h, dalloc(&h->dRowEq, (size_t)h->Rs));
+    HIP_TRY(h, dalloc(&h->dRowXidx, (size_t)h->Rs)); HIP_TRY(h, dalloc(&h->dRowState, (size_t)h->Rs));
+    HIP_TRY(h, dalloc(&h->dRowMap, rowmap.size()));
+    HIP_TRY(h, hipMemcpy(h->dRowMap, rowmap.data(), rowmap.size() * sizeof(int), hipMemcpyHostToDevice));
+    auto up = [&](int* dst, const std::vector<int>& v, int fill) {
+        std::vector<int> full((size_t)h->Rs, fill);
+        for (size_t i = 0; i < v.size(); ++i) full[(size_t)nz + i] = v[i];
+        return hipMemcpy(dst, full.data(), full.size() * sizeof(int), hipMemcpyHostToDevice);
+    };
+    HIP_TRY(h, up(h->dRowTraj, row_traj, 0)); HIP_TRY(h, up(h->dRowEq, row_eq, 0));
+    HIP_TRY(h, up(h->dRowXidx, row_xidx, 0)); HIP_TRY(h, up(h->dRowState, row_state, 0));
+    std::vector<double> lo(n, -1e300), hi(n, 1e300);
+    if (h->has_box) { lo.assign(xmin, xmin + n); hi.assign(xmax, xmax + n); }
+    HIP_TRY(h, hipMemcpy(h->dXmin, lo.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->dXmax, hi.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    h->ghat_inst = per_instance;
+    return ALMPC_OK;
+}
+
+// Ghat_i of every instance from the per-instance design in place (G_i, d_i) and the models the rows roll out through: the
+// time-invariant slots (bA, bB) or stage models [batch][N][..] (A_all / B_all non-null).  Launch only (handle's stream).
+hipError_t launch_ghat_inst(almpc_handle* h, const double* A_all, const double* B_all) {
+    GhatInstParams gp;
+    gp.n = h->n; gp.m = h->m; gp.N = h->N; gp.nz = h->nz; gp.nzs = h->nzs; gp.mc = h->mc; gp.R = h->R; gp.Rs = h->Rs;
+    const long n = h->n, m = h->m, N = h->N;
+    if (A_all) { gp.A = A_all; gp.B = B_all; gp.A_stride = N * n * n; gp.B_stride = N * n * m; gp.A_kstride = n * n; gp.B_kstride = n * m; }
+    else { gp.A = h->bA; gp.B = h->bB; gp.A_stride = n * n; gp.B_stride = n * m; gp.A_kstride = 0; gp.B_kstride = 0; }
+    gp.G = h->bG; gp.G_stride = (long)h->nz * h->nzs; gp.dvec = h->bD; gp.d_stride = h->nzs;
+    gp.rowmap = h->dRowMap; gp.Ghat = h->dGhat; gp.Ghat_stride = (long)h->R * h->Rs; gp.gnorm = h->dGnorm; gp.gnorm_stride = h->Rs;
+    const size_t lds = (size_t)(n * (n + m) + 2) * sizeof(double);
+    const dim3 grid((unsigned)h->batch), block(GHAT_THREADS);
+    if (n <= 4) hipLaunchKernelGGL((k_ghat_inst<4>), grid, block, lds, h->stream, gp);
+    else if (n <= 8) hipLaunchKernelGGL((k_ghat_inst<8>), grid, block, lds, h->stream, gp);
+    else if (n <= 16) hipLaunchKernelGGL((k_ghat_inst<16>), grid, block, lds, h->stream, gp);
+    else hipLaunchKernelGGL((k_ghat_inst<32>), grid, block, lds, h->stream, gp);
+    return hipGetLastError();
 }
 
 // Device copies of the weights the structured solve uses (R with the reference's branch rule applied: zero if R[1,1] == 0)
@@ -387,6 +467,21 @@ int almpc_set_terminal_equality(almpc_handle* h, int on) {
     return ALMPC_OK;
 }
 
+int almpc_set_state_box(almpc_handle* h, const double* xmin, const double* xmax) {
+    if (!h) return ALMPC_ERR_INVALID;
+    if ((xmin == nullptr) != (xmax == nullptr)) return fail(h, ALMPC_ERR_INVALID, "set_state_box: give both xmin and xmax or neither");
+    if (h->structured && xmin) return fail(h, ALMPC_ERR_UNSUPPORTED, "structured solve: input box only (no state rows)");
+    if (xmin) {
+        for (int i = 0; i < h->n; ++i)
+            if (!(xmin[i] <= xmax[i])) return fail(h, ALMPC_ERR_INVALID, "set_state_box: xmin > xmax");
+        h->boxmin.assign(xmin, xmin + h->n); h->boxmax.assign(xmax, xmax + h->n);
+    } else { h->boxmin.clear(); h->boxmax.clear(); }
+    h->designed = false;  // takes effect at the next per-instance / time-varying / SQP design
+    h->sqp.ready = h->sqp.started = false;
+    h->relin.ready = false;
+    return ALMPC_OK;
+}
+
 int almpc_set_structured_fallback(almpc_handle* h, int on) {
     if (!h) return ALMPC_ERR_INVALID;
     if (on && !riccati_shape_ok(h)) return fail(h, ALMPC_ERR_UNSUPPORTED, "structured fallback: needs n <= 32, m <= 16 and its buffers in 160 KB of LDS");
@@ -450,52 +545,12 @@ int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const
     h->useS = (Rm[0] != 0.0 && Sm[0] != 0.0) ? 1 : 0;  // the reference drops the S term together with R (src/sub/design_mpc.jl:423-466)
     h->rho = rho; h->sigma = sigma;
 
-    // ---- state rows: the state box for stages 2..N+1 (stage 1 is x0 itself, checked per instance) and/or the terminal
-    // equality on stage N+1 (which then replaces the box rows of that stage)
-    h->has_box = xmin ? 1 : 0;
-    std::vector<int> rowsel, row_traj, row_eq, row_xidx, row_state;
-    if (h->has_box)
-        for (int i = 0; i < n; ++i)
-            if (!(xmin[i] <= xmax[i])) return fail(h, ALMPC_ERR_INVALID, "design: xmin > xmax");
+    // ---- state rows (state box, terminal equality): row tables and the shared constraint-space matrix
+    { const int rc_ = setup_state_rows(h, xmin, xmax, false); if (rc_ != ALMPC_OK) return rc_; }
+    std::vector<int> rowsel;   // rows of Gamma the state rows are, in row order
     for (int k = 0; k < N; ++k)
-        for (int i = 0; i < n; ++i) {
-            const bool is_eq = h->terminal_eq && k == N - 1;
-            if (!(h->has_box || is_eq)) continue;
-            rowsel.push_back(k * n + i);
-            row_traj.push_back((k + 1) * (n + m) + i);
-            row_eq.push_back(is_eq ? 1 : 0);
-            row_xidx.push_back((k + 1) * n + i);
-            row_state.push_back(i);
-        }
-    h->mc = (int)rowsel.size();
-    h->R = nz + h->mc;
-    h->np_pairs = (h->R + 127) / 128;
-    h->Rs = 128 * h->np_pairs;
-    for (void* q : {(void*)h->dGhat, (void*)h->dGnorm, (void*)h->dXmin, (void*)h->dXmax, (void*)h->dRowTraj, (void*)h->dRowEq,
-                    (void*)h->dRowXidx, (void*)h->dRowState})
-        if (q) (void)hipFree(q);
-    h->dGhat = h->dGnorm = h->dXmin = h->dXmax = nullptr;
-    h->dRowTraj = h->dRowEq = h->dRowXidx = h->dRowState = nullptr;
-    if (h->mc > 0) {
-        if (h->np_pairs > 4) return fail(h, ALMPC_ERR_UNSUPPORTED, "design: state rows need n*N + m*N <= 512");
-        if ((size_t)(N + 1) * (n + m) > 32 * 32) return fail(h, ALMPC_ERR_UNSUPPORTED, "design: state rows need (N+1)*(n+m) <= 1024");
-        HIP_TRY(h, dalloc(&h->dGhat, (size_t)h->R * h->Rs));
-        HIP_TRY(h, dalloc(&h->dGnorm, (size_t)h->Rs));
-        HIP_TRY(h, dalloc(&h->dXmin, (size_t)n)); HIP_TRY(h, dalloc(&h->dXmax, (size_t)n));
-        HIP_TRY(h, dalloc(&h->dRowTraj, (size_t)h->Rs)); HIP_TRY(h, dalloc(&h->dRowEq, (size_t)h->Rs));
-        HIP_TRY(h, dalloc(&h->dRowXidx, (size_t)h->Rs)); HIP_TRY(h, dalloc(&h->dRowState, (size_t)h->Rs));
-        auto up = [&](int* dst, const std::vector<int>& v, int fill) {
-            std::vector<int> full((size_t)h->Rs, fill);
-            for (size_t i = 0; i < v.size(); ++i) full[(size_t)nz + i] = v[i];
-            return hipMemcpy(dst, full.data(), full.size() * sizeof(int), hipMemcpyHostToDevice);
-        };
-        HIP_TRY(h, up(h->dRowTraj, row_traj, 0)); HIP_TRY(h, up(h->dRowEq, row_eq, 0));
-        HIP_TRY(h, up(h->dRowXidx, row_xidx, 0)); HIP_TRY(h, up(h->dRowState, row_state, 0));
-        std::vector<double> lo(n, -1e300), hi(n, 1e300);
-        if (h->has_box) { lo.assign(xmin, xmin + n); hi.assign(xmax, xmax + n); }
-        HIP_TRY(h, hipMemcpy(h->dXmin, lo.data(), n * sizeof(double), hipMemcpyHostToDevice));
-        HIP_TRY(h, hipMemcpy(h->dXmax, hi.data(), n * sizeof(double), hipMemcpyHostToDevice));
-    }
+        for (int i = 0; i < n; ++i)
+            if (h->has_box || (h->terminal_eq && k == N - 1)) rowsel.push_back(k * n + i);
     int rc = design_shared_device(h->stream, n, m, N, h->nzs, h->nrb, h->ks, h->ksf, Am, Bm, Qm, Rm, Sm, Pm, rho, sigma,
                                   h->dMinvFrag, h->dVFrag, h->dHFrag, h->dFFrag, h->dG, h->dD, h->H, h->F, h->d, h->err,
                                   rowsel, h->Rs, h->dGhat, h->dGnorm, h->rho_mode, h->dRho);
@@ -764,7 +819,6 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
     }
     if (!A_batch || !B_batch || !Q || !R || !umin || !umax) return fail(h, ALMPC_ERR_INVALID, "design_batched: null matrix pointer");
     if (!(rho > 0.0) || !(sigma >= 0.0)) return fail(h, ALMPC_ERR_INVALID, "design_batched: rho must be > 0 and sigma >= 0");
-    if (h->terminal_eq) return fail(h, ALMPC_ERR_UNSUPPORTED, "design_batched: state rows (terminal equality) need a shared model");
     h->designed = false;  // the previous design is overwritten below; set again by the last statement on success
     h->sqp.ready = h->sqp.started = false;
     h->relin.ready = false;
@@ -803,10 +857,12 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
     h->P.assign(Pall.begin(), Pall.begin() + (size_t)n * n);
     h->hS = Sm;
     h->rho = rho; h->sigma = sigma;
-    h->has_box = 0; h->mc = 0; h->R = nz; h->np_pairs = 1; h->Rs = 128;
     const int useR = Rm[0] != 0.0, useS = useR && Sm[0] != 0.0;
     h->useS = useS;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    // state rows (almpc_set_state_box, almpc_set_terminal_equality): one constraint-space matrix per instance
+    { const int rc_ = setup_state_rows(h, h->boxmin.empty() ? nullptr : h->boxmin.data(), h->boxmax.empty() ? nullptr : h->boxmax.data(), true);
+      if (rc_ != ALMPC_OK) return rc_; }
     { const int rc_ = ensure_batched_alloc(h); if (rc_ != ALMPC_OK) return rc_; }
     hipStream_t st = h->stream;
     double *dQ = nullptr, *dR = nullptr, *dS = nullptr;
@@ -847,15 +903,20 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
             lp.qadd = dQa; lp.H = h->bH; lp.q = h->bQ;
             e = launch_design_ltv(h, lp, st);
         }
+        if (e == hipSuccess && h->mc > 0) {   // (needs G_i, d_i: the factor step comes first when there are state rows)
+            e = ensure_dyn_lds(reinterpret_cast<const void*>(k_design_inverse), 520 * sizeof(double));
+            if (e == hipSuccess) { launch_batched_factor(h, ds, rho, sigma, st); e = launch_ghat_inst(h, dAll, dBll); }
+        }
         if (e == hipSuccess) e = hipStreamSynchronize(st);  // the staging buffers are released right away
         (void)hipFree(dAll); (void)hipFree(dBll); (void)hipFree(dC); (void)hipFree(dE); (void)hipFree(dQa);
         if (e != hipSuccess) { release(); return fail(h, ALMPC_ERR_HIP, std::string("design_ltv: ") + hipGetErrorString(e)); }
         BTRY(ensure_dyn_lds(reinterpret_cast<const void*>(k_design_inverse), 520 * sizeof(double)));
-        launch_batched_factor(h, ds, rho, sigma, st);
+        if (h->mc == 0) launch_batched_factor(h, ds, rho, sigma, st);
         hipLaunchKernelGGL(k_neg_gm, dim3(4, gb), dim3(256), 0, st, nz, nzs, n, nzs, h->bG, h->bFs, h->bVs, ds.G, ds.Fs);
         BTRY(hipGetLastError());
     } else {
         BTRY(launch_batched_design(h, ds, useR, useS, dQ, dR, dS, rho, sigma));
+        if (h->mc > 0) BTRY(launch_ghat_inst(h, nullptr, nullptr));
     }
     std::vector<int> flags(b, 0);
     BTRY(hipMemcpyAsync(flags.data(), h->bFlag, b * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1047,7 +1108,8 @@ int almpc_relin_fnn_setup(almpc_handle* h, int H, int L, int activation, const d
     if (!q.xnext) HIP_TRY(h, dalloc(&q.xnext, b * n));
     h->P = Pm; h->hS = Sm; h->useS = q.useS;
     h->rho = rho; h->sigma = sigma;
-    h->has_box = 0; h->mc = 0; h->R = nz; h->np_pairs = 1; h->Rs = 128;
+    { const int rc_ = setup_state_rows(h, h->boxmin.empty() ? nullptr : h->boxmin.data(), h->boxmax.empty() ? nullptr : h->boxmax.data(), true);
+      if (rc_ != ALMPC_OK) return rc_; }
     h->batched = true; h->ltv = false;
     h->state_valid = true;
     if (h->fallback) {
@@ -1087,6 +1149,7 @@ int almpc_relin_fnn_step_async(almpc_handle* h, const almpc_opts* opts) {
         const hipError_t e_ = launch_batched_design(h, ds, q.useR, q.useS, q.Q, q.R, q.S, h->rho, h->sigma);
         if (e_ != hipSuccess) { h->skip_admm = 0; return fail(h, ALMPC_ERR_HIP, std::string("relin design: ") + hipGetErrorString(e_)); }
     }
+    if (h->mc > 0) HIP_TRY(h, launch_ghat_inst(h, nullptr, nullptr));
     if (q.useS) {
         hipLaunchKernelGGL(k_fs_scale, dim3(256), dim3(256), 0, st, h->batch, nz, nzs, q.gS, 0L, h->bD, h->dFS);
         hipLaunchKernelGGL(k_neg_gm, dim3(1, (unsigned)h->batch), dim3(256), 0, st, nz, nzs, 1, nz, h->bG, h->dFS, h->dV0S,
@@ -1246,6 +1309,7 @@ int almpc_sqp_fnn_setup(almpc_handle* h, int H, int L, int activation, const dou
     h->hS = Sm;
     h->useS = q.useS;
     h->rho = rho; h->sigma = sigma;
+    if (!h->boxmin.empty() || h->terminal_eq) return fail(h, ALMPC_ERR_UNSUPPORTED, "sqp_fnn_setup: state rows are not built for the SQP loop");
     h->has_box = 0; h->mc = 0; h->R = nz; h->np_pairs = 1; h->Rs = 128;
     h->xref_stride = (long)n * (N + 1); h->uref_stride = nz; h->fS_stride = nz;
     h->designed = false;  // becomes true with the first iteration's design
@@ -1617,9 +1681,15 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         { const int rc_ = flush_admm(); if (rc_ != ALMPC_OK) return rc_; }
         PolishGenParams gp;
         gp.nz = h->nz; gp.mc = h->mc; gp.R = h->R; gp.Rs = h->Rs; gp.m = h->m; gp.n = h->n; gp.N = h->N; gp.batch = h->batch; gp.nzs = h->nzs;
+        if (h->batched && !h->ghat_inst) return fail(h, ALMPC_ERR_NOT_DESIGNED, "calculate: state rows without their per-instance matrices");
+        if (h->ltv) return fail(h, ALMPC_ERR_UNSUPPORTED, "calculate: state rows with a time-varying design are not built");
+        if (h->batched) {
+            gp.Ghat_stride = (long)h->R * h->Rs; gp.gnorm_stride = h->Rs; gp.d_stride = h->nzs;
+            gp.A_stride = (long)h->n * h->n; gp.B_stride = (long)h->n * h->m;
+        }
         gp.Ghat = h->dGhat; gp.gnorm = h->dGnorm; gp.row_traj = h->dRowTraj; gp.row_eq = h->dRowEq; gp.row_xidx = h->dRowXidx;
         gp.row_state = h->dRowState; gp.xmin = h->dXmin; gp.xmax = h->dXmax; gp.has_box = h->has_box;
-        gp.dvec = h->dD; gp.umin = h->dUmin; gp.umax = h->dUmax; gp.uref = h->dUref; gp.uref_stride = h->uref_stride;
+        gp.dvec = h->batched ? h->bD : h->dD; gp.umin = h->dUmin; gp.umax = h->dUmax; gp.uref = h->dUref; gp.uref_stride = h->uref_stride;
         gp.zs = h->dZs; gp.ys = h->dYs; gp.v0 = h->dV0; gp.status = h->dStatus; gp.piters = h->dPiters;
         gp.max_iter = o.polish_max_iter > 0 ? o.polish_max_iter : 20 * h->R + 50;
         gp.roll_g = roll_g; gp.roll_cpl = roll_cpl; gp.roll = rp;

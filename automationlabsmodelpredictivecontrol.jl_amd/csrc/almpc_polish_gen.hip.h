@@ -28,6 +28,7 @@ struct PolishGenParams {
     int nz, mc, R, Rs, m, n, N, batch, nzs;
     const double* Ghat;   // [R][Rs] dense symmetric
     const double* gnorm;  // [Rs] sqrt(Ghat_rr) (pad rows: 1)
+    long Ghat_stride = 0, gnorm_stride = 0, d_stride = 0, A_stride = 0, B_stride = 0;  // per-instance models: doubles between instances
     const int* row_traj;  // [Rs] for state rows: offset of e_x[i,k] in the wave's trajectory buffer Z ((k)*C + i); else -1
     const int* row_eq;    // [Rs] 1 for terminal-equality rows
     const int* row_xidx;  // [Rs] for state rows: i + n*k index into x_ref (k = reference stage 2..N+1 -> 1..N); else 0
@@ -72,6 +73,11 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
     }
     const int st_in = p.status[inst];
     const int nz = p.nz, nzs = p.nzs, R = p.R, Rs = p.Rs;
+    const double* Gh = p.Ghat + (size_t)inst * p.Ghat_stride;
+    const double* gnv = p.gnorm + (size_t)inst * p.gnorm_stride;
+    const double* dvi = p.dvec + (size_t)inst * p.d_stride;
+    const double* Ai = p.roll.A + (size_t)inst * p.A_stride;
+    const double* Bi = p.roll.B + (size_t)inst * p.B_stride;
     const size_t base = (size_t)inst * nzs;
     const int pos = lane & (WL - 1), hf = (HS == 2) ? (lane >> 5) : 0;
     const bool lowhalf = lane < WL;
@@ -97,7 +103,7 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
         const d2 vv = *reinterpret_cast<const d2*>(p.v0 + base + rc);
         const d2 yy = *reinterpret_cast<const d2*>(p.ys + base + rc);
         const d2 zz = *reinterpret_cast<const d2*>(p.zs + base + rc);
-        const d2 dv = *reinterpret_cast<const d2*>(p.dvec + rc);
+        const d2 dv = *reinterpret_cast<const d2*>(dvi + rc);
         y0 = yy[0]; y1 = yy[1]; z0 = zz[0]; z1 = zz[1];
         // trajectory of v0: Z rows [e_x(k); e_u(k)]
         for (int e = 0; e < 2; ++e) {
@@ -111,10 +117,10 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
         }
         wave_fence_lds();
         switch (p.roll_cpl) {
-            case 1: rollout_steps<1>(Z, n, m, N, p.roll_g, lane, rp.A, rp.B); break;
-            case 2: rollout_steps<2>(Z, n, m, N, p.roll_g, lane, rp.A, rp.B); break;
-            case 4: rollout_steps<4>(Z, n, m, N, p.roll_g, lane, rp.A, rp.B); break;
-            default: rollout_steps<8>(Z, n, m, N, p.roll_g, lane, rp.A, rp.B); break;
+            case 1: rollout_steps<1>(Z, n, m, N, p.roll_g, lane, Ai, Bi); break;
+            case 2: rollout_steps<2>(Z, n, m, N, p.roll_g, lane, Ai, Bi); break;
+            case 4: rollout_steps<4>(Z, n, m, N, p.roll_g, lane, Ai, Bi); break;
+            default: rollout_steps<8>(Z, n, m, N, p.roll_g, lane, Ai, Bi); break;
         }
 #pragma unroll
         for (int q = 0; q < NP; ++q)
@@ -126,7 +132,7 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
                 act[q][e] = false;
                 bnd[q][e] = 0.0;
                 const int rcl = valid[q][e] ? r : 0;
-                gn[q][e] = valid[q][e] ? p.gnorm[rcl] : 1.0;
+                gn[q][e] = valid[q][e] ? gnv[rcl] : 1.0;
                 if (r < nz) {  // input row, bounds exactly as k_admm forms them
                     const double di = 1.0 / (e ? dv[1] : dv[0]);
                     const double ur = p.uref[(size_t)inst * p.uref_stride + r];
@@ -203,7 +209,7 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
 #pragma unroll
                 for (int t = 0; t < CH; ++t) {
                     const int off = 2 * lane + 128 * q;
-                    g[t] = *reinterpret_cast<const d2*>(p.Ghat + (size_t)wrow_s[l0 + t] * Rs + (off < Rs ? off : 0));
+                    g[t] = *reinterpret_cast<const d2*>(Gh + (size_t)wrow_s[l0 + t] * Rs + (off < Rs ? off : 0));
                     av[t] = ab[l0 + t];
                 }
 #pragma unroll
@@ -215,7 +221,7 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             const int off = 2 * lane + 128 * q;
-            const d2 g = *reinterpret_cast<const d2*>(p.Ghat + (size_t)j * Rs + (off < Rs ? off : 0));
+            const d2 g = *reinterpret_cast<const d2*>(Gh + (size_t)j * Rs + (off < Rs ? off : 0));
             gj[q][0] = g[0]; gj[q][1] = g[1];
         }
     };
@@ -486,7 +492,7 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
     {
         const int r0 = 2 * lane, r1 = 2 * lane + 1;
         const int rc = (r0 < nzs) ? r0 : 0;
-        const d2 dvp = *reinterpret_cast<const d2*>(p.dvec + rc);
+        const d2 dvp = *reinterpret_cast<const d2*>(dvi + rc);
         if (r0 < nz) {
             const double ur = rp.uref[(size_t)inst * rp.uref_stride + r0];
             const double uu = fmin(fmax(wout[0] * dvp[0] + ur, rp.umin[r0 % m]), rp.umax[r0 % m]);
@@ -504,10 +510,10 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
         for (int i = lane; i < n; i += 64) Z[i] = rp.x0[(size_t)inst * n + i] - rp.xref[(size_t)inst * rp.xref_stride + i];
         wave_fence_lds();
         switch (p.roll_cpl) {
-            case 1: rollout_steps<1>(Z, n, m, N, p.roll_g, lane, rp.A, rp.B); break;
-            case 2: rollout_steps<2>(Z, n, m, N, p.roll_g, lane, rp.A, rp.B); break;
-            case 4: rollout_steps<4>(Z, n, m, N, p.roll_g, lane, rp.A, rp.B); break;
-            default: rollout_steps<8>(Z, n, m, N, p.roll_g, lane, rp.A, rp.B); break;
+            case 1: rollout_steps<1>(Z, n, m, N, p.roll_g, lane, Ai, Bi); break;
+            case 2: rollout_steps<2>(Z, n, m, N, p.roll_g, lane, Ai, Bi); break;
+            case 4: rollout_steps<4>(Z, n, m, N, p.roll_g, lane, Ai, Bi); break;
+            default: rollout_steps<8>(Z, n, m, N, p.roll_g, lane, Ai, Bi); break;
         }
         const int nx = n * (N + 1);
         const size_t xo = (size_t)inst * nx;
@@ -519,6 +525,97 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
     }
     if (QUEUE) wave_fence_lds();  // the next instance reuses this wave's LDS slot
   } while (QUEUE);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// k_ghat_inst: Ghat_i = A_i G_i A_i' of ONE instance per workgroup, for designs with a model per instance (almpc_design_batched,
+// the re-linearisation pipeline) or per instance and stage (almpc_design_ltv, the SQP loop).  The state rows of A_i = [I; C'_i] are
+// rows of the prediction matrix times the scaling, C'_i = Gamma_i[rows] D_i; applying Gamma_i to a vector is a rollout from a zero
+// state, so no prediction matrix is formed:
+//   pass 0, thread = column a < nz:   roll out the input sequence D_i G_i[:, a]     -> (C' G)[r, a]  (and its transpose block)
+//   pass 1, thread = state row w < mc: roll out the input sequence D_i (C' G)[w, :]' -> (C' G C)[r, w]
+// with the state in registers (NX >= n of them) and the stage's [A B] broadcast from LDS.  Cold path: design time only.
+struct GhatInstParams {
+    int n, m, N, nz, nzs, mc, R, Rs;
+    const double* A; const double* B;          // column-major blocks
+    long A_stride, B_stride;                   // doubles between instances
+    long A_kstride, B_kstride;                 // doubles between stages (0: one model for the whole horizon)
+    const double* G; long G_stride;            // [nz][nzs] H'_i^-1
+    const double* dvec; long d_stride;
+    const int* rowmap;                         // [N*n]: state (stage k+2, i) at k*n + i -> state-row index 0..mc-1, or -1
+    double* Ghat; long Ghat_stride;            // [R][Rs] (columns R..Rs stay zero)
+    double* gnorm; long gnorm_stride;          // [Rs]
+};
+constexpr int GHAT_THREADS = 256;
+
+template <int NX>
+__global__ __launch_bounds__(GHAT_THREADS) void k_ghat_inst(GhatInstParams p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int inst = blockIdx.x, tid = threadIdx.x;
+    const int n = p.n, m = p.m, N = p.N, nz = p.nz, nzs = p.nzs, mc = p.mc, R = p.R, Rs = p.Rs;
+    double* AB = smem;  // A (n x n) then B (n x m), column-major
+    const double* G = p.G + (size_t)inst * p.G_stride;
+    const double* dv = p.dvec + (size_t)inst * p.d_stride;
+    double* Gh = p.Ghat + (size_t)inst * p.Ghat_stride;
+    double* gn = p.gnorm + (size_t)inst * p.gnorm_stride;
+    for (int t = tid; t < nz * nz; t += GHAT_THREADS) Gh[(size_t)(t / nz) * Rs + t % nz] = G[(size_t)(t / nz) * nzs + t % nz];
+    for (int pass = 0; pass < 2; ++pass) {
+        const int ncol = pass == 0 ? nz : mc;
+        for (int c0 = 0; c0 < ncol; c0 += GHAT_THREADS) {
+            const int c = c0 + tid;
+            const bool on = c < ncol;
+            const int cc = on ? c : 0;
+            double x[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) x[i] = 0.0;
+            for (int t = 0; t < N; ++t) {
+                if (t == 0 || p.A_kstride != 0) {
+                    __syncthreads();
+                    const double* At = p.A + (size_t)inst * p.A_stride + (size_t)t * p.A_kstride;
+                    const double* Bt = p.B + (size_t)inst * p.B_stride + (size_t)t * p.B_kstride;
+                    for (int e = tid; e < n * n; e += GHAT_THREADS) AB[e] = At[e];
+                    for (int e = tid; e < n * m; e += GHAT_THREADS) AB[n * n + e] = Bt[e];
+                    __syncthreads();
+                }
+                double xn[NX];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xn[i] = 0.0;
+#pragma unroll
+                for (int j = 0; j < NX; ++j)
+                    if (j < n) {
+                        const double xj = x[j];
+#pragma unroll
+                        for (int i = 0; i < NX; ++i)
+                            if (i < n) xn[i] += AB[j * n + i] * xj;
+                    }
+                for (int b = 0; b < m; ++b) {
+                    const int row = t * m + b;
+                    const double src = pass == 0 ? G[(size_t)row * nzs + cc] : Gh[(size_t)(nz + cc) * Rs + row];
+                    const double ub = dv[row] * src;
+#pragma unroll
+                    for (int i = 0; i < NX; ++i)
+                        if (i < n) xn[i] += AB[n * n + b * n + i] * ub;
+                }
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    x[i] = xn[i];
+                    if (i < n && on) {
+                        const int r = p.rowmap[t * n + i];
+                        if (r >= 0) {
+                            if (pass == 0) { Gh[(size_t)(nz + r) * Rs + c] = xn[i]; Gh[(size_t)c * Rs + nz + r] = xn[i]; }
+                            else Gh[(size_t)(nz + r) * Rs + nz + c] = xn[i];
+                        }
+                    }
+                }
+            }
+        }
+        __threadfence();   // pass 1 reads what other threads of the workgroup wrote in pass 0 (and the diagonal below, pass 1)
+        __syncthreads();
+    }
+    for (int r = tid; r < Rs; r += GHAT_THREADS) {
+        const double v = r < R ? Gh[(size_t)r * Rs + r] : 1.0;
+        gn[r] = sqrt(v > 0.0 ? v : 1.0);
+    }
 }
 
 // first launch: one wave per instance, working sets up to 32 rows (two waves per SIMD: at most 256 registers)

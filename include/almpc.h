@@ -159,6 +159,16 @@ int almpc_set_step_fusion(almpc_handle* h, int on);
  */
 int almpc_set_structured_fallback(almpc_handle* h, int on);
 
+/*
+ * State box of the designs that have no xmin / xmax arguments of their own -- almpc_design_batched, almpc_design_ltv, the
+ * re-linearisation pipeline: x_min <= x[:,k] <= x_max for stages 1..N+1, the rows kw `mpc_state_constraint` adds in every delegate
+ * of the reference (src/sub/model_modeler_implementation/linear/mpc_modeler_implementation_linear.jl:62-70,
+ * .../fnn/mpc_modeler_implementation_fnn.jl:146-153).  Takes effect at the next such design; NULL, NULL removes it.  Together with
+ * almpc_set_terminal_equality these designs then build one constraint-space matrix per instance (k_ghat_inst) and the step's exact
+ * finish is the dual active-set kernel of the shared-model state rows with per-instance operands.
+ */
+int almpc_set_state_box(almpc_handle* h, const double* xmin, const double* xmax);
+
 int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const double* Q,
                         const double* R, const double* S, const double* P, const double* umin,
                         const double* umax, const double* xmin, const double* xmax, double rho,
@@ -173,8 +183,9 @@ int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const
  * `almpc_design_batched`).  Q, R, S, umin, umax as in almpc_design_shared.  P: NULL -> DARE(A_i, B_i, Q, R) per instance
  * (host, src/sub/design_mpc.jl:327); else one n*n matrix (P_per_instance = 0) or [batch][n*n] (P_per_instance = 1).
  * Prediction matrices, condensed Hessian (FP64 MFMA contraction), scaling and both inverses are built on the device for
- * every instance; the step then runs one workgroup per instance with the instance's KKT inverse in LDS.  Not available
- * with per-instance models: state rows (state box, terminal equality), almpc_advance_plant.  A later
+ * every instance; the step then runs one workgroup per instance with the instance's KKT inverse in LDS.  State rows:
+ * almpc_set_state_box / almpc_set_terminal_equality before the design.  Not available with per-instance models:
+ * almpc_advance_plant.  A later
  * almpc_design_shared switches the handle back to the shared-model path.
  */
 int almpc_design_batched(almpc_handle* h, const double* A_batch, const double* B_batch, const double* Q,
