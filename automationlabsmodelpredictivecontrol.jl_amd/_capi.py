@@ -286,11 +286,12 @@ class Solver:
                                                 _ptr(umax), float(rho), float(sigma)))
 
     def design_ltv(self, A_all, B_all, c_all, xbar, ubar, x_ref, u_ref, Q, R, S=None, P=None, umin=None, umax=None, rho=0.1, sigma=1e-6,
-                   rho_profile="scalar"):
+                   rho_profile="scalar", xmin=None, xmax=None, terminal="none"):
         """Time-varying models: A_all (batch, N, n, n), B_all (batch, N, n, m), c_all (batch, N, n) or None, xbar (batch, n, N+1),
-        ubar (batch, m, N), x_ref (n, N+1) / u_ref (m, N) or None, P (n, n) or (batch, n, n).  The QP variable is v = u - ubar."""
+        ubar (batch, m, N), x_ref (n, N+1) / u_ref (m, N) or None, P (n, n) or (batch, n, n).  The QP variable is v = u - ubar.
+        xmin / xmax: state box on xbar + dx (stages 1..N+1); terminal = "equality": xbar + dx = x_ref at stage N+1."""
         n, m, N, b = self.n, self.m, self.N, self.batch
-        self._state_rows(None, None, "none")
+        self._state_rows(xmin, xmax, terminal)
         self._check(self.L.almpc_set_rho_profile(self.h, {"scalar": 0, "stiffness": 1}[rho_profile]))
         A = np.ascontiguousarray(np.asarray(A_all, dtype=np.float64).reshape(b, N, n, n).transpose(0, 1, 3, 2))
         B = np.ascontiguousarray(np.asarray(B_all, dtype=np.float64).reshape(b, N, n, m).transpose(0, 1, 3, 2))
@@ -313,11 +314,12 @@ class Solver:
                                             _ptr(S), _ptr(P), p_inst, _ptr(umin), _ptr(umax), float(rho), float(sigma)))
 
     def sqp_fnn_setup(self, W_in, W_h, b_h, W_out, x_ref, u_ref, Q, R, S=None, P=None, umin=None, umax=None, act="relu", rho=0.1,
-                      sigma=1e-6, rho_profile="scalar"):
+                      sigma=1e-6, rho_profile="scalar", xmin=None, xmax=None, terminal="none"):
         """SQP outer loop for an Fnn model (almpc_sqp_fnn_*): network as in fnn_linearize, x_ref (n, N+1) / u_ref (m, N) or None,
-        P (n, n) or (batch, n, n)."""
+        P (n, n) or (batch, n, n).  xmin / xmax: the state box of the reference's NLP branch
+        (.../fnn/mpc_modeler_implementation_fnn.jl:146-153) as rows of every iteration's QP; terminal = "equality"."""
         n, m, N, b = self.n, self.m, self.N, self.batch
-        self._state_rows(None, None, "none")
+        self._state_rows(xmin, xmax, terminal)
         self._check(self.L.almpc_set_rho_profile(self.h, {"scalar": 0, "stiffness": 1}[rho_profile]))
         W_in, W_out = np.asfortranarray(W_in, dtype=np.float64), np.asfortranarray(W_out, dtype=np.float64)
         H = W_in.shape[0]

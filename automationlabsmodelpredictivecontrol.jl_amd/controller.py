@@ -230,19 +230,22 @@ def _design_blackbox(system: ConstrainedBlackBoxControlDiscreteSystem, horizon: 
     C = _design_linear(lin_first, horizon, sample_time, references, kws=kws, _terminal_P=P)
     C.system = system
     if lin_mode == "step":
-        if "mpc_state_constraint" in kws or kws.get("mpc_terminal_ingredient", "none") == "equality":
-            raise NotImplementedError("mpc_linearization='step' (per-instance models) has no state rows")
+        state_box = "mpc_state_constraint" in kws   # the rows of .../fnn/mpc_modeler_implementation_fnn.jl:52-58, per instance
+        term_eq = kws.get("mpc_terminal_ingredient", "none") == "equality"
         mod = C.tuning.modeler
         sopt = dict(kws.get("mpc_solver_options", {}))
         f = system.f
         # instances whose linearisation is open-loop unstable (condensed Hessian singular to working precision) are redone in the
         # multiple-shooting form by the structured solve (almpc_set_structured_fallback) when the shape allows it
-        if mod.solver.n <= 32 and mod.solver.m <= 16 and float(np.asarray(weights.S)[0, 0]) == 0.0 and kws.get("mpc_structured_fallback", True):
+        if (mod.solver.n <= 32 and mod.solver.m <= 16 and float(np.asarray(weights.S)[0, 0]) == 0.0 and kws.get("mpc_structured_fallback", True)
+                and not (state_box or term_eq)):   # (the structured solve has no state rows)
             mod.solver._check(mod.solver.L.almpc_set_structured_fallback(mod.solver.h, 1))
         # device-resident pipeline (almpc_relin_fnn_*): Jacobians -> per-instance designs -> step, no host pointers per step
         mod.solver.relin_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, references.x, references.u, weights.Q, weights.R, weights.S, np.array(P),
                                    system.U.low, system.U.high, act=f.act, rho=float(sopt.get("rho", 0.1)),
-                                   sigma=float(sopt.get("sigma", 1e-6)), rho_profile=kws.get("mpc_rho_profile", "scalar"))
+                                   sigma=float(sopt.get("sigma", 1e-6)), rho_profile=kws.get("mpc_rho_profile", "scalar"),
+                                   xmin=system.X.low if state_box else None, xmax=system.X.high if state_box else None,
+                                   terminal="equality" if term_eq else "none")
         mod.relinearize = dict(system=system, device=dev)
     return C
 
@@ -261,8 +264,9 @@ def _design_blackbox_nonlinear(system, horizon, sample_time, references, weights
     if solver_name in ("osqp", "scip", "ipopt"):
         raise NotImplementedError(f"mpc_solver={solver_name!r} is the reference's CPU path; this build provides 'hip' (and 'auto' -> 'hip')")
     terminal = kws.get("mpc_terminal_ingredient", D["mpc_terminal_ingredient"])
-    if terminal in ("equality", "contractive") or "mpc_state_constraint" in kws:
-        raise NotImplementedError("non_linear programming on the device: input box only (no state rows, no terminal constraint)")
+    if terminal == "contractive":
+        raise NotImplementedError("terminal ingredient 'contractive' is a quadratic constraint (src/sub/design_mpc.jl:333-340), not a QP row")
+    state_box = "mpc_state_constraint" in kws       # .../fnn/mpc_modeler_implementation_fnn.jl:146-153: rows of every SQP iteration's QP
     f = system.f
     n, m = system.statedim, system.inputdim
     batch = int(kws.get("mpc_batch", 1))
@@ -273,7 +277,9 @@ def _design_blackbox_nonlinear(system, horizon, sample_time, references, weights
     solver = _capi.Solver(n, m, horizon, batch, device=int(kws.get("mpc_device", 0)), timing=bool(kws.get("mpc_timing", False)))
     solver.sqp_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, x_ref, u_ref, weights.Q, weights.R, weights.S, P, system.U.low, system.U.high,
                          act=f.act, rho=float(sopt.get("rho", 0.1)), sigma=float(sopt.get("sigma", 1e-6)),
-                         rho_profile=kws.get("mpc_rho_profile", "scalar"))
+                         rho_profile=kws.get("mpc_rho_profile", "scalar"),
+                         xmin=system.X.low if state_box else None, xmax=system.X.high if state_box else None,
+                         terminal="equality" if terminal == "equality" else "none")
     mod = HipModeler(solver, _capi.default_opts(**sopt), batch)
     mod.sqp = dict(iterations=int(kws.get("mpc_sqp_iterations", 10)), step=float(kws.get("mpc_sqp_step", 1.0)),
                    warm_start=bool(kws.get("mpc_sqp_warm_start", True)), u_prev=None,

@@ -67,6 +67,8 @@ struct almpc_handle {
     int* dRowMap = nullptr;        // [N*n] state (stage k+2, i) -> state-row index or -1 (k_ghat_inst)
     bool ghat_inst = false;        // dGhat / dGnorm hold one constraint-space matrix PER INSTANCE ([batch][R][Rs], [batch][Rs])
     std::vector<double> boxmin, boxmax;  // almpc_set_state_box: the state box of the per-instance / time-varying / SQP designs
+    double *lA = nullptr, *lB = nullptr, *lC = nullptr, *lE = nullptr;  // almpc_design_ltv with state rows: stage models, defects and
+                                                                        // state errors kept for the step's rollouts
     // per-instance models (almpc_design_batched): persistent per-instance operands ...
     bool batched = false;
     bool ltv = false;             // almpc_design_ltv: references and gradient are part of the design
@@ -173,7 +175,7 @@ void free_all(almpc_handle* h) {
     void* ptrs[] = {h->dMinvFrag, h->dVFrag, h->dHFrag, h->dFFrag, h->dG, h->dD, h->dUmin, h->dUmax, h->dA, h->dB,
                     h->dXref, h->dUref, h->dFS, h->dV0S, h->dRho, h->dRollM, h->dX0, h->dXs, h->dZs, h->dYs, h->dV0, h->dW, h->dX, h->dEx,
                     h->dU, h->dEu, h->dStatus, h->dIters, h->dPiters, h->dPerm, h->dYflags, h->dSglobal, h->dGhat, h->dGnorm, h->dXmin,
-                    h->dXmax, h->dRowTraj, h->dRowEq, h->dRowXidx, h->dRowState, h->dRowMap, h->bA, h->bB, h->bMinv, h->bG, h->bHs, h->bFs,
+                    h->dXmax, h->dRowTraj, h->dRowEq, h->dRowXidx, h->dRowState, h->dRowMap, h->lA, h->lB, h->lC, h->lE, h->bA, h->bB, h->bMinv, h->bG, h->bHs, h->bFs,
                     h->bVs, h->bD, h->bRho, h->bH, h->bF, h->bPhi, h->bGk, h->bGam, h->bW, h->bWP, h->bP, h->bFlag, h->bQ, h->dOverflow,
                     h->sqp.W_in, h->sqp.W_h, h->sqp.b_h, h->sqp.W_out, h->sqp.A, h->sqp.B, h->sqp.c, h->sqp.fval, h->sqp.ebar,
                     h->sqp.qadd, h->sqp.xref, h->sqp.uref, h->sqp.Q, h->sqp.R, h->sqp.S, h->sqp.bad, h->sqp.stats, h->sqp.mer, h->sqp.xback, h->sqp.uback, h->sqp.dxback, h->sqp.vback};
@@ -908,6 +910,12 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
             if (e == hipSuccess) { launch_batched_factor(h, ds, rho, sigma, st); e = launch_ghat_inst(h, dAll, dBll); }
         }
         if (e == hipSuccess) e = hipStreamSynchronize(st);  // the staging buffers are released right away
+        for (double** q : {&h->lA, &h->lB, &h->lC, &h->lE})
+            if (*q) { (void)hipFree(*q); *q = nullptr; }
+        if (e == hipSuccess && h->mc > 0) {   // ... except with state rows: the step rolls the stage models out
+            h->lA = dAll; h->lB = dBll; h->lC = dC; h->lE = dE;
+            dAll = dBll = dC = dE = nullptr;
+        }
         (void)hipFree(dAll); (void)hipFree(dBll); (void)hipFree(dC); (void)hipFree(dE); (void)hipFree(dQa);
         if (e != hipSuccess) { release(); return fail(h, ALMPC_ERR_HIP, std::string("design_ltv: ") + hipGetErrorString(e)); }
         BTRY(ensure_dyn_lds(reinterpret_cast<const void*>(k_design_inverse), 520 * sizeof(double)));
@@ -1309,8 +1317,10 @@ int almpc_sqp_fnn_setup(almpc_handle* h, int H, int L, int activation, const dou
     h->hS = Sm;
     h->useS = q.useS;
     h->rho = rho; h->sigma = sigma;
-    if (!h->boxmin.empty() || h->terminal_eq) return fail(h, ALMPC_ERR_UNSUPPORTED, "sqp_fnn_setup: state rows are not built for the SQP loop");
-    h->has_box = 0; h->mc = 0; h->R = nz; h->np_pairs = 1; h->Rs = 128;
+    // state rows (almpc_set_state_box: the box of .../fnn/mpc_modeler_implementation_fnn.jl:146-153; terminal equality): one
+    // constraint-space matrix per instance, rebuilt with every iteration's linearisation
+    { const int rc_ = setup_state_rows(h, h->boxmin.empty() ? nullptr : h->boxmin.data(), h->boxmax.empty() ? nullptr : h->boxmax.data(), true);
+      if (rc_ != ALMPC_OK) return rc_; }
     h->xref_stride = (long)n * (N + 1); h->uref_stride = nz; h->fS_stride = nz;
     h->designed = false;  // becomes true with the first iteration's design
     h->batched = true; h->ltv = true;
@@ -1410,6 +1420,7 @@ int almpc_sqp_fnn_iterate(almpc_handle* h, int iters, double step_scale, const a
         HIP_TRY(h, launch_design_ltv(h, lp, st));
         h->skip_admm = (q.guess_from_iterate && q.since_start > 0) ? 1 : 0;
         launch_batched_factor(h, ds, h->rho, h->sigma, st);
+        if (h->mc > 0) HIP_TRY(h, launch_ghat_inst(h, q.A, q.B));
         hipLaunchKernelGGL(k_fs_scale, dim3(256), dim3(256), 0, st, h->batch, nz, nzs, h->bQ, (long)nz, h->bD, h->dFS);
         hipLaunchKernelGGL(k_neg_gm, dim3(1, (unsigned)b), dim3(256), 0, st, nz, nzs, 1, nz, h->bG, h->dFS, h->dV0S, (long)nz * nzs, (long)nz);
         HIP_TRY(h, hipGetLastError());
@@ -1419,7 +1430,7 @@ int almpc_sqp_fnn_iterate(almpc_handle* h, int iters, double step_scale, const a
         if (rc != ALMPC_OK) return rc;
         // structured fallback: an instance whose condensed Hessian came out indefinite to working precision (open-loop unstable
         // linearisation over the horizon) or whose QP was left unsolved gets this iteration's QP solved in its stage-wise form
-        if (h->fallback) HIP_TRY(h, launch_riccati(h, 2, nullptr, 0));
+        if (h->fallback && h->mc == 0) HIP_TRY(h, launch_riccati(h, 2, nullptr, 0));   // (k_riccati has no state rows)
         q.since_start += 1;
         sp.stats = q.stats + 2 * it;
         hipLaunchKernelGGL(k_sqp_step, dim3((unsigned)b), dim3(256), step_lds, st, sp);
@@ -1439,8 +1450,8 @@ int almpc_sqp_fnn_iterate(almpc_handle* h, int iters, double step_scale, const a
     for (size_t i = 0; i < b; ++i)
         if (bad[i])
             return fail(h, ALMPC_ERR_NUMERIC, "sqp_fnn_iterate: instance " + std::to_string(i) +
-                        ": an iteration was skipped (condensed Hessian not positive definite to working precision, or a non-finite QP "
-                        "solution); its iterate is the last good one, the other instances are unaffected");
+                        ": an iteration was skipped (condensed Hessian not positive definite to working precision, a non-finite QP "
+                        "solution, or -- with state rows -- an infeasible QP); its iterate is the last good one, the other instances are unaffected");
     return ALMPC_OK;
 }
 
@@ -1682,7 +1693,13 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         PolishGenParams gp;
         gp.nz = h->nz; gp.mc = h->mc; gp.R = h->R; gp.Rs = h->Rs; gp.m = h->m; gp.n = h->n; gp.N = h->N; gp.batch = h->batch; gp.nzs = h->nzs;
         if (h->batched && !h->ghat_inst) return fail(h, ALMPC_ERR_NOT_DESIGNED, "calculate: state rows without their per-instance matrices");
-        if (h->ltv) return fail(h, ALMPC_ERR_UNSUPPORTED, "calculate: state rows with a time-varying design are not built");
+        if (h->ltv) {
+            const bool sq = h->sqp.ready;
+            gp.ltv = 1;
+            gp.ltvA = sq ? h->sqp.A : h->lA; gp.ltvB = sq ? h->sqp.B : h->lB; gp.ltvC = sq ? h->sqp.c : h->lC;
+            if (!gp.ltvA || !gp.ltvB) return fail(h, ALMPC_ERR_NOT_DESIGNED, "calculate: state rows of a time-varying design without its stage models");
+            if (h->terminal_eq) { gp.eq_off = (sq ? h->sqp.ebar : h->lE) + (size_t)(h->N - 1) * h->n; gp.eq_stride = (long)h->N * h->n; }
+        }
         if (h->batched) {
             gp.Ghat_stride = (long)h->R * h->Rs; gp.gnorm_stride = h->Rs; gp.d_stride = h->nzs;
             gp.A_stride = (long)h->n * h->n; gp.B_stride = (long)h->n * h->m;

@@ -29,6 +29,14 @@ struct PolishGenParams {
     const double* Ghat;   // [R][Rs] dense symmetric
     const double* gnorm;  // [Rs] sqrt(Ghat_rr) (pad rows: 1)
     long Ghat_stride = 0, gnorm_stride = 0, d_stride = 0, A_stride = 0, B_stride = 0;  // per-instance models: doubles between instances
+    // time-varying designs (almpc_design_ltv, the SQP loop): the state rows are rows of dx, dx_{k+1} = A_k dx_k + B_k v_k + c_k, dx_0 = 0,
+    // with bounds relative to the linearisation trajectory (which sits in the reference slots); no x / e_x outputs
+    int ltv = 0;
+    const double* ltvA = nullptr;  // [batch][N][n*n]
+    const double* ltvB = nullptr;  // [batch][N][n*m]
+    const double* ltvC = nullptr;  // [batch][N][n] or null
+    const double* eq_off = nullptr;  // [batch][eq_stride]: terminal equality e_x[:,N+1] = 0 in dx: dx_N = -eq_off (= x_ref - xbar at N+1)
+    long eq_stride = 0;
     const int* row_traj;  // [Rs] for state rows: offset of e_x[i,k] in the wave's trajectory buffer Z ((k)*C + i); else -1
     const int* row_eq;    // [Rs] 1 for terminal-equality rows
     const int* row_xidx;  // [Rs] for state rows: i + n*k index into x_ref (k = reference stage 2..N+1 -> 1..N); else 0
@@ -50,6 +58,53 @@ struct PolishGenParams {
 constexpr int PGEN_WAVES = 4;
 // LDS per wave (doubles): Sinv WL x WL | rowbuf Rs(<=512) | pbufa WL | pbufb WL | wrow_s (WL ints) | Z trajectory shares Sinv
 __host__ __device__ constexpr int pgen_lds_per_wave(int WL) { return WL * WL + 512 + WL + WL + WL / 2; }
+
+// Rollout through stage models (time-varying designs): Z rows [dx(k); v(k)], dx(0) in Z[0..n); lane layout as rollout_steps, the
+// stage's coefficients come from global memory and are requested one stage ahead of the chain.
+template <int CPL>
+__device__ __forceinline__ void rollout_steps_ltv(double* Z, int n, int m, int N, int G, int lane, const double* A, const double* B,
+                                                  const double* c) {
+    const int C = n + m;
+    const int i = lane / G, g = lane % G, ic = i < n ? i : 0;
+    int jc[CPL];
+    size_t offA[CPL], offB[CPL];
+    bool isA[CPL], ok[CPL];
+#pragma unroll
+    for (int t = 0; t < CPL; ++t) {
+        const int j = g * CPL + t;
+        ok[t] = (i < n) && (j < C);
+        isA[t] = j < n;
+        offA[t] = (size_t)(j < n ? j : 0) * n + ic;
+        offB[t] = (size_t)((j >= n && j < C) ? j - n : 0) * n + ic;
+        jc[t] = j < C ? j : C - 1;
+    }
+    auto load = [&](int k, double (&cf)[CPL], double& ck) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) {
+            const double av = A[(size_t)k * n * n + offA[t]], bv = B[(size_t)k * n * m + offB[t]];
+            cf[t] = ok[t] ? (isA[t] ? av : bv) : 0.0;
+        }
+        ck = c ? c[(size_t)k * n + ic] : 0.0;
+    };
+    double cf[CPL], ck;
+    load(0, cf, ck);
+    for (int k = 0; k < N; ++k) {
+        double nf[CPL], nck = 0.0;
+        load(k + 1 < N ? k + 1 : k, nf, nck);
+        const double* zk = Z + (size_t)k * C;
+        double acc = 0.0;
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) acc += cf[t] * zk[jc[t]];
+        for (int o = 1; o < G; o <<= 1) acc += __shfl_xor(acc, o);
+        if (g == 0 && i < n) Z[(size_t)(k + 1) * C + i] = acc + ck;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) cf[t] = nf[t];
+        ck = nck;
+    }
+}
 
 template <int NP, int WL>
 __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double* smem) {
@@ -78,6 +133,27 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
     const double* dvi = p.dvec + (size_t)inst * p.d_stride;
     const double* Ai = p.roll.A + (size_t)inst * p.A_stride;
     const double* Bi = p.roll.B + (size_t)inst * p.B_stride;
+    const int n_ = p.n, m_ = p.m, N_ = p.N;
+    const double* lA = p.ltv ? p.ltvA + (size_t)inst * N_ * n_ * n_ : nullptr;
+    const double* lB = p.ltv ? p.ltvB + (size_t)inst * N_ * n_ * m_ : nullptr;
+    const double* lC = (p.ltv && p.ltvC) ? p.ltvC + (size_t)inst * N_ * n_ : nullptr;
+    auto roll = [&](double* Zb) __attribute__((always_inline)) {
+        if (p.ltv) {
+            switch (p.roll_cpl) {
+                case 1: rollout_steps_ltv<1>(Zb, n_, m_, N_, p.roll_g, lane, lA, lB, lC); break;
+                case 2: rollout_steps_ltv<2>(Zb, n_, m_, N_, p.roll_g, lane, lA, lB, lC); break;
+                case 4: rollout_steps_ltv<4>(Zb, n_, m_, N_, p.roll_g, lane, lA, lB, lC); break;
+                default: rollout_steps_ltv<8>(Zb, n_, m_, N_, p.roll_g, lane, lA, lB, lC); break;
+            }
+        } else {
+            switch (p.roll_cpl) {
+                case 1: rollout_steps<1>(Zb, n_, m_, N_, p.roll_g, lane, Ai, Bi); break;
+                case 2: rollout_steps<2>(Zb, n_, m_, N_, p.roll_g, lane, Ai, Bi); break;
+                case 4: rollout_steps<4>(Zb, n_, m_, N_, p.roll_g, lane, Ai, Bi); break;
+                default: rollout_steps<8>(Zb, n_, m_, N_, p.roll_g, lane, Ai, Bi); break;
+            }
+        }
+    };
     const size_t base = (size_t)inst * nzs;
     const int pos = lane & (WL - 1), hf = (HS == 2) ? (lane >> 5) : 0;
     const bool lowhalf = lane < WL;
@@ -111,17 +187,13 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
             if (r < nz) Z[(size_t)(r / m) * C + n + r % m] = vv[e] * dv[e];
         }
         for (int i = lane; i < n; i += 64) {
-            const double xv = rp.x0[(size_t)inst * n + i];
-            Z[i] = xv - rp.xref[(size_t)inst * rp.xref_stride + i];
+            // (time-varying design: stage 1 of the linearisation trajectory, which sits in the reference slot, is x0; dx_0 = 0)
+            const double xv = p.ltv ? rp.xref[(size_t)inst * rp.xref_stride + i] : rp.x0[(size_t)inst * n + i];
+            Z[i] = p.ltv ? 0.0 : xv - rp.xref[(size_t)inst * rp.xref_stride + i];
             if (p.has_box && !(xv >= p.xmin[i] && xv <= p.xmax[i])) x0_bad = true;  // stage 1 is x0 itself
         }
         wave_fence_lds();
-        switch (p.roll_cpl) {
-            case 1: rollout_steps<1>(Z, n, m, N, p.roll_g, lane, Ai, Bi); break;
-            case 2: rollout_steps<2>(Z, n, m, N, p.roll_g, lane, Ai, Bi); break;
-            case 4: rollout_steps<4>(Z, n, m, N, p.roll_g, lane, Ai, Bi); break;
-            default: rollout_steps<8>(Z, n, m, N, p.roll_g, lane, Ai, Bi); break;
-        }
+        roll(Z);
 #pragma unroll
         for (int q = 0; q < NP; ++q)
 #pragma unroll
@@ -142,7 +214,10 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
                 } else if (valid[q][e]) {  // state row: value e_x[i,k] of the v0 trajectory, shared bounds
                     const int tr = p.row_traj[rcl];
                     s0v[q][e] = Z[tr];
-                    if (p.row_eq[rcl]) { lo[q][e] = 0.0; hi[q][e] = 0.0; }
+                    if (p.row_eq[rcl]) {
+                        const double off = p.eq_off ? -p.eq_off[(size_t)inst * p.eq_stride + p.row_state[rcl]] : 0.0;
+                        lo[q][e] = off; hi[q][e] = off;
+                    }
                     else {
                         const double xr = rp.xref[(size_t)inst * rp.xref_stride + p.row_xidx[rcl]];
                         lo[q][e] = p.xmin[p.row_state[rcl]] - xr;
@@ -507,20 +582,17 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
             rp.eu[(size_t)inst * nz + r1] = uu - ur;
             Z[(size_t)(r1 / m) * C + n + r1 % m] = uu - ur;
         }
+        if (!p.ltv) {   // (x / e_x are not defined for a time-varying design: the caller rolls the nonlinear model out)
         for (int i = lane; i < n; i += 64) Z[i] = rp.x0[(size_t)inst * n + i] - rp.xref[(size_t)inst * rp.xref_stride + i];
         wave_fence_lds();
-        switch (p.roll_cpl) {
-            case 1: rollout_steps<1>(Z, n, m, N, p.roll_g, lane, Ai, Bi); break;
-            case 2: rollout_steps<2>(Z, n, m, N, p.roll_g, lane, Ai, Bi); break;
-            case 4: rollout_steps<4>(Z, n, m, N, p.roll_g, lane, Ai, Bi); break;
-            default: rollout_steps<8>(Z, n, m, N, p.roll_g, lane, Ai, Bi); break;
-        }
+        roll(Z);
         const int nx = n * (N + 1);
         const size_t xo = (size_t)inst * nx;
         for (int t = lane; t < nx; t += 64) {
             const double ev = Z[(size_t)(t / n) * C + t % n];
             rp.ex[xo + t] = ev;
             rp.x[xo + t] = (t < n) ? rp.x0[(size_t)inst * n + t] : ev + rp.xref[(size_t)inst * rp.xref_stride + t];
+        }
         }
     }
     if (QUEUE) wave_fence_lds();  // the next instance reuses this wave's LDS slot

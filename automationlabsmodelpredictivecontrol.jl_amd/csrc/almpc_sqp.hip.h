@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void k_sqp_step(SqpParams p) {
     __syncthreads();
     if (tid == 0) {
         const int redo_ = p.adaptive && p.mer[4 * i + 2] != 0.0;   // trial point rejected in k_sqp_prepare: this QP is void
-        const int bad = !redo_ && ((red[8] + red[9] + red[10] + red[11] != 0.0) || p.flag[i] != 0 || p.status[i] == 2);
+        const int bad = !redo_ && ((red[8] + red[9] + red[10] + red[11] != 0.0) || p.flag[i] != 0 || p.status[i] == 2 || p.status[i] == 3);
         skip = bad || redo_;
         if (bad) p.bad[i] = 1;
         else if (!redo_) {

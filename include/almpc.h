@@ -165,7 +165,9 @@ int almpc_set_structured_fallback(almpc_handle* h, int on);
  * of the reference (src/sub/model_modeler_implementation/linear/mpc_modeler_implementation_linear.jl:62-70,
  * .../fnn/mpc_modeler_implementation_fnn.jl:146-153).  Takes effect at the next such design; NULL, NULL removes it.  Together with
  * almpc_set_terminal_equality these designs then build one constraint-space matrix per instance (k_ghat_inst) and the step's exact
- * finish is the dual active-set kernel of the shared-model state rows with per-instance operands.
+ * finish is the dual active-set kernel of the shared-model state rows with per-instance operands.  Time-varying designs and the SQP
+ * loop: the box is on xbar + dx, the terminal equality reads xbar + dx = x_ref at stage N+1; an SQP iteration whose QP is infeasible
+ * is skipped for that instance (almpc_sqp_fnn_skipped) -- there is no elastic mode.  The structured solve has no state rows.
  */
 int almpc_set_state_box(almpc_handle* h, const double* xmin, const double* xmax);
 

@@ -8,7 +8,7 @@
 # solver tag "hip" next to osqp/scip/ipopt/auto (src/sub/solver_selection.jl:9-14).
 module AlmpcHIP
 
-export hip_solver_def, HipModeler, AlmpcOpts, design_hip, terminal_weight, design_batched!, design_sqp_fnn!, sqp_start!, sqp_iterate!,
+export hip_solver_def, HipModeler, AlmpcOpts, design_hip, terminal_weight, set_state_rows!, design_batched!, design_sqp_fnn!, sqp_start!, sqp_iterate!,
        design_relin_fnn!, relin_step!, relin_advance!, update_initialization!, calculate!, read_results!,
        _model_predictive_control_computation, comm_unique_id, comm_init!, comm_summary, comm_allgather_first_input
 
@@ -81,6 +81,24 @@ function design_hip(A::Matrix{Float64}, B::Matrix{Float64}, Q::Matrix{Float64}, 
     # references: n x (N+1) and m x N Julia matrices are already the ABI's [N+1][n] / [N][m] memory
     check(h, ccall((:almpc_set_reference, libalmpc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Cint),
                    h, x_ref, u_ref, 0))
+    return mod
+end
+
+"""
+    set_state_rows!(mod; xmin = nothing, xmax = nothing, terminal = "none")
+
+State box (kw `mpc_state_constraint`; .../fnn/mpc_modeler_implementation_fnn.jl:52-58,146-153) and terminal equality
+(src/sub/design_mpc.jl:330-331) of the designs without `xmin`/`xmax` arguments: call before `design_batched!`, `design_sqp_fnn!`,
+`design_relin_fnn!`.
+"""
+function set_state_rows!(mod::HipModeler; xmin::Union{Nothing,Vector{Float64}} = nothing, xmax::Union{Nothing,Vector{Float64}} = nothing,
+                         terminal::String = "none")
+    (xmin === nothing) == (xmax === nothing) || error("give both xmin and xmax or neither")
+    check(mod.handle, ccall((:almpc_set_terminal_equality, libalmpc), Cint, (Ptr{Cvoid}, Cint), mod.handle, terminal == "equality" ? 1 : 0))
+    pmin = xmin === nothing ? Ptr{Float64}(C_NULL) : pointer(xmin)
+    pmax = xmax === nothing ? Ptr{Float64}(C_NULL) : pointer(xmax)
+    GC.@preserve xmin xmax check(mod.handle, ccall((:almpc_set_state_box, libalmpc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}),
+                                                   mod.handle, pmin, pmax))
     return mod
 end
 

@@ -211,13 +211,14 @@ def s_rate_gradient(p: MPCProblem):
     return 2.0 * D.T @ np.kron(np.eye(N - 1), p.S) @ D @ p.u_ref.T.reshape(-1)
 
 
-def ltv_qp(A_list, B_list, c_list, xbar, ubar, x_ref, u_ref, Q, R, S, P, u_min, u_max):
+def ltv_qp(A_list, B_list, c_list, xbar, ubar, x_ref, u_ref, Q, R, S, P, u_min, u_max, return_prediction=False):
     """QP of one SQP / multiple-shooting iteration around the trajectory (xbar n x (N+1), ubar m x N), in v = u - ubar
     (almpc_design_ltv; BASELINE.json configs[4] -- the reference has no such path, only the QP is reference-shaped):
         dx_{k+1} = A_k dx_k + B_k v_k + c_k, dx_0 = 0   =>   dX = Gam v + g
         cost of src/sub/design_mpc.jl:405-468 evaluated at (xbar + dx, ubar + v), with the same R / S branch rules and the
         S term on u itself,  bounds u_min <= ubar + v <= u_max.
-    Returns H, q, lo, hi of  min 1/2 v'Hv + q'v."""
+    Returns H, q, lo, hi of  min 1/2 v'Hv + q'v  (and Gam, g with return_prediction: the state rows of a state box / terminal
+    equality are rows of dX = Gam v + g, see ltv_state_rows)."""
     N = len(A_list)
     n, m = np.asarray(B_list[0]).shape
     nz = m * N
@@ -257,7 +258,58 @@ def ltv_qp(A_list, B_list, c_list, xbar, ubar, x_ref, u_ref, Q, R, S, P, u_min, 
     q = 2.0 * q
     lo = (np.asarray(u_min, dtype=np.float64)[:, None] - np.asarray(ubar)).T.reshape(-1)
     hi = (np.asarray(u_max, dtype=np.float64)[:, None] - np.asarray(ubar)).T.reshape(-1)
+    if return_prediction:
+        return H, q, lo, hi, Gam, g
     return H, q, lo, hi
+
+
+def ltv_state_rows(Gam, g, xbar, x_ref, x_min, x_max, terminal):
+    """State rows of one SQP iteration's QP (almpc_set_state_box / almpc_set_terminal_equality with a time-varying design): the box
+    x_min <= xbar_k + dx_k <= x_max for stages 2..N+1 (.../fnn/mpc_modeler_implementation_fnn.jl:146-153; stage 1 is x0) and / or
+    x_{N+1} = x_ref_{N+1}, i.e. dx_N = x_ref - xbar there (src/sub/design_mpc.jl:330-331), as rows of dX = Gam v + g.
+    Returns C, a0, lo_c, hi_c, eq."""
+    xbar = np.asarray(xbar, dtype=np.float64)
+    n, N1 = xbar.shape
+    N = N1 - 1
+    rows, lo, hi, eq = [], [], [], []
+    for k in range(N):
+        for i in range(n):
+            is_eq = terminal == "equality" and k == N - 1
+            if not (x_min is not None or is_eq):
+                continue
+            rows.append(k * n + i)
+            eq.append(is_eq)
+            if is_eq:
+                b = x_ref[i, k + 1] - xbar[i, k + 1]
+                lo.append(b); hi.append(b)
+            else:
+                lo.append(x_min[i] - xbar[i, k + 1]); hi.append(x_max[i] - xbar[i, k + 1])
+    rows = np.array(rows, dtype=int)
+    return Gam[rows], g[rows], np.array(lo), np.array(hi), np.array(eq, dtype=bool)
+
+
+def solve_qp_rows_exact(H, f, lo, hi, C, a0, lo_c, hi_c, eq_c):
+    """Exact solution of  min 1/2 v'Hv + f'v,  lo <= v <= hi,  lo_c <= C v + a0 <= hi_c  (rows eq_c: equalities) by the dual active
+    set in constraint space of the Jacobi-scaled problem, KKT-certified; ValueError if infeasible.  Returns v and the active rows."""
+    nz = H.shape[0]
+    d = jacobi_scaling(H)
+    Hs = H * d[:, None] * d[None, :]
+    A = np.vstack([np.eye(nz), C * d[None, :]])
+    G = np.linalg.inv(Hs)
+    Ghat = A @ G @ A.T
+    v0 = -G @ (f * d)
+    s0 = A @ v0 + np.concatenate([np.zeros(nz), a0])
+    lo_r = np.concatenate([lo / d, lo_c])
+    hi_r = np.concatenate([hi / d, hi_c])
+    eq = np.concatenate([np.zeros(nz, dtype=bool), eq_c])
+    r = solve_qp_dual_active_set(Ghat, s0, lo_r, hi_r, eq)
+    if r["status"] == 3:
+        raise ValueError("infeasible QP")
+    w = r["s"][:nz]
+    res = kkt_general(Hs, f * d, A, s0 - A @ v0, lo_r, hi_r, w, r["lam"])
+    if r["status"] != 0 or res > 1e-7 * max(1.0, float(np.max(np.abs(f * d)))):
+        raise RuntimeError(f"general exact solver did not certify: status {r['status']}, KKT residual {res:g}")
+    return np.clip(w * d, lo, hi), [j for j in r["W"]]
 
 
 def condensed_qp(p: MPCProblem, x0):
@@ -1196,13 +1248,14 @@ def nlp_kkt_residual(model: FnnModel, x0, U, x_ref, u_ref, Q, R, S, P, u_min, u_
 
 
 def sqp_fnn(model: FnnModel, x0, x_ref, u_ref, Q, R, S, P, u_min, u_max, iters, u_guess=None, step_scale=1.0, adaptive=False,
-            merit_mu=None, structured=False):
+            merit_mu=None, structured=False, x_min=None, x_max=None, terminal="none", return_active=False):
     """CPU restatement of the device loop almpc_sqp_fnn_*: Gauss-Newton SQP with multiple shooting, every QP solved exactly
     (solve_box_qp_exact).  Returns X (n, N+1), U (m, N) and the per-iteration (|v|_inf, |defect|_inf) history (None for an
     iteration whose QP was void).
     adaptive: step rule 1 of almpc_sqp_fnn_set_step_rule -- l1 merit function phi = J + mu |defects|_1, mu = 2 max(|P|, |Q|),
     tested a posteriori at the top of the next iteration: if phi did not decrease the iterate returns to the last accepted point
-    plus half the step and the iteration's QP is void; accepted steps double the factor back up to 1; at 1/64 accept anyway."""
+    plus half the step and the iteration's QP is void; accepted steps double the factor back up to 1; at 1/64 accept anyway.
+    x_min / x_max / terminal: state rows of every iteration's QP (ltv_state_rows); ValueError when a QP is infeasible."""
     m, N = u_ref.shape
     U = np.clip(u_ref if u_guess is None else u_guess, u_min[:, None], u_max[:, None]).astype(np.float64)
     X = fnn_rollout(model, x0, U)
@@ -1213,6 +1266,7 @@ def sqp_fnn(model: FnnModel, x0, x_ref, u_ref, Q, R, S, P, u_min, u_max, iters, 
     mu = 2.0 * max(np.abs(P).max(), np.abs(Q).max()) if merit_mu is None else float(merit_mu)
     a, ref = 1.0, np.inf
     Xb = Ub = dXb = Vb = None
+    n_state_active = 0
 
     def merit(X, U, fv):
         EX, EU = X - x_ref, U - u_ref
@@ -1241,6 +1295,14 @@ def sqp_fnn(model: FnnModel, x0, x_ref, u_ref, Q, R, S, P, u_min, u_max, iters, 
             rr = riccati_active_set(A, B, Q, Rz, P, np.zeros(x0.size), (u_min[:, None] - U).T, (u_max[:, None] - U).T, c=np.array(c),
                                     ebar=(X[:, 1:] - x_ref[:, 1:]).T, qu=(Rz @ (U - u_ref)).T)
             v = rr["v"].T
+        elif x_min is not None or terminal == "equality":
+            if x_min is not None and (np.any(x0 < x_min) or np.any(x0 > x_max)):
+                raise ValueError("infeasible: x[:,1] = x0 violates the state box")
+            H, q, lo, hi, Gam, g = ltv_qp(A, B, c, X, U, x_ref, u_ref, Q, Rz, Sz, P, u_min, u_max, return_prediction=True)
+            C, a0, lo_c, hi_c, eq_c = ltv_state_rows(Gam, g, X, x_ref, x_min, x_max, terminal)
+            vv, W = solve_qp_rows_exact(H, q, lo, hi, C, a0, lo_c, hi_c, eq_c)
+            n_state_active = sum(1 for j in W if j >= H.shape[0])
+            v = vv.reshape(N, m).T
         else:
             H, q, lo, hi = ltv_qp(A, B, c, X, U, x_ref, u_ref, Q, Rz, Sz, P, u_min, u_max)
             v = solve_box_qp_exact(H, q, lo, hi).reshape(N, m).T
@@ -1254,6 +1316,8 @@ def sqp_fnn(model: FnnModel, x0, x_ref, u_ref, Q, R, S, P, u_min, u_max, iters, 
             Xb, Ub, dXb, Vb = X.copy(), U.copy(), step_scale * dX, step_scale * v
         sc = step_scale * (a if adaptive else 1.0)
         X, U = X + sc * dX, np.clip(U + sc * v, u_min[:, None], u_max[:, None])
+    if return_active:
+        return X, U, hist, n_state_active
     return X, U, hist
 
 

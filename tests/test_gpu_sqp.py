@@ -247,3 +247,49 @@ def test_config5_at_the_benchmark_batch_size(capi, mo):
     for i in (3, 200):
         X, U, hist = mo.sqp_fnn(f, X0[i], kw["x_ref"], kw["u_ref"], kw["Q"], kw["R"], kw["S"], kw["P"], kw["u_min"], kw["u_max"], iters, adaptive=True)
         assert np.abs(r["u"][i] - U).max() <= 1e-5
+
+
+def test_sqp_with_state_box(capi, mo):
+    """The state box of the reference's NLP branch (.../fnn/mpc_modeler_implementation_fnn.jl:146-153) in the SQP loop: rows of every
+    iteration's QP.  Checked against the restatement with exact QP solves (same rows), and directly: the final trajectory is the
+    network's own rollout, inside the box, with state rows active at the solution."""
+    b, N, iters = 24, 20, 25
+    f = mo.synthetic_fnn(act="tanh")
+    n, m = 4, 2
+    x_ref = np.tile(np.array([0.2, -0.1, 0.05, 0.0])[:, None], (1, N + 1)); u_ref = np.tile(np.array([0.1, -0.2])[:, None], (1, N))
+    Q, R, P, S = 100.0 * np.eye(n), 0.1 * np.eye(m), 150.0 * np.eye(n), np.zeros((m, m))
+    umin, umax = -np.ones(m), np.ones(m)
+    # the box: 0.6 of the range the unconstrained solutions of these instances sweep (tools: oracle sqp_fnn without rows), so that
+    # the transients run into it; the initial states are moved inside
+    xlo, xhi = np.array([-0.12, -0.58, -0.25, -0.35]), np.array([0.25, 0.09, 0.07, 0.22])
+    X0 = x_ref[:, 0][None, :] + 0.5 * mo.splitmix_normal(0x5EED0005, 40, b, n)
+    X0 = np.clip(X0, xlo + 0.02 * (xhi - xlo), xhi - 0.02 * (xhi - xlo))
+    s = capi.Solver(n, m, N, b)
+    s.sqp_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, x_ref, u_ref, Q, R, S, P, umin, umax, act="tanh", xmin=xlo, xmax=xhi)
+    s.sqp_fnn_start(X0)
+    # three of these instances have an infeasible first QP (no elastic mode: the reference's Ipopt would report the NLP's
+    # linearisation infeasible too, and JuMP.value would throw): they are skipped and named, the others are unaffected
+    with pytest.raises(capi.AlmpcError) as ei:
+        s.sqp_fnn_iterate(iters)
+    assert ei.value.code == -6 and "infeasible" in str(ei.value)
+    skipped = np.flatnonzero(s.sqp_fnn_skipped())
+    r = s.get_results()
+    s.close()
+    infeasible = []
+    for i in range(b):
+        try:
+            X, U, hist, na = mo.sqp_fnn(f, X0[i], x_ref, u_ref, Q, R, S, P, umin, umax, 1, x_min=xlo, x_max=xhi, return_active=True)
+        except ValueError:
+            infeasible.append(i)
+    assert list(skipped) == infeasible and len(infeasible) == 3
+    good = [i for i in range(b) if i not in infeasible]
+    nact = 0
+    for i in good:
+        assert np.abs(r["x"][i] - mo.fnn_rollout(f, X0[i], r["u"][i])).max() <= 1e-5    # (instance 16 converges slowly: 2e-6 steps left)
+        assert np.all(r["x"][i] <= xhi[:, None] + 1e-5) and np.all(r["x"][i] >= xlo[:, None] - 1e-5)
+        nact += int(((r["x"][i][:, 1:] >= xhi[:, None] - 1e-6) | (r["x"][i][:, 1:] <= xlo[:, None] + 1e-6)).sum())
+    assert nact > 10 * len(good), "the box never binds: test inputs too tame"
+    for i in (0, 5, 11, 16, 23):
+        X, U, hist, na = mo.sqp_fnn(f, X0[i], x_ref, u_ref, Q, R, S, P, umin, umax, iters, x_min=xlo, x_max=xhi, return_active=True)
+        assert na >= 17
+        assert np.abs(r["u"][i] - U).max() <= U_TOL and np.abs(r["x"][i] - X).max() <= 1e-5
