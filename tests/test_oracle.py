@@ -468,3 +468,26 @@ def test_riccati_active_set_solves_the_qp_of_an_sqp_iteration(mo):
         Xb, Ub, hb = mo.sqp_fnn(f, x0, x_ref, u_ref, Q, R, S, P, -np.ones(m), np.ones(m), it, structured=True)
         assert np.abs(Ua - Ub).max() <= 1e-10 and np.abs(Xa - Xb).max() <= 1e-10
         assert abs(ha[-1][0] - hb[-1][0]) <= 1e-10 * max(1.0, ha[-1][0])
+
+
+def test_ltv_state_rows_reduce_to_the_lti_state_box(mo):
+    """ltv_qp + ltv_state_rows + solve_qp_rows_exact with A_k = A, B_k = B, zero inputs and the free response as linearisation
+    trajectory is the state-box problem of solve_mpc_exact (same rows, same optimum); and an infeasible box raises."""
+    p = mo.make_problem(np.array([[1.0, 1.0], [0.0, 1.0]]), np.array([[0.5], [1.0]]), 10, [-1.0], [1.0],
+                        x_min=[-10.0, -0.8], x_max=[10.0, 0.8], terminal="equality")
+    x0 = np.array([4.0, 0.0])
+    e = mo.solve_mpc_exact(p, x0, return_info=True)
+    assert e["info"]["n_active_state"] > 2   # (the two equality rows and velocity-box rows)
+    N, n, m = p.N, 2, 1
+    xbar = np.zeros((n, N + 1)); xbar[:, 0] = x0
+    for k in range(N):
+        xbar[:, k + 1] = p.A @ xbar[:, k]
+    ubar = np.zeros((m, N))
+    H, q, lo, hi, Gam, g = mo.ltv_qp([p.A] * N, [p.B] * N, None, xbar, ubar, p.x_ref, p.u_ref, p.Q, p.R, p.S, p.P, p.u_min, p.u_max,
+                                     return_prediction=True)
+    C, a0, lo_c, hi_c, eq_c = mo.ltv_state_rows(Gam, g, xbar, p.x_ref, p.x_min, p.x_max, "equality")
+    v, W = mo.solve_qp_rows_exact(H, q, lo, hi, C, a0, lo_c, hi_c, eq_c)
+    assert np.abs(v.reshape(N, m).T - e["u"]).max() <= 1e-8
+    with pytest.raises(ValueError):
+        C2, a2, l2, h2, e2 = mo.ltv_state_rows(Gam, g, xbar, p.x_ref, np.array([-10.0, -0.05]), np.array([10.0, 0.05]), "equality")
+        mo.solve_qp_rows_exact(H, q, lo, hi, C2, a2, l2, h2, e2)
