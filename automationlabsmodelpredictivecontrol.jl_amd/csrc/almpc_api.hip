@@ -1048,7 +1048,6 @@ int almpc_relin_fnn_setup(almpc_handle* h, int H, int L, int activation, const d
                                           "comes from the linearisation at the last reference, src/sub/design_mpc.jl:312-327)");
     if (activation < 0 || activation > 4) return fail(h, ALMPC_ERR_UNSUPPORTED, "relin_fnn_setup: activation must be 0..4");
     if (!(rho > 0.0) || !(sigma >= 0.0)) return fail(h, ALMPC_ERR_INVALID, "relin_fnn_setup: rho must be > 0 and sigma >= 0");
-    if (h->terminal_eq) return fail(h, ALMPC_ERR_UNSUPPORTED, "relin_fnn_setup: state rows (terminal equality) need a shared model");
     const int n = h->n, m = h->m, N = h->N, nz = h->nz;
     const size_t b = (size_t)h->batch, nin = (size_t)n + m;
     if ((2 * (size_t)H + 2 * (size_t)H * nin + nin) * sizeof(double) > 160 * 1024)
@@ -1234,7 +1233,6 @@ int almpc_sqp_fnn_setup(almpc_handle* h, int H, int L, int activation, const dou
         return fail(h, ALMPC_ERR_INVALID, "sqp_fnn_setup: null pointer or bad network shape (P must be given)");
     if (activation < 0 || activation > 4) return fail(h, ALMPC_ERR_UNSUPPORTED, "sqp_fnn_setup: activation must be 0..4");
     if (!(rho > 0.0) || !(sigma >= 0.0)) return fail(h, ALMPC_ERR_INVALID, "sqp_fnn_setup: rho must be > 0 and sigma >= 0");
-    if (h->terminal_eq) return fail(h, ALMPC_ERR_UNSUPPORTED, "sqp_fnn_setup: state rows (terminal equality) need a shared model");
     const int n = h->n, m = h->m, N = h->N, nz = h->nz, nzs = h->nzs;
     const size_t b = (size_t)h->batch, nin = (size_t)n + m;
     if (n > 64 || sqp_step_lds_doubles(n, m, N) * sizeof(double) > 160 * 1024)
@@ -1710,9 +1708,9 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         gp.zs = h->dZs; gp.ys = h->dYs; gp.v0 = h->dV0; gp.status = h->dStatus; gp.piters = h->dPiters;
         gp.max_iter = o.polish_max_iter > 0 ? o.polish_max_iter : 20 * h->R + 50;
         gp.roll_g = roll_g; gp.roll_cpl = roll_cpl; gp.roll = rp;
-        if (!h->dOverflow) HIP_TRY(h, dalloc(&h->dOverflow, (size_t)h->batch + 2));
+        if (!h->dOverflow) HIP_TRY(h, dalloc(&h->dOverflow, (size_t)h->batch * 33 + 2));   // list, then [batch][32] working sets
         HIP_TRY(h, hipMemsetAsync(h->dOverflow, 0, 2 * sizeof(int32_t), st));
-        gp.ovf = h->dOverflow;
+        gp.ovf = h->dOverflow; gp.ovf_ws = h->dOverflow + 2 + h->batch;
         const dim3 grid((h->batch + PGEN_WAVES - 1) / PGEN_WAVES), block(64 * PGEN_WAVES);
         // first launch: working sets up to 32 rows, every instance; second launch: the instances the first one flagged, up to 64 rows
         const size_t l32 = (size_t)PGEN_WAVES * pgen_lds_per_wave(32) * sizeof(double);

@@ -50,6 +50,8 @@ struct PolishGenParams {
     int32_t* status; int32_t* piters;
     int32_t* ovf;         // [0] number of flagged instances (working set outgrew the 32-row build), [1] queue cursor of the
                           // second launch, [2 ...] the flagged instances; [0] and [1] are zeroed before the first launch
+    int32_t* ovf_ws;      // [batch][32] working set of a flagged instance when it ran out of room, row | (side + 1) << 12, the
+                          // second launch's guess ([0] = -1: none, it builds its guess from the ADMM hand-off as the first did)
     int max_iter;
     int roll_g, roll_cpl;
     RolloutParams roll;
@@ -110,7 +112,7 @@ template <int NP, int WL>
 __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double* smem) {
     static_assert(WL == 32 || WL == 64, "working-set capacity: 32 (mirrored half-waves) or 64 (one position per lane)");
     constexpr int HS = 64 / WL;  // lanes per position: 2 = the half-waves split the columns of a sweep, 1 = no split
-    constexpr int CH = 8;
+    constexpr int CH = NP >= 3 ? 4 : 8;  // rows of Ghat per group of loads: NP * CH <= 16 loads (32 registers) in flight per lane
     constexpr bool QUEUE = WL == 64;  // the 64-row build is the second launch: persistent waves pull flagged instances
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   do {  // (one pass in the first launch)
@@ -128,6 +130,13 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
     }
     const int st_in = p.status[inst];
     const int nz = p.nz, nzs = p.nzs, R = p.R, Rs = p.Rs;
+#ifdef ALMPC_STAMPS
+    const int stamp_id = inst + (QUEUE ? p.batch : 0);
+#define PGEN_STAMP(SLOT) ALMPC_STAMP(stamp_id, SLOT)
+#else
+#define PGEN_STAMP(SLOT)
+#endif
+    PGEN_STAMP(0);
     const double* Gh = p.Ghat + (size_t)inst * p.Ghat_stride;
     const double* gnv = p.gnorm + (size_t)inst * p.gnorm_stride;
     const double* dvi = p.dvec + (size_t)inst * p.d_stride;
@@ -169,8 +178,8 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
 
     // ---- rows of this lane: pairs (2 lane, 2 lane + 1) + 128 q
     int rrow[NP][2];
-    double s0v[NP][2], sv[NP][2], lo[NP][2], hi[NP][2], gn[NP][2], bnd[NP][2];
-    bool act[NP][2], valid[NP][2];
+    double s0v[NP][2], sv[NP][2], lo[NP][2], hi[NP][2], gn[NP][2];
+    unsigned actm = 0, eqm = 0;   // bit 2 q + e: the row is in the working set / is a terminal-equality row
     double y0 = 0, y1 = 0, z0 = 0, z1 = 0;
     bool x0_bad = false;
     // unconstrained minimiser v0 and the box-ADMM iterate (input rows live in pair 0)
@@ -192,43 +201,61 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
             Z[i] = p.ltv ? 0.0 : xv - rp.xref[(size_t)inst * rp.xref_stride + i];
             if (p.has_box && !(xv >= p.xmin[i] && xv <= p.xmax[i])) x0_bad = true;  // stage 1 is x0 itself
         }
+        // Row data: every load is unconditional on a clamped index and issued BEFORE the rollout of v0, level by level (tables, then
+        // what they point to), so that the whole set is in flight together and its latency hides behind the rollout.
+        int tr_[NP][2], eq_[NP][2], xi_[NP][2], si_[NP][2];
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int r = 2 * lane + e + 128 * q;
+                const int rcl = r < R ? r : 0;
+                rrow[q][e] = r;
+                tr_[q][e] = p.row_traj[rcl]; eq_[q][e] = p.row_eq[rcl]; xi_[q][e] = p.row_xidx[rcl]; si_[q][e] = p.row_state[rcl];
+                gn[q][e] = gnv[rcl];
+            }
+        double xr_[NP][2], xmn_[NP][2], xmx_[NP][2], eqo_[NP][2], urf[2], umn[2], umx[2];
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                xr_[q][e] = rp.xref[(size_t)inst * rp.xref_stride + xi_[q][e]];
+                xmn_[q][e] = p.xmin[si_[q][e]]; xmx_[q][e] = p.xmax[si_[q][e]];
+                eqo_[q][e] = p.eq_off ? -p.eq_off[(size_t)inst * p.eq_stride + si_[q][e]] : 0.0;
+            }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {   // input rows live in pair 0
+            const int r = 2 * lane + e, rcl = r < nz ? r : 0;
+            urf[e] = p.uref[(size_t)inst * p.uref_stride + rcl];
+            umn[e] = p.umin[rcl % m]; umx[e] = p.umax[rcl % m];
+        }
         wave_fence_lds();
         roll(Z);
 #pragma unroll
         for (int q = 0; q < NP; ++q)
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const int r = 2 * lane + e + 128 * q;
-                rrow[q][e] = r;
-                valid[q][e] = r < R;
-                act[q][e] = false;
-                bnd[q][e] = 0.0;
-                const int rcl = valid[q][e] ? r : 0;
-                gn[q][e] = valid[q][e] ? gnv[rcl] : 1.0;
-                if (r < nz) {  // input row, bounds exactly as k_admm forms them
+                const int r = rrow[q][e];
+                const bool valid = r < R;
+                if (!valid) gn[q][e] = 1.0;
+                if (valid && r >= nz && eq_[q][e] != 0) eqm |= 1u << (2 * q + e);
+                const double zst = Z[tr_[q][e]];   // state row: value e_x[i,k] of the v0 trajectory (row 0 of Z for the others)
+                if (q == 0 && r < nz) {  // input row, bounds exactly as k_admm forms them
                     const double di = 1.0 / (e ? dv[1] : dv[0]);
-                    const double ur = p.uref[(size_t)inst * p.uref_stride + r];
-                    lo[q][e] = (p.umin[r % m] - ur) * di;
-                    hi[q][e] = (p.umax[r % m] - ur) * di;
+                    lo[q][e] = (umn[e] - urf[e]) * di;
+                    hi[q][e] = (umx[e] - urf[e]) * di;
                     s0v[q][e] = e ? vv[1] : vv[0];
-                } else if (valid[q][e]) {  // state row: value e_x[i,k] of the v0 trajectory, shared bounds
-                    const int tr = p.row_traj[rcl];
-                    s0v[q][e] = Z[tr];
-                    if (p.row_eq[rcl]) {
-                        const double off = p.eq_off ? -p.eq_off[(size_t)inst * p.eq_stride + p.row_state[rcl]] : 0.0;
-                        lo[q][e] = off; hi[q][e] = off;
-                    }
-                    else {
-                        const double xr = rp.xref[(size_t)inst * rp.xref_stride + p.row_xidx[rcl]];
-                        lo[q][e] = p.xmin[p.row_state[rcl]] - xr;
-                        hi[q][e] = p.xmax[p.row_state[rcl]] - xr;
-                    }
+                } else if (valid) {  // state row, shared bounds relative to the reference (or the linearisation trajectory)
+                    s0v[q][e] = zst;
+                    lo[q][e] = eq_[q][e] ? eqo_[q][e] : xmn_[q][e] - xr_[q][e];
+                    hi[q][e] = eq_[q][e] ? eqo_[q][e] : xmx_[q][e] - xr_[q][e];
                 } else { lo[q][e] = -__builtin_inf(); hi[q][e] = __builtin_inf(); s0v[q][e] = 0.0; }
                 sv[q][e] = s0v[q][e];
             }
     }
     x0_bad = __any(x0_bad);
     wave_fence_lds();
+    PGEN_STAMP(1);
     // ---- Sinv := identity (Z is dead now)
 #pragma unroll 8
     for (int t = 0; t < WL / HS; ++t) Sl[(HS * t + hf) * WL + pos] = ((HS * t + hf) == pos) ? 1.0 : 0.0;
@@ -276,20 +303,24 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
     auto g_rows_times = [&](const double* ab, double (&qv)[NP][2]) {
 #pragma unroll
         for (int q = 0; q < NP; ++q) { qv[q][0] = 0.0; qv[q][1] = 0.0; }
-        for (int l0 = 0; l0 < k; l0 += CH) {
+        for (int l0 = 0; l0 < k; l0 += CH) {   // (all NP * CH loads of a group go out before the first is used)
+            d2 g[CH][NP];
+            double av[CH];
 #pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                d2 g[CH];
-                double av[CH];
+            for (int t = 0; t < CH; ++t) {
+                // (row index from the position's register: a scalar base address, one lane offset per pair for all rows)
+                const double* row = Gh + (size_t)__builtin_amdgcn_readlane(wrow, l0 + t) * Rs;
+                av[t] = ab[l0 + t];
 #pragma unroll
-                for (int t = 0; t < CH; ++t) {
+                for (int q = 0; q < NP; ++q) {
                     const int off = 2 * lane + 128 * q;
-                    g[t] = *reinterpret_cast<const d2*>(Gh + (size_t)wrow_s[l0 + t] * Rs + (off < Rs ? off : 0));
-                    av[t] = ab[l0 + t];
+                    g[t][q] = *reinterpret_cast<const d2*>(row + (off < Rs ? off : 0));
                 }
-#pragma unroll
-                for (int t = 0; t < CH; ++t) { qv[q][0] += g[t][0] * av[t]; qv[q][1] += g[t][1] * av[t]; }
             }
+#pragma unroll
+            for (int t = 0; t < CH; ++t)
+#pragma unroll
+                for (int q = 0; q < NP; ++q) { qv[q][0] += g[t][q][0] * av[t]; qv[q][1] += g[t][q][1] * av[t]; }
         }
     };
     auto load_row = [&](int j, double (&gj)[NP][2]) {
@@ -321,12 +352,37 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
 #pragma unroll
         for (int q = 0; q < NP; ++q) { sv[q][0] = s0v[q][0] - qv[q][0]; sv[q][1] = s0v[q][1] - qv[q][1]; }
     };
+    // The rows of the working set must sit on their bounds in values computed from scratch.  With an ill-conditioned Ghat_WW the
+    // bordered inverse loses digits and they do not: refine the multipliers on that residual (a few rounds of iterative refinement);
+    // false when it does not settle -- the instance is then NOT reported as solved.
+    auto refine = [&]() -> bool {
+        put_rows(gn);
+        const double gw = rowbuf[wrow];
+        wave_fence_lds();
+        for (int rr = 0; rr < 4; ++rr) {
+            put_rows(sv);
+            const double rv = rowbuf[wrow] - wbnd;
+            const double res = wave_max((lowhalf && pos < k) ? fabs(rv) / gw : 0.0);
+            if (res <= 1e-9) return true;
+            if (rr == 3) break;
+            put_pos(pbufa, (pos < k) ? rv : 0.0);
+            const double dl = s_matvec(pbufa);
+            const double dlm = (pos < k) ? dl : 0.0;
+            lam += dlm;
+            put_pos(pbufb, dlm);
+            double qv[NP][2];
+            g_rows_times(pbufb, qv);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) { sv[q][0] -= qv[q][0]; sv[q][1] -= qv[q][1]; }
+        }
+        return false;
+    };
     auto mark = [&](int j, bool on, double bval) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < NP; ++q)
 #pragma unroll
             for (int e = 0; e < 2; ++e)
-                if (rrow[q][e] == j) { act[q][e] = on; bnd[q][e] = bval; }
+                if (rrow[q][e] == j) actm = on ? (actm | (1u << (2 * q + e))) : (actm & ~(1u << (2 * q + e)));
     };
     // border Sinv with row j given u = Sinv c and isc = 1/(Ghat_jj - c'u)
     auto border = [&](int j, double u, double isc, double bval, int sd, double lamj) __attribute__((always_inline)) {
@@ -378,8 +434,8 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
         wave_fence_lds();
     };
     // direction of adding row j, first half: c = Ghat[W,j] -> u = Sinv c (also left in pbufb), dp = Ghat_jj - c'u
-    auto dir_u = [&](int j, double (&gj)[NP][2], double& u, double& dp, double& gjj) __attribute__((always_inline)) {
-        load_row(j, gj);
+    auto dir_u = [&](int j, double (&gj)[NP][2], double& u, double& dp, double& gjj, bool loaded = false) __attribute__((always_inline)) {
+        if (!loaded) load_row(j, gj);
         put_rows(gj);
         const double cv = rowbuf[wrow];
         const double c = (pos < k) ? cv : 0.0;
@@ -400,6 +456,7 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
     const bool skip = (st_in == 2) || x0_bad;
     bool give_up = skip;
     bool overflow = false;  // the working set hit WL rows
+    bool guess_overflow = false;  // ... while the guess was still being built (its rows beyond WL are not in the working set)
     if (!skip) {
         // ---- initial working set: equality rows, then the input rows the ADMM multipliers flag (rows ascending)
         int flag[NP][2];
@@ -410,8 +467,8 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
             for (int e = 0; e < 2; ++e) {
                 int f = 0;
                 const int r = rrow[q][e];
-                if (valid[q][e]) {
-                    if (r >= nz) { if (p.row_eq[r]) f = 2; }
+                if (r < R) {
+                    if (r >= nz) { if ((eqm >> (2 * q + e)) & 1u) f = 2; }
                     else {
                         const double yy = e ? y1 : y0, ww = fmin(fmax(e ? z1 : z0, lo[q][e]), hi[q][e]);
                         if (yy < 0.0 && ww <= lo[q][e]) f = -1;
@@ -439,27 +496,42 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
         cnt = base_pos;
         wave_fence_lds();
         // guessed rows live in registers of lane = guess index (up to 64 of them)
-        const int g_row = (lane < cnt && lane < 64) ? ibuf[lane] : 0;
-        const int g_sd = (lane < cnt && lane < 64) ? ibuf[64 + lane] : 0;
-        double bsel[NP][2];
-#pragma unroll
-        for (int q = 0; q < NP; ++q)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) bsel[q][e] = (flag[q][e] == -1) ? lo[q][e] : hi[q][e];  // equality rows: lo == hi
+        int g_row = (lane < cnt && lane < 64) ? ibuf[lane] : 0;
+        int g_sd = (lane < cnt && lane < 64) ? ibuf[64 + lane] : 0;
+        if (QUEUE) {   // second launch: start from the working set the first launch had when it ran out of room
+            const int w0 = p.ovf_ws[(size_t)inst * 32];
+            if (w0 >= 0) {
+                const int wv_ = p.ovf_ws[(size_t)inst * 32 + (lane & 31)];
+                cnt = 32;
+                g_row = lane < 32 ? (wv_ & 0xFFF) : 0;
+                g_sd = lane < 32 ? ((wv_ >> 12) & 3) - 1 : 0;
+            }
+        }
         wave_fence_lds();
         // Build the working set row by row (bordering), skipping rows that are linearly dependent on the rows already
-        // taken: a saturated guess can hold more rows than there are variables.
+        // taken: a saturated guess can hold more rows than there are variables.  The next row of Ghat is requested while the
+        // current one is processed.
         const int ng = cnt < 64 ? cnt : 64;
+        double gnx[NP][2];
+        if (ng > 0) load_row(__builtin_amdgcn_readlane(g_row, 0), gnx);
         for (int gi = 0; gi < ng; ++gi) {
-            if (k == WL) { give_up = true; overflow = true; break; }
+            if (k == WL) { give_up = true; overflow = true; guess_overflow = true; break; }
             const int j = __builtin_amdgcn_readlane(g_row, gi), sd = __builtin_amdgcn_readlane(g_sd, gi);
             double gj[NP][2], u, dp, gjj;
-            dir_u(j, gj, u, dp, gjj);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) { gj[q][0] = gnx[q][0]; gj[q][1] = gnx[q][1]; }
+            if (gi + 1 < ng) load_row(__builtin_amdgcn_readlane(g_row, gi + 1), gnx);
+            dir_u(j, gj, u, dp, gjj, true);
             if (!(dp > 1e-10 * gjj)) continue;
-            border(j, u, 1.0 / dp, row_value(bsel, j), sd, 0.0);
+            border(j, u, 1.0 / dp, sd < 0 ? row_value(lo, j) : row_value(hi, j), sd, 0.0);   // (equality rows: lo == hi)
         }
+        PGEN_STAMP(2);
+#ifdef ALMPC_STAMPS
+        if (g_stamps && lane == 0) g_stamps[(size_t)stamp_id * 16 + 8] = k;
+#endif
         if (!give_up && k > 0) recompute();
     }
+    PGEN_STAMP(3);
 
     const int max_iter = p.max_iter;
     if (!give_up) {
@@ -474,6 +546,7 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
             remove_pos(vi, true);
             ++it;
         }
+        PGEN_STAMP(4);
         // ---- Goldfarb-Idnani main loop
         bool fresh = false;
         while (it < max_iter) {
@@ -485,7 +558,8 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
             for (int q = 0; q < NP; ++q)
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    const double v = (valid[q][e] && !act[q][e]) ? fmax(sv[q][e] - hi[q][e], lo[q][e] - sv[q][e]) / gn[q][e] : -__builtin_inf();
+                    // (rows beyond R have infinite bounds: their measure is -inf by itself)
+                    const double v = !((actm >> (2 * q + e)) & 1u) ? fmax(sv[q][e] - hi[q][e], lo[q][e] - sv[q][e]) / gn[q][e] : -__builtin_inf();
                     if (v > vbest) { vbest = v; which = 2 * q + e; }
                 }
             const double vmax = wave_max(vbest);
@@ -493,6 +567,8 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
             if (!(vmax > 1e-9)) {
                 if (fresh) { fin = 0; break; }
                 recompute();  // confirm on values computed from scratch
+                if (k > 0 && !refine()) { fin = 1; break; }   // (measured: rebuilding the inverse from the rows does not rescue these --
+                                                              // their Ghat_WW is singular to working precision: edge of feasibility)
                 fresh = true;
                 --it;
                 continue;
@@ -548,6 +624,10 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
         }
     }
     if (x0_bad && st_in != 2) fin = 3;
+    PGEN_STAMP(5);
+#ifdef ALMPC_STAMPS
+    if (g_stamps && lane == 0) { g_stamps[(size_t)stamp_id * 16 + 9] = it; g_stamps[(size_t)stamp_id * 16 + 10] = k; }
+#endif
 
     // ---- result: w = input rows of s (pair 0), then the fused rollout
     d2 wout;
@@ -555,14 +635,18 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
         wout[0] = (st_in == 2) ? z0 : fmin(fmax(z0, lo[0][0]), hi[0][0]);
         wout[1] = (st_in == 2) ? z1 : fmin(fmax(z1, lo[0][1]), hi[0][1]);
     } else {
-        wout[0] = act[0][0] ? bnd[0][0] : fmin(fmax(sv[0][0], lo[0][0]), hi[0][0]);
-        wout[1] = act[0][1] ? bnd[0][1] : fmin(fmax(sv[0][1], lo[0][1]), hi[0][1]);
+        // an input row of the working set sits on the bound it was added at: the nearer one, exactly
+        const double c0 = fmin(fmax(sv[0][0], lo[0][0]), hi[0][0]), c1 = fmin(fmax(sv[0][1], lo[0][1]), hi[0][1]);
+        wout[0] = (actm & 1u) ? ((sv[0][0] - lo[0][0] < hi[0][0] - sv[0][0]) ? lo[0][0] : hi[0][0]) : c0;
+        wout[1] = (actm & 2u) ? ((sv[0][1] - lo[0][1] < hi[0][1] - sv[0][1]) ? lo[0][1] : hi[0][1]) : c1;
     }
     if (lane == 0) {
         p.piters[inst] = it;
         p.status[inst] = (st_in == 2) ? 2 : ((fin == 0) ? 0 : (fin == 3 ? 3 : 1));
         if (!QUEUE && overflow && fin != 3) p.ovf[2 + atomicAdd(p.ovf, 1)] = inst;
     }
+    if (!QUEUE && overflow && fin != 3 && lane < 32)   // (WL = 32 here: both half-waves mirror the positions)
+        p.ovf_ws[(size_t)inst * 32 + lane] = guess_overflow ? -1 : (wrow | ((wsd + 1) << 12));
     wave_fence_lds();
     {
         const int r0 = 2 * lane, r1 = 2 * lane + 1;
@@ -588,13 +672,26 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
         roll(Z);
         const int nx = n * (N + 1);
         const size_t xo = (size_t)inst * nx;
-        for (int t = lane; t < nx; t += 64) {
-            const double ev = Z[(size_t)(t / n) * C + t % n];
-            rp.ex[xo + t] = ev;
-            rp.x[xo + t] = (t < n) ? rp.x0[(size_t)inst * n + t] : ev + rp.xref[(size_t)inst * rp.xref_stride + t];
+        for (int t0 = 0; t0 < nx; t0 += 256) {   // (four reference loads in flight per lane)
+            double xr4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int t = t0 + 64 * j + lane, tc = t < nx ? t : 0;
+                xr4[j] = (tc < n) ? rp.x0[(size_t)inst * n + tc] : rp.xref[(size_t)inst * rp.xref_stride + tc];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int t = t0 + 64 * j + lane;
+                if (t < nx) {
+                    const double ev = Z[(size_t)(t / n) * C + t % n];
+                    rp.ex[xo + t] = ev;
+                    rp.x[xo + t] = (t < n) ? xr4[j] : ev + xr4[j];
+                }
+            }
         }
         }
     }
+    PGEN_STAMP(6);
     if (QUEUE) wave_fence_lds();  // the next instance reuses this wave's LDS slot
   } while (QUEUE);
 }

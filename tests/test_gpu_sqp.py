@@ -164,9 +164,14 @@ def test_mirror_non_linear_programming_type(pkg, mo):
     res = pkg._model_predictive_control_computation(C, X1)
     st, de = C.tuning.modeler.last_sqp_history
     assert st[-1] <= 1e-3 and de[-1] <= 1e-8
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError):   # a quadratic constraint, not a QP row (src/sub/design_mpc.jl:333-340)
         pkg.proceed_controller(sys_, "model_predictive_control", N, 1, x_ref, u_ref, mpc_programming_type="non_linear",
-                               mpc_terminal_ingredient="equality")
+                               mpc_terminal_ingredient="contractive")
+    # the terminal equality is a row of every iteration's QP (tests/test_gpu_state_rows_instances.py has the solves)
+    Ce = pkg.proceed_controller(sys_, "model_predictive_control", N, 1, x_ref, u_ref, mpc_programming_type="non_linear",
+                                mpc_terminal_ingredient="equality")
+    assert Ce.tuning.terminal_ingredient.Xf == "equality"
+    Ce.tuning.modeler.solver.close()
     C.tuning.modeler.solver.close()
 
 
