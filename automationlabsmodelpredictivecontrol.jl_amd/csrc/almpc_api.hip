@@ -655,12 +655,10 @@ void launch_batched_factor(almpc_handle* h, const DesignStrides& ds, double rho,
     const unsigned gb = (unsigned)h->batch;
     hipLaunchKernelGGL(k_design_scale, dim3(1, gb), dim3(256), 0, st, nz, nzs, n, h->bH, h->bF, h->bD, h->bHs, h->bFs, h->bFlag, ds);
     const size_t inv_lds = 520 * sizeof(double);
-    hipLaunchKernelGGL(k_design_inverse, dim3(1, gb), dim3(DESIGN_INVERSE_THREADS), inv_lds, st, nz, nzs, h->bHs, 0.0, (const double*)nullptr, h->bG, h->bFlag,
-                       ds.Hs, 0L, ds.G, 1L);
+    launch_design_inverse(dim3(1, gb), inv_lds, st, nz, nzs, h->bHs, 0.0, (const double*)nullptr, h->bG, h->bFlag, ds.Hs, 0L, ds.G, 1L);
     if (h->skip_admm) return;  // no ADMM phase in this solve: its KKT inverse is not needed
     hipLaunchKernelGGL(k_design_rho, dim3(1, gb), dim3(256), 0, st, nz, nzs, h->rho_mode, rho, h->bG, h->bRho, ds.G, ds.rho);
-    hipLaunchKernelGGL(k_design_inverse, dim3(1, gb), dim3(DESIGN_INVERSE_THREADS), inv_lds, st, nz, nzs, h->bHs, sigma, (const double*)h->bRho, h->bMinv,
-                       h->bFlag, ds.Hs, ds.rho, ds.Minv, 1L);
+    launch_design_inverse(dim3(1, gb), inv_lds, st, nz, nzs, h->bHs, sigma, (const double*)h->bRho, h->bMinv, h->bFlag, ds.Hs, ds.rho, ds.Minv, 1L);
 }
 
 DesignStrides batched_strides(const almpc_handle* h, bool p_inst) {
@@ -769,8 +767,6 @@ hipError_t launch_batched_design(almpc_handle* h, const DesignStrides& ds, int u
         hipLaunchKernelGGL(k_design_hessian, dim3(nrb, gb), dim3(64 * (nrb + njf)), hess_lds, st, hp);
     }
     e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    e = ensure_dyn_lds(reinterpret_cast<const void*>(k_design_inverse), 520 * sizeof(double));
     if (e != hipSuccess) return e;
     launch_batched_factor(h, ds, rho, sigma, st);
     hipLaunchKernelGGL(k_neg_gm, dim3(4, gb), dim3(256), 0, st, nz, nzs, n, nzs, h->bG, h->bFs, h->bVs, ds.G, ds.Fs);
@@ -906,8 +902,8 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
             e = launch_design_ltv(h, lp, st);
         }
         if (e == hipSuccess && h->mc > 0) {   // (needs G_i, d_i: the factor step comes first when there are state rows)
-            e = ensure_dyn_lds(reinterpret_cast<const void*>(k_design_inverse), 520 * sizeof(double));
-            if (e == hipSuccess) { launch_batched_factor(h, ds, rho, sigma, st); e = launch_ghat_inst(h, dAll, dBll); }
+            launch_batched_factor(h, ds, rho, sigma, st);
+            e = launch_ghat_inst(h, dAll, dBll);
         }
         if (e == hipSuccess) e = hipStreamSynchronize(st);  // the staging buffers are released right away
         for (double** q : {&h->lA, &h->lB, &h->lC, &h->lE})
@@ -918,7 +914,6 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
         }
         (void)hipFree(dAll); (void)hipFree(dBll); (void)hipFree(dC); (void)hipFree(dE); (void)hipFree(dQa);
         if (e != hipSuccess) { release(); return fail(h, ALMPC_ERR_HIP, std::string("design_ltv: ") + hipGetErrorString(e)); }
-        BTRY(ensure_dyn_lds(reinterpret_cast<const void*>(k_design_inverse), 520 * sizeof(double)));
         if (h->mc == 0) launch_batched_factor(h, ds, rho, sigma, st);
         hipLaunchKernelGGL(k_neg_gm, dim3(4, gb), dim3(256), 0, st, nz, nzs, n, nzs, h->bG, h->bFs, h->bVs, ds.G, ds.Fs);
         BTRY(hipGetLastError());
@@ -1391,7 +1386,6 @@ int almpc_sqp_fnn_iterate(almpc_handle* h, int iters, double step_scale, const a
         q.stats_cap = iters;
     }
     HIP_TRY(h, hipMemsetAsync(q.stats, 0, (size_t)2 * iters * sizeof(unsigned long long), st));
-    HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(k_design_inverse), (size_t)((520 * sizeof(double)))));
     const DesignStrides ds = batched_strides(h, q.sP != 0);
     const size_t step_lds = sqp_step_lds_doubles(n, m, N) * sizeof(double);
     if (step_lds > 64 * 1024) HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(k_sqp_step), (size_t)(step_lds)));

@@ -222,7 +222,11 @@ __global__ __launch_bounds__(256) void k_design_scale(int nz, int nzs, int n, co
 // the LDS return path, and the 4 x 16 tile moves 3.2 x fewer bytes per FMA than one row x 32 columns per thread did (same
 // operations on the same operands: bit-identical results).  nz <= 128.
 constexpr int DESIGN_INVERSE_THREADS = 256;
-__global__ __launch_bounds__(DESIGN_INVERSE_THREADS) void k_design_inverse(int nz, int nzs, const double* Hs, double cshift, const double* dshift,
+// <AR, KC>: row slots and columns per thread -- the register tile covers 32 AR x 8 KC entries: <4, 16> = 128 x 128 (nz <= 128), <2, 8> =
+// 64 x 64 (nz <= 64: a quarter of the FMAs per pivot; the re-linearisation pipeline's 40 x 40 matrices).  Same operations on the same
+// operands in both: bit-identical results.
+template <int AR, int KC>
+__global__ __launch_bounds__(DESIGN_INVERSE_THREADS) void k_design_inverse_t(int nz, int nzs, const double* Hs, double cshift, const double* dshift,
                                                         double* Out, int* flag, long sHs, long sShift, long sOut, long sFlag) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     Hs += blockIdx.y * sHs; Out += blockIdx.y * sOut; flag += blockIdx.y * sFlag;
@@ -232,37 +236,37 @@ __global__ __launch_bounds__(DESIGN_INVERSE_THREADS) void k_design_inverse(int n
     int* badp = reinterpret_cast<int*>(smem + 512);
     const int ri = threadIdx.x & 31, g = threadIdx.x >> 5;
     if (threadIdx.x == 0) *badp = 0;
-    double S[4][16];
+    double S[AR][KC];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < AR; ++a)
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int i = ri + 32 * a, c = 16 * g + k;
+        for (int k = 0; k < KC; ++k) {
+            const int i = ri + 32 * a, c = KC * g + k;
             double v = 0.0;
             if (i < nz && c < nz) v = Hs[(size_t)c * nzs + i] + (i == c ? cshift + (dshift ? dshift[i] : 0.0) : 0.0);
             S[a][k] = v;
         }
     for (int gq = 0; gq < 8; ++gq) {
-        const int ap = gq >> 1;                     // row slot of the pivot rows of this column group (uniform)
+        const int ap = (KC * gq) >> 5;              // row slot of the pivot rows of this column group (uniform)
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int pv = 16 * gq + k;
+        for (int k = 0; k < KC; ++k) {
+            const int pv = KC * gq + k;
             if (pv < nz) {  // uniform
                 double* pr = prow + (pv & 1) * 128;
                 double* pc = pcol + (pv & 1) * 128;
                 const bool rowp = ri == (pv & 31);  // this thread holds a piece of row pv (in slot ap)
                 if (g == gq) {                      // column pv, every row
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) pc[ri + 32 * a] = S[a][k];
+                    for (int a = 0; a < AR; ++a) pc[ri + 32 * a] = S[a][k];
                 }
-                if (rowp) {                         // row pv, this thread's 16 columns
+                if (rowp) {                         // row pv, this thread's KC columns
 #pragma unroll
-                    for (int a = 0; a < 4; ++a)
+                    for (int a = 0; a < AR; ++a)
                         if (a == ap) {
 #pragma unroll
-                            for (int kk = 0; kk < 16; kk += 2) {
+                            for (int kk = 0; kk < KC; kk += 2) {
                                 d2 w; w[0] = S[a][kk]; w[1] = S[a][kk + 1];
-                                *reinterpret_cast<d2*>(pr + 16 * g + kk) = w;
+                                *reinterpret_cast<d2*>(pr + KC * g + kk) = w;
                             }
                         }
                 }
@@ -270,21 +274,21 @@ __global__ __launch_bounds__(DESIGN_INVERSE_THREADS) void k_design_inverse(int n
                 const double piv = pr[pv];
                 if (!(piv > 0.0) && threadIdx.x == 0) *badp = 1;
                 const double ip = 1.0 / (piv > 0.0 ? piv : 1.0);
-                double w[16];
+                double w[KC];
 #pragma unroll
-                for (int kk = 0; kk < 16; kk += 2) {
-                    const d2 t = *reinterpret_cast<const d2*>(pr + 16 * g + kk);
+                for (int kk = 0; kk < KC; kk += 2) {
+                    const d2 t = *reinterpret_cast<const d2*>(pr + KC * g + kk);
                     w[kk] = t[0]; w[kk + 1] = t[1];
                 }
 #pragma unroll
-                for (int a = 0; a < 4; ++a) {
+                for (int a = 0; a < AR; ++a) {
                     const bool isp = rowp && a == ap;
                     const double f = isp ? 0.0 : pc[ri + 32 * a] * ip;   // the pivot row itself is rescaled, not eliminated
 #pragma unroll
-                    for (int kk = 0; kk < 16; ++kk) S[a][kk] = __builtin_fma(-f, w[kk], S[a][kk]);
+                    for (int kk = 0; kk < KC; ++kk) S[a][kk] = __builtin_fma(-f, w[kk], S[a][kk]);
                     if (isp) {
 #pragma unroll
-                        for (int kk = 0; kk < 16; ++kk) S[a][kk] *= ip;
+                        for (int kk = 0; kk < KC; ++kk) S[a][kk] *= ip;
                     }
                     if (g == gq) S[a][k] = isp ? ip : -f;  // column pv
                 }
@@ -292,14 +296,20 @@ __global__ __launch_bounds__(DESIGN_INVERSE_THREADS) void k_design_inverse(int n
         }
     }
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < AR; ++a)
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int i = ri + 32 * a, c = 16 * g + k;
+        for (int k = 0; k < KC; ++k) {
+            const int i = ri + 32 * a, c = KC * g + k;
             if (i < nz && c < nz) Out[(size_t)c * nzs + i] = S[a][k];
         }
     __syncthreads();
     if (threadIdx.x == 0 && *badp) atomicExch(flag, 2);
+}
+// launcher: the smallest register tile that holds the matrix
+inline void launch_design_inverse(dim3 grid, size_t lds, hipStream_t st, int nz, int nzs, const double* Hs, double cshift, const double* dshift,
+                                  double* Out, int* flag, long sHs, long sShift, long sOut, long sFlag) {
+    if (nz <= 64) hipLaunchKernelGGL((k_design_inverse_t<2, 8>), grid, dim3(DESIGN_INVERSE_THREADS), lds, st, nz, nzs, Hs, cshift, dshift, Out, flag, sHs, sShift, sOut, sFlag);
+    else hipLaunchKernelGGL((k_design_inverse_t<4, 16>), grid, dim3(DESIGN_INVERSE_THREADS), lds, st, nz, nzs, Hs, cshift, dshift, Out, flag, sHs, sShift, sOut, sFlag);
 }
 
 // ---- K5 (shared-model design): Out = (Hs + c I + diag(dshift))^-1 by Cholesky -----------------------------
