@@ -769,7 +769,7 @@ hipError_t launch_batched_design(almpc_handle* h, const DesignStrides& ds, int u
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     launch_batched_factor(h, ds, rho, sigma, st);
-    hipLaunchKernelGGL(k_neg_gm, dim3(4, gb), dim3(256), 0, st, nz, nzs, n, nzs, h->bG, h->bFs, h->bVs, ds.G, ds.Fs);
+    launch_neg_gm_batched(st, gb, nz, nzs, n, h->bG, h->bFs, h->bVs, ds.G, ds.Fs);
     return hipGetLastError();
 }
 
@@ -915,7 +915,7 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
         (void)hipFree(dAll); (void)hipFree(dBll); (void)hipFree(dC); (void)hipFree(dE); (void)hipFree(dQa);
         if (e != hipSuccess) { release(); return fail(h, ALMPC_ERR_HIP, std::string("design_ltv: ") + hipGetErrorString(e)); }
         if (h->mc == 0) launch_batched_factor(h, ds, rho, sigma, st);
-        hipLaunchKernelGGL(k_neg_gm, dim3(4, gb), dim3(256), 0, st, nz, nzs, n, nzs, h->bG, h->bFs, h->bVs, ds.G, ds.Fs);
+        launch_neg_gm_batched(st, gb, nz, nzs, n, h->bG, h->bFs, h->bVs, ds.G, ds.Fs);
         BTRY(hipGetLastError());
     } else {
         BTRY(launch_batched_design(h, ds, useR, useS, dQ, dR, dS, rho, sigma));

@@ -225,8 +225,13 @@ constexpr int DESIGN_INVERSE_THREADS = 256;
 // <AR, KC>: row slots and columns per thread -- the register tile covers 32 AR x 8 KC entries: <4, 16> = 128 x 128 (nz <= 128), <2, 8> =
 // 64 x 64 (nz <= 64: a quarter of the FMAs per pivot; the re-linearisation pipeline's 40 x 40 matrices).  Same operations on the same
 // operands in both: bit-identical results.
-template <int AR, int KC>
-__global__ __launch_bounds__(DESIGN_INVERSE_THREADS) void k_design_inverse_t(int nz, int nzs, const double* Hs, double cshift, const double* dshift,
+// Round 2, measured on 4096 quadrotor-size matrices (1.24 ms per launch, SQ counters: 106 VALU instructions per pivot and thread for
+// 32 FMAs, VALU 57 % busy, 26 % of the wave cycles in s_waitcnt) and NOT faster, each tried by itself: 512 threads with a 4 x 8 tile
+// (4 waves per SIMD instead of 2), the reciprocal by v_rcp_f64 + two Newton steps instead of the IEEE division (kept: it is shorter),
+// a wave-uniform column ownership with the pivot row eliminated like the others (60 instructions per pivot).  What would change the
+// picture is a blocked sweep with the trailing update on FP64 MFMA (one instruction per 1024 FMAs); not built.
+template <int AR, int KC, int NG = 8>   // NG column groups of 32 threads each
+__global__ __launch_bounds__(32 * NG) void k_design_inverse_t(int nz, int nzs, const double* Hs, double cshift, const double* dshift,
                                                         double* Out, int* flag, long sHs, long sShift, long sOut, long sFlag) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     Hs += blockIdx.y * sHs; Out += blockIdx.y * sOut; flag += blockIdx.y * sFlag;
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(DESIGN_INVERSE_THREADS) void k_design_inverse_t(int
             if (i < nz && c < nz) v = Hs[(size_t)c * nzs + i] + (i == c ? cshift + (dshift ? dshift[i] : 0.0) : 0.0);
             S[a][k] = v;
         }
-    for (int gq = 0; gq < 8; ++gq) {
+    for (int gq = 0; gq < NG; ++gq) {
         const int ap = (KC * gq) >> 5;              // row slot of the pivot rows of this column group (uniform)
 #pragma unroll
         for (int k = 0; k < KC; ++k) {
@@ -273,7 +278,12 @@ __global__ __launch_bounds__(DESIGN_INVERSE_THREADS) void k_design_inverse_t(int
                 __syncthreads();
                 const double piv = pr[pv];
                 if (!(piv > 0.0) && threadIdx.x == 0) *badp = 1;
-                const double ip = 1.0 / (piv > 0.0 ? piv : 1.0);
+                // 1 / pivot: hardware reciprocal + two Newton steps (relative error ~1e-16; the IEEE division is ~35 instructions and
+                // every thread of the workgroup needs the value: as many issue cycles as the pivot's 32 FMAs)
+                const double pvs = piv > 0.0 ? piv : 1.0;
+                double ip = __builtin_amdgcn_rcp(pvs);
+                ip = __builtin_fma(__builtin_fma(-pvs, ip, 1.0), ip, ip);
+                ip = __builtin_fma(__builtin_fma(-pvs, ip, 1.0), ip, ip);
                 double w[KC];
 #pragma unroll
                 for (int kk = 0; kk < KC; kk += 2) {
@@ -417,6 +427,57 @@ __global__ __launch_bounds__(256) void k_neg_gm(int nz, int nzs, int ncols, int 
         for (; j < nz; ++j) a0 += G[(size_t)j * nzs + r] * mcol[j];
         Out[(size_t)c * ld + r] = -((a0 + a1) + (a2 + a3));
     }
+}
+
+// The same product for ALL columns of one instance at a time (per-instance designs: V_i = -G_i F'_i, n columns): k_neg_gm reads G once
+// per column -- n x 123 KB per quadrotor-size instance through L2 -- this one reads it once: thread = row r, the n columns'
+// partial sums in registers, M staged in LDS.  Same summation order per element as k_neg_gm (bit-identical results).
+template <int NC>
+__global__ __launch_bounds__(128) void k_neg_gm_cols(int nz, int nzs, int ncols, int ld, const double* G, const double* M, double* Out,
+                                                     long sG, long sM) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];   // [ncols][nz]
+    G += blockIdx.y * sG; M += blockIdx.y * sM; Out += blockIdx.y * sM;
+    for (int t = threadIdx.x; t < ncols * nz; t += blockDim.x) smem[t] = M[(size_t)(t / nz) * ld + t % nz];
+    __syncthreads();
+    const int r = threadIdx.x < nz ? threadIdx.x : nz - 1;
+    double a[NC][4];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { a[c][0] = 0.0; a[c][1] = 0.0; a[c][2] = 0.0; a[c][3] = 0.0; }
+    int j = 0;
+    for (; j + 8 <= nz; j += 8) {
+        double g[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) g[u] = G[(size_t)(j + u) * nzs + r];
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (c < ncols) {
+                const double* mv = smem + c * nz + j;
+                a[c][0] += g[0] * mv[0] + g[4] * mv[4];
+                a[c][1] += g[1] * mv[1] + g[5] * mv[5];
+                a[c][2] += g[2] * mv[2] + g[6] * mv[6];
+                a[c][3] += g[3] * mv[3] + g[7] * mv[7];
+            }
+    }
+    for (; j < nz; ++j) {
+        const double gv = G[(size_t)j * nzs + r];
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (c < ncols) a[c][0] += gv * smem[c * nz + j];
+    }
+    if (threadIdx.x < nz) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (c < ncols) Out[(size_t)c * ld + r] = -((a[c][0] + a[c][1]) + (a[c][2] + a[c][3]));
+    }
+}
+// per-instance V_i = -G_i F'_i: all n columns in one pass over G_i when they fit the register tile
+inline void launch_neg_gm_batched(hipStream_t st, unsigned batch, int nz, int nzs, int ncols, const double* G, const double* M, double* Out,
+                                  long sG, long sM) {
+    const size_t lds = (size_t)ncols * nz * sizeof(double);
+    if (nz <= 128 && ncols <= 4 && lds <= 48 * 1024) hipLaunchKernelGGL((k_neg_gm_cols<4>), dim3(1, batch), dim3(128), lds, st, nz, nzs, ncols, nzs, G, M, Out, sG, sM);
+    else if (nz <= 128 && ncols <= 8 && lds <= 48 * 1024) hipLaunchKernelGGL((k_neg_gm_cols<8>), dim3(1, batch), dim3(128), lds, st, nz, nzs, ncols, nzs, G, M, Out, sG, sM);
+    else if (nz <= 128 && ncols <= 16 && lds <= 48 * 1024) hipLaunchKernelGGL((k_neg_gm_cols<16>), dim3(1, batch), dim3(128), lds, st, nz, nzs, ncols, nzs, G, M, Out, sG, sM);
+    else hipLaunchKernelGGL(k_neg_gm, dim3(4, batch), dim3(256), 0, st, nz, nzs, ncols, nzs, G, M, Out, sG, sM);
 }
 
 // ---- constraint space for state rows (state box / terminal equality): Ghat = A G A',  A = [I; C'],  C' = Gamma[rows] D ----

@@ -479,7 +479,12 @@ __global__ __launch_bounds__(256) void k_design_instance(DesignInstParams p) {
     for (int t = threadIdx.x; t < N * mm; t += T) {
         const int d = t / mm, e = t % mm, pp = e % m, qq = e / m;
         double C = 0.0;
-        for (int i = N - 1; i >= d; --i) {
+        // Block diagonal d is walked from the last block row up (i = N-1 .. d), skewed by d steps: at step tau every thread is in
+        // block COLUMN j = N-1-tau, so the lanes (d, pp) of one qq store a contiguous piece of one column of H (the plain walk had
+        // every lane in a different column: 8-byte scattered stores, 0.36 TB/s)
+        for (int tau = 0; tau < N; ++tau) {   // (uniform trip count: the skew is in the predicate)
+            if (tau < d) continue;
+            const int i = N - 1 - tau + d;
             if (i < N - 1) {
                 const int a = N - 2 - i;
                 const double* g = Gk + (size_t)a * nm + (size_t)pp * n;
