@@ -65,6 +65,8 @@ struct almpc_handle {
     int *dRowTraj = nullptr, *dRowEq = nullptr, *dRowXidx = nullptr, *dRowState = nullptr;
     int32_t* dOverflow = nullptr;  // [2 + batch] k_polish_gen: count, cursor and list of instances to redo with the 64-row build
     int* dRowMap = nullptr;        // [N*n] state (stage k+2, i) -> state-row index or -1 (k_ghat_inst)
+    double *dGhatE = nullptr, *dWinvE = nullptr;  // shared design with the terminal equality: original rows E of Ghat, Ghat_EE^-1
+    int eq_proj = 0;               // dGhat is the matrix projected on the terminal equality (k_ghat_project)
     bool ghat_inst = false;        // dGhat / dGnorm hold one constraint-space matrix PER INSTANCE ([batch][R][Rs], [batch][Rs])
     std::vector<double> boxmin, boxmax;  // almpc_set_state_box: the state box of the per-instance / time-varying / SQP designs
     double *lA = nullptr, *lB = nullptr, *lC = nullptr, *lE = nullptr;  // almpc_design_ltv with state rows: stage models, defects and
@@ -175,7 +177,7 @@ void free_all(almpc_handle* h) {
     void* ptrs[] = {h->dMinvFrag, h->dVFrag, h->dHFrag, h->dFFrag, h->dG, h->dD, h->dUmin, h->dUmax, h->dA, h->dB,
                     h->dXref, h->dUref, h->dFS, h->dV0S, h->dRho, h->dRollM, h->dX0, h->dXs, h->dZs, h->dYs, h->dV0, h->dW, h->dX, h->dEx,
                     h->dU, h->dEu, h->dStatus, h->dIters, h->dPiters, h->dPerm, h->dYflags, h->dSglobal, h->dGhat, h->dGnorm, h->dXmin,
-                    h->dXmax, h->dRowTraj, h->dRowEq, h->dRowXidx, h->dRowState, h->dRowMap, h->lA, h->lB, h->lC, h->lE, h->bA, h->bB, h->bMinv, h->bG, h->bHs, h->bFs,
+                    h->dXmax, h->dRowTraj, h->dRowEq, h->dRowXidx, h->dRowState, h->dRowMap, h->dGhatE, h->dWinvE, h->lA, h->lB, h->lC, h->lE, h->bA, h->bB, h->bMinv, h->bG, h->bHs, h->bFs,
                     h->bVs, h->bD, h->bRho, h->bH, h->bF, h->bPhi, h->bGk, h->bGam, h->bW, h->bWP, h->bP, h->bFlag, h->bQ, h->dOverflow,
                     h->sqp.W_in, h->sqp.W_h, h->sqp.b_h, h->sqp.W_out, h->sqp.A, h->sqp.B, h->sqp.c, h->sqp.fval, h->sqp.ebar,
                     h->sqp.qadd, h->sqp.xref, h->sqp.uref, h->sqp.Q, h->sqp.R, h->sqp.S, h->sqp.bad, h->sqp.stats, h->sqp.mer, h->sqp.xback, h->sqp.uback, h->sqp.dxback, h->sqp.vback};
@@ -225,6 +227,9 @@ int setup_state_rows(almpc_handle* h, const double* xmin, const double* xmax, bo
     h->dGhat = h->dGnorm = h->dXmin = h->dXmax = nullptr;
     h->dRowTraj = h->dRowEq = h->dRowXidx = h->dRowState = h->dRowMap = nullptr;
     h->ghat_inst = false;
+    if (h->dGhatE) { (void)hipFree(h->dGhatE); h->dGhatE = nullptr; }
+    if (h->dWinvE) { (void)hipFree(h->dWinvE); h->dWinvE = nullptr; }
+    h->eq_proj = 0;
     if (h->mc == 0) return ALMPC_OK;
     if (h->np_pairs > 4) return fail(h, ALMPC_ERR_UNSUPPORTED, "design: state rows need n*N + m*N <= 512");
     if ((size_t)(N + 1) * (n + m) > 32 * 32) return fail(h, ALMPC_ERR_UNSUPPORTED, "design: state rows need (N+1)*(n+m) <= 1024");
@@ -557,6 +562,38 @@ int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const
                                   h->dMinvFrag, h->dVFrag, h->dHFrag, h->dFFrag, h->dG, h->dD, h->H, h->F, h->d, h->err,
                                   rowsel, h->Rs, h->dGhat, h->dGnorm, h->rho_mode, h->dRho);
     if (rc != ALMPC_OK) return rc;
+    if (h->terminal_eq && h->mc >= n && !getenv("ALMPC_NO_EQ_PROJECTION")) {
+        // the n terminal-equality rows (the last n state rows) are in every working set: eliminate them here, once
+        const int ne = n, eq0 = h->R - n, Rs = h->Rs;
+        std::vector<double> GE((size_t)ne * Rs), GEE((size_t)ne * ne), Y;
+        HIP_TRY(h, hipMemcpy(GE.data(), h->dGhat + (size_t)eq0 * Rs, GE.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int a = 0; a < ne; ++a)
+            for (int b = 0; b < ne; ++b) GEE[(size_t)b * ne + a] = GE[(size_t)a * Rs + eq0 + b];
+        hm::mat Winv = hm::eye(ne);
+        bool ok = hm::lu_solve(GEE, Winv, ne, ne);
+        for (double v : Winv) ok = ok && std::isfinite(v);
+        if (ok) {   // (a singular Ghat_EE -- terminal state not reachable in N steps -- keeps the row-by-row path, which reports it)
+            Y.assign((size_t)ne * Rs, 0.0);   // Y = Winv GhatE, row-major [ne][Rs]
+            for (int a = 0; a < ne; ++a)
+                for (int e = 0; e < ne; ++e) {
+                    const double wv = Winv[(size_t)e * ne + a];   // Winv(a, e)
+                    for (int b = 0; b < Rs; ++b) Y[(size_t)a * Rs + b] += wv * GE[(size_t)e * Rs + b];
+                }
+            std::vector<double> Wrow((size_t)ne * ne);
+            for (int a = 0; a < ne; ++a)
+                for (int e = 0; e < ne; ++e) Wrow[(size_t)a * ne + e] = Winv[(size_t)e * ne + a];
+            double* dY = nullptr;
+            HIP_TRY(h, dalloc(&h->dGhatE, GE.size())); HIP_TRY(h, dalloc(&h->dWinvE, Wrow.size())); HIP_TRY(h, dalloc(&dY, Y.size()));
+            HIP_TRY(h, hipMemcpy(h->dGhatE, GE.data(), GE.size() * sizeof(double), hipMemcpyHostToDevice));
+            HIP_TRY(h, hipMemcpy(h->dWinvE, Wrow.data(), Wrow.size() * sizeof(double), hipMemcpyHostToDevice));
+            HIP_TRY(h, hipMemcpy(dY, Y.data(), Y.size() * sizeof(double), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k_ghat_project, dim3(512), dim3(256), 0, h->stream, h->R, Rs, ne, eq0, h->dGhatE, dY, h->dGhat, h->dGnorm);
+            HIP_TRY(h, hipGetLastError());
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            (void)hipFree(dY);
+            h->eq_proj = 1;
+        }
+    }
     HIP_TRY(h, hipMemcpy(h->dUmin, umin, m * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->dUmax, umax, m * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->dA, A, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice));
@@ -1696,6 +1733,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
             gp.Ghat_stride = (long)h->R * h->Rs; gp.gnorm_stride = h->Rs; gp.d_stride = h->nzs;
             gp.A_stride = (long)h->n * h->n; gp.B_stride = (long)h->n * h->m;
         }
+        if (h->eq_proj && !h->batched) { gp.eq_proj = 1; gp.eq0 = h->R - h->n; gp.ne = h->n; gp.GhatE = h->dGhatE; gp.WinvE = h->dWinvE; }
         gp.Ghat = h->dGhat; gp.gnorm = h->dGnorm; gp.row_traj = h->dRowTraj; gp.row_eq = h->dRowEq; gp.row_xidx = h->dRowXidx;
         gp.row_state = h->dRowState; gp.xmin = h->dXmin; gp.xmax = h->dXmax; gp.has_box = h->has_box;
         gp.dvec = h->batched ? h->bD : h->dD; gp.umin = h->dUmin; gp.umax = h->dUmax; gp.uref = h->dUref; gp.uref_stride = h->uref_stride;

@@ -523,6 +523,21 @@ __global__ __launch_bounds__(256) void k_ghat(int nz, int mc, int nzs, int Rs, c
         if (t >= R) gnorm[t] = 1.0;
 }
 
+// Terminal equality eliminated at design time: Ghat -= GhatE' Y with Y = Ghat_EE^-1 GhatE (host), rows / columns E exactly zero,
+// gnorm from the projected diagonal (1 on E).  One thread per element.
+__global__ __launch_bounds__(256) void k_ghat_project(int R, int Rs, int ne, int eq0, const double* GhatE, const double* Y, double* Ghat,
+                                                      double* gnorm) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < R * Rs; t += gridDim.x * blockDim.x) {
+        const int a = t / Rs, b = t % Rs;
+        if (b >= R) continue;
+        double v = Ghat[t];
+        for (int e = 0; e < ne; ++e) v -= GhatE[(size_t)e * Rs + a] * Y[(size_t)e * Rs + b];
+        if ((a >= eq0 && a < eq0 + ne) || (b >= eq0 && b < eq0 + ne)) v = 0.0;
+        Ghat[t] = v;
+        if (a == b) gnorm[a] = (a >= eq0 && a < eq0 + ne) ? 1.0 : sqrt(v > 0.0 ? v : 1.0);
+    }
+}
+
 // Runs the whole shared-model design on `stream` and leaves the packed operands in the handle's buffers.
 // Returns 0 or a negative almpc_status value (numbers as in include/almpc.h).
 inline int design_shared_device(hipStream_t stream, int n, int m, int N, int nzs, int nrb, int ks, int ksf,

@@ -37,6 +37,13 @@ struct PolishGenParams {
     const double* ltvC = nullptr;  // [batch][N][n] or null
     const double* eq_off = nullptr;  // [batch][eq_stride]: terminal equality e_x[:,N+1] = 0 in dx: dx_N = -eq_off (= x_ref - xbar at N+1)
     long eq_stride = 0;
+    // Shared-model designs with the terminal equality: the ne equality rows (rows eq0 .. eq0 + ne - 1, always in the working set) are
+    // eliminated at design time -- Ghat is the PROJECTED matrix Ghat - Ghat[:,E] Ghat_EE^-1 Ghat[E,:] (zero rows / columns E), and
+    // every instance starts from s0 - Ghat[:,E] Ghat_EE^-1 (s0_E - b): the minimiser subject to the equality.  The finish then runs
+    // on the remaining rows only: 12 bordering steps per instance (66 k cycles) and 12 of the 32 working-set slots are saved.
+    int eq_proj = 0, eq0 = 0, ne = 0;
+    const double* GhatE = nullptr;   // [ne][Rs] the ORIGINAL rows E of Ghat
+    const double* WinvE = nullptr;   // [ne][ne] Ghat_EE^-1
     const int* row_traj;  // [Rs] for state rows: offset of e_x[i,k] in the wave's trajectory buffer Z ((k)*C + i); else -1
     const int* row_eq;    // [Rs] 1 for terminal-equality rows
     const int* row_xidx;  // [Rs] for state rows: i + n*k index into x_ref (k = reference stage 2..N+1 -> 1..N); else 0
@@ -252,6 +259,42 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
                 } else { lo[q][e] = -__builtin_inf(); hi[q][e] = __builtin_inf(); s0v[q][e] = 0.0; }
                 sv[q][e] = s0v[q][e];
             }
+        if (p.eq_proj) {   // start from the minimiser subject to the terminal equality; its rows leave the problem
+            const int ne = p.ne, eq0 = p.eq0;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                d2 v; v[0] = s0v[q][0]; v[1] = s0v[q][1];
+                *reinterpret_cast<d2*>(rowbuf + 2 * lane + 128 * q) = v;
+            }
+            wave_fence_lds();
+            double lamE = 0.0;
+            if (lane < ne)
+                for (int e2 = 0; e2 < ne; ++e2) {
+                    const double b = p.eq_off ? -p.eq_off[(size_t)inst * p.eq_stride + e2] : 0.0;
+                    lamE += p.WinvE[lane * ne + e2] * (rowbuf[eq0 + e2] - b);
+                }
+            if (lane < WL) pbufa[lane] = (lane < ne) ? lamE : 0.0;   // (ne <= n <= 32 <= WL)
+            wave_fence_lds();
+            for (int e2 = 0; e2 < ne; ++e2) {
+                const double le = pbufa[e2];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const int off = 2 * lane + 128 * q;
+                    const d2 g = *reinterpret_cast<const d2*>(p.GhatE + (size_t)e2 * Rs + (off < Rs ? off : 0));
+                    s0v[q][0] -= g[0] * le; s0v[q][1] -= g[1] * le;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int r = rrow[q][e];
+                    if (r >= eq0 && r < eq0 + ne) { s0v[q][e] = lo[q][e]; lo[q][e] = -__builtin_inf(); hi[q][e] = __builtin_inf(); }
+                    sv[q][e] = s0v[q][e];
+                }
+            eqm = 0;
+            wave_fence_lds();
+        }
     }
     x0_bad = __any(x0_bad);
     wave_fence_lds();
