@@ -550,6 +550,27 @@ def main():
                           "status_counts": np.bincount(rq["status"], minlength=3).tolist(),
                           "note": "merit-function step rule, start = the network's own rollout; the whole iteration runs on the handle's stream; "
                                   "the KKT residual is sampled after 40 iterations"}
+        # per-kernel averages of the iteration from the committed rocprofv3 summary of the same command (profiles/): the iteration is a
+        # chain of one-workgroup-per-instance launches, each latency bound at 256 instances -- there is no HBM or MFMA roofline it nears;
+        # the inverse's FP64 rate (2 nz^3 flops per matrix) is stated against the vector FP64 peak for scale
+        try:
+            import csv
+            ks = {}
+            with open(os.path.join(ROOT, "profiles", "r2_bench_kernel_stats.csv")) as f:
+                for row in csv.DictReader(f):
+                    for short in ("k_design_ltv_reg", "k_design_inverse_t<4, 16", "k_polish_sgl", "k_sqp_step", "k_sqp_prepare", "k_guess_iterate",
+                                  "k_fnn_rollout"):
+                        if short in row["Name"]:
+                            ks[short.split("<")[0] if "<" not in short else short + ", 8>"] = round(float(row["MinNs"]) / 1e3, 1)
+            if ks:
+                nzq = mq * Nq
+                inv_us = ks.get("k_design_inverse_t<4, 16, 8>")
+                out["sqp_fnn"]["kernel_us_min"] = ks
+                if inv_us:
+                    out["sqp_fnn"]["inverse_fp64_tflops"] = {"achieved": 2.0 * nzq ** 3 * bq / (inv_us * 1e-6) / 1e12, "peak_vector_fp64": 78.6,
+                                                             "note": "256 matrices of 100 x 100: one workgroup each on 256 CUs, 100 dependent pivots"}
+        except (OSError, KeyError, ValueError):
+            pass
         sq.close()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
