@@ -109,6 +109,19 @@ def test_relin_pipeline_with_state_box(capi, mo):
     idx = [i for i in range(0, batch, 3) if np.abs(np.linalg.eigvals(f.jacobian(X0[i], u_ref[:, 0])[0])).max() < 1.3]
     na, ninf = _check_instances(mo, r, probs, X0, idx)
     assert len(idx) > 20 and na > 0
+    # a warm step (guess = the previous inputs shifted, no ADMM phase) from the same states lands on the same optima
+    s2 = capi.Solver(n, m, N, batch)
+    s2.relin_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, x_ref, u_ref, Q, R, None, P, [-1, -1], [1, 1], act=f.act, xmin=-xmax, xmax=xmax)
+    s2.update_initialization(0.9 * X0)
+    s2.relin_fnn_step()
+    s2.update_initialization(X0)
+    s2.relin_fnn_step(capi.default_opts(warm_start=1))
+    r2 = s2.get_results()
+    s2.close()
+    assert np.all(r2["iters"] == 0)
+    same = (r["status"] == 0) & (r2["status"] == 0)
+    assert np.array_equal(r["status"] == 3, r2["status"] == 3) and same.sum() >= 0.9 * batch
+    assert np.abs(r["u"][same] - r2["u"][same]).max() <= U_TOL
 
 
 def _ltv_case(mo, b, N, seed):
