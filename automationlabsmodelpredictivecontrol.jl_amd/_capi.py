@@ -80,6 +80,8 @@ def load():
     L.almpc_set_terminal_equality.argtypes = [_hp, ctypes.c_int]
     L.almpc_set_state_box.argtypes = [_hp, _dp, _dp]
     L.almpc_set_state_box.restype = ctypes.c_int
+    L.almpc_sqp_fnn_set_structured.argtypes = [_hp, ctypes.c_int]
+    L.almpc_sqp_fnn_set_structured.restype = ctypes.c_int
     L.almpc_set_rho_profile.argtypes = [_hp, ctypes.c_int]
     L.almpc_set_rho_profile.restype = ctypes.c_int
     L.almpc_set_step_fusion.argtypes = [_hp, ctypes.c_int]
@@ -314,12 +316,13 @@ class Solver:
                                             _ptr(S), _ptr(P), p_inst, _ptr(umin), _ptr(umax), float(rho), float(sigma)))
 
     def sqp_fnn_setup(self, W_in, W_h, b_h, W_out, x_ref, u_ref, Q, R, S=None, P=None, umin=None, umax=None, act="relu", rho=0.1,
-                      sigma=1e-6, rho_profile="scalar", xmin=None, xmax=None, terminal="none"):
+                      sigma=1e-6, rho_profile="scalar", xmin=None, xmax=None, terminal="none", qp_solver="condensed"):
         """SQP outer loop for an Fnn model (almpc_sqp_fnn_*): network as in fnn_linearize, x_ref (n, N+1) / u_ref (m, N) or None,
-        P (n, n) or (batch, n, n).  xmin / xmax: the state box of the reference's NLP branch
+        P (n, n) or (batch, n, n).  qp_solver: "condensed" (default) or "structured" (every QP through k_riccati, no condensed design).  xmin / xmax: the state box of the reference's NLP branch
         (.../fnn/mpc_modeler_implementation_fnn.jl:146-153) as rows of every iteration's QP; terminal = "equality"."""
         n, m, N, b = self.n, self.m, self.N, self.batch
         self._state_rows(xmin, xmax, terminal)
+        self._check(self.L.almpc_sqp_fnn_set_structured(self.h, 1 if qp_solver == "structured" else 0))
         self._check(self.L.almpc_set_rho_profile(self.h, {"scalar": 0, "stiffness": 1}[rho_profile]))
         W_in, W_out = np.asfortranarray(W_in, dtype=np.float64), np.asfortranarray(W_out, dtype=np.float64)
         H = W_in.shape[0]

@@ -96,6 +96,8 @@ struct almpc_handle {
         int step_rule = 0;        // 0 fixed step, 1 merit-function safeguard (almpc_sqp_fnn_set_step_rule)
         long since_start = 0;     // iterations since almpc_sqp_fnn_start: the first one gets its guess from ADMM, the others from the iterate
         int guess_from_iterate = 1;  // diagnostic: ALMPC_SQP_ADMM_ALWAYS=1 keeps the ADMM phase in every iteration
+        int structured_qp = 0;       // almpc_sqp_fnn_set_structured: every iteration's QP goes to k_riccati in its stage-wise form
+                                     // (no condensed design at all: no Hessian build, no inverse, no m N <= 128 limit)
         unsigned long long* stats = nullptr;  // [iters][2]
         int stats_cap = 0;
     } sqp;
@@ -322,7 +324,8 @@ hipError_t launch_riccati(almpc_handle* h, int filter, const double* guess, int 
     rp.lds_per_wave = riccati_lds_doubles(h->n, h->m, h->N);
     rp.A_kstride = 0; rp.B_kstride = 0; rp.c = nullptr; rp.c_stride = 0; rp.ebar = nullptr; rp.ebar_stride = 0;
     rp.qu = nullptr; rp.qu_stride = 0; rp.qu_scale = 1.0; rp.flag = nullptr; rp.v_only = 0;
-    if (h->sqp.ready && filter == 2) {   // the QP of the current SQP iteration: stage models, defects, state errors, input gradient
+    if (h->sqp.ready && filter >= 2) {   // the QP of the current SQP iteration: stage models, defects, state errors, input gradient
+                                         // (2: instances the condensed path flagged or left unsolved; 3: every instance)
         const almpc_handle::Sqp& q = h->sqp;
         const long n = h->n, m = h->m, N = h->N;
         rp.A = q.A; rp.A_stride = N * n * n; rp.A_kstride = n * n;
@@ -1296,13 +1299,14 @@ int almpc_sqp_fnn_setup(almpc_handle* h, int H, int L, int activation, const dou
     }
     { const int rc_ = ensure_batched_alloc(h); if (rc_ != ALMPC_OK) return rc_; }
     almpc_handle::Sqp& q = h->sqp;
-    const int keep_rule = q.step_rule;
+    const int keep_rule = q.step_rule, keep_structured = q.structured_qp;
     void* old[] = {q.W_in, q.W_h, q.b_h, q.W_out, q.A, q.B, q.c, q.fval, q.ebar, q.qadd, q.xref, q.uref, q.Q, q.R, q.S, q.bad, q.stats, q.mer, q.xback, q.uback, q.dxback, q.vback,
                    h->dXref, h->dUref, h->dFS, h->dV0S};
     for (void* p_ : old)
         if (p_) (void)hipFree(p_);
     q = almpc_handle::Sqp();
     q.step_rule = keep_rule;
+    q.structured_qp = keep_structured;
     h->dXref = h->dUref = h->dFS = h->dV0S = nullptr;
     auto up = [&](double** d, const double* src, size_t cnt) -> hipError_t {
         hipError_t e = dalloc(d, cnt ? cnt : 1);
@@ -1354,7 +1358,8 @@ int almpc_sqp_fnn_setup(almpc_handle* h, int H, int L, int activation, const dou
     h->xref_stride = (long)n * (N + 1); h->uref_stride = nz; h->fS_stride = nz;
     h->designed = false;  // becomes true with the first iteration's design
     h->batched = true; h->ltv = true;
-    if (h->fallback) {
+    if (q.structured_qp && h->mc > 0) return fail(h, ALMPC_ERR_UNSUPPORTED, "sqp_fnn_setup: the structured QP solve has no state rows");
+    if (h->fallback || q.structured_qp) {
         if (q.useS) return fail(h, ALMPC_ERR_UNSUPPORTED, "structured fallback: no input-rate weight");
         const int rc_ = riccati_weights(h, Qm, Rm, nullptr);
         if (rc_ != ALMPC_OK) return rc_;
@@ -1446,6 +1451,15 @@ int almpc_sqp_fnn_iterate(almpc_handle* h, int iters, double step_scale, const a
         HIP_TRY(h, launch_fnn_jacobian(fp, h->num_cus, st));
         hipLaunchKernelGGL(k_sqp_prepare, dim3((unsigned)b), dim3(256), 0, st, sp);
         HIP_TRY(h, hipMemsetAsync(h->bFlag, 0, b * sizeof(int), st));
+        if (q.structured_qp) {   // the QP in its stage-wise form for every instance; start: v = 0 (working set = the iterate's inputs on a bound)
+            h->designed = true;
+            HIP_TRY(h, launch_riccati(h, 3, h->dUref, opts ? opts->polish_max_iter : 0));
+            q.since_start += 1;
+            sp.stats = q.stats + 2 * it;
+            hipLaunchKernelGGL(k_sqp_step, dim3((unsigned)b), dim3(256), step_lds, st, sp);
+            HIP_TRY(h, hipGetLastError());
+            continue;
+        }
         HIP_TRY(h, launch_design_ltv(h, lp, st));
         h->skip_admm = (q.guess_from_iterate && q.since_start > 0) ? 1 : 0;
         launch_batched_factor(h, ds, h->rho, h->sigma, st);
@@ -1481,6 +1495,15 @@ int almpc_sqp_fnn_iterate(almpc_handle* h, int iters, double step_scale, const a
             return fail(h, ALMPC_ERR_NUMERIC, "sqp_fnn_iterate: instance " + std::to_string(i) +
                         ": an iteration was skipped (condensed Hessian not positive definite to working precision, a non-finite QP "
                         "solution, or -- with state rows -- an infeasible QP); its iterate is the last good one, the other instances are unaffected");
+    return ALMPC_OK;
+}
+
+int almpc_sqp_fnn_set_structured(almpc_handle* h, int on) {
+    if (!h) return ALMPC_ERR_INVALID;
+    if (on && !riccati_shape_ok(h)) return fail(h, ALMPC_ERR_UNSUPPORTED, "sqp_fnn_set_structured: needs n <= 32, m <= 16 and its buffers in 160 KB of LDS");
+    h->sqp.structured_qp = on ? 1 : 0;
+    h->designed = false;   // takes effect at the next almpc_sqp_fnn_setup
+    h->sqp.ready = h->sqp.started = false;
     return ALMPC_OK;
 }
 

@@ -255,6 +255,15 @@ int almpc_sqp_fnn_skipped(almpc_handle* h, int32_t* skipped /* [batch], 1 = some
 int almpc_sqp_fnn_set_step_rule(almpc_handle* h, int rule);
 
 /*
+ * QP solver of the SQP loop (call before almpc_sqp_fnn_setup): 0 (default) the condensed path -- k_design_ltv, per-instance factors,
+ * the step kernels --, 1 the stage-wise form for EVERY instance and iteration: k_riccati on (A_k, B_k, c_k), started from the
+ * iterate's own working set (v = 0).  No Hessian is formed or inverted; with the short state vectors of the Fnn models an iteration
+ * is a few backward sweeps per instance.  Same QP, same optimum (parity: oracle sqp_fnn(structured=True)).  Needs n <= 32, m <= 16,
+ * no input-rate weight, no state rows.
+ */
+int almpc_sqp_fnn_set_structured(almpc_handle* h, int on);
+
+/*
  * Per-step re-linearisation of a black-box Fnn model, resident on the device (BASELINE.json configs[3]).  The reference
  * linearises a black-box model ONCE, at the first reference (.../fnn/mpc_modeler_implementation_fnn.jl:38-46), and then runs the
  * linear path; this is the extension in which every instance is re-linearised at its own current state in every step: one call =

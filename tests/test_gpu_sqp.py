@@ -298,3 +298,39 @@ def test_sqp_with_state_box(capi, mo):
         X, U, hist, na = mo.sqp_fnn(f, X0[i], x_ref, u_ref, Q, R, S, P, umin, umax, iters, x_min=xlo, x_max=xhi, return_active=True)
         assert na >= 17
         assert np.abs(r["u"][i] - U).max() <= U_TOL and np.abs(r["x"][i] - X).max() <= 1e-5
+
+
+def test_sqp_with_the_structured_qp_solver(capi, mo):
+    """almpc_sqp_fnn_set_structured: every iteration's QP in its stage-wise form (k_riccati), no condensed design.  Same loop, same
+    QPs: the iterates follow the restatement with stage-wise solves and end where the condensed path ends."""
+    b, N, iters = 32, 50, 30
+    f, s, kw, X0 = _setup(capi, mo, b, N)
+    s.sqp_fnn_start(X0)
+    st_c, de_c = s.sqp_fnn_iterate(iters)
+    rc = s.get_results()
+    s.close()
+    n, m = 4, 2
+    s2 = capi.Solver(n, m, N, b)
+    s2.sqp_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, kw["x_ref"], kw["u_ref"], kw["Q"], kw["R"], kw["S"], kw["P"], kw["u_min"], kw["u_max"],
+                     act="tanh", qp_solver="structured")
+    s2.sqp_fnn_start(X0)
+    st, de = s2.sqp_fnn_iterate(iters)
+    r = s2.get_results()
+    s2.close()
+    assert np.all(r["status"] == 0)
+    assert st[-1] <= 1e-7 and de[-1] <= 1e-12, (st, de)
+    np.testing.assert_allclose(st[:6], st_c[:6], rtol=1e-5, atol=1e-8)     # same QPs, two solvers
+    assert np.abs(r["u"] - rc["u"]).max() <= U_TOL and np.abs(r["x"] - rc["x"]).max() <= 1e-5
+    for i in (0, 19):
+        X, U, hist = mo.sqp_fnn(f, X0[i], kw["x_ref"], kw["u_ref"], kw["Q"], kw["R"], kw["S"], kw["P"], kw["u_min"], kw["u_max"], iters, structured=True)
+        assert np.abs(r["u"][i] - U).max() <= U_TOL
+    for i in range(b):
+        assert np.abs(r["x"][i] - mo.fnn_rollout(f, X0[i], r["u"][i])).max() <= 1e-9
+        assert mo.nlp_kkt_residual(f, X0[i], r["u"][i], kw["x_ref"], kw["u_ref"], kw["Q"], kw["R"], kw["S"], kw["P"], kw["u_min"], kw["u_max"]) <= 1e-5
+    with pytest.raises(capi.AlmpcError):   # no state rows in the stage-wise solve
+        s3 = capi.Solver(n, m, N, 4)
+        try:
+            s3.sqp_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, kw["x_ref"], kw["u_ref"], kw["Q"], kw["R"], kw["S"], kw["P"], kw["u_min"], kw["u_max"],
+                             act="tanh", qp_solver="structured", xmin=-np.ones(4), xmax=np.ones(4))
+        finally:
+            s3.close()
