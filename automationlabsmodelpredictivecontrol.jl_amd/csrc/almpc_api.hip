@@ -1756,6 +1756,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
             gp.Ghat_stride = (long)h->R * h->Rs; gp.gnorm_stride = h->Rs; gp.d_stride = h->nzs;
             gp.A_stride = (long)h->n * h->n; gp.B_stride = (long)h->n * h->m;
         }
+        if (!h->batched && h->roll_s > 0) { gp.rollM = h->dRollM; gp.roll_s = h->roll_s; gp.roll_nb = h->roll_nb; }
         if (h->eq_proj && !h->batched) { gp.eq_proj = 1; gp.eq0 = h->R - h->n; gp.ne = h->n; gp.GhatE = h->dGhatE; gp.WinvE = h->dWinvE; }
         gp.Ghat = h->dGhat; gp.gnorm = h->dGnorm; gp.row_traj = h->dRowTraj; gp.row_eq = h->dRowEq; gp.row_xidx = h->dRowXidx;
         gp.row_state = h->dRowState; gp.xmin = h->dXmin; gp.xmax = h->dXmax; gp.has_box = h->has_box;

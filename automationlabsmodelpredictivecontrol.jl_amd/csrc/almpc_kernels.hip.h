@@ -653,7 +653,7 @@ __device__ __forceinline__ void roll_run(const double (&cu)[SMX], const double (
     const int nx = n * (N + 1), sm = s * m;
     if (lane < n) {  // stage 1 of the reference's numbering: x[:,1] = x0, e_x[:,1] = x0 - x_ref[:,1]
         gex[lane] = e0v;
-        gx[lane] = x0r;
+        if (gx) gx[lane] = x0r;   // (gx == nullptr: only e_x is wanted -- the state-row finish rolls v0 out into LDS)
     }
     const bool mine = lane < s * n;
     // input part of a block: independent of the chain, so the next block's is summed while this block's values leave
@@ -691,7 +691,7 @@ __device__ __forceinline__ void roll_run(const double (&cu)[SMX], const double (
         if (xref_lds) asm volatile("" : "+v"(xr));   // keeps the two reference paths apart (a select of the addresses = flat loads)
         if (ok) {
             gex[t] = ev;
-            gx[t] = ev + xr;
+            if (gx) gx[t] = ev + xr;
         }
     }
 }

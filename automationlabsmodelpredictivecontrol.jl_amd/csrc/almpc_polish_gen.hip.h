@@ -41,6 +41,12 @@ struct PolishGenParams {
     // eliminated at design time -- Ghat is the PROJECTED matrix Ghat - Ghat[:,E] Ghat_EE^-1 Ghat[E,:] (zero rows / columns E), and
     // every instance starts from s0 - Ghat[:,E] Ghat_EE^-1 (s0_E - b): the minimiser subject to the equality.  The finish then runs
     // on the remaining rows only: 12 bordering steps per instance (66 k cycles) and 12 of the 32 working-set slots are saved.
+    // shared model with the design's blocked-rollout table (rollout_blocked, csrc/almpc_kernels.hip.h): the output rollout advances s
+    // stages at a time and streams x / e_x to HBM (14.9 k + 4.5 k cycles -> 10.7 k + 0.6 k at the quadrotor shape); null: stage by
+    // stage.  (The v0 trajectory of the prologue stays stage by stage: its values are needed in LDS, and the blocked form through a
+    // generic pointer plus 80 more live registers cost more there than the shorter chain saved -- measured.)
+    const double* rollM = nullptr;
+    int roll_s = 0, roll_nb = 0;
     int eq_proj = 0, eq0 = 0, ne = 0;
     const double* GhatE = nullptr;   // [ne][Rs] the ORIGINAL rows E of Ghat
     const double* WinvE = nullptr;   // [ne][ne] Ghat_EE^-1
@@ -182,6 +188,8 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
     const RolloutParams& rp = p.roll;
     const int n = p.n, m = p.m, N = p.N, C = n + m;
     double* Z = Sl;  // trajectory buffer (N+1) x C, first use (s0) and last use (outputs); Sinv lives here in between
+    double* EUB = Sl;         // blocked rollout of the outputs: e_u in stage order, zero padded (256 doubles)
+    const bool blocked = !p.ltv && p.rollM != nullptr && p.A_stride == 0;
 
     // ---- rows of this lane: pairs (2 lane, 2 lane + 1) + 128 q
     int rrow[NP][2];
@@ -237,7 +245,9 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
             umn[e] = p.umin[rcl % m]; umx[e] = p.umax[rcl % m];
         }
         wave_fence_lds();
+        PGEN_STAMP(11);
         roll(Z);
+        PGEN_STAMP(12);
 #pragma unroll
         for (int q = 0; q < NP; ++q)
 #pragma unroll
@@ -709,10 +719,32 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
             rp.eu[(size_t)inst * nz + r1] = uu - ur;
             Z[(size_t)(r1 / m) * C + n + r1 % m] = uu - ur;
         }
-        if (!p.ltv) {   // (x / e_x are not defined for a time-varying design: the caller rolls the nonlinear model out)
+        if (blocked) {   // outputs straight from the blocked rollout (values leave for HBM as they are produced)
+            {
+                d2 ev;
+                ev[0] = (r0 < nz) ? Z[(size_t)(r0 / m) * C + n + r0 % m] : 0.0;
+                ev[1] = (r1 < nz) ? Z[(size_t)(r1 / m) * C + n + r1 % m] : 0.0;
+                wave_fence_lds();
+                *reinterpret_cast<d2*>(EUB + 2 * lane) = ev;
+                d2 zz; zz[0] = 0.0; zz[1] = 0.0;
+                *reinterpret_cast<d2*>(EUB + 128 + 2 * lane) = zz;
+            }
+            double e0v = 0.0, x0r = 0.0;
+            if (lane < n) { x0r = rp.x0[(size_t)inst * n + lane]; e0v = x0r - rp.xref[(size_t)inst * rp.xref_stride + lane]; }
+            double cu[ROLL_SMX], cx[ROLL_NX];
+            roll_load<ROLL_SMX, ROLL_NX>(p.rollM, lane, cu, cx);
+            wave_fence_lds();
+            PGEN_STAMP(13);
+            const size_t xo = (size_t)inst * n * (N + 1);
+            roll_run<ROLL_SMX, ROLL_NX>(cu, cx, n, m, N, p.roll_s, p.roll_nb, lane, EUB, e0v, x0r, nullptr,
+                                        rp.xref + (size_t)inst * rp.xref_stride, rp.x + xo, rp.ex + xo);
+            PGEN_STAMP(14);
+        } else if (!p.ltv) {   // (x / e_x are not defined for a time-varying design: the caller rolls the nonlinear model out)
         for (int i = lane; i < n; i += 64) Z[i] = rp.x0[(size_t)inst * n + i] - rp.xref[(size_t)inst * rp.xref_stride + i];
         wave_fence_lds();
+        PGEN_STAMP(13);
         roll(Z);
+        PGEN_STAMP(14);
         const int nx = n * (N + 1);
         const size_t xo = (size_t)inst * nx;
         for (int t0 = 0; t0 < nx; t0 += 256) {   // (four reference loads in flight per lane)

@@ -40,6 +40,10 @@ for tier, sl in (("first launch (32 rows)", slice(0, b)), ("second launch (64 ro
     for j, nm in enumerate(names):
         d = st[:, j + 1] - st[:, j]
         print(f"   {nm:28s} median {int(np.median(d)):7d}  p90 {int(np.percentile(d, 90)):7d}  max {int(d.max()):7d}")
+    for nm, a, b_ in (("  prologue: loads + Z fill", 0, 11), ("  prologue: rollout of v0", 11, 12), ("  prologue: row data", 12, 1),
+                      ("  epilogue: u / e_u stores", 5, 13), ("  epilogue: rollout", 13, 14), ("  epilogue: x / e_x stores", 14, 6)):
+        d = st[:, b_] - st[:, a]
+        print(f"   {nm:28s} median {int(np.median(d)):7d}  p90 {int(np.percentile(d, 90)):7d}")
     tot = st[:, 6] - st[:, 0]
     print(f"   total per instance          median {int(np.median(tot)):7d}  p90 {int(np.percentile(tot, 90)):7d}  max {int(tot.max()):7d}")
     its = st[:, 9]; kg = st[:, 8]; kf = st[:, 10]
