@@ -340,12 +340,20 @@ hipError_t launch_riccati(almpc_handle* h, int filter, const double* guess, int 
     while (waves > 1 && per * waves > 160 * 1024) --waves;
     const size_t lds = per * waves;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(k_riccati), lds);
-    if (e != hipSuccess) return e;
     int wgs = (h->batch + waves - 1) / waves;
     const int cap = h->num_cus * 2;
     if (wgs > cap) wgs = cap;
-    hipLaunchKernelGGL(k_riccati, dim3(wgs), dim3(64 * waves), lds, h->stream, rp);
+#define RICCATI_LAUNCH(NC_, MC_)                                                                               \
+    do {                                                                                                       \
+        const hipError_t e_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_riccati_t<NC_, MC_>), lds);       \
+        if (e_ != hipSuccess) return e_;                                                                       \
+        hipLaunchKernelGGL((k_riccati_t<NC_, MC_>), dim3(wgs), dim3(64 * waves), lds, h->stream, rp);          \
+    } while (0)
+    if (h->n == 12 && h->m == 4 && !getenv("ALMPC_RICCATI_GENERIC")) RICCATI_LAUNCH(12, 4);
+    else if (h->n == 4 && h->m == 2 && !getenv("ALMPC_RICCATI_GENERIC")) RICCATI_LAUNCH(4, 2);
+    else if (h->n == 2 && h->m == 1 && !getenv("ALMPC_RICCATI_GENERIC")) RICCATI_LAUNCH(2, 1);
+    else RICCATI_LAUNCH(0, 0);
+#undef RICCATI_LAUNCH
     return hipGetLastError();
 }
 
