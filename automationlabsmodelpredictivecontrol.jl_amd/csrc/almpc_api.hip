@@ -800,9 +800,17 @@ hipError_t launch_batched_design(almpc_handle* h, const DesignStrides& ds, int u
         dp.n = n; dp.m = m; dp.N = N; dp.nz = nz; dp.useR = useR; dp.useS = useS;
         dp.A = h->bA; dp.B = h->bB; dp.P = h->bP; dp.sA = ds.A; dp.sB = ds.B; dp.sP = ds.P;
         dp.Q = dQ; dp.R = dR; dp.S = dS; dp.H = h->bH; dp.F = h->bF; dp.sH = ds.H; dp.sF = ds.F;
-        e = ensure_dyn_lds(reinterpret_cast<const void*>(k_design_instance), inst_lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_design_instance, dim3(gb), dim3(256), inst_lds, st, dp);
+#define DESIGN_INST(NC_, MC_)                                                                                \
+    do {                                                                                                     \
+        e = ensure_dyn_lds(reinterpret_cast<const void*>(k_design_instance_t<NC_, MC_>), inst_lds);          \
+        if (e != hipSuccess) return e;                                                                       \
+        hipLaunchKernelGGL((k_design_instance_t<NC_, MC_>), dim3(gb), dim3(256), inst_lds, st, dp);          \
+    } while (0)
+        if (n == 12 && m == 4) DESIGN_INST(12, 4);
+        else if (n == 4 && m == 2) DESIGN_INST(4, 2);
+        else if (n == 2 && m == 1) DESIGN_INST(2, 1);
+        else DESIGN_INST(0, 0);
+#undef DESIGN_INST
     } else {
         hipLaunchKernelGGL(k_design_blocks, dim3(1, gb), dim3(256), (size_t)(3 * n * n + n * m) * sizeof(double), st, n, m, N,
                            h->bA, h->bB, h->bPhi, h->bGk, ds);

@@ -400,9 +400,13 @@ __host__ __device__ inline size_t design_instance_lds_doubles(int n, int m, int 
     return (size_t)4 * n * n + (size_t)n * m + (size_t)(N + 1) * n * n + (size_t)5 * N * n * m;
 }
 
-__global__ __launch_bounds__(256) void k_design_instance(DesignInstParams p) {
+// <NC, MC>: n and m at compile time for the common shapes (0, 0: run time): the products are short loops over n / m with two LDS
+// reads per term, which only unroll -- and only then have their reads in flight together -- when the bounds are constants
+// (same finding as k_riccati_t).
+template <int NC, int MC>
+__global__ __launch_bounds__(256) void k_design_instance_t(DesignInstParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int n = p.n, m = p.m, N = p.N, nz = p.nz;
+    const int n = NC ? NC : p.n, m = MC ? MC : p.m, N = p.N, nz = p.nz;
     const int nn = n * n, nm = n * m;
     const double* A = p.A + blockIdx.x * p.sA;
     const double* B = p.B + blockIdx.x * p.sB;
