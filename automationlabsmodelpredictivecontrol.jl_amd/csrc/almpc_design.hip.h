@@ -228,7 +228,9 @@ constexpr int DESIGN_INVERSE_THREADS = 256;
 // Round 2, measured on 4096 quadrotor-size matrices (1.24 ms per launch, SQ counters: 106 VALU instructions per pivot and thread for
 // 32 FMAs, VALU 57 % busy, 26 % of the wave cycles in s_waitcnt) and NOT faster, each tried by itself: 512 threads with a 4 x 8 tile
 // (4 waves per SIMD instead of 2), the reciprocal by v_rcp_f64 + two Newton steps instead of the IEEE division (kept: it is shorter),
-// a wave-uniform column ownership with the pivot row eliminated like the others.  Also built, measured and removed: a blocked sweep on
+// a wave-uniform column ownership with the pivot row eliminated like the others, pivots unrolled in windows of four with the
+// register tile rotated in between (loop body 10 KB of code instead of 39 KB: instruction fetch is not the limit either).  Also
+// built, measured and removed: a blocked sweep on
 // FP64 MFMA (8 x 8 tiles of 16 x 16 as accumulators, four waves, pivot block inverted inside one wave by cross-lane reads, T = A_IK Pi
 // with one step of iterative refinement -- without it the explicit 16 x 16 inverse costs five digits: 4e-7 against 1.7e-11 --, row K
 // from the transposes of the column results, two barriers per block step): 1.4 ms per launch, slower than this kernel, and 8e-8 on u
