@@ -279,7 +279,8 @@ def _design_blackbox_nonlinear(system, horizon, sample_time, references, weights
                          act=f.act, rho=float(sopt.get("rho", 0.1)), sigma=float(sopt.get("sigma", 1e-6)),
                          rho_profile=kws.get("mpc_rho_profile", "scalar"),
                          xmin=system.X.low if state_box else None, xmax=system.X.high if state_box else None,
-                         terminal="equality" if terminal == "equality" else "none")
+                         terminal="equality" if terminal == "equality" else "none",
+                         qp_solver=kws.get("mpc_sqp_qp_solver", "condensed"))   # "structured": every QP through k_riccati
     mod = HipModeler(solver, _capi.default_opts(**sopt), batch)
     mod.sqp = dict(iterations=int(kws.get("mpc_sqp_iterations", 10)), step=float(kws.get("mpc_sqp_step", 1.0)),
                    warm_start=bool(kws.get("mpc_sqp_warm_start", True)), u_prev=None,

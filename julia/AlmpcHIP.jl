@@ -143,7 +143,10 @@ Then per step:  `sqp_start!(mod, x0)`;  `sqp_iterate!(mod, iters)`;  results thr
 """
 function design_sqp_fnn!(mod::HipModeler, W_in::Matrix{Float64}, W_h::Array{Float64,3}, b_h::Matrix{Float64}, W_out::Matrix{Float64},
                          activation::Integer, Q::Matrix{Float64}, R::Matrix{Float64}, S::Matrix{Float64}, P::Matrix{Float64},
-                         umin::Vector{Float64}, umax::Vector{Float64}; x_ref::Matrix{Float64}, u_ref::Matrix{Float64})
+                         umin::Vector{Float64}, umax::Vector{Float64}; x_ref::Matrix{Float64}, u_ref::Matrix{Float64},
+                         structured_qp::Bool = false)
+    # structured_qp: every iteration's QP in the multiple-shooting form (k_riccati) instead of the condensed one
+    check(mod.handle, ccall((:almpc_sqp_fnn_set_structured, libalmpc), Cint, (Ptr{Cvoid}, Cint), mod.handle, structured_qp ? 1 : 0))
     check(mod.handle, ccall((:almpc_sqp_fnn_setup, libalmpc), Cint,
                    (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
                     Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint, Ptr{Float64}, Ptr{Float64}, Cdouble, Cdouble),
