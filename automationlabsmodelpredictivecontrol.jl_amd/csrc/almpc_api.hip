@@ -824,7 +824,9 @@ hipError_t launch_batched_design(almpc_handle* h, const DesignStrides& ds, int u
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    launch_batched_factor(h, ds, rho, sigma, st);
+    DesignStrides ds2 = ds;
+    ds2.h_symmetric = (inst_lds <= 160 * 1024) ? 1 : 0;   // (the LDS route writes both halves of H_i from one value)
+    launch_batched_factor(h, ds2, rho, sigma, st);
     launch_neg_gm_batched(st, gb, nz, nzs, n, h->bG, h->bFs, h->bVs, ds.G, ds.Fs);
     return hipGetLastError();
 }

@@ -25,6 +25,7 @@ namespace almpc {
 struct DesignStrides {
     long A = 0, B = 0, P = 0, Phi = 0, Gk = 0, Gam = 0, WP = 0, H = 0, F = 0, d = 0, Hs = 0, Fs = 0, G = 0, Minv = 0, rho = 0,
          flag = 0;
+    int h_symmetric = 0;   // H is symmetric by construction (k_design_instance): k_design_scale skips its transposed, uncoalesced read
 };
 
 // ---- K1/K2 -------------------------------------------------------------------------------------
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256) void k_design_scale(int nz, int nzs, int n, co
             const int t = t0 + u < nz * nz ? t0 + u : nz * nz - 1;
             cc[u] = t / nz; rr[u] = t - cc[u] * nz;
             ha[u] = H[(size_t)cc[u] * nz + rr[u]];
-            hb[u] = H[(size_t)rr[u] * nz + cc[u]];
+            hb[u] = st.h_symmetric ? ha[u] : H[(size_t)rr[u] * nz + cc[u]];   // (0.5 (a + a) = a exactly)
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
