@@ -10,7 +10,10 @@ module AlmpcHIP
 
 export hip_solver_def, HipModeler, AlmpcOpts, design_hip, terminal_weight, set_state_rows!, design_batched!, design_sqp_fnn!, sqp_start!, sqp_iterate!,
        design_relin_fnn!, relin_step!, relin_advance!, update_initialization!, calculate!, read_results!,
-       _model_predictive_control_computation, comm_unique_id, comm_init!, comm_summary, comm_allgather_first_input
+       _model_predictive_control_computation, comm_unique_id, comm_init!, comm_summary, comm_allgather_first_input,
+       calculate_async!, synchronize!, relin_step_async!, advance_plant!, update_initialization_device!, device_results, set_step_fusion!,
+       set_structured_fallback!, sqp_skipped, design_instance, gradient_instance, design_ltv!, fnn_linearize, dare, default_opts,
+       get_timing, timing_reset!, timing_set_stride!, timing_summary, relin_timing, debug_poison_lds!
 
 const libalmpc = get(ENV, "ALMPC_LIB", "libalmpc.so")
 
@@ -251,6 +254,120 @@ function comm_allgather_first_input(mod::HipModeler, world::Integer)
                             mod.handle, out, C_NULL))
     return out
 end
+
+# ---- the rest of the ABI: asynchronous stepping, timing, parity hooks, device-resident results, helpers ----
+"launch a step on the handle's stream and return at once; `synchronize!` waits for it"
+function calculate_async!(mod::HipModeler)
+    o = Ref(mod.opts)
+    check(mod.handle, ccall((:almpc_calculate_async, libalmpc), Cint, (Ptr{Cvoid}, Ref{AlmpcOpts}), mod.handle, o))
+end
+synchronize!(mod::HipModeler) = check(mod.handle, ccall((:almpc_synchronize, libalmpc), Cint, (Ptr{Cvoid},), mod.handle))
+function relin_step_async!(mod::HipModeler)
+    o = Ref(mod.opts)
+    check(mod.handle, ccall((:almpc_relin_fnn_step_async, libalmpc), Cint, (Ptr{Cvoid}, Ref{AlmpcOpts}), mod.handle, o))
+end
+"x0 <- A x0 + B u[:,1] on the device (shared-model designs): the closed loop without a host round trip"
+advance_plant!(mod::HipModeler) = check(mod.handle, ccall((:almpc_advance_plant, libalmpc), Cint, (Ptr{Cvoid},), mod.handle))
+"x0 already in device memory (`d_x0`: device pointer to batch x n doubles)"
+update_initialization_device!(mod::HipModeler, d_x0::Ptr{Float64}) =
+    check(mod.handle, ccall((:almpc_update_initialization_device, libalmpc), Cint, (Ptr{Cvoid}, Ptr{Float64}), mod.handle, d_x0))
+"device pointers of the result arrays of the last step (x, e_x, u, e_u): for callers that keep the loop on the GPU"
+function device_results(mod::HipModeler)
+    px, pex, pu, peu = Ref{Ptr{Float64}}(C_NULL), Ref{Ptr{Float64}}(C_NULL), Ref{Ptr{Float64}}(C_NULL), Ref{Ptr{Float64}}(C_NULL)
+    check(mod.handle, ccall((:almpc_device_results, libalmpc), Cint,
+                            (Ptr{Cvoid}, Ref{Ptr{Float64}}, Ref{Ptr{Float64}}, Ref{Ptr{Float64}}, Ref{Ptr{Float64}}), mod.handle, px, pex, pu, peu))
+    return px[], pex[], pu[], peu[]
+end
+set_step_fusion!(mod::HipModeler, on::Bool) = check(mod.handle, ccall((:almpc_set_step_fusion, libalmpc), Cint, (Ptr{Cvoid}, Cint), mod.handle, on ? 1 : 0))
+"instances the condensed path leaves unsolved (open-loop unstable linearisations) are redone in the multiple-shooting form; before the design"
+set_structured_fallback!(mod::HipModeler, on::Bool) =
+    check(mod.handle, ccall((:almpc_set_structured_fallback, libalmpc), Cint, (Ptr{Cvoid}, Cint), mod.handle, on ? 1 : 0))
+"instances whose SQP iteration was skipped (indefinite condensed Hessian, non-finite or infeasible QP)"
+function sqp_skipped(mod::HipModeler)
+    out = Vector{Int32}(undef, mod.batch)
+    check(mod.handle, ccall((:almpc_sqp_fnn_skipped, libalmpc), Cint, (Ptr{Cvoid}, Ptr{Int32}), mod.handle, out))
+    return out
+end
+"(H_i, F_i, d_i) of one instance of a per-instance design; `gradient_instance`: q_i of a time-varying design (parity hooks)"
+function design_instance(mod::HipModeler, i::Integer)
+    nz = mod.m * mod.N
+    H, F, d = Matrix{Float64}(undef, nz, nz), Matrix{Float64}(undef, nz, mod.n), Vector{Float64}(undef, nz)
+    check(mod.handle, ccall((:almpc_get_design_instance, libalmpc), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                            mod.handle, i - 1, H, F, d))
+    return H, F, d
+end
+function gradient_instance(mod::HipModeler, i::Integer)
+    q = Vector{Float64}(undef, mod.m * mod.N)
+    check(mod.handle, ccall((:almpc_get_gradient_instance, libalmpc), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}), mod.handle, i - 1, q))
+    return q
+end
+"""
+    design_ltv!(mod, A_all, B_all, c_all, xbar, ubar, Q, R, S, P, umin, umax; x_ref, u_ref)
+
+Time-varying models per instance (`A_all` n x n x N x batch, `B_all` n x m x N x batch, `c_all` n x N x batch or `nothing`,
+`xbar` n x (N+1) x batch, `ubar` m x N x batch): the QP of one SQP / multiple-shooting iteration in v = u - ubar (`almpc_design_ltv`).
+"""
+function design_ltv!(mod::HipModeler, A_all::Array{Float64,4}, B_all::Array{Float64,4}, c_all, xbar::Array{Float64,3}, ubar::Array{Float64,3},
+                     Q::Matrix{Float64}, R::Matrix{Float64}, S::Matrix{Float64}, P::Matrix{Float64}, umin::Vector{Float64}, umax::Vector{Float64};
+                     x_ref::Matrix{Float64}, u_ref::Matrix{Float64})
+    pc = c_all === nothing ? Ptr{Float64}(C_NULL) : pointer(c_all)
+    GC.@preserve c_all check(mod.handle, ccall((:almpc_design_ltv, libalmpc), Cint,
+                   (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                    Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint, Ptr{Float64}, Ptr{Float64}, Cdouble, Cdouble),
+                   mod.handle, A_all, B_all, pc, xbar, ubar, x_ref, u_ref, Q, R, S, P, 0, umin, umax, mod.opts.rho, mod.opts.sigma))
+    return mod
+end
+"Jacobians (A_i, B_i) and values of an Fnn at `x` (n x batch), `u` (m x batch) on device `device` (the batched `proceed_system_linearization`)"
+function fnn_linearize(W_in::Matrix{Float64}, W_h::Array{Float64,3}, b_h::Matrix{Float64}, W_out::Matrix{Float64}, activation::Integer,
+                       x::Matrix{Float64}, u::Matrix{Float64}; device::Integer = 0)
+    n, m, b = size(x, 1), size(u, 1), size(x, 2)
+    A, B, f = Array{Float64,3}(undef, n, n, b), Array{Float64,3}(undef, n, m, b), Matrix{Float64}(undef, n, b)
+    rc = ccall((:almpc_fnn_linearize, libalmpc), Cint,
+               (Cint, Cint, Cint, Cint, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint, Ptr{Float64}, Ptr{Float64},
+                Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+               device, n, m, size(W_in, 1), size(W_h, 3), activation, W_in, W_h, b_h, W_out, b, x, u, A, B, f)
+    rc == 0 || error("almpc_fnn_linearize failed ($rc)")
+    return A, B, f
+end
+"P = DARE(A, B, Q, R) as the library computes it (host; src/sub/design_mpc.jl:327)"
+function dare(A::Matrix{Float64}, B::Matrix{Float64}, Q::Matrix{Float64}, R::Matrix{Float64})
+    n, m = size(B)
+    P = Matrix{Float64}(undef, n, n)
+    rc = ccall((:almpc_dare, libalmpc), Cint, (Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), n, m, A, B, Q, R, P)
+    rc == 0 || error("almpc_dare: no convergence ($rc)")
+    return P
+end
+"library defaults of the options (OSQP's, plus the documented changes)"
+function default_opts()
+    o = Ref(AlmpcOpts())
+    ccall((:almpc_default_opts, libalmpc), Cvoid, (Ref{AlmpcOpts},), o)
+    return o[]
+end
+# timing (handles created with ALMPC_FLAG_TIMING = 0x1): per-stage milliseconds of the last step / sums since the last reset
+function get_timing(mod::HipModeler)
+    t = zeros(Float32, 4)
+    check(mod.handle, ccall((:almpc_get_timing, libalmpc), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}),
+                            mod.handle, pointer(t, 1), pointer(t, 2), pointer(t, 3), pointer(t, 4)))
+    return (admm_ms = t[1], polish_ms = t[2], rollout_ms = t[3], total_ms = t[4])
+end
+timing_reset!(mod::HipModeler, reserve_steps::Integer = 0) =
+    check(mod.handle, ccall((:almpc_timing_reset, libalmpc), Cint, (Ptr{Cvoid}, Cint), mod.handle, reserve_steps))
+timing_set_stride!(mod::HipModeler, every::Integer) =
+    check(mod.handle, ccall((:almpc_timing_set_stride, libalmpc), Cint, (Ptr{Cvoid}, Cint), mod.handle, every))
+function timing_summary(mod::HipModeler)
+    steps = Ref{Cint}(0); t = zeros(Float64, 4)
+    check(mod.handle, ccall((:almpc_timing_summary, libalmpc), Cint, (Ptr{Cvoid}, Ref{Cint}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                            mod.handle, steps, pointer(t, 1), pointer(t, 2), pointer(t, 3), pointer(t, 4)))
+    return (steps = Int(steps[]), admm_ms = t[1], polish_ms = t[2], rollout_ms = t[3], total_ms = t[4])
+end
+function relin_timing(mod::HipModeler)
+    t = zeros(Float32, 3)
+    check(mod.handle, ccall((:almpc_relin_fnn_timing, libalmpc), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}),
+                            mod.handle, pointer(t, 1), pointer(t, 2), pointer(t, 3)))
+    return (jacobian_ms = t[1], design_ms = t[2], step_ms = t[3])
+end
+"diagnostic: fill the LDS of every CU with NaN patterns before a step (a kernel that reads LDS it did not write then shows)"
+debug_poison_lds!(mod::HipModeler) = check(mod.handle, ccall((:almpc_debug_poison_lds, libalmpc), Cint, (Ptr{Cvoid},), mod.handle))
 
 # the name BASELINE.json uses; absent from the reference (SURVEY.md section 0): one batched step
 function _model_predictive_control_computation(mod::HipModeler, X0::Matrix{Float64}, x, e_x, u, e_u)
