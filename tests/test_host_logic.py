@@ -124,3 +124,16 @@ def test_reference_side_patch_applies_to_the_reference(tmp_path):
     hdr = open(os.path.join(ROOT, "include", "almpc.h")).read()
     for sym in set(re.findall(r"ccall\(\(:(almpc_[a-z_]+), libalmpc\)", shim)):
         assert re.search(r"\b" + sym + r"\s*\(", hdr), sym
+
+
+def test_julia_shim_binds_every_entry_point_of_the_header():
+    """julia/AlmpcHIP.jl is the binding a maintainer of the reference would add: every symbol include/almpc.h declares has a ccall
+    there (the shim cannot be executed here -- no julia -- so at least its coverage of the ABI is checked)."""
+    import re
+    header = open(os.path.join(ROOT, "include", "almpc.h")).read()
+    names = sorted(set(re.findall(r"\b(almpc_[a-z0-9_]+)\s*\(", header)))
+    shim = open(os.path.join(ROOT, "julia", "AlmpcHIP.jl")).read()
+    bound = set(re.findall(r"\(:(almpc_[a-z0-9_]+), libalmpc\)", shim))
+    missing = [n for n in names if n not in bound]
+    assert not missing, f"not bound in julia/AlmpcHIP.jl: {missing}"
+    assert len(names) >= 45
