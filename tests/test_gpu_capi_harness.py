@@ -1,5 +1,6 @@
 """The C ABI from a non-Python caller: tests/capi_harness.c (plain C, gcc, links libalmpc.so, column-major arrays as `ccall` passes
-them) solves the golden cases of tests/golden/ and checks them itself; it also makes the almpc_comm_* calls of a one-rank job."""
+them) solves the golden cases of tests/golden/ and checks them itself, makes the almpc_comm_* calls of a one-rank job, and solves the
+same cases once more as one model per instance with an (inactive) state box: almpc_set_state_box + almpc_design_batched from C."""
 import json
 import os
 import subprocess
@@ -46,3 +47,4 @@ def test_c_caller_solves_the_golden_cases(tmp_path, capi, name):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith(("OK ", "FAIL "))][-1]   # (librccl may print a version banner)
     assert line.startswith("OK ") and f"instances {len(cases)} unsolved 0" in line
     assert "comm_rc 0 ranks 1" in line, line      # the library loaded librccl and ran its collectives on a one-rank communicator
+    assert "per-instance+state-box unsolved 0" in line, line
