@@ -258,6 +258,27 @@ __global__ __launch_bounds__(32 * NG) void k_design_inverse_t(int nz, int nzs, c
             if (i < nz && c < nz) v = Hs[(size_t)c * nzs + i] + (i == c ? cshift + (dshift ? dshift[i] : 0.0) : 0.0);
             S[a][k] = v;
         }
+    // The reciprocal of a pivot is a chain of five dependent FP64 operations (v_rcp_f64 + two Newton steps: ~550 cycles of latency,
+    // measured with the stamps below) that every thread used to walk AFTER the barrier, i.e. on the critical path of every pivot.
+    // It is computed one pivot early instead: while pivot pv updates the tile, every thread updates the column of pivot pv + 1 first
+    // and starts the reciprocal of its own entry of that column in the row slot of row pv + 1 -- for the thread that owns element
+    // (pv + 1, pv + 1) that is the next pivot -- under the other 60 FMAs of the update; the owner publishes it with the pivot row.
+    auto fast_rcp = [](double v) __attribute__((always_inline)) -> double {
+        const double pvs = v > 0.0 ? v : 1.0;
+        double r = __builtin_amdgcn_rcp(pvs);
+        r = __builtin_fma(__builtin_fma(-pvs, r, 1.0), r, r);
+        r = __builtin_fma(__builtin_fma(-pvs, r, 1.0), r, r);
+        return r;
+    };
+    double* ipslot = smem + 514;   // [2] reciprocal of the pivot, published by its owner
+    double nip = fast_rcp(S[0][0]);   // (pivot 0: thread 0's entry)
+    double ncand = S[0][0];
+#ifdef ALMPC_STAMPS
+    long long sg_[6] = {0, 0, 0, 0, 0, 0}, st_ = 0;
+#define INV_T(S_) do { __builtin_amdgcn_sched_barrier(0); const long long t_ = __builtin_readcyclecounter(); if (S_ >= 0) sg_[S_ < 0 ? 0 : S_] += t_ - st_; st_ = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define INV_T(S_)
+#endif
     for (int gq = 0; gq < NG; ++gq) {
         const int ap = (KC * gq) >> 5;              // row slot of the pivot rows of this column group (uniform)
 #pragma unroll
@@ -267,6 +288,7 @@ __global__ __launch_bounds__(32 * NG) void k_design_inverse_t(int nz, int nzs, c
                 double* pr = prow + (pv & 1) * 128;
                 double* pc = pcol + (pv & 1) * 128;
                 const bool rowp = ri == (pv & 31);  // this thread holds a piece of row pv (in slot ap)
+                INV_T(-1);
                 if (g == gq) {                      // column pv, every row
 #pragma unroll
                     for (int a = 0; a < AR; ++a) pc[ri + 32 * a] = S[a][k];
@@ -281,34 +303,58 @@ __global__ __launch_bounds__(32 * NG) void k_design_inverse_t(int nz, int nzs, c
                                 *reinterpret_cast<d2*>(pr + KC * g + kk) = w;
                             }
                         }
+                    if (g == gq) {                  // this thread owns the pivot element itself
+                        ipslot[pv & 1] = nip;
+                        if (!(ncand > 0.0)) *badp = 1;
+                    }
                 }
+                INV_T(0);
                 __syncthreads();
-                const double piv = pr[pv];
-                if (!(piv > 0.0) && threadIdx.x == 0) *badp = 1;
-                // 1 / pivot: hardware reciprocal + two Newton steps (relative error ~1e-16; the IEEE division is ~35 instructions and
-                // every thread of the workgroup needs the value: as many issue cycles as the pivot's 32 FMAs)
-                const double pvs = piv > 0.0 ? piv : 1.0;
-                double ip = __builtin_amdgcn_rcp(pvs);
-                ip = __builtin_fma(__builtin_fma(-pvs, ip, 1.0), ip, ip);
-                ip = __builtin_fma(__builtin_fma(-pvs, ip, 1.0), ip, ip);
+                INV_T(1);
+#ifdef ALMPC_STAMPS
+                if (g_stamps && threadIdx.x == 0 && (blockIdx.y == 0 || blockIdx.y == gridDim.y / 2))
+                    g_stamps[(size_t)(blockIdx.y == 0 ? 0 : 1) * 256 + pv] = __builtin_readcyclecounter();
+#endif
+                const double ip = ipslot[pv & 1];
+                INV_T(2);
                 double w[KC];
 #pragma unroll
                 for (int kk = 0; kk < KC; kk += 2) {
                     const d2 t = *reinterpret_cast<const d2*>(pr + KC * g + kk);
                     w[kk] = t[0]; w[kk + 1] = t[1];
                 }
+                INV_T(3);
+                double f[AR];
+                bool ispa[AR];
 #pragma unroll
                 for (int a = 0; a < AR; ++a) {
-                    const bool isp = rowp && a == ap;
-                    const double f = isp ? 0.0 : pc[ri + 32 * a] * ip;   // the pivot row itself is rescaled, not eliminated
-#pragma unroll
-                    for (int kk = 0; kk < KC; ++kk) S[a][kk] = __builtin_fma(-f, w[kk], S[a][kk]);
-                    if (isp) {
-#pragma unroll
-                        for (int kk = 0; kk < KC; ++kk) S[a][kk] *= ip;
-                    }
-                    if (g == gq) S[a][k] = isp ? ip : -f;  // column pv
+                    ispa[a] = rowp && a == ap;
+                    f[a] = ispa[a] ? 0.0 : pc[ri + 32 * a] * ip;   // the pivot row itself is rescaled, not eliminated
                 }
+                // the column of the next pivot first, and its reciprocal in flight under the rest of the update
+                const int kn = (k + 1) % KC;   // (a constant once the pivot loop is unrolled)
+                const int an = (pv + 1) >> 5;
+#pragma unroll
+                for (int a = 0; a < AR; ++a) {
+                    double v = __builtin_fma(-f[a], w[kn], S[a][kn]);
+                    if (ispa[a]) v *= ip;
+                    S[a][kn] = v;
+                    if (a == an) ncand = v;
+                }
+                nip = fast_rcp(ncand);
+#pragma unroll
+                for (int a = 0; a < AR; ++a) {
+#pragma unroll
+                    for (int kk = 0; kk < KC; ++kk)
+                        if (kk != kn) S[a][kk] = __builtin_fma(-f[a], w[kk], S[a][kk]);
+                    if (ispa[a]) {
+#pragma unroll
+                        for (int kk = 0; kk < KC; ++kk)
+                            if (kk != kn) S[a][kk] *= ip;
+                    }
+                    if (g == gq) S[a][k] = ispa[a] ? ip : -f[a];  // column pv
+                }
+                INV_T(4);
             }
         }
     }
@@ -321,6 +367,10 @@ __global__ __launch_bounds__(32 * NG) void k_design_inverse_t(int nz, int nzs, c
         }
     __syncthreads();
     if (threadIdx.x == 0 && *badp) atomicExch(flag, 2);
+#ifdef ALMPC_STAMPS
+    if (g_stamps && threadIdx.x == 0 && blockIdx.y == 0)
+        for (int c_ = 0; c_ < 5; ++c_) g_stamps[(size_t)2 * 256 + c_] = sg_[c_];
+#endif
 }
 // launcher: the smallest register tile that holds the matrix
 inline void launch_design_inverse(dim3 grid, size_t lds, hipStream_t st, int nz, int nzs, const double* Hs, double cshift, const double* dshift,
