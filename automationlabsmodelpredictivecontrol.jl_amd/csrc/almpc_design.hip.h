@@ -372,10 +372,84 @@ __global__ __launch_bounds__(32 * NG) void k_design_inverse_t(int nz, int nzs, c
         for (int c_ = 0; c_ < 5; ++c_) g_stamps[(size_t)2 * 256 + c_] = sg_[c_];
 #endif
 }
+// ---- K5, nz <= 64: ONE WAVE per matrix, no LDS and no barrier ---------------------------------------------------------------------
+// Lane i holds row i (NCOL >= nz columns in registers).  The pivot row reaches the lanes through v_readlane (an SGPR operand of the
+// FMAs), the pivot column is each lane's own register.  To keep that register's index a compile-time constant without unrolling
+// the pivots, the row is rotated by one column after every pivot: position 0 is always the pivot column, position c holds column
+// (c + pivots done) mod NCOL.  The reciprocal of the next pivot is started one pivot early, as above.  The multi-wave kernel spends
+// three LDS round trips of ~450 cycles per pivot (stamps: tools/stamps_inverse.py); this one has no round trip at all on its chain.
+template <int NCOL>
+__global__ __launch_bounds__(256) void k_design_inverse_wave(int nz, int nzs, int batch, const double* Hs, double cshift, const double* dshift,
+                                                             double* Out, int* flag, long sHs, long sShift, long sOut, long sFlag) {
+    const int lane = threadIdx.x & 63;
+    const int inst = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (inst >= batch) return;
+    Hs += (size_t)inst * sHs; Out += (size_t)inst * sOut; flag += (size_t)inst * sFlag;
+    if (dshift) dshift += (size_t)inst * sShift;
+    const int i = lane;
+    double S[NCOL];
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c) {
+        double v = (i == c) ? 1.0 : 0.0;   // (padding: unit diagonal)
+        if (i < nz && c < nz) v = Hs[(size_t)c * nzs + i] + (i == c ? cshift + (dshift ? dshift[i] : 0.0) : 0.0);
+        S[c] = v;
+    }
+    auto fast_rcp = [](double v) __attribute__((always_inline)) -> double {
+        const double pvs = v > 0.0 ? v : 1.0;
+        double r = __builtin_amdgcn_rcp(pvs);
+        r = __builtin_fma(__builtin_fma(-pvs, r, 1.0), r, r);
+        r = __builtin_fma(__builtin_fma(-pvs, r, 1.0), r, r);
+        return r;
+    };
+    bool bad = false;
+    double piv = readlane_d(S[0], 0);
+    double ip = fast_rcp(piv);
+#pragma unroll 1
+    for (int pv = 0; pv < nz; ++pv) {
+        if (!(piv > 0.0)) bad = true;
+        const bool isp = i == pv;
+        const double f = isp ? 0.0 : S[0] * ip;      // the pivot row itself is rescaled, not eliminated
+        // the next pivot first: column at position 1, row pv + 1
+        const int pn = pv + 1 < 64 ? pv + 1 : 63;
+        double w1 = readlane_d(S[1], pv);
+        double s1 = __builtin_fma(-f, w1, S[1]);
+        if (isp) s1 *= ip;
+        S[1] = s1;
+        const double npiv = readlane_d(s1, pn);
+        const double nip = fast_rcp(npiv);
+#pragma unroll
+        for (int c = 2; c < NCOL; ++c) {
+            const double w = readlane_d(S[c], pv);
+            double v = __builtin_fma(-f, w, S[c]);
+            if (isp) v *= ip;
+            S[c] = v;
+        }
+        const double c0 = isp ? ip : -f;             // column pv of the inverse so far
+        // rotate: the next pivot column moves to position 0, the finished one to the end
+#pragma unroll
+        for (int c = 0; c + 1 < NCOL; ++c) S[c] = S[c + 1];
+        S[NCOL - 1] = c0;
+        piv = npiv; ip = nip;
+    }
+    // position c holds column (c + nz) mod NCOL
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c) {
+        const int col = (c + nz) % NCOL;
+        if (i < nz && col < nz) Out[(size_t)col * nzs + i] = S[c];
+    }
+    if (__any(bad) && lane == 0) atomicExch(flag, 2);
+}
+
 // launcher: the smallest register tile that holds the matrix
 inline void launch_design_inverse(dim3 grid, size_t lds, hipStream_t st, int nz, int nzs, const double* Hs, double cshift, const double* dshift,
                                   double* Out, int* flag, long sHs, long sShift, long sOut, long sFlag) {
-    if (nz <= 64) hipLaunchKernelGGL((k_design_inverse_t<2, 8>), grid, dim3(DESIGN_INVERSE_THREADS), lds, st, nz, nzs, Hs, cshift, dshift, Out, flag, sHs, sShift, sOut, sFlag);
+    if (nz <= 64 && !getenv("ALMPC_INV_TILE")) {   // one wave per matrix (grid.y = matrices, as for the tile kernels)
+        const int b = (int)grid.y;
+        const dim3 g2((unsigned)((b + 3) / 4));
+#define INV_WAVE(NC_) hipLaunchKernelGGL((k_design_inverse_wave<NC_>), g2, dim3(256), 0, st, nz, nzs, b, Hs, cshift, dshift, Out, flag, sHs, sShift, sOut, sFlag)
+        if (nz <= 16) INV_WAVE(16); else if (nz <= 32) INV_WAVE(32); else if (nz <= 48) INV_WAVE(48); else INV_WAVE(64);
+#undef INV_WAVE
+    } else if (nz <= 64) hipLaunchKernelGGL((k_design_inverse_t<2, 8>), grid, dim3(DESIGN_INVERSE_THREADS), lds, st, nz, nzs, Hs, cshift, dshift, Out, flag, sHs, sShift, sOut, sFlag);
     else hipLaunchKernelGGL((k_design_inverse_t<4, 16>), grid, dim3(DESIGN_INVERSE_THREADS), lds, st, nz, nzs, Hs, cshift, dshift, Out, flag, sHs, sShift, sOut, sFlag);
 }
 
