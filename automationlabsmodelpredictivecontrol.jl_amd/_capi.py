@@ -119,6 +119,36 @@ def load():
     L.almpc_fnn_linearize.restype = ctypes.c_int
     L.almpc_debug_poison_lds.restype = ctypes.c_int
     L.almpc_timing_summary.argtypes = [_hp, ctypes.POINTER(ctypes.c_int)] + [_dp] * 4
+    # host-facing step path (pinned staging, copy streams) and one-process multi-GPU groups
+    L.almpc_update_initialization_async.argtypes = [_hp, _dp]
+    L.almpc_get_results_async.argtypes = [_hp, ctypes.c_uint32]
+    L.almpc_get_results_wait.argtypes = [_hp, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _ip]
+    L.almpc_host_results.argtypes = [_hp, ctypes.c_int] + [ctypes.POINTER(ctypes.c_void_p)] * 8
+    L.almpc_get_first_input.argtypes = [_hp, _dp]
+    L.almpc_group_create.argtypes = [ctypes.POINTER(_hp), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     ctypes.POINTER(ctypes.c_int), ctypes.c_uint32]
+    L.almpc_group_destroy.argtypes = [_hp]
+    L.almpc_group_destroy.restype = None
+    L.almpc_group_last_error.argtypes = [_hp]
+    L.almpc_group_last_error.restype = ctypes.c_char_p
+    L.almpc_group_size.argtypes = [_hp]
+    L.almpc_group_handle.argtypes = [_hp, ctypes.c_int]
+    L.almpc_group_handle.restype = _hp
+    L.almpc_group_shard.argtypes = [_hp, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    L.almpc_group_design_shared.argtypes = [_hp] + [_dp] * 10 + [ctypes.c_double, ctypes.c_double]
+    L.almpc_group_set_reference.argtypes = [_hp, _dp, _dp, ctypes.c_int]
+    L.almpc_group_update_initialization.argtypes = [_hp, _dp]
+    L.almpc_group_calculate.argtypes = [_hp, ctypes.POINTER(almpc_opts)]
+    L.almpc_group_calculate_async.argtypes = [_hp, ctypes.POINTER(almpc_opts)]
+    L.almpc_group_synchronize.argtypes = [_hp]
+    L.almpc_group_get_results.argtypes = [_hp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _ip]
+    L.almpc_timing_samples.argtypes = [_hp, ctypes.c_int, ctypes.POINTER(ctypes.c_int), _fp, _fp, _fp, _fp]
+    L.almpc_timing_samples.restype = ctypes.c_int
+    for name in ("almpc_update_initialization_async", "almpc_get_results_async", "almpc_get_results_wait", "almpc_host_results",
+                 "almpc_get_first_input", "almpc_group_create", "almpc_group_size", "almpc_group_shard", "almpc_group_design_shared",
+                 "almpc_group_set_reference", "almpc_group_update_initialization", "almpc_group_calculate",
+                 "almpc_group_calculate_async", "almpc_group_synchronize", "almpc_group_get_results"):
+        getattr(L, name).restype = ctypes.c_int
     for name in ("almpc_create", "almpc_design_shared", "almpc_set_reference", "almpc_update_initialization",
                  "almpc_update_initialization_device", "almpc_calculate", "almpc_calculate_async", "almpc_synchronize",
                  "almpc_get_results", "almpc_get_design", "almpc_device_results", "almpc_get_timing", "almpc_timing_reset",
@@ -129,6 +159,15 @@ def load():
 
 
 OPT_NO_WARM_STATE = 0x1  # almpc.h: ALMPC_OPT_NO_WARM_STATE (opts.reserved[0])
+# almpc.h: ALMPC_WANT_* (almpc_get_results_async)
+WANT = {"x": 0x01, "e_x": 0x02, "u": 0x04, "e_u": 0x08, "status": 0x10, "iters": 0x20, "polish_iters": 0x40, "u0": 0x80}
+
+
+def _want_mask(want):
+    try:
+        return sum(WANT[k] for k in set(want))
+    except KeyError as e:
+        raise ValueError(f"unknown result {e.args[0]!r}; choose from {sorted(WANT)}") from None
 
 
 def comm_unique_id() -> bytes:
@@ -478,6 +517,54 @@ class Solver:
             if k in bufs: bufs[k] = bufs[k].transpose(0, 2, 1)
         return bufs
 
+    # ---- host-facing step path: pinned staging, transfers on copy streams (include/almpc.h "Host-facing step path")
+    def update_initialization_async(self, x0):
+        """x0 (batch, n) -> pinned slot -> upload on the copy-in stream; the next calculate waits for it on the device."""
+        x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(self.batch, self.n)
+        self._check(self.L.almpc_update_initialization_async(self.h, _ptr(x0)))
+
+    def get_results_async(self, want=("u0", "status")) -> int:
+        """Ask for results of the last enqueued step (names of WANT; "u0" = u[:, 1] of every instance); returns a ticket."""
+        t = self.L.almpc_get_results_async(self.h, _want_mask(want))
+        if t < 0:
+            self._check(t)
+        return t
+
+    def get_results_wait(self, ticket, want=("u0", "status"), copy=True):
+        """Results of a ticket.  copy=True: fresh arrays (almpc_get_results_wait); copy=False: views of the handle's pinned slot
+        (almpc_host_results: zero-copy, valid until two more requests).  Shapes as get_results; u0 (batch, m)."""
+        b, n, m, N = self.batch, self.n, self.m, self.N
+        shapes = {"x": (b, N + 1, n), "e_x": (b, N + 1, n), "u": (b, N, m), "e_u": (b, N, m), "u0": (b, m),
+                  "status": (b,), "iters": (b,), "polish_iters": (b,)}
+        order = ("x", "e_x", "u", "e_u", "u0", "status", "iters", "polish_iters")
+        want = set(want)
+        _want_mask(want)
+        if copy:
+            bufs = {k: np.empty(shapes[k], dtype=np.int32 if k in ("status", "iters", "polish_iters") else np.float64) for k in want}
+            args = [(bufs[k].ctypes.data_as(_ip if bufs[k].dtype == np.int32 else _dp) if k in bufs else None) for k in order]
+            self._check(self.L.almpc_get_results_wait(self.h, int(ticket), *args))
+        else:
+            self._check(self.L.almpc_get_results_wait(self.h, int(ticket), *([None] * 8)))
+            ps = [ctypes.c_void_p() for _ in order]
+            self._check(self.L.almpc_host_results(self.h, int(ticket), *[ctypes.byref(q) for q in ps]))
+            bufs = {}
+            for k, q in zip(order, ps):
+                if k in want:
+                    if not q.value:
+                        raise AlmpcError(-1, f"result {k!r} was not part of the request of ticket {ticket}")
+                    ct = ctypes.c_int32 if k in ("status", "iters", "polish_iters") else ctypes.c_double
+                    cnt = int(np.prod(shapes[k]))
+                    bufs[k] = np.ctypeslib.as_array(ctypes.cast(q.value, ctypes.POINTER(ct)), shape=(cnt,)).reshape(shapes[k])
+        for k in ("x", "e_x", "u", "e_u"):
+            if k in bufs: bufs[k] = bufs[k].transpose(0, 2, 1)
+        return bufs
+
+    def get_first_input(self):
+        """u[:, 1] of every instance, (batch, m): what a receding-horizon caller applies (almpc_get_first_input)."""
+        u0 = np.empty((self.batch, self.m))
+        self._check(self.L.almpc_get_first_input(self.h, _ptr(u0)))
+        return u0
+
     def get_design(self):
         n, nz = self.n, self.nz
         H = np.empty((nz, nz), order="F"); F = np.empty((nz, n), order="F"); P = np.empty((n, n), order="F"); d = np.empty(nz)
@@ -506,6 +593,14 @@ class Solver:
     def timing_reset(self, reserve_steps=0):
         self._check(self.L.almpc_timing_reset(self.h, int(reserve_steps)))
 
+    def timing_samples(self, cap=4096):
+        """Per recorded step its stage times (ms): dict of float32 arrays of length min(cap, steps recorded since the reset)."""
+        n = ctypes.c_int()
+        a = {k: np.zeros(int(cap), dtype=np.float32) for k in ("admm_ms", "polish_ms", "rollout_ms", "total_ms")}
+        self._check(self.L.almpc_timing_samples(self.h, int(cap), ctypes.byref(n), *[a[k].ctypes.data_as(_fp) for k in a]))
+        k = min(int(cap), n.value)
+        return {key: v[:k] for key, v in a.items()}
+
     def timing_summary(self):
         n = ctypes.c_int()
         v = [ctypes.c_double() for _ in range(4)]
@@ -513,3 +608,103 @@ class Solver:
         out = dict(zip(("admm_ms", "polish_ms", "rollout_ms", "total_ms"), [x.value for x in v]))
         out["steps"] = n.value
         return out
+
+
+class _HandleView(Solver):
+    """A Solver over a handle owned by a Group (no create / destroy of its own)."""
+
+    def __init__(self, L, h, n, m, N, batch):
+        self.L, self.h = L, h
+        self.n, self.m, self.N, self.batch = n, m, N, batch
+        self.nz = m * N
+
+    def close(self):
+        self.h = None
+
+    __del__ = close
+
+
+class Group:
+    """One process, several GPUs (almpc_group_*): one handle per entry of `devices` on its contiguous shard of the batch; every call
+    fans out over the handles, nothing on the step path synchronises across devices.  Host arrays cover the whole batch."""
+
+    def __init__(self, n, m, N, batch, devices, timing=False):
+        self.L = load()
+        self.n, self.m, self.N, self.batch = int(n), int(m), int(N), int(batch)
+        devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+        g = _hp()
+        rc = self.L.almpc_group_create(ctypes.byref(g), self.n, self.m, self.N, self.batch, len(devices), devs, FLAG_TIMING if timing else 0)
+        if rc != ALMPC_OK:
+            raise AlmpcError(rc, "almpc_group_create failed (are the devices visible? there is no CPU fallback)")
+        self.g = g
+        self.shards = []
+        for i in range(len(devices)):
+            f, c = ctypes.c_int(), ctypes.c_int()
+            self._check(self.L.almpc_group_shard(self.g, i, ctypes.byref(f), ctypes.byref(c)))
+            self.shards.append((f.value, c.value))
+        self.handles = [_HandleView(self.L, _hp(self.L.almpc_group_handle(self.g, i)), self.n, self.m, self.N, c)
+                        for i, (_, c) in enumerate(self.shards)]
+
+    def _check(self, rc):
+        if rc != ALMPC_OK:
+            raise AlmpcError(rc, (self.L.almpc_group_last_error(self.g) or b"").decode())
+
+    def close(self):
+        if getattr(self, "g", None):
+            for hv in self.handles:
+                hv.close()
+            self.L.almpc_group_destroy(self.g)
+            self.g = None
+
+    __del__ = close
+
+    def design_shared(self, A, B, Q, R, S=None, P=None, umin=None, umax=None, xmin=None, xmax=None, rho=0.1, sigma=1e-6,
+                      terminal="none", rho_profile="scalar"):
+        n, m = self.n, self.m
+        for hv in self.handles:   # per-handle options go through the handles (almpc_group_handle)
+            hv._check(self.L.almpc_set_terminal_equality(hv.h, 1 if terminal == "equality" else 0))
+            hv._check(self.L.almpc_set_rho_profile(hv.h, {"scalar": 0, "stiffness": 1}[rho_profile]))
+        A, B, Q, R = _colmajor(A, (n, n)), _colmajor(B, (n, m)), _colmajor(Q, (n, n)), _colmajor(R, (m, m))
+        S = None if S is None else _colmajor(S, (m, m))
+        P = None if P is None else _colmajor(P, (n, n))
+        umin = np.ascontiguousarray(umin, dtype=np.float64).reshape(m)
+        umax = np.ascontiguousarray(umax, dtype=np.float64).reshape(m)
+        xmin = None if xmin is None else np.ascontiguousarray(xmin, dtype=np.float64).reshape(n)
+        xmax = None if xmax is None else np.ascontiguousarray(xmax, dtype=np.float64).reshape(n)
+        self._check(self.L.almpc_group_design_shared(self.g, _ptr(A), _ptr(B), _ptr(Q), _ptr(R), _ptr(S), _ptr(P), _ptr(umin),
+                                                     _ptr(umax), _ptr(xmin), _ptr(xmax), float(rho), float(sigma)))
+
+    def set_reference(self, x_ref, u_ref, per_instance=False):
+        n, m, N = self.n, self.m, self.N
+        x_ref, u_ref = np.asarray(x_ref, dtype=np.float64), np.asarray(u_ref, dtype=np.float64)
+        if per_instance:
+            xr = np.ascontiguousarray(x_ref.reshape(self.batch, n, N + 1).transpose(0, 2, 1))
+            ur = np.ascontiguousarray(u_ref.reshape(self.batch, m, N).transpose(0, 2, 1))
+        else:
+            xr = np.ascontiguousarray(x_ref.reshape(n, N + 1).T)
+            ur = np.ascontiguousarray(u_ref.reshape(m, N).T)
+        self._check(self.L.almpc_group_set_reference(self.g, _ptr(xr), _ptr(ur), 1 if per_instance else 0))
+
+    def update_initialization(self, x0):
+        x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(self.batch, self.n)
+        self._check(self.L.almpc_group_update_initialization(self.g, _ptr(x0)))
+
+    def calculate(self, opts: almpc_opts | None = None, sync=True):
+        fn = self.L.almpc_group_calculate if sync else self.L.almpc_group_calculate_async
+        self._check(fn(self.g, None if opts is None else ctypes.byref(opts)))
+
+    def synchronize(self):
+        self._check(self.L.almpc_group_synchronize(self.g))
+
+    def get_results(self, want=("x", "e_x", "u", "e_u", "status", "iters", "polish_iters")):
+        b, n, m, N = self.batch, self.n, self.m, self.N
+        shapes = {"x": (b, N + 1, n), "e_x": (b, N + 1, n), "u": (b, N, m), "e_u": (b, N, m), "u0": (b, m),
+                  "status": (b,), "iters": (b,), "polish_iters": (b,)}
+        order = ("x", "e_x", "u", "e_u", "u0", "status", "iters", "polish_iters")
+        _want_mask(want)
+        bufs = {k: np.empty(shapes[k], dtype=np.int32 if k in ("status", "iters", "polish_iters") else np.float64) for k in set(want)}
+        args = [(bufs[k].ctypes.data_as(_ip if bufs[k].dtype == np.int32 else _dp) if k in bufs else None) for k in order]
+        self._check(self.L.almpc_group_get_results(self.g, *args))
+        for k in ("x", "e_x", "u", "e_u"):
+            if k in bufs: bufs[k] = bufs[k].transpose(0, 2, 1)
+        return bufs

@@ -126,6 +126,35 @@ struct almpc_handle {
     int comm_rank = 0, comm_world = 0;
     long long* dComm4 = nullptr;       // [4] summary words
     double *dU0 = nullptr, *dU0all = nullptr;  // [batch][m] packed first inputs, [world][batch][m] gathered
+    // host-facing step path (almpc_update_initialization_async, almpc_get_results_async / _wait, almpc_get_first_input): pinned
+    // staging owned by the handle, copies on their own streams, rings of IO_DEPTH slots so that the transfers of one step run
+    // under the kernel of the next (csrc/almpc_hostio.inc.h)
+    static constexpr int IO_DEPTH = 2;
+    struct Io {
+        bool ready = false;
+        hipStream_t s_out = nullptr;
+        // x0 ring: pinned host slots the kernels read in place (dX0 = the device's address of the slot); h->dX0 points at the latest
+        double* hX0[IO_DEPTH] = {nullptr, nullptr};
+        double* dX0[IO_DEPTH] = {nullptr, nullptr};
+        hipEvent_t ev_used[IO_DEPTH] = {nullptr, nullptr};   // the last step that read the slot has finished (recorded on the compute stream)
+        bool used_pending[IO_DEPTH] = {false, false};
+        int x0_slot = -1;     // slot h->dX0 points at (-1: the handle's own buffer)
+        double* dX0_own = nullptr;   // the handle's own x0 buffer while h->dX0 points into the ring
+        long x0_count = 0;
+        // result ring: ticket t lives in slot t % IO_DEPTH
+        double *hX[IO_DEPTH] = {nullptr, nullptr}, *hEx[IO_DEPTH] = {nullptr, nullptr}, *hU[IO_DEPTH] = {nullptr, nullptr},
+               *hEu[IO_DEPTH] = {nullptr, nullptr}, *hU0[IO_DEPTH] = {nullptr, nullptr};
+        int32_t* hInts[IO_DEPTH] = {nullptr, nullptr};       // pinned [3][batch]: status | iters | polish_iters
+        double* dU0[IO_DEPTH] = {nullptr, nullptr};          // the device's addresses of hU0 / hInts (the pack kernel writes the pinned
+        int32_t* dInts[IO_DEPTH] = {nullptr, nullptr};       // slots directly)
+        hipEvent_t ev_packed[IO_DEPTH] = {nullptr, nullptr}; // compute stream: the results of the slot's step exist (copy-out stream waits)
+        hipEvent_t ev_done[IO_DEPTH] = {nullptr, nullptr};   // everything the slot's request asked for has landed in pinned memory
+        uint32_t want[IO_DEPTH] = {0, 0};
+        long ticket[IO_DEPTH] = {-1, -1};
+        long next_ticket = 0;
+        bool big_copy_pending = false;  // a read-back of x / e_x / u / e_u (straight from the result buffers) may still be running:
+        int big_copy_slot = 0;          // the next step waits for it before it overwrites them
+    } io;
     // timing (ALMPC_FLAG_TIMING): one set of 4 events per step since the last almpc_timing_reset
     std::vector<hipEvent_t> ev;  // 4 per step
     size_t ev_used = 0;          // steps recorded
@@ -175,7 +204,19 @@ hipError_t launch_admm(int nrb, int ks, const AdmmParams& p, int grid, size_t ld
     return hipErrorInvalidValue;
 }
 
+void io_free(almpc_handle* h);   // almpc_hostio.inc.h
+
+// After almpc_update_initialization_async h->dX0 points at a pinned host slot the kernels read in place.  Entry points that WRITE x0
+// through a device-side copy go back to the handle's own device buffer first.
+void io_release_x0(almpc_handle* h) {
+    if (h->io.x0_slot >= 0) {
+        h->dX0 = h->io.dX0_own;
+        h->io.x0_slot = -1;
+    }
+}
+
 void free_all(almpc_handle* h) {
+    io_free(h);
     void* ptrs[] = {h->dMinvFrag, h->dVFrag, h->dHFrag, h->dFFrag, h->dG, h->dD, h->dUmin, h->dUmax, h->dA, h->dB,
                     h->dXref, h->dUref, h->dFS, h->dV0S, h->dRho, h->dRollM, h->dX0, h->dXs, h->dZs, h->dYs, h->dV0, h->dW, h->dX, h->dEx,
                     h->dU, h->dEu, h->dStatus, h->dIters, h->dPiters, h->dPerm, h->dYflags, h->dSglobal, h->dGhat, h->dGnorm, h->dXmin,
@@ -315,6 +356,7 @@ hipError_t launch_riccati(almpc_handle* h, int filter, const double* guess, int 
     rp.B = pi ? h->bB : h->dB; rp.B_stride = pi ? (long)h->n * h->m : 0;
     rp.Q = h->rQ; rp.R = h->rR;
     rp.P = h->r_batched_P ? h->bP : h->rP; rp.P_stride = h->r_batched_P ? h->rP_stride : 0;
+    if (!rp.Q || !rp.R || !rp.P || !h->rKst) return hipErrorInvalidValue;   // no riccati_weights() for this design: nothing to launch with
     rp.umin = h->dUmin; rp.umax = h->dUmax;
     rp.uref = h->dUref; rp.uref_stride = h->uref_stride; rp.xref = h->dXref; rp.xref_stride = h->xref_stride;
     rp.x0 = h->dX0; rp.uguess = guess; rp.filter = filter; rp.Kst = h->rKst; rp.Pst = h->rPst;
@@ -520,6 +562,7 @@ int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const
         for (int i = 0; i < m; ++i)
             if (!(umin[i] <= umax[i])) return fail(h, ALMPC_ERR_INVALID, "design: umin > umax");
         h->designed = false;
+        h->sqp.ready = h->sqp.started = false;   // (an SQP loop set up on this handle is gone with its per-instance reference buffers)
         HIP_TRY(h, hipSetDevice(h->device));
         hm::mat Am(A, A + (size_t)n * n), Bm(B, B + (size_t)n * m), Qm(Q, Q + (size_t)n * n), Rm(R, R + (size_t)m * m), Pm;
         if (P) Pm.assign(P, P + (size_t)n * n);
@@ -1099,6 +1142,8 @@ int almpc_relin_fnn_setup(almpc_handle* h, int H, int L, int activation, const d
     if (H < 1 || L < 0 || !W_in || !W_out || (L > 0 && (!W_h || !b_h)) || !Q || !R || !P || !umin || !umax)
         return fail(h, ALMPC_ERR_INVALID, "relin_fnn_setup: null pointer or bad network shape (P must be given: the terminal weight "
                                           "comes from the linearisation at the last reference, src/sub/design_mpc.jl:312-327)");
+    if (h->structured)
+        return fail(h, ALMPC_ERR_UNSUPPORTED, "relin_fnn_setup: a handle created with ALMPC_FLAG_STRUCTURED has no condensed per-instance designs");
     if (activation < 0 || activation > 4) return fail(h, ALMPC_ERR_UNSUPPORTED, "relin_fnn_setup: activation must be 0..4");
     if (!(rho > 0.0) || !(sigma >= 0.0)) return fail(h, ALMPC_ERR_INVALID, "relin_fnn_setup: rho must be > 0 and sigma >= 0");
     const int n = h->n, m = h->m, N = h->N, nz = h->nz;
@@ -1225,7 +1270,7 @@ int almpc_relin_fnn_step_async(almpc_handle* h, const almpc_opts* opts) {
     o2.warm_start = 0;   // (the per-instance ADMM's own warm start is not what a warm step of this pipeline means)
     const int rc = almpc_calculate_async(h, &o2);
     h->skip_admm = 0;
-    if (rc != ALMPC_OK) return rc;
+    if (rc != ALMPC_OK) { h->designed = false; return rc; }   // (no step ran on this step's designs: the handle is not left "designed")
     q.have_prev = true;
     hipLaunchKernelGGL(k_flag_to_status, dim3((h->batch + 255) / 256), dim3(256), 0, st, h->batch, h->bFlag, h->dStatus);
     HIP_TRY(h, hipGetLastError());
@@ -1256,6 +1301,7 @@ int almpc_relin_fnn_advance(almpc_handle* h) {
     fp.x = h->dX0; fp.u = q.u0; fp.ppi = 1; fp.xs_group = n; fp.us_group = m;
     fp.A = h->bA; fp.B = h->bB; fp.f = q.xnext;   // (the Jacobian slots are scratch here: the next step re-linearises at the new state)
     HIP_TRY(h, launch_fnn_jacobian(fp, h->num_cus, st));
+    io_release_x0(h);
     HIP_TRY(h, hipMemcpyAsync(h->dX0, q.xnext, (size_t)h->batch * n * sizeof(double), hipMemcpyDeviceToDevice, st));
     return ALMPC_OK;
 }
@@ -1290,7 +1336,12 @@ int almpc_sqp_fnn_setup(almpc_handle* h, int H, int L, int activation, const dou
     const size_t b = (size_t)h->batch, nin = (size_t)n + m;
     if (n > 64 || sqp_step_lds_doubles(n, m, N) * sizeof(double) > 160 * 1024)
         return fail(h, ALMPC_ERR_UNSUPPORTED, "sqp_fnn_setup: n <= 64 (one lane per state in the update kernel) and its stage buffers must fit LDS");
-    if (!ltv_supported(h))
+    if (h->structured) {   // a structured handle has no condensed path: every QP of the loop goes to k_riccati (any m N <= 1024)
+        if (!riccati_shape_ok(h)) return fail(h, ALMPC_ERR_UNSUPPORTED, "sqp_fnn_setup: the stage-wise QP solve needs n <= 32, m <= 16 and its buffers in LDS");
+        h->sqp.structured_qp = 1;
+    }
+    const bool sq_struct = h->sqp.structured_qp != 0;
+    if (!sq_struct && !ltv_supported(h))
         return fail(h, ALMPC_ERR_UNSUPPORTED, "sqp_fnn_setup: nz <= 128, or nz^2 + 3 n nz doubles must fit the 160 KB of LDS");
     if ((2 * (size_t)H + 2 * (size_t)H * nin + nin) * sizeof(double) > 160 * 1024)
         return fail(h, ALMPC_ERR_UNSUPPORTED, "sqp_fnn_setup: the network's forward-mode Jacobian must fit the 160 KB of LDS");
@@ -1315,7 +1366,13 @@ int almpc_sqp_fnn_setup(almpc_handle* h, int H, int L, int activation, const dou
         const hm::mat Pm = sym(P + i * n * n, n);
         std::copy(Pm.begin(), Pm.end(), Pall.begin() + i * n * n);
     }
-    { const int rc_ = ensure_batched_alloc(h); if (rc_ != ALMPC_OK) return rc_; }
+    if (sq_struct && !h->batched_alloc) {   // the stage-wise QP needs no condensed operand: terminal weights and the flag words only
+        if (!h->bP) HIP_TRY(h, dalloc(&h->bP, b * n * n));
+        if (!h->bFlag) HIP_TRY(h, dalloc(&h->bFlag, b));
+    } else {
+        const int rc_ = ensure_batched_alloc(h);
+        if (rc_ != ALMPC_OK) return rc_;
+    }
     almpc_handle::Sqp& q = h->sqp;
     const int keep_rule = q.step_rule, keep_structured = q.structured_qp;
     void* old[] = {q.W_in, q.W_h, q.b_h, q.W_out, q.A, q.B, q.c, q.fval, q.ebar, q.qadd, q.xref, q.uref, q.Q, q.R, q.S, q.bad, q.stats, q.mer, q.xback, q.uback, q.dxback, q.vback,
@@ -1352,18 +1409,20 @@ int almpc_sqp_fnn_setup(almpc_handle* h, int H, int L, int activation, const dou
                           // set: 0.2 |P| rejects good steps near the solution, 10 |P| rejects every full step of some instances
     }
     HIP_TRY(h, hipMemset(q.bad, 0, b * sizeof(int)));
-    if (!h->bQ) HIP_TRY(h, dalloc(&h->bQ, b * nz));
     HIP_TRY(h, dalloc(&h->dXref, b * (size_t)n * (N + 1))); HIP_TRY(h, dalloc(&h->dUref, b * nz));
-    HIP_TRY(h, dalloc(&h->dFS, b * nz)); HIP_TRY(h, dalloc(&h->dV0S, b * nz));
     HIP_TRY(h, hipMemcpy(h->bP, Pall.data(), Pall.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->dUmin, umin, m * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->dUmax, umax, m * sizeof(double), hipMemcpyHostToDevice));
-    // F_i = 0 for an LTV design (the gradient is explicit), so F'_i and V_i stay zero; stage-0 model slots are unused but read
-    HIP_TRY(h, hipMemset(h->bF, 0, b * nz * n * sizeof(double)));
-    HIP_TRY(h, hipMemset(h->bFs, 0, b * n * nzs * sizeof(double)));
-    HIP_TRY(h, hipMemset(h->bVs, 0, b * n * nzs * sizeof(double)));
-    HIP_TRY(h, hipMemset(h->bA, 0, b * n * n * sizeof(double)));
-    HIP_TRY(h, hipMemset(h->bB, 0, b * n * m * sizeof(double)));
+    if (h->batched_alloc) {   // the condensed route (also kept ready when a condensed handle sends its QPs to k_riccati after an earlier design)
+        if (!h->bQ) HIP_TRY(h, dalloc(&h->bQ, b * nz));
+        HIP_TRY(h, dalloc(&h->dFS, b * nz)); HIP_TRY(h, dalloc(&h->dV0S, b * nz));
+        // F_i = 0 for an LTV design (the gradient is explicit), so F'_i and V_i stay zero; stage-0 model slots are unused but read
+        HIP_TRY(h, hipMemset(h->bF, 0, b * nz * n * sizeof(double)));
+        HIP_TRY(h, hipMemset(h->bFs, 0, b * n * nzs * sizeof(double)));
+        HIP_TRY(h, hipMemset(h->bVs, 0, b * n * nzs * sizeof(double)));
+        HIP_TRY(h, hipMemset(h->bA, 0, b * n * n * sizeof(double)));
+        HIP_TRY(h, hipMemset(h->bB, 0, b * n * m * sizeof(double)));
+    }
     q.H = H; q.L = L; q.act = activation; q.useR = Rm[0] != 0.0; q.useS = q.useR && Sm[0] != 0.0; q.sP = p_inst ? (long)n * n : 0;
     h->P.assign(Pall.begin(), Pall.begin() + (size_t)n * n);
     h->hS = Sm;
@@ -1396,6 +1455,7 @@ int almpc_sqp_fnn_start(almpc_handle* h, const double* x0, const double* u_guess
     const size_t b = (size_t)h->batch;
     hipStream_t st = h->stream;
     HIP_TRY(h, hipStreamSynchronize(st));
+    io_release_x0(h);
     HIP_TRY(h, hipMemcpy(h->dX0, x0, b * n * sizeof(double), hipMemcpyHostToDevice));
     if (u_guess) {
         std::vector<double> ug(u_guess, u_guess + b * nz), lo(m), hi(m);
@@ -1558,6 +1618,8 @@ int almpc_set_reference(almpc_handle* h, const double* xref, const double* uref,
     if (!h) return ALMPC_ERR_INVALID;
     if (!h->designed) return fail(h, ALMPC_ERR_NOT_DESIGNED, "set_reference before design");
     if (h->ltv) return fail(h, ALMPC_ERR_INVALID, "set_reference: the references of an LTV design are arguments of almpc_design_ltv");
+    if (h->relin.ready)
+        return fail(h, ALMPC_ERR_INVALID, "set_reference: the references of the re-linearisation pipeline are arguments of almpc_relin_fnn_setup");
     if (!xref || !uref) return fail(h, ALMPC_ERR_INVALID, "set_reference: null pointer");
     HIP_TRY(h, hipSetDevice(h->device));
     const int n = h->n, m = h->m, N = h->N, nz = h->nz;
@@ -1643,6 +1705,7 @@ int almpc_set_reference(almpc_handle* h, const double* xref, const double* uref,
 int almpc_update_initialization(almpc_handle* h, const double* x0) {
     if (!h || !x0) return h ? fail(h, ALMPC_ERR_INVALID, "update_initialization: null x0") : ALMPC_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
+    io_release_x0(h);
     HIP_TRY(h, hipMemcpyAsync(h->dX0, x0, (size_t)h->batch * h->n * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return ALMPC_OK;
@@ -1651,6 +1714,7 @@ int almpc_update_initialization(almpc_handle* h, const double* x0) {
 int almpc_update_initialization_device(almpc_handle* h, const double* d_x0) {
     if (!h || !d_x0) return h ? fail(h, ALMPC_ERR_INVALID, "update_initialization_device: null x0") : ALMPC_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
+    io_release_x0(h);
     HIP_TRY(h, hipMemcpyAsync(h->dX0, d_x0, (size_t)h->batch * h->n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     return ALMPC_OK;
 }
@@ -1671,11 +1735,22 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
     const bool keep_state = !((o.reserved[0] & ALMPC_OPT_NO_WARM_STATE) && !h->batched && o.polish && h->mc == 0);
     if (o.warm_start && !h->state_valid)
         return fail(h, ALMPC_ERR_INVALID, "calculate: warm_start = 1, but the previous step ran with ALMPC_OPT_NO_WARM_STATE (no ADMM state was kept)");
-    h->state_valid = keep_state;
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->io.big_copy_pending) {   // an asynchronous read-back straight from the result buffers: this step overwrites them
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->io.ev_done[h->io.big_copy_slot], 0));
+        h->io.big_copy_pending = false;
+    }
+    auto io_step_done = [&]() -> int {   // the x0 slot of an asynchronous update is free again once this step has finished
+        h->state_valid = keep_state;     // (recorded only here: every launch of the step went out)
+        if (h->io.x0_slot >= 0) {
+            HIP_TRY(h, hipEventRecord(h->io.ev_used[h->io.x0_slot], h->stream));
+            h->io.used_pending[h->io.x0_slot] = true;
+        }
+        return ALMPC_OK;
+    };
     if (h->structured) {   // the Riccati active-set solve is the whole step (polish_max_iter caps its working-set changes)
         HIP_TRY(h, launch_riccati(h, 0, nullptr, o.polish_max_iter));
-        return ALMPC_OK;
+        return io_step_done();
     }
     const bool timing = (h->flags & ALMPC_FLAG_TIMING) != 0 && (h->step_count++ % (size_t)h->timing_stride) == 0;
     hipStream_t st = h->stream;
@@ -1848,7 +1923,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         size_t l_step = l_glds - g_lds * sizeof(double);
         if (admm_lds > l_step) l_step = admm_lds;
         l_step += g_lds * sizeof(double);
-        const bool step_fused = admm_pending && h->fuse_step && !h->polish_no_glds && h->nrb == 8 && (h->ks == 30 || h->ks == 32) &&
+        const bool step_fused = admm_pending && h->fuse_step && POLISH_WAVES_GLDS == 8 && !h->polish_no_glds && h->nrb == 8 && (h->ks == 30 || h->ks == 32) &&
                                 fused && l_step <= 160 * 1024;
         if (step_fused) {
             admm_pending = false;
@@ -1912,7 +1987,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         HIP_TRY(h, hipEventRecord(ev[3], st));
         h->ev_used += 1;
     }
-    return ALMPC_OK;
+    return io_step_done();
 }
 
 int almpc_synchronize(almpc_handle* h) {
@@ -2017,6 +2092,24 @@ int almpc_timing_summary(almpc_handle* h, int* steps, double* ms_admm, double* m
     if (ms_polish) *ms_polish = p;
     if (ms_rollout) *ms_rollout = r;
     if (ms_total) *ms_total = t;
+    return ALMPC_OK;
+}
+
+int almpc_timing_samples(almpc_handle* h, int cap, int* count, float* ms_admm, float* ms_polish, float* ms_rollout, float* ms_total) {
+    if (!h || cap < 0) return ALMPC_ERR_INVALID;
+    if (!(h->flags & ALMPC_FLAG_TIMING)) return fail(h, ALMPC_ERR_INVALID, "handle was created without ALMPC_FLAG_TIMING");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const size_t nrec = std::min((size_t)cap, h->ev_used);
+    for (size_t sidx = 0; sidx < nrec; ++sidx) {
+        hipEvent_t* ev = &h->ev[4 * sidx];
+        float f = 0;
+        HIP_TRY(h, hipEventElapsedTime(&f, ev[0], ev[1])); if (ms_admm) ms_admm[sidx] = f;
+        HIP_TRY(h, hipEventElapsedTime(&f, ev[1], ev[2])); if (ms_polish) ms_polish[sidx] = f;
+        HIP_TRY(h, hipEventElapsedTime(&f, ev[2], ev[3])); if (ms_rollout) ms_rollout[sidx] = f;
+        HIP_TRY(h, hipEventElapsedTime(&f, ev[0], ev[3])); if (ms_total) ms_total[sidx] = f;
+    }
+    if (count) *count = (int)h->ev_used;
     return ALMPC_OK;
 }
 
@@ -2165,8 +2258,10 @@ int almpc_advance_plant(almpc_handle* h) {
     if (h->batched) return fail(h, ALMPC_ERR_UNSUPPORTED, "advance_plant: per-instance models have no shared plant (advance the states on the caller's side)");
     HIP_TRY(h, hipSetDevice(h->device));
     const int per_block = 256 / h->n;
+    const double* x0_in = h->dX0;
+    io_release_x0(h);   // (a pinned x0 slot is read once more here; the new states go to the handle's own device buffer)
     hipLaunchKernelGGL(k_advance_plant, dim3((h->batch + per_block - 1) / per_block), dim3(256), (size_t)per_block * h->n * sizeof(double),
-                       h->stream, h->n, h->m, h->N, h->batch, h->dA, h->dB, h->dU, h->dX0);
+                       h->stream, h->n, h->m, h->N, h->batch, h->dA, h->dB, h->dU, x0_in, h->dX0);
     HIP_TRY(h, hipGetLastError());
     return ALMPC_OK;
 }
@@ -2203,3 +2298,5 @@ int almpc_dbg_stamps_fetch(almpc_handle* h, long long* out, int waves) {
 #endif
 
 }  // extern "C"
+
+#include "almpc_hostio.inc.h"

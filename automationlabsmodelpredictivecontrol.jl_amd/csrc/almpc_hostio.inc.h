@@ -1,0 +1,357 @@
+// almpc_hostio.inc.h -- the host-facing side of a step (included by almpc_api.hip after the handle and its entry points).
+//
+// The reference's per-step contract is host in / host out: update_initialization!(C, x0) takes a host vector
+// (src/main/computation_mpc.jl:17-29), calculate!(C) leaves x, e_x, u, e_u in host matrices (src/main/computation_mpc.jl:50-53),
+// and what a receding-horizon caller applies is u[:,1].  Through almpc_update_initialization / almpc_get_results that is a
+// synchronous pageable upload and seven synchronous pageable read-backs per step (32 MB at the benchmark shape).  Here:
+//   * pinned staging owned by the handle, rings of IO_DEPTH slots;
+//   * x0 is not copied at all: the step's kernels read it from the pinned slot over the link (393 KB, requested in the ADMM
+//     prologue under the 230 KB of operands every workgroup pulls anyway), so an update is a host memcpy and a pointer flip -- no
+//     HIP call;
+//   * the small results (first inputs, status, iteration counts: 147 KB) are written by one pack kernel straight into the pinned
+//     slot, followed by one event: the next step starts right behind it;
+//   * the large arrays go out on a copy-out stream tied to the compute stream by events, so their read-back of step k runs under
+//     the kernel of step k+1 only as far as the result buffers allow (the next step waits for it before overwriting them);
+//   * the first input of every instance (m doubles: 131 KB at the benchmark shape instead of 32 MB) as a result of its own;
+//   * zero-copy views of the pinned slots for callers that can read them in place (Julia: unsafe_wrap).
+// And one process driving several GPUs (almpc_group_*): one handle per device on its contiguous shard of the batch, every entry
+// point fans out over the handles without a cross-device synchronisation on the step path (SURVEY.md section 8b proposal:
+// almpc_create(..., n_devices, device_ids, ...); section 8e: instances never interact).
+
+namespace {
+
+// u0[i][a] = u[i][0][a] and copies of the three per-instance words of the step: everything small a host caller wants after a step,
+// packed into the slot's own buffers so that the next step (which rewrites u / status / iters) can start while they travel
+__global__ __launch_bounds__(256) void k_pack_step_summary(int batch, int m, int N, const double* u, const int32_t* status,
+                                                           const int32_t* iters, const int32_t* piters, double* u0, int32_t* ints) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < (long)batch * m) u0[t] = u[(t / m) * (long)m * N + (t % m)];
+    if (t < batch) {
+        ints[t] = status[t];
+        ints[(long)batch + t] = iters ? iters[t] : 0;
+        ints[2L * batch + t] = piters[t];
+    }
+}
+
+template <typename T>
+hipError_t pinned(T** p, size_t count) {
+    return hipHostMalloc(reinterpret_cast<void**>(p), count * sizeof(T), hipHostMallocDefault);
+}
+
+int io_init(almpc_handle* h) {
+    almpc_handle::Io& io = h->io;
+    if (io.ready) return ALMPC_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamCreateWithFlags(&io.s_out, hipStreamNonBlocking));
+    const size_t b = (size_t)h->batch;
+    for (int s = 0; s < almpc_handle::IO_DEPTH; ++s) {
+        HIP_TRY(h, pinned(&io.hX0[s], b * h->n));
+        HIP_TRY(h, pinned(&io.hU0[s], b * h->m));
+        HIP_TRY(h, pinned(&io.hInts[s], 3 * b));
+        // the device's view of the pinned slots (kernels read x0 from / write the step summary to host memory directly)
+        HIP_TRY(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&io.dX0[s]), io.hX0[s], 0));
+        HIP_TRY(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&io.dU0[s]), io.hU0[s], 0));
+        HIP_TRY(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&io.dInts[s]), io.hInts[s], 0));
+        for (hipEvent_t* e : {&io.ev_used[s], &io.ev_packed[s], &io.ev_done[s]})
+            HIP_TRY(h, hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+    io.ready = true;
+    return ALMPC_OK;
+}
+
+void io_free(almpc_handle* h) {
+    almpc_handle::Io& io = h->io;
+    if (io.dX0_own) h->dX0 = io.dX0_own;
+    if (io.s_out) (void)hipStreamSynchronize(io.s_out);
+    for (int s = 0; s < almpc_handle::IO_DEPTH; ++s) {
+        for (void* p : {(void*)io.hX0[s], (void*)io.hX[s], (void*)io.hEx[s], (void*)io.hU[s], (void*)io.hEu[s], (void*)io.hU0[s], (void*)io.hInts[s]})
+            if (p) (void)hipHostFree(p);
+        for (hipEvent_t e : {io.ev_used[s], io.ev_packed[s], io.ev_done[s]})
+            if (e) (void)hipEventDestroy(e);
+    }
+    if (io.s_out) (void)hipStreamDestroy(io.s_out);
+    io = almpc_handle::Io();
+}
+
+// Wait for an event the way almpc_synchronize waits for the stream: poll first (a blocking wake-up costs milliseconds on this pool)
+hipError_t event_wait(hipEvent_t e) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipEventQuery(e);
+        if (q != hipErrorNotReady) return q;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
+    }
+    return hipEventSynchronize(e);
+}
+
+}  // namespace
+
+extern "C" {
+
+int almpc_update_initialization_async(almpc_handle* h, const double* x0) {
+    if (!h || !x0) return h ? fail(h, ALMPC_ERR_INVALID, "update_initialization_async: null x0") : ALMPC_ERR_INVALID;
+    { const int rc = io_init(h); if (rc != ALMPC_OK) return rc; }
+    almpc_handle::Io& io = h->io;
+    const int s = (int)(io.x0_count % almpc_handle::IO_DEPTH);
+    // the slot is free once the last step that read it has finished (normally long ago: IO_DEPTH - 1 steps may be in flight)
+    if (io.used_pending[s]) {
+        HIP_TRY(h, hipSetDevice(h->device));
+        HIP_TRY(h, event_wait(io.ev_used[s]));
+        io.used_pending[s] = false;
+    }
+    std::memcpy(io.hX0[s], x0, (size_t)h->batch * h->n * sizeof(double));
+    if (io.x0_slot < 0) io.dX0_own = h->dX0;   // (the handle's own buffer is kept and freed with the handle)
+    h->dX0 = io.dX0[s];                        // kernels enqueued from here on read this slot, in place, over the link
+    io.x0_slot = s;
+    io.x0_count += 1;
+    return ALMPC_OK;
+}
+
+int almpc_get_results_async(almpc_handle* h, uint32_t want) {
+    if (!h) return ALMPC_ERR_INVALID;
+    if (!h->designed) return fail(h, ALMPC_ERR_NOT_DESIGNED, "get_results_async before design");
+    if (want == 0 || (want & ~(uint32_t)ALMPC_WANT_ALL)) return fail(h, ALMPC_ERR_INVALID, "get_results_async: want must be a non-empty mask of ALMPC_WANT_*");
+    { const int rc = io_init(h); if (rc != ALMPC_OK) return rc; }
+    almpc_handle::Io& io = h->io;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const long t = io.next_ticket;
+    const int s = (int)(t % almpc_handle::IO_DEPTH);
+    const size_t b = (size_t)h->batch, xs = b * h->n * (h->N + 1), us = b * h->nz;
+    // (the pinned slot of ticket t - IO_DEPTH is overwritten from here on: its views are valid until this call, as the header says)
+    const bool big = (want & (ALMPC_WANT_X | ALMPC_WANT_E_X | ALMPC_WANT_U | ALMPC_WANT_E_U)) != 0;
+    if (io.big_copy_pending && big) {   // two read-backs from the same result buffers in a row (no step between them): keep order simple
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, io.ev_done[io.big_copy_slot], 0));
+        io.big_copy_pending = false;
+    }
+    if ((want & ALMPC_WANT_X) && !io.hX[s]) HIP_TRY(h, pinned(&io.hX[s], xs));
+    if ((want & ALMPC_WANT_E_X) && !io.hEx[s]) HIP_TRY(h, pinned(&io.hEx[s], xs));
+    if ((want & ALMPC_WANT_U) && !io.hU[s]) HIP_TRY(h, pinned(&io.hU[s], us));
+    if ((want & ALMPC_WANT_E_U) && !io.hEu[s]) HIP_TRY(h, pinned(&io.hEu[s], us));
+    const bool small = (want & (ALMPC_WANT_FIRST_INPUT | ALMPC_WANT_STATUS | ALMPC_WANT_ITERS | ALMPC_WANT_POLISH_ITERS)) != 0;
+    if (small) {   // straight into the pinned slot: no copy, the next step starts right behind this kernel
+        const long cnt = std::max((long)b * h->m, (long)b);
+        hipLaunchKernelGGL(k_pack_step_summary, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, h->batch, h->m, h->N,
+                           (const double*)h->dU, (const int32_t*)h->dStatus, (const int32_t*)h->dIters, (const int32_t*)h->dPiters,
+                           io.dU0[s], io.dInts[s]);
+        HIP_TRY(h, hipGetLastError());
+    }
+    if (big) {
+        HIP_TRY(h, hipEventRecord(io.ev_packed[s], h->stream));
+        HIP_TRY(h, hipStreamWaitEvent(io.s_out, io.ev_packed[s], 0));
+        if (want & ALMPC_WANT_U) HIP_TRY(h, hipMemcpyAsync(io.hU[s], h->dU, us * sizeof(double), hipMemcpyDeviceToHost, io.s_out));
+        if (want & ALMPC_WANT_E_U) HIP_TRY(h, hipMemcpyAsync(io.hEu[s], h->dEu, us * sizeof(double), hipMemcpyDeviceToHost, io.s_out));
+        if (want & ALMPC_WANT_X) HIP_TRY(h, hipMemcpyAsync(io.hX[s], h->dX, xs * sizeof(double), hipMemcpyDeviceToHost, io.s_out));
+        if (want & ALMPC_WANT_E_X) HIP_TRY(h, hipMemcpyAsync(io.hEx[s], h->dEx, xs * sizeof(double), hipMemcpyDeviceToHost, io.s_out));
+        HIP_TRY(h, hipEventRecord(io.ev_done[s], io.s_out));   // (after the pack kernel as well: s_out waited for the compute stream)
+    } else {
+        HIP_TRY(h, hipEventRecord(io.ev_done[s], h->stream));
+    }
+    if (big) { io.big_copy_pending = true; io.big_copy_slot = s; }
+    io.want[s] = want;
+    io.ticket[s] = t;
+    io.next_ticket += 1;
+    return (int)(t & 0x3fffffff);
+}
+
+static int io_slot_of(almpc_handle* h, int ticket, const char* who) {
+    almpc_handle::Io& io = h->io;
+    if (!io.ready || ticket < 0) { fail(h, ALMPC_ERR_INVALID, std::string(who) + ": no such ticket"); return -1; }
+    for (int s = 0; s < almpc_handle::IO_DEPTH; ++s)
+        if (io.ticket[s] >= 0 && (int)(io.ticket[s] & 0x3fffffff) == ticket) return s;
+    fail(h, ALMPC_ERR_INVALID, std::string(who) + ": ticket is not outstanding (only the last IO_DEPTH requests are kept)");
+    return -1;
+}
+
+int almpc_get_results_wait(almpc_handle* h, int ticket, double* x, double* e_x, double* u, double* e_u, double* u0, int32_t* status,
+                           int32_t* iters, int32_t* polish_iters) {
+    if (!h) return ALMPC_ERR_INVALID;
+    const int s = io_slot_of(h, ticket, "get_results_wait");
+    if (s < 0) return ALMPC_ERR_INVALID;
+    almpc_handle::Io& io = h->io;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, event_wait(io.ev_done[s]));
+    const uint32_t w = io.want[s];
+    const size_t b = (size_t)h->batch, xs = b * h->n * (h->N + 1), us = b * h->nz;
+    auto need = [&](const void* p, uint32_t bit) { return p != nullptr && !(w & bit); };
+    if (need(x, ALMPC_WANT_X) || need(e_x, ALMPC_WANT_E_X) || need(u, ALMPC_WANT_U) || need(e_u, ALMPC_WANT_E_U) ||
+        need(u0, ALMPC_WANT_FIRST_INPUT) || need(status, ALMPC_WANT_STATUS) || need(iters, ALMPC_WANT_ITERS) ||
+        need(polish_iters, ALMPC_WANT_POLISH_ITERS))
+        return fail(h, ALMPC_ERR_INVALID, "get_results_wait: a result was asked for that the request of this ticket did not include");
+    if (x) std::memcpy(x, io.hX[s], xs * sizeof(double));
+    if (e_x) std::memcpy(e_x, io.hEx[s], xs * sizeof(double));
+    if (u) std::memcpy(u, io.hU[s], us * sizeof(double));
+    if (e_u) std::memcpy(e_u, io.hEu[s], us * sizeof(double));
+    if (u0) std::memcpy(u0, io.hU0[s], b * h->m * sizeof(double));
+    if (status) std::memcpy(status, io.hInts[s], b * sizeof(int32_t));
+    if (iters) std::memcpy(iters, io.hInts[s] + b, b * sizeof(int32_t));
+    if (polish_iters) std::memcpy(polish_iters, io.hInts[s] + 2 * b, b * sizeof(int32_t));
+    return ALMPC_OK;
+}
+
+int almpc_host_results(almpc_handle* h, int ticket, const double** x, const double** e_x, const double** u, const double** e_u,
+                       const double** u0, const int32_t** status, const int32_t** iters, const int32_t** polish_iters) {
+    if (!h) return ALMPC_ERR_INVALID;
+    const int s = io_slot_of(h, ticket, "host_results");
+    if (s < 0) return ALMPC_ERR_INVALID;
+    almpc_handle::Io& io = h->io;
+    const uint32_t w = io.want[s];
+    const size_t b = (size_t)h->batch;
+    if (x) *x = (w & ALMPC_WANT_X) ? io.hX[s] : nullptr;
+    if (e_x) *e_x = (w & ALMPC_WANT_E_X) ? io.hEx[s] : nullptr;
+    if (u) *u = (w & ALMPC_WANT_U) ? io.hU[s] : nullptr;
+    if (e_u) *e_u = (w & ALMPC_WANT_E_U) ? io.hEu[s] : nullptr;
+    if (u0) *u0 = (w & ALMPC_WANT_FIRST_INPUT) ? io.hU0[s] : nullptr;
+    if (status) *status = (w & ALMPC_WANT_STATUS) ? io.hInts[s] : nullptr;
+    if (iters) *iters = (w & ALMPC_WANT_ITERS) ? io.hInts[s] + b : nullptr;
+    if (polish_iters) *polish_iters = (w & ALMPC_WANT_POLISH_ITERS) ? io.hInts[s] + 2 * b : nullptr;
+    return ALMPC_OK;
+}
+
+int almpc_get_first_input(almpc_handle* h, double* u0) {
+    if (!h || !u0) return h ? fail(h, ALMPC_ERR_INVALID, "get_first_input: null u0") : ALMPC_ERR_INVALID;
+    const int t = almpc_get_results_async(h, ALMPC_WANT_FIRST_INPUT);
+    if (t < 0) return t;
+    return almpc_get_results_wait(h, t, nullptr, nullptr, nullptr, nullptr, u0, nullptr, nullptr, nullptr);
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// One process, several GPUs
+// ------------------------------------------------------------------------------------------------
+struct almpc_group {
+    int n = 0, m = 0, N = 0, batch = 0;
+    std::vector<almpc_handle*> hs;
+    std::vector<int> first, count;   // shard of handle i: instances [first, first + count)
+    std::vector<int> tickets;
+    std::string err;
+};
+
+namespace {
+int gfail(almpc_group* g, int code, int i) {
+    if (g) g->err = "handle " + std::to_string(i) + ": " + (g->hs[i] ? g->hs[i]->err : std::string("null"));
+    return code;
+}
+}  // namespace
+
+extern "C" {
+
+int almpc_group_create(almpc_group** out, int n, int m, int N, int batch, int n_devices, const int* device_ids, uint32_t flags) {
+    if (!out) return ALMPC_ERR_INVALID;
+    *out = nullptr;
+    if (n_devices < 1 || !device_ids || batch < n_devices) return ALMPC_ERR_INVALID;
+    almpc_group* g = new almpc_group();
+    g->n = n; g->m = m; g->N = N; g->batch = batch;
+    for (int i = 0; i < n_devices; ++i) {   // contiguous shards, sizes differing by at most one (the rule of sharding.shard_range)
+        const int base = batch / n_devices, rem = batch % n_devices;
+        const int cnt = base + (i < rem ? 1 : 0), fst = i * base + std::min(i, rem);
+        almpc_handle* h = nullptr;
+        const int rc = almpc_create(&h, n, m, N, cnt, device_ids[i], flags);
+        if (rc != ALMPC_OK) {
+            for (almpc_handle* q : g->hs) almpc_destroy(q);
+            delete g;
+            return rc;
+        }
+        g->hs.push_back(h); g->first.push_back(fst); g->count.push_back(cnt);
+    }
+    g->tickets.assign(n_devices, -1);
+    *out = g;
+    return ALMPC_OK;
+}
+
+void almpc_group_destroy(almpc_group* g) {
+    if (!g) return;
+    for (almpc_handle* h : g->hs) almpc_destroy(h);
+    delete g;
+}
+
+const char* almpc_group_last_error(const almpc_group* g) { return g ? g->err.c_str() : "null group"; }
+int almpc_group_size(const almpc_group* g) { return g ? (int)g->hs.size() : 0; }
+almpc_handle* almpc_group_handle(almpc_group* g, int i) { return (g && i >= 0 && i < (int)g->hs.size()) ? g->hs[i] : nullptr; }
+
+int almpc_group_shard(const almpc_group* g, int i, int* first, int* count) {
+    if (!g || i < 0 || i >= (int)g->hs.size()) return ALMPC_ERR_INVALID;
+    if (first) *first = g->first[i];
+    if (count) *count = g->count[i];
+    return ALMPC_OK;
+}
+
+int almpc_group_design_shared(almpc_group* g, const double* A, const double* B, const double* Q, const double* R, const double* S,
+                              const double* P, const double* umin, const double* umax, const double* xmin, const double* xmax,
+                              double rho, double sigma) {
+    if (!g) return ALMPC_ERR_INVALID;
+    for (size_t i = 0; i < g->hs.size(); ++i) {
+        const int rc = almpc_design_shared(g->hs[i], A, B, Q, R, S, P, umin, umax, xmin, xmax, rho, sigma);
+        if (rc != ALMPC_OK) return gfail(g, rc, (int)i);
+    }
+    return ALMPC_OK;
+}
+
+int almpc_group_set_reference(almpc_group* g, const double* xref, const double* uref, int per_instance) {
+    if (!g || !xref || !uref) return ALMPC_ERR_INVALID;
+    for (size_t i = 0; i < g->hs.size(); ++i) {
+        const size_t ox = per_instance ? (size_t)g->first[i] * g->n * (g->N + 1) : 0, ou = per_instance ? (size_t)g->first[i] * g->m * g->N : 0;
+        const int rc = almpc_set_reference(g->hs[i], xref + ox, uref + ou, per_instance);
+        if (rc != ALMPC_OK) return gfail(g, rc, (int)i);
+    }
+    return ALMPC_OK;
+}
+
+// x0 [batch][n], host: every device's upload is enqueued (pinned staging, copy-in streams) before any of them is waited for
+int almpc_group_update_initialization(almpc_group* g, const double* x0) {
+    if (!g || !x0) return ALMPC_ERR_INVALID;
+    for (size_t i = 0; i < g->hs.size(); ++i) {
+        const int rc = almpc_update_initialization_async(g->hs[i], x0 + (size_t)g->first[i] * g->n);
+        if (rc != ALMPC_OK) return gfail(g, rc, (int)i);
+    }
+    return ALMPC_OK;
+}
+
+int almpc_group_calculate_async(almpc_group* g, const almpc_opts* opts) {
+    if (!g) return ALMPC_ERR_INVALID;
+    for (size_t i = 0; i < g->hs.size(); ++i) {
+        const int rc = almpc_calculate_async(g->hs[i], opts);
+        if (rc != ALMPC_OK) return gfail(g, rc, (int)i);
+    }
+    return ALMPC_OK;
+}
+
+int almpc_group_synchronize(almpc_group* g) {
+    if (!g) return ALMPC_ERR_INVALID;
+    for (size_t i = 0; i < g->hs.size(); ++i) {
+        const int rc = almpc_synchronize(g->hs[i]);
+        if (rc != ALMPC_OK) return gfail(g, rc, (int)i);
+    }
+    return ALMPC_OK;
+}
+
+int almpc_group_calculate(almpc_group* g, const almpc_opts* opts) {
+    const int rc = almpc_group_calculate_async(g, opts);
+    return rc != ALMPC_OK ? rc : almpc_group_synchronize(g);
+}
+
+// Results of the whole batch into the caller's arrays (layouts of almpc_get_results; u0 [batch][m]; any pointer may be NULL): the
+// read-backs of all devices are in flight together, each into its slice.
+int almpc_group_get_results(almpc_group* g, double* x, double* e_x, double* u, double* e_u, double* u0, int32_t* status, int32_t* iters,
+                            int32_t* polish_iters) {
+    if (!g) return ALMPC_ERR_INVALID;
+    const uint32_t want = (x ? ALMPC_WANT_X : 0) | (e_x ? ALMPC_WANT_E_X : 0) | (u ? ALMPC_WANT_U : 0) | (e_u ? ALMPC_WANT_E_U : 0) |
+                          (u0 ? ALMPC_WANT_FIRST_INPUT : 0) | (status ? ALMPC_WANT_STATUS : 0) | (iters ? ALMPC_WANT_ITERS : 0) |
+                          (polish_iters ? ALMPC_WANT_POLISH_ITERS : 0);
+    if (!want) return ALMPC_OK;
+    for (size_t i = 0; i < g->hs.size(); ++i) {
+        g->tickets[i] = almpc_get_results_async(g->hs[i], want);
+        if (g->tickets[i] < 0) return gfail(g, g->tickets[i], (int)i);
+    }
+    for (size_t i = 0; i < g->hs.size(); ++i) {
+        const size_t f = (size_t)g->first[i], xs = (size_t)g->n * (g->N + 1), us = (size_t)g->m * g->N;
+        const int rc = almpc_get_results_wait(g->hs[i], g->tickets[i], x ? x + f * xs : nullptr, e_x ? e_x + f * xs : nullptr,
+                                              u ? u + f * us : nullptr, e_u ? e_u + f * us : nullptr, u0 ? u0 + f * g->m : nullptr,
+                                              status ? status + f : nullptr, iters ? iters + f : nullptr,
+                                              polish_iters ? polish_iters + f : nullptr);
+        if (rc != ALMPC_OK) return gfail(g, rc, (int)i);
+    }
+    return ALMPC_OK;
+}
+
+}  // extern "C"

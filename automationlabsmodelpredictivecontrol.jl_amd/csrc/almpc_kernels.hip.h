@@ -702,7 +702,10 @@ __device__ __forceinline__ void roll_run(const double (&cu)[SMX], const double (
 // instances from a queue (hard ones first, see k_admm) until it is empty: every row of G an update needs is an LDS
 // read instead of an L2 round trip, which is what the dependent chain of an active-set change was waiting on.
 constexpr int POLISH_WAVES = 4;
-constexpr int POLISH_WAVES_GLDS = 8;
+#ifndef ALMPC_EXP_POLISH_WAVES
+#define ALMPC_EXP_POLISH_WAVES 8
+#endif
+constexpr int POLISH_WAVES_GLDS = ALMPC_EXP_POLISH_WAVES;   // (experiments: -DALMPC_EXP_POLISH_WAVES=12|16 on the two-kernel path)
 // LDS per wave (doubles): row buffer 128 | two position buffers 64 | row-index buffer (64 ints); the trajectory
 // buffer of the fused rollout lies over the same words (the active-set state is dead by then)
 constexpr int POLISH_LDS_MIN_PER_WAVE = 128 + 64 + 64 + 32;
@@ -1627,7 +1630,8 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
 }
 
 template <bool GLDS>
-__global__ __launch_bounds__(64 * (GLDS ? POLISH_WAVES_GLDS : POLISH_WAVES)) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ __launch_bounds__(64 * (GLDS ? POLISH_WAVES_GLDS : POLISH_WAVES))
+__attribute__((amdgpu_waves_per_eu(GLDS ? POLISH_WAVES_GLDS / 4 : 2, GLDS ? POLISH_WAVES_GLDS / 4 : 2)))
 void k_polish(PolishParams p_arg) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     polish_body<GLDS, false, 0>(p_arg, smem);
@@ -1651,8 +1655,8 @@ constexpr int STEP_KOFF = (int)((sizeof(AdmmParams) + 7) & ~size_t(7));  // Poli
 template <int NRB, int KS>
 __global__ __launch_bounds__(64 * NRB) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_step_fused(AdmmParams ap, PolishParams pp) {
-    static_assert(NRB == POLISH_WAVES_GLDS, "the polish queue is written for 8 waves");
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    if constexpr (NRB != POLISH_WAVES_GLDS) return;   // (experimental builds with another polish width have no fused step)
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int gs = (pp.nz + 1) & ~1, hs = gs / 2;  // rows of G packed to stride gs in LDS (as polish_body<true, ...> reads them)
     auto request_g = [&]() __attribute__((always_inline)) {
@@ -1755,13 +1759,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_rollout(RolloutParams p) {
 // Closed loop on the device: x0 <- A x0 + B u[:,1] for every instance (the plant the controller was designed for), so that a
 // receding-horizon run needs no host round trip between steps.  One thread per (instance, state).
 __global__ __launch_bounds__(256) void k_advance_plant(int n, int m, int N, int batch, const double* A, const double* B,
-                                                      const double* u, double* x0) {
+                                                      const double* u, const double* x0_in, double* x0) {
     extern __shared__ __attribute__((aligned(16))) double smem[];  // old x0 of the block's instances
     const int per_block = blockDim.x / n;  // instances per block
     const int li = threadIdx.x / n, i = threadIdx.x % n;
     const int inst = blockIdx.x * per_block + li;
     const bool ok = li < per_block && inst < batch;
-    if (ok) smem[li * n + i] = x0[(size_t)inst * n + i];
+    if (ok) smem[li * n + i] = x0_in[(size_t)inst * n + i];
     __syncthreads();
     if (!ok) return;
     double s = 0.0;

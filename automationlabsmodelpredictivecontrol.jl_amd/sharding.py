@@ -80,6 +80,38 @@ class Ranks:
             self.dist = None
 
 
+def visible_gpu_count() -> int:
+    """GPUs a process started from here would see, WITHOUT initialising HIP in this process (a launcher must stay free to start
+    its ranks): hipGetDeviceCount in a short-lived child process (it honours HIP_/ROCR_VISIBLE_DEVICES and the container's device
+    cgroup, which a walk over /sys/class/kfd would not); the kfd topology is the fallback when no child can be started."""
+    import subprocess
+    import sys
+    code = ("import ctypes\n"
+            "n = ctypes.c_int(0)\n"
+            "try:\n"
+            "    lib = ctypes.CDLL('libamdhip64.so')\n"
+            "    rc = lib.hipGetDeviceCount(ctypes.byref(n))\n"
+            "    print(n.value if rc == 0 else 0)\n"
+            "except OSError:\n"
+            "    print(0)\n")
+    try:
+        out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=120, text=True)
+        return max(0, int(out.stdout.strip().splitlines()[-1]))
+    except (OSError, ValueError, IndexError, subprocess.SubprocessError):
+        pass
+    count = 0
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(base):
+            with open(os.path.join(base, node, "properties")) as f:
+                props = dict(ln.split()[:2] for ln in f if len(ln.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                count += 1
+    except (OSError, ValueError):
+        return 0
+    return count
+
+
 def aggregate_rate(units_per_rank: float, steps: int, elapsed_max: float, world: int) -> float:
     """Whole-job throughput: units all ranks processed / max-over-ranks time (weak scaling)."""
     return world * units_per_rank * steps / elapsed_max

@@ -331,6 +331,71 @@ int almpc_advance_plant(almpc_handle* h);
 int almpc_get_results(almpc_handle* h, double* x, double* e_x, double* u, double* e_u,
                       int32_t* status, int32_t* iters, int32_t* polish_iters);
 
+/*
+ * Host-facing step path.  The reference's per-step contract is host in / host out (update_initialization!(C, x0),
+ * src/main/computation_mpc.jl:17-29; calculate! leaves x, e_x, u, e_u in host matrices, src/main/computation_mpc.jl:50-53), and a
+ * receding-horizon caller applies u[:,1] only.  These entry points move exactly what is asked for through pinned staging owned by
+ * the handle, on copy streams of their own, so that the transfers of one step run under the kernel of the next:
+ *   almpc_update_initialization_async   x0 [batch][n] (host): copied into a pinned slot of the handle, which the kernels of the next
+ *                                       almpc_calculate(_async) read in place over the link (393 KB at the benchmark shape, requested
+ *                                       under the operands every workgroup loads anyway): no HIP call, no device-side copy.  Returns
+ *                                       at once; blocks only if both slots are still being read (two steps in flight).
+ *   almpc_get_results_async             asks for the results of the LAST enqueued step: `want` = mask of ALMPC_WANT_*.  The small
+ *                                       ones (first inputs, status, iteration counts) are written by one pack kernel straight into
+ *                                       the pinned slot, so the next step may start right behind it; x / e_x / u / e_u go out on a
+ *                                       copy stream straight from the result buffers (the next step waits for that read-back).
+ *                                       Returns a ticket >= 0 (or a negative almpc_status); the last 2 tickets are kept.
+ *   almpc_get_results_wait              blocks until the ticket's read-back has landed, then copies the non-NULL arrays out of the
+ *                                       pinned slot (layouts of almpc_get_results; u0 [batch][m] = u[:,1] of every instance).
+ *   almpc_host_results                  zero-copy: pointers into the pinned slot of a ticket (NULL for arrays that were not asked
+ *                                       for); valid after almpc_get_results_wait(h, ticket, NULL...) until 2 more requests.
+ *   almpc_get_first_input               synchronous convenience: u0 [batch][m] of the last step (131 KB at the benchmark shape
+ *                                       instead of the 32 MB of almpc_get_results).
+ */
+#define ALMPC_WANT_X 0x01u
+#define ALMPC_WANT_E_X 0x02u
+#define ALMPC_WANT_U 0x04u
+#define ALMPC_WANT_E_U 0x08u
+#define ALMPC_WANT_STATUS 0x10u
+#define ALMPC_WANT_ITERS 0x20u
+#define ALMPC_WANT_POLISH_ITERS 0x40u
+#define ALMPC_WANT_FIRST_INPUT 0x80u
+#define ALMPC_WANT_ALL 0xFFu
+int almpc_update_initialization_async(almpc_handle* h, const double* x0);
+int almpc_get_results_async(almpc_handle* h, uint32_t want);
+int almpc_get_results_wait(almpc_handle* h, int ticket, double* x, double* e_x, double* u, double* e_u, double* u0,
+                           int32_t* status, int32_t* iters, int32_t* polish_iters);
+int almpc_host_results(almpc_handle* h, int ticket, const double** x, const double** e_x, const double** u, const double** e_u,
+                       const double** u0, const int32_t** status, const int32_t** iters, const int32_t** polish_iters);
+int almpc_get_first_input(almpc_handle* h, double* u0);
+
+/*
+ * One process, several GPUs (almpc_create(..., n_devices, device_ids, ...); the reference API is one
+ * process, one call: proceed_controller, src/main/main_mpc.jl:22-53).  A group is one handle per entry of device_ids (a device may
+ * appear more than once), handle i on the contiguous shard [first_i, first_i + count_i) of the batch (sizes differ by at most
+ * one); instances never interact, so a group call fans out over the handles and nothing on the step path synchronises across
+ * devices: almpc_group_calculate_async enqueues on every device before almpc_group_synchronize waits for any.  Host arrays are
+ * those of the single-handle calls with `batch` = the whole batch.  Options that are per handle (almpc_set_rho_profile,
+ * almpc_set_terminal_equality, ...) are set through almpc_group_handle(g, i) before the design.
+ */
+typedef struct almpc_group almpc_group;
+int almpc_group_create(almpc_group** out, int n, int m, int N, int batch, int n_devices, const int* device_ids, uint32_t flags);
+void almpc_group_destroy(almpc_group* g);
+const char* almpc_group_last_error(const almpc_group* g);
+int almpc_group_size(const almpc_group* g);
+almpc_handle* almpc_group_handle(almpc_group* g, int i);
+int almpc_group_shard(const almpc_group* g, int i, int* first, int* count);
+int almpc_group_design_shared(almpc_group* g, const double* A, const double* B, const double* Q, const double* R, const double* S,
+                              const double* P, const double* umin, const double* umax, const double* xmin, const double* xmax,
+                              double rho, double sigma);
+int almpc_group_set_reference(almpc_group* g, const double* xref, const double* uref, int per_instance);
+int almpc_group_update_initialization(almpc_group* g, const double* x0);
+int almpc_group_calculate(almpc_group* g, const almpc_opts* opts);
+int almpc_group_calculate_async(almpc_group* g, const almpc_opts* opts);
+int almpc_group_synchronize(almpc_group* g);
+int almpc_group_get_results(almpc_group* g, double* x, double* e_x, double* u, double* e_u, double* u0, int32_t* status,
+                            int32_t* iters, int32_t* polish_iters);
+
 /* Design data for parity tests: H nz*nz, F nz*n (both unscaled, column-major), P n*n, d nz. */
 int almpc_get_design(almpc_handle* h, double* H, double* F, double* P, double* d);
 
@@ -360,6 +425,10 @@ int almpc_timing_reset(almpc_handle* h, int reserve_steps);
 int almpc_timing_set_stride(almpc_handle* h, int every);
 int almpc_timing_summary(almpc_handle* h, int* steps, double* ms_admm, double* ms_polish,
                          double* ms_rollout, double* ms_total);
+/* The individual samples behind almpc_timing_summary: per recorded step its four stage times (arrays of `cap` floats, any may be
+ * NULL; the first min(cap, *count) entries are filled); *count = steps recorded since the reset.  Synchronises the stream. */
+int almpc_timing_samples(almpc_handle* h, int cap, int* count, float* ms_admm, float* ms_polish, float* ms_rollout,
+                         float* ms_total);
 
 /*
  * Discrete algebraic Riccati solution P of  A'PA - P - A'PB (R + B'PB)^-1 B'PA + Q = 0  (host, n x n): what

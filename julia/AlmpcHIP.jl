@@ -13,7 +13,10 @@ export hip_solver_def, HipModeler, AlmpcOpts, design_hip, terminal_weight, set_s
        _model_predictive_control_computation, comm_unique_id, comm_init!, comm_summary, comm_allgather_first_input,
        calculate_async!, synchronize!, relin_step_async!, advance_plant!, update_initialization_device!, device_results, set_step_fusion!,
        set_structured_fallback!, sqp_skipped, design_instance, gradient_instance, design_ltv!, fnn_linearize, dare, default_opts,
-       get_timing, timing_reset!, timing_set_stride!, timing_summary, relin_timing, debug_poison_lds!
+       get_timing, timing_reset!, timing_set_stride!, timing_summary, timing_samples, relin_timing, debug_poison_lds!,
+       update_initialization_async!, results_async, results_wait!, host_results, first_input, first_input!,
+       HipGroup, group_design_hip, group_handle, group_shard, group_update_initialization!, group_calculate!, group_calculate_async!,
+       group_synchronize!, group_read_results!
 
 const libalmpc = get(ENV, "ALMPC_LIB", "libalmpc.so")
 
@@ -176,19 +179,102 @@ function update_initialization!(mod::HipModeler, x0::VecOrMat{Float64})
     check(mod.handle, ccall((:almpc_update_initialization, libalmpc), Cint, (Ptr{Cvoid}, Ptr{Float64}), mod.handle, x0))
 end
 
-# calculate!(C): fills u, e_u (m x N x batch) and x, e_x (n x (N+1) x batch) in place (src/main/computation_mpc.jl:38-55)
-function calculate!(mod::HipModeler, x::Array{Float64}, e_x::Array{Float64}, u::Array{Float64}, e_u::Array{Float64})
-    o = Ref(mod.opts)
-    check(mod.handle, ccall((:almpc_calculate, libalmpc), Cint, (Ptr{Cvoid}, Ref{AlmpcOpts}), mod.handle, o))
-    status = Vector{Int32}(undef, mod.batch)
-    check(mod.handle, ccall((:almpc_get_results, libalmpc), Cint,
-                            (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}),
-                            mod.handle, x, e_x, u, e_u, status, C_NULL, C_NULL))
+# The library writes batch * n * (N+1) / batch * m * N doubles through these pointers: anything shorter would be a heap overflow
+# (the reference allocates ONE instance's matrices, src/sub/design_mpc.jl:515-529; a batched caller must allocate the batch).
+function check_result_sizes(mod::HipModeler, x, e_x, u, e_u)
+    nx, nu = mod.n * (mod.N + 1) * mod.batch, mod.m * mod.N * mod.batch
+    for (name, a, want) in (("x", x, nx), ("e_x", e_x, nx), ("u", u, nu), ("e_u", e_u, nu))
+        a === nothing && continue
+        length(a) == want || throw(DimensionMismatch("$name holds $(length(a)) values, the handle writes $want (n or m x horizon x batch = $(mod.batch))"))
+    end
+end
+
+function throw_on_status(status)
     # the reference never checks the solver status and lets JuMP.value throw when there is no primal (src/main/computation_mpc.jl:41-53)
     any(==(2), status) && error("calculate!: non-finite values in at least one instance (no solution to read)")
     any(==(3), status) && error("calculate!: infeasible problem in at least one instance (state box / terminal equality)")
     return status
 end
+
+# calculate!(C): fills u, e_u (m x N x batch) and x, e_x (n x (N+1) x batch) in place (src/main/computation_mpc.jl:38-55).
+# first_move_only = true: only u[:, 1, :] is brought back (m x batch values, written into the first stage of `u`; 131 KB instead of
+# 32 MB at the benchmark shape) -- what a receding-horizon caller applies; x, e_x, e_u are left untouched.
+function calculate!(mod::HipModeler, x::Array{Float64}, e_x::Array{Float64}, u::Array{Float64}, e_u::Array{Float64};
+                    first_move_only::Bool = false)
+    check_result_sizes(mod, x, e_x, u, e_u)
+    o = Ref(mod.opts)
+    status = Vector{Int32}(undef, mod.batch)
+    if first_move_only
+        check(mod.handle, ccall((:almpc_calculate_async, libalmpc), Cint, (Ptr{Cvoid}, Ref{AlmpcOpts}), mod.handle, o))
+        t = results_async(mod; u0 = true, status = true)
+        u0 = Matrix{Float64}(undef, mod.m, mod.batch)
+        results_wait!(mod, t; u0 = u0, status = status)
+        ur = reshape(u, mod.m, mod.N, mod.batch)
+        @views ur[:, 1, :] .= u0
+    else
+        check(mod.handle, ccall((:almpc_calculate, libalmpc), Cint, (Ptr{Cvoid}, Ref{AlmpcOpts}), mod.handle, o))
+        check(mod.handle, ccall((:almpc_get_results, libalmpc), Cint,
+                                (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}),
+                                mod.handle, x, e_x, u, e_u, status, C_NULL, C_NULL))
+    end
+    return throw_on_status(status)
+end
+
+# ---- host-facing step path: pinned staging owned by the handle, transfers on copy streams (include/almpc.h) ----
+"x0 (n x batch) -> pinned slot -> upload on the copy-in stream; returns at once, the next step waits for it on the device"
+function update_initialization_async!(mod::HipModeler, x0::VecOrMat{Float64})
+    length(x0) == mod.n * mod.batch || throw(DimensionMismatch("x0 must hold n x batch values"))
+    check(mod.handle, ccall((:almpc_update_initialization_async, libalmpc), Cint, (Ptr{Cvoid}, Ptr{Float64}), mod.handle, x0))
+end
+
+const WANT_X, WANT_E_X, WANT_U, WANT_E_U, WANT_STATUS, WANT_ITERS, WANT_POLISH_ITERS, WANT_FIRST_INPUT =
+    UInt32(0x01), UInt32(0x02), UInt32(0x04), UInt32(0x08), UInt32(0x10), UInt32(0x20), UInt32(0x40), UInt32(0x80)
+
+"ask for results of the last enqueued step (read-back on the copy-out stream, the next step may start meanwhile); returns a ticket"
+function results_async(mod::HipModeler; x::Bool = false, e_x::Bool = false, u::Bool = false, e_u::Bool = false, u0::Bool = false,
+                       status::Bool = false, iters::Bool = false, polish_iters::Bool = false)
+    want = (x ? WANT_X : UInt32(0)) | (e_x ? WANT_E_X : UInt32(0)) | (u ? WANT_U : UInt32(0)) | (e_u ? WANT_E_U : UInt32(0)) |
+           (u0 ? WANT_FIRST_INPUT : UInt32(0)) | (status ? WANT_STATUS : UInt32(0)) | (iters ? WANT_ITERS : UInt32(0)) |
+           (polish_iters ? WANT_POLISH_ITERS : UInt32(0))
+    t = ccall((:almpc_get_results_async, libalmpc), Cint, (Ptr{Cvoid}, UInt32), mod.handle, want)
+    t < 0 && check(mod.handle, t)
+    return t
+end
+
+"wait for a ticket and copy the given arrays out of the pinned slot (`nothing`: not wanted); sizes are checked"
+function results_wait!(mod::HipModeler, ticket::Integer; x = nothing, e_x = nothing, u = nothing, e_u = nothing, u0 = nothing,
+                       status = nothing, iters = nothing, polish_iters = nothing)
+    check_result_sizes(mod, x, e_x, u, e_u)
+    u0 === nothing || length(u0) == mod.m * mod.batch || throw(DimensionMismatch("u0 must hold m x batch values"))
+    for (name, a) in (("status", status), ("iters", iters), ("polish_iters", polish_iters))
+        a === nothing || length(a) == mod.batch || throw(DimensionMismatch("$name must hold batch values"))
+    end
+    pf(a) = a === nothing ? Ptr{Float64}(C_NULL) : pointer(a)
+    pi(a) = a === nothing ? Ptr{Int32}(C_NULL) : pointer(a)
+    GC.@preserve x e_x u e_u u0 status iters polish_iters check(mod.handle, ccall((:almpc_get_results_wait, libalmpc), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}),
+        mod.handle, ticket, pf(x), pf(e_x), pf(u), pf(e_u), pf(u0), pi(status), pi(iters), pi(polish_iters)))
+end
+
+"zero-copy views of a ticket's pinned slot (after `results_wait!(mod, ticket)`): arrays that were not asked for come back as `nothing`; valid until two more requests"
+function host_results(mod::HipModeler, ticket::Integer)
+    pd = [Ref{Ptr{Float64}}(C_NULL) for _ in 1:5]; pn = [Ref{Ptr{Int32}}(C_NULL) for _ in 1:3]
+    check(mod.handle, ccall((:almpc_host_results, libalmpc), Cint,
+        (Ptr{Cvoid}, Cint, Ref{Ptr{Float64}}, Ref{Ptr{Float64}}, Ref{Ptr{Float64}}, Ref{Ptr{Float64}}, Ref{Ptr{Float64}}, Ref{Ptr{Int32}},
+         Ref{Ptr{Int32}}, Ref{Ptr{Int32}}), mod.handle, ticket, pd[1], pd[2], pd[3], pd[4], pd[5], pn[1], pn[2], pn[3]))
+    w(p, dims) = p[] == C_NULL ? nothing : unsafe_wrap(Array, p[], dims)
+    return (x = w(pd[1], (mod.n, mod.N + 1, mod.batch)), e_x = w(pd[2], (mod.n, mod.N + 1, mod.batch)), u = w(pd[3], (mod.m, mod.N, mod.batch)),
+            e_u = w(pd[4], (mod.m, mod.N, mod.batch)), u0 = w(pd[5], (mod.m, mod.batch)), status = w(pn[1], (mod.batch,)),
+            iters = w(pn[2], (mod.batch,)), polish_iters = w(pn[3], (mod.batch,)))
+end
+
+"u[:, 1] of every instance of the last step, m x batch (`almpc_get_first_input`)"
+function first_input!(mod::HipModeler, u0::Matrix{Float64})
+    length(u0) == mod.m * mod.batch || throw(DimensionMismatch("u0 must hold m x batch values"))
+    check(mod.handle, ccall((:almpc_get_first_input, libalmpc), Cint, (Ptr{Cvoid}, Ptr{Float64}), mod.handle, u0))
+    return u0
+end
+first_input(mod::HipModeler) = first_input!(mod, Matrix{Float64}(undef, mod.m, mod.batch))
 
 """
     design_relin_fnn!(mod, W_in, W_h, b_h, W_out, activation, Q, R, S, P, umin, umax; x_ref, u_ref)
@@ -221,6 +307,7 @@ relin_advance!(mod::HipModeler) = check(mod.handle, ccall((:almpc_relin_fnn_adva
 
 "copy the results of the last step into caller-owned arrays (m x N x batch, n x (N+1) x batch); returns the per-instance status"
 function read_results!(mod::HipModeler, x::Array{Float64}, e_x::Array{Float64}, u::Array{Float64}, e_u::Array{Float64})
+    check_result_sizes(mod, x, e_x, u, e_u)
     status = Vector{Int32}(undef, mod.batch)
     check(mod.handle, ccall((:almpc_get_results, libalmpc), Cint,
                             (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}),
@@ -360,6 +447,13 @@ function timing_summary(mod::HipModeler)
                             mod.handle, steps, pointer(t, 1), pointer(t, 2), pointer(t, 3), pointer(t, 4)))
     return (steps = Int(steps[]), admm_ms = t[1], polish_ms = t[2], rollout_ms = t[3], total_ms = t[4])
 end
+"per recorded step its four stage times in ms (rows: admm, polish, rollout, total), at most `cap` steps"
+function timing_samples(mod::HipModeler, cap::Integer = 4096)
+    cnt = Ref{Cint}(0); t = zeros(Float32, cap, 4)
+    check(mod.handle, ccall((:almpc_timing_samples, libalmpc), Cint, (Ptr{Cvoid}, Cint, Ref{Cint}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}),
+                            mod.handle, cap, cnt, pointer(t, 1), pointer(t, cap + 1), pointer(t, 2cap + 1), pointer(t, 3cap + 1)))
+    return t[1:min(cap, Int(cnt[])), :]
+end
 function relin_timing(mod::HipModeler)
     t = zeros(Float32, 3)
     check(mod.handle, ccall((:almpc_relin_fnn_timing, libalmpc), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}),
@@ -369,10 +463,99 @@ end
 "diagnostic: fill the LDS of every CU with NaN patterns before a step (a kernel that reads LDS it did not write then shows)"
 debug_poison_lds!(mod::HipModeler) = check(mod.handle, ccall((:almpc_debug_poison_lds, libalmpc), Cint, (Ptr{Cvoid},), mod.handle))
 
-# the name BASELINE.json uses; absent from the reference (SURVEY.md section 0): one batched step
-function _model_predictive_control_computation(mod::HipModeler, X0::Matrix{Float64}, x, e_x, u, e_u)
-    update_initialization!(mod, X0)
-    calculate!(mod, x, e_x, u, e_u)
+# ---- one Julia process, several GPUs (almpc_group_*): the reference API is one process, one call (src/main/main_mpc.jl:22-53) ----
+mutable struct HipGroup
+    group::Ptr{Cvoid}
+    n::Int; m::Int; N::Int; batch::Int
+    opts::AlmpcOpts
+end
+
+function gcheck(g, rc)
+    rc == 0 && return
+    error("libalmpc group error $rc: " * unsafe_string(ccall((:almpc_group_last_error, libalmpc), Cstring, (Ptr{Cvoid},), g)))
+end
+
+"handle i (1-based) of the group as a HipModeler on its shard: for the per-handle options and anything the group calls do not cover"
+function group_handle(g::HipGroup, i::Integer)
+    h = ccall((:almpc_group_handle, libalmpc), Ptr{Cvoid}, (Ptr{Cvoid}, Cint), g.group, i - 1)
+    h == C_NULL && throw(BoundsError(g, i))
+    return HipModeler(h, g.n, g.m, g.N, group_shard(g, i)[2], g.opts)    # (no finalizer: the group owns the handle)
+end
+"(first instance (1-based), count) of handle i's contiguous shard"
+function group_shard(g::HipGroup, i::Integer)
+    f, c = Ref{Cint}(0), Ref{Cint}(0)
+    gcheck(g.group, ccall((:almpc_group_shard, libalmpc), Cint, (Ptr{Cvoid}, Cint, Ref{Cint}, Ref{Cint}), g.group, i - 1, f, c))
+    return Int(f[]) + 1, Int(c[])
+end
+
+"`design_hip` over several devices: `devices` lists one HIP device id per shard (`mpc_batch` instances are cut into contiguous shards)"
+function group_design_hip(A::Matrix{Float64}, B::Matrix{Float64}, Q::Matrix{Float64}, R::Matrix{Float64}, S::Matrix{Float64},
+                          umin::Vector{Float64}, umax::Vector{Float64}, N::Int; batch::Int, devices::Vector{Int},
+                          x_ref::Matrix{Float64}, u_ref::Matrix{Float64}, opts::AlmpcOpts = AlmpcOpts(),
+                          xmin::Union{Nothing,Vector{Float64}} = nothing, xmax::Union{Nothing,Vector{Float64}} = nothing,
+                          terminal::String = "none", rho_profile::String = "scalar", P::Union{Nothing,Matrix{Float64}} = nothing)
+    n, m = size(B)
+    terminal == "contractive" && error("terminal ingredient \"contractive\" is a quadratic constraint (src/sub/design_mpc.jl:333-340), not a QP row")
+    gref = Ref{Ptr{Cvoid}}(C_NULL)
+    devs = Cint.(devices)
+    rc = ccall((:almpc_group_create, libalmpc), Cint, (Ref{Ptr{Cvoid}}, Cint, Cint, Cint, Cint, Cint, Ptr{Cint}, UInt32),
+               gref, n, m, N, batch, length(devs), devs, 0)
+    rc == 0 || error("almpc_group_create failed ($rc): are the devices visible? (there is no CPU fallback)")
+    g = HipGroup(gref[], n, m, N, batch, opts)
+    finalizer(x -> ccall((:almpc_group_destroy, libalmpc), Cvoid, (Ptr{Cvoid},), x.group), g)
+    for i in 1:ccall((:almpc_group_size, libalmpc), Cint, (Ptr{Cvoid},), g.group)
+        h = group_handle(g, i).handle
+        check(h, ccall((:almpc_set_terminal_equality, libalmpc), Cint, (Ptr{Cvoid}, Cint), h, terminal == "equality" ? 1 : 0))
+        check(h, ccall((:almpc_set_rho_profile, libalmpc), Cint, (Ptr{Cvoid}, Cint), h, rho_profile == "stiffness" ? 1 : 0))
+    end
+    pP = P === nothing ? Ptr{Float64}(C_NULL) : pointer(P)
+    pxmin = xmin === nothing ? Ptr{Float64}(C_NULL) : pointer(xmin)
+    pxmax = xmax === nothing ? Ptr{Float64}(C_NULL) : pointer(xmax)
+    GC.@preserve P xmin xmax gcheck(g.group, ccall((:almpc_group_design_shared, libalmpc), Cint,
+                   (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                    Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cdouble, Cdouble),
+                   g.group, A, B, Q, R, S, pP, umin, umax, pxmin, pxmax, opts.rho, opts.sigma))
+    gcheck(g.group, ccall((:almpc_group_set_reference, libalmpc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Cint), g.group, x_ref, u_ref, 0))
+    return g
+end
+
+function group_update_initialization!(g::HipGroup, x0::VecOrMat{Float64})
+    length(x0) == g.n * g.batch || throw(DimensionMismatch("x0 must hold n x batch values"))
+    gcheck(g.group, ccall((:almpc_group_update_initialization, libalmpc), Cint, (Ptr{Cvoid}, Ptr{Float64}), g.group, x0))
+end
+function group_calculate_async!(g::HipGroup)
+    o = Ref(g.opts)
+    gcheck(g.group, ccall((:almpc_group_calculate_async, libalmpc), Cint, (Ptr{Cvoid}, Ref{AlmpcOpts}), g.group, o))
+end
+group_synchronize!(g::HipGroup) = gcheck(g.group, ccall((:almpc_group_synchronize, libalmpc), Cint, (Ptr{Cvoid},), g.group))
+function group_calculate!(g::HipGroup)
+    o = Ref(g.opts)
+    gcheck(g.group, ccall((:almpc_group_calculate, libalmpc), Cint, (Ptr{Cvoid}, Ref{AlmpcOpts}), g.group, o))
+end
+"results of the whole batch (any array may be `nothing`); `u0`: m x batch first inputs; returns the per-instance status"
+function group_read_results!(g::HipGroup; x = nothing, e_x = nothing, u = nothing, e_u = nothing, u0 = nothing)
+    nx, nu = g.n * (g.N + 1) * g.batch, g.m * g.N * g.batch
+    for (name, a, want) in (("x", x, nx), ("e_x", e_x, nx), ("u", u, nu), ("e_u", e_u, nu), ("u0", u0, g.m * g.batch))
+        a === nothing || length(a) == want || throw(DimensionMismatch("$name holds $(length(a)) values, the group writes $want"))
+    end
+    status = Vector{Int32}(undef, g.batch)
+    pf(a) = a === nothing ? Ptr{Float64}(C_NULL) : pointer(a)
+    GC.@preserve x e_x u e_u u0 gcheck(g.group, ccall((:almpc_group_get_results, libalmpc), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}),
+        g.group, pf(x), pf(e_x), pf(u), pf(e_u), pf(u0), status, C_NULL, C_NULL))
+    return throw_on_status(status)
+end
+
+# the name BASELINE.json uses; absent from the reference (SURVEY.md section 0): one batched step, host in / host out
+function _model_predictive_control_computation(mod::HipModeler, X0::Matrix{Float64}, x, e_x, u, e_u; first_move_only::Bool = false)
+    check_result_sizes(mod, x, e_x, u, e_u)
+    update_initialization_async!(mod, X0)
+    calculate!(mod, x, e_x, u, e_u; first_move_only = first_move_only)
+end
+function _model_predictive_control_computation(g::HipGroup, X0::Matrix{Float64}, x, e_x, u, e_u)
+    group_update_initialization!(g, X0)
+    group_calculate!(g)
+    group_read_results!(g; x = x, e_x = e_x, u = u, e_u = e_u)
 end
 
 end # module

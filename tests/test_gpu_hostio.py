@@ -1,0 +1,172 @@
+"""The host-facing step path and the one-process multi-GPU group (pytest -m gpu), through the C ABI:
+  * almpc_get_results_async / _wait and almpc_get_first_input return exactly what almpc_get_results returns
+    (reference contract: update_initialization!(C, x0) / calculate!(C), src/main/computation_mpc.jl:17-29,38-55);
+  * a pipelined loop (upload of step k+1 and read-back of step k under the kernels) hands every ticket the results of ITS step;
+  * zero-copy views of the pinned slots equal the copies;
+  * a group of two handles (both on device 0: the box has one GPU) equals the one-handle run of the concatenated batch
+    (almpc_create(..., n_devices, device_ids, ...); section 8e: shards are independent);
+  * all eight 4096-instance shards of configs[2] (32,768 instances, seed 0x5EED0003) go through the HIP path."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+U_TOL = 1e-6
+
+
+def _solver(capi, p, batch, **kw):
+    s = capi.Solver(p.n, p.m, p.N, batch, device=0)
+    s.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max, **kw)
+    s.set_reference(p.x_ref, p.u_ref)
+    return s
+
+
+def _x0(mo, batch, first=0, seed=0x5EED0002):
+    amp = np.array([0.3, 1.0, 3.0])[np.arange(first, first + batch) % 3]
+    return mo.splitmix_normal(seed, first, batch, 12) * mo.QUADROTOR_X0_SCALE[None] * amp[:, None]
+
+
+ALL = ("x", "e_x", "u", "e_u", "status", "iters", "polish_iters")
+
+
+def test_async_results_equal_the_synchronous_read_back(capi, mo):
+    p = mo.quadrotor()
+    batch = 100   # not a multiple of the tile
+    s = _solver(capi, p, batch)
+    X0 = _x0(mo, batch)
+    s.update_initialization(X0)
+    s.calculate()
+    ref = s.get_results(want=ALL)
+    t = s.get_results_async(want=ALL + ("u0",))
+    got = s.get_results_wait(t, want=ALL + ("u0",))
+    for k in ALL:
+        assert np.array_equal(got[k], ref[k]), k
+    assert np.array_equal(got["u0"], ref["u"][:, :, 0])
+    assert np.array_equal(s.get_first_input(), ref["u"][:, :, 0])
+    # zero-copy views of the pinned slot
+    t2 = s.get_results_async(want=("u", "x", "status", "u0"))
+    v = s.get_results_wait(t2, want=("u", "x", "status", "u0"), copy=False)
+    assert np.array_equal(v["u"], ref["u"]) and np.array_equal(v["x"], ref["x"]) and np.array_equal(v["status"], ref["status"])
+    assert np.array_equal(v["u0"], ref["u"][:, :, 0])
+    # asking a ticket for something its request did not include, or for a ticket that is gone, is an error -- not stale data
+    with pytest.raises(capi.AlmpcError):
+        s.get_results_wait(t2, want=("e_x",))
+    with pytest.raises(capi.AlmpcError):
+        s.get_results_wait(t, want=("u0",))      # two requests later: the slot was reused
+    with pytest.raises(ValueError):
+        s.get_results_async(want=("nope",))
+    s.close()
+
+
+def test_pipelined_host_loop_hands_every_ticket_its_own_step(capi, mo):
+    """x0 of step k+1 is uploaded and u[:,1] of step k is read back while the kernels run; depth-2 rings on both sides."""
+    p = mo.quadrotor()
+    batch = 256
+    steps = 7
+    X0s = [_x0(mo, batch, first=1000 * k) for k in range(steps)]
+    # reference: the plain synchronous path, one step at a time
+    s = _solver(capi, p, batch)
+    want = []
+    for X0 in X0s:
+        s.update_initialization(X0)
+        s.calculate()
+        r = s.get_results(want=("u", "status"))
+        want.append((r["u"][:, :, 0].copy(), r["status"].copy()))
+    s.close()
+    s = _solver(capi, p, batch)
+    got, tickets = [], []
+    for k, X0 in enumerate(X0s):
+        s.update_initialization_async(X0)
+        s.calculate(sync=False)
+        tickets.append(s.get_results_async(want=("u0", "status")))
+        if k >= 1:
+            got.append(s.get_results_wait(tickets[k - 1], want=("u0", "status")))
+    got.append(s.get_results_wait(tickets[-1], want=("u0", "status")))
+    for k in range(steps):
+        assert np.array_equal(got[k]["u0"], want[k][0]), k
+        assert np.array_equal(got[k]["status"], want[k][1]), k
+    # the synchronous entry points still work on a handle that has used the asynchronous ones
+    s.update_initialization(X0s[2])
+    s.calculate()
+    assert np.array_equal(s.get_results(want=("u",))["u"][:, :, 0], want[2][0])
+    s.close()
+
+
+def test_full_read_back_then_next_step_does_not_race(capi, mo):
+    """x / e_x / u / e_u are read straight from the result buffers: the next step must wait for that read-back."""
+    p = mo.quadrotor()
+    batch = 512
+    s = _solver(capi, p, batch)
+    Xa, Xb = _x0(mo, batch), _x0(mo, batch, first=5000)
+    s.update_initialization(Xa); s.calculate(); ra = s.get_results(want=("x", "u"))
+    s.update_initialization(Xb); s.calculate(); rb = s.get_results(want=("x", "u"))
+    s.update_initialization_async(Xa); s.calculate(sync=False)
+    ta = s.get_results_async(want=("x", "u"))
+    s.update_initialization_async(Xb); s.calculate(sync=False)     # enqueued while the read-back of step a may still run
+    tb = s.get_results_async(want=("x", "u"))
+    ga = s.get_results_wait(ta, want=("x", "u"))
+    gb = s.get_results_wait(tb, want=("x", "u"))
+    assert np.array_equal(ga["x"], ra["x"]) and np.array_equal(ga["u"], ra["u"])
+    assert np.array_equal(gb["x"], rb["x"]) and np.array_equal(gb["u"], rb["u"])
+    s.close()
+
+
+def test_group_of_two_handles_equals_one_handle_on_the_concatenated_batch(capi, mo):
+    p = mo.quadrotor()
+    batch = 2 * 1024 + 40     # shards 1044 + 1044: neither a multiple of the tile
+    X0 = _x0(mo, batch)
+    one = _solver(capi, p, batch, rho=45.0, rho_profile="stiffness")
+    opts = capi.default_opts(rho=45.0, max_iter=6, check_every=6)
+    one.update_initialization(X0); one.calculate(opts)
+    ref = one.get_results(want=ALL)
+    one.close()
+    g = capi.Group(p.n, p.m, p.N, batch, devices=[0, 0])
+    assert [c for _, c in g.shards] == [1044, 1044] and [f for f, _ in g.shards] == [0, 1044]
+    g.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max, rho=45.0, rho_profile="stiffness")
+    g.set_reference(p.x_ref, p.u_ref)
+    g.update_initialization(X0)
+    g.calculate(opts, sync=False)
+    g.synchronize()
+    got = g.get_results(want=ALL + ("u0",))
+    for k in ALL:
+        assert np.array_equal(got[k], ref[k]), k
+    assert np.array_equal(got["u0"], ref["u"][:, :, 0])
+    # a second step through the group (x0 ring slot 1) and per-instance references sliced per shard
+    xr = np.zeros((batch, p.n, p.N + 1)); ur = np.zeros((batch, p.m, p.N))
+    xr[:, 0, :] = 0.1 * np.arange(batch)[:, None] / batch
+    g.set_reference(xr, ur, per_instance=True)
+    g.update_initialization(X0)
+    g.calculate(opts)
+    got2 = g.get_results(want=("u", "status"))
+    one = _solver(capi, p, batch, rho=45.0, rho_profile="stiffness")
+    one.set_reference(xr, ur, per_instance=True)
+    one.update_initialization(X0); one.calculate(opts)
+    ref2 = one.get_results(want=("u", "status"))
+    one.close()
+    assert np.array_equal(got2["u"], ref2["u"]) and np.array_equal(got2["status"], ref2["status"])
+    g.close()
+
+
+def test_config2_all_eight_shards(capi, mo):
+    """configs[2]: 32,768 instances (seed 0x5EED0003) as eight contiguous 4096-instance shards, each through the HIP path with the
+    bench's options; every instance certified, sampled instances against the exact oracle.  (One GPU here: the shards run one
+    after the other on device 0 -- what each rank of the 8-GPU job does on its own device.)"""
+    p = mo.quadrotor()
+    des = mo.design_shared(p)
+    d = des["d"]
+    s = _solver(capi, p, 4096, rho=45.0, rho_profile="stiffness")
+    opts = capi.default_opts(rho=45.0, max_iter=6, check_every=6, keep_warm_state=False)
+    for rank in range(8):
+        X0 = _x0(mo, 4096, first=4096 * rank, seed=0x5EED0003)
+        s.update_initialization_async(X0)
+        s.calculate(opts, sync=False)
+        r = s.get_results_wait(s.get_results_async(want=("e_u", "u", "status")), want=("e_u", "u", "status"))
+        assert np.all(r["status"] == 0), (rank, np.bincount(r["status"]))
+        W = r["e_u"].transpose(0, 2, 1).reshape(4096, -1) / d[None]
+        Fs = X0 @ des["Fs"].T
+        Gd = W @ des["Hs"] + Fs
+        kkt = np.abs(W - np.clip(W - Gd, des["lo"][None], des["hi"][None])).max(axis=1)
+        assert kkt.max() <= 1e-8 * max(1.0, np.abs(Fs).max()), rank
+        for i in (0, 1337, 4095):
+            assert np.abs(r["u"][i] - mo.solve_mpc_exact(p, X0[i])["u"]).max() <= U_TOL, (rank, i)
+    s.close()

@@ -153,6 +153,49 @@ def test_structured_handle_refuses_what_it_does_not_build(capi, mo):
         assert np.abs(r["u"][i] - mo.solve_mpc_exact(p, np.array(x0))["u"]).max() <= U_TOL
     with pytest.raises(capi.AlmpcError):
         capi.Solver(40, 2, 10, 1, structured=True)      # n > 32
+    # the condensed per-instance pipelines are refused (ALMPC_ERR_UNSUPPORTED), not launched with null operands
+    f = mo.synthetic_fnn(act="tanh")
+    s = capi.Solver(4, 2, 10, 2, structured=True)
+    xr, ur = np.zeros((4, 11)), np.zeros((2, 10))
+    with pytest.raises(capi.AlmpcError) as ei:
+        s.relin_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, xr, ur, 100.0 * np.eye(4), 0.1 * np.eye(2), None, 150.0 * np.eye(4), [-1, -1], [1, 1], act="tanh")
+    assert ei.value.code == -4
+    with pytest.raises(capi.AlmpcError) as ei:     # an SQP loop on a structured handle is the stage-wise one: no input-rate weight there
+        s.sqp_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, xr, ur, 100.0 * np.eye(4), 0.1 * np.eye(2), 0.5 * np.eye(2), 150.0 * np.eye(4), [-1, -1], [1, 1], act="tanh")
+    assert ei.value.code == -4
+    s.close()
+
+
+def test_sqp_on_a_structured_handle_beyond_the_condensed_horizon(capi, mo):
+    """ALMPC_FLAG_STRUCTURED + almpc_sqp_fnn_*: m N = 160 > 128 (a condensed handle cannot even be created), every iteration's QP in
+    its stage-wise form, no condensed operand allocated.  Against the restatement's stage-wise loop and the NLP's own certificate."""
+    n, m, N, b, iters = 4, 2, 80, 8, 25
+    with pytest.raises(capi.AlmpcError):
+        capi.Solver(n, m, N, b)
+    f = mo.synthetic_fnn(act="tanh")
+    x_ref = np.tile(np.array([0.2, -0.1, 0.05, 0.0])[:, None], (1, N + 1)); u_ref = np.tile(np.array([0.1, -0.2])[:, None], (1, N))
+    X0 = x_ref[:, 0][None, :] + 0.6 * mo.splitmix_normal(0x5EED0005, 0, b, n)
+    Q, R, P = 100.0 * np.eye(n), 0.1 * np.eye(m), 150.0 * np.eye(n)
+    S = np.zeros((m, m))
+    umin, umax = -np.ones(m), np.ones(m)
+    s = capi.Solver(n, m, N, b, structured=True)
+    s.sqp_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, x_ref, u_ref, Q, R, None, P, umin, umax, act="tanh")
+    s.sqp_fnn_start(X0)
+    st, de = s.sqp_fnn_iterate(iters, step_rule="merit")
+    r = s.get_results()
+    assert np.all(r["status"] == 0)
+    assert st[-1] <= 1e-6 and de[-1] <= 1e-10, (st, de)
+    for i in range(b):
+        assert np.abs(r["x"][i] - mo.fnn_rollout(f, X0[i], r["u"][i])).max() <= 1e-9
+        assert mo.nlp_kkt_residual(f, X0[i], r["u"][i], x_ref, u_ref, Q, R, S, P, umin, umax) <= 1e-5
+    # a shared design afterwards takes the handle back to the plain structured solve
+    p = mo.make_problem(np.eye(4) * 0.9, np.ones((4, 2)) * 0.1, N, umin, umax)
+    s.design_shared(p.A, p.B, p.Q, p.R, None, None, p.u_min, p.u_max)
+    s.update_initialization(X0)
+    s.calculate()
+    r2 = s.get_results()
+    assert np.abs(r2["u"][0] - mo.solve_mpc_structured(p, X0[0])["u"]).max() <= U_TOL
+    s.close()
 
 
 def test_sqp_loop_solves_an_indefinite_condensed_qp_through_the_stage_wise_form(capi, mo):
