@@ -40,7 +40,13 @@ mutable struct HipModeler            # what sits in tuning.modeler (`modeler::An
     handle::Ptr{Cvoid}
     n::Int; m::Int; N::Int; batch::Int
     opts::AlmpcOpts
+    # what `calculate!` runs: :linear (almpc_calculate on the design in place), :relin (per-step re-linearisation of a black-box
+    # model, almpc_relin_fnn_step), :sqp (the NonLinearProgramming branch: almpc_sqp_fnn_start from the last x0 + `sqp_iterations`)
+    mode::Symbol
+    sqp_iterations::Int
+    x0::Vector{Float64}              # :sqp only: the last initialisation (the loop restarts from it in every calculate!)
 end
+HipModeler(h, n, m, N, batch, opts) = HipModeler(h, n, m, N, batch, opts, :linear, 20, Float64[])
 
 function check(h, rc)
     rc == 0 && return
@@ -176,6 +182,10 @@ end
 # update_initialization!(C, x0): x0 is a Vector (batch 1) or an n x batch Matrix (src/main/computation_mpc.jl:17-29)
 function update_initialization!(mod::HipModeler, x0::VecOrMat{Float64})
     length(x0) == mod.n * mod.batch || throw(DimensionMismatch("x0 must hold n x batch values"))
+    if mod.mode === :sqp
+        mod.x0 = vec(copy(x0))      # the SQP loop uploads it in sqp_start! (almpc_sqp_fnn_start)
+        return
+    end
     check(mod.handle, ccall((:almpc_update_initialization, libalmpc), Cint, (Ptr{Cvoid}, Ptr{Float64}), mod.handle, x0))
 end
 
@@ -204,6 +214,16 @@ function calculate!(mod::HipModeler, x::Array{Float64}, e_x::Array{Float64}, u::
     check_result_sizes(mod, x, e_x, u, e_u)
     o = Ref(mod.opts)
     status = Vector{Int32}(undef, mod.batch)
+    if mod.mode === :relin || mod.mode === :sqp
+        if mod.mode === :relin
+            relin_step!(mod)
+        else
+            length(mod.x0) == mod.n * mod.batch || error("calculate!: update_initialization! first")
+            sqp_start!(mod, mod.x0)
+            sqp_iterate!(mod, mod.sqp_iterations)
+        end
+        return throw_on_status(read_results!(mod, x, e_x, u, e_u))
+    end
     if first_move_only
         check(mod.handle, ccall((:almpc_calculate_async, libalmpc), Cint, (Ptr{Cvoid}, Ref{AlmpcOpts}), mod.handle, o))
         t = results_async(mod; u0 = true, status = true)

@@ -96,9 +96,12 @@ def test_workloads_module_matches_the_oracle_generators(pkg, mo):
 
 
 def test_reference_side_patch_applies_to_the_reference(tmp_path):
-    """julia/reference_hip.patch (the four reference-side edits of INTEGRATION.md as an actual diff: hip_solver_def tag, "hip" in
-    _IMPLEMENTATION_SOLVER_LIST, the design branch to AlmpcHIP.design_hip, the dispatch in update_initialization! / calculate!) applies
-    cleanly to the reference's own files.  Build container only: the GPU box has no /root/reference."""
+    """julia/reference_hip.patch (the reference-side edits of INTEGRATION.md as an actual diff: hip_solver_def tag, "hip" in
+    _IMPLEMENTATION_SOLVER_LIST, the design branches of the linear-system AND the black-box method to
+    _model_predictive_control_design_hip, batch-sized result arrays, the dispatch in update_initialization! / calculate!, and the
+    shim itself as src/hip/AlmpcHIP.jl) applies cleanly to the reference's own files and is what julia/make_reference_patch.py
+    produces from the current shim.  Build container only: the GPU box has no /root/reference."""
+    import importlib.util
     import shutil
     import subprocess
     ref = "/root/reference"
@@ -111,19 +114,37 @@ def test_reference_side_patch_applies_to_the_reference(tmp_path):
         shutil.copy(os.path.join(ref, f), tmp_path / f)
     patch = os.path.join(ROOT, "julia", "reference_hip.patch")
     touched = {ln.split(" b/")[1].strip() for ln in open(patch) if ln.startswith("diff --git")}
-    assert touched == set(files)
+    assert touched == set(files) | {"src/hip/AlmpcHIP.jl"}
     r = subprocess.run(["git", "apply", "--check", "--verbose", patch], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0, r.stderr
     subprocess.check_call(["git", "apply", patch], cwd=tmp_path)
     sel = open(tmp_path / "src/sub/solver_selection.jl").read()
     assert "hip = hip_solver_def()," in sel
-    assert "AlmpcHIP.design_hip(" in open(tmp_path / "src/sub/design_mpc.jl").read()
+    design = open(tmp_path / "src/sub/design_mpc.jl").read()
+    assert "AlmpcHIP.design_hip(" in design
+    # both design methods branch to the GPU design: the linear-system one and the black-box one
+    assert design.count("if mpc_solver isa hip_solver_def") == 2
+    assert "AlmpcHIP.design_relin_fnn!(" in design and "AlmpcHIP.design_sqp_fnn!(" in design and "AlmpcHIP.fnn_linearize(" in design
+    # results of a batched controller are allocated with the batch (a single-instance allocation would be overrun by the library)
+    assert "_memory_allocation_initialization_results_hip(" in design and "(horizon + 1) * batch" in design
+    # the shim travels with the patch, identical to julia/AlmpcHIP.jl
+    shim = open(os.path.join(ROOT, "julia", "AlmpcHIP.jl")).read()
+    assert open(tmp_path / "src/hip/AlmpcHIP.jl").read() == shim
+    spec = importlib.util.spec_from_file_location("make_reference_patch", os.path.join(ROOT, "julia", "make_reference_patch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.build(ref) == open(patch).read(), "julia/reference_hip.patch is stale: run python julia/make_reference_patch.py"
     # every ccall in the shim names a symbol the header declares
     import re
-    shim = open(os.path.join(ROOT, "julia", "AlmpcHIP.jl")).read()
     hdr = open(os.path.join(ROOT, "include", "almpc.h")).read()
     for sym in set(re.findall(r"ccall\(\(:(almpc_[a-z_]+), libalmpc\)", shim)):
         assert re.search(r"\b" + sym + r"\s*\(", hdr), sym
+    # the entry points that write through caller-supplied result pointers check the lengths first (a single-instance allocation with
+    # mpc_batch > 1 must raise DimensionMismatch, not overrun the Julia heap)
+    for fn in ("function calculate!(", "function read_results!(", "function results_wait!(", "function _model_predictive_control_computation(mod::HipModeler"):
+        body = shim[shim.index(fn):]
+        body = body[:body.index("\nend\n")]
+        assert "check_result_sizes(mod, x, e_x, u, e_u)" in body, fn
 
 
 def test_julia_shim_binds_every_entry_point_of_the_header():
