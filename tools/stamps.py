@@ -1,7 +1,7 @@
 """Diagnostic: run the -DALMPC_STAMPS build and print per-phase cycle statistics (lane-0 stamps of every wave)."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["ALMPC_LIB"] = os.path.join(ROOT, "automationlabsmodelpredictivecontrol.jl_amd", "lib", "libalmpc_stamps.so")
+os.environ["ALMPC_LIB"] = os.environ.get("ALMPC_STAMPS_LIB") or os.path.join(ROOT, "automationlabsmodelpredictivecontrol.jl_amd", "lib", "libalmpc_stamps.so")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np, almpc_loader, bench, mpc_oracle as mo
 capi = almpc_loader.load_package()._capi
@@ -34,6 +34,12 @@ for i, nm in enumerate(["admm prologue", "admm loop", "admm v0 product", "admm r
     print(f"{nm:28s} cycles: median {int(np.median(v)):7d}  p90 {int(np.percentile(v,90)):7d}  max {v.max():7d}")
 ex = out[ok2]
 print("admm prologue split: start->e0 written", int(np.median(ex[:,5]-ex[:,0])), " barrier", int(np.median(ex[:,6]-ex[:,5])), " f' + constants", int(np.median(ex[:,7]-ex[:,6])), " init + nf reduce", int(np.median(ex[:,1]-ex[:,7])))
+fine = full[10240:10240 + 2048]
+okf = fine[:, 0] > 0
+if okf.any():
+    base = out[:2048][okf][:, 0]
+    print("admm prologue fine (cycles from the wave's start): x0 loads issued", int(np.median(fine[okf, 0] - base)), " + F' / constants issued",
+          int(np.median(fine[okf, 1] - base)), " + fragments issued", int(np.median(fine[okf, 2] - base)), " e0 in LDS", int(np.median(out[:2048][okf][:, 5] - base)))
 print("admm loop cycles / iteration:", np.median(da[:, 1]) / opts.max_iter)
 tot = out[ok][:, 14] - out[ok][:, 8]
 print("total per wave: median", int(np.median(tot)), "p90", int(np.percentile(tot, 90)), "max", tot.max(), " (2.4 GHz: max = %.1f us)" % (tot.max() / 2400.0))
