@@ -142,6 +142,8 @@ def load():
     L.almpc_group_calculate_async.argtypes = [_hp, ctypes.POINTER(almpc_opts)]
     L.almpc_group_synchronize.argtypes = [_hp]
     L.almpc_group_get_results.argtypes = [_hp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _ip]
+    L.almpc_set_start_from.argtypes = [_hp, _hp]
+    L.almpc_set_start_from.restype = ctypes.c_int
     L.almpc_timing_samples.argtypes = [_hp, ctypes.c_int, ctypes.POINTER(ctypes.c_int), _fp, _fp, _fp, _fp]
     L.almpc_timing_samples.restype = ctypes.c_int
     for name in ("almpc_update_initialization_async", "almpc_get_results_async", "almpc_get_results_wait", "almpc_host_results",
@@ -469,6 +471,11 @@ class Solver:
         H = np.empty((nz, nz), order="F"); F = np.empty((nz, n), order="F"); d = np.empty(nz)
         self._check(self.L.almpc_get_design_instance(self.h, int(i), _ptr(H), _ptr(F), _ptr(d)))
         return dict(H=H, F=F, d=d)
+
+    def start_from(self, other: "Solver"):
+        """Structured handle: the next calculate starts from `other`'s last inputs (same batch, horizon <= this one's): horizon
+        continuation / chaining of solvers (almpc_set_start_from)."""
+        self._check(self.L.almpc_set_start_from(self.h, other.h))
 
     def set_step_fusion(self, on: bool):
         """One kernel per step (default) or the two-kernel path whose stage times can be told apart."""

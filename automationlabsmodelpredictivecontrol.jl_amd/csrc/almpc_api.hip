@@ -119,6 +119,10 @@ struct almpc_handle {
     bool structured = false;
     int fallback = 0;
     double *rQ = nullptr, *rR = nullptr, *rP = nullptr, *rKst = nullptr, *rPst = nullptr;   // device copies of Q, R (branch rule applied), shared P; gain scratch
+    double* rGuess = nullptr;   // [batch][N][m] start of the next structured solve (almpc_set_start_from / opts.warm_start), else nullptr
+    bool guess_ready = false;   // rGuess was filled for the NEXT almpc_calculate (consumed by it)
+    bool r_has_step = false;    // a structured step has run on this design: its inputs can seed a warm start
+    hipEvent_t ev_guess = nullptr;
     long rP_stride = 0;   // per-instance terminal weights (batched designs): doubles between instances of bP, else 0 with rP
     bool r_batched_P = false;
     // multi-GPU (almpc_comm_*): this handle's rank in an RCCL communicator of one process per GPU
@@ -232,8 +236,9 @@ void free_all(almpc_handle* h) {
     for (auto& e : h->relin.ev)
         if (e) (void)hipEventDestroy(e);
     if (h->comm && rccl_api().ok) (void)rccl_api().CommDestroy(h->comm);
-    for (void* p : {(void*)h->dComm4, (void*)h->dU0, (void*)h->dU0all, (void*)h->rQ, (void*)h->rR, (void*)h->rP, (void*)h->rKst, (void*)h->rPst})
+    for (void* p : {(void*)h->dComm4, (void*)h->dU0, (void*)h->dU0all, (void*)h->rQ, (void*)h->rR, (void*)h->rP, (void*)h->rKst, (void*)h->rPst, (void*)h->rGuess})
         if (p) (void)hipFree(p);
+    if (h->ev_guess) (void)hipEventDestroy(h->ev_guess);
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
     h->ev.clear();
@@ -550,6 +555,26 @@ int almpc_set_structured_fallback(almpc_handle* h, int on) {
     return ALMPC_OK;
 }
 
+int almpc_set_start_from(almpc_handle* h, almpc_handle* src) {
+    if (!h || !src) return ALMPC_ERR_INVALID;
+    if (!h->structured) return fail(h, ALMPC_ERR_UNSUPPORTED, "set_start_from: the handle must be a structured one (ALMPC_FLAG_STRUCTURED)");
+    if (!h->designed || !src->designed) return fail(h, ALMPC_ERR_NOT_DESIGNED, "set_start_from before design (of either handle)");
+    if (src->n != h->n || src->m != h->m || src->batch != h->batch || src->N > h->N || src->device != h->device)
+        return fail(h, ALMPC_ERR_INVALID, "set_start_from: the source must have the same n, m, batch and device and a horizon <= this handle's");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (!h->rGuess) HIP_TRY(h, dalloc(&h->rGuess, (size_t)h->batch * h->nz));
+    if (!h->ev_guess) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_guess, hipEventDisableTiming));
+    // the source's last step must be done before its inputs are read on this handle's stream (no host wait)
+    HIP_TRY(h, hipEventRecord(h->ev_guess, src->stream));
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_guess, 0));
+    const long cnt = (long)h->batch * h->nz;
+    hipLaunchKernelGGL(k_guess_from_inputs, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, h->batch, h->m, src->N, h->N, 0,
+                       (const double*)src->dU, (const double*)h->dUref, h->uref_stride, h->rGuess);
+    HIP_TRY(h, hipGetLastError());
+    h->guess_ready = true;
+    return ALMPC_OK;
+}
+
 int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const double* Q, const double* R,
                         const double* S, const double* P, const double* umin, const double* umax,
                         const double* xmin, const double* xmax, double rho, double sigma) {
@@ -562,6 +587,7 @@ int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const
         for (int i = 0; i < m; ++i)
             if (!(umin[i] <= umax[i])) return fail(h, ALMPC_ERR_INVALID, "design: umin > umax");
         h->designed = false;
+        h->r_has_step = false; h->guess_ready = false;
         h->sqp.ready = h->sqp.started = false;   // (an SQP loop set up on this handle is gone with its per-instance reference buffers)
         HIP_TRY(h, hipSetDevice(h->device));
         hm::mat Am(A, A + (size_t)n * n), Bm(B, B + (size_t)n * m), Qm(Q, Q + (size_t)n * n), Rm(R, R + (size_t)m * m), Pm;
@@ -1749,7 +1775,18 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         return ALMPC_OK;
     };
     if (h->structured) {   // the Riccati active-set solve is the whole step (polish_max_iter caps its working-set changes)
-        HIP_TRY(h, launch_riccati(h, 0, nullptr, o.polish_max_iter));
+        const double* guess = nullptr;
+        if (h->guess_ready) { guess = h->rGuess; h->guess_ready = false; }   // almpc_set_start_from: consumed by this step
+        else if (o.warm_start && h->r_has_step) {   // receding horizon: the previous step's inputs shifted by one stage (the last stage repeated)
+            if (!h->rGuess) HIP_TRY(h, dalloc(&h->rGuess, (size_t)h->batch * h->nz));
+            const long cnt = (long)h->batch * h->nz;
+            hipLaunchKernelGGL(k_guess_from_inputs, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, h->batch, h->m, h->N, h->N, 1,
+                               (const double*)h->dU, (const double*)h->dUref, h->uref_stride, h->rGuess);
+            HIP_TRY(h, hipGetLastError());
+            guess = h->rGuess;
+        }
+        HIP_TRY(h, launch_riccati(h, 0, guess, o.polish_max_iter));
+        h->r_has_step = true;
         return io_step_done();
     }
     const bool timing = (h->flags & ALMPC_FLAG_TIMING) != 0 && (h->step_count++ % (size_t)h->timing_stride) == 0;

@@ -160,6 +160,17 @@ int almpc_set_step_fusion(almpc_handle* h, int on);
 int almpc_set_structured_fallback(almpc_handle* h, int on);
 
 /*
+ * Start of the NEXT almpc_calculate(_async) of a structured handle `h` from the inputs of `src`'s last step (any handle on the
+ * same device with the same n, m, batch and a horizon <= h's; enqueued on h's stream behind src's step, no host wait): the stages
+ * `src` has start at its inputs, the ones beyond at the input reference.  Horizon continuation: the active bounds of an MPC problem
+ * with the DARE terminal weight sit in the early stages, so the condensed path at a short horizon (tens of microseconds) hands the
+ * stage-wise path at a long one its working set -- the quadrotor at N = 50 from N = 30: at most 4 working-set changes instead of up
+ * to 123 from the clipped LQR start.  The optimum does not depend on the start.  A structured handle also honours opts.warm_start = 1:
+ * the start is then its own previous inputs shifted by one stage (the receding-horizon shift, last stage repeated).
+ */
+int almpc_set_start_from(almpc_handle* h, almpc_handle* src);
+
+/*
  * State box of the designs that have no xmin / xmax arguments of their own -- almpc_design_batched, almpc_design_ltv, the
  * re-linearisation pipeline: x_min <= x[:,k] <= x_max for stages 1..N+1, the rows kw `mpc_state_constraint` adds in every delegate
  * of the reference (src/sub/model_modeler_implementation/linear/mpc_modeler_implementation_linear.jl:62-70,

@@ -11,7 +11,7 @@ module AlmpcHIP
 export hip_solver_def, HipModeler, AlmpcOpts, design_hip, terminal_weight, set_state_rows!, design_batched!, design_sqp_fnn!, sqp_start!, sqp_iterate!,
        design_relin_fnn!, relin_step!, relin_advance!, update_initialization!, calculate!, read_results!,
        _model_predictive_control_computation, comm_unique_id, comm_init!, comm_summary, comm_allgather_first_input,
-       calculate_async!, synchronize!, relin_step_async!, advance_plant!, update_initialization_device!, device_results, set_step_fusion!,
+       calculate_async!, synchronize!, relin_step_async!, advance_plant!, start_from!, update_initialization_device!, device_results, set_step_fusion!,
        set_structured_fallback!, sqp_skipped, design_instance, gradient_instance, design_ltv!, fnn_linearize, dare, default_opts,
        get_timing, timing_reset!, timing_set_stride!, timing_summary, timing_samples, relin_timing, debug_poison_lds!,
        update_initialization_async!, results_async, results_wait!, host_results, first_input, first_input!,
@@ -385,6 +385,9 @@ function device_results(mod::HipModeler)
                             (Ptr{Cvoid}, Ref{Ptr{Float64}}, Ref{Ptr{Float64}}, Ref{Ptr{Float64}}, Ref{Ptr{Float64}}), mod.handle, px, pex, pu, peu))
     return px[], pex[], pu[], peu[]
 end
+"structured handle: the next step starts from `src`'s last inputs (same batch, horizon <= this one's): horizon continuation"
+start_from!(mod::HipModeler, src::HipModeler) =
+    check(mod.handle, ccall((:almpc_set_start_from, libalmpc), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), mod.handle, src.handle))
 set_step_fusion!(mod::HipModeler, on::Bool) = check(mod.handle, ccall((:almpc_set_step_fusion, libalmpc), Cint, (Ptr{Cvoid}, Cint), mod.handle, on ? 1 : 0))
 "instances the condensed path leaves unsolved (open-loop unstable linearisations) are redone in the multiple-shooting form; before the design"
 set_structured_fallback!(mod::HipModeler, on::Bool) =

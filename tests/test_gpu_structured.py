@@ -235,3 +235,57 @@ def test_sqp_loop_solves_an_indefinite_condensed_qp_through_the_stage_wise_form(
         o = mo.solve_mpc_structured(p, X0[i])
         assert o["status"] == 0 and np.abs(out[True]["u"][i] - o["u"]).max() <= 1e-6
     assert ((np.abs(out[True]["u"]) >= 1.0).sum()) >= 1                             # the box is active somewhere
+
+
+def test_horizon_continuation_and_warm_start(capi, mo):
+    """almpc_set_start_from: the condensed path at N = 30 hands the stage-wise path at N = 50 its working set.  Same optimum as
+    the plain structured solve (the start does not matter), far fewer working-set changes; and opts.warm_start = 1 on a structured
+    handle (previous inputs shifted by one stage) along a closed loop."""
+    b = 192
+    amp = np.array([0.3, 1.0, 3.0])[np.arange(b) % 3]
+    X0 = mo.splitmix_normal(0x5EED0002, 0, b, 12) * mo.QUADROTOR_X0_SCALE[None] * amp[:, None]
+    X0[0] = mo.splitmix_normal(0x5EED0002, 1871, 1, 12)[0] * mo.QUADROTOR_X0_SCALE * 3.0   # the benchmark batch's hardest instance
+    p30, p50 = mo.quadrotor(30), mo.quadrotor(50)
+    s50 = capi.Solver(12, 4, 50, b, structured=True)
+    s50.design_shared(p50.A, p50.B, p50.Q, p50.R, None, None, p50.u_min, p50.u_max)
+    s50.set_reference(p50.x_ref, p50.u_ref)
+    s50.update_initialization(X0)
+    s50.calculate()
+    plain = s50.get_results()
+    s30 = capi.Solver(12, 4, 30, b)
+    s30.design_shared(p30.A, p30.B, p30.Q, p30.R, None, None, p30.u_min, p30.u_max)
+    s30.set_reference(p30.x_ref, p30.u_ref)
+    s30.update_initialization(X0)
+    s30.calculate(sync=False)
+    s50.start_from(s30)          # enqueued behind s30's step on s50's stream: no host wait in between
+    s50.calculate()
+    cont = s50.get_results()
+    assert np.all(plain["status"] == 0) and np.all(cont["status"] == 0)
+    assert np.abs(cont["u"] - plain["u"]).max() <= 1e-8 and np.abs(cont["x"] - plain["x"]).max() <= 1e-7
+    assert cont["polish_iters"].max() <= 8 < plain["polish_iters"].max(), (cont["polish_iters"].max(), plain["polish_iters"].max())
+    for i in (0, 7, 100):
+        assert np.abs(cont["u"][i] - mo.solve_mpc_structured(p50, X0[i])["u"]).max() <= U_TOL
+    # the start is consumed by one step: the next plain step starts from the clipped LQR point again
+    s50.calculate()
+    again = s50.get_results()
+    assert np.array_equal(again["polish_iters"], plain["polish_iters"])
+    # a source with a longer horizon, another batch or another shape is refused
+    with pytest.raises(capi.AlmpcError):
+        s30.start_from(s50)
+    # closed loop with warm starts: x+ = A x + B u[:,1]; every step equals the cold solve of the same state
+    x = X0.copy()
+    warm = capi.default_opts(warm_start=1)
+    s50.update_initialization(x); s50.calculate()
+    for _ in range(3):
+        u0 = s50.get_results(want=("u",))["u"][:, :, 0]
+        x = x @ p50.A.T + u0 @ p50.B.T
+        s50.update_initialization(x)
+        s50.calculate(warm)
+        rw = s50.get_results()
+        s50.calculate()
+        rc = s50.get_results()
+        assert np.all(rw["status"] == 0)
+        assert np.abs(rw["u"] - rc["u"]).max() <= 1e-8
+        assert rw["polish_iters"].sum() < rc["polish_iters"].sum()
+        s50.update_initialization(x); s50.calculate(warm)   # leave the warm result in place for the next shift
+    s30.close(); s50.close()
