@@ -723,6 +723,24 @@ def main():
                                     "note": "one step = Jacobians at (x0_i, u_ref[:,1]) + per-instance condensed designs + ADMM + polish on the "
                                             "handle's stream (almpc_relin_fnn_step); stage_ms: HIP events of a step on a second handle "
                                             "created with ALMPC_FLAG_TIMING"}
+        # roofline of the figure (per-instance-model regime): flops of one instance-step = A^k stack 2 n^3 N + Gamma
+        # blocks 2 n^2 m N + Gamma' Qbar Gamma (block-triangular: ~ 2/3 nz nN nz) + two nz x nz inverses 2 * 2 nz^3 + V_i 2 nz^2 n +
+        # K ADMM iterations 2 nz^2 each; bytes = 13,344-type vectors (here 8 (n + 2 nz + 2 n (N+1)) + 8 (n^2 + n m)) + the materialised
+        # H_i, H'_i, G_i, M_i^-1 (written by the design, read by the step: 2 * 4 * 8 nz nzs)
+        nz3, nzs3 = m3 * N3, 16 * ((m3 * N3 + 15) // 16)
+        k_admm3 = int(capi.default_opts().max_iter)
+        fl3 = (2 * n3 ** 3 * N3 + 2 * n3 * n3 * m3 * N3 + (2.0 / 3.0) * 2 * nz3 * n3 * N3 * nz3 + 4.0 * nz3 ** 3 + 2 * nz3 * nz3 * n3
+               + k_admm3 * 2 * nz3 * nz3)
+        by3 = 8 * (n3 + 2 * nz3 + 2 * n3 * (N3 + 1)) + 8 * (n3 * n3 + n3 * m3) + 2 * 4 * 8 * nz3 * nzs3
+        sec3 = best3 / k3
+        out["config3_fnn_relin"]["roofline"] = {
+            "bound": "hbm", "kernel": "k_design_inverse_wave / k_admm_inst (a chain of 6 + 2 one-workgroup-per-instance launches per step)",
+            "achieved": b3 * by3 / sec3 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b3 * by3 / sec3 / 1e9 / HBM_PEAK_GBS,
+            "traffic": None, "algorithmic_bytes_per_instance_step": by3, "algorithmic_flops_per_instance_step": fl3,
+            "fp64_tflops": b3 * fl3 / sec3 / 1e12, "fp64_frac": b3 * fl3 / sec3 / 1e12 / FP64_PEAK_TFLOPS,
+            "note": "1024 instances of a 40 x 40 problem are 4 instances per CU: every kernel of the chain is bound by the latency of its own "
+                    "dependent steps (40 pivots per inverse, the ADMM iterations, the active-set changes), far from both rooflines; the "
+                    "floor of this shape is the sum of those chains (~0.15 ms), not bytes or flops"}
         s3.close()
 
     if rank == 0 and world == 1 and not args.no_structured:
@@ -775,7 +793,7 @@ def main():
                                                         "working_set_changes_mean": float(rcn["polish_iters"].mean()),
                                                         "working_set_changes_max": int(rcn["polish_iters"].max()), "u_err_inf_sampled": errc,
                                                         "note": "one step = the condensed N = 30 step + almpc_set_start_from + the N = 50 stage-wise solve"},
-                                 "roofline": {"bound": "latency", "kernel": "k_riccati_t<12,4>", "achieved": fl / (bestc / kc) / 1e12, "peak": FP64_PEAK_TFLOPS,
+                                 "roofline": {"bound": "mfma", "kernel": "k_riccati_t<12,4> (FP64 vector pipeline: same 78.6 TFLOP/s peak as the matrix cores)", "achieved": fl / (bestc / kc) / 1e12, "peak": FP64_PEAK_TFLOPS,
                                               "unit": "TFLOP/s", "frac": fl / (bestc / kc) / 1e12 / FP64_PEAK_TFLOPS,
                                               "note": "one wave per instance, every product of a stage an LDS-resident 12 x 12 / 12 x 4 loop: bound by the "
                                                       "dependent chain of N backward stages (~16 k cycles each), not by a throughput roofline; flops = "
@@ -841,6 +859,20 @@ def main():
                                                              "note": "256 matrices of 100 x 100: one workgroup each on 256 CUs, 100 dependent pivots"}
         except (OSError, KeyError, ValueError):
             pass
+        # roofline of the figure: flops of one instance-iteration = Jacobians N (2 H (n + m) + 2 L H^2 + 2 n H) (n + m + 1) + the LTV
+        # condensed Hessian ~ N n nz^2 (row blocks Gamma_k' Q Gamma_k accumulated stage by stage) + one nz x nz inverse 2 nz^3 (the
+        # second one only in the first iteration) + v0 2 nz^2 + the active-set finish (~ 2 nz^2 per change)
+        nzq = mq * Nq
+        Hq_, Lq_ = int(np.asarray(W_in).shape[0]), len(W_h)
+        flq = (Nq * (2 * Hq_ * (nq + mq) + 2 * Lq_ * Hq_ * Hq_ + 2 * nq * Hq_) * (nq + mq + 1) + Nq * nq * nzq * nzq + 2.0 * nzq ** 3
+               + 2 * nzq * nzq + 10 * 2 * nzq * nzq)
+        secq = best / its
+        out["sqp_fnn"]["roofline"] = {
+            "bound": "mfma", "kernel": "k_design_inverse_t<4,16,8> (100 x 100 Gauss-Jordan per instance: the longest of the 13 launches)",
+            "achieved": bq * flq / secq / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": bq * flq / secq / 1e12 / FP64_PEAK_TFLOPS,
+            "traffic": None, "algorithmic_flops_per_instance_iteration": flq,
+            "note": "FP64 vector pipeline (78.6 TFLOP/s peak, as the matrix cores); 256 instances are one workgroup per CU in every kernel of "
+                    "the chain: each is bound by its own dependent steps (100 pivots, N stage updates), not by a throughput roofline"}
         sq.close()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -559,6 +559,41 @@ def solve_qp_dual_active_set(Ghat, s0, lo, hi, eq=None, W0=None, side0=None, max
     return dict(s=s, lam=lam, W=list(W), iters=it, status=status)
 
 
+def feasibility_slack(p: MPCProblem, x0):
+    """Method-independent feasibility certificate of the state-row problem (state box of ..linear.jl:62-70, terminal equality of
+    src/sub/design_mpc.jl:330-331): the smallest t for which inputs inside their box exist with  x_min - t <= x_k <= x_max + t
+    (k = 2..N+1; the equality e_x[:,N+1] = 0 held exactly), by linear programming (scipy HiGHS).  t <= 0: feasible (|t| = the margin);
+    t > 0: infeasible, by that much.  +inf: not even the terminal equality can be met.  Checker only (tests)."""
+    from scipy.optimize import linprog
+    Phi, Gam, _, _ = condense(p)
+    n, m, N, nz = p.n, p.m, p.N, p.nz
+    e0 = np.asarray(x0, dtype=np.float64) - p.x_ref[:, 0]
+    free = Phi @ e0
+    xr = p.x_ref[:, 1:].T.reshape(-1)
+    ur = p.u_ref.T.reshape(-1)
+    c = np.zeros(nz + 1); c[-1] = 1.0
+    A_ub, b_ub = [], []
+    if p.x_min is not None:
+        hi = np.tile(p.x_max, N) - xr - free
+        lo = np.tile(p.x_min, N) - xr - free
+        A_ub = [np.hstack([Gam, -np.ones((n * N, 1))]), np.hstack([-Gam, -np.ones((n * N, 1))])]
+        b_ub = [hi, -lo]
+    A_eq = b_eq = None
+    if p.terminal == "equality":
+        A_eq = np.hstack([Gam[-n:], np.zeros((n, 1))]); b_eq = -free[-n:]
+    bounds = [(p.u_min[k % m] - ur[k], p.u_max[k % m] - ur[k]) for k in range(nz)] + [(None, None)]
+    if not A_ub:
+        A_ub, b_ub = [np.zeros((1, nz + 1))], [np.zeros(1)]
+        A_ub[0][0, -1] = -1.0
+    r = linprog(c, A_ub=np.vstack(A_ub), b_ub=np.concatenate(b_ub), A_eq=A_eq, b_eq=b_eq, bounds=bounds, method="highs")
+    if r.status != 0:
+        return float("inf")
+    t = float(r.x[-1])
+    if p.x_min is not None:   # stage 1 is x0 itself
+        t = max(t, float(np.max(np.maximum(np.asarray(x0) - p.x_max, p.x_min - np.asarray(x0)))))
+    return t
+
+
 def solve_mpc_exact(p: MPCProblem, x0, return_info=False):
     """One MPC step, exact (KKT-certified).  Box-only problems: primal active set on the condensed QP.  With the
     state box and/or the terminal equality: dual active set in constraint space (`solve_qp_dual_active_set`),

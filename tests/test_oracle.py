@@ -491,3 +491,21 @@ def test_ltv_state_rows_reduce_to_the_lti_state_box(mo):
     with pytest.raises(ValueError):
         C2, a2, l2, h2, e2 = mo.ltv_state_rows(Gam, g, xbar, p.x_ref, np.array([-10.0, -0.05]), np.array([10.0, 0.05]), "equality")
         mo.solve_qp_rows_exact(H, q, lo, hi, C2, a2, l2, h2, e2)
+
+
+def test_feasibility_certificate_by_linear_programming(mo):
+    """feasibility_slack: the LP certificate the full-batch state-row test classifies uncertified instances with.  Double integrator
+    with a state box and the terminal equality: an interior start has a margin, a start the box cannot hold is infeasible by the
+    overshoot, and a terminal equality out of reach is +inf."""
+    p = mo.make_problem(np.array([[1.0, 1.0], [0.0, 1.0]]), np.array([[0.5], [1.0]]), 10, np.array([-1.0]), np.array([1.0]),
+                        x_min=np.array([-5.0, -5.0]), x_max=np.array([5.0, 5.0]), terminal="equality")
+    assert mo.feasibility_slack(p, np.array([1.0, 0.0])) < -1.0
+    assert mo.feasibility_slack(p, np.array([4.9, 4.0])) == float("inf")      # cannot stop in 10 steps with |u| <= 1 from v = 4 ... and
+    pb = mo.make_problem(p.A, p.B, 10, p.u_min, p.u_max, x_min=p.x_min, x_max=p.x_max)   # ... without the equality: overshoots the box
+    t = mo.feasibility_slack(pb, np.array([4.9, 4.0]))
+    assert 1.0 < t < 20.0
+    # consistent with the exact solver: feasible <=> solve_mpc_exact returns, infeasible <=> it raises
+    e = mo.solve_mpc_exact(p, np.array([1.0, 0.0]))
+    assert np.abs(e["x"][:, -1]).max() <= 1e-9
+    with pytest.raises((ValueError, RuntimeError)):
+        mo.solve_mpc_exact(pb, np.array([4.9, 4.0]))
