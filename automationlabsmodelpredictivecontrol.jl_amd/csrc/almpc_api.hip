@@ -1802,8 +1802,9 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         HIP_TRY(h, hipEventRecord(ev[0], st));
     }
 
+    AdmmInstParams ip;
+    bool inst_pending = false;   // per-instance ADMM not launched yet: small problems go out fused with their finish (k_step_inst_wave)
     if (h->batched) {  // per-instance models: one workgroup per instance, KKT inverse in LDS
-        AdmmInstParams ip;
         ip.nz = h->nz; ip.n = h->n; ip.m = h->m; ip.batch = h->batch; ip.nzs = h->nzs;
         ip.Minv = h->bMinv; ip.Hs = h->bHs; ip.Fs = h->bFs; ip.Vs = h->bVs; ip.dvec = h->bD; ip.rhovec = h->bRho;
         ip.fS = h->dFS; ip.v0S = h->dV0S; ip.umin = h->dUmin; ip.umax = h->dUmax;
@@ -1818,6 +1819,12 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
             else hipLaunchKernelGGL(k_guess_iterate, dim3((h->batch + 3) / 4), dim3(256), 0, st, ip);
             HIP_TRY(h, hipGetLastError());
         } else {
+            inst_pending = true;
+        }
+    }
+    auto flush_admm_inst = [&]() -> int {   // the two-launch path of per-instance models: k_admm_inst on its own
+        if (!inst_pending) return ALMPC_OK;
+        inst_pending = false;
         const size_t l = (12 * (size_t)h->nzs + 64 + 2 * (size_t)h->m) * sizeof(double);
         if (l > 64 * 1024)
             HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(k_admm_inst), (size_t)(l)));
@@ -1827,8 +1834,8 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         if (wgs > h->batch) wgs = h->batch;
         hipLaunchKernelGGL(k_admm_inst, dim3(wgs), dim3(ADMM_INST_THREADS), l, st, ip);
         HIP_TRY(h, hipGetLastError());
-        }
-    }
+        return ALMPC_OK;
+    };
     AdmmParams ap;
     bool admm_pending = false;  // shared-model ADMM not launched yet: it may go out fused with the polish (k_step_fused)
     const int admm_grid = (h->batch + TILE - 1) / TILE;
@@ -1848,6 +1855,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
     admm_pending = true;
     }
     auto flush_admm = [&]() -> int {  // the two-kernel path: ADMM on its own
+        { const int rci_ = flush_admm_inst(); if (rci_ != ALMPC_OK) return rci_; }
         if (admm_pending) {
             admm_pending = false;
             HIP_TRY(h, launch_admm(h->nrb, h->ks, ap, admm_grid, admm_lds, st));
@@ -1972,6 +1980,29 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
                 HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(k_step_fused<8, 32>), (size_t)(l_step)));
                 hipLaunchKernelGGL((k_step_fused<8, 32>), dim3(pp.ntiles), dim3(512), l_step, st, ap, pp);
             }
+                } else if (inst_pending && h->nzs <= 64 && fused && !(getenv("ALMPC_NO_INST_WAVE") && getenv("ALMPC_NO_INST_WAVE")[0] == '1') &&
+                           ((size_t)SL.total + (size_t)per_wave + (size_t)h->nz * h->nzs) * sizeof(double) <= 64 * 1024) {
+            // small per-instance problems (BASELINE configs[3]): ONE wave per instance for the whole step -- ADMM with the KKT
+            // inverse in registers, then the single-wave finish with G_i in the wave's LDS (the second-tier Sinv, rarely needed at
+            // these sizes, stays in the global scratch: with its 32 KB per wave only three waves would fit a CU)
+            inst_pending = false;
+            const size_t sgl_wave = (size_t)per_wave + (size_t)h->nz * h->nzs;
+            const size_t l_sgl = ((size_t)SL.total + sgl_wave) * sizeof(double);
+            pp.sg_off = -1;
+            pp.g_off = per_wave;
+            pp.lds_per_wave = (int)sgl_wave;
+            pp.direct = 1;
+            if (timing) HIP_TRY(h, hipEventRecord(ev[1], st));  // no boundary between the phases to time: admm_ms reads 0
+#define STEP_INST(NZC_)                                                                                              \
+    do {                                                                                                             \
+        HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(k_step_inst_wave<NZC_>), l_sgl));                    \
+        hipLaunchKernelGGL((k_step_inst_wave<NZC_>), dim3((unsigned)h->batch), dim3(64), l_sgl, st, ip, pp);         \
+    } while (0)
+            if (h->nzs <= 16) STEP_INST(16);
+            else if (h->nzs <= 32) STEP_INST(32);
+            else if (h->nzs <= 48) STEP_INST(48);
+            else STEP_INST(64);
+#undef STEP_INST
                 } else {
         { const int rc_ = flush_admm(); if (rc_ != ALMPC_OK) return rc_; }
         if (l_glds <= 160 * 1024 && !h->polish_no_glds && !h->batched) {

@@ -307,6 +307,152 @@ __global__ __launch_bounds__(ADMM_INST_THREADS) __attribute__((amdgpu_waves_per_
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_step_inst_wave<NZC>: one kernel per step for SMALL per-instance problems (padded size nzs <= NZC <= 64; BASELINE configs[3]: nz 40).
+// k_admm_inst is built to stream a 115 KB KKT inverse per instance through four waves; at nz = 40 the matrix is 15 KB, 1024
+// instances are four per CU, and the two-launch step (137 us) is latency of barriers and of a workgroup per instance.  Here ONE wave
+// owns an instance for the whole step: lane r holds row r of M_i^-1 in registers (column c of the symmetric matrix is one coalesced
+// load), the right-hand side is broadcast through a 64-double LDS buffer (uniform-address reads), every reduction is a DPP chain --
+// no workgroup barrier anywhere --, and the same wave then runs the exact active-set finish of polish_body (single-wave build: G_i
+// and the second-tier Sinv in the wave's LDS) on the iterate it has just written.  Same arithmetic as k_admm_inst per row (the sums
+// run over columns in ascending order instead of four partial sums: results agree to rounding).
+template <int NZC>
+__device__ __forceinline__ void admm_wave_body(const AdmmInstParams& q, const int inst, double* buf /* LDS, >= 2 * 64 doubles */) {
+    const int lane = threadIdx.x & 63;
+    const int nz = q.nz, nzs = q.nzs, n = q.n;
+    const bool own = lane < nz;
+    const int r = own ? lane : 0;
+    // ---- loads: row r of M_i^-1 (= column r, symmetric: element (r, c) at c * nzs + r), the row constants, e0
+    double mrow[NZC];
+    {
+        const double* Mi = GL(q.Minv) + (size_t)inst * nz * nzs + r;
+#pragma unroll
+        for (int c = 0; c < NZC; ++c) mrow[c] = (c < nz) ? Mi[(size_t)c * nzs] : 0.0;
+    }
+    const double dvr = own ? GL(q.dvec)[(size_t)inst * nzs + r] : 1.0;
+    const double rho = own ? GL(q.rhovec)[(size_t)inst * nzs + r] : 1.0;
+    const double ur = GL(q.uref)[(size_t)inst * q.uref_stride + r];
+    double fs = own ? GL(q.fS)[(size_t)inst * nz + r] : 0.0;
+    double v0 = own ? GL(q.v0S)[(size_t)inst * nz + r] : 0.0;
+    const double e0l = (lane < n) ? GL(q.x0)[(size_t)inst * n + lane] - GL(q.xref)[(size_t)inst * q.xref_stride + lane] : 0.0;
+    const double dinv = 1.0 / dvr;
+    const double lo = own ? (q.umin[r % q.m] - ur) * dinv : 0.0, hi = own ? (q.umax[r % q.m] - ur) * dinv : 0.0;
+    // ---- f' = F'_i e0 + fS, v0 = V_i e0 + v0S: column c of F'_i / V_i is one coalesced load, e0_c comes from lane c
+    {
+        const double* Fi = GL(q.Fs) + (size_t)inst * n * nzs + r;
+        const double* Vi = GL(q.Vs) + (size_t)inst * n * nzs + r;
+        for (int c0 = 0; c0 < n; c0 += 4) {
+            double fc[4], vc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = (c0 + u < n) ? c0 + u : 0;
+                fc[u] = Fi[(size_t)c * nzs]; vc[u] = Vi[(size_t)c * nzs];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (c0 + u < n) { const double e = readlane_d(e0l, c0 + u); fs += fc[u] * e; v0 += vc[u] * e; }
+        }
+        if (!own) { fs = 0.0; v0 = 0.0; }
+    }
+    const double nf = wave_max(fabs(fs * dinv));   // |f/d|_inf
+    double x = 0.0, z = 0.0, yt = 0.0, px = 0.0;
+    const double sigma = q.sigma, alpha = q.alpha;
+    if (q.warm) {
+        const size_t o = (size_t)inst * nzs + r;
+        if (own) { x = GL(q.xs)[o]; yt = GL(q.ys)[o] / rho; z = fmin(fmax(GL(q.zs)[o], lo), hi); }
+        // px = H'_i x: one product with the instance's scaled Hessian, column by column from global memory
+        const double* Hi = GL(q.Hs) + (size_t)inst * nz * nzs + r;
+        double a = 0.0;
+        for (int c = 0; c < nz; ++c) a += Hi[(size_t)c * nzs] * readlane_d(x, c);
+        px = own ? a : 0.0;
+    }
+    double rown = own ? sigma * x - fs + rho * (z - yt) : 0.0;
+    bool active = true;
+    int my_iters = q.max_iter, my_status = 1;
+    double* pc = buf;
+    double* pn = buf + 64;
+#pragma unroll 1
+    for (int it = 1; it <= q.max_iter; ++it) {
+        pc[lane] = rown;          // pad rows: 0
+        wave_fence_lds();
+        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+        for (int c = 0; c < NZC; c += 2) {   // uniform-address reads: the right-hand side broadcast to every lane, two entries per read
+            const d2 rv = *reinterpret_cast<const d2*>(pc + c);
+            acc0 = __builtin_fma(mrow[c], rv[0], acc0);
+            acc1 = __builtin_fma(mrow[c + 1], rv[1], acc1);
+        }
+        const double xt = acc0 + acc1;
+        if (active) {
+            const double hxt = rown - (sigma + rho) * xt;  // H' xt, from the KKT identity
+            px = alpha * hxt + (1.0 - alpha) * px;
+            x = alpha * xt + (1.0 - alpha) * x;
+            const double w = alpha * xt + (1.0 - alpha) * z + yt;
+            const double zn = fmin(fmax(w, lo), hi);
+            yt = w - zn;
+            z = zn;
+            rown = own ? sigma * x - fs + rho * (z - yt) : 0.0;
+        }
+        { double* t = pc; pc = pn; pn = t; }
+        const bool check = (it % q.check_every == 0) || (it == q.max_iter);
+        if (check) {
+            const double yi = rho * yt;
+            const double rp = wave_max(own ? fabs(dvr * (x - z)) : 0.0);
+            __builtin_amdgcn_sched_barrier(0);
+            const double nx = wave_max(own ? fabs(dvr * x) : 0.0);
+            __builtin_amdgcn_sched_barrier(0);
+            const double nzn = wave_max(own ? fabs(dvr * z) : 0.0);
+            __builtin_amdgcn_sched_barrier(0);
+            const double rd = wave_max(own ? fabs((px + fs + yi) * dinv) : 0.0);
+            __builtin_amdgcn_sched_barrier(0);
+            const double nhx = wave_max(own ? fabs(px * dinv) : 0.0);
+            __builtin_amdgcn_sched_barrier(0);
+            const double ny = wave_max(own ? fabs(yi * dinv) : 0.0);
+            __builtin_amdgcn_sched_barrier(0);
+            const double sfin = x + yi + px;
+            const double bad = wave_max((own && !(fabs(sfin) <= 1.79e308)) ? 1.0 : 0.0);
+            if (active) {
+                const bool conv = (rp <= q.eps_abs + q.eps_rel * fmax(nx, nzn)) && (rd <= q.eps_abs + q.eps_rel * fmax(fmax(nhx, ny), nf));
+                if (bad > 0.0) { active = false; my_iters = it; my_status = 2; }
+                else if (conv) { active = false; my_iters = it; my_status = 0; }
+            }
+            if (!active) break;
+        }
+    }
+    // ---- hand-off to the finish: the arrays k_admm_inst writes
+    if (lane == 0) {
+        GL(q.iters)[inst] = my_iters;
+        GL(q.status)[inst] = my_status;
+        GL(q.piters)[inst] = 0;
+        GL(q.perm)[inst] = inst;
+    }
+    if (lane < nzs) {
+        const size_t o = (size_t)inst * nzs + lane;
+        GL(q.xs)[o] = own ? x : 0.0;
+        GL(q.zs)[o] = own ? z : 0.0;
+        GL(q.ys)[o] = own ? rho * yt : 0.0;
+        GL(q.v0)[o] = own ? v0 : 0.0;
+    }
+}
+
+constexpr int STEP_INST_KOFF = (int)((sizeof(AdmmInstParams) + 7) & ~size_t(7));   // PolishParams follows AdmmInstParams in the kernarg segment
+
+template <int NZC>
+__global__ __launch_bounds__(64) void k_step_inst_wave(AdmmInstParams ip, PolishParams pp) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int inst = blockIdx.x;
+    if (inst < ip.batch) {
+        // the ADMM phase borrows the head of the wave's polish slot (rowbuf | pbufa: 192 doubles) for its broadcast buffers
+        const PolishShared SL = polish_shared_layout(pp.roll.n, pp.m, pp.roll.N, pp.nz, pp.nzs, pp.fuse_rollout);
+        admm_wave_body<NZC>(ip, inst, smem + SL.total);
+    }
+    // the finish reads the iterate back through global memory: make this wave's stores visible to its own later loads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    polish_body<false, false, STEP_INST_KOFF, true>(pp, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_guess_iterate: hand-off to the active-set finish for an SQP iteration after the first one, instead of an ADMM phase.
 // The QP variable is v = u - ubar around the current iterate, so v = 0 is feasible, and the rows that are active at the
 // solution of this QP are, up to a few changes, the inputs that already sit ON a bound: the previous QP put them there and the

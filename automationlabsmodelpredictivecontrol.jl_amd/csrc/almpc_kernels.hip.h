@@ -479,6 +479,7 @@ struct PolishParams {
                          // word beside the queue counter) and otherwise falls back to the global scratch
     int g_off;           // k_polish_sgl: offset of the wave's copy of its instance's G_i (nz rows of nzs doubles)
     int max_iter;
+    int direct = 0;      // k_step_inst_wave: workgroup (= wave) b finishes instance b itself (no perm lookup)
     int fuse_rollout;    // 1: this kernel also produces u, e_u, x, e_x (roll.*), no separate k_rollout launch; 2: u, e_u only;
                          // 3: as 1 with the blocked rollout (shared model: rollM)
     int roll_g, roll_cpl; // rollout lane decomposition: roll_g lanes per state row, roll_cpl columns of [A B] per lane
@@ -851,7 +852,10 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
     double* Sg;
     int cap2 = 64;
     bool own_slot = false;
-    if constexpr (SGL) Sg = wave_lds + p.sg_off;
+    // (single-wave builds keep it in the wave's LDS unless the host gave it no room there: sg_off < 0 -- k_step_inst_wave, where a
+    // 32 KB slot per wave would leave three waves per CU for four instances)
+    const bool sg_lds = SGL && p.sg_off >= 0;
+    if (sg_lds) Sg = wave_lds + p.sg_off;
     else Sg = GL(p.sglobal) + (size_t)inst * POLISH_GLB_PER_INST;
 
     double lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0, v00, v01, w0 = 0, w1 = 0, y0, y1, z0, z1;
@@ -935,7 +939,7 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
     // Broadcasts of a position-distributed vector go through a 64-entry LDS buffer (one uniform-address read per
     // element, pipelined with the Sinv reads) rather than through v_readlane pairs.
     auto sync_s = [&](auto m) {  // order this wave's writes to Sinv before its later reads
-        if constexpr (decltype(m)::glb && !SGL) {
+        if (decltype(m)::glb && !sg_lds) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1622,7 +1626,9 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
     } else {
         // slot s -> (tile s % ntiles, rank s / ntiles): the dispatch order starts with the hardest instance of every tile
         const int slot = blockIdx.x * NWV + wv;
-        if (slot < p.ntiles * 16) {
+        if (p.direct) {
+            if (slot < p.batch) process(slot);
+        } else if (slot < p.ntiles * 16) {
             const int inst = p.perm[(slot % p.ntiles) * 16 + slot / p.ntiles];
             if (inst >= 0) process(inst);
         }

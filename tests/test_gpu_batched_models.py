@@ -331,3 +331,46 @@ def test_relin_closed_loop_warm_steps(capi, mo):
         sw.relin_fnn_advance()
     assert nact > 20
     sw.close(); sc.close()
+
+
+def test_wave_per_instance_step_equals_the_two_launch_path(capi, mo, monkeypatch):
+    """k_step_inst_wave (small per-instance problems: one wave per instance for the whole step) against the k_admm_inst + k_polish
+    pair on the same models and states: same certified optimum (the sums of a product run in a different order: 1e-9), same
+    statuses; and against the exact oracle on a sample."""
+    n, m, N, b = 4, 2, 20, 300
+    rng = np.random.default_rng(7)
+    f = mo.synthetic_fnn(act="relu")
+    x_ref = np.tile(np.array([0.2, -0.1, 0.05, 0.0])[:, None], (1, N + 1)); u_ref = np.tile(np.array([0.1, -0.2])[:, None], (1, N))
+    X0 = x_ref[:, 0][None, :] + mo.splitmix_normal(0x5EED0004, 0, b, n)
+    A = np.empty((b, n, n)); B = np.empty((b, n, m))
+    for i in range(b):
+        A[i], B[i] = f.jacobian(X0[i], u_ref[:, 0])
+    Q, R, P = 100.0 * np.eye(n), 0.1 * np.eye(m), 150.0 * np.eye(n)
+    res = {}
+    for tag, env in (("wave", None), ("pair", "1")):
+        if env:
+            monkeypatch.setenv("ALMPC_NO_INST_WAVE", env)
+        else:
+            monkeypatch.delenv("ALMPC_NO_INST_WAVE", raising=False)
+        s = capi.Solver(n, m, N, b)
+        s.design_batched(A, B, Q, R, None, P, -np.ones(m), np.ones(m))
+        s.set_reference(x_ref, u_ref)
+        s.update_initialization(X0)
+        s.calculate()
+        res[tag] = s.get_results()
+        # a warm-started second step (the ADMM state of the first) goes through the same kernel
+        s.calculate(capi.default_opts(warm_start=1))
+        res[tag + "_warm"] = s.get_results()
+        s.close()
+    monkeypatch.delenv("ALMPC_NO_INST_WAVE", raising=False)
+    for a_, b_ in (("wave", "pair"), ("wave_warm", "pair_warm")):
+        assert np.array_equal(res[a_]["status"], res[b_]["status"])
+        ok = res[a_]["status"] == 0
+        assert ok.mean() >= 0.97
+        assert np.abs(res[a_]["u"][ok] - res[b_]["u"][ok]).max() <= 1e-9
+        assert np.abs(res[a_]["x"][ok] - res[b_]["x"][ok]).max() <= 1e-8
+    assert np.array_equal(res["wave"]["iters"], res["pair"]["iters"])
+    for i in range(0, b, 37):
+        if res["wave"]["status"][i] == 0:
+            pi = mo.make_problem(A[i], B[i], N, -np.ones(m), np.ones(m), x_ref=x_ref, u_ref=u_ref, P=P)
+            assert np.abs(res["wave"]["u"][i] - mo.solve_mpc_exact(pi, X0[i])["u"]).max() <= 1e-6
