@@ -161,6 +161,7 @@ struct almpc_handle {
     } io;
     // timing (ALMPC_FLAG_TIMING): one set of 4 events per step since the last almpc_timing_reset
     std::vector<hipEvent_t> ev;  // 4 per step
+    std::vector<char> ev_two;    // per recorded step: 1 = a one-kernel step, only its events 1 and 2 (around the kernel) were recorded
     size_t ev_used = 0;          // steps recorded
     int timing_stride = 1;       // record events on every timing_stride-th step only (each event costs ~3 us of stream time)
     size_t step_count = 0;
@@ -1799,8 +1800,16 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
             for (size_t i = old; i < h->ev.size(); ++i) HIP_TRY(h, hipEventCreate(&h->ev[i]));
         }
         ev = &h->ev[4 * h->ev_used];
-        HIP_TRY(h, hipEventRecord(ev[0], st));
+        if (h->ev_two.size() < h->ev_used + 1) h->ev_two.resize(h->ev_used + 64, 0);
     }
+    // event 0 (start of the step) is recorded in front of the step's first launch -- unless the step turns out to be ONE kernel: then
+    // only the pair around that kernel is recorded (an event record costs ~3.5 us of stream time: four of them are 5 % of such a step)
+    bool ev0_done = false;
+    auto ev0 = [&]() -> hipError_t {
+        if (!timing || ev0_done) return hipSuccess;
+        ev0_done = true;
+        return hipEventRecord(ev[0], st);
+    };
 
     AdmmInstParams ip;
     bool inst_pending = false;   // per-instance ADMM not launched yet: small problems go out fused with their finish (k_step_inst_wave)
@@ -1815,6 +1824,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         ip.max_iter = o.max_iter; ip.check_every = o.check_every; ip.warm = o.warm_start ? 1 : 0;
         if (h->skip_admm) {
             if (!o.polish) return fail(h, ALMPC_ERR_INVALID, "calculate: the SQP loop needs opts.polish = 1");
+            HIP_TRY(h, ev0());
             if (h->skip_admm == 2) hipLaunchKernelGGL(k_guess_shift, dim3((h->batch + 3) / 4), dim3(256), 0, st, ip, (const double*)h->dU, h->N);
             else hipLaunchKernelGGL(k_guess_iterate, dim3((h->batch + 3) / 4), dim3(256), 0, st, ip);
             HIP_TRY(h, hipGetLastError());
@@ -1825,6 +1835,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
     auto flush_admm_inst = [&]() -> int {   // the two-launch path of per-instance models: k_admm_inst on its own
         if (!inst_pending) return ALMPC_OK;
         inst_pending = false;
+        HIP_TRY(h, ev0());
         const size_t l = (12 * (size_t)h->nzs + 64 + 2 * (size_t)h->m) * sizeof(double);
         if (l > 64 * 1024)
             HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(k_admm_inst), (size_t)(l)));
@@ -1856,6 +1867,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
     }
     auto flush_admm = [&]() -> int {  // the two-kernel path: ADMM on its own
         { const int rci_ = flush_admm_inst(); if (rci_ != ALMPC_OK) return rci_; }
+        HIP_TRY(h, ev0());
         if (admm_pending) {
             admm_pending = false;
             HIP_TRY(h, launch_admm(h->nrb, h->ks, ap, admm_grid, admm_lds, st));
@@ -2052,7 +2064,8 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
     // its cap, a non-finite or indefinite condensed problem) are redone in the multiple-shooting form, from the step's own result
     if (h->fallback && !h->ltv && h->mc == 0 && o.polish) HIP_TRY(h, launch_riccati(h, 1, h->dU, 0));
     if (timing) {
-        HIP_TRY(h, hipEventRecord(ev[3], st));
+        if (ev0_done) HIP_TRY(h, hipEventRecord(ev[3], st));
+        h->ev_two[h->ev_used] = ev0_done ? 0 : 1;
         h->ev_used += 1;
     }
     return io_step_done();
@@ -2150,6 +2163,10 @@ int almpc_timing_summary(almpc_handle* h, int* steps, double* ms_admm, double* m
     for (size_t sidx = 0; sidx < h->ev_used; ++sidx) {
         hipEvent_t* ev = &h->ev[4 * sidx];
         float f = 0;
+        if (h->ev_two[sidx]) {   // one-kernel step: the pair around the kernel is all there is
+            HIP_TRY(h, hipEventElapsedTime(&f, ev[1], ev[2])); p += f; t += f;
+            continue;
+        }
         HIP_TRY(h, hipEventElapsedTime(&f, ev[0], ev[1])); a += f;
         HIP_TRY(h, hipEventElapsedTime(&f, ev[1], ev[2])); p += f;
         HIP_TRY(h, hipEventElapsedTime(&f, ev[2], ev[3])); r += f;
@@ -2172,6 +2189,11 @@ int almpc_timing_samples(almpc_handle* h, int cap, int* count, float* ms_admm, f
     for (size_t sidx = 0; sidx < nrec; ++sidx) {
         hipEvent_t* ev = &h->ev[4 * sidx];
         float f = 0;
+        if (h->ev_two[sidx]) {
+            HIP_TRY(h, hipEventElapsedTime(&f, ev[1], ev[2]));
+            if (ms_admm) ms_admm[sidx] = 0; if (ms_polish) ms_polish[sidx] = f; if (ms_rollout) ms_rollout[sidx] = 0; if (ms_total) ms_total[sidx] = f;
+            continue;
+        }
         HIP_TRY(h, hipEventElapsedTime(&f, ev[0], ev[1])); if (ms_admm) ms_admm[sidx] = f;
         HIP_TRY(h, hipEventElapsedTime(&f, ev[1], ev[2])); if (ms_polish) ms_polish[sidx] = f;
         HIP_TRY(h, hipEventElapsedTime(&f, ev[2], ev[3])); if (ms_rollout) ms_rollout[sidx] = f;
@@ -2186,12 +2208,18 @@ int almpc_get_timing(almpc_handle* h, float* ms_admm, float* ms_polish, float* m
     if (!(h->flags & ALMPC_FLAG_TIMING) || h->ev_used == 0) return fail(h, ALMPC_ERR_INVALID, "timing not enabled or no step timed yet");
     HIP_TRY(h, hipSetDevice(h->device));
     hipEvent_t* ev = &h->ev[4 * (h->ev_used - 1)];
-    HIP_TRY(h, hipEventSynchronize(ev[3]));
     float a = 0, p = 0, r = 0, t = 0;
+    if (h->ev_two[h->ev_used - 1]) {
+        HIP_TRY(h, hipEventSynchronize(ev[2]));
+        HIP_TRY(h, hipEventElapsedTime(&p, ev[1], ev[2]));
+        t = p;
+    } else {
+    HIP_TRY(h, hipEventSynchronize(ev[3]));
     HIP_TRY(h, hipEventElapsedTime(&a, ev[0], ev[1]));
     HIP_TRY(h, hipEventElapsedTime(&p, ev[1], ev[2]));
     HIP_TRY(h, hipEventElapsedTime(&r, ev[2], ev[3]));
     HIP_TRY(h, hipEventElapsedTime(&t, ev[0], ev[3]));
+    }
     if (ms_admm) *ms_admm = a;
     if (ms_polish) *ms_polish = p;
     if (ms_rollout) *ms_rollout = r;

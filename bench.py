@@ -772,7 +772,7 @@ def main():
                 solver.calculate(opts, sync=False)
                 ss.start_from(solver)
                 ss.calculate(sync=False)
-            ss.synchronize()
+                ss.synchronize()    # (one step at a time: the next condensed step does not run under this step's k_riccati on the other stream)
             bestc = min(bestc, time.perf_counter() - t0)
         rcn = ss.get_results(want=("status", "polish_iters", "u"))
         import mpc_oracle as mo
