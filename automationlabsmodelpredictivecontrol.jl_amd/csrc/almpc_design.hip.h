@@ -249,14 +249,24 @@ __global__ __launch_bounds__(32 * NG) void k_design_inverse_t(int nz, int nzs, c
     const int ri = threadIdx.x & 31, g = threadIdx.x >> 5;
     if (threadIdx.x == 0) *badp = 0;
     double S[AR][KC];
+    // all loads in flight before the first wait: clamped addresses instead of a branch per element (see k_design_inverse_wave)
+    double shiftv[AR];
+#pragma unroll
+    for (int a = 0; a < AR; ++a) {
+        const int i = ri + 32 * a, ic = i < nz ? i : nz - 1;
+        shiftv[a] = cshift + (dshift ? dshift[ic] : 0.0);
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            const int c = KC * g + k;
+            S[a][k] = Hs[(size_t)(c < nz ? c : nz - 1) * nzs + ic];
+        }
+    }
 #pragma unroll
     for (int a = 0; a < AR; ++a)
 #pragma unroll
         for (int k = 0; k < KC; ++k) {
             const int i = ri + 32 * a, c = KC * g + k;
-            double v = 0.0;
-            if (i < nz && c < nz) v = Hs[(size_t)c * nzs + i] + (i == c ? cshift + (dshift ? dshift[i] : 0.0) : 0.0);
-            S[a][k] = v;
+            S[a][k] = (i < nz && c < nz) ? S[a][k] + (i == c ? shiftv[a] : 0.0) : 0.0;
         }
     // The reciprocal of a pivot is a chain of five dependent FP64 operations (v_rcp_f64 + two Newton steps: ~550 cycles of latency,
     // measured with the stamps below) that every thread used to walk AFTER the barrier, i.e. on the critical path of every pivot.
@@ -372,27 +382,56 @@ __global__ __launch_bounds__(32 * NG) void k_design_inverse_t(int nz, int nzs, c
         for (int c_ = 0; c_ < 5; ++c_) g_stamps[(size_t)2 * 256 + c_] = sg_[c_];
 #endif
 }
-// ---- K5, nz <= 64: ONE WAVE per matrix, no LDS and no barrier ---------------------------------------------------------------------
-// Lane i holds row i (NCOL >= nz columns in registers).  The pivot row reaches the lanes through v_readlane (an SGPR operand of the
-// FMAs), the pivot column is each lane's own register.  To keep that register's index a compile-time constant without unrolling
-// the pivots, the row is rotated by one column after every pivot: position 0 is always the pivot column, position c holds column
-// (c + pivots done) mod NCOL.  The reciprocal of the next pivot is started one pivot early, as above.  The multi-wave kernel spends
-// three LDS round trips of ~450 cycles per pivot (stamps: tools/stamps_inverse.py); this one has no round trip at all on its chain.
+// ---- K5, nz <= 64: ONE WAVE per matrix, no barrier ------------------------------------------------------------------------------
+// Lane i holds row i (NCOL >= nz columns in registers).  A pivot is S_ij -= f_i w_j with f = pivot column / d (each lane's own
+// register) and w = pivot row, which every lane needs as NCOL scalars.  Round 2 fetched them with v_readlane (an SGPR operand per
+// FMA): 2 x v_readlane_b32 + FMA per column measured 38-44 cycles per column whatever the order (tools/microbench/inverse_wave.hip:
+// a VALU write to a scalar register costs far more than its issue slot), 1.7-2.4 k cycles per pivot.  Now the pivot row comes
+// through LDS with no cross-lane instruction at all:
+//  * the sweep keeps the matrix (anti)symmetric -- S_pj = S_jp for columns not yet used as pivots, -S_jp for the ones that were --
+//    so the pivot ROW is the pivot COLUMN with those signs: one ds_write_b64 per lane publishes it (lane j writes w_j), NCOL / 2
+//    ds_read_b128 at a wave-uniform address bring it back as VGPR operands, one v_fma_f64 per column and nothing else;
+//  * the pivot row is rescaled by the SAME FMA that eliminates the other rows: its lane takes f = 1 - 1/d, so that
+//    fma(-f, w_j, S_pj) = S_pj / d (the multiplier 1 - f carries one extra rounding of size eps d: nothing for d <= 1, which is every
+//    pivot of a Jacobi-scaled Hessian without shift; 1.7 digits on that one row for the largest shifted pivot, d = 46, of the
+//    ADMM's KKT matrix, which only feeds the working-set guess);
+//  * pivots are unrolled in blocks of eight with compile-time register indices and the register row is rotated by eight columns per
+//    block (position c holds column (c + pivots done, rounded down to eight) mod NCOL); the pivot row is published in position
+//    order, so the reads have immediate offsets;
+//  * the column of the next pivot is updated first, its pivot row is published and its reciprocal started under the other FMAs.
+// The wave talks to itself only: LDS operations of one wave execute in order, the fence keeps the compiler from reordering them.
+#ifdef INV_STAMPS
+__device__ long long g_inv_dbg[16];
+#define INV_W(N_) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_inv_dbg[N_] = __builtin_readcyclecounter(); } while (0)
+#else
+#define INV_W(N_)
+#endif
 template <int NCOL>
 __global__ __launch_bounds__(256) void k_design_inverse_wave(int nz, int nzs, int batch, const double* Hs, double cshift, const double* dshift,
                                                              double* Out, int* flag, long sHs, long sShift, long sOut, long sFlag) {
+    constexpr int PB = 8;
+    static_assert(NCOL % PB == 0 && NCOL > PB, "column count: a multiple of the pivot block");
+    __shared__ __attribute__((aligned(16))) double wbuf_all[4][2][64];
     const int lane = threadIdx.x & 63;
     const int inst = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (inst >= batch) return;
+    double* wbuf = &wbuf_all[threadIdx.x >> 6][0][0];
     Hs += (size_t)inst * sHs; Out += (size_t)inst * sOut; flag += (size_t)inst * sFlag;
     if (dshift) dshift += (size_t)inst * sShift;
     const int i = lane;
     double S[NCOL];
+    // every load is issued before the first one is waited for: the addresses are clamped into the matrix instead of branched around
+    // (a branch per element made the compiler wait for each load in turn: NCOL memory latencies in a row, 20 of the 27 us this
+    // kernel took for 40 x 40 matrices)
+    INV_W(0);
+    const int ic = i < nz ? i : nz - 1;
+    const double shift = cshift + (dshift ? dshift[ic] : 0.0);
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c) S[c] = Hs[(size_t)(c < nz ? c : nz - 1) * nzs + ic];
 #pragma unroll
     for (int c = 0; c < NCOL; ++c) {
-        double v = (i == c) ? 1.0 : 0.0;   // (padding: unit diagonal)
-        if (i < nz && c < nz) v = Hs[(size_t)c * nzs + i] + (i == c ? cshift + (dshift ? dshift[i] : 0.0) : 0.0);
-        S[c] = v;
+        const double v = S[c] + (i == c ? shift : 0.0);
+        S[c] = (i < nz && c < nz) ? v : ((i == c) ? 1.0 : 0.0);   // (padding: unit diagonal)
     }
     auto fast_rcp = [](double v) __attribute__((always_inline)) -> double {
         const double pvs = v > 0.0 ? v : 1.0;
@@ -401,43 +440,72 @@ __global__ __launch_bounds__(256) void k_design_inverse_wave(int nz, int nzs, in
         r = __builtin_fma(__builtin_fma(-pvs, r, 1.0), r, r);
         return r;
     };
+    // lane j publishes w_j of pivot pv (its entry of column pv, sign by the rule above) at the POSITION of column j
+    auto publish = [&](double colv, int pv, int rot) __attribute__((always_inline)) {
+        int pos = i - rot; if (pos < 0) pos += NCOL;
+        if (i < NCOL) wbuf[(pv & 1) * 64 + pos] = (i < pv) ? -colv : colv;
+    };
     bool bad = false;
     double piv = readlane_d(S[0], 0);
+    INV_W(1);
     double ip = fast_rcp(piv);
+    int nrot = 0;
+    publish(S[0], 0, 0);
 #pragma unroll 1
-    for (int pv = 0; pv < nz; ++pv) {
-        if (!(piv > 0.0)) bad = true;
-        const bool isp = i == pv;
-        const double f = isp ? 0.0 : S[0] * ip;      // the pivot row itself is rescaled, not eliminated
-        // the next pivot first: column at position 1, row pv + 1
-        const int pn = pv + 1 < 64 ? pv + 1 : 63;
-        double w1 = readlane_d(S[1], pv);
-        double s1 = __builtin_fma(-f, w1, S[1]);
-        if (isp) s1 *= ip;
-        S[1] = s1;
-        const double npiv = readlane_d(s1, pn);
-        const double nip = fast_rcp(npiv);
+    for (int p0 = 0; p0 < nz; p0 += PB) {
+        INV_W(4 + (p0 >> 3));
 #pragma unroll
-        for (int c = 2; c < NCOL; ++c) {
-            const double w = readlane_d(S[c], pv);
-            double v = __builtin_fma(-f, w, S[c]);
-            if (isp) v *= ip;
-            S[c] = v;
+        for (int k = 0; k < PB; ++k) {
+            const int pv = p0 + k;
+            if (pv < nz) {   // (uniform)
+                if (!(piv > 0.0)) bad = true;
+                wave_fence_lds();
+                const double* w = wbuf + (pv & 1) * 64;
+                const bool isp = i == pv;
+                const double f = isp ? 1.0 - ip : S[k] * ip;
+                // the next pivot first: column at position k + 1, row pv + 1
+                const int pn = pv + 1 < 64 ? pv + 1 : 63;
+                S[k + 1] = __builtin_fma(-f, w[k + 1], S[k + 1]);
+                publish(S[k + 1], pv + 1, k + 1 == PB ? nrot + PB : nrot);
+#ifdef INV_EXP_NOCHAIN
+                const double npiv = piv + 1e-9;
+                const double nip = ip + 1e-9;
+#else
+                const double npiv = readlane_d(S[k + 1], pn);
+                const double nip = fast_rcp(npiv);
+#endif
+#ifdef INV_EXP_NOFMA
+                if (pv < 0)
+#endif
+#pragma unroll
+                for (int c = 0; c < NCOL; c += 2) {
+                    const d2 wc = *reinterpret_cast<const d2*>(w + c);
+                    if (c != k && c != k + 1) S[c] = __builtin_fma(-f, wc[0], S[c]);
+                    if (c + 1 != k && c + 1 != k + 1) S[c + 1] = __builtin_fma(-f, wc[1], S[c + 1]);
+                }
+                S[k] = isp ? ip : -f;            // column pv of the inverse so far
+                piv = npiv; ip = nip;
+            }
         }
-        const double c0 = isp ? ip : -f;             // column pv of the inverse so far
-        // rotate: the next pivot column moves to position 0, the finished one to the end
+        // rotate by one block: the next eight pivot columns move to positions 0..7, the finished ones to the end
+        double t[PB];
 #pragma unroll
-        for (int c = 0; c + 1 < NCOL; ++c) S[c] = S[c + 1];
-        S[NCOL - 1] = c0;
-        piv = npiv; ip = nip;
+        for (int k = 0; k < PB; ++k) t[k] = S[k];
+#pragma unroll
+        for (int c = 0; c + PB < NCOL; ++c) S[c] = S[c + PB];
+#pragma unroll
+        for (int k = 0; k < PB; ++k) S[NCOL - PB + k] = t[k];
+        nrot += PB;
     }
-    // position c holds column (c + nz) mod NCOL
+    INV_W(2);
+    // position c holds column (c + nrot) mod NCOL
 #pragma unroll
     for (int c = 0; c < NCOL; ++c) {
-        const int col = (c + nz) % NCOL;
+        const int col = (c + nrot) % NCOL;
         if (i < nz && col < nz) Out[(size_t)col * nzs + i] = S[c];
     }
     if (__any(bad) && lane == 0) atomicExch(flag, 2);
+    INV_W(3);
 }
 
 // launcher: the smallest register tile that holds the matrix

@@ -272,6 +272,22 @@ def test_relin_pipeline_on_device_equals_host_path(capi, mo):
         for key in ("status", "iters", "polish_iters", "u", "x", "e_u", "e_x"):
             assert np.array_equal(a[key], b[key]), key
         assert (a["status"] == 0).mean() >= 0.98 and t["design_ms"] > 0 and t["step_ms"] > 0
+        if S is None:
+            # with the structured fallback (input box, no input-rate weight) nothing stays unsolved: the instances the condensed path
+            # gives up on are solved by k_riccati, the others keep their results bit for bit
+            sf = capi.Solver(n, m, N, batch, structured_fallback=True)
+            sf.relin_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, x_ref, u_ref, Q, R, None, P, [-1, -1], [1, 1], act=f.act)
+            sf.update_initialization(X0)
+            sf.relin_fnn_step(opts)
+            c = sf.get_results()
+            sf.close()
+            assert np.all(c["status"] == 0), np.bincount(c["status"])
+            ok = a["status"] == 0
+            assert np.array_equal(a["u"][ok], c["u"][ok])
+            for i in np.nonzero(~ok)[0][:4]:
+                pi = mo.make_problem(A[i], B[i], N, [-1, -1], [1, 1], x_ref=x_ref, u_ref=u_ref, P=P)
+                ex = mo.rollout(pi, X0[i], (c["u"][i] - pi.u_ref).T.reshape(-1))["x"]
+                assert np.abs(c["x"][i] - ex).max() <= 1e-9 * max(1.0, np.abs(ex).max())
         for i in range(0, batch, 23):
             if a["status"][i] == 0:
                 p = mo.make_problem(A[i], B[i], N, [-1, -1], [1, 1], x_ref=x_ref, u_ref=u_ref, s=0.0 if S is None else 0.3, P=P)
