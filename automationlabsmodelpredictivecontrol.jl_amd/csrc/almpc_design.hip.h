@@ -459,6 +459,12 @@ __global__ __launch_bounds__(256) void k_design_inverse_wave(int nz, int nzs, in
             const int pv = p0 + k;
             if (pv < nz) {   // (uniform)
                 if (!(piv > 0.0)) bad = true;
+#ifdef INV_STAMPS
+#define INV_P(N_) do { if (k == 3 && p0 == 8) { __builtin_amdgcn_sched_barrier(0); INV_W(N_); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define INV_P(N_)
+#endif
+                INV_P(10);
                 wave_fence_lds();
                 const double* w = wbuf + (pv & 1) * 64;
                 const bool isp = i == pv;
@@ -471,8 +477,11 @@ __global__ __launch_bounds__(256) void k_design_inverse_wave(int nz, int nzs, in
                 const double npiv = piv + 1e-9;
                 const double nip = ip + 1e-9;
 #else
+                INV_P(11);
                 const double npiv = readlane_d(S[k + 1], pn);
+                INV_P(12);
                 const double nip = fast_rcp(npiv);
+                INV_P(13);
 #endif
 #ifdef INV_EXP_NOFMA
                 if (pv < 0)
@@ -485,6 +494,7 @@ __global__ __launch_bounds__(256) void k_design_inverse_wave(int nz, int nzs, in
                 }
                 S[k] = isp ? ip : -f;            // column pv of the inverse so far
                 piv = npiv; ip = nip;
+                INV_P(14);
             }
         }
         // rotate by one block: the next eight pivot columns move to positions 0..7, the finished ones to the end
@@ -508,6 +518,146 @@ __global__ __launch_bounds__(256) void k_design_inverse_wave(int nz, int nzs, in
     INV_W(3);
 }
 
+// ---- K5, 64 < nz <= 128: four waves per matrix, wave q = columns 32 q .. 32 q + 31 of ALL rows (lane l: rows l and l + 64) --------
+// The one-wave scheme above with the columns dealt to four waves.  Per pivot ONE barrier and one publication: the wave that owns the
+// pivot column writes w (the pivot row, = its column with the signs of the sweep's antisymmetry) and the reciprocal of the pivot,
+// which the lane holding it has computed itself -- no v_readlane anywhere; every wave then reads its two f sources (its own rows of
+// w), 16 ds_read_b128 at a wave-uniform address for its 32 columns, and issues 64 FMAs.  The column of the next pivot is updated and
+// published first, under the other columns.  Against the 4 x 16 register tile (k_design_inverse_t: two barrier round trips and a pivot
+// column AND row per pivot, 2.3-2.8 k cycles per pivot): 112 -> 41 us for 256 matrices of 100 x 100 (the SQP iteration), 1.31 -> 0.6 ms
+// for 4096 of 120 x 120 (the batched design).
+// HOIST: all sixteen pivot-row reads of a wave are issued right behind the two reads of the chain (one matrix per CU: their latency
+// runs under the chain, 65 -> 58 us for 256 matrices of 100 x 100); without it they are issued four at a time between the FMAs (two
+// or more workgroups per CU: a chain read does not queue behind 8 waves x 16 reads in the CU's one LDS pipeline, 0.63 against 1.03 ms
+// for 4096 matrices of 120 x 120).
+template <bool HOIST>
+__global__ __launch_bounds__(256) void k_design_inverse_c32(int nz, int nzs, const double* Hs, double cshift, const double* dshift,
+                                                            double* Out, int* flag, long sHs, long sShift, long sOut, long sFlag) {
+    __shared__ __attribute__((aligned(16))) double wb[2][128];
+    __shared__ double ips[2];
+    __shared__ int badp;
+    Hs += blockIdx.y * sHs; Out += blockIdx.y * sOut; flag += blockIdx.y * sFlag;
+    if (dshift) dshift += blockIdx.y * sShift;
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    if (threadIdx.x == 0) badp = 0;
+    double S[2][32];
+    double shiftv[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {   // every load in flight before the first wait (clamped addresses, no branch per element)
+        const int i = lane + 64 * a, ic = i < nz ? i : nz - 1;
+        shiftv[a] = cshift + (dshift ? dshift[ic] : 0.0);
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            const int col = 32 * q + c;
+            S[a][c] = Hs[(size_t)(col < nz ? col : nz - 1) * nzs + ic];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            const int i = lane + 64 * a, col = 32 * q + c;
+            S[a][c] = (i < nz && col < nz) ? S[a][c] + (i == col ? shiftv[a] : 0.0) : (i == col ? 1.0 : 0.0);
+        }
+    auto fast_rcp = [](double v) __attribute__((always_inline)) -> double {
+        const double pvs = v > 0.0 ? v : 1.0;
+        double r = __builtin_amdgcn_rcp(pvs);
+        r = __builtin_fma(__builtin_fma(-pvs, r, 1.0), r, r);
+        r = __builtin_fma(__builtin_fma(-pvs, r, 1.0), r, r);
+        return r;
+    };
+    if (q == 0) {   // pivot 0: column 0 as it is
+        wb[0][lane] = S[0][0]; wb[0][lane + 64] = S[1][0];
+        if (lane == 0) { ips[0] = fast_rcp(S[0][0]); if (!(S[0][0] > 0.0)) badp = 1; }
+    }
+#pragma unroll 1
+    for (int qp = 0; qp < 4; ++qp) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const int pv = 32 * qp + k;
+            if (pv < nz) {   // (uniform)
+#ifdef INV_STAMPS
+#define INV_Q(N_) do { if (k == 5 && qp == 0) { __builtin_amdgcn_sched_barrier(0); INV_W(N_); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define INV_Q(N_)
+#endif
+                INV_Q(9);
+                __syncthreads();
+                INV_Q(10);
+                // every LDS read of this pivot is issued here, ahead of the publication below (the compiler will not move a read
+                // across a write to the other half of the buffer): their latency runs under the chain of the next pivot
+                const double* w = wb[pv & 1];
+                const double ip = ips[pv & 1];
+                double wi[2];
+                // (relaxed atomic loads = plain ds_read_b64 that the optimiser does not sink into a branch behind the sixteen others)
+                wi[0] = __hip_atomic_load(wb[pv & 1] + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                wi[1] = __hip_atomic_load(wb[pv & 1] + lane + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                double wreg[32];
+                if (HOIST) {
+#pragma unroll
+                    for (int c = 0; c < 32; c += 2) {
+                        const d2 t = *reinterpret_cast<const d2*>(w + 32 * q + c);
+                        wreg[c] = t[0]; wreg[c + 1] = t[1];
+                    }
+                }
+                double f[2];
+                bool isp[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int i = lane + 64 * a;
+                    isp[a] = i == pv;
+                    f[a] = isp[a] ? 1.0 - ip : ((i < pv) ? -wi[a] : wi[a]) * ip;   // S_i,pv / d; the pivot row is rescaled by the same FMA
+                }
+                INV_Q(11);
+                // the column of the next pivot first (local index kn in the wave that owns it; an ordinary column in the others)
+                const int kn = (k + 1) & 31;
+                const int owner_next = (k + 1 < 32) ? qp : qp + 1;
+                if (!HOIST) wreg[kn] = w[32 * q + kn];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) S[a][kn] = __builtin_fma(-f[a], wreg[kn], S[a][kn]);
+                if (q == owner_next && pv + 1 < nz) {
+                    double* wn = wb[(pv + 1) & 1];
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        const int i = lane + 64 * a;
+                        wn[i] = (i <= pv) ? -S[a][kn] : S[a][kn];
+                    }
+                    const double cand = ((pv + 1) >> 6) ? S[1][kn] : S[0][kn];
+                    const double r = fast_rcp(cand);
+                    if (lane == ((pv + 1) & 63)) { ips[(pv + 1) & 1] = r; if (!(cand > 0.0)) badp = 1; }
+                }
+                INV_Q(12);
+                // the other columns
+#pragma unroll
+                for (int c = 0; c < 32; ++c) {
+                    if (!HOIST && (c & 1) == 0) {
+                        const d2 t = *reinterpret_cast<const d2*>(w + 32 * q + c);
+                        wreg[c] = t[0]; wreg[c + 1] = t[1];
+                    }
+                    if (c == kn) continue;
+                    if (c == k && q == qp) {   // column pv of the inverse so far
+#pragma unroll
+                        for (int a = 0; a < 2; ++a) S[a][k] = isp[a] ? ip : -f[a];
+                        continue;
+                    }
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) S[a][c] = __builtin_fma(-f[a], wreg[c], S[a][c]);
+                }
+                INV_Q(13);
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            const int i = lane + 64 * a, col = 32 * q + c;
+            if (i < nz && col < nz) Out[(size_t)col * nzs + i] = S[a][c];
+        }
+    __syncthreads();
+    if (threadIdx.x == 0 && badp) atomicExch(flag, 2);
+}
+
 // launcher: the smallest register tile that holds the matrix
 inline void launch_design_inverse(dim3 grid, size_t lds, hipStream_t st, int nz, int nzs, const double* Hs, double cshift, const double* dshift,
                                   double* Out, int* flag, long sHs, long sShift, long sOut, long sFlag) {
@@ -518,6 +668,10 @@ inline void launch_design_inverse(dim3 grid, size_t lds, hipStream_t st, int nz,
         if (nz <= 16) INV_WAVE(16); else if (nz <= 32) INV_WAVE(32); else if (nz <= 48) INV_WAVE(48); else INV_WAVE(64);
 #undef INV_WAVE
     } else if (nz <= 64) hipLaunchKernelGGL((k_design_inverse_t<2, 8>), grid, dim3(DESIGN_INVERSE_THREADS), lds, st, nz, nzs, Hs, cshift, dshift, Out, flag, sHs, sShift, sOut, sFlag);
+    else if (!getenv("ALMPC_INV_TILE")) {
+        if (grid.y <= 256) hipLaunchKernelGGL(k_design_inverse_c32<true>, grid, dim3(256), 0, st, nz, nzs, Hs, cshift, dshift, Out, flag, sHs, sShift, sOut, sFlag);
+        else hipLaunchKernelGGL(k_design_inverse_c32<false>, grid, dim3(256), 0, st, nz, nzs, Hs, cshift, dshift, Out, flag, sHs, sShift, sOut, sFlag);
+    }
     else hipLaunchKernelGGL((k_design_inverse_t<4, 16>), grid, dim3(DESIGN_INVERSE_THREADS), lds, st, nz, nzs, Hs, cshift, dshift, Out, flag, sHs, sShift, sOut, sFlag);
 }
 

@@ -35,7 +35,9 @@ int main(int argc, char** argv) {
 #ifdef INV_STAMPS
     { long long d[16]; hipMemcpyFromSymbol(d, HIP_SYMBOL(g_inv_dbg), sizeof(d));
       printf("cycles: loads %lld, pivots %lld (%.0f per pivot), stores %lld\n", d[1] - d[0], d[2] - d[1], (double)(d[2] - d[1]) / nz, d[3] - d[2]);
-      printf("  blocks of 8 pivots:"); for (int q = 0; q * 8 < nz; ++q) printf(" %lld", (q * 8 + 8 < nz ? d[5 + q] : d[2]) - d[4 + q]); printf("\n"); }
+      printf("  blocks of 8 pivots:"); for (int q = 0; q * 8 < nz; ++q) printf(" %lld", (q * 8 + 8 < nz ? d[5 + q] : d[2]) - d[4 + q]); printf("\n");
+      if (nz > 64) printf("  four-wave kernel, pivot 5, wave 0: barrier %lld, reads + f %lld, next column + publication %lld, other columns %lld\n", d[10] - d[9], d[11] - d[10], d[12] - d[11], d[13] - d[12]);
+      else printf("  pivot 11: w[k+1] + fma + publish %lld, readlane %lld, reciprocal %lld, other columns %lld\n", d[11] - d[10], d[12] - d[11], d[13] - d[12], d[14] - d[13]); }
 #endif
     std::vector<double> O(A.size()); std::vector<int> F(b);
     hipMemcpy(O.data(), dO, O.size() * 8, hipMemcpyDeviceToHost); hipMemcpy(F.data(), dF, b * 4, hipMemcpyDeviceToHost);
