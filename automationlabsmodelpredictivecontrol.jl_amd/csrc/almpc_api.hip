@@ -40,6 +40,8 @@ struct almpc_handle {
     double *dMinvFrag = nullptr, *dVFrag = nullptr, *dHFrag = nullptr, *dFFrag = nullptr, *dG = nullptr;
     double *dD = nullptr, *dUmin = nullptr, *dUmax = nullptr, *dA = nullptr, *dB = nullptr;
     double *dXref = nullptr, *dUref = nullptr, *dFS = nullptr, *dV0S = nullptr, *dRho = nullptr;
+    size_t ref_cap[3] = {0, 0, 0};   // doubles in dXref, dUref, dFS (= dV0S) as almpc_set_reference allocated them: re-used while the sizes stay
+    double *wQ = nullptr, *wR = nullptr, *wS = nullptr;   // design weights on the device (almpc_design_batched / _ltv)
     int rho_mode = 0;  // 0 scalar rho (OSQP), 1 stiffness profile rho / G_ii
     // blocked rollout of the shared model (rollout_blocked): [Gamma_s | Phi_s] rows per lane, built at design time
     double* dRollM = nullptr;
@@ -226,7 +228,7 @@ void free_all(almpc_handle* h) {
                     h->dXref, h->dUref, h->dFS, h->dV0S, h->dRho, h->dRollM, h->dX0, h->dXs, h->dZs, h->dYs, h->dV0, h->dW, h->dX, h->dEx,
                     h->dU, h->dEu, h->dStatus, h->dIters, h->dPiters, h->dPerm, h->dYflags, h->dSglobal, h->dGhat, h->dGnorm, h->dXmin,
                     h->dXmax, h->dRowTraj, h->dRowEq, h->dRowXidx, h->dRowState, h->dRowMap, h->dGhatE, h->dWinvE, h->lA, h->lB, h->lC, h->lE, h->bA, h->bB, h->bMinv, h->bG, h->bHs, h->bFs,
-                    h->bVs, h->bD, h->bRho, h->bH, h->bF, h->bPhi, h->bGk, h->bGam, h->bW, h->bWP, h->bP, h->bFlag, h->bQ, h->dOverflow,
+                    h->bVs, h->bD, h->bRho, h->bH, h->bF, h->bPhi, h->bGk, h->bGam, h->bW, h->bWP, h->bP, h->bFlag, h->bQ, h->dOverflow, h->wQ, h->wR, h->wS,
                     h->sqp.W_in, h->sqp.W_h, h->sqp.b_h, h->sqp.W_out, h->sqp.A, h->sqp.B, h->sqp.c, h->sqp.fval, h->sqp.ebar,
                     h->sqp.qadd, h->sqp.xref, h->sqp.uref, h->sqp.Q, h->sqp.R, h->sqp.S, h->sqp.bad, h->sqp.stats, h->sqp.mer, h->sqp.xback, h->sqp.uback, h->sqp.dxback, h->sqp.vback};
     for (void* p : ptrs)
@@ -948,6 +950,15 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
     h->designed = false;  // the previous design is overwritten below; set again by the last statement on success
     h->sqp.ready = h->sqp.started = false;
     h->relin.ready = false;
+    // ALMPC_DESIGN_TRACE=1: host-side time between the marks below on stderr (where a design call spends its wall clock)
+    const bool trace_ = getenv("ALMPC_DESIGN_TRACE") != nullptr;
+    auto t_mark_ = std::chrono::steady_clock::now();
+    auto tr = [&](const char* what) {
+        if (!trace_) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[almpc design] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(now - t_mark_).count());
+        t_mark_ = now;
+    };
     HIP_TRY(h, hipSetDevice(h->device));
     const int n = h->n, m = h->m, N = h->N, nz = h->nz, nzs = h->nzs;
     const size_t b = (size_t)h->batch;
@@ -985,15 +996,20 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
     h->rho = rho; h->sigma = sigma;
     const int useR = Rm[0] != 0.0, useS = useR && Sm[0] != 0.0;
     h->useS = useS;
+    tr("host preparation");
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    tr("stream idle");
     // state rows (almpc_set_state_box, almpc_set_terminal_equality): one constraint-space matrix per instance
     { const int rc_ = setup_state_rows(h, h->boxmin.empty() ? nullptr : h->boxmin.data(), h->boxmax.empty() ? nullptr : h->boxmax.data(), true);
       if (rc_ != ALMPC_OK) return rc_; }
     { const int rc_ = ensure_batched_alloc(h); if (rc_ != ALMPC_OK) return rc_; }
     hipStream_t st = h->stream;
-    double *dQ = nullptr, *dR = nullptr, *dS = nullptr;
-    HIP_TRY(h, dalloc(&dQ, (size_t)n * n)); HIP_TRY(h, dalloc(&dR, (size_t)m * m)); HIP_TRY(h, dalloc(&dS, (size_t)m * m));
-    auto release = [&]() { (void)hipFree(dQ); (void)hipFree(dR); (void)hipFree(dS); };
+    tr("state rows + allocation");
+    if (!h->wQ) HIP_TRY(h, dalloc(&h->wQ, (size_t)n * n));
+    if (!h->wR) HIP_TRY(h, dalloc(&h->wR, (size_t)m * m));
+    if (!h->wS) HIP_TRY(h, dalloc(&h->wS, (size_t)m * m));
+    double *dQ = h->wQ, *dR = h->wR, *dS = h->wS;   // (kept with the handle: three hipMalloc + hipFree per design cost 0.15 ms)
+    auto release = [&]() {};
 #define BTRY(call)                                                                                                  \
     do {                                                                                                            \
         hipError_t e_ = (call);                                                                                     \
@@ -1006,6 +1022,7 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
     BTRY(hipMemcpyAsync(dR, Rm.data(), Rm.size() * sizeof(double), hipMemcpyHostToDevice, st));
     BTRY(hipMemcpyAsync(dS, Sm.data(), Sm.size() * sizeof(double), hipMemcpyHostToDevice, st));
     BTRY(hipMemsetAsync(h->bFlag, 0, b * sizeof(int), st));
+    tr("weights alloc + copies queued");
     const DesignStrides ds = batched_strides(h, p_inst);
     const unsigned gb = (unsigned)b;
     double *dAll = nullptr, *dBll = nullptr, *dC = nullptr, *dE = nullptr, *dQa = nullptr;  // LTV staging (freed below)
@@ -1049,6 +1066,7 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
         BTRY(launch_batched_design(h, ds, useR, useS, dQ, dR, dS, rho, sigma));
         if (h->mc > 0) BTRY(launch_ghat_inst(h, nullptr, nullptr));
     }
+    tr("kernels queued");
     std::vector<int> flags(b, 0);
     BTRY(hipMemcpyAsync(flags.data(), h->bFlag, b * sizeof(int), hipMemcpyDeviceToHost, st));
     // host copies of instance 0 for almpc_get_design (every instance: almpc_get_design_instance)
@@ -1057,8 +1075,10 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
     BTRY(hipMemcpyAsync(h->F.data(), h->bF, h->F.size() * sizeof(double), hipMemcpyDeviceToHost, st));
     BTRY(hipMemcpyAsync(h->d.data(), h->bD, h->d.size() * sizeof(double), hipMemcpyDeviceToHost, st));
     BTRY(hipStreamSynchronize(st));
+    tr("device done");
 #undef BTRY
     release();
+    tr("weights freed");
     for (size_t i = 0; i < b; ++i)
         if (flags[i] != 0)
             return fail(h, ALMPC_ERR_NUMERIC, "design_batched: instance " + std::to_string(i) +
@@ -1078,6 +1098,7 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
         std::vector<double> xr((size_t)n * (N + 1), 0.0), ur((size_t)nz, 0.0);
         const int rc = almpc_set_reference(h, xr.data(), ur.data(), 0);
         if (rc != ALMPC_OK) h->designed = false;
+        tr("flags + set_reference");
         return rc;
     }
     // LTV: the QP variable is v = u - ubar, so ubar takes the place of the input reference (bounds umin - ubar <= v, u = v + ubar);
@@ -1229,6 +1250,7 @@ int almpc_relin_fnn_setup(almpc_handle* h, int H, int L, int activation, const d
     // shared references; the scaled input-rate gradient fS_i = d_i .* gS and v0S_i = -G_i fS_i are per instance (re-made every step)
     for (double** pp_ : {&h->dXref, &h->dUref, &h->dFS, &h->dV0S})
         if (*pp_) { (void)hipFree(*pp_); *pp_ = nullptr; }
+    h->ref_cap[0] = h->ref_cap[1] = h->ref_cap[2] = 0;
     HIP_TRY(h, up(&h->dXref, xr.data(), xr.size())); HIP_TRY(h, up(&h->dUref, ur.data(), ur.size()));
     HIP_TRY(h, dalloc(&h->dFS, b * nz)); HIP_TRY(h, dalloc(&h->dV0S, b * nz));
     HIP_TRY(h, hipMemset(h->dFS, 0, b * nz * sizeof(double))); HIP_TRY(h, hipMemset(h->dV0S, 0, b * nz * sizeof(double)));
@@ -1410,6 +1432,7 @@ int almpc_sqp_fnn_setup(almpc_handle* h, int H, int L, int activation, const dou
     q.step_rule = keep_rule;
     q.structured_qp = keep_structured;
     h->dXref = h->dUref = h->dFS = h->dV0S = nullptr;
+    h->ref_cap[0] = h->ref_cap[1] = h->ref_cap[2] = 0;
     auto up = [&](double** d, const double* src, size_t cnt) -> hipError_t {
         hipError_t e = dalloc(d, cnt ? cnt : 1);
         if (e == hipSuccess && src && cnt) e = hipMemcpy(*d, src, cnt * sizeof(double), hipMemcpyHostToDevice);
@@ -1657,6 +1680,7 @@ int almpc_set_reference(almpc_handle* h, const double* xref, const double* uref,
         h->designed = false;
         if (h->dXref) { (void)hipFree(h->dXref); h->dXref = nullptr; }
         if (h->dUref) { (void)hipFree(h->dUref); h->dUref = nullptr; }
+        h->ref_cap[0] = h->ref_cap[1] = h->ref_cap[2] = 0;
         HIP_TRY(h, dalloc(&h->dXref, cnt * xs));
         HIP_TRY(h, dalloc(&h->dUref, cnt * us));
         HIP_TRY(h, hipMemcpy(h->dXref, xref, cnt * xs * sizeof(double), hipMemcpyHostToDevice));
@@ -1669,15 +1693,20 @@ int almpc_set_reference(almpc_handle* h, const double* xref, const double* uref,
     h->sqp.ready = h->sqp.started = false;  // the SQP iterate lived in the reference buffers released here
     h->relin.ready = false;                 // ... and so did the re-linearisation pipeline's references
     h->designed = false;                    // the reference buffers are replaced below: designed again on success only
-    if (h->dXref) { (void)hipFree(h->dXref); h->dXref = nullptr; }
-    if (h->dUref) { (void)hipFree(h->dUref); h->dUref = nullptr; }
-    if (h->dFS) { (void)hipFree(h->dFS); h->dFS = nullptr; }
-    if (h->dV0S) { (void)hipFree(h->dV0S); h->dV0S = nullptr; }
-    HIP_TRY(h, dalloc(&h->dXref, cnt * xs));
-    HIP_TRY(h, dalloc(&h->dUref, cnt * us));
     const size_t fcnt = h->batched ? (size_t)h->batch : cnt;  // per-instance models: fS depends on d_i
-    HIP_TRY(h, dalloc(&h->dFS, fcnt * us));
-    HIP_TRY(h, dalloc(&h->dV0S, fcnt * us));
+    // (a re-design or a new reference of the same shape keeps the four buffers: hipFree + hipMalloc cost ~0.1 ms each)
+    if (!(h->dXref && h->dUref && h->dFS && h->dV0S && h->ref_cap[0] == cnt * xs && h->ref_cap[1] == cnt * us && h->ref_cap[2] == fcnt * us)) {
+        if (h->dXref) { (void)hipFree(h->dXref); h->dXref = nullptr; }
+        if (h->dUref) { (void)hipFree(h->dUref); h->dUref = nullptr; }
+        if (h->dFS) { (void)hipFree(h->dFS); h->dFS = nullptr; }
+        if (h->dV0S) { (void)hipFree(h->dV0S); h->dV0S = nullptr; }
+        h->ref_cap[0] = h->ref_cap[1] = h->ref_cap[2] = 0;
+        HIP_TRY(h, dalloc(&h->dXref, cnt * xs));
+        HIP_TRY(h, dalloc(&h->dUref, cnt * us));
+        HIP_TRY(h, dalloc(&h->dFS, fcnt * us));
+        HIP_TRY(h, dalloc(&h->dV0S, fcnt * us));
+        h->ref_cap[0] = cnt * xs; h->ref_cap[1] = cnt * us; h->ref_cap[2] = fcnt * us;
+    }
     HIP_TRY(h, hipMemcpy(h->dXref, xref, cnt * xs * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->dUref, uref, cnt * us * sizeof(double), hipMemcpyHostToDevice));
     // fS = d .* (2 D'Sbar D u_ref): the input-rate cost is on u, not e_u (src/sub/design_mpc.jl:423-446)
@@ -1697,7 +1726,11 @@ int almpc_set_reference(almpc_handle* h, const double* xref, const double* uref,
                 for (int r = 0; r < nz; ++r) f[r] *= h->d[r];
         }
     }
-    if (h->batched) {  // fS_i = d_i .* g and v0S_i = -G_i fS_i on the device, one vector per instance
+    if (h->batched && !h->useS) {   // no input-rate weight: fS_i = 0 and v0S_i = -G_i fS_i = 0 (no pass over the 0.5 GB of G_i)
+        HIP_TRY(h, hipMemsetAsync(h->dFS, 0, fcnt * us * sizeof(double), h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->dV0S, 0, fcnt * us * sizeof(double), h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    } else if (h->batched) {  // fS_i = d_i .* g and v0S_i = -G_i fS_i on the device, one vector per instance
         double* dGs = nullptr;
         HIP_TRY(h, dalloc(&dGs, cnt * us));
         hipError_t e = hipMemcpy(dGs, fS.data(), cnt * us * sizeof(double), hipMemcpyHostToDevice);

@@ -194,20 +194,28 @@ __global__ __launch_bounds__(256) void k_design_scale(int nz, int nzs, int n, co
         if (t < 128) ds[t] = v;
     }
     __syncthreads();
-    // four elements per thread and pass: eight loads in flight instead of two behind an integer division
-    for (int t0 = 4 * threadIdx.x; t0 < nz * nz; t0 += 4 * blockDim.x) {
-        double ha[4], hb[4];
-        int rr[4], cc[4];
+    // four consecutive elements per thread and pass, (column, row) carried along instead of divided out (one division per thread)
+    {
+        const int step = 4 * (int)blockDim.x, dc = step / nz, dr = step - dc * nz;
+        int t0 = 4 * threadIdx.x, c0 = t0 / nz, r0 = t0 - c0 * nz;
+        for (; t0 < nz * nz; t0 += step) {
+            double ha[4], hb[4];
+            int rr[4], cc[4];
+            int r = r0, c = c0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int t = t0 + u < nz * nz ? t0 + u : nz * nz - 1;
-            cc[u] = t / nz; rr[u] = t - cc[u] * nz;
-            ha[u] = H[(size_t)cc[u] * nz + rr[u]];
-            hb[u] = st.h_symmetric ? ha[u] : H[(size_t)rr[u] * nz + cc[u]];   // (0.5 (a + a) = a exactly)
+            for (int u = 0; u < 4; ++u) {
+                const bool in = t0 + u < nz * nz;
+                cc[u] = in ? c : nz - 1; rr[u] = in ? r : nz - 1;
+                ha[u] = H[(size_t)cc[u] * nz + rr[u]];
+                hb[u] = st.h_symmetric ? ha[u] : H[(size_t)rr[u] * nz + cc[u]];   // (0.5 (a + a) = a exactly)
+                if (++r == nz) { r = 0; ++c; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (t0 + u < nz * nz) Hs[(size_t)cc[u] * nzs + rr[u]] = ds[rr[u]] * (0.5 * (ha[u] + hb[u])) * ds[cc[u]];
+            r0 += dr; c0 += dc;
+            if (r0 >= nz) { r0 -= nz; ++c0; }
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (t0 + u < nz * nz) Hs[(size_t)cc[u] * nzs + rr[u]] = ds[rr[u]] * (0.5 * (ha[u] + hb[u])) * ds[cc[u]];
     }
     for (int t = threadIdx.x; t < nz * n; t += blockDim.x) {
         const int r = t % nz, c = t / nz;
@@ -530,8 +538,9 @@ __global__ __launch_bounds__(256) void k_design_inverse_wave(int nz, int nzs, in
 // runs under the chain, 65 -> 58 us for 256 matrices of 100 x 100); without it they are issued four at a time between the FMAs (two
 // or more workgroups per CU: a chain read does not queue behind 8 waves x 16 reads in the CU's one LDS pipeline, 0.63 against 1.03 ms
 // for 4096 matrices of 120 x 120).
-template <bool HOIST>
-__global__ __launch_bounds__(256) void k_design_inverse_c32(int nz, int nzs, const double* Hs, double cshift, const double* dshift,
+// CW: columns per wave (128 / CW waves per matrix).
+template <int CW, bool HOIST>
+__global__ __launch_bounds__(64 * (128 / CW)) void k_design_inverse_c32(int nz, int nzs, const double* Hs, double cshift, const double* dshift,
                                                             double* Out, int* flag, long sHs, long sShift, long sOut, long sFlag) {
     __shared__ __attribute__((aligned(16))) double wb[2][128];
     __shared__ double ips[2];
@@ -540,23 +549,23 @@ __global__ __launch_bounds__(256) void k_design_inverse_c32(int nz, int nzs, con
     if (dshift) dshift += blockIdx.y * sShift;
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     if (threadIdx.x == 0) badp = 0;
-    double S[2][32];
+    double S[2][CW];
     double shiftv[2];
 #pragma unroll
     for (int a = 0; a < 2; ++a) {   // every load in flight before the first wait (clamped addresses, no branch per element)
         const int i = lane + 64 * a, ic = i < nz ? i : nz - 1;
         shiftv[a] = cshift + (dshift ? dshift[ic] : 0.0);
 #pragma unroll
-        for (int c = 0; c < 32; ++c) {
-            const int col = 32 * q + c;
+        for (int c = 0; c < CW; ++c) {
+            const int col = CW * q + c;
             S[a][c] = Hs[(size_t)(col < nz ? col : nz - 1) * nzs + ic];
         }
     }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int c = 0; c < 32; ++c) {
-            const int i = lane + 64 * a, col = 32 * q + c;
+        for (int c = 0; c < CW; ++c) {
+            const int i = lane + 64 * a, col = CW * q + c;
             S[a][c] = (i < nz && col < nz) ? S[a][c] + (i == col ? shiftv[a] : 0.0) : (i == col ? 1.0 : 0.0);
         }
     auto fast_rcp = [](double v) __attribute__((always_inline)) -> double {
@@ -571,10 +580,10 @@ __global__ __launch_bounds__(256) void k_design_inverse_c32(int nz, int nzs, con
         if (lane == 0) { ips[0] = fast_rcp(S[0][0]); if (!(S[0][0] > 0.0)) badp = 1; }
     }
 #pragma unroll 1
-    for (int qp = 0; qp < 4; ++qp) {
+    for (int qp = 0; qp < 128 / CW; ++qp) {
 #pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            const int pv = 32 * qp + k;
+        for (int k = 0; k < CW; ++k) {
+            const int pv = CW * qp + k;
             if (pv < nz) {   // (uniform)
 #ifdef INV_STAMPS
 #define INV_Q(N_) do { if (k == 5 && qp == 0) { __builtin_amdgcn_sched_barrier(0); INV_W(N_); __builtin_amdgcn_sched_barrier(0); } } while (0)
@@ -592,11 +601,11 @@ __global__ __launch_bounds__(256) void k_design_inverse_c32(int nz, int nzs, con
                 // (relaxed atomic loads = plain ds_read_b64 that the optimiser does not sink into a branch behind the sixteen others)
                 wi[0] = __hip_atomic_load(wb[pv & 1] + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 wi[1] = __hip_atomic_load(wb[pv & 1] + lane + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                double wreg[32];
+                double wreg[CW];
                 if (HOIST) {
 #pragma unroll
-                    for (int c = 0; c < 32; c += 2) {
-                        const d2 t = *reinterpret_cast<const d2*>(w + 32 * q + c);
+                    for (int c = 0; c < CW; c += 2) {
+                        const d2 t = *reinterpret_cast<const d2*>(w + CW * q + c);
                         wreg[c] = t[0]; wreg[c + 1] = t[1];
                     }
                 }
@@ -610,12 +619,16 @@ __global__ __launch_bounds__(256) void k_design_inverse_c32(int nz, int nzs, con
                 }
                 INV_Q(11);
                 // the column of the next pivot first (local index kn in the wave that owns it; an ordinary column in the others)
-                const int kn = (k + 1) & 31;
-                const int owner_next = (k + 1 < 32) ? qp : qp + 1;
-                if (!HOIST) wreg[kn] = w[32 * q + kn];
+                const int kn = (k + 1) % CW;
+                const int owner_next = (k + 1 < CW) ? qp : qp + 1;
+                if (!HOIST) wreg[kn] = w[CW * q + kn];
 #pragma unroll
                 for (int a = 0; a < 2; ++a) S[a][kn] = __builtin_fma(-f[a], wreg[kn], S[a][kn]);
+#ifdef INV_EXP_NOPUBLISH
+                if (q == owner_next && pv + 1 < nz && pv < 0) {
+#else
                 if (q == owner_next && pv + 1 < nz) {
+#endif
                     double* wn = wb[(pv + 1) & 1];
 #pragma unroll
                     for (int a = 0; a < 2; ++a) {
@@ -628,10 +641,13 @@ __global__ __launch_bounds__(256) void k_design_inverse_c32(int nz, int nzs, con
                 }
                 INV_Q(12);
                 // the other columns
+#ifdef INV_EXP_NOBULK
+                if (pv < 0)
+#endif
 #pragma unroll
-                for (int c = 0; c < 32; ++c) {
+                for (int c = 0; c < CW; ++c) {
                     if (!HOIST && (c & 1) == 0) {
-                        const d2 t = *reinterpret_cast<const d2*>(w + 32 * q + c);
+                        const d2 t = *reinterpret_cast<const d2*>(w + CW * q + c);
                         wreg[c] = t[0]; wreg[c + 1] = t[1];
                     }
                     if (c == kn) continue;
@@ -650,8 +666,8 @@ __global__ __launch_bounds__(256) void k_design_inverse_c32(int nz, int nzs, con
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int c = 0; c < 32; ++c) {
-            const int i = lane + 64 * a, col = 32 * q + c;
+        for (int c = 0; c < CW; ++c) {
+            const int i = lane + 64 * a, col = CW * q + c;
             if (i < nz && col < nz) Out[(size_t)col * nzs + i] = S[a][c];
         }
     __syncthreads();
@@ -669,8 +685,12 @@ inline void launch_design_inverse(dim3 grid, size_t lds, hipStream_t st, int nz,
 #undef INV_WAVE
     } else if (nz <= 64) hipLaunchKernelGGL((k_design_inverse_t<2, 8>), grid, dim3(DESIGN_INVERSE_THREADS), lds, st, nz, nzs, Hs, cshift, dshift, Out, flag, sHs, sShift, sOut, sFlag);
     else if (!getenv("ALMPC_INV_TILE")) {
-        if (grid.y <= 256) hipLaunchKernelGGL(k_design_inverse_c32<true>, grid, dim3(256), 0, st, nz, nzs, Hs, cshift, dshift, Out, flag, sHs, sShift, sOut, sFlag);
-        else hipLaunchKernelGGL(k_design_inverse_c32<false>, grid, dim3(256), 0, st, nz, nzs, Hs, cshift, dshift, Out, flag, sHs, sShift, sOut, sFlag);
+        const char* cwv = getenv("ALMPC_INV_CW");   // (experiment: columns per wave)
+        const int cw = cwv ? atoi(cwv) : (grid.y <= 256 ? 16 : 32);   // one matrix per CU: eight waves of 16 columns (51 against 59 us at nz 100)
+#define INV_C32(CW_, H_) hipLaunchKernelGGL((k_design_inverse_c32<CW_, H_>), grid, dim3(64 * (128 / CW_)), 0, st, nz, nzs, Hs, cshift, dshift, Out, flag, sHs, sShift, sOut, sFlag)
+        if (grid.y <= 256) { if (cw == 8) INV_C32(8, true); else if (cw == 16) INV_C32(16, true); else INV_C32(32, true); }
+        else { if (cw == 8) INV_C32(8, false); else if (cw == 16) INV_C32(16, false); else INV_C32(32, false); }
+#undef INV_C32
     }
     else hipLaunchKernelGGL((k_design_inverse_t<4, 16>), grid, dim3(DESIGN_INVERSE_THREADS), lds, st, nz, nzs, Hs, cshift, dshift, Out, flag, sHs, sShift, sOut, sFlag);
 }
