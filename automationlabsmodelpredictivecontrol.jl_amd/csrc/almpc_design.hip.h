@@ -194,6 +194,34 @@ __global__ __launch_bounds__(256) void k_design_scale(int nz, int nzs, int n, co
         if (t < 128) ds[t] = v;
     }
     __syncthreads();
+    if (st.h_symmetric && (nz & 1) == 0) {
+        // H_i came out symmetric (LDS route of k_design_instance) and columns are 16-byte aligned: two rows per load and store, two pairs
+        // per thread and pass, (column, row pair) carried along instead of divided out
+        const int hp = nz >> 1, total = hp * nz, step = 2 * (int)blockDim.x, dc = step / hp, dr = step - dc * hp;
+        int t0 = 2 * threadIdx.x, c0 = t0 / hp, r0 = t0 - c0 * hp;
+        for (; t0 < total; t0 += step) {
+            d2 hv[2];
+            int rr[2], cc[2];
+            int r = r0, c = c0;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bool in = t0 + u < total;
+                cc[u] = in ? c : nz - 1; rr[u] = in ? r : hp - 1;
+                hv[u] = *reinterpret_cast<const d2*>(H + (size_t)cc[u] * nz + 2 * rr[u]);
+                if (++r == hp) { r = 0; ++c; }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (t0 + u < total) {
+                    d2 o;
+                    o[0] = ds[2 * rr[u]] * hv[u][0] * ds[cc[u]];
+                    o[1] = ds[2 * rr[u] + 1] * hv[u][1] * ds[cc[u]];
+                    *reinterpret_cast<d2*>(Hs + (size_t)cc[u] * nzs + 2 * rr[u]) = o;
+                }
+            r0 += dr; c0 += dc;
+            if (r0 >= hp) { r0 -= hp; ++c0; }
+        }
+    } else
     // four consecutive elements per thread and pass, (column, row) carried along instead of divided out (one division per thread)
     {
         const int step = 4 * (int)blockDim.x, dc = step / nz, dr = step - dc * nz;
