@@ -734,13 +734,14 @@ def main():
         by3 = 8 * (n3 + 2 * nz3 + 2 * n3 * (N3 + 1)) + 8 * (n3 * n3 + n3 * m3) + 2 * 4 * 8 * nz3 * nzs3
         sec3 = best3 / k3
         out["config3_fnn_relin"]["roofline"] = {
-            "bound": "hbm", "kernel": "k_design_inverse_wave / k_admm_inst (a chain of 6 + 2 one-workgroup-per-instance launches per step)",
+            "bound": "hbm", "kernel": "k_step_inst_wave<48> (94 us) + 2 x k_design_inverse_wave<48> (28 us) + 5 small design launches per step",
             "achieved": b3 * by3 / sec3 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b3 * by3 / sec3 / 1e9 / HBM_PEAK_GBS,
             "traffic": None, "algorithmic_bytes_per_instance_step": by3, "algorithmic_flops_per_instance_step": fl3,
             "fp64_tflops": b3 * fl3 / sec3 / 1e12, "fp64_frac": b3 * fl3 / sec3 / 1e12 / FP64_PEAK_TFLOPS,
             "note": "1024 instances of a 40 x 40 problem are 4 instances per CU: every kernel of the chain is bound by the latency of its own "
                     "dependent steps (40 pivots per inverse, the ADMM iterations, the active-set changes), far from both rooflines; the "
-                    "floor of this shape is the sum of those chains (~0.15 ms), not bytes or flops"}
+                    "floor of this shape is the sum of those chains (~0.15 ms: 40 pivots at ~1 k cycles per inverse, 25 ADMM iterations + the finish in "
+                    "k_step_inst_wave ~0.09 ms), not bytes or flops"}
         s3.close()
 
     if rank == 0 and world == 1 and not args.no_structured:
@@ -843,20 +844,25 @@ def main():
         # the inverse's FP64 rate (2 nz^3 flops per matrix) is stated against the vector FP64 peak for scale
         try:
             import csv
-            ks = {}
-            with open(os.path.join(ROOT, "profiles", "r2_bench_kernel_stats.csv")) as f:
+            ks, src = {}, None
+            for cand in ("r3_sqp_kernel_stats.csv", "r2_sqp_kernel_stats.csv"):
+                if os.path.exists(os.path.join(ROOT, "profiles", cand)):
+                    src = cand
+                    break
+            with open(os.path.join(ROOT, "profiles", src)) as f:
                 for row in csv.DictReader(f):
-                    for short in ("k_design_ltv_reg", "k_design_inverse_t<4, 16", "k_polish_sgl", "k_sqp_step", "k_sqp_prepare", "k_guess_iterate",
-                                  "k_fnn_rollout"):
+                    for short in ("k_design_ltv_reg", "k_design_inverse_c32", "k_design_inverse_t<4, 16", "k_polish_sgl", "k_sqp_step", "k_sqp_prepare",
+                                  "k_guess_iterate", "k_fnn_jacobian_w", "k_design_scale", "k_fnn_rollout"):
                         if short in row["Name"]:
-                            ks[short.split("<")[0] if "<" not in short else short + ", 8>"] = round(float(row["MinNs"]) / 1e3, 1)
+                            ks[short.split("<")[0]] = round(float(row["AverageNs"]) / 1e3, 1)
             if ks:
                 nzq = mq * Nq
-                inv_us = ks.get("k_design_inverse_t<4, 16, 8>")
-                out["sqp_fnn"]["kernel_us_min"] = ks
+                inv_us = ks.get("k_design_inverse_c32") or ks.get("k_design_inverse_t")
+                out["sqp_fnn"]["kernel_us_avg"] = ks
+                out["sqp_fnn"]["kernel_us_source"] = "profiles/" + src + " (rocprofv3 --kernel-trace --stats of tools/profile_sqp.py 256 50 20 25; not measured in this run)"
                 if inv_us:
                     out["sqp_fnn"]["inverse_fp64_tflops"] = {"achieved": 2.0 * nzq ** 3 * bq / (inv_us * 1e-6) / 1e12, "peak_vector_fp64": 78.6,
-                                                             "note": "256 matrices of 100 x 100: one workgroup each on 256 CUs, 100 dependent pivots"}
+                                                             "note": "256 matrices of 100 x 100: one workgroup (eight waves) each on 256 CUs, 100 dependent pivots"}
         except (OSError, KeyError, ValueError):
             pass
         # roofline of the figure: flops of one instance-iteration = Jacobians N (2 H (n + m) + 2 L H^2 + 2 n H) (n + m + 1) + the LTV
@@ -868,11 +874,12 @@ def main():
                + 2 * nzq * nzq + 10 * 2 * nzq * nzq)
         secq = best / its
         out["sqp_fnn"]["roofline"] = {
-            "bound": "mfma", "kernel": "k_design_inverse_t<4,16,8> (100 x 100 Gauss-Jordan per instance: the longest of the 13 launches)",
+            "bound": "mfma", "kernel": "k_polish_sgl / k_design_ltv_reg (~85 us each: the two longest of the 13 launches; the 100 x 100 Gauss-Jordan inverse "
+                                       "k_design_inverse_c32<16,true> is third at ~52 us)",
             "achieved": bq * flq / secq / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": bq * flq / secq / 1e12 / FP64_PEAK_TFLOPS,
             "traffic": None, "algorithmic_flops_per_instance_iteration": flq,
             "note": "FP64 vector pipeline (78.6 TFLOP/s peak, as the matrix cores); 256 instances are one workgroup per CU in every kernel of "
-                    "the chain: each is bound by its own dependent steps (100 pivots, N stage updates), not by a throughput roofline"}
+                    "the chain: each is bound by its own dependent steps (100 pivots at ~1.2 k cycles, N stage updates, the active-set changes), not by a throughput roofline"}
         sq.close()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
