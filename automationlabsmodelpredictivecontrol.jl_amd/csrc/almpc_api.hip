@@ -826,11 +826,22 @@ bool ltv_supported(const almpc_handle* h) {
 
 template <int NC>
 hipError_t launch_design_ltv_reg(almpc_handle* h, const DesignLtvParams& lp, size_t lds, hipStream_t st) {
+    // 8 x 8 register tiles on 256 threads (ALMPC_LTV_T8=1): measured SLOWER (SQP iteration 0.392 against 0.348 ms): the stage is bound
+    // by the latency of its dependent LDS steps, which 16 waves hide better than four, not by LDS bytes
+    const bool t8 = NC > 0 && h->n * h->n + h->n * h->m <= 256 - h->n && getenv("ALMPC_LTV_T8");
+    if (t8) {
+        if (lds > 64 * 1024) {
+            const hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(k_design_ltv_reg<NC, 8>), (size_t)(lds));
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL((k_design_ltv_reg<NC, 8>), dim3((unsigned)h->batch), dim3(256), lds, st, lp);
+        return hipGetLastError();
+    }
     if (lds > 64 * 1024) {
-        const hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(k_design_ltv_reg<NC>), (size_t)(lds));
+        const hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(k_design_ltv_reg<NC, 4>), (size_t)(lds));
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_design_ltv_reg<NC>), dim3((unsigned)h->batch), dim3(1024), lds, st, lp);
+    hipLaunchKernelGGL((k_design_ltv_reg<NC, 4>), dim3((unsigned)h->batch), dim3(1024), lds, st, lp);
     return hipGetLastError();
 }
 

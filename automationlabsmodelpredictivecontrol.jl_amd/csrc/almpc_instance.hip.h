@@ -775,15 +775,21 @@ __global__ __launch_bounds__(256) void k_design_ltv(DesignLtvParams p) {
 // of LDS per element (the LDS build above spends 85 % of its time there), the row blocks are stored stage-row-major ([l][c]:
 // lanes read consecutive addresses), q sits in the registers of threads c < nz, the next stage's (A, B) are fetched one stage
 // two stages ahead (a stage is shorter than an HBM round trip), defects and state errors are staged in LDS once, and a stage
-// needs two barriers.  LDS: 3 n 128 + 4 n^2 + 2 n m + 4 n + 2 N n doubles (16 KB for n = 4, N = 50).
+// needs two barriers -- ONE when n is a template parameter (round 3): thread c then builds column c of the new row block AND of Q_k
+// times it in registers (2 n^2 FMAs) and writes both, double buffered, before the stage's only barrier; 16 waves meet at a barrier
+// in ~450 cycles, the stage's arithmetic is ~400.  R and S sit in LDS (the epilogue's loads of them, one per element behind a
+// branch, were waited for one by one).  LDS: 4 n 128 + 4 n^2 + 2 n m + 4 n + 2 N n + 2 m^2 doubles (20 KB for n = 4, N = 50).
 constexpr int LTV_REG_NZ = 128;  // (the kernel uses t >> 7 and t & 127)
 
 __host__ __device__ inline size_t design_ltv_reg_lds_doubles(int n, int m, int N) {
-    return 3 * (size_t)n * LTV_REG_NZ + 4 * (size_t)n * n + 2 * (size_t)n * m + 4 * (size_t)n + 2 * (size_t)N * n;
+    return 4 * (size_t)n * LTV_REG_NZ + 4 * (size_t)n * n + 2 * (size_t)n * m + 4 * (size_t)n + 2 * (size_t)N * n + 2 * (size_t)m * m;
 }
 
-template <int NC>  // NC > 0: the state dimension at compile time (the stage loops unroll); 0: any n
-__global__ __launch_bounds__(1024) void k_design_ltv_reg(DesignLtvParams p) {
+// TS: side of a thread's register tile (4: 1024 threads, the default; 8: 256 threads, half the LDS bytes per FMA -- measured slower, 124
+// against 81 us for N = 50: a stage (1.6 us) is a chain of dependent LDS steps that 16 waves hide better than four).
+template <int NC, int TS = 4>  // NC > 0: the state dimension at compile time (the stage loops unroll); 0: any n
+__global__ __launch_bounds__((128 / TS) * (128 / TS)) void k_design_ltv_reg(DesignLtvParams p) {
+    constexpr int DX = 128 / TS;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NZP = LTV_REG_NZ;
     const int n = NC > 0 ? NC : p.n, m = p.m, N = p.N, nz = p.nz, nn = n * n, nm = n * m, nab = nn + nm;
@@ -791,7 +797,8 @@ __global__ __launch_bounds__(1024) void k_design_ltv_reg(DesignLtvParams p) {
     double* Gc = smem;                    // [n][NZP] current row block of Gamma~ (row l of the block, column c)
     double* Gn = Gc + (size_t)n * NZP;
     double* T = Gn + (size_t)n * NZP;     // Q_k times the row block
-    double* AB = T + (size_t)n * NZP;     // [2][nn + nm]: (A_k, B_k) of the current and of the next stage
+    double* T2 = T + (size_t)n * NZP;     // (second buffer of the one-barrier path)
+    double* AB = T2 + (size_t)n * NZP;    // [2][nn + nm]: (A_k, B_k) of the current and of the next stage
     double* Qs = AB + 2 * nab;
     double* Ps = Qs + nn;
     double* gk = Ps + nn;
@@ -799,12 +806,14 @@ __global__ __launch_bounds__(1024) void k_design_ltv_reg(DesignLtvParams p) {
     double* rv2 = gn + n;                 // [2][n]: g~ + ebar of the current stage, double buffered over the stages
     double* cs = rv2 + 2 * n;             // [N][n] defects
     double* es = cs + (size_t)N * n;      // [N][n] state errors
-    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5, T_ = 1024;
-    double acc[4][4];
+    double* Rs = es + (size_t)N * n;      // [m][m]
+    double* Ss = Rs + (size_t)m * m;      // [m][m]
+    const int tid = threadIdx.x, tx = tid % DX, ty = tid / DX, T_ = DX * DX;
+    double acc[TS][TS];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TS; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+        for (int j = 0; j < TS; ++j) acc[i][j] = 0.0;
     double qacc = 0.0;
     // (A, B) of the stages are contiguous per instance: [N][nn] and [N][nm]; element e < nab of stage k
     const double* Ag = p.A + inst * N * (size_t)nn;
@@ -816,8 +825,9 @@ __global__ __launch_bounds__(1024) void k_design_ltv_reg(DesignLtvParams p) {
         if (N > 1) AB[nab + tid] = ab_load(1);
         if (N > 2) pre = ab_load(2);
     }
-    for (int t = tid; t < 3 * n * NZP; t += T_) Gc[t] = 0.0;  // Gc, Gn, T
+    for (int t = tid; t < 4 * n * NZP; t += T_) Gc[t] = 0.0;  // Gc, Gn, T, T2
     for (int t = tid; t < nn; t += T_) { Qs[t] = p.Q[t]; Ps[t] = p.P[inst * p.sP + t]; }
+    for (int t = tid; t < m * m; t += T_) { Rs[t] = p.useR ? p.R[t] : 0.0; Ss[t] = p.useS ? p.S[t] : 0.0; }
     for (int t = tid; t < n; t += T_) gk[t] = 0.0;
     for (int t = tid; t < N * n; t += T_) {
         cs[t] = p.c ? p.c[inst * N * n + t] : 0.0;
@@ -828,6 +838,76 @@ __global__ __launch_bounds__(1024) void k_design_ltv_reg(DesignLtvParams p) {
         const double* Ak = AB + (k & 1) * nab;
         const double* Bk = Ak + nn;
         const int wcols = (k + 1) * m;  // columns of the row block that are non-zero after this stage
+        const double* Qk = (k == N - 1) ? Ps : Qs;  // stage N+1 carries only P (src/sub/design_mpc.jl:448-456)
+        if constexpr (NC > 0) {
+            // one barrier per stage: thread c owns column c of the new row block (n values in registers) and of Q_k times it
+            double* Tn = (k & 1) ? T2 : T;
+            if (tid < wcols) {
+                const int c = tid;
+                double g[NC];
+                if (c >= k * m) {
+#pragma unroll
+                    for (int pr = 0; pr < NC; ++pr) g[pr] = Bk[(c - k * m) * NC + pr];
+                } else {
+                    double gc[NC];
+#pragma unroll
+                    for (int l = 0; l < NC; ++l) gc[l] = Gc[l * NZP + c];
+#pragma unroll
+                    for (int pr = 0; pr < NC; ++pr) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int l = 0; l < NC; ++l) v += Ak[l * NC + pr] * gc[l];
+                        g[pr] = v;
+                    }
+                }
+#pragma unroll
+                for (int pr = 0; pr < NC; ++pr) {
+                    Gn[pr * NZP + c] = g[pr];
+                    double v = 0.0;
+#pragma unroll
+                    for (int l = 0; l < NC; ++l) v += Qk[l * NC + pr] * g[l];
+                    Tn[pr * NZP + c] = v;
+                }
+            }
+            if (tid >= T_ - n) {  // the last n threads (for n <= 7 they have no share of the row block)
+                const int pr = tid - (T_ - n);
+                double v = cs[k * n + pr];
+                for (int l = 0; l < n; ++l) v += Ak[l * n + pr] * gk[l];
+                gn[pr] = v;
+                rv2[(k & 1) * n + pr] = v + es[k * n + pr];
+            }
+            __syncthreads();
+            { double* t = Gc; Gc = Gn; Gn = t; }
+            { double* t = gk; gk = gn; gn = t; }
+            const double* rv = rv2 + (k & 1) * n;
+            if (tid < nab) {  // this stage's (A, B) slot is free (last read before the barrier above): it takes stage k + 2
+                if (k + 2 < N) AB[(k & 1) * nab + tid] = pre;
+                if (k + 3 < N) pre = ab_load(k + 3);
+            }
+            const int ni = (wcols + DX - 1) / DX;  // DX-column groups that hold non-zeros
+#pragma unroll
+            for (int l = 0; l < NC; ++l) {
+                double a[TS], b[TS];
+#pragma unroll
+                for (int i = 0; i < TS; ++i) {
+                    a[i] = i < ni ? Gc[l * NZP + tx + DX * i] : 0.0;
+                    b[i] = i < ni ? Tn[l * NZP + ty + DX * i] : 0.0;
+                }
+#pragma unroll
+                for (int i = 0; i < TS; ++i)
+#pragma unroll
+                    for (int j = 0; j < TS; ++j) acc[i][j] += a[i] * b[j];
+            }
+            if (tid < wcols) {
+                double v = 0.0;
+#pragma unroll
+                for (int l = 0; l < NC; ++l) v += Tn[l * NZP + tid] * rv[l];
+                qacc += v;
+            }
+            // no second barrier: the next stage writes the OTHER row-block buffer, the other T, the other g~ and the other rv before its
+            // barrier; this stage's buffers are rewritten two stages on, i.e. after every thread has passed the next barrier
+            continue;
+        }
         for (int t = tid; t < n * NZP; t += T_) {   // element (pr, c) of the row block: c = t mod 128, no division
             const int c = t & (NZP - 1), pr = t >> 7;
             if (c < wcols) {
@@ -850,7 +930,6 @@ __global__ __launch_bounds__(1024) void k_design_ltv_reg(DesignLtvParams p) {
         __syncthreads();
         { double* t = Gc; Gc = Gn; Gn = t; }
         { double* t = gk; gk = gn; gn = t; }
-        const double* Qk = (k == N - 1) ? Ps : Qs;  // stage N+1 carries only P (src/sub/design_mpc.jl:448-456)
         const double* rv = rv2 + (k & 1) * n;
         for (int t = tid; t < n * NZP; t += T_) {
             const int c = t & (NZP - 1), pr = t >> 7;
@@ -865,18 +944,18 @@ __global__ __launch_bounds__(1024) void k_design_ltv_reg(DesignLtvParams p) {
             if (k + 3 < N) pre = ab_load(k + 3);
         }
         __syncthreads();
-        const int ni = (wcols + 31) >> 5;  // 32-column groups that hold non-zeros
+        const int ni = (wcols + DX - 1) / DX;  // DX-column groups that hold non-zeros
         for (int l = 0; l < n; ++l) {
-            double a[4], b[4];
+            double a[TS], b[TS];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a[i] = i < ni ? Gc[l * NZP + tx + 32 * i] : 0.0;
-                b[i] = i < ni ? T[l * NZP + ty + 32 * i] : 0.0;
+            for (int i = 0; i < TS; ++i) {
+                a[i] = i < ni ? Gc[l * NZP + tx + DX * i] : 0.0;
+                b[i] = i < ni ? T[l * NZP + ty + DX * i] : 0.0;
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TS; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+                for (int j = 0; j < TS; ++j) acc[i][j] += a[i] * b[j];
         }
         if (tid < wcols) {
             double v = 0.0;
@@ -888,17 +967,17 @@ __global__ __launch_bounds__(1024) void k_design_ltv_reg(DesignLtvParams p) {
     }
     double* H = p.H + inst * (size_t)nz * nz;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < TS; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = tx + 32 * i, c = ty + 32 * j;
+        for (int i = 0; i < TS; ++i) {
+            const int r = tx + DX * i, c = ty + DX * j;
             if (r < nz && c < nz) {
                 double v = 2.0 * acc[i][j];
                 const int ir = r / m, ar = r % m, ic = c / m, ac = c % m;
-                if (p.useR && ir == ic) v += 2.0 * p.R[(size_t)ac * m + ar];
+                if (p.useR && ir == ic) v += 2.0 * Rs[ac * m + ar];
                 if (p.useS) {
-                    if (ir == ic) v += 2.0 * ((ir <= N - 2 ? 1 : 0) + (ir >= 1 ? 1 : 0)) * p.S[(size_t)ac * m + ar];
-                    else if (ir - ic == 1 || ic - ir == 1) v -= 2.0 * p.S[(size_t)ac * m + ar];
+                    if (ir == ic) v += 2.0 * ((ir <= N - 2 ? 1 : 0) + (ir >= 1 ? 1 : 0)) * Ss[ac * m + ar];
+                    else if (ir - ic == 1 || ic - ir == 1) v -= 2.0 * Ss[ac * m + ar];
                 }
                 H[(size_t)c * nz + r] = v;
             }
