@@ -236,9 +236,16 @@ __device__ __forceinline__ void admm_body(const AdmmParams& p, double* smem, Aft
         __syncthreads();
         // px = H' x needs one true product: stream the H' fragments once
         d4 acc = {0.0, 0.0, 0.0, 0.0};
-        for (int ks = 0; ks < KS; ++ks) {
-            double ah = p.HFrag[((size_t)(wv * KS + ks)) * 64 + lane];
-            acc = mfma_f64(ah, rhs0[(4 * ks + q) * TILE + col], acc);
+        // (eight fragments per L2 round trip: one at a time the compiler waited for each load, ~190 cycles x KS)
+#pragma unroll
+        for (int ks0 = 0; ks0 < KS; ks0 += 8) {
+            double ah[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (ks0 + u < KS) ah[u] = p.HFrag[((size_t)(wv * KS + ks0 + u)) * 64 + lane];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (ks0 + u < KS) acc = mfma_f64(ah[u], rhs0[(4 * (ks0 + u) + q) * TILE + col], acc);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) px[i] = acc[i];
