@@ -1010,8 +1010,24 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
     auto g_load = [&](int l0, d2 (&g)[CH]) {
         // row indices straight from the position-distributed register (v_readlane -> scalar address part): the LDS copy wrow_s cost a
         // dependent LDS round trip per chunk before the rows of G could even be requested
+#ifdef ALMPC_EXP_ROWS_READLANE
 #pragma unroll
         for (int t = 0; t < CH; ++t) g[t] = *reinterpret_cast<const d2*>(Gp + (__builtin_amdgcn_readlane(wrow, l0 + t) * gs + rc));
+#else
+        // Round 3: CH row indices in CH / 4 wave-uniform 16-byte reads of the LDS copy, addresses on the vector unit.  v_readlane ->
+        // s_mul -> address costs ~30 cycles per row one after the other (tools/microbench/dep_latency.hip: a VALU write to a scalar
+        // register is slow to reach its reader), 1.0 k of the 4.1 k cycles of a one-row change at 30 rows; the LDS copy is ONE ~80-cycle
+        // round trip per chunk.  (What round 2 measured as slower was one dependent ds_read per row.)
+        typedef int i4 __attribute__((ext_vector_type(4)));
+        int rows[CH];
+#pragma unroll
+        for (int t = 0; t < CH; t += 4) {
+            const i4 r4 = *reinterpret_cast<const i4*>(wrow_s + l0 + t);
+            rows[t] = r4[0]; rows[t + 1] = r4[1]; rows[t + 2] = r4[2]; rows[t + 3] = r4[3];
+        }
+#pragma unroll
+        for (int t = 0; t < CH; ++t) g[t] = *reinterpret_cast<const d2*>(Gp + (rows[t] * gs + rc));
+#endif
     };
     auto g_fma = [&](int l0, const double* ab, const d2 (&g)[CH], double& q0, double& q1) {
         double av[CH];
