@@ -504,6 +504,15 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
     return __hiloint2double(hi, lo);
 }
 
+// 1 / v by v_rcp_f64 (2^-24) and two Newton steps: ~43 cycles on a dependent chain against ~90 for the IEEE division sequence
+// (div_scale, rcp, Newton, div_fmas, div_fixup); the last bit may differ.  tools/microbench/dep_latency.hip.
+__device__ __forceinline__ double fast_rcp_d(double v) {
+    double r = __builtin_amdgcn_rcp(v);
+    r = __builtin_fma(__builtin_fma(-v, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-v, r, 1.0), r, r);
+    return r;
+}
+
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -1088,9 +1097,10 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
             g_load(l0, g);
             g_fma(l0, pbufb, g, q0, q1);
         }
+        // (measured and dropped, round 3: two chunks in flight -- the loads of chunk c + 1 ahead of the FMAs of chunk c: mixed batch -1 %)
         ALMPC_ACC(2);
         const double sc = gjj - wave_sum(lowhalf ? c * u : 0.0);
-        const double isc = 1.0 / sc;
+        const double isc = fast_rcp_d(sc);
         const double mu = (tj - bval) * isc;
         t0 -= mu * (gj[0] - q0);
         t1 -= mu * (gj[1] - q1);
@@ -1226,8 +1236,8 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
             {
                 const bool f0 = in0 && !act0, f1 = in1 && !act1;
                 const bool up0 = t0 > hi0, dn0 = t0 < lo0, up1 = t1 > hi1, dn1 = t1 < lo1;
-                const double c0 = ((up0 ? hi0 : lo0) - w0) / (t0 - w0);
-                const double c1 = ((up1 ? hi1 : lo1) - w1) / (t1 - w1);
+                const double c0 = ((up0 ? hi0 : lo0) - w0) * fast_rcp_d(t0 - w0);   // (only rows with t outside their box count: t != w there)
+                const double c1 = ((up1 ? hi1 : lo1) - w1) * fast_rcp_d(t1 - w1);
                 const bool v0 = f0 && (up0 || dn0), v1 = f1 && (up1 || dn1);
                 if (v0) { rr = c0; rside = up0 ? 1 : -1; }
                 if (v1 && (!v0 || c1 < c0)) { rr = c1; rside = up1 ? 1 : -1; second = true; }  // ties keep the smaller row
@@ -1236,14 +1246,15 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
             if (rmin < 1.0) {
                 if (k == (M::glb ? cap2 : M::WL)) { --it; overflow = true; return; }  // redo this pass in the next mode
                 const int owner = __builtin_ctzll(__ballot(rr == rmin));  // smallest lane = smallest row among ties
+                // every lane has its own candidate ready (row parity, side, bound): three v_readlane that depend on `owner` only,
+                // instead of a chain owner -> parity -> select -> bound
+                const double bcand = second ? (rside > 0 ? hi1 : lo1) : (rside > 0 ? hi0 : lo0);
                 const int jmin = 2 * owner + (__builtin_amdgcn_readlane(second ? 1 : 0, owner));
+                const int sd = __builtin_amdgcn_readlane(rside, owner);
+                const double bval = readlane_d(bcand, owner);
                 const double tt = fmax(rmin, 0.0);
                 if (in0 && !act0) w0 += tt * (t0 - w0);
                 if (in1 && !act1) w1 += tt * (t1 - w1);
-                const int sd = __builtin_amdgcn_readlane(rside, owner);
-                const double bh = readlane_d((jmin & 1) ? hi1 : hi0, owner);
-                const double bl = readlane_d((jmin & 1) ? lo1 : lo0, owner);
-                const double bval = sd > 0 ? bh : bl;
                 if (r0 == jmin) w0 = bval;
                 if (r1 == jmin) w1 = bval;
                 ALMPC_ACC(5);
