@@ -121,6 +121,7 @@ def load():
     L.almpc_timing_summary.argtypes = [_hp, ctypes.POINTER(ctypes.c_int)] + [_dp] * 4
     # host-facing step path (pinned staging, copy streams) and one-process multi-GPU groups
     L.almpc_update_initialization_async.argtypes = [_hp, _dp]
+    L.almpc_x0_staging.argtypes = [_hp, ctypes.POINTER(_dp)]
     L.almpc_get_results_async.argtypes = [_hp, ctypes.c_uint32]
     L.almpc_get_results_wait.argtypes = [_hp, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _ip]
     L.almpc_host_results.argtypes = [_hp, ctypes.c_int] + [ctypes.POINTER(ctypes.c_void_p)] * 8
@@ -146,7 +147,7 @@ def load():
     L.almpc_set_start_from.restype = ctypes.c_int
     L.almpc_timing_samples.argtypes = [_hp, ctypes.c_int, ctypes.POINTER(ctypes.c_int), _fp, _fp, _fp, _fp]
     L.almpc_timing_samples.restype = ctypes.c_int
-    for name in ("almpc_update_initialization_async", "almpc_get_results_async", "almpc_get_results_wait", "almpc_host_results",
+    for name in ("almpc_x0_staging", "almpc_update_initialization_async", "almpc_get_results_async", "almpc_get_results_wait", "almpc_host_results",
                  "almpc_get_first_input", "almpc_group_create", "almpc_group_size", "almpc_group_shard", "almpc_group_design_shared",
                  "almpc_group_set_reference", "almpc_group_update_initialization", "almpc_group_calculate",
                  "almpc_group_calculate_async", "almpc_group_synchronize", "almpc_group_get_results"):
@@ -529,6 +530,13 @@ class Solver:
         """x0 (batch, n) -> pinned slot -> upload on the copy-in stream; the next calculate waits for it on the device."""
         x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(self.batch, self.n)
         self._check(self.L.almpc_update_initialization_async(self.h, _ptr(x0)))
+
+    def x0_staging(self):
+        """Zero-copy input (almpc_x0_staging): a (batch, n) view of the pinned slot the next update_initialization_async will use.
+        Fill it in place and pass it to update_initialization_async: no staging copy."""
+        ptr = _dp()
+        self._check(self.L.almpc_x0_staging(self.h, ctypes.byref(ptr)))
+        return np.ctypeslib.as_array(ptr, shape=(self.batch, self.n))
 
     def get_results_async(self, want=("u0", "status")) -> int:
         """Ask for results of the last enqueued step (names of WANT; "u0" = u[:, 1] of every instance); returns a ticket."""

@@ -88,6 +88,22 @@ hipError_t event_wait(hipEvent_t e) {
 
 extern "C" {
 
+// Zero-copy input: the pinned slot the NEXT almpc_update_initialization_async will hand to the device.  The caller writes its states
+// there and passes the same pointer on: no staging copy.
+int almpc_x0_staging(almpc_handle* h, double** x0_slot) {
+    if (!h || !x0_slot) return h ? fail(h, ALMPC_ERR_INVALID, "x0_staging: null pointer") : ALMPC_ERR_INVALID;
+    { const int rc = io_init(h); if (rc != ALMPC_OK) return rc; }
+    almpc_handle::Io& io = h->io;
+    const int s = (int)(io.x0_count % almpc_handle::IO_DEPTH);
+    if (io.used_pending[s]) {   // the slot is written by the caller from here on: the last step that read it must have finished
+        HIP_TRY(h, hipSetDevice(h->device));
+        HIP_TRY(h, event_wait(io.ev_used[s]));
+        io.used_pending[s] = false;
+    }
+    *x0_slot = io.hX0[s];
+    return ALMPC_OK;
+}
+
 int almpc_update_initialization_async(almpc_handle* h, const double* x0) {
     if (!h || !x0) return h ? fail(h, ALMPC_ERR_INVALID, "update_initialization_async: null x0") : ALMPC_ERR_INVALID;
     { const int rc = io_init(h); if (rc != ALMPC_OK) return rc; }
@@ -99,7 +115,7 @@ int almpc_update_initialization_async(almpc_handle* h, const double* x0) {
         HIP_TRY(h, event_wait(io.ev_used[s]));
         io.used_pending[s] = false;
     }
-    std::memcpy(io.hX0[s], x0, (size_t)h->batch * h->n * sizeof(double));
+    if (x0 != io.hX0[s]) std::memcpy(io.hX0[s], x0, (size_t)h->batch * h->n * sizeof(double));   // (almpc_x0_staging: already in place)
     if (io.x0_slot < 0) io.dX0_own = h->dX0;   // (the handle's own buffer is kept and freed with the handle)
     h->dX0 = io.dX0[s];                        // kernels enqueued from here on read this slot, in place, over the link
     io.x0_slot = s;

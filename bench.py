@@ -129,6 +129,38 @@ def api_path_figures(capi, solver, X0, opts, steps):
                          "unsolved_last": int((st != 0).sum()), "matches_get_results": bool(np.array_equal(u0, ref_u0)),
                          "note": "host x0 in -> step -> host u[:,1] + status out, every step; depth-2 pipeline (the results of step k are "
                                  "waited for after step k+1 is enqueued); C ABI called with prebuilt arguments"}
+    # zero-copy variant: x0 written in place into the handle's pinned slot (almpc_x0_staging), results read in place (almpc_host_results)
+    slotp = dp()
+
+    def step_zero(fill):
+        ok(L.almpc_x0_staging(h, ctypes.byref(slotp)))
+        if fill:   # (the benchmark's states do not change from step to step: both slots are filled once, before the timed loop; a real
+            np.copyto(np.ctypeslib.as_array(slotp, shape=x0c.shape), x0c)   # caller's plant writes its new states here instead)
+        ok(L.almpc_update_initialization_async(h, slotp))
+        ok(L.almpc_calculate_async(h, op))
+        return ok(L.almpc_get_results_async(h, mask))
+
+    def wait_zero(t):
+        ok(L.almpc_get_results_wait(h, t, None, None, None, None, None, None, None, None))
+    for _ in range(4):
+        wait_zero(step_zero(True))
+    best = float("inf")
+    for _rep in range(3):
+        t0 = time.perf_counter()
+        prev = -1
+        for _ in range(k):
+            t = step_zero(False)
+            if prev >= 0:
+                wait_zero(prev)
+            prev = t
+        wait_zero(prev)
+        best = min(best, time.perf_counter() - t0)
+    zview = solver.get_results_wait(prev, want=("u0", "status"), copy=False)
+    out["first_move_zero_copy"] = {"value": k / best, "unit": "batch-steps/s", "ms_per_step": 1e3 * best / k,
+                                   "matches_get_results": bool(np.array_equal(zview["u0"], ref_u0)) and bool((zview["status"] == 0).all()),
+                                   "note": "as first_move without the two staging copies: x0 lives in the handle's pinned slot (almpc_x0_staging; the "
+                                           "caller's write of its states is not part of the figure: it replaces the write into the caller's own "
+                                           "array), u[:,1] and status are read in place (almpc_host_results)"}
     # the same without pipelining: every step waits for its own results (a closed loop whose plant lives on the host)
     best = float("inf")
     for _rep in range(3):

@@ -351,6 +351,10 @@ int almpc_get_results(almpc_handle* h, double* x, double* e_x, double* u, double
  *                                       almpc_calculate(_async) read in place over the link (393 KB at the benchmark shape, requested
  *                                       under the operands every workgroup loads anyway): no HIP call, no device-side copy.  Returns
  *                                       at once; blocks only if both slots are still being read (two steps in flight).
+ *   almpc_x0_staging                    zero-copy variant of the above: *x0_slot = the pinned host buffer ([batch][n]) that the NEXT
+ *                                       almpc_update_initialization_async will use.  Write the states there (e.g. straight from the
+ *                                       plant simulation) and pass the same pointer to almpc_update_initialization_async: the
+ *                                       staging copy is skipped.  The pointer is valid until that call.
  *   almpc_get_results_async             asks for the results of the LAST enqueued step: `want` = mask of ALMPC_WANT_*.  The small
  *                                       ones (first inputs, status, iteration counts) are written by one pack kernel straight into
  *                                       the pinned slot, so the next step may start right behind it; x / e_x / u / e_u go out on a
@@ -373,6 +377,7 @@ int almpc_get_results(almpc_handle* h, double* x, double* e_x, double* u, double
 #define ALMPC_WANT_FIRST_INPUT 0x80u
 #define ALMPC_WANT_ALL 0xFFu
 int almpc_update_initialization_async(almpc_handle* h, const double* x0);
+int almpc_x0_staging(almpc_handle* h, double** x0_slot);
 int almpc_get_results_async(almpc_handle* h, uint32_t want);
 int almpc_get_results_wait(almpc_handle* h, int ticket, double* x, double* e_x, double* u, double* e_u, double* u0,
                            int32_t* status, int32_t* iters, int32_t* polish_iters);

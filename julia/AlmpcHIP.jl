@@ -247,6 +247,14 @@ function update_initialization_async!(mod::HipModeler, x0::VecOrMat{Float64})
     check(mod.handle, ccall((:almpc_update_initialization_async, libalmpc), Cint, (Ptr{Cvoid}, Ptr{Float64}), mod.handle, x0))
 end
 
+"zero-copy input: an n x batch matrix over the pinned slot the next `update_initialization_async!` will use -- write the states into it (e.g.
+straight from the plant simulation) and pass it on: the staging copy is skipped.  Valid until that call."
+function x0_staging(mod::HipModeler)
+    slot = Ref{Ptr{Float64}}(C_NULL)
+    check(mod.handle, ccall((:almpc_x0_staging, libalmpc), Cint, (Ptr{Cvoid}, Ref{Ptr{Float64}}), mod.handle, slot))
+    return unsafe_wrap(Array, slot[], (mod.n, mod.batch))
+end
+
 const WANT_X, WANT_E_X, WANT_U, WANT_E_U, WANT_STATUS, WANT_ITERS, WANT_POLISH_ITERS, WANT_FIRST_INPUT =
     UInt32(0x01), UInt32(0x02), UInt32(0x04), UInt32(0x08), UInt32(0x10), UInt32(0x20), UInt32(0x40), UInt32(0x80)
 

@@ -58,6 +58,38 @@ def test_async_results_equal_the_synchronous_read_back(capi, mo):
     s.close()
 
 
+def test_zero_copy_x0_slot(capi, mo):
+    """almpc_x0_staging: states written straight into the pinned slot give the results of the copying path; the slots alternate, and a
+    slot handed out again has been released by the step that read it."""
+    p = mo.quadrotor()
+    batch = 70
+    s = _solver(capi, p, batch)
+    ref_s = _solver(capi, p, batch)
+    seen = set()
+    for step in range(5):
+        X0 = _x0(mo, batch, first=1000 * step)
+        view = s.x0_staging()
+        assert view.shape == (batch, 12)
+        seen.add(view.ctypes.data)
+        view[...] = X0                       # the caller's plant writes here
+        s.update_initialization_async(view)  # same pointer: no staging copy
+        s.calculate(sync=False)
+        t = s.get_results_async(want=("u0", "status"))
+        ref_s.update_initialization(X0)
+        ref_s.calculate()
+        ref = ref_s.get_results(want=("u", "status"))
+        got = s.get_results_wait(t, want=("u0", "status"))
+        assert np.array_equal(got["u0"], ref["u"][:, :, 0]) and np.array_equal(got["status"], ref["status"]), step
+    assert len(seen) == 2                    # two slots, used in turn
+    # an ordinary array still goes through the staging copy
+    X0 = _x0(mo, batch, first=77)
+    s.update_initialization_async(X0)
+    s.calculate()
+    ref_s.update_initialization(X0); ref_s.calculate()
+    assert np.array_equal(s.get_first_input(), ref_s.get_results(want=("u",))["u"][:, :, 0])
+    s.close(); ref_s.close()
+
+
 def test_pipelined_host_loop_hands_every_ticket_its_own_step(capi, mo):
     """x0 of step k+1 is uploaded and u[:,1] of step k is read back while the kernels run; depth-2 rings on both sides."""
     p = mo.quadrotor()
