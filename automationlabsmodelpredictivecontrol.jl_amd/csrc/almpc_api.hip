@@ -139,6 +139,14 @@ struct almpc_handle {
     struct Io {
         bool ready = false;
         hipStream_t s_out = nullptr;
+        // ALMPC_X0_UPLOAD=1: the pinned slot is copied into a device slot by the copy engine on a stream of its own, under the step that
+        // is running, instead of being read in place by the kernels.  Reading in place costs the step +9 us at the benchmark shape
+        // (393 KB over the link at its START, tools/dbg_x0_home.py), the upload costs three HIP calls and a copy-engine latency per step:
+        // measured 11.7 k (upload) against 12.8 k (in place) batch-steps/s on the pipelined first-move loop, 8.3 k against 10.4 k serial
+        hipStream_t s_in = nullptr;
+        bool upload = false;
+        double* dX0dev[IO_DEPTH] = {nullptr, nullptr};
+        hipEvent_t ev_in[IO_DEPTH] = {nullptr, nullptr};
         // x0 ring: pinned host slots the kernels read in place (dX0 = the device's address of the slot); h->dX0 points at the latest
         double* hX0[IO_DEPTH] = {nullptr, nullptr};
         double* dX0[IO_DEPTH] = {nullptr, nullptr};

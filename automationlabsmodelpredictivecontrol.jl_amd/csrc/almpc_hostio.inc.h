@@ -5,9 +5,11 @@
 // and what a receding-horizon caller applies is u[:,1].  Through almpc_update_initialization / almpc_get_results that is a
 // synchronous pageable upload and seven synchronous pageable read-backs per step (32 MB at the benchmark shape).  Here:
 //   * pinned staging owned by the handle, rings of IO_DEPTH slots;
-//   * x0 is not copied at all: the step's kernels read it from the pinned slot over the link (393 KB, requested in the ADMM
-//     prologue under the 230 KB of operands every workgroup pulls anyway), so an update is a host memcpy and a pointer flip -- no
-//     HIP call;
+//   * x0 is not copied at all: the step's kernels read it from the pinned slot over the link (393 KB), so an update is a host
+//     memcpy (or none: almpc_x0_staging) and a pointer flip -- no HIP call.  The price is +9 us on the step (the 393 KB cross the link
+//     at its start, every workgroup waits for its tile); the alternative, a copy-engine upload into a device slot on a stream of its
+//     own (ALMPC_X0_UPLOAD=1), removes that but costs three HIP calls and a DMA latency per step and came out slower (11.7 against
+//     12.8 k batch-steps/s pipelined, 8.3 against 10.4 k serial);
 //   * the small results (first inputs, status, iteration counts: 147 KB) are written by one pack kernel straight into the pinned
 //     slot, followed by one event: the next step starts right behind it;
 //   * the large arrays go out on a copy-out stream tied to the compute stream by events, so their read-back of step k runs under
@@ -43,6 +45,8 @@ int io_init(almpc_handle* h) {
     if (io.ready) return ALMPC_OK;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamCreateWithFlags(&io.s_out, hipStreamNonBlocking));
+    HIP_TRY(h, hipStreamCreateWithFlags(&io.s_in, hipStreamNonBlocking));
+    { const char* up = getenv("ALMPC_X0_UPLOAD"); io.upload = up && up[0] == '1'; }
     const size_t b = (size_t)h->batch;
     for (int s = 0; s < almpc_handle::IO_DEPTH; ++s) {
         HIP_TRY(h, pinned(&io.hX0[s], b * h->n));
@@ -52,7 +56,8 @@ int io_init(almpc_handle* h) {
         HIP_TRY(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&io.dX0[s]), io.hX0[s], 0));
         HIP_TRY(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&io.dU0[s]), io.hU0[s], 0));
         HIP_TRY(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&io.dInts[s]), io.hInts[s], 0));
-        for (hipEvent_t* e : {&io.ev_used[s], &io.ev_packed[s], &io.ev_done[s]})
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&io.dX0dev[s]), b * h->n * sizeof(double)));
+        for (hipEvent_t* e : {&io.ev_used[s], &io.ev_packed[s], &io.ev_done[s], &io.ev_in[s]})
             HIP_TRY(h, hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
     io.ready = true;
@@ -63,13 +68,17 @@ void io_free(almpc_handle* h) {
     almpc_handle::Io& io = h->io;
     if (io.dX0_own) h->dX0 = io.dX0_own;
     if (io.s_out) (void)hipStreamSynchronize(io.s_out);
+    if (io.s_in) (void)hipStreamSynchronize(io.s_in);
     for (int s = 0; s < almpc_handle::IO_DEPTH; ++s) {
+        if (io.dX0dev[s]) (void)hipFree(io.dX0dev[s]);
+        if (io.ev_in[s]) (void)hipEventDestroy(io.ev_in[s]);
         for (void* p : {(void*)io.hX0[s], (void*)io.hX[s], (void*)io.hEx[s], (void*)io.hU[s], (void*)io.hEu[s], (void*)io.hU0[s], (void*)io.hInts[s]})
             if (p) (void)hipHostFree(p);
         for (hipEvent_t e : {io.ev_used[s], io.ev_packed[s], io.ev_done[s]})
             if (e) (void)hipEventDestroy(e);
     }
     if (io.s_out) (void)hipStreamDestroy(io.s_out);
+    if (io.s_in) (void)hipStreamDestroy(io.s_in);
     io = almpc_handle::Io();
 }
 
@@ -117,7 +126,17 @@ int almpc_update_initialization_async(almpc_handle* h, const double* x0) {
     }
     if (x0 != io.hX0[s]) std::memcpy(io.hX0[s], x0, (size_t)h->batch * h->n * sizeof(double));   // (almpc_x0_staging: already in place)
     if (io.x0_slot < 0) io.dX0_own = h->dX0;   // (the handle's own buffer is kept and freed with the handle)
-    h->dX0 = io.dX0[s];                        // kernels enqueued from here on read this slot, in place, over the link
+    if (io.upload) {
+        // pinned slot -> device slot on the copy-in stream (under the step that is running); everything enqueued on the compute stream
+        // from here on comes after it
+        HIP_TRY(h, hipSetDevice(h->device));
+        HIP_TRY(h, hipMemcpyAsync(io.dX0dev[s], io.hX0[s], (size_t)h->batch * h->n * sizeof(double), hipMemcpyHostToDevice, io.s_in));
+        HIP_TRY(h, hipEventRecord(io.ev_in[s], io.s_in));
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, io.ev_in[s], 0));
+        h->dX0 = io.dX0dev[s];
+    } else {
+        h->dX0 = io.dX0[s];                    // kernels enqueued from here on read this slot, in place, over the link
+    }
     io.x0_slot = s;
     io.x0_count += 1;
     return ALMPC_OK;
