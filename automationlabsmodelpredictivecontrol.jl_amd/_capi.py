@@ -700,8 +700,15 @@ class Group:
             ur = np.ascontiguousarray(u_ref.reshape(m, N).T)
         self._check(self.L.almpc_group_set_reference(self.g, _ptr(xr), _ptr(ur), 1 if per_instance else 0))
 
-    def update_initialization(self, x0):
+    def update_initialization(self, x0, resident=False):
+        """x0 (batch, n) to the handles' shards.  Default: almpc_group_update_initialization (pinned slots read in place by the next
+        step, no device copy -- the per-step path).  resident=True: a device copy per handle (almpc_update_initialization), for states
+        that many steps will read (the pinned slot costs every step its transfer over the link)."""
         x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(self.batch, self.n)
+        if resident:
+            for hv, (f, c) in zip(self.handles, self.shards):
+                hv.update_initialization(x0[f:f + c])
+            return
         self._check(self.L.almpc_group_update_initialization(self.g, _ptr(x0)))
 
     def calculate(self, opts: almpc_opts | None = None, sync=True):

@@ -234,7 +234,7 @@ def single_process(args):
         return 2
     g.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max, rho=rho, rho_profile=args.rho_profile)
     g.set_reference(p.x_ref, p.u_ref)
-    g.update_initialization(X0)
+    g.update_initialization(X0, resident=True)   # (HBM resident, as the N-process path: the timed steps do not pull x0 over the link)
     opts = capi.default_opts(rho=rho, max_iter=args.max_iter, check_every=args.max_iter, keep_warm_state=False)
 
     def run(k):
