@@ -97,7 +97,11 @@ def test_admm_iterate_matches_oracle_per_instance(capi, mo):
             assert np.abs(r["e_u"][i].T.reshape(-1) - v).max() <= 1e-9 * max(1.0, np.abs(v).max())
 
 
-@pytest.mark.parametrize("n,m,N", [(1, 1, 1), (2, 1, 12), (3, 2, 7), (5, 3, 9), (4, 2, 20), (7, 5, 25), (2, 1, 128), (16, 8, 16)])
+# (the second row: nz on both sides of every size class of the register inverses -- 16 / 32 / 48 / 64 columns of the one-wave kernel,
+# 65 .. 128 for the multi-wave one)
+@pytest.mark.parametrize("n,m,N", [(1, 1, 1), (2, 1, 12), (3, 2, 7), (5, 3, 9), (4, 2, 20), (7, 5, 25), (2, 1, 128), (16, 8, 16),
+                                   (2, 1, 16), (2, 1, 17), (2, 2, 16), (3, 3, 11), (2, 3, 16), (2, 7, 7), (3, 1, 63), (2, 4, 16),
+                                   (3, 5, 13), (2, 1, 97), (3, 1, 127)])
 def test_random_plant_families_of_many_shapes(capi, mo, n, m, N):
     b = 17
     As, Bs = random_family(n, m, b, seed=1000 * n + 10 * m + N)
@@ -112,6 +116,21 @@ def test_random_plant_families_of_many_shapes(capi, mo, n, m, N):
         if r["status"][i] == 0:
             assert np.abs(r["u"][i] - e["u"]).max() <= U_TOL * max(1.0, np.abs(e["x"]).max())
     assert (r["status"] == 0).mean() >= 0.9
+
+
+def test_more_than_256_designs_beyond_64_variables(capi, mo):
+    """nz = 65 with 300 models: the throughput variant of the multi-wave inverse (more matrices than CUs), odd sizes in both halves."""
+    n, m, N, b = 3, 5, 13, 300
+    As, Bs = random_family(n, m, b, seed=4242)
+    X0 = np.random.default_rng(6).standard_normal((b, n)) * 2.0
+    umin, umax = -np.ones(m), np.ones(m)
+    sv, r = solve_batched(capi, As, Bs, N, umin, umax, X0)
+    sv.close()
+    assert (r["status"] == 0).mean() >= 0.95
+    for i in range(0, b, 37):
+        if r["status"][i] == 0:
+            e = mo.solve_mpc_exact(mo.make_problem(As[i], Bs[i], N, umin, umax), X0[i])
+            assert np.abs(r["u"][i] - e["u"]).max() <= U_TOL * max(1.0, np.abs(e["x"]).max())
 
 
 def test_identical_models_reproduce_the_shared_path(capi, mo):
