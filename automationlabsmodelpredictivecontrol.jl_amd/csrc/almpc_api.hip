@@ -12,6 +12,7 @@
 #include "almpc_sqp.hip.h"
 #include "almpc_comm.hip.h"
 #include "almpc_riccati.hip.h"
+#include "almpc_sdual.hip.h"
 #include "almpc_host_math.h"
 #include "../../include/almpc.h"
 
@@ -127,6 +128,18 @@ struct almpc_handle {
     hipEvent_t ev_guess = nullptr;
     long rP_stride = 0;   // per-instance terminal weights (batched designs): doubles between instances of bP, else 0 with rP
     bool r_batched_P = false;
+    // stage-wise dual active-set solve (k_sdual, csrc/almpc_sdual.hip.h): input box, state box, terminal equality and S in the
+    // multiple-shooting form; stage records of the unconstrained problem (shared: host Riccati at design time)
+    struct Sd {
+        bool ready = false;
+        int nt = 0, NT = 0, MC = 0;          // stage-state dimension (n, or n + m with S) and the instantiated (padded) dimensions
+        double* rec = nullptr; size_t rec_cap = 0; long rec_stride = 0, rec_kstride = 0;
+        double* base = nullptr; size_t base_cap = 0; long base_stride = 0; bool has_base = false;
+        double *xmin = nullptr, *xmax = nullptr, *eqt = nullptr;   // state box [n] (null: none), terminal-equality target [n] zeros (null: none)
+        bool has_box = false, has_eq = false, useS = false;
+        int32_t* ovf = nullptr;
+        std::vector<double> S;               // symmetrised S (base terms of time-varying input references)
+    } sd;
     // multi-GPU (almpc_comm_*): this handle's rank in an RCCL communicator of one process per GPU
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_world = 0;
@@ -247,7 +260,8 @@ void free_all(almpc_handle* h) {
     for (auto& e : h->relin.ev)
         if (e) (void)hipEventDestroy(e);
     if (h->comm && rccl_api().ok) (void)rccl_api().CommDestroy(h->comm);
-    for (void* p : {(void*)h->dComm4, (void*)h->dU0, (void*)h->dU0all, (void*)h->rQ, (void*)h->rR, (void*)h->rP, (void*)h->rKst, (void*)h->rPst, (void*)h->rGuess})
+    for (void* p : {(void*)h->dComm4, (void*)h->dU0, (void*)h->dU0all, (void*)h->rQ, (void*)h->rR, (void*)h->rP, (void*)h->rKst, (void*)h->rPst, (void*)h->rGuess,
+                    (void*)h->sd.rec, (void*)h->sd.base, (void*)h->sd.xmin, (void*)h->sd.xmax, (void*)h->sd.eqt, (void*)h->sd.ovf})
         if (p) (void)hipFree(p);
     if (h->ev_guess) (void)hipEventDestroy(h->ev_guess);
     for (auto& e : h->ev)
@@ -415,6 +429,157 @@ hipError_t launch_riccati(almpc_handle* h, int filter, const double* guess, int 
     return hipGetLastError();
 }
 
+// ---- stage-wise dual active-set solve (k_sdual) ----------------------------------------------------------------------------
+// instantiated (NT, MC): the smallest pair that covers (nt, m)
+const int SD_SHAPES[][2] = {{2, 2}, {4, 2}, {6, 2}, {8, 4}, {12, 4}, {16, 4}, {16, 8}, {32, 16}, {48, 16}};
+bool sdual_pick_shape(int nt, int m, int* NT, int* MC) {
+    for (const auto& s : SD_SHAPES)
+        if (nt <= s[0] && m <= s[1]) { *NT = s[0]; *MC = s[1]; return true; }
+    return false;
+}
+constexpr int SD_WCAP1 = 32, SD_WCAP2 = 64;   // working-set capacity of the first launch / of the redo of the instances that outgrew it
+bool sdual_shape_ok(int n, int m, int N, bool useS) {
+    int NT = 0, MC = 0;
+    if (!sdual_pick_shape(useS ? n + m : n, m, &NT, &MC)) return false;
+    if (sdual_tp(NT, MC, N) > 4096) return false;   // (one bit per coordinate and lane in the working-set mask)
+    return (size_t)sdual_lds_doubles(NT, MC, N, SD_WCAP2) * sizeof(double) <= 160 * 1024;
+}
+
+// Stage records of a SHARED model on the device (host Riccati, design time), state box / terminal equality / S of the design.
+// Rm: the reference's branch rule applied (zeros when R[1,1] == 0); Sm null: no input-rate term.
+int sdual_setup_shared(almpc_handle* h, const hm::mat& Am, const hm::mat& Bm, const hm::mat& Qm, const hm::mat& Rm, const hm::mat* Sm,
+                       const hm::mat& Pm, const double* xmin, const double* xmax, bool terminal_eq) {
+    const int n = h->n, m = h->m, N = h->N;
+    almpc_handle::Sd& sd = h->sd;
+    sd.ready = false;
+    sd.useS = Sm != nullptr;
+    sd.nt = sd.useS ? n + m : n;
+    if (!sdual_pick_shape(sd.nt, m, &sd.NT, &sd.MC) || !sdual_shape_ok(n, m, N, sd.useS))
+        return fail(h, ALMPC_ERR_UNSUPPORTED, "stage-wise solve: n (+ m with an input-rate weight) <= 48, m <= 16 and (N + 1)(n + m) <= 4096");
+    hm::mat rec;
+    bool inv = false;
+    if (!hm::stage_records(Am, Bm, Qm, Rm, Sm, Pm, n, m, N, sd.NT, sd.MC, rec, inv))
+        return fail(h, ALMPC_ERR_NUMERIC, "stage-wise solve: R + B'PB is singular (Riccati recursion of the unconstrained problem)");
+    const size_t stage = (size_t)sdual_rec_stage(sd.NT, sd.MC);
+    const size_t cnt = inv ? stage : stage * N;
+    if (sd.rec_cap < cnt) {
+        if (sd.rec) { (void)hipFree(sd.rec); sd.rec = nullptr; }
+        HIP_TRY(h, dalloc(&sd.rec, cnt));
+        sd.rec_cap = cnt;
+    }
+    HIP_TRY(h, hipMemcpy(sd.rec, rec.data() + (inv ? stage * (N - 1) : 0), cnt * sizeof(double), hipMemcpyHostToDevice));
+    sd.rec_stride = 0;
+    sd.rec_kstride = inv ? 0 : (long)stage;
+    sd.has_box = xmin != nullptr;
+    if (sd.has_box) {
+        if (!sd.xmin) HIP_TRY(h, dalloc(&sd.xmin, (size_t)n));
+        if (!sd.xmax) HIP_TRY(h, dalloc(&sd.xmax, (size_t)n));
+        HIP_TRY(h, hipMemcpy(sd.xmin, xmin, n * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(sd.xmax, xmax, n * sizeof(double), hipMemcpyHostToDevice));
+    }
+    sd.has_eq = terminal_eq;
+    if (sd.has_eq) {
+        if (!sd.eqt) HIP_TRY(h, dalloc(&sd.eqt, (size_t)n));
+        HIP_TRY(h, hipMemset(sd.eqt, 0, n * sizeof(double)));
+    }
+    if (!sd.ovf) HIP_TRY(h, dalloc(&sd.ovf, (size_t)h->batch));
+    HIP_TRY(h, hipMemset(sd.ovf, 0, (size_t)h->batch * sizeof(int32_t)));
+    sd.S = Sm ? *Sm : hm::mat();
+    sd.has_base = false; sd.base_stride = 0;
+    sd.ready = true;
+    return ALMPC_OK;
+}
+
+// Linear cost terms of the stage-wise problem that depend on the references: only the input-rate term does (it is on u = v + u_ref,
+// src/sub/design_mpc.jl:423-446): stage k >= 1 carries (w_k - v_k + dU)'S(w_k - v_k + dU), dU = u_ref[k-1] - u_ref[k]  ->
+// +S dU on the coordinates of w_k = v_{k-1}, -S dU on those of v_k.  Zero for references that are constant over the horizon.
+int sdual_update_base(almpc_handle* h, const double* uref, size_t cnt) {
+    almpc_handle::Sd& sd = h->sd;
+    sd.has_base = false; sd.base_stride = 0;
+    if (!sd.ready || !sd.useS) return ALMPC_OK;
+    const int n = h->n, m = h->m, N = h->N, SP = sd.NT + sd.MC;
+    const size_t TP = (size_t)sdual_tp(sd.NT, sd.MC, N), us = (size_t)h->nz;
+    std::vector<double> base(cnt * TP, 0.0);
+    bool any = false;
+    for (size_t c = 0; c < cnt; ++c)
+        for (int k = 1; k < N; ++k)
+            for (int a = 0; a < m; ++a) {
+                double sv = 0.0;
+                for (int b = 0; b < m; ++b) sv += sd.S[(size_t)b * m + a] * (uref[c * us + (size_t)(k - 1) * m + b] - uref[c * us + (size_t)k * m + b]);
+                if (sv != 0.0) any = true;
+                base[c * TP + (size_t)k * SP + n + a] += sv;
+                base[c * TP + (size_t)k * SP + sd.NT + a] -= sv;
+            }
+    if (!any) return ALMPC_OK;
+    if (sd.base_cap < base.size()) {
+        if (sd.base) { (void)hipFree(sd.base); sd.base = nullptr; }
+        HIP_TRY(h, dalloc(&sd.base, base.size()));
+        sd.base_cap = base.size();
+    }
+    HIP_TRY(h, hipMemcpy(sd.base, base.data(), base.size() * sizeof(double), hipMemcpyHostToDevice));
+    sd.has_base = true;
+    sd.base_stride = cnt > 1 ? (long)TP : 0;
+    return ALMPC_OK;
+}
+
+template <int NT, int MC>
+hipError_t launch_sdual_t(almpc_handle* h, SdualParams sp) {
+    // first launch: every (filtered) instance with room for SD_WCAP1 rows; second: the instances that outgrew it, with SD_WCAP2
+    for (int tier = 0; tier < 2; ++tier) {
+        sp.wcap = tier == 0 ? SD_WCAP1 : SD_WCAP2;
+        sp.only_ovf = tier;
+        sp.lds_per_wave = sdual_lds_doubles(NT, MC, sp.N, sp.wcap);
+        const size_t per = (size_t)sp.lds_per_wave * sizeof(double);
+        int waves = SDUAL_WAVES;
+        while (waves > 1 && per * waves > 160 * 1024) --waves;
+        if (per * waves > 160 * 1024) return hipErrorInvalidValue;
+        if (tier == 1) waves = 1;   // few instances: spread them over the compute units
+        const size_t lds = per * waves;
+        int per_cu = (int)((160 * 1024) / lds);
+        if (per_cu < 1) per_cu = 1;
+        if (per_cu * waves > 8) per_cu = 8 / waves > 0 ? 8 / waves : 1;
+        int wgs = (sp.batch + waves - 1) / waves;
+        const int cap = h->num_cus * per_cu;
+        if (wgs > cap) wgs = cap;
+        const hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(k_sdual<NT, MC>), lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_sdual<NT, MC>), dim3(wgs), dim3(64 * waves), lds, h->stream, sp);
+        const hipError_t e2 = hipGetLastError();
+        if (e2 != hipSuccess) return e2;
+        sp.filter = 0;   // the second tier selects by the overflow flag alone (the first one has rewritten the statuses)
+    }
+    return hipSuccess;
+}
+
+// k_sdual over the batch (filter 0), over the instances whose status is not 0 (filter 1: redo after the condensed path), start from
+// `guess` (inputs [batch][N][m]) when given
+hipError_t launch_sdual(almpc_handle* h, int filter, const double* guess, int max_iter) {
+    const almpc_handle::Sd& sd = h->sd;
+    if (!sd.ready) return hipErrorInvalidValue;
+    SdualParams sp;
+    std::memset(&sp, 0, sizeof(sp));
+    sp.n = h->n; sp.nt = sd.nt; sp.m = h->m; sp.N = h->N; sp.batch = h->batch;
+    sp.rec = sd.rec; sp.rec_stride = sd.rec_stride; sp.rec_kstride = sd.rec_kstride;
+    sp.base = sd.has_base ? sd.base : nullptr; sp.base_stride = sd.base_stride;
+    sp.pc = nullptr; sp.ct = nullptr; sp.pc_stride = 0;
+    sp.umin = h->dUmin; sp.umax = h->dUmax; sp.uref = h->dUref; sp.uref_stride = h->uref_stride;
+    sp.xmin = sd.has_box ? sd.xmin : nullptr; sp.xmax = sd.has_box ? sd.xmax : nullptr;
+    sp.xbref = h->dXref; sp.xbref_stride = h->xref_stride;
+    sp.eqt = sd.has_eq ? sd.eqt : nullptr; sp.eqt_stride = 0;
+    sp.x0 = h->dX0; sp.xref = h->dXref; sp.xref_stride = h->xref_stride;
+    sp.uguess = guess; sp.filter = filter; sp.flag = nullptr; sp.v_only = 0;
+    sp.x = h->dX; sp.ex = h->dEx; sp.u = h->dU; sp.eu = h->dEu; sp.status = h->dStatus; sp.piters = h->dPiters;
+    sp.ovf = sd.ovf; sp.only_ovf = 0;
+    sp.rows_state = (sd.has_box || sd.has_eq) ? 1 : 0;
+    const int rows = h->N * h->m + ((sd.has_box || sd.has_eq) ? h->N * h->n : 0);
+    sp.max_iter = max_iter > 0 ? max_iter : 20 * rows + 50;
+    sp.tol = 1e-9;
+#define SD_CASE(NT_, MC_) if (sd.NT == NT_ && sd.MC == MC_) return launch_sdual_t<NT_, MC_>(h, sp)
+    SD_CASE(2, 2); SD_CASE(4, 2); SD_CASE(6, 2); SD_CASE(8, 4); SD_CASE(12, 4); SD_CASE(16, 4); SD_CASE(16, 8); SD_CASE(32, 16); SD_CASE(48, 16);
+#undef SD_CASE
+    return hipErrorInvalidValue;
+}
+
 }  // namespace
 
 extern "C" {
@@ -546,7 +711,6 @@ int almpc_set_terminal_equality(almpc_handle* h, int on) {
 int almpc_set_state_box(almpc_handle* h, const double* xmin, const double* xmax) {
     if (!h) return ALMPC_ERR_INVALID;
     if ((xmin == nullptr) != (xmax == nullptr)) return fail(h, ALMPC_ERR_INVALID, "set_state_box: give both xmin and xmax or neither");
-    if (h->structured && xmin) return fail(h, ALMPC_ERR_UNSUPPORTED, "structured solve: input box only (no state rows)");
     if (xmin) {
         for (int i = 0; i < h->n; ++i)
             if (!(xmin[i] <= xmax[i])) return fail(h, ALMPC_ERR_INVALID, "set_state_box: xmin > xmax");
@@ -593,10 +757,12 @@ int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const
     if (!A || !B || !Q || !R || !umin || !umax) return fail(h, ALMPC_ERR_INVALID, "design: null matrix pointer");
     if (h->structured) {   // ALMPC_FLAG_STRUCTURED: no condensed matrices at all; rho / sigma are not used
         const int n = h->n, m = h->m, N = h->N;
-        if (xmin || xmax || h->terminal_eq) return fail(h, ALMPC_ERR_UNSUPPORTED, "structured solve: input box only (no state rows)");
-        if (R[0] != 0.0 && S && S[0] != 0.0) return fail(h, ALMPC_ERR_UNSUPPORTED, "structured solve: no input-rate weight S");
+        if ((xmin == nullptr) != (xmax == nullptr)) return fail(h, ALMPC_ERR_INVALID, "design: give both xmin and xmax or neither");
         for (int i = 0; i < m; ++i)
             if (!(umin[i] <= umax[i])) return fail(h, ALMPC_ERR_INVALID, "design: umin > umax");
+        if (xmin)
+            for (int i = 0; i < n; ++i)
+                if (!(xmin[i] <= xmax[i])) return fail(h, ALMPC_ERR_INVALID, "design: xmin > xmax");
         h->designed = false;
         h->r_has_step = false; h->guess_ready = false;
         h->sqp.ready = h->sqp.started = false;   // (an SQP loop set up on this handle is gone with its per-instance reference buffers)
@@ -605,13 +771,30 @@ int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const
         if (P) Pm.assign(P, P + (size_t)n * n);
         else if (!hm::dare(Am, Bm, Qm, Rm, n, m, Pm)) return fail(h, ALMPC_ERR_NUMERIC, "design: DARE did not converge");
         h->P = Pm; h->H.clear(); h->F.clear(); h->d.clear();
-        { const int rc_ = riccati_weights(h, Qm, Rm, Pm.data()); if (rc_ != ALMPC_OK) return rc_; }
+        // the reference's branch rules (src/sub/design_mpc.jl:423-466): R and S enter only with a non-zero [1,1] element, S only with R
+        const bool useS = R[0] != 0.0 && S && S[0] != 0.0;
+        hm::mat Rb = Rm, Sm;
+        if (Rm[0] == 0.0) std::fill(Rb.begin(), Rb.end(), 0.0);
+        if (useS) Sm.assign(S, S + (size_t)m * m);
+        h->sd.ready = false;
+        if (sdual_shape_ok(n, m, N, useS) && !getenv("ALMPC_STRUCTURED_PRIMAL")) {
+            // the stage-wise dual active set (k_sdual): input box, state box, terminal equality, input-rate weight
+            const int rc_ = sdual_setup_shared(h, Am, Bm, Qm, Rb, useS ? &Sm : nullptr, Pm, xmin, xmax, h->terminal_eq != 0);
+            if (rc_ != ALMPC_OK) return rc_;
+        } else if (xmin || h->terminal_eq || useS)
+            return fail(h, ALMPC_ERR_UNSUPPORTED, "structured solve: state rows / input-rate weight need the stage-wise dual solve (n + m <= 48, (N + 1)(n + m) <= 4096)");
+        // the primal Riccati active set (k_riccati, input box only): the solver of shapes k_sdual does not cover and the safety net for
+        // instances the dual method leaves without a certificate (a saturated open-loop unstable plant: Ghat_WW numerically singular)
+        if (riccati_shape_ok(h)) { const int rc_ = riccati_weights(h, Qm, Rm, Pm.data()); if (rc_ != ALMPC_OK) return rc_; }
+        else if (!h->sd.ready) return fail(h, ALMPC_ERR_UNSUPPORTED, "structured solve: shape outside both stage-wise solvers");
         HIP_TRY(h, hipMemcpy(h->dUmin, umin, m * sizeof(double), hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(h->dUmax, umax, m * sizeof(double), hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(h->dA, A, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(h->dB, B, (size_t)n * m * sizeof(double), hipMemcpyHostToDevice));
         h->batched = false; h->ltv = false; h->r_batched_P = false; h->rP_stride = 0;
-        h->hS.assign((size_t)m * m, 0.0); h->useS = 0;
+        h->hS.assign((size_t)m * m, 0.0); h->useS = useS ? 1 : 0;
+        if (useS) h->hS = Sm;
+        h->has_box = xmin ? 1 : 0;
         h->designed = true;
         std::vector<double> xr((size_t)n * (N + 1), 0.0), ur((size_t)h->nz, 0.0);
         const int rc_ref = almpc_set_reference(h, xr.data(), ur.data(), 0);
@@ -1706,6 +1889,7 @@ int almpc_set_reference(almpc_handle* h, const double* xref, const double* uref,
         HIP_TRY(h, hipMemcpy(h->dUref, uref, cnt * us * sizeof(double), hipMemcpyHostToDevice));
         h->xref_stride = per_instance ? (long)xs : 0;
         h->uref_stride = per_instance ? (long)us : 0;
+        { const int rc_ = sdual_update_base(h, uref, cnt); if (rc_ != ALMPC_OK) return rc_; }
         h->designed = true;
         return ALMPC_OK;
     }
@@ -1838,7 +2022,12 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
             HIP_TRY(h, hipGetLastError());
             guess = h->rGuess;
         }
-        HIP_TRY(h, launch_riccati(h, 0, guess, o.polish_max_iter));
+        if (h->sd.ready) {
+            HIP_TRY(h, launch_sdual(h, 0, guess, o.polish_max_iter));
+            // safety net (input box only, S = 0): what the dual method left without a certificate goes to the primal Riccati active set
+            if (!h->sd.has_box && !h->sd.has_eq && !h->sd.useS && h->rKst && !h->batched) HIP_TRY(h, launch_riccati(h, 1, h->dU, 0));
+        } else
+            HIP_TRY(h, launch_riccati(h, 0, guess, o.polish_max_iter));
         h->r_has_step = true;
         return io_step_done();
     }

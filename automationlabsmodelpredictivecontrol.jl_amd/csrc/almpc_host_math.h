@@ -126,5 +126,97 @@ inline bool dare(const mat& A, const mat& B, const mat& Q, const mat& R, int n, 
     return true;
 }
 
+// Stage records of the UNCONSTRAINED stage-wise problem for k_sdual (csrc/almpc_sdual.hip.h), shared model: backward Riccati
+// recursion of the reference's cost (src/sub/design_mpc.jl:405-468: Q on stages 1..N-1, P on stage N, R on every input, and -- when
+// `S` is given -- the input-rate term (u_k - u_{k+1})'S(u_k - u_{k+1}), k = 0..N-2, which makes the stage state [e_k; v_{k-1}],
+// nt = n + m, and adds cross terms) over e_{k+1} = A e_k + B v_k.  Per stage k and row l of NT + MC rows, 2 NT + 2 MC doubles:
+//   l < nt:      [ Acl'(l, :) | -K(:, l)' | Acl(l, :) | -Bt(l, :) ]        Acl = At - Bt K,  K = Lam^-1 (Bt'P+At + M'),
+//   l = NT + a:  [ Lb(a, :)   | Li(a, :)  | -K(a, :)  | -e_a      ]        Lam = Rt + Bt'P+Bt, Li = Lam^-1, Lb = Li Bt'
+// (oracle: oracle/stagewise_oracle.py::stage_gains).  R: the reference's branch rule already applied by the caller (zeros when R[1,1]
+// == 0).  `invariant`: every stage has the same record to 1e-11 (DARE terminal weight, no S): the kernel then loads it once.
+inline bool stage_records(const mat& A, const mat& B, const mat& Q, const mat& R, const mat* S, const mat& P, int n, int m, int N,
+                          int NT, int MC, mat& rec, bool& invariant) {
+    const int nt = S ? n + m : n;
+    if (nt > NT || m > MC) return false;
+    const int RL = 2 * NT + 2 * MC, LRP = NT + MC;
+    const size_t stage = (size_t)LRP * RL;
+    rec.assign(stage * N, 0.0);
+    mat At((size_t)nt * nt, 0.0), Bt((size_t)nt * m, 0.0);
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) At[(size_t)j * nt + i] = A[(size_t)j * n + i];
+    for (int a = 0; a < m; ++a) {
+        for (int i = 0; i < n; ++i) Bt[(size_t)a * nt + i] = B[(size_t)a * n + i];
+        if (S) Bt[(size_t)a * nt + n + a] = 1.0;
+    }
+    const mat AtT = transpose(At, nt, nt), BtT = transpose(Bt, nt, m);
+    mat Pn((size_t)nt * nt, 0.0);
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) Pn[(size_t)j * nt + i] = 0.5 * (P[(size_t)j * n + i] + P[(size_t)i * n + j]);
+    for (int k = N - 1; k >= 0; --k) {
+        mat Qt((size_t)nt * nt, 0.0), Mx((size_t)nt * m, 0.0), Rt = R;
+        for (int j = 0; j < m; ++j)
+            for (int i = 0; i < m; ++i) Rt[(size_t)j * m + i] = 0.5 * (R[(size_t)j * m + i] + R[(size_t)i * m + j]);
+        if (k >= 1) {
+            for (int j = 0; j < n; ++j)
+                for (int i = 0; i < n; ++i) Qt[(size_t)j * nt + i] = 0.5 * (Q[(size_t)j * n + i] + Q[(size_t)i * n + j]);
+            if (S)
+                for (int b = 0; b < m; ++b)
+                    for (int a = 0; a < m; ++a) {
+                        const double sv = 0.5 * ((*S)[(size_t)b * m + a] + (*S)[(size_t)a * m + b]);
+                        Qt[(size_t)(n + b) * nt + n + a] = sv;
+                        Mx[(size_t)b * nt + n + a] = -sv;
+                        Rt[(size_t)b * m + a] += sv;
+                    }
+        }
+        const mat PA = mul(Pn, At, nt, nt, nt), PB = mul(Pn, Bt, nt, nt, m);
+        mat Lam = mul(BtT, PB, m, nt, m);
+        for (size_t i = 0; i < Lam.size(); ++i) Lam[i] += Rt[i];
+        mat Gm = mul(BtT, PA, m, nt, nt);   // m x nt
+        for (int j = 0; j < nt; ++j)
+            for (int a = 0; a < m; ++a) Gm[(size_t)j * m + a] += Mx[(size_t)a * nt + j];
+        mat Li = eye(m);
+        if (!lu_solve(Lam, Li, m, m)) return false;
+        for (int b = 0; b < m; ++b)
+            for (int a = 0; a < b; ++a) { const double v = 0.5 * (Li[(size_t)b * m + a] + Li[(size_t)a * m + b]); Li[(size_t)b * m + a] = Li[(size_t)a * m + b] = v; }
+        const mat K = mul(Li, Gm, m, m, nt);     // m x nt
+        const mat Lb = mul(Li, BtT, m, m, nt);   // m x nt
+        mat Acl = At;
+        const mat BK = mul(Bt, K, nt, m, nt);
+        for (size_t i = 0; i < Acl.size(); ++i) Acl[i] -= BK[i];
+        for (double v : K)
+            if (!std::isfinite(v)) return false;
+        double* rk = rec.data() + stage * k;
+        for (int l = 0; l < nt; ++l) {
+            double* row = rk + (size_t)l * RL;
+            for (int j = 0; j < nt; ++j) row[j] = Acl[(size_t)l * nt + j];                       // Acl'(l, j) = Acl(j, l)
+            for (int b = 0; b < m; ++b) row[NT + b] = -K[(size_t)l * m + b];                    // -K(b, l)
+            for (int j = 0; j < nt; ++j) row[NT + MC + j] = Acl[(size_t)j * nt + l];            // Acl(l, j)
+            for (int b = 0; b < m; ++b) row[2 * NT + MC + b] = -Bt[(size_t)b * nt + l];         // -Bt(l, b)
+        }
+        for (int a = 0; a < m; ++a) {
+            double* row = rk + (size_t)(NT + a) * RL;
+            for (int j = 0; j < nt; ++j) row[j] = Lb[(size_t)j * m + a];
+            for (int b = 0; b < m; ++b) row[NT + b] = Li[(size_t)b * m + a];
+            for (int j = 0; j < nt; ++j) row[NT + MC + j] = -K[(size_t)j * m + a];
+            row[2 * NT + MC + a] = -1.0;
+        }
+        // P_k = Qt + At'P+At - Gm'K, symmetrised
+        mat Pnew = mul(AtT, PA, nt, nt, nt);
+        const mat GK = mul(transpose(Gm, m, nt), K, nt, m, nt);
+        for (size_t i = 0; i < Pnew.size(); ++i) Pnew[i] += Qt[i] - GK[i];
+        for (int j = 0; j < nt; ++j)
+            for (int i = 0; i <= j; ++i) {
+                const double v = 0.5 * (Pnew[(size_t)j * nt + i] + Pnew[(size_t)i * nt + j]);
+                Pn[(size_t)j * nt + i] = Pn[(size_t)i * nt + j] = v;
+            }
+    }
+    double scale = 0.0, dev = 0.0;
+    for (size_t i = 0; i < stage; ++i) scale = std::fmax(scale, std::fabs(rec[stage * (N - 1) + i]));
+    for (int k = 0; k + 1 < N; ++k)
+        for (size_t i = 0; i < stage; ++i) dev = std::fmax(dev, std::fabs(rec[stage * k + i] - rec[stage * (N - 1) + i]));
+    invariant = dev <= 1e-11 * std::fmax(scale, 1e-300);
+    return true;
+}
+
 }  // namespace hm
 }  // namespace almpc

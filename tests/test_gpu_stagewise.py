@@ -1,0 +1,148 @@
+"""GPU tests of the stage-wise dual active-set solve, k_sdual (csrc/almpc_sdual.hip.h): the multiple-shooting form the reference
+builds -- dynamics as constraints, input box, state box on every stage (..linear.jl:48-78), terminal equality
+(src/sub/design_mpc.jl:330-331), input-rate weight S (src/sub/design_mpc.jl:423-446) -- on structured handles, i.e. also beyond the
+condensed kernels' m N <= 128 (quadrotor at N = 50: m N = 200).
+Oracles: mpc_oracle.solve_mpc_exact (the condensed exact solver with its method-independent KKT certificate; raises ValueError for an
+infeasible problem) at 1e-6 on u, and the numpy restatement of the same algorithm (stagewise_oracle.solve_stage_dual: same decisions,
+so the iteration counts agree)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+U_TOL = 1e-6
+
+XMAX = np.array([3, 3, 3, 1.5, 1.5, 1.5, 0.3, 0.3, 0.3, 1.0, 1.0, 1.0])
+
+
+@pytest.fixture(scope="module")
+def so():
+    import stagewise_oracle
+    return stagewise_oracle
+
+
+def _solve(capi, p, X0, guess_from=None, **kw):
+    s = capi.Solver(p.n, p.m, p.N, len(X0), structured=True)
+    s.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max, xmin=p.x_min, xmax=p.x_max, terminal=p.terminal)
+    s.set_reference(p.x_ref, p.u_ref)
+    s.update_initialization(X0)
+    s.calculate()
+    r = s.get_results()
+    s.close()
+    return r
+
+
+def _check_against_exact(mo, p, X0, r, sample):
+    """status and u of the sampled instances against the exact oracle: 0 <-> solved within U_TOL, 3 <-> the oracle raises ValueError"""
+    n_inf = 0
+    for i in sample:
+        try:
+            e = mo.solve_mpc_exact(p, X0[i])
+        except ValueError:
+            assert r["status"][i] == 3, (i, r["status"][i])
+            n_inf += 1
+            continue
+        assert r["status"][i] == 0, (i, r["status"][i])
+        assert np.abs(r["u"][i] - e["u"]).max() <= U_TOL, (i, np.abs(r["u"][i] - e["u"]).max())
+        assert np.abs(r["x"][i] - e["x"]).max() <= 1e-5
+    return n_inf
+
+
+def _properties(p, X0, r):
+    """every solved instance: dynamics, input box, state box, terminal equality"""
+    ok = r["status"] == 0
+    ex, eu = r["e_x"][ok], r["e_u"][ok]
+    pred = np.einsum("ij,bjk->bik", p.A, ex[:, :, :-1]) + np.einsum("ij,bjk->bik", p.B, eu)
+    assert np.abs(pred - ex[:, :, 1:]).max() <= 1e-8 * max(1.0, np.abs(ex).max())
+    assert np.all(r["u"][ok] >= p.u_min[None, :, None]) and np.all(r["u"][ok] <= p.u_max[None, :, None])
+    if p.x_min is not None:
+        assert np.all(r["x"][ok] >= p.x_min[None, :, None] - 1e-7) and np.all(r["x"][ok] <= p.x_max[None, :, None] + 1e-7)
+    if p.terminal == "equality":
+        assert np.abs(ex[:, :, -1]).max() <= 1e-7
+    np.testing.assert_array_equal(r["x"][:, :, 0], X0)
+
+
+@pytest.mark.parametrize("case", ["box", "box_only_inputs", "eq", "box_eq", "S", "S_box_tvref"])
+def test_quadrotor_N30_against_the_exact_oracle(capi, mo, so, case):
+    q = mo.quadrotor(30)
+    kw = {}
+    amp = 3.0
+    if case in ("box", "box_eq", "S_box_tvref"):
+        kw.update(x_min=-XMAX, x_max=XMAX)
+    if case in ("eq", "box_eq"):
+        kw.update(terminal="equality"); amp = 1.0
+    if case in ("S", "S_box_tvref"):
+        kw.update(s=5.0)
+    if case == "S_box_tvref":
+        kw.update(u_ref=0.01 * np.sin(np.arange(30))[None, :] * np.ones((4, 1)))
+    p = mo.make_problem(q.A, q.B, 30, q.u_min, q.u_max, **kw)
+    X0 = mo.quadrotor_x0_batch(96, amp)
+    if p.x_min is not None:
+        X0 = np.clip(X0, -0.99 * XMAX, 0.99 * XMAX)
+    r = _solve(capi, p, X0)
+    assert set(np.unique(r["status"])) <= {0, 3}
+    _properties(p, X0, r)
+    n_inf = _check_against_exact(mo, p, X0, r, range(0, 96, 4))
+    if case in ("box_only_inputs", "eq", "S"):
+        assert n_inf == 0 and np.all(r["status"] == 0)
+    # same decisions as the numpy restatement
+    for i in (0, 17, 50, 95):
+        o = so.solve_mpc_stagewise(p, X0[i])
+        assert o["status"] == r["status"][i]
+        if o["status"] == 0:
+            assert o["iters"] == r["polish_iters"][i], (i, o["iters"], r["polish_iters"][i])
+            assert np.abs(r["u"][i] - o["u"]).max() <= 1e-9
+
+
+@pytest.mark.parametrize("case", ["box", "eq", "S"])
+def test_quadrotor_N50_state_rows_beyond_the_condensed_horizon(capi, mo, so, case):
+    """m N = 200: no condensed handle exists for this shape (missing #1)."""
+    q = mo.quadrotor(50)
+    kw = dict(x_min=-XMAX, x_max=XMAX) if case == "box" else (dict(terminal="equality") if case == "eq" else dict(s=5.0))
+    p = mo.make_problem(q.A, q.B, 50, q.u_min, q.u_max, **kw)
+    X0 = np.concatenate([mo.quadrotor_x0_batch(48, a, first_instance=48 * k) for k, a in enumerate((0.3, 1.0, 3.0))])
+    if case == "eq":
+        X0 = X0[:96]
+    if p.x_min is not None:
+        X0 = np.clip(X0, -0.99 * XMAX, 0.99 * XMAX)
+    r = _solve(capi, p, X0)
+    assert set(np.unique(r["status"])) <= {0, 3}
+    _properties(p, X0, r)
+    n_inf = _check_against_exact(mo, p, X0, r, range(0, len(X0), 6))
+    if case != "box":
+        assert n_inf == 0 and np.all(r["status"] == 0)
+    for i in (0, 60, len(X0) - 1):
+        o = so.solve_mpc_stagewise(p, X0[i])
+        assert o["status"] == r["status"][i]
+        if o["status"] == 0:
+            assert o["iters"] == r["polish_iters"][i]
+
+
+def test_double_integrator_with_everything(capi, mo, so):
+    """n = 2, m = 1 (padded to the (4, 2) build with S): box, equality and S together, infeasible instances named."""
+    d = mo.double_integrator(10)
+    p = mo.make_problem(d.A, d.B, 6, d.u_min, d.u_max, s=2.0, x_min=[-6.0, -1.5], x_max=[6.0, 1.5], terminal="equality")
+    rng = np.random.default_rng(3)
+    X0 = np.stack([rng.uniform(-5.9, 5.9, 64), rng.uniform(-1.4, 1.4, 64)], axis=1)
+    r = _solve(capi, p, X0)
+    assert set(np.unique(r["status"])) <= {0, 3}
+    assert (r["status"] == 0).sum() >= 8 and (r["status"] == 3).sum() >= 2
+    _properties(p, X0, r)
+    _check_against_exact(mo, p, X0, r, range(64))
+
+
+def test_working_sets_beyond_the_first_tier(capi, mo, so):
+    """Heavily saturated instances: more than 32 rows in the working set (second launch with room for 64)."""
+    q = mo.quadrotor(50)
+    p = mo.make_problem(q.A, q.B, 50, q.u_min, q.u_max)
+    X0 = mo.quadrotor_x0_batch(48, 6.0)
+    r = _solve(capi, p, X0)
+    assert np.all(r["status"] == 0)
+    big = 0
+    for i in range(0, 48, 4):
+        e = mo.solve_mpc_exact(p, X0[i])
+        assert np.abs(r["u"][i] - e["u"]).max() <= U_TOL
+        v = e["e_u"]
+        nact = int(((e["u"] >= p.u_max[:, None] - 1e-12) | (e["u"] <= p.u_min[:, None] + 1e-12)).sum())
+        big += nact > 32
+    assert big >= 1
