@@ -138,6 +138,8 @@ struct almpc_handle {
         double *xmin = nullptr, *xmax = nullptr, *eqt = nullptr;   // state box [n] (null: none), terminal-equality target [n] zeros (null: none)
         bool has_box = false, has_eq = false, useS = false;
         int32_t* ovf = nullptr;
+        int32_t* wsave = nullptr;   // [batch][SDUAL_WSAVE] working set of an instance that ran out of room (start of the next tier)
+        double* sinv_glb = nullptr; size_t sinv_cap = 0;   // third tier: Sinv of 128 x 129 per wave of its grid
         std::vector<double> S;               // symmetrised S (base terms of time-varying input references)
     } sd;
     // multi-GPU (almpc_comm_*): this handle's rank in an RCCL communicator of one process per GPU
@@ -261,7 +263,7 @@ void free_all(almpc_handle* h) {
         if (e) (void)hipEventDestroy(e);
     if (h->comm && rccl_api().ok) (void)rccl_api().CommDestroy(h->comm);
     for (void* p : {(void*)h->dComm4, (void*)h->dU0, (void*)h->dU0all, (void*)h->rQ, (void*)h->rR, (void*)h->rP, (void*)h->rKst, (void*)h->rPst, (void*)h->rGuess,
-                    (void*)h->sd.rec, (void*)h->sd.base, (void*)h->sd.xmin, (void*)h->sd.xmax, (void*)h->sd.eqt, (void*)h->sd.ovf})
+                    (void*)h->sd.rec, (void*)h->sd.base, (void*)h->sd.xmin, (void*)h->sd.xmax, (void*)h->sd.eqt, (void*)h->sd.ovf, (void*)h->sd.wsave, (void*)h->sd.sinv_glb})
         if (p) (void)hipFree(p);
     if (h->ev_guess) (void)hipEventDestroy(h->ev_guess);
     for (auto& e : h->ev)
@@ -437,11 +439,11 @@ bool sdual_pick_shape(int nt, int m, int* NT, int* MC) {
         if (nt <= s[0] && m <= s[1]) { *NT = s[0]; *MC = s[1]; return true; }
     return false;
 }
-constexpr int SD_WCAP1 = 32, SD_WCAP2 = 64;   // working-set capacity of the first launch / of the redo of the instances that outgrew it
+constexpr int SD_WCAP1 = 32, SD_WCAP2 = 64, SD_WCAP3 = 128;   // working-set capacity of the first launch / of the redos of the instances that outgrew it
 bool sdual_shape_ok(int n, int m, int N, bool useS) {
     int NT = 0, MC = 0;
     if (!sdual_pick_shape(useS ? n + m : n, m, &NT, &MC)) return false;
-    if (sdual_tp(NT, MC, N) > 4096) return false;   // (one bit per coordinate and lane in the working-set mask)
+    if ((N + 64 / (NT + MC)) / (64 / (NT + MC)) > 64) return false;   // (one bit per coordinate and lane in the working-set mask)
     return (size_t)sdual_lds_doubles(NT, MC, N, SD_WCAP2) * sizeof(double) <= 160 * 1024;
 }
 
@@ -483,6 +485,7 @@ int sdual_setup_shared(almpc_handle* h, const hm::mat& Am, const hm::mat& Bm, co
         HIP_TRY(h, hipMemset(sd.eqt, 0, n * sizeof(double)));
     }
     if (!sd.ovf) HIP_TRY(h, dalloc(&sd.ovf, (size_t)h->batch));
+    if (!sd.wsave) HIP_TRY(h, dalloc(&sd.wsave, (size_t)h->batch * SDUAL_WSAVE));
     HIP_TRY(h, hipMemset(sd.ovf, 0, (size_t)h->batch * sizeof(int32_t)));
     sd.S = Sm ? *Sm : hm::mat();
     sd.has_base = false; sd.base_stride = 0;
@@ -524,29 +527,47 @@ int sdual_update_base(almpc_handle* h, const double* uref, size_t cnt) {
 
 template <int NT, int MC>
 hipError_t launch_sdual_t(almpc_handle* h, SdualParams sp) {
-    // first launch: every (filtered) instance with room for SD_WCAP1 rows; second: the instances that outgrew it, with SD_WCAP2
-    for (int tier = 0; tier < 2; ++tier) {
-        sp.wcap = tier == 0 ? SD_WCAP1 : SD_WCAP2;
-        sp.only_ovf = tier;
-        sp.lds_per_wave = sdual_lds_doubles(NT, MC, sp.N, sp.wcap);
+    // first launch: every (filtered) instance with room for SD_WCAP1 rows; second: the instances that outgrew it, with SD_WCAP2;
+    // third: SD_WCAP3 rows, two working-set positions per lane, Sinv in a global scratch (rare: mostly infeasible instances whose
+    // verdict needs that many rows)
+    for (int tier = 0; tier < 3; ++tier) {
+        sp.wcap = tier == 0 ? SD_WCAP1 : (tier == 1 ? SD_WCAP2 : SD_WCAP3);
+        sp.only_ovf = tier > 0;
+        sp.lds_per_wave = sdual_lds_doubles(NT, MC, sp.N, sp.wcap, tier < 2);
         const size_t per = (size_t)sp.lds_per_wave * sizeof(double);
         int waves = SDUAL_WAVES;
         while (waves > 1 && per * waves > 160 * 1024) --waves;
         if (per * waves > 160 * 1024) return hipErrorInvalidValue;
-        if (tier == 1) waves = 1;   // few instances: spread them over the compute units
+        if (tier >= 1) waves = 1;   // few instances: spread them over the compute units
         const size_t lds = per * waves;
         int per_cu = (int)((160 * 1024) / lds);
         if (per_cu < 1) per_cu = 1;
         if (per_cu * waves > 8) per_cu = 8 / waves > 0 ? 8 / waves : 1;
         int wgs = (sp.batch + waves - 1) / waves;
-        const int cap = h->num_cus * per_cu;
+        int cap = h->num_cus * per_cu;
+        if (tier == 2) cap = h->num_cus;
         if (wgs > cap) wgs = cap;
-        const hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(k_sdual<NT, MC>), lds);
+        hipError_t e;
+        if (tier < 2) {
+            e = ensure_dyn_lds(reinterpret_cast<const void*>(k_sdual<NT, MC, 1>), lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((k_sdual<NT, MC, 1>), dim3(wgs), dim3(64 * waves), lds, h->stream, sp);
+        } else {
+            const size_t need = (size_t)wgs * waves * SD_WCAP3 * (SD_WCAP3 + 1);
+            if (h->sd.sinv_cap < need) {
+                if (h->sd.sinv_glb) { (void)hipFree(h->sd.sinv_glb); h->sd.sinv_glb = nullptr; h->sd.sinv_cap = 0; }
+                e = dalloc(&h->sd.sinv_glb, need);
+                if (e != hipSuccess) return e;
+                h->sd.sinv_cap = need;
+            }
+            sp.sinv_glb = h->sd.sinv_glb;
+            e = ensure_dyn_lds(reinterpret_cast<const void*>(k_sdual<NT, MC, 2>), lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((k_sdual<NT, MC, 2>), dim3(wgs), dim3(64 * waves), lds, h->stream, sp);
+        }
+        e = hipGetLastError();
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_sdual<NT, MC>), dim3(wgs), dim3(64 * waves), lds, h->stream, sp);
-        const hipError_t e2 = hipGetLastError();
-        if (e2 != hipSuccess) return e2;
-        sp.filter = 0;   // the second tier selects by the overflow flag alone (the first one has rewritten the statuses)
+        sp.filter = 0;   // the later tiers select by the overflow flag alone (the first one has rewritten the statuses)
     }
     return hipSuccess;
 }
@@ -569,7 +590,7 @@ hipError_t launch_sdual(almpc_handle* h, int filter, const double* guess, int ma
     sp.x0 = h->dX0; sp.xref = h->dXref; sp.xref_stride = h->xref_stride;
     sp.uguess = guess; sp.filter = filter; sp.flag = nullptr; sp.v_only = 0;
     sp.x = h->dX; sp.ex = h->dEx; sp.u = h->dU; sp.eu = h->dEu; sp.status = h->dStatus; sp.piters = h->dPiters;
-    sp.ovf = sd.ovf; sp.only_ovf = 0;
+    sp.ovf = sd.ovf; sp.only_ovf = 0; sp.wsave = sd.wsave;
     sp.rows_state = (sd.has_box || sd.has_eq) ? 1 : 0;
     const int rows = h->N * h->m + ((sd.has_box || sd.has_eq) ? h->N * h->n : 0);
     sp.max_iter = max_iter > 0 ? max_iter : 20 * rows + 50;

@@ -23,6 +23,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
+#include "almpc_kernels.hip.h"
 
 namespace almpc {
 
@@ -43,19 +45,21 @@ struct SdualParams {
     int v_only;                                        // 1: write e_u, status, piters only
     double* x; double* ex; double* u; double* eu;      // results, layouts of almpc_get_results
     int32_t* status; int32_t* piters;
-    int32_t* ovf;                                      // [batch] or null: 1 = the working set outgrew wcap (the caller redoes it with more room)
+    int32_t* ovf;                                      // [batch] or null: 1 + rows = the working set outgrew wcap (the caller redoes it with more room)
+    int32_t* wsave;                                    // [batch][SDUAL_WSAVE] or null: that working set (row << 2 | side code), the start of the next tier
     int only_ovf;                                      // 1: only instances with ovf != 0 (second tier)
     int rows_state;                                    // 1: the problem has state rows (an "infeasible" verdict is meaningful)
     int max_iter;
     double tol;
-    int wcap;                                          // working-set capacity (<= 64)
+    int wcap;                                          // working-set capacity (<= 64 PPL)
     int lds_per_wave;                                  // doubles
+    double* sinv_glb;                                  // PPL = 2 builds: [waves in the grid][wcap (wcap + 1)] scratch for Sinv
 };
 
 __host__ __device__ inline int sdual_tp(int NT, int MC, int N) { return (N * (NT + MC) + NT + 1) & ~1; }
-__host__ __device__ inline int sdual_lds_doubles(int NT, int MC, int N, int wcap) {
-    // s, w: 2 TP | Sinv: wcap (wcap + 1) | gbuf NT | cbuf, ubuf: 2 wcap
-    return (2 * sdual_tp(NT, MC, N) + wcap * (wcap + 1) + NT + 2 * wcap + 4 + 1) & ~1;
+__host__ __device__ inline int sdual_lds_doubles(int NT, int MC, int N, int wcap, bool sinv_in_lds = true) {
+    // s, w: 2 TP | Sinv: wcap (wcap + 1) (first two tiers) | gbuf NT | cbuf, ubuf: 2 wcap | slist: 128 ints | blo, bhi: 2 (NT + MC) | beq: NT
+    return (2 * sdual_tp(NT, MC, N) + (sinv_in_lds ? wcap * (wcap + 1) : 0) + NT + 2 * wcap + 64 + 2 * (NT + MC) + NT + 4 + 1) & ~1;
 }
 __host__ __device__ inline int sdual_rec_row(int NT, int MC) { return 2 * NT + 2 * MC; }
 __host__ __device__ inline int sdual_rec_stage(int NT, int MC) { return (NT + MC) * sdual_rec_row(NT, MC); }
@@ -66,50 +70,112 @@ __device__ __forceinline__ void sd_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ double sd_wave_sum(double v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ int sd_wave_max_i(int v) {
-    for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(v, o); v = w > v ? w : v; }
-    return v;
-}
+// wave-wide reductions on the DPP path (almpc_kernels.hip.h: row_ror butterflies, row_bcast15 / 31; ~100 cycles) -- the
+// __shfl_xor butterflies they replace go through the LDS crossbar (ds_bpermute: ~150 cycles per step, six steps, three values)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int sd_dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false); }
+#define SD_WAVE_REDUCE_I(NAME, OP)                                                                       \
+    __device__ __forceinline__ int NAME(int v) {                                                          \
+        { const int o = sd_dpp_i<0x121, 0xF>(v); v = OP(v, o); }                                          \
+        { const int o = sd_dpp_i<0x122, 0xF>(v); v = OP(v, o); }                                          \
+        { const int o = sd_dpp_i<0x124, 0xF>(v); v = OP(v, o); }                                          \
+        { const int o = sd_dpp_i<0x128, 0xF>(v); v = OP(v, o); }                                          \
+        { const int o = sd_dpp_i<0x142, 0xA>(v); const bool take = ((threadIdx.x >> 4) & 1) != 0; v = take ? OP(v, o) : v; }   \
+        { const int o = sd_dpp_i<0x143, 0xC>(v); const bool take = ((threadIdx.x >> 5) & 1) != 0; v = take ? OP(v, o) : v; }   \
+        return __builtin_amdgcn_readlane(v, 63);                                                          \
+    }
+__device__ __forceinline__ int sd_op_max_i(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int sd_op_min_i(int a, int b) { return a < b ? a : b; }
+SD_WAVE_REDUCE_I(sd_wave_max_i, sd_op_max_i)
+SD_WAVE_REDUCE_I(sd_wave_min_i, sd_op_min_i)
+#undef SD_WAVE_REDUCE_I
+__device__ __forceinline__ double sd_wave_sum(double v) { return wave_sum(v); }
 // (value, index) reductions: larger / smaller value wins, ties -> smaller index
 __device__ __forceinline__ void sd_argmax(double& v, int& idx) {
-    for (int o = 32; o > 0; o >>= 1) {
-        const double ov = __shfl_xor(v, o);
-        const int oi = __shfl_xor(idx, o);
-        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-    }
+    const double mv = wave_max(v);
+    idx = sd_wave_min_i(v == mv ? idx : 0x7fffffff);
+    v = mv;
 }
 __device__ __forceinline__ void sd_argmin(double& v, int& idx) {
-    for (int o = 32; o > 0; o >>= 1) {
-        const double ov = __shfl_xor(v, o);
-        const int oi = __shfl_xor(idx, o);
-        if (ov < v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-    }
+    const double mv = wave_min(v);
+    idx = sd_wave_min_i(v == mv ? idx : 0x7fffffff);
+    v = mv;
 }
 
 constexpr int SDUAL_WAVES = 4;
+constexpr int SDUAL_WSAVE = 128;   // rows of a start list (saved working set of a tier / guess)
 
-template <int NT, int MC>
-__global__ __launch_bounds__(64 * SDUAL_WAVES) void k_sdual(SdualParams p) {
+// acc += coef * (src of lane J of this lane's row of 16): one VOP2 DPP instruction, no LDS and no scalar register on the way
+// (v_fmac_f64 takes the row_newbcast control on gfx90a and later).  FIRST: two wait states between the VALU write of src and its
+// DPP read (the hazard recogniser does not look into inline assembly).
+template <int J, bool FIRST>
+__device__ __forceinline__ void sd_fma_bcast(double& acc, double src, double coef) {
+    if constexpr (FIRST)
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(coef), "n"(J));
+    else
+        asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(coef), "n"(J));
+}
+// acc0 / acc1 += sum_j coef[j] * bcast_{J0 + j}(src), j = 0..CNT-1 (compile-time unrolled: the DPP control is an immediate)
+template <int J0, int CNT, int IDX = 0>
+__device__ __forceinline__ void sd_dot_bcast(double& acc0, double& acc1, double src, const double* coef) {
+    if constexpr (IDX < CNT) {
+        if constexpr ((IDX & 1) == 0) sd_fma_bcast<J0 + IDX, IDX == 0>(acc0, src, coef[IDX]);
+        else sd_fma_bcast<J0 + IDX, false>(acc1, src, coef[IDX]);
+        sd_dot_bcast<J0, CNT, IDX + 1>(acc0, acc1, src, coef);
+    }
+}
+
+#ifdef ALMPC_STAMPS
+#define SD_T0() do { __builtin_amdgcn_sched_barrier(0); sd_t = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define SD_ACC(S) do { __builtin_amdgcn_sched_barrier(0); const long long t_ = __builtin_readcyclecounter(); sd_acc[S] += t_ - sd_t; sd_t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SD_T0()
+#define SD_ACC(S)
+#endif
+
+// <NT, MC>: padded stage-state / input dimensions; PPL: working-set positions per lane -- 1: up to 64 rows, Sinv in LDS; 2: up to
+// 128 rows, Sinv in a global scratch (the third tier: rare instances, mostly infeasible ones whose verdict needs that many rows).
+template <int NT, int MC, int PPL>
+__global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
     static_assert((NT % 2) == 0 && (MC % 2) == 0, "even dimensions (16-byte loads)");
+    static_assert(PPL == 1 || PPL == 2, "one or two working-set positions per lane");
     constexpr int SP = NT + MC;          // coordinates per stage: state slot [0, NT), input slot [NT, NT + MC)
     constexpr int RL = 2 * NT + 2 * MC;  // doubles per record row
+    constexpr bool BIG = PPL == 2;
+    constexpr bool ROWDPP = SP <= 16;    // a stage fits one row of 16 lanes: DPP broadcasts instead of LDS round trips
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int n = p.n, nt = p.nt, m = p.m, N = p.N, wcap = p.wcap, LD = wcap + 1;
+    const int wv = threadIdx.x >> 6, lane0 = threadIdx.x & 63;
+    const int n = p.n, m = p.m, N = p.N, wcap = p.wcap, LD = wcap + 1;
     const int TP = sdual_tp(NT, MC, N);
     double* L = smem + (size_t)wv * p.lds_per_wave;
     double* sA = L;
     double* sB = sA + TP;
-    double* Sinv = sB + TP;                    // [wcap][LD]
-    double* gbuf = Sinv + wcap * LD + (wcap * LD & 1);
+    double* SinvL = sB + TP;                   // [wcap][LD] (PPL = 1)
+    double* gbuf = SinvL + (BIG ? 0 : wcap * LD + (wcap * LD & 1));
     double* cbuf = gbuf + NT;
     double* ubuf = cbuf + wcap;
-    const bool is_state_lane = lane < NT, is_input_lane = lane >= NT && lane < SP;
-    const int rrow = lane < SP ? lane : SP - 1;   // record row of this lane (idle lanes shadow the last row; their results are dropped)
+    int* slist = reinterpret_cast<int*>(ubuf + wcap);   // [SDUAL_WSAVE] start list
+    double* blo = ubuf + wcap + 64;   // [SP] bounds of a slot in ABSOLUTE coordinates (u, x): the row values in s are absolute too
+    double* bhi = blo + SP;
+    double* beq = bhi + SP;           // [NT] terminal-equality target for x_N
+    const int wpb = (int)(blockDim.x >> 6);
+    double* SinvG = BIG ? p.sinv_glb + (size_t)(blockIdx.x * wpb + wv) * wcap * LD : nullptr;
+    // Sinv element access: LDS (in-order within the wave), or the global scratch read back past the L1 (written by other lanes)
+    auto sld = [&](int i, int j) -> double {
+        if constexpr (BIG) return __hip_atomic_load(SinvG + (size_t)i * LD + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else return SinvL[i * LD + j];
+    };
+    auto sst = [&](int i, int j, double v) {
+        if constexpr (BIG) __hip_atomic_store(SinvG + (size_t)i * LD + j, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else SinvL[i * LD + j] = v;
+    };
+    auto sfence = [&]() {
+        if constexpr (BIG) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+        sd_fence();
+    };
+    const bool is_state_lane = lane0 < NT, is_input_lane = lane0 >= NT && lane0 < SP;
+    // record row of this lane0: the DPP build repeats the stage in every row of 16 lanes; else idle lanes shadow the last row
+    const int rrow = ROWDPP ? ((lane0 & 15) < SP ? (lane0 & 15) : SP - 1) : (lane0 < SP ? lane0 : SP - 1);
     const bool kvar = p.rec_kstride != 0;
     const bool has_box = p.xmin != nullptr, has_eq = p.eqt != nullptr, with_c = p.pc != nullptr;
 
@@ -130,15 +196,22 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES) void k_sdual(SdualParams p) {
     };
     if (!kvar && p.rec_stride == 0) { load_bw(p.rec, 0); load_fw(p.rec, 0); }
 
-    const int wpb = (int)(blockDim.x >> 6);
     const int nwaves = gridDim.x * wpb;
     for (int inst = blockIdx.x * wpb + wv; inst < p.batch; inst += nwaves) {
+        // (the lane index made opaque per instance: per-lane addresses of the rarely used arrays are then computed where they are used
+        // instead of being hoisted out of this loop into registers that stay live across the whole solve)
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
         if (p.only_ovf) {
             if (p.ovf[inst] == 0) continue;
         } else if ((p.filter == 1 && p.status[inst] == 0) || (p.filter == 2 && p.status[inst] == 0 && p.flag[inst] == 0)) {
             if (p.ovf && lane == 0) p.ovf[inst] = 0;
             continue;
         }
+#ifdef ALMPC_STAMPS
+        long long sd_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sd_t = 0;
+        long long sd_nbw = 0, sd_nfw = 0;
+#endif
         const double* recg = p.rec + (size_t)inst * p.rec_stride;
         const double* urg = p.uref + (size_t)inst * p.uref_stride;
         const double* xbr = p.xbref ? p.xbref + (size_t)inst * p.xbref_stride : nullptr;
@@ -152,29 +225,149 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES) void k_sdual(SdualParams p) {
         double* w = sB;    // sources of a sweep, then its result
         double e0l = 0.0;  // e_0 (state lanes)
         if (lane < n) e0l = p.x0 ? p.x0[(size_t)inst * n + lane] - (xrg ? xrg[lane] : 0.0) : 0.0;
+        double e0l16 = 0.0;   // the same per row of 16 lanes (DPP build)
+        if (ROWDPP && (lane & 15) < n) e0l16 = p.x0 ? p.x0[(size_t)inst * n + (lane & 15)] - (xrg ? xrg[lane & 15] : 0.0) : 0.0;
 
+        // The row values in s are kept in ABSOLUTE coordinates (u = v + u_ref, x = e + x_ref): bounds are then per-slot constants (no
+        // reference offset on the scan's path); a sweep produces deviations, the offsets are added once after every full solve.
+        if (lane < SP) {
+            double lo = -1e300, hi = 1e300;
+            if (lane >= NT) { const int a_ = lane - NT; if (a_ < m) { lo = p.umin[a_]; hi = p.umax[a_]; } }
+            else if (lane < n && has_box) { lo = p.xmin[lane]; hi = p.xmax[lane]; }
+            blo[lane] = lo; bhi[lane] = hi;
+            if (lane < NT) beq[lane] = (has_eq && lane < n) ? eqg[lane] + (xbr ? xbr[(size_t)N * n + lane] : 0.0) : 0.0;
+        }
+        sd_fence();
         // bounds of coordinate t (row: the coordinate carries bounds at all)
         auto bounds_of = [&](int t, double& lo, double& hi, bool& row, bool& iseq) {
             const int k = t / SP, j = t - k * SP;
-            lo = -1e300; hi = 1e300; row = false; iseq = false;
-            if (j >= NT) {
-                const int a = j - NT;
-                if (a < m && k < N) { const double ur = urg[k * m + a]; lo = p.umin[a] - ur; hi = p.umax[a] - ur; row = true; }
-            } else if (j < n && k >= 1 && k <= N) {
-                if (has_eq && k == N) { lo = hi = eqg[j]; row = true; iseq = true; }
-                else if (has_box) { const double xr = xbr ? xbr[k * n + j] : 0.0; lo = p.xmin[j] - xr; hi = p.xmax[j] - xr; row = true; }
-            }
+            lo = blo[j]; hi = bhi[j]; iseq = false;
+            row = j >= NT ? (j - NT < m && k < N) : (j < n && k >= 1 && k <= N && has_box);
+            if (has_eq && k == N && j < n) { lo = hi = beq[j]; row = true; iseq = true; }
         };
         auto width_of = [&](double lo, double hi) { return (lo > -1e299 && hi < 1e299 && hi > lo) ? hi - lo : 1.0; };
+        uint64_t inW = 0ull;   // bit e: the lane's e-th coordinate (own_lane / own_bit) is in the working set
+        // scan layout: a lane looks at ONE slot of the stage (jslot) in the stages kg, kg + G, ...: the row class, the bounds and the
+        // width are per-lane constants
+        constexpr int G = 64 / SP;
+        const bool sc_ok = lane < G * SP;
+        const int jslot = lane % SP, kg = lane / SP;
+        int sc_type = 0;            // 0: not a row, 1: input bound, 2: state bound
+        double sc_lo = 0.0, sc_hi = 0.0, sc_iw = 1.0, sc_eq = 0.0;
+        const double* sc_ref = nullptr;   // reference offsets of the lane's slot (to_abs)
+        int sc_rs = 0;
+        if (sc_ok) {
+            if (jslot >= NT) {
+                const int a_ = jslot - NT;
+                if (a_ < m) { sc_type = 1; sc_ref = urg + a_; sc_rs = m; }
+            } else if (jslot < n) {
+                sc_type = (has_box || has_eq) ? 2 : 0;
+                sc_ref = xbr ? xbr + jslot : nullptr; sc_rs = n;
+                sc_eq = beq[jslot];
+            }
+            sc_lo = blo[jslot]; sc_hi = bhi[jslot];
+            sc_iw = 1.0 / width_of(sc_lo, sc_hi);
+        }
+        const int sc_el = (N + G) / G;   // elements per lane: stages kg + e G <= N
+        // most violated row outside the working set: value (in units of the row's width), coordinate (ties: smallest), NaN flag
+        auto scan = [&](double& vbest, int& tbest, bool& nan) {
+            vbest = -__builtin_inf(); tbest = 0x7fffffff;
+            double chk = 0.0;
+#pragma unroll 4
+            for (int e = 0; e < sc_el; ++e) {
+                const int k = kg + e * G;
+                const int t = k * SP + jslot;
+                const bool in_traj = sc_ok && (k < N || (k == N && jslot < NT));
+                const double sv = s[in_traj ? t : 0];
+                chk += in_traj ? sv - sv : 0.0;
+                bool row = in_traj && !((inW >> e) & 1ull);
+                double lo = sc_lo, hi = sc_hi, iw = sc_iw;
+                if (sc_type == 1) row = row && k < N;
+                else if (sc_type == 2) {
+                    const bool eqrow = has_eq && k == N;
+                    row = row && k >= 1 && (has_box || eqrow);
+                    if (eqrow) { lo = sc_eq; hi = sc_eq; iw = 1.0; }
+                } else row = false;
+                const double vio = fmax(sv - hi, lo - sv) * iw;
+                if (row && vio > vbest) { vbest = vio; tbest = t; }
+            }
+            nan = __any(chk != 0.0);
+            sd_argmax(vbest, tbest);
+        };
+        // deviations -> absolute coordinates: s[t] += reference of the coordinate (after a full solve)
+        auto to_abs = [&]() {
+#pragma unroll 4
+            for (int e = 0; e < sc_el; ++e) {
+                const int k = kg + e * G;
+                const bool ok = sc_ok && sc_ref && (sc_type == 1 || jslot < n) && (jslot >= NT ? k < N : k <= N);
+                const int kc = ok ? k : 0;
+                const double off = sc_ref ? sc_ref[(size_t)kc * sc_rs] : 0.0;
+                if (ok) s[k * SP + jslot] += off;
+            }
+            sd_fence();
+        };
+        auto own_lane = [&](int t) { const int k = t / SP; return (k % G) * SP + (t - k * SP); };
+        auto own_bit = [&](int t) { return (t / SP) / G; };
 
-        // ---- one affine sweep over w (sources in, trajectory out).  kb: highest stage that carries a source; kend: forward stages 0..kend-1
+        // ---- one affine sweep over w (sources in, trajectory out).  kb: highest stage that carries a source (< 0: none -- the backward
+        // pass is skipped); kend: forward stages 0..kend-1; full_problem: x_0 = e_0 and the defects count
         auto sweep = [&](int kb, int kend, bool full_problem) {
+            SD_T0();
+            const bool use_c = full_problem && with_c;
+            int kstart = use_c ? N - 1 : (kb >= N ? N - 1 : kb);
+            if constexpr (ROWDPP) {
+                // all operands of a stage live in ONE row of 16 lanes: broadcasts are DPP row_newbcast operands of the FMAs, the
+                // recursion never touches LDS (the four rows of the wave compute the same thing; row 0 writes).  Two builds of the
+                // loops: GEN = stage-varying records and / or defects (loads inside the loop), else nothing but the chain.
+                const int l16 = lane & 15;
+                const bool st_l = l16 < NT, wr_l = lane < SP;   // (wr_l: the lanes of row 0 that own a coordinate of the stage)
+                const int lsl = l16 < SP ? l16 : SP - 1;        // (padding lanes of the row shadow its last slot: loads without branches)
+                auto body = [&](auto gen_tag) {
+                    constexpr bool GEN = decltype(gen_tag)::value;
+                    double pv = 0.0;
+                    if ((kb >= N || use_c) && st_l) pv = w[N * SP + l16];
+                    if (GEN && use_c && st_l) pv += pcg[(size_t)(N - 1) * NT + l16];
+                    double own = w[(kstart >= 0 ? kstart : 0) * SP + lsl];
+                    for (int k = kstart; k >= 0; --k) {
+                        if (GEN && kvar) load_bw(recg, k);
+                        const double own_next = w[(k > 0 ? k - 1 : 0) * SP + lsl];
+                        double acc0 = st_l ? own : 0.0, acc1 = 0.0;
+                        sd_dot_bcast<0, NT>(acc0, acc1, pv, r1);
+                        sd_dot_bcast<NT, MC>(acc0, acc1, own, sb);
+                        double out = acc0 + acc1;
+                        if (GEN && use_c && k > 0 && st_l) out += pcg[(size_t)(k - 1) * NT + l16];
+                        if (!st_l && wr_l) w[k * SP + l16] = out;   // kff_k over the consumed input sources
+                        pv = st_l ? out : 0.0;
+                        own = own_next;
+                    }
+                    sd_fence();
+#ifdef ALMPC_STAMPS
+                    sd_nbw += kstart + 1; sd_nfw += kend;
+#endif
+                    SD_ACC(0);
+                    double xv = st_l ? ((full_problem && l16 < n) ? e0l16 : 0.0) : w[lsl];
+                    if (wr_l && st_l) w[l16] = xv;
+                    for (int k = 0; k < kend; ++k) {
+                        if (GEN && kvar) load_fw(recg, k);
+                        const double kf_next = w[(k + 1 < kend ? k + 1 : k) * SP + lsl];
+                        double acc0 = (GEN && use_c && st_l) ? ctg[(size_t)k * NT + l16] : 0.0, acc1 = 0.0;
+                        sd_dot_bcast<0, NT>(acc0, acc1, xv, r2);
+                        sd_dot_bcast<NT, MC>(acc0, acc1, xv, r3);
+                        const double out = acc0 + acc1;
+                        if (wr_l) w[(st_l ? (k + 1) * SP : k * SP) + l16] = out;
+                        xv = st_l ? out : kf_next;
+                    }
+                    sd_fence();
+                    SD_ACC(1);
+                };
+                if (kvar || use_c) body(std::true_type{});
+                else body(std::false_type{});
+                return;
+            }
             // backward
-            int kstart = N - 1;
             double gl = 0.0;
-            if (kb >= N || full_problem) { if (is_state_lane) gl = w[N * SP + lane]; }
-            else kstart = kb;
-            if (full_problem && with_c && is_state_lane) gl += pcg[(size_t)(N - 1) * NT + lane];
+            if (kb >= N || use_c) { if (is_state_lane) gl = w[N * SP + lane]; }
+            if (use_c && is_state_lane) gl += pcg[(size_t)(N - 1) * NT + lane];
             if (is_state_lane) gbuf[lane] = gl;
             sd_fence();
             for (int k = kstart; k >= 0; --k) {
@@ -190,12 +383,16 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES) void k_sdual(SdualParams p) {
 #pragma unroll
                 for (int j = 0; j < MC; j += 2) { acc0 = fma(sb[j], su[j], acc0); acc1 = fma(sb[j + 1], su[j + 1], acc1); }
                 double out = acc0 + acc1;
-                if (full_problem && with_c && k > 0 && is_state_lane) out += pcg[(size_t)(k - 1) * NT + lane];
+                if (use_c && k > 0 && is_state_lane) out += pcg[(size_t)(k - 1) * NT + lane];
                 sd_fence();
                 if (is_state_lane) gbuf[lane] = out;
                 else if (is_input_lane) w[k * SP + lane] = out;   // kff_k over the consumed input sources
                 sd_fence();
             }
+#ifdef ALMPC_STAMPS
+            sd_nbw += kstart + 1; sd_nfw += kend;
+#endif
+            SD_ACC(0);
             // forward
             if (is_state_lane) w[lane] = full_problem ? (lane < n ? e0l : 0.0) : 0.0;
             sd_fence();
@@ -206,7 +403,7 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES) void k_sdual(SdualParams p) {
                 for (int j = 0; j < NT; ++j) xk[j] = w[k * SP + j];
 #pragma unroll
                 for (int j = 0; j < MC; ++j) kf[j] = w[k * SP + NT + j];
-                double acc0 = (full_problem && with_c && is_state_lane) ? ctg[(size_t)k * NT + lane] : 0.0, acc1 = 0.0;
+                double acc0 = (use_c && is_state_lane) ? ctg[(size_t)k * NT + lane] : 0.0, acc1 = 0.0;
 #pragma unroll
                 for (int j = 0; j < NT; j += 2) { acc0 = fma(r2[j], xk[j], acc0); acc1 = fma(r2[j + 1], xk[j + 1], acc1); }
 #pragma unroll
@@ -217,104 +414,133 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES) void k_sdual(SdualParams p) {
                 else if (is_input_lane) w[k * SP + lane] = out;
                 sd_fence();
             }
+            SD_ACC(1);
         };
         auto zero_w = [&]() {
             for (int t = lane; t < TP; t += 64) w[t] = 0.0;
         };
 
-        // ---- working set: position i lives on lane i
+        // ---- working set: position i lives on lane i & 63, slot i >> 6
         int nW = 0, kmaxW = -1;
-        int Wrow = 0, Wside = 0;
-        double lam = 0.0, cpos = 0.0, rpos = 0.0;
-        uint64_t inW = 0ull;   // bit e: coordinate e * 64 + lane is in the working set
+        int Wrow[PPL], Wside[PPL];
+        double lam[PPL], cpos[PPL], rpos[PPL];
+#pragma unroll
+        for (int sl = 0; sl < PPL; ++sl) { Wrow[sl] = 0; Wside[sl] = 0; lam[sl] = 0.0; cpos[sl] = 0.0; rpos[sl] = 0.0; }
         auto stage_of = [&](int t) { const int k = t / SP; return k < N ? k : N; };
-        auto bound_of_pos = [&]() {   // bound the row of this lane's position sits on
+        auto pick_i = [&](const int* a, int sl) { if constexpr (PPL == 1) return a[0]; else return sl ? a[1] : a[0]; };
+        auto pick_d = [&](const double* a, int sl) { if constexpr (PPL == 1) return a[0]; else return sl ? a[1] : a[0]; };
+        // value of working-set position pos (wave-uniform): v_readlane, not the LDS crossbar
+        auto from_pos_i = [&](const int* a, int pos) { const int pu = __builtin_amdgcn_readfirstlane(pos); return __builtin_amdgcn_readlane(pick_i(a, pu >> 6), pu & 63); };
+        auto from_pos_d = [&](const double* a, int pos) { const int pu = __builtin_amdgcn_readfirstlane(pos); return readlane_d(pick_d(a, pu >> 6), pu & 63); };
+        auto bound_of_row = [&](int t, int side) {
             double lo, hi; bool row, iseq;
-            bounds_of(Wrow, lo, hi, row, iseq);
-            return Wside >= 0 ? hi : lo;
+            bounds_of(t, lo, hi, row, iseq);
+            return side >= 0 ? hi : lo;
         };
-        auto sinv_mul = [&](const double* vec) {   // (Sinv vec)_lane for lane < nW
-            double a0 = 0.0, a1 = 0.0;
-            const double* rowp = Sinv + (size_t)(lane < nW ? lane : 0) * LD;
-            int j = 0;
-            for (; j + 1 < nW; j += 2) { a0 = fma(rowp[j], vec[j], a0); a1 = fma(rowp[j + 1], vec[j + 1], a1); }
-            if (j < nW) a0 = fma(rowp[j], vec[j], a0);
-            return lane < nW ? a0 + a1 : 0.0;
+        // out[sl] = (Sinv vec)_{64 sl + lane}
+        auto sinv_mul = [&](const double* vec, double* out) {
+#pragma unroll
+            for (int sl = 0; sl < PPL; ++sl) {
+                const int i = sl * 64 + lane;
+                const int ir = i < nW ? i : 0;
+                double a0 = 0.0, a1 = 0.0;
+                int j = 0;
+                for (; j + 1 < nW; j += 2) { a0 = fma(sld(ir, j), vec[j], a0); a1 = fma(sld(ir, j + 1), vec[j + 1], a1); }
+                if (j < nW) a0 = fma(sld(ir, j), vec[j], a0);
+                out[sl] = i < nW ? a0 + a1 : 0.0;
+            }
         };
-        // append row t (side sd); c in cpos (lanes < nW), u = Sinv c in rpos, gpp = Ghat_tt.  False: dependent on the rows already there.
+        // append row t (side sd); c in cpos, u = Sinv c in rpos, gpp = Ghat_tt.  False: dependent on the rows already there.
         auto border = [&](int t, int sd, double gpp) {
-            const double sc = gpp - sd_wave_sum(lane < nW ? cpos * rpos : 0.0);
+            double dot = 0.0;
+#pragma unroll
+            for (int sl = 0; sl < PPL; ++sl) dot += (sl * 64 + lane < nW) ? cpos[sl] * rpos[sl] : 0.0;
+            const double sc = gpp - sd_wave_sum(dot);
             if (!(sc > 1e-12 * gpp)) return false;
             const double isc = 1.0 / sc;
-            if (lane < nW) ubuf[lane] = rpos;
+#pragma unroll
+            for (int sl = 0; sl < PPL; ++sl)
+                if (sl * 64 + lane < nW) ubuf[sl * 64 + lane] = rpos[sl];
             sd_fence();
-            if (lane < nW) {
-                double* rowp = Sinv + (size_t)lane * LD;
-                const double f = rpos * isc;
-                for (int j = 0; j < nW; ++j) rowp[j] = fma(f, ubuf[j], rowp[j]);
-                rowp[nW] = -f;
-            } else if (lane == nW) {
-                double* rowp = Sinv + (size_t)nW * LD;
-                for (int j = 0; j < nW; ++j) rowp[j] = -ubuf[j] * isc;
-                rowp[nW] = isc;
+#pragma unroll
+            for (int sl = 0; sl < PPL; ++sl) {
+                const int i = sl * 64 + lane;
+                if (i < nW) {
+                    const double f = rpos[sl] * isc;
+                    for (int j = 0; j < nW; ++j) sst(i, j, fma(f, ubuf[j], sld(i, j)));
+                    sst(i, nW, -f);
+                } else if (i == nW) {
+                    for (int j = 0; j < nW; ++j) sst(nW, j, -ubuf[j] * isc);
+                    sst(nW, nW, isc);
+                    Wrow[sl] = t; Wside[sl] = sd; lam[sl] = 0.0;
+                }
             }
-            if (lane == nW) { Wrow = t; Wside = sd; lam = 0.0; }
-            if (lane == (t & 63)) inW |= 1ull << (t >> 6);
+            if (lane == own_lane(t)) inW |= 1ull << own_bit(t);
             const int ks = stage_of(t);
             kmaxW = ks > kmaxW ? ks : kmaxW;
             ++nW;
-            sd_fence();
+            sfence();
             return true;
         };
         auto remove_pos = [&](int pos) {
             const int q = nW - 1;
-            const int trow = __shfl(Wrow, pos);
-            const double piv = Sinv[(size_t)pos * LD + pos];
-            const double ipiv = 1.0 / piv;
-            if (lane < nW && lane != pos) {
-                double* rowp = Sinv + (size_t)lane * LD;
-                const double f = rowp[pos] * ipiv;
-                const double* prow = Sinv + (size_t)pos * LD;
-                for (int j = 0; j < nW; ++j)
-                    if (j != pos) rowp[j] = fma(-f, prow[j], rowp[j]);
-            }
-            sd_fence();
-            if (pos != q) {   // the last position moves into the hole
-                if (lane < q && lane != pos) Sinv[(size_t)lane * LD + pos] = Sinv[(size_t)lane * LD + q];
-                sd_fence();
-                if (lane == q) {
-                    const double* qrow = Sinv + (size_t)q * LD;
-                    double* prow = Sinv + (size_t)pos * LD;
-                    for (int j = 0; j < q; ++j)
-                        if (j != pos) prow[j] = qrow[j];
-                    prow[pos] = qrow[q];
+            const int trow = from_pos_i(Wrow, pos);
+            const double ipiv = 1.0 / sld(pos, pos);
+#pragma unroll
+            for (int sl = 0; sl < PPL; ++sl) {
+                const int i = sl * 64 + lane;
+                if (i < nW && i != pos) {
+                    const double f = sld(i, pos) * ipiv;
+                    for (int j = 0; j < nW; ++j)
+                        if (j != pos) sst(i, j, fma(-f, sld(pos, j), sld(i, j)));
                 }
-                const int wr = __shfl(Wrow, q), ws = __shfl(Wside, q);
-                const double wl = __shfl(lam, q), wc = __shfl(cpos, q);
-                if (lane == pos) { Wrow = wr; Wside = ws; lam = wl; cpos = wc; }
             }
-            if (lane == (trow & 63)) inW &= ~(1ull << (trow >> 6));
+            sfence();
+            if (pos != q) {   // the last position moves into the hole
+#pragma unroll
+                for (int sl = 0; sl < PPL; ++sl) {
+                    const int i = sl * 64 + lane;
+                    if (i < q && i != pos) sst(i, pos, sld(i, q));
+                }
+                sfence();
+                if (lane == (q & 63)) {
+                    for (int j = 0; j < q; ++j)
+                        if (j != pos) sst(pos, j, sld(q, j));
+                    sst(pos, pos, sld(q, q));
+                }
+                const int wr = from_pos_i(Wrow, q), ws = from_pos_i(Wside, q);
+                const double wl = from_pos_d(lam, q), wc = from_pos_d(cpos, q);
+#pragma unroll
+                for (int sl = 0; sl < PPL; ++sl)
+                    if (sl * 64 + lane == pos) { Wrow[sl] = wr; Wside[sl] = ws; lam[sl] = wl; cpos[sl] = wc; }
+            }
+            if (lane == own_lane(trow)) inW &= ~(1ull << own_bit(trow));
             --nW;
-            kmaxW = sd_wave_max_i(lane < nW ? stage_of(Wrow) : -1);
-            sd_fence();
+            int km = -1;
+#pragma unroll
+            for (int sl = 0; sl < PPL; ++sl)
+                if (sl * 64 + lane < nW) { const int ks = stage_of(Wrow[sl]); km = ks > km ? ks : km; }
+            kmaxW = sd_wave_max_i(km);
+            sfence();
         };
-        // the trajectory for the current multipliers, from scratch: w = base + lam / 2 on the working-set rows, full sweep, s <-> w
-        auto full_solve = [&]() {
-            if (bsg) { for (int t = lane; t < TP; t += 64) w[t] = bsg[t]; }
-            else zero_w();
-            sd_fence();
-            if (lane < nW) w[Wrow] += 0.5 * lam;
-            sd_fence();
-            sweep(N, N, true);
-            double* t_ = s; s = w; w = t_;
+        // position of the working-set row with coordinate t (it is there)
+        auto pos_of_row = [&](int t) {
+            int found = -1;
+#pragma unroll
+            for (int sl = 0; sl < PPL; ++sl)
+                if (sl * 64 + lane < nW && Wrow[sl] == t) found = sl * 64 + lane;
+            return sd_wave_max_i(found);
         };
-        // response of the unconstrained problem to a unit multiplier on coordinate t: w = Ghat[:, t] for stages < kend
-        auto response = [&](int t, int kend) {
-            zero_w();
+        auto gather_c = [&]() {   // c = Ghat[W, t] from the response in w
+#pragma unroll
+            for (int sl = 0; sl < PPL; ++sl)
+                if (sl * 64 + lane < nW) { cpos[sl] = w[Wrow[sl]]; }
+        };
+        auto publish = [&](const double* v) {   // per-position values -> cbuf
+#pragma unroll
+            for (int sl = 0; sl < PPL; ++sl)
+                if (sl * 64 + lane < nW) cbuf[sl * 64 + lane] = v[sl];
             sd_fence();
-            if (lane == 0) w[t] = -0.5;
-            sd_fence();
-            sweep(stage_of(t), kend, false);
         };
 
         int it = 0, status = 1;
@@ -326,216 +552,290 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES) void k_sdual(SdualParams p) {
             x0_out = e0l < p.xmin[lane] - xr || e0l > p.xmax[lane] - xr;
         }
         x0_out = __any(x0_out);
-        full_solve();   // s = the unconstrained solution
-        if (x0_out) status = 3;
-        else {
-            // ---- start: terminal-equality rows, then the guess's inputs on a bound
-            auto try_add_start = [&](int t, int sd, int kend) {
-                if (nW >= wcap) { overflow = true; return; }
-                response(t, kend);
-                if (lane < nW) cpos = w[Wrow];
-                const double gpp = w[t];
-                sd_fence();
-                if (lane < nW) cbuf[lane] = cpos;
-                sd_fence();
-                rpos = sinv_mul(cbuf);
-                (void)border(t, sd, gpp);
-            };
-            if (has_eq)
-                for (int i = 0; i < n; ++i) try_add_start(N * SP + i, 0, N);
-            if (p.uguess) {
-                // highest stage of the guess's working set first (the forward passes of its responses stop there)
-                int kg = -1;
-                for (int t = lane; t < N * m; t += 64) {
-                    const int k = t / m, a = t - k * m;
-                    const double ur = urg[t], lo = p.umin[a] - ur, hi = p.umax[a] - ur;
-                    double v = p.uguess[(size_t)inst * N * m + t] - ur;
-                    v = v != v ? 0.0 : v;
-                    if (hi > lo && (v >= hi || v <= lo)) kg = k > kg ? k : kg;
-                }
-                kg = sd_wave_max_i(kg);
-                if (has_eq) kg = N;
-                const int kend = kg + 1 < N ? kg + 1 : N;
-                for (int t0 = 0; t0 < N * m && !overflow; t0 += 64) {   // trajectory order, 64 inputs per ballot
-                    const int t = t0 + lane;
-                    int sdl = 0;
-                    if (t < N * m) {
-                        const int k = t / m, a = t - k * m;
-                        const double ur = urg[t], lo = p.umin[a] - ur, hi = p.umax[a] - ur;
-                        double v = p.uguess[(size_t)inst * N * m + t] - ur;
-                        v = v != v ? 0.0 : v;
-                        if (hi > lo) sdl = v >= hi ? 1 : (v <= lo ? -1 : 0);
-                    }
-                    unsigned long long any = __ballot(sdl != 0);
-                    const unsigned long long ups = __ballot(sdl > 0);
-                    while (any && !overflow) {
-                        const int b = __ffsll(any) - 1;
-                        any &= any - 1;
-                        const int tt = t0 + b, k = tt / m, a = tt - k * m;
-                        try_add_start(k * SP + NT + a, ((ups >> b) & 1ull) ? 1 : -1, kend);
-                    }
-                }
-            }
-            if (nW > 0 && !overflow) {
-                // multipliers of the start from s0; rows whose multiplier has the wrong sign leave, worst first
-                while (nW > 0) {
-                    const double b = lane < nW ? bound_of_pos() : 0.0;
-                    if (lane < nW) cbuf[lane] = s[Wrow] - b;
-                    sd_fence();
-                    const double lw = sinv_mul(cbuf);
-                    double viol = -__builtin_inf();
-                    if (lane < nW && Wside != 0) viol = Wside > 0 ? -lw : lw;
-                    const double lmax = fabs(lane < nW ? lw : 0.0);
-                    double lm = lmax;
-                    for (int o = 32; o > 0; o >>= 1) lm = fmax(lm, __shfl_xor(lm, o));
-                    int vi = lane < nW ? Wrow : 0x7fffffff;
-                    double vv = viol;
-                    sd_argmax(vv, vi);
-                    if (!(vv > 1e-12 * fmax(1.0, lm))) { lam = lane < nW ? lw : 0.0; break; }
-                    const int pos = __ffsll((unsigned long long)__ballot(lane < nW && Wrow == vi)) - 1;
-                    sd_fence();
-                    remove_pos(pos);
-                    ++it;
-                }
-                full_solve();
-            }
-            // ---- main loop
-            int refined = 0;
-            while (it < p.max_iter && !overflow) {
+
+        // One loop, ONE sweep per pass (a single copy of the sweep and of the scan in the code): the mode says what the sweep is for.
+        //   M_FULL   the trajectory of the current multipliers from scratch (the unconstrained solution at the start, the confirmation
+        //            of a solution, the restart after the start rows / a refinement of the multipliers)
+        //   M_START  response of the next row of the start list (terminal-equality rows, the guess's inputs on a bound, or the working
+        //            set a smaller tier ran out of room with): bordered in without a step
+        //   M_RESP   response of the most violated row p: c = Ghat[W, p], Ghat_pp
+        //   M_DIR    direction Ghat (e_p - sum_w r_w e_w) in row space: ratio test, step, drop of a blocking row or addition of p
+        //   M_TOP    (no sweep) pick the most violated row or go and confirm
+        enum { M_FULL, M_START, M_RESP, M_DIR, M_TOP };
+        enum { A_INIT, A_TOP, A_CONFIRM };
+        int mode = M_FULL, after = A_INIT;
+        int ns = 0, si = 0, st_kend = N, refined = 0;
+        int pr = 0, sd = 0;
+        double bp = 0.0, lam_p = 0.0, gpp = 0.0;
+        for (;;) {
+            if (mode == M_TOP) {
+                if (it >= p.max_iter || overflow) break;
                 ++it;
-                // most violated row outside the working set (violation in units of the row's width; ties -> smallest coordinate)
-                double vbest = -__builtin_inf();
-                int tbest = 0x7fffffff;
-                double chk = 0.0;
-                for (int e = 0, t = lane; t < TP; ++e, t += 64) {
-                    const double sv = s[t];
-                    chk += sv - sv;
-                    if ((inW >> e) & 1ull) continue;
-                    double lo, hi; bool row, iseq;
-                    bounds_of(t, lo, hi, row, iseq);
-                    if (!row) continue;
-                    const double vio = fmax(sv - hi, lo - sv) / width_of(lo, hi);
-                    if (vio > vbest) { vbest = vio; tbest = t; }
+                SD_T0();
+                double vbest; int tbest; bool nanf;
+                scan(vbest, tbest, nanf);
+                if (nanf) { bad = true; break; }
+                SD_ACC(2);
+                if (!(vbest > p.tol)) { mode = M_FULL; after = A_CONFIRM; }
+                else {
+                    pr = tbest;
+                    double plo, phi; bool prow_, peq;
+                    bounds_of(pr, plo, phi, prow_, peq);
+                    sd = s[pr] > phi ? 1 : -1;
+                    bp = sd > 0 ? phi : plo;
+                    if (nW >= wcap) { overflow = true; break; }
+                    lam_p = 0.0;
+                    mode = M_RESP;
                 }
-                if (__any(chk != 0.0)) { bad = true; break; }
-                sd_argmax(vbest, tbest);
-                if (!(vbest > p.tol)) {
+            }
+            // ---- sources of this pass's sweep
+            int kb, kend;
+            bool full = false;
+            if (mode == M_FULL) {
+                if (bsg) { for (int t = lane; t < TP; t += 64) w[t] = bsg[t]; }
+                else zero_w();
+                sd_fence();
+#pragma unroll
+                for (int sl = 0; sl < PPL; ++sl)
+                    if (sl * 64 + lane < nW) w[Wrow[sl]] += 0.5 * lam[sl];
+                sd_fence();
+                kb = bsg ? N : kmaxW;   // no reference-dependent cost terms: sources only on the working-set rows
+                kend = N; full = true;
+            } else {
+                SD_T0();
+                if (mode == M_DIR) {
+                    publish(cpos);
+                    sinv_mul(cbuf, rpos);
+                }
+                zero_w();
+                sd_fence();
+                const int tsrc = mode == M_START ? (slist[si] >> 2) : pr;
+                if (lane == 0) w[tsrc] = -0.5;
+                if (mode == M_DIR) {
+#pragma unroll
+                    for (int sl = 0; sl < PPL; ++sl)
+                        if (sl * 64 + lane < nW) w[Wrow[sl]] = 0.5 * rpos[sl];
+                }
+                sd_fence();
+                const int ksrc = stage_of(tsrc);
+                const int km = ksrc > kmaxW ? ksrc : kmaxW;
+                kb = mode == M_DIR ? km : ksrc;
+                kend = mode == M_DIR ? N : (mode == M_START ? st_kend : (km + 1 < N ? km + 1 : N));
+                SD_ACC(3);
+            }
+            sweep(kb, kend, full);
+            // ---- what the sweep was for
+            if (mode == M_FULL) {
+                double* t_ = s; s = w; w = t_;
+                to_abs();
+                if (after == A_INIT) {
+                    if (x0_out) { status = 3; break; }
+                    // the start list: saved working set of the previous tier, or terminal-equality rows + the guess's inputs on a bound
+                    ns = 0;
+                    int kg = -1;
+                    if (p.only_ovf && p.wsave) {
+                        const int cnt = p.ovf[inst] - 1;
+                        for (int i = lane; i < cnt; i += 64) slist[i] = p.wsave[(size_t)inst * SDUAL_WSAVE + i];
+                        ns = cnt;
+                        kg = N;
+                    } else {
+                        if (has_eq) {
+                            if (lane < n) slist[lane] = ((N * SP + lane) << 2) | 2;
+                            ns = n;
+                            kg = N;
+                        }
+                        if (p.uguess) {
+                            for (int t0 = 0; t0 < N * m; t0 += 64) {   // trajectory order, 64 inputs per ballot
+                                const int t = t0 + lane;
+                                int sdl = 0, tt = 0;
+                                if (t < N * m) {
+                                    const int k = t / m, a_ = t - k * m;
+                                    const double ur = urg[t], lo = p.umin[a_] - ur, hi = p.umax[a_] - ur;
+                                    double v = p.uguess[(size_t)inst * N * m + t] - ur;
+                                    v = v != v ? 0.0 : v;
+                                    if (hi > lo) sdl = v >= hi ? 1 : (v <= lo ? -1 : 0);
+                                    tt = k * SP + NT + a_;
+                                    if (sdl != 0 && k > kg) kg = k;
+                                }
+                                const unsigned long long any = __ballot(sdl != 0);
+                                const int before = __popcll(any & ((1ull << lane) - 1ull));
+                                if (sdl != 0 && ns + before < SDUAL_WSAVE) slist[ns + before] = (tt << 2) | (sdl > 0 ? 1 : 0);
+                                ns += __popcll(any);
+                            }
+                            kg = sd_wave_max_i(kg);
+                        }
+                    }
+                    if (ns > SDUAL_WSAVE) ns = SDUAL_WSAVE;
+                    st_kend = kg + 1 < N ? kg + 1 : N;
+                    sd_fence();
+                    si = 0;
+                    mode = ns > 0 ? M_START : M_TOP;
+                    if (ns > 0 && nW >= wcap) { overflow = true; break; }
+                } else if (after == A_TOP) mode = M_TOP;
+                else {
                     // confirmation from scratch: working-set rows on their bounds, nothing else violated
-                    full_solve();
-                    double res = 0.0, resn = 0.0;
-                    if (lane < nW) {
-                        double lo, hi; bool row, iseq;
-                        bounds_of(Wrow, lo, hi, row, iseq);
-                        res = s[Wrow] - (Wside >= 0 ? hi : lo);
-                        resn = fabs(res) / width_of(lo, hi);
+                    double res[PPL], resn = 0.0;
+#pragma unroll
+                    for (int sl = 0; sl < PPL; ++sl) {
+                        res[sl] = 0.0;
+                        if (sl * 64 + lane < nW) {
+                            double lo, hi; bool row, iseq;
+                            bounds_of(Wrow[sl], lo, hi, row, iseq);
+                            res[sl] = s[Wrow[sl]] - (Wside[sl] >= 0 ? hi : lo);
+                            resn = fmax(resn, fabs(res[sl]) / width_of(lo, hi));
+                        }
                     }
-                    double vmax = -__builtin_inf(), chk2 = 0.0;
-                    for (int e = 0, t = lane; t < TP; ++e, t += 64) {
-                        const double sv = s[t];
-                        chk2 += sv - sv;
-                        if ((inW >> e) & 1ull) continue;
-                        double lo, hi; bool row, iseq;
-                        bounds_of(t, lo, hi, row, iseq);
-                        if (!row) continue;
-                        vmax = fmax(vmax, fmax(sv - hi, lo - sv) / width_of(lo, hi));
-                    }
-                    if (__any(chk2 != 0.0)) { bad = true; break; }
-                    for (int o = 32; o > 0; o >>= 1) { vmax = fmax(vmax, __shfl_xor(vmax, o)); resn = fmax(resn, __shfl_xor(resn, o)); }
+                    double vmax; int tmax_; bool nan2;
+                    scan(vmax, tmax_, nan2);
+                    if (nan2) { bad = true; break; }
+                    resn = wave_max(resn);
                     if (resn <= 1e-8 && vmax <= 1e-8) { status = 0; break; }
                     if (refined >= 3) break;
                     ++refined;
                     if (nW > 0) {
-                        if (lane < nW) cbuf[lane] = res;
-                        sd_fence();
-                        const double dl = sinv_mul(cbuf);
-                        if (lane < nW) lam += dl;
-                        full_solve();
-                    }
-                    continue;
+                        double dl[PPL];
+                        publish(res);
+                        sinv_mul(cbuf, dl);
+#pragma unroll
+                        for (int sl = 0; sl < PPL; ++sl)
+                            if (sl * 64 + lane < nW) lam[sl] += dl[sl];
+                        mode = M_FULL; after = A_TOP;
+                    } else mode = M_TOP;
                 }
-                const int pr = tbest;
-                double plo, phi; bool prow_, peq;
-                bounds_of(pr, plo, phi, prow_, peq);
-                const int sd = s[pr] > phi ? 1 : -1;
-                const double bp = sd > 0 ? phi : plo;
-                if (nW >= wcap) { overflow = true; break; }
-                double lam_p = 0.0;
-                {
-                    const int km = stage_of(pr) > kmaxW ? stage_of(pr) : kmaxW;
-                    response(pr, km + 1 < N ? km + 1 : N);
-                }
-                if (lane < nW) cpos = w[Wrow];
-                const double gpp = w[pr];
+            } else if (mode == M_START) {
+                const int code = slist[si];
+                const int t = code >> 2, sdr = (code & 2) ? 0 : ((code & 1) ? 1 : -1);
+                gather_c();
+                const double g_tt = w[t];
                 sd_fence();
-                bool infeasible = false;
-                while (true) {
-                    if (lane < nW) cbuf[lane] = cpos;
-                    sd_fence();
-                    rpos = sinv_mul(cbuf);
-                    // direction in row space: Ghat (e_p - sum_w r_w e_w)
-                    zero_w();
-                    sd_fence();
-                    if (lane == 0) w[pr] = -0.5;
-                    if (lane < nW) w[Wrow] = 0.5 * rpos;
-                    sd_fence();
-                    {
-                        const int kb = stage_of(pr) > kmaxW ? stage_of(pr) : kmaxW;
-                        sweep(kb, N, false);
-                    }
-                    const double dp = w[pr];
-                    const bool dependent = !(dp > 1e-12 * gpp);
-                    const double tau2 = dependent ? __builtin_inf() : fabs(s[pr] - bp) / dp;
-                    double t1 = __builtin_inf();
-                    int bi = 0x7fffffff;
-                    if (lane < nW && Wside != 0) {
-                        const double ri = rpos * sd;
-                        if (Wside > 0 && ri > 0.0) { t1 = fmax(lam, 0.0) / ri; bi = Wrow; }
-                        else if (Wside < 0 && ri < 0.0) { t1 = fmin(lam, 0.0) / ri; bi = Wrow; }
-                    }
-                    sd_argmin(t1, bi);
-                    const bool have_blk = bi != 0x7fffffff && t1 < __builtin_inf();
-                    if (dependent && !have_blk) { infeasible = true; break; }
-                    const double tau = fmin(t1, tau2);
-                    if (!dependent) {
-                        const double f = -(double)sd * tau;
-                        for (int t = lane; t < TP; t += 64) s[t] = fma(f, w[t], s[t]);
-                    }
-                    if (lane < nW) lam -= (double)sd * tau * rpos;
-                    lam_p += (double)sd * tau;
-                    sd_fence();
-                    if (have_blk && t1 < tau2) {
-                        const int pos = __ffsll((unsigned long long)__ballot(lane < nW && Wrow == bi)) - 1;
+                publish(cpos);
+                sinv_mul(cbuf, rpos);
+                (void)border(t, sdr, g_tt);
+                ++si;
+                if (si < ns && nW >= wcap) { overflow = true; break; }
+                if (si >= ns) {
+                    // multipliers of the start from s0; rows whose multiplier has the wrong sign leave, worst first
+                    while (nW > 0) {
+                        double dv[PPL], lw[PPL];
+#pragma unroll
+                        for (int sl = 0; sl < PPL; ++sl) dv[sl] = (sl * 64 + lane < nW) ? s[Wrow[sl]] - bound_of_row(Wrow[sl], Wside[sl]) : 0.0;
+                        publish(dv);
+                        sinv_mul(cbuf, lw);
+                        double vv = -__builtin_inf(), lm = 0.0;
+                        int vi = 0x7fffffff;
+#pragma unroll
+                        for (int sl = 0; sl < PPL; ++sl)
+                            if (sl * 64 + lane < nW) {
+                                lm = fmax(lm, fabs(lw[sl]));
+                                if (Wside[sl] != 0) {
+                                    const double viol = Wside[sl] > 0 ? -lw[sl] : lw[sl];
+                                    if (viol > vv || (viol == vv && Wrow[sl] < vi)) { vv = viol; vi = Wrow[sl]; }
+                                }
+                            }
+                        lm = wave_max(lm);
+                        sd_argmax(vv, vi);
+                        if (!(vv > 1e-12 * fmax(1.0, lm))) {
+#pragma unroll
+                            for (int sl = 0; sl < PPL; ++sl) lam[sl] = (sl * 64 + lane < nW) ? lw[sl] : 0.0;
+                            break;
+                        }
+                        const int pos = pos_of_row(vi);
+                        sd_fence();
                         remove_pos(pos);
                         ++it;
-                        if (it >= p.max_iter) break;
-                        continue;
                     }
-                    if (border(pr, sd, gpp)) { if (lane == nW - 1) lam = lam_p; }
+                    if (nW > 0) { mode = M_FULL; after = A_TOP; }
+                    else mode = M_TOP;
+                }
+            } else if (mode == M_RESP) {
+                gather_c();
+                gpp = w[pr];
+                sd_fence();
+                mode = M_DIR;
+            } else {   // M_DIR
+                const double dp = w[pr];
+                const bool dependent = !(dp > 1e-12 * gpp);
+                const double tau2 = dependent ? __builtin_inf() : fabs(s[pr] - bp) / dp;
+                double t1 = __builtin_inf();
+                int bi = 0x7fffffff;
+#pragma unroll
+                for (int sl = 0; sl < PPL; ++sl)
+                    if (sl * 64 + lane < nW && Wside[sl] != 0) {
+                        const double ri = rpos[sl] * sd;
+                        double cand = __builtin_inf();
+                        if (Wside[sl] > 0 && ri > 0.0) cand = fmax(lam[sl], 0.0) / ri;
+                        else if (Wside[sl] < 0 && ri < 0.0) cand = fmin(lam[sl], 0.0) / ri;
+                        if (cand < t1 || (cand == t1 && cand < __builtin_inf() && Wrow[sl] < bi)) { t1 = cand; bi = Wrow[sl]; }
+                    }
+                sd_argmin(t1, bi);
+                const bool have_blk = bi != 0x7fffffff && t1 < __builtin_inf();
+                if (dependent && !have_blk) { status = 3; break; }
+                const double tau = fmin(t1, tau2);
+                if (!dependent) {
+                    const double f = -(double)sd * tau;
+                    for (int t = lane; t < TP; t += 64) s[t] = fma(f, w[t], s[t]);
+                }
+#pragma unroll
+                for (int sl = 0; sl < PPL; ++sl)
+                    if (sl * 64 + lane < nW) lam[sl] -= (double)sd * tau * rpos[sl];
+                lam_p += (double)sd * tau;
+                sd_fence();
+                SD_ACC(4);
+                if (have_blk && t1 < tau2) {
+                    remove_pos(pos_of_row(bi));
+                    ++it;
+                    SD_ACC(5);
+                    if (it >= p.max_iter) break;
+                    // (mode stays M_DIR: new direction for the same row with the smaller working set)
+                } else {
+                    if (border(pr, sd, gpp)) {
+#pragma unroll
+                        for (int sl = 0; sl < PPL; ++sl)
+                            if (sl * 64 + lane == nW - 1) lam[sl] = lam_p;
+                    }
                     if (lane == 0) s[pr] = bp;
                     sd_fence();
-                    break;
+                    SD_ACC(5);
+                    mode = M_TOP;
                 }
-                if (infeasible) { status = 3; break; }
+            }
+        }
+        // a working set that ran out of room: kept for the next tier (rows and sides; the multipliers are recomputed there)
+        if (overflow && !bad && p.wsave) {
+#pragma unroll
+            for (int sl = 0; sl < PPL; ++sl) {
+                const int i = sl * 64 + lane;
+                if (i < nW && i < SDUAL_WSAVE) p.wsave[(size_t)inst * SDUAL_WSAVE + i] = (Wrow[sl] << 2) | (Wside[sl] == 0 ? 2 : (Wside[sl] > 0 ? 1 : 0));
             }
         }
         if (status == 3 && !p.rows_state) status = 1;   // an input box alone is never infeasible: a numerical verdict, not a certificate
+#ifdef ALMPC_STAMPS
+        if (g_stamps && lane == 0) {
+            for (int c_ = 0; c_ < 6; ++c_) g_stamps[(size_t)inst * 16 + c_] = sd_acc[c_];
+            g_stamps[(size_t)inst * 16 + 8] = it; g_stamps[(size_t)inst * 16 + 9] = sd_nbw; g_stamps[(size_t)inst * 16 + 10] = sd_nfw;
+            g_stamps[(size_t)inst * 16 + 11] = nW;
+        }
+#endif
         // ---- outputs
         const int st_out = bad ? 2 : status;
-        if (p.ovf && lane == 0) p.ovf[inst] = (overflow && !bad) ? 1 : 0;
+        if (p.ovf && lane == 0) p.ovf[inst] = (overflow && !bad) ? 1 + (nW < SDUAL_WSAVE ? nW : SDUAL_WSAVE) : 0;
         for (int t = lane; t < N * m; t += 64) {
             const int k = t / m, a = t - k * m;
             const double ur = urg[t];
-            const double v = s[k * SP + NT + a];
-            double uu = (bad || st_out == 3) ? v + ur : fmin(fmax(v + ur, p.umin[a]), p.umax[a]);
+            const double ua = s[k * SP + NT + a];   // absolute
+            const double uu = (bad || st_out == 3) ? ua : fmin(fmax(ua, p.umin[a]), p.umax[a]);
             if (!p.v_only) p.u[(size_t)inst * N * m + t] = uu;
             p.eu[(size_t)inst * N * m + t] = uu - ur;
         }
         if (!p.v_only) {
             for (int t = lane; t < (N + 1) * n; t += 64) {
                 const int k = t / n, i = t - k * n;
-                const double e = k == 0 ? (p.x0 ? p.x0[(size_t)inst * n + i] - (xrg ? xrg[i] : 0.0) : 0.0) : s[k * SP + i];
-                p.ex[(size_t)inst * (N + 1) * n + t] = e;
-                p.x[(size_t)inst * (N + 1) * n + t] = (k == 0 && p.x0) ? p.x0[(size_t)inst * n + i] : e + (xrg ? xrg[t] : 0.0);
+                const double xr = xrg ? xrg[t] : 0.0, xb = xbr ? xbr[t] : 0.0;
+                // (the row values carry the offset of the BOUNDS' reference xbref; the outputs are relative to xref: the same array for an
+                // MPC problem)
+                const double xa = k == 0 ? (p.x0 ? p.x0[(size_t)inst * n + i] : xr) : s[k * SP + i] - xb + xr;
+                p.x[(size_t)inst * (N + 1) * n + t] = xa;
+                p.ex[(size_t)inst * (N + 1) * n + t] = xa - xr;
             }
         }
         if (lane == 0) {
