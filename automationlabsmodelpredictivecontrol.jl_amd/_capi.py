@@ -249,9 +249,10 @@ def fnn_linearize(W_in, W_h, b_h, W_out, x, u, act="relu", device=0, want_f=Fals
 class Solver:
     """Thin object wrapper of an almpc_handle: one device, one batch shard."""
 
-    def __init__(self, n, m, N, batch, device=0, timing=False, structured=False, structured_fallback=False):
-        """structured: ALMPC_FLAG_STRUCTURED (the Riccati active-set solve of the multiple-shooting form is the handle's solver: any
-        m*N <= 1024).  structured_fallback: a condensed handle whose unsolved instances are redone by that solve."""
+    def __init__(self, n, m, N, batch, device=0, timing=False, structured=False, structured_fallback=None):
+        """structured: ALMPC_FLAG_STRUCTURED (the stage-wise solve of the multiple-shooting form is the handle's solver: no m*N <= 128
+        limit).  structured_fallback: the redo of the instances a condensed step leaves without a certificate by the stage-wise
+        solvers -- None: the library default (on wherever they cover the design), True: required, False: off."""
         self.L = load()
         self.n, self.m, self.N, self.batch = int(n), int(m), int(N), int(batch)
         self.nz = self.m * self.N
@@ -261,8 +262,8 @@ class Solver:
         if rc != ALMPC_OK:
             raise AlmpcError(rc, "almpc_create failed (is a gfx950 GPU visible? there is no CPU fallback)")
         self.h = h
-        if structured_fallback:
-            self._check(self.L.almpc_set_structured_fallback(self.h, 1))
+        if structured_fallback is not None:
+            self._check(self.L.almpc_set_structured_fallback(self.h, 1 if structured_fallback else 0))
 
     def _check(self, rc):
         if rc != ALMPC_OK:

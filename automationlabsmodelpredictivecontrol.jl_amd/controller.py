@@ -236,10 +236,9 @@ def _design_blackbox(system: ConstrainedBlackBoxControlDiscreteSystem, horizon: 
         sopt = dict(kws.get("mpc_solver_options", {}))
         f = system.f
         # instances whose linearisation is open-loop unstable (condensed Hessian singular to working precision) are redone in the
-        # multiple-shooting form by the structured solve (almpc_set_structured_fallback) when the shape allows it
-        if (mod.solver.n <= 32 and mod.solver.m <= 16 and float(np.asarray(weights.S)[0, 0]) == 0.0 and kws.get("mpc_structured_fallback", True)
-                and not (state_box or term_eq)):   # (the structured solve has no state rows)
-            mod.solver._check(mod.solver.L.almpc_set_structured_fallback(mod.solver.h, 1))
+        # multiple-shooting form by the stage-wise solvers: the library's default; mpc_structured_fallback = False switches it off
+        if not kws.get("mpc_structured_fallback", True):
+            mod.solver._check(mod.solver.L.almpc_set_structured_fallback(mod.solver.h, 0))
         # device-resident pipeline (almpc_relin_fnn_*): Jacobians -> per-instance designs -> step, no host pointers per step
         mod.solver.relin_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, references.x, references.u, weights.Q, weights.R, weights.S, np.array(P),
                                    system.U.low, system.U.high, act=f.act, rho=float(sopt.get("rho", 0.1)),

@@ -120,7 +120,7 @@ struct almpc_handle {
     // structured (Riccati) solve: the handle's only solver (ALMPC_FLAG_STRUCTURED) or the fallback for instances the condensed path
     // leaves unsolved (almpc_set_structured_fallback)
     bool structured = false;
-    int fallback = 0;
+    int fallback = 2;   // 0 off, 1 asked for (a design it cannot serve is an error), 2 default: on wherever the stage-wise solvers cover the design
     double *rQ = nullptr, *rR = nullptr, *rP = nullptr, *rKst = nullptr, *rPst = nullptr;   // device copies of Q, R (branch rule applied), shared P; gain scratch
     double* rGuess = nullptr;   // [batch][N][m] start of the next structured solve (almpc_set_start_from / opts.warm_start), else nullptr
     bool guess_ready = false;   // rGuess was filled for the NEXT almpc_calculate (consumed by it)
@@ -137,6 +137,12 @@ struct almpc_handle {
         double* base = nullptr; size_t base_cap = 0; long base_stride = 0; bool has_base = false;
         double *xmin = nullptr, *xmax = nullptr, *eqt = nullptr;   // state box [n] (null: none), terminal-equality target [n] zeros (null: none)
         bool has_box = false, has_eq = false, useS = false;
+        bool per_instance = false;          // records per instance (k_sgains) instead of the host's shared ones
+        int gain_N = 0;                     // stages k_sgains computes (1: stage-invariant records)
+        double *dQ = nullptr, *dR = nullptr, *dS = nullptr, *dP = nullptr;   // weights of k_sgains (R with the branch rule applied; dP: a shared terminal weight)
+        int* bad = nullptr;                 // [batch] k_sgains: R + B'PB not positive definite
+        bool sqp = false;                   // the QP of an SQP iteration: stage models, defects and cost terms of the loop (h->sqp)
+        double *pc = nullptr, *ct = nullptr;   // [batch][N][NT] P_{k+1} c_k, c_k
         int32_t* ovf = nullptr;
         int32_t* wsave = nullptr;   // [batch][SDUAL_WSAVE] working set of an instance that ran out of room (start of the next tier)
         double* sinv_glb = nullptr; size_t sinv_cap = 0;   // third tier: Sinv of 128 x 129 per wave of its grid
@@ -263,7 +269,7 @@ void free_all(almpc_handle* h) {
         if (e) (void)hipEventDestroy(e);
     if (h->comm && rccl_api().ok) (void)rccl_api().CommDestroy(h->comm);
     for (void* p : {(void*)h->dComm4, (void*)h->dU0, (void*)h->dU0all, (void*)h->rQ, (void*)h->rR, (void*)h->rP, (void*)h->rKst, (void*)h->rPst, (void*)h->rGuess,
-                    (void*)h->sd.rec, (void*)h->sd.base, (void*)h->sd.xmin, (void*)h->sd.xmax, (void*)h->sd.eqt, (void*)h->sd.ovf, (void*)h->sd.wsave, (void*)h->sd.sinv_glb})
+                    (void*)h->sd.rec, (void*)h->sd.base, (void*)h->sd.xmin, (void*)h->sd.xmax, (void*)h->sd.eqt, (void*)h->sd.ovf, (void*)h->sd.wsave, (void*)h->sd.sinv_glb, (void*)h->sd.dQ, (void*)h->sd.dR, (void*)h->sd.dS, (void*)h->sd.dP, (void*)h->sd.bad, (void*)h->sd.pc, (void*)h->sd.ct})
         if (p) (void)hipFree(p);
     if (h->ev_guess) (void)hipEventDestroy(h->ev_guess);
     for (auto& e : h->ev)
@@ -480,15 +486,12 @@ int sdual_setup_shared(almpc_handle* h, const hm::mat& Am, const hm::mat& Bm, co
         HIP_TRY(h, hipMemcpy(sd.xmax, xmax, n * sizeof(double), hipMemcpyHostToDevice));
     }
     sd.has_eq = terminal_eq;
-    if (sd.has_eq) {
-        if (!sd.eqt) HIP_TRY(h, dalloc(&sd.eqt, (size_t)n));
-        HIP_TRY(h, hipMemset(sd.eqt, 0, n * sizeof(double)));
-    }
     if (!sd.ovf) HIP_TRY(h, dalloc(&sd.ovf, (size_t)h->batch));
     if (!sd.wsave) HIP_TRY(h, dalloc(&sd.wsave, (size_t)h->batch * SDUAL_WSAVE));
     HIP_TRY(h, hipMemset(sd.ovf, 0, (size_t)h->batch * sizeof(int32_t)));
     sd.S = Sm ? *Sm : hm::mat();
     sd.has_base = false; sd.base_stride = 0;
+    sd.per_instance = false; sd.gain_N = 0; sd.sqp = false;
     sd.ready = true;
     return ALMPC_OK;
 }
@@ -525,14 +528,112 @@ int sdual_update_base(almpc_handle* h, const double* uref, size_t cnt) {
     return ALMPC_OK;
 }
 
+// Weights and buffers of the stage-wise solve with a model PER INSTANCE (almpc_design_batched, the re-linearisation pipeline): the stage
+// records come from k_sgains (launch_sgains) -- `invariant`: the terminal weight is every instance's own DARE solution and there is
+// no input-rate weight, so one stage per instance suffices.  Rm: as given (the branch rule is applied here); Sm null: no rate term.
+int sdual_setup_batched(almpc_handle* h, const hm::mat& Qm, const hm::mat& Rm, const hm::mat* Sm, bool invariant,
+                        const double* xmin, const double* xmax, bool terminal_eq) {
+    const int n = h->n, m = h->m, N = h->N;
+    almpc_handle::Sd& sd = h->sd;
+    sd.ready = false;
+    sd.useS = Sm != nullptr;
+    sd.nt = sd.useS ? n + m : n;
+    if (!sdual_pick_shape(sd.nt, m, &sd.NT, &sd.MC) || !sdual_shape_ok(n, m, N, sd.useS))
+        return fail(h, ALMPC_ERR_UNSUPPORTED, "stage-wise solve: n (+ m with an input-rate weight) <= 48, m <= 16 and (N + 1)(n + m) <= 4096");
+    if ((size_t)sgains_lds_doubles(sd.nt, m) * sizeof(double) > 160 * 1024) return fail(h, ALMPC_ERR_UNSUPPORTED, "stage-wise solve: the gain recursion does not fit LDS");
+    hm::mat Qs = Qm, Rs = Rm;
+    if (Rm[0] == 0.0) std::fill(Rs.begin(), Rs.end(), 0.0);
+    if (!sd.dQ) HIP_TRY(h, dalloc(&sd.dQ, (size_t)n * n));
+    if (!sd.dR) HIP_TRY(h, dalloc(&sd.dR, (size_t)m * m));
+    HIP_TRY(h, hipMemcpy(sd.dQ, Qs.data(), Qs.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(sd.dR, Rs.data(), Rs.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (Sm) {
+        if (!sd.dS) HIP_TRY(h, dalloc(&sd.dS, (size_t)m * m));
+        HIP_TRY(h, hipMemcpy(sd.dS, Sm->data(), Sm->size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    const size_t stage = (size_t)sdual_rec_stage(sd.NT, sd.MC);
+    sd.gain_N = invariant ? 1 : N;
+    const size_t cnt = (size_t)h->batch * sd.gain_N * stage;
+    if (sd.rec_cap < cnt) {
+        if (sd.rec) { (void)hipFree(sd.rec); sd.rec = nullptr; }
+        HIP_TRY(h, dalloc(&sd.rec, cnt));
+        sd.rec_cap = cnt;
+    }
+    sd.rec_stride = (long)(sd.gain_N * stage);
+    sd.rec_kstride = invariant ? 0 : (long)stage;
+    sd.per_instance = true; sd.sqp = false;
+    sd.has_box = xmin != nullptr;
+    if (sd.has_box) {
+        if (!sd.xmin) HIP_TRY(h, dalloc(&sd.xmin, (size_t)n));
+        if (!sd.xmax) HIP_TRY(h, dalloc(&sd.xmax, (size_t)n));
+        HIP_TRY(h, hipMemcpy(sd.xmin, xmin, n * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(sd.xmax, xmax, n * sizeof(double), hipMemcpyHostToDevice));
+    }
+    sd.has_eq = terminal_eq;
+    if (!sd.ovf) HIP_TRY(h, dalloc(&sd.ovf, (size_t)h->batch));
+    HIP_TRY(h, hipMemset(sd.ovf, 0, (size_t)h->batch * sizeof(int32_t)));
+    if (!sd.wsave) HIP_TRY(h, dalloc(&sd.wsave, (size_t)h->batch * SDUAL_WSAVE));
+    if (!sd.bad) HIP_TRY(h, dalloc(&sd.bad, (size_t)h->batch));
+    HIP_TRY(h, hipMemset(sd.bad, 0, (size_t)h->batch * sizeof(int)));
+    sd.S = Sm ? *Sm : hm::mat();
+    sd.has_base = false; sd.base_stride = 0;
+    sd.ready = true;
+    return ALMPC_OK;
+}
+
+// k_sgains over the handle's per-instance models (bA, bB; terminal weights bP, shared or per instance): all instances
+// (filter 0) or the ones the condensed step left unsolved (filter 1)
+hipError_t launch_sgains(almpc_handle* h, int filter) {
+    const almpc_handle::Sd& sd = h->sd;
+    SgainsParams gp;
+    std::memset(&gp, 0, sizeof(gp));
+    const long n = h->n, m = h->m;
+    gp.n = h->n; gp.nt = sd.nt; gp.m = h->m; gp.N = sd.gain_N; gp.batch = h->batch; gp.NT = sd.NT; gp.MC = sd.MC;
+    gp.A = h->bA; gp.A_stride = n * n; gp.A_kstride = 0;
+    gp.B = h->bB; gp.B_stride = n * m; gp.B_kstride = 0;
+    gp.P = h->bP; gp.P_stride = h->rP_stride;   // (one matrix with stride 0, or one per instance)
+    gp.Q = sd.dQ; gp.R = sd.dR; gp.S = sd.useS ? sd.dS : nullptr;
+    gp.c = nullptr; gp.c_stride = 0;
+    gp.filter = filter; gp.status = h->dStatus; gp.flag = nullptr;
+    gp.rec = sd.rec; gp.rec_stride = sd.rec_stride;
+    gp.pc = nullptr; gp.ct = nullptr; gp.pc_stride = 0;
+    gp.bad = sd.bad;
+    if (sd.sqp) {   // the QP of the current SQP iteration: stage models, defects, state errors and input gradient of the loop
+        const almpc_handle::Sqp& q = h->sqp;
+        const long N = h->N;
+        gp.A = q.A; gp.A_stride = N * n * n; gp.A_kstride = n * n;
+        gp.B = q.B; gp.B_stride = N * n * m; gp.B_kstride = n * m;
+        gp.P = h->bP; gp.P_stride = q.sP;
+        gp.c = q.c; gp.c_stride = N * n;
+        gp.pc = sd.pc; gp.ct = sd.ct; gp.pc_stride = N * sd.NT;
+        gp.ebar = q.ebar; gp.ebar_stride = N * n; gp.qadd = q.qadd; gp.qadd_stride = N * m; gp.qscale = 0.5;
+        gp.base = sd.base; gp.base_stride = sd.base_stride;
+        gp.flag = h->bFlag;
+    }
+    if (!gp.A || !gp.B || !gp.P || !gp.rec) return hipErrorInvalidValue;
+    gp.lds_per_wave = sgains_lds_doubles(sd.nt, h->m);
+    const size_t per = (size_t)gp.lds_per_wave * sizeof(double);
+    int waves = SGAINS_WAVES;
+    while (waves > 1 && per * waves > 160 * 1024) --waves;
+    const size_t lds = per * waves;
+    int wgs = (h->batch + waves - 1) / waves;
+    const int cap = h->num_cus * 2;
+    if (wgs > cap) wgs = cap;
+    const hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(k_sgains), lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_sgains, dim3(wgs), dim3(64 * waves), lds, h->stream, gp);
+    return hipGetLastError();
+}
+
 template <int NT, int MC>
-hipError_t launch_sdual_t(almpc_handle* h, SdualParams sp) {
+hipError_t launch_sdual_t(almpc_handle* h, SdualParams sp, int tier0, int tier1) {
     // first launch: every (filtered) instance with room for SD_WCAP1 rows; second: the instances that outgrew it, with SD_WCAP2;
     // third: SD_WCAP3 rows, two working-set positions per lane, Sinv in a global scratch (rare: mostly infeasible instances whose
     // verdict needs that many rows)
-    for (int tier = 0; tier < 3; ++tier) {
+    // (tier0 = tier1 = 1: ONE launch with room for SD_WCAP2 rows -- the redo of the few instances a condensed step left unsolved)
+    for (int tier = tier0; tier <= tier1; ++tier) {
         sp.wcap = tier == 0 ? SD_WCAP1 : (tier == 1 ? SD_WCAP2 : SD_WCAP3);
-        sp.only_ovf = tier > 0;
+        sp.only_ovf = tier > tier0;
         sp.lds_per_wave = sdual_lds_doubles(NT, MC, sp.N, sp.wcap, tier < 2);
         const size_t per = (size_t)sp.lds_per_wave * sizeof(double);
         int waves = SDUAL_WAVES;
@@ -574,7 +675,7 @@ hipError_t launch_sdual_t(almpc_handle* h, SdualParams sp) {
 
 // k_sdual over the batch (filter 0), over the instances whose status is not 0 (filter 1: redo after the condensed path), start from
 // `guess` (inputs [batch][N][m]) when given
-hipError_t launch_sdual(almpc_handle* h, int filter, const double* guess, int max_iter) {
+hipError_t launch_sdual(almpc_handle* h, int filter, const double* guess, int max_iter, bool single_launch = false) {
     const almpc_handle::Sd& sd = h->sd;
     if (!sd.ready) return hipErrorInvalidValue;
     SdualParams sp;
@@ -586,16 +687,26 @@ hipError_t launch_sdual(almpc_handle* h, int filter, const double* guess, int ma
     sp.umin = h->dUmin; sp.umax = h->dUmax; sp.uref = h->dUref; sp.uref_stride = h->uref_stride;
     sp.xmin = sd.has_box ? sd.xmin : nullptr; sp.xmax = sd.has_box ? sd.xmax : nullptr;
     sp.xbref = h->dXref; sp.xbref_stride = h->xref_stride;
-    sp.eqt = sd.has_eq ? sd.eqt : nullptr; sp.eqt_stride = 0;
+    sp.eqt = sd.has_eq ? h->dXref + (size_t)h->N * h->n : nullptr; sp.eqt_stride = h->xref_stride;   // x_N = x_ref_N
     sp.x0 = h->dX0; sp.xref = h->dXref; sp.xref_stride = h->xref_stride;
     sp.uguess = guess; sp.filter = filter; sp.flag = nullptr; sp.v_only = 0;
     sp.x = h->dX; sp.ex = h->dEx; sp.u = h->dU; sp.eu = h->dEu; sp.status = h->dStatus; sp.piters = h->dPiters;
+    if (sd.sqp) {   // dx_0 = 0, variable v = u - ubar (the handle's per-instance references ARE the iterate xbar, ubar), cost terms per instance
+        const almpc_handle::Sqp& q = h->sqp;
+        sp.base = sd.base; sp.base_stride = sd.base_stride;
+        sp.pc = sd.pc; sp.ct = sd.ct; sp.pc_stride = (long)h->N * sd.NT;
+        sp.eqt = sd.has_eq ? q.xref + (size_t)h->N * h->n : nullptr; sp.eqt_stride = 0;
+        sp.x0 = nullptr; sp.xref = nullptr; sp.xref_stride = 0;
+        sp.flag = h->bFlag; sp.v_only = 1;
+    }
     sp.ovf = sd.ovf; sp.only_ovf = 0; sp.wsave = sd.wsave;
+    sp.gbad = sd.per_instance ? sd.bad : nullptr;
     sp.rows_state = (sd.has_box || sd.has_eq) ? 1 : 0;
     const int rows = h->N * h->m + ((sd.has_box || sd.has_eq) ? h->N * h->n : 0);
     sp.max_iter = max_iter > 0 ? max_iter : 20 * rows + 50;
     sp.tol = 1e-9;
-#define SD_CASE(NT_, MC_) if (sd.NT == NT_ && sd.MC == MC_) return launch_sdual_t<NT_, MC_>(h, sp)
+    const int tier0 = single_launch ? 1 : 0, tier1 = single_launch ? 1 : 2;
+#define SD_CASE(NT_, MC_) if (sd.NT == NT_ && sd.MC == MC_) return launch_sdual_t<NT_, MC_>(h, sp, tier0, tier1)
     SD_CASE(2, 2); SD_CASE(4, 2); SD_CASE(6, 2); SD_CASE(8, 4); SD_CASE(12, 4); SD_CASE(16, 4); SD_CASE(16, 8); SD_CASE(32, 16); SD_CASE(48, 16);
 #undef SD_CASE
     return hipErrorInvalidValue;
@@ -745,7 +856,8 @@ int almpc_set_state_box(almpc_handle* h, const double* xmin, const double* xmax)
 
 int almpc_set_structured_fallback(almpc_handle* h, int on) {
     if (!h) return ALMPC_ERR_INVALID;
-    if (on && !riccati_shape_ok(h)) return fail(h, ALMPC_ERR_UNSUPPORTED, "structured fallback: needs n <= 32, m <= 16 and its buffers in 160 KB of LDS");
+    if (on && !riccati_shape_ok(h) && !sdual_shape_ok(h->n, h->m, h->N, false))
+        return fail(h, ALMPC_ERR_UNSUPPORTED, "structured fallback: the shape is outside both stage-wise solvers");
     h->fallback = on ? 1 : 0;
     h->designed = false;  // takes effect at the next design (which prepares the weights on the device)
     return ALMPC_OK;
@@ -917,11 +1029,23 @@ int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const
             h->roll_s = sblk; h->roll_nb = (N + sblk - 1) / sblk;
         }
     }
+    // redo of the instances a step leaves without a certificate (default on): the stage-wise dual active set (k_sdual: also state rows
+    // and S), and behind it -- input box only, S = 0 -- the primal Riccati active set
+    h->sd.ready = false;
     if (h->fallback) {
-        if (h->mc > 0 || h->useS) return fail(h, ALMPC_ERR_UNSUPPORTED, "structured fallback: input box only, no input-rate weight");
-        const int rc_ = riccati_weights(h, Qm, Rm, Pm.data());
-        if (rc_ != ALMPC_OK) return rc_;
-        h->r_batched_P = false; h->rP_stride = 0;
+        const bool useS = h->useS != 0;
+        if (sdual_shape_ok(n, m, N, useS)) {
+            hm::mat Rb = Rm;
+            if (Rm[0] == 0.0) std::fill(Rb.begin(), Rb.end(), 0.0);
+            const int rc_ = sdual_setup_shared(h, Am, Bm, Qm, Rb, useS ? &Sm : nullptr, Pm, xmin, xmax, h->terminal_eq != 0);
+            if (rc_ != ALMPC_OK && h->fallback == 1) return rc_;
+        } else if (h->fallback == 1 && (h->mc > 0 || useS))
+            return fail(h, ALMPC_ERR_UNSUPPORTED, "structured fallback: state rows / input-rate weight need n + m <= 48 and (N + 1)(n + m) <= 4096");
+        if (riccati_shape_ok(h) && h->mc == 0 && !useS) {
+            const int rc_ = riccati_weights(h, Qm, Rm, Pm.data());
+            if (rc_ != ALMPC_OK) return rc_;
+            h->r_batched_P = false; h->rP_stride = 0;
+        }
     }
     h->designed = true;
     h->batched = false;
@@ -1131,14 +1255,19 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
                           double rho, double sigma, const LtvInputs* ltv) {
     if (!h) return ALMPC_ERR_INVALID;
     if (h->structured) {   // one model per instance, structured solve: models and terminal weights on the device, nothing condensed
-        if (ltv) return fail(h, ALMPC_ERR_UNSUPPORTED, "structured solve: time-varying designs are not built");
+        if (ltv) return fail(h, ALMPC_ERR_UNSUPPORTED, "structured solve: time-varying designs go through almpc_sqp_fnn_* (stage models on the device)");
         if (!A_batch || !B_batch || !Q || !R || !umin || !umax) return fail(h, ALMPC_ERR_INVALID, "design_batched: null matrix pointer");
-        if (R[0] != 0.0 && S && S[0] != 0.0) return fail(h, ALMPC_ERR_UNSUPPORTED, "structured solve: no input-rate weight S");
         const int n = h->n, m = h->m, N = h->N;
         const size_t b = (size_t)h->batch;
+        const bool useS = R[0] != 0.0 && S && S[0] != 0.0;
         h->designed = false;
         HIP_TRY(h, hipSetDevice(h->device));
-        hm::mat Qm(Q, Q + (size_t)n * n), Rm(R, R + (size_t)m * m);
+        hm::mat Qm(Q, Q + (size_t)n * n), Rm(R, R + (size_t)m * m), Sm;
+        if (useS) {
+            Sm.assign(S, S + (size_t)m * m);
+            for (int j = 0; j < m; ++j)
+                for (int i = 0; i < j; ++i) { const double v = 0.5 * (Sm[(size_t)j * m + i] + Sm[(size_t)i * m + j]); Sm[(size_t)j * m + i] = Sm[(size_t)i * m + j] = v; }
+        }
         const bool p_inst = P ? (P_per_instance != 0) : true;
         hm::mat Pall;
         if (P) Pall.assign(P, P + (p_inst ? b : 1) * (size_t)n * n);
@@ -1156,12 +1285,29 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
         HIP_TRY(h, hipMemcpy(h->bA, A_batch, b * n * n * sizeof(double), hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(h->bB, B_batch, b * n * m * sizeof(double), hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(h->bP, Pall.data(), Pall.size() * sizeof(double), hipMemcpyHostToDevice));
-        { const int rc_ = riccati_weights(h, Qm, Rm, nullptr); if (rc_ != ALMPC_OK) return rc_; }
+        h->batched = true; h->ltv = false; h->r_batched_P = true; h->rP_stride = p_inst ? (long)n * n : 0;
+        const double* bxmin = h->boxmin.empty() ? nullptr : h->boxmin.data();
+        const double* bxmax = h->boxmax.empty() ? nullptr : h->boxmax.data();
+        h->sd.ready = false;
+        if (sdual_shape_ok(n, m, N, useS) && !getenv("ALMPC_STRUCTURED_PRIMAL")) {
+            const int rc_ = sdual_setup_batched(h, Qm, Rm, useS ? &Sm : nullptr, P == nullptr && !useS, bxmin, bxmax, h->terminal_eq != 0);
+            if (rc_ != ALMPC_OK) return rc_;
+            HIP_TRY(h, launch_sgains(h, 0));
+            std::vector<int> bad(b, 0);
+            HIP_TRY(h, hipMemcpyAsync(bad.data(), h->sd.bad, b * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            for (size_t i = 0; i < b; ++i)
+                if (bad[i]) return fail(h, ALMPC_ERR_NUMERIC, "design_batched: R + B'PB is not positive definite for instance " + std::to_string(i));
+        } else if (bxmin || h->terminal_eq || useS)
+            return fail(h, ALMPC_ERR_UNSUPPORTED, "structured solve: state rows / input-rate weight need the stage-wise dual solve (n + m <= 48, (N + 1)(n + m) <= 4096)");
+        if (riccati_shape_ok(h)) { const int rc_ = riccati_weights(h, Qm, Rm, nullptr); if (rc_ != ALMPC_OK) return rc_; }
+        else if (!h->sd.ready) return fail(h, ALMPC_ERR_UNSUPPORTED, "structured solve: shape outside both stage-wise solvers");
         HIP_TRY(h, hipMemcpy(h->dUmin, umin, m * sizeof(double), hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(h->dUmax, umax, m * sizeof(double), hipMemcpyHostToDevice));
         h->P.assign(Pall.begin(), Pall.begin() + (size_t)n * n); h->H.clear(); h->F.clear(); h->d.clear();
-        h->hS.assign((size_t)m * m, 0.0); h->useS = 0;
-        h->batched = true; h->ltv = false; h->r_batched_P = true; h->rP_stride = p_inst ? (long)n * n : 0;
+        h->hS.assign((size_t)m * m, 0.0); h->useS = useS ? 1 : 0;
+        if (useS) h->hS = Sm;
+        h->has_box = bxmin ? 1 : 0;
         h->designed = true;
         std::vector<double> xr((size_t)n * (N + 1), 0.0), ur((size_t)h->nz, 0.0);
         const int rc_ref = almpc_set_reference(h, xr.data(), ur.data(), 0);
@@ -1308,11 +1454,21 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
                         (flags[i] == 1 ? ": condensed Hessian has a non-positive diagonal" : ": Cholesky pivot not positive"));
     HIP_TRY(h, hipMemcpy(h->dUmin, umin, m * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->dUmax, umax, m * sizeof(double), hipMemcpyHostToDevice));
+    h->sd.ready = false;
     if (h->fallback && !ltv) {
-        if (useS) return fail(h, ALMPC_ERR_UNSUPPORTED, "structured fallback: no input-rate weight");
-        const int rc_ = riccati_weights(h, Qm, Rm, nullptr);
-        if (rc_ != ALMPC_OK) return rc_;
         h->r_batched_P = true; h->rP_stride = p_inst ? (long)n * n : 0;
+        if (sdual_shape_ok(n, m, N, useS != 0)) {
+            // stage records of every instance now (the models stay): one stage when the terminal weight is the instance's own DARE solution
+            const int rc_ = sdual_setup_batched(h, Qm, Rm, useS ? &Sm : nullptr, P == nullptr && !useS,
+                                                h->boxmin.empty() ? nullptr : h->boxmin.data(), h->boxmax.empty() ? nullptr : h->boxmax.data(), h->terminal_eq != 0);
+            if (rc_ != ALMPC_OK && h->fallback == 1) return rc_;
+            if (rc_ == ALMPC_OK) { HIP_TRY(h, launch_sgains(h, 0)); HIP_TRY(h, hipStreamSynchronize(h->stream)); }
+        } else if (h->fallback == 1 && (h->mc > 0 || useS))
+            return fail(h, ALMPC_ERR_UNSUPPORTED, "structured fallback: state rows / input-rate weight need n + m <= 48 and (N + 1)(n + m) <= 4096");
+        if (riccati_shape_ok(h) && h->mc == 0 && !useS) {
+            const int rc_ = riccati_weights(h, Qm, Rm, nullptr);
+            if (rc_ != ALMPC_OK) return rc_;
+        }
     }
     h->designed = true;
     h->batched = true;
@@ -1489,11 +1645,20 @@ int almpc_relin_fnn_setup(almpc_handle* h, int H, int L, int activation, const d
       if (rc_ != ALMPC_OK) return rc_; }
     h->batched = true; h->ltv = false;
     h->state_valid = true;
+    h->sd.ready = false;
     if (h->fallback) {
-        if (q.useS) return fail(h, ALMPC_ERR_UNSUPPORTED, "structured fallback: no input-rate weight");
-        const int rc_ = riccati_weights(h, Qm, Rm, nullptr);
-        if (rc_ != ALMPC_OK) return rc_;
         h->r_batched_P = true; h->rP_stride = 0;
+        if (sdual_shape_ok(n, m, N, q.useS != 0)) {
+            // (the models change with every step: the records of the instances a step leaves unsolved are computed in that step)
+            const int rc_ = sdual_setup_batched(h, Qm, Rm, q.useS ? &Sm : nullptr, false,
+                                                h->boxmin.empty() ? nullptr : h->boxmin.data(), h->boxmax.empty() ? nullptr : h->boxmax.data(), h->terminal_eq != 0);
+            if (rc_ != ALMPC_OK && h->fallback == 1) return rc_;
+        } else if (h->fallback == 1 && (h->mc > 0 || q.useS))
+            return fail(h, ALMPC_ERR_UNSUPPORTED, "structured fallback: state rows / input-rate weight need n + m <= 48 and (N + 1)(n + m) <= 4096");
+        if (riccati_shape_ok(h) && h->mc == 0 && !q.useS) {
+            const int rc_ = riccati_weights(h, Qm, Rm, nullptr);
+            if (rc_ != ALMPC_OK) return rc_;
+        }
     }
     q.ready = true;
     return ALMPC_OK;
@@ -1609,7 +1774,8 @@ int almpc_sqp_fnn_setup(almpc_handle* h, int H, int L, int activation, const dou
     if (n > 64 || sqp_step_lds_doubles(n, m, N) * sizeof(double) > 160 * 1024)
         return fail(h, ALMPC_ERR_UNSUPPORTED, "sqp_fnn_setup: n <= 64 (one lane per state in the update kernel) and its stage buffers must fit LDS");
     if (h->structured) {   // a structured handle has no condensed path: every QP of the loop goes to k_riccati (any m N <= 1024)
-        if (!riccati_shape_ok(h)) return fail(h, ALMPC_ERR_UNSUPPORTED, "sqp_fnn_setup: the stage-wise QP solve needs n <= 32, m <= 16 and its buffers in LDS");
+        if (!riccati_shape_ok(h) && !sdual_shape_ok(h->n, h->m, h->N, false))
+            return fail(h, ALMPC_ERR_UNSUPPORTED, "sqp_fnn_setup: the shape is outside both stage-wise QP solvers");
         h->sqp.structured_qp = 1;
     }
     const bool sq_struct = h->sqp.structured_qp != 0;
@@ -1703,17 +1869,49 @@ int almpc_sqp_fnn_setup(almpc_handle* h, int H, int L, int activation, const dou
     h->rho = rho; h->sigma = sigma;
     // state rows (almpc_set_state_box: the box of .../fnn/mpc_modeler_implementation_fnn.jl:146-153; terminal equality): one
     // constraint-space matrix per instance, rebuilt with every iteration's linearisation
-    { const int rc_ = setup_state_rows(h, h->boxmin.empty() ? nullptr : h->boxmin.data(), h->boxmax.empty() ? nullptr : h->boxmax.data(), true);
-      if (rc_ != ALMPC_OK) return rc_; }
+    const double* bxmin = h->boxmin.empty() ? nullptr : h->boxmin.data();
+    const double* bxmax = h->boxmax.empty() ? nullptr : h->boxmax.data();
+    if (q.structured_qp) {   // no constraint-space matrix: the state rows are coordinates of the stage-wise trajectory (k_sdual)
+        const int rc_ = setup_state_rows(h, nullptr, nullptr, true);
+        if (rc_ != ALMPC_OK) return rc_;
+        h->has_box = bxmin ? 1 : 0;
+        h->mc = bxmin ? N * n : (h->terminal_eq ? n : 0);
+    } else {
+        const int rc_ = setup_state_rows(h, bxmin, bxmax, true);
+        if (rc_ != ALMPC_OK) return rc_;
+    }
     h->xref_stride = (long)n * (N + 1); h->uref_stride = nz; h->fS_stride = nz;
     h->designed = false;  // becomes true with the first iteration's design
     h->batched = true; h->ltv = true;
-    if (q.structured_qp && h->mc > 0) return fail(h, ALMPC_ERR_UNSUPPORTED, "sqp_fnn_setup: the structured QP solve has no state rows");
+    h->r_batched_P = true; h->rP_stride = q.sP;
+    h->sd.ready = false;
     if (h->fallback || q.structured_qp) {
-        if (q.useS) return fail(h, ALMPC_ERR_UNSUPPORTED, "structured fallback: no input-rate weight");
-        const int rc_ = riccati_weights(h, Qm, Rm, nullptr);
-        if (rc_ != ALMPC_OK) return rc_;
-        h->r_batched_P = true; h->rP_stride = q.sP;
+        // stage-wise QP of an iteration: k_sgains (stage records, defects' value-function terms, cost terms) + k_sdual; behind it, for
+        // an input box without S, the primal Riccati active set
+        if (sdual_shape_ok(n, m, N, q.useS != 0)) {
+            const int rc_ = sdual_setup_batched(h, Qm, Rm, q.useS ? &Sm : nullptr, false, bxmin, bxmax, h->terminal_eq != 0);
+            if (rc_ != ALMPC_OK && (h->fallback == 1 || q.structured_qp)) return rc_;
+            if (rc_ == ALMPC_OK) {
+                almpc_handle::Sd& sd = h->sd;
+                const size_t TP = (size_t)sdual_tp(sd.NT, sd.MC, N);
+                if (sd.base_cap < b * TP) {
+                    if (sd.base) { (void)hipFree(sd.base); sd.base = nullptr; }
+                    HIP_TRY(h, dalloc(&sd.base, b * TP));
+                    sd.base_cap = b * TP;
+                }
+                sd.has_base = true; sd.base_stride = (long)TP;
+                if (sd.pc) { (void)hipFree(sd.pc); sd.pc = nullptr; }
+                if (sd.ct) { (void)hipFree(sd.ct); sd.ct = nullptr; }
+                HIP_TRY(h, dalloc(&sd.pc, b * N * sd.NT)); HIP_TRY(h, dalloc(&sd.ct, b * N * sd.NT));
+                sd.sqp = true;
+            }
+        } else if ((q.structured_qp || h->fallback == 1) && (h->mc > 0 || q.useS))
+            return fail(h, ALMPC_ERR_UNSUPPORTED, "sqp_fnn_setup: state rows / input-rate weight in the stage-wise QP need n + m <= 48 and (N + 1)(n + m) <= 4096");
+        if (riccati_shape_ok(h) && h->mc == 0 && !q.useS) {
+            const int rc_ = riccati_weights(h, Qm, Rm, nullptr);
+            if (rc_ != ALMPC_OK) return rc_;
+        } else if (!h->sd.ready && q.structured_qp)
+            return fail(h, ALMPC_ERR_UNSUPPORTED, "sqp_fnn_setup: the shape is outside both stage-wise QP solvers");
     }
     q.ready = true; q.started = false;
     return ALMPC_OK;
@@ -1804,7 +2002,13 @@ int almpc_sqp_fnn_iterate(almpc_handle* h, int iters, double step_scale, const a
         HIP_TRY(h, hipMemsetAsync(h->bFlag, 0, b * sizeof(int), st));
         if (q.structured_qp) {   // the QP in its stage-wise form for every instance; start: v = 0 (working set = the iterate's inputs on a bound)
             h->designed = true;
-            HIP_TRY(h, launch_riccati(h, 3, h->dUref, opts ? opts->polish_max_iter : 0));
+            if (h->sd.ready) {
+                HIP_TRY(h, launch_sgains(h, 0));
+                HIP_TRY(h, launch_sdual(h, 0, h->dUref, opts ? opts->polish_max_iter : 0));
+                // (what the dual method leaves without a certificate -- saturated unstable linearisations -- goes to the primal one)
+                if (h->mc == 0 && !q.useS && h->rKst) HIP_TRY(h, launch_riccati(h, 2, h->dUref, 0));
+            } else
+                HIP_TRY(h, launch_riccati(h, 3, h->dUref, opts ? opts->polish_max_iter : 0));
             q.since_start += 1;
             sp.stats = q.stats + 2 * it;
             hipLaunchKernelGGL(k_sqp_step, dim3((unsigned)b), dim3(256), step_lds, st, sp);
@@ -1824,7 +2028,10 @@ int almpc_sqp_fnn_iterate(almpc_handle* h, int iters, double step_scale, const a
         if (rc != ALMPC_OK) return rc;
         // structured fallback: an instance whose condensed Hessian came out indefinite to working precision (open-loop unstable
         // linearisation over the horizon) or whose QP was left unsolved gets this iteration's QP solved in its stage-wise form
-        if (h->fallback && h->mc == 0) HIP_TRY(h, launch_riccati(h, 2, nullptr, 0));   // (k_riccati has no state rows)
+        if (h->fallback) {
+            if (h->sd.ready) { HIP_TRY(h, launch_sgains(h, 2)); HIP_TRY(h, launch_sdual(h, 2, nullptr, 0, true)); }
+            if (h->mc == 0 && !q.useS && h->rKst) HIP_TRY(h, launch_riccati(h, 2, nullptr, 0));
+        }
         q.since_start += 1;
         sp.stats = q.stats + 2 * it;
         hipLaunchKernelGGL(k_sqp_step, dim3((unsigned)b), dim3(256), step_lds, st, sp);
@@ -1851,7 +2058,8 @@ int almpc_sqp_fnn_iterate(almpc_handle* h, int iters, double step_scale, const a
 
 int almpc_sqp_fnn_set_structured(almpc_handle* h, int on) {
     if (!h) return ALMPC_ERR_INVALID;
-    if (on && !riccati_shape_ok(h)) return fail(h, ALMPC_ERR_UNSUPPORTED, "sqp_fnn_set_structured: needs n <= 32, m <= 16 and its buffers in 160 KB of LDS");
+    if (on && !riccati_shape_ok(h) && !sdual_shape_ok(h->n, h->m, h->N, false))
+        return fail(h, ALMPC_ERR_UNSUPPORTED, "sqp_fnn_set_structured: the shape is outside both stage-wise QP solvers");
     h->sqp.structured_qp = on ? 1 : 0;
     h->designed = false;   // takes effect at the next almpc_sqp_fnn_setup
     h->sqp.ready = h->sqp.started = false;
@@ -1982,6 +2190,7 @@ int almpc_set_reference(almpc_handle* h, const double* xref, const double* uref,
     h->xref_stride = per_instance ? (long)xs : 0;
     h->uref_stride = per_instance ? (long)us : 0;
     h->fS_stride = (per_instance || h->batched) ? (long)us : 0;
+    { const int rc_ = sdual_update_base(h, uref, cnt); if (rc_ != ALMPC_OK) return rc_; }
     h->designed = true;
     return ALMPC_OK;
 }
@@ -2046,7 +2255,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         if (h->sd.ready) {
             HIP_TRY(h, launch_sdual(h, 0, guess, o.polish_max_iter));
             // safety net (input box only, S = 0): what the dual method left without a certificate goes to the primal Riccati active set
-            if (!h->sd.has_box && !h->sd.has_eq && !h->sd.useS && h->rKst && !h->batched) HIP_TRY(h, launch_riccati(h, 1, h->dU, 0));
+            if (!h->sd.has_box && !h->sd.has_eq && !h->sd.useS && h->rKst) HIP_TRY(h, launch_riccati(h, 1, h->dU, 0));
         } else
             HIP_TRY(h, launch_riccati(h, 0, guess, o.polish_max_iter));
         h->r_has_step = true;
@@ -2324,7 +2533,13 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
     }
     // structured fallback: instances the condensed path left without a certificate (status != 0: an active-set finish that ran into
     // its cap, a non-finite or indefinite condensed problem) are redone in the multiple-shooting form, from the step's own result
-    if (h->fallback && !h->ltv && h->mc == 0 && o.polish) HIP_TRY(h, launch_riccati(h, 1, h->dU, 0));
+    if (h->fallback && !h->ltv && o.polish) {
+        if (h->sd.ready && !getenv("ALMPC_DBG_NO_SDUAL_FB")) {
+            if (h->relin.ready) HIP_TRY(h, launch_sgains(h, 1));   // (this step's linearisations, unsolved instances only)
+            HIP_TRY(h, launch_sdual(h, 1, h->dU, 0, true));
+        }
+        if (h->mc == 0 && !h->useS && h->rKst && !getenv("ALMPC_DBG_NO_PRIMAL_NET")) HIP_TRY(h, launch_riccati(h, 1, h->dU, 0));
+    }
     if (timing) {
         if (ev0_done) HIP_TRY(h, hipEventRecord(ev[3], st));
         h->ev_two[h->ev_used] = ev0_done ? 0 : 1;

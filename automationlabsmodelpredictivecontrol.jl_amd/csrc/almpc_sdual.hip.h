@@ -25,6 +25,7 @@
 #include <stdint.h>
 #include <type_traits>
 #include "almpc_kernels.hip.h"
+#include "almpc_riccati.hip.h"
 
 namespace almpc {
 
@@ -37,7 +38,7 @@ struct SdualParams {
     const double* uref; long uref_stride;              // [N][m]: input bounds are umin - uref_k .. umax - uref_k
     const double* xmin; const double* xmax;            // [n] or null: no state box
     const double* xbref; long xbref_stride;            // [N+1][n]: state bounds are xmin - xbref_k .. xmax - xbref_k
-    const double* eqt; long eqt_stride;                // [n] terminal equality target for e_N, or null
+    const double* eqt; long eqt_stride;                // [n] terminal equality target for x_N in ABSOLUTE coordinates (the state reference of stage N), or null
     const double* x0; const double* xref; long xref_stride;   // e_0 = x0 - xref_0 (x0 null: e_0 = 0); x = e + xref
     const double* uguess;                              // [batch][N][m] inputs whose bounds seed the working set, or null
     int filter;                                        // 0 all instances; 1 status != 0; 2 status != 0 or flag != 0 (flag cleared when solved)
@@ -46,6 +47,7 @@ struct SdualParams {
     double* x; double* ex; double* u; double* eu;      // results, layouts of almpc_get_results
     int32_t* status; int32_t* piters;
     int32_t* ovf;                                      // [batch] or null: 1 + rows = the working set outgrew wcap (the caller redoes it with more room)
+    const int* gbad;                                   // [batch] or null: 1 = the instance's stage records are not usable (k_sgains: R + B'PB not positive definite): left alone
     int32_t* wsave;                                    // [batch][SDUAL_WSAVE] or null: that working set (row << 2 | side code), the start of the next tier
     int only_ovf;                                      // 1: only instances with ovf != 0 (second tier)
     int rows_state;                                    // 1: the problem has state rows (an "infeasible" verdict is meaningful)
@@ -198,6 +200,11 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
 
     const int nwaves = gridDim.x * wpb;
     for (int inst = blockIdx.x * wpb + wv; inst < p.batch; inst += nwaves) {
+        if (p.gbad && p.gbad[inst] != 0) {   // no usable records: the instance keeps (or gets) a non-zero status
+            if (p.filter == 0 && !p.only_ovf && lane0 == 0) { p.status[inst] = 1; p.piters[inst] = 0; }
+            if (p.ovf && !p.only_ovf && lane0 == 0) p.ovf[inst] = 0;
+            continue;
+        }
         // (the lane index made opaque per instance: per-lane addresses of the rarely used arrays are then computed where they are used
         // instead of being hoisted out of this loop into registers that stay live across the whole solve)
         int lane = lane0;
@@ -235,7 +242,7 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
             if (lane >= NT) { const int a_ = lane - NT; if (a_ < m) { lo = p.umin[a_]; hi = p.umax[a_]; } }
             else if (lane < n && has_box) { lo = p.xmin[lane]; hi = p.xmax[lane]; }
             blo[lane] = lo; bhi[lane] = hi;
-            if (lane < NT) beq[lane] = (has_eq && lane < n) ? eqg[lane] + (xbr ? xbr[(size_t)N * n + lane] : 0.0) : 0.0;
+            if (lane < NT) beq[lane] = (has_eq && lane < n) ? eqg[lane] : 0.0;
         }
         sd_fence();
         // bounds of coordinate t (row: the coordinate carries bounds at all)
@@ -629,6 +636,11 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
                 double* t_ = s; s = w; w = t_;
                 to_abs();
                 if (after == A_INIT) {
+                    {   // non-finite inputs (x0, references, models) show in the unconstrained solution
+                        double chk0 = 0.0;
+                        for (int t = lane; t < TP; t += 64) chk0 += s[t] - s[t];
+                        if (__any(chk0 != 0.0)) { bad = true; break; }
+                    }
                     if (x0_out) { status = 3; break; }
                     // the start list: saved working set of the previous tier, or terminal-equality rows + the guess's inputs on a bound
                     ns = 0;
@@ -665,6 +677,9 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
                             kg = sd_wave_max_i(kg);
                         }
                     }
+                    // a guess that fills the working set to the brim is not a guess worth having (e.g. the saturated iterate of a
+                    // condensed step that failed): start from the equality rows alone
+                    if (!(p.only_ovf && p.wsave) && ns > wcap - 8) { ns = has_eq ? n : 0; kg = has_eq ? N : -1; }
                     if (ns > SDUAL_WSAVE) ns = SDUAL_WSAVE;
                     st_kend = kg + 1 < N ? kg + 1 : N;
                     sd_fence();
@@ -741,8 +756,7 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
                         }
                         const int pos = pos_of_row(vi);
                         sd_fence();
-                        remove_pos(pos);
-                        ++it;
+                        remove_pos(pos);   // (not counted as an iteration: no sweep, O(|W|^2) -- the count is of scans + steps)
                     }
                     if (nW > 0) { mode = M_FULL; after = A_TOP; }
                     else mode = M_TOP;
@@ -844,6 +858,166 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
             if (p.filter == 2 && st_out == 0) p.flag[inst] = 0;
         }
         sd_fence();
+    }
+}
+
+
+// ---- stage records of models PER INSTANCE (and per stage: the QP of an SQP iteration): the backward Riccati recursion of the
+// unconstrained problem, once per instance and solve -- the device counterpart of hm::stage_records (csrc/almpc_host_math.h; oracle:
+// oracle/stagewise_oracle.py::stage_gains).  One wave per instance, every matrix of the recursion in the wave's slice of LDS; cold
+// path (O(N nt^3) per instance, against O(N nt^2) per working-set change in k_sdual).
+struct SgainsParams {
+    int n, nt, m, N, batch, NT, MC;
+    const double* A; long A_stride, A_kstride;     // n x n column-major
+    const double* B; long B_stride, B_kstride;     // n x m
+    const double* P; long P_stride;                // n x n terminal weight
+    const double* Q; const double* R; const double* S;   // shared weights; R with the reference's branch rule applied; S null: none
+    const double* c; long c_stride;                // [N][n] defects or null
+    int filter; const int32_t* status; const int* flag;   // as k_sdual: 1 status != 0, 2 status != 0 or flag != 0
+    double* rec; long rec_stride;                  // [N][NT + MC][2 NT + 2 MC] per instance
+    double* pc; double* ct; long pc_stride;        // [N][NT] per instance (with c)
+    // linear cost terms of an SQP iteration's QP, written to base [batch][TP] (k_sdual's `base`) when base != null:
+    //   state slot k = 1..N-1: Q ebar_{k-1}, slot N: P ebar_{N-1} (the state cost is on e_k + ebar_{k-1});  input slot k: qscale qadd_k
+    const double* ebar; long ebar_stride;          // [N][n]
+    const double* qadd; long qadd_stride; double qscale;   // [N][m]
+    double* base; long base_stride;
+    int* bad;                                      // [batch] or null: 1 = R + B'PB not positive definite for some stage
+    int lds_per_wave;
+};
+__host__ __device__ inline int sgains_lds_doubles(int nt, int m) {
+    // At, Pn, PA, Pw: 4 nt^2 | Bt, PB: 2 nt m | Gm, K: 2 m nt | Lam, Li, Rt: 3 m^2 | cv: nt
+    return (4 * nt * nt + 4 * nt * m + 3 * m * m + nt + 3) & ~1;
+}
+constexpr int SGAINS_WAVES = 4;
+
+__global__ __launch_bounds__(64 * SGAINS_WAVES) void k_sgains(SgainsParams p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = p.n, nt = p.nt, m = p.m, N = p.N, NT = p.NT, MC = p.MC;
+    const int nn = nt * nt, nm = nt * m, mm = m * m, RL = 2 * NT + 2 * MC;
+    const bool useS = p.S != nullptr;
+    double* L = smem + (size_t)wv * p.lds_per_wave;
+    double* At = L;          double* Pn = At + nn;    double* PA = Pn + nn;   double* Pw = PA + nn;
+    double* Bt = Pw + nn;    double* PB = Bt + nm;    double* Gm = PB + nm;   double* Ks = Gm + nm;
+    double* Lam = Ks + nm;   double* Li = Lam + mm;   double* Rt = Li + mm;   double* cv = Rt + mm;
+    const int wpb = (int)(blockDim.x >> 6), nwaves = gridDim.x * wpb;
+    for (int inst = blockIdx.x * wpb + wv; inst < p.batch; inst += nwaves) {
+        if ((p.filter == 1 && p.status[inst] == 0) || (p.filter == 2 && p.status[inst] == 0 && p.flag[inst] == 0)) continue;
+        const double* Ag = p.A + (size_t)inst * p.A_stride;
+        const double* Bg = p.B + (size_t)inst * p.B_stride;
+        const double* Pg = p.P + (size_t)inst * p.P_stride;
+        const double* cg = p.c ? p.c + (size_t)inst * p.c_stride : nullptr;
+        double* recg = p.rec + (size_t)inst * p.rec_stride;
+        bool notpd = false;
+        rw_fence();
+        for (int t = lane; t < nn; t += 64) {
+            const int i = t % nt, j = t / nt;
+            Pn[t] = (i < n && j < n) ? 0.5 * (Pg[i + j * n] + Pg[j + i * n]) : 0.0;
+        }
+        if (p.base) {
+            const int SP = NT + MC, TP = sdual_tp(NT, MC, N);
+            double* bg = p.base + (size_t)inst * p.base_stride;
+            const double* eb = p.ebar ? p.ebar + (size_t)inst * p.ebar_stride : nullptr;
+            const double* qa = p.qadd ? p.qadd + (size_t)inst * p.qadd_stride : nullptr;
+            for (int t = lane; t < TP; t += 64) {
+                const int k = t / SP, j = t - k * SP;
+                double v = 0.0;
+                if (j < n && k >= 1 && k <= N && eb) {
+                    for (int l = 0; l < n; ++l) {
+                        const double wgt = k == N ? 0.5 * (Pg[j + l * n] + Pg[l + j * n]) : 0.5 * (p.Q[j + l * n] + p.Q[l + j * n]);
+                        v += wgt * eb[(size_t)(k - 1) * n + l];
+                    }
+                } else if (j >= NT && j - NT < m && k < N && qa) v = p.qscale * qa[(size_t)k * m + (j - NT)];
+                bg[t] = v;
+            }
+        }
+        for (int k = N - 1; k >= 0; --k) {
+            const double* Ak = Ag + (size_t)k * p.A_kstride;
+            const double* Bk = Bg + (size_t)k * p.B_kstride;
+            rw_fence();
+            for (int t = lane; t < nn; t += 64) { const int i = t % nt, j = t / nt; At[t] = (i < n && j < n) ? Ak[i + j * n] : 0.0; }
+            for (int t = lane; t < nm; t += 64) { const int i = t % nt, a = t / nt; Bt[t] = i < n ? Bk[i + a * n] : (i - n == a ? 1.0 : 0.0); }
+            for (int t = lane; t < mm; t += 64) {
+                const int a = t % m, b = t / m;
+                Rt[t] = 0.5 * (p.R[a + b * m] + p.R[b + a * m]) + ((useS && k >= 1) ? 0.5 * (p.S[a + b * m] + p.S[b + a * m]) : 0.0);
+            }
+            for (int t = lane; t < nt; t += 64) cv[t] = (cg && t < n) ? cg[(size_t)k * n + t] : 0.0;
+            rw_fence();
+            wv_matmul<false>(PA, Pn, At, nt, nt, nt, lane);
+            wv_matmul<false>(PB, Pn, Bt, nt, nt, m, lane);
+            if (cg) {   // Pc_k = P_{k+1} ct_k, ct_k (padded rows)
+                for (int i = lane; i < NT; i += 64) {
+                    double sacc = 0.0;
+                    if (i < nt) for (int j = 0; j < nt; ++j) sacc += Pn[i + j * nt] * cv[j];
+                    p.pc[(size_t)inst * p.pc_stride + (size_t)k * NT + i] = sacc;
+                    p.ct[(size_t)inst * p.pc_stride + (size_t)k * NT + i] = i < nt ? cv[i] : 0.0;
+                }
+            }
+            rw_fence();
+            wv_matmul<true>(Lam, Bt, PB, m, nt, m, lane);    // Bt' P+ Bt
+            wv_matmul<true>(Gm, Bt, PA, m, nt, nt, lane);    // Bt' P+ At   (m x nt)
+            rw_fence();
+            for (int t = lane; t < mm; t += 64) Lam[t] += Rt[t];
+            if (useS && k >= 1)
+                for (int t = lane; t < mm; t += 64) { const int a = t % m, b = t / m; Gm[a + (n + b) * m] -= 0.5 * (p.S[b + a * m] + p.S[a + b * m]); }   // + M', M = [0; -S]
+            rw_fence();
+            for (int t = lane; t < mm; t += 64) { const int a = t % m, b = t / m; Li[t] = 0.5 * (Lam[t] + Lam[b + a * m]); }
+            rw_fence();
+            for (int pv = 0; pv < m; ++pv) {   // in-place Gauss-Jordan (SPD: no pivoting)
+                double nv[4];
+                int cnt = 0;
+                const double piv = Li[pv + pv * m];
+                notpd = notpd || !(piv > 0.0);
+                const double ip = 1.0 / piv;
+                for (int t = lane; t < mm; t += 64) {
+                    const int i = t % m, j = t / m;
+                    const double lip = Li[i + pv * m], lpj = Li[pv + j * m];
+                    nv[cnt++] = (i == pv) ? ((j == pv) ? ip : lpj * ip) : ((j == pv) ? -lip * ip : Li[t] - lip * lpj * ip);
+                }
+                rw_fence();
+                cnt = 0;
+                for (int t = lane; t < mm; t += 64) Li[t] = nv[cnt++];
+                rw_fence();
+            }
+            wv_matmul<false>(Ks, Li, Gm, m, m, nt, lane);   // K = Lam^-1 Gm
+            rw_fence();
+            // record rows of stage k
+            double* rk = recg + (size_t)k * (NT + MC) * RL;
+            for (int t = lane; t < (NT + MC) * RL; t += 64) {
+                const int row = t / RL, col = t - row * RL;
+                double v = 0.0;
+                if (row < nt) {
+                    const int l = row;
+                    if (col < NT) { const int j = col; if (j < nt) { double acl = At[j + l * nt]; for (int b = 0; b < m; ++b) acl -= Bt[j + b * nt] * Ks[b + l * m]; v = acl; } }   // Acl(j, l)
+                    else if (col < NT + MC) { const int b = col - NT; if (b < m) v = -Ks[b + l * m]; }
+                    else if (col < 2 * NT + MC) { const int j = col - NT - MC; if (j < nt) { double acl = At[l + j * nt]; for (int b = 0; b < m; ++b) acl -= Bt[l + b * nt] * Ks[b + j * m]; v = acl; } }   // Acl(l, j)
+                    else { const int b = col - 2 * NT - MC; if (b < m) v = -Bt[l + b * nt]; }
+                } else if (row >= NT && row - NT < m) {
+                    const int a = row - NT;
+                    if (col < NT) { const int j = col; if (j < nt) { double lb = 0.0; for (int b = 0; b < m; ++b) lb += Li[a + b * m] * Bt[j + b * nt]; v = lb; } }   // Lb(a, j)
+                    else if (col < NT + MC) { const int b = col - NT; if (b < m) v = 0.5 * (Li[a + b * m] + Li[b + a * m]); }
+                    else if (col < 2 * NT + MC) { const int j = col - NT - MC; if (j < nt) v = -Ks[a + j * m]; }
+                    else { const int b = col - 2 * NT - MC; v = (b == a) ? -1.0 : 0.0; }
+                }
+                rk[t] = v;
+            }
+            // P_k = Qt + At' PA - Gm' K, symmetrised
+            for (int t = lane; t < nn; t += 64) {
+                const int i = t % nt, j = t / nt;
+                double sacc = 0.0;
+                if (k >= 1) {
+                    if (i < n && j < n) sacc = 0.5 * (p.Q[i + j * n] + p.Q[j + i * n]);
+                    else if (useS && i >= n && j >= n) sacc = 0.5 * (p.S[(i - n) + (j - n) * m] + p.S[(j - n) + (i - n) * m]);
+                }
+                for (int l = 0; l < nt; ++l) sacc += At[l + i * nt] * PA[l + j * nt];
+                for (int a = 0; a < m; ++a) sacc -= Gm[a + i * m] * Ks[a + j * m];
+                Pw[t] = sacc;
+            }
+            rw_fence();
+            for (int t = lane; t < nn; t += 64) { const int i = t % nt, j = t / nt; Pn[t] = 0.5 * (Pw[t] + Pw[j + i * nt]); }
+            rw_fence();
+        }
+        if (p.bad && lane == 0) p.bad[inst] = notpd ? 1 : 0;
     }
 }
 

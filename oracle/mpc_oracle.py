@@ -1343,7 +1343,17 @@ def sqp_fnn(model: FnnModel, x0, x_ref, u_ref, Q, R, S, P, u_min, u_max, iters, 
         for k in range(N):
             Ak, Bk = model.jacobian(X[:, k], U[:, k])
             A.append(Ak); B.append(Bk); c.append(fv[:, k] - X[:, k + 1])
-        if structured:   # the QP in its stage-wise form (riccati_active_set): no condensed Hessian, also for unstable linearisations
+        if structured == "dual":   # the QP in its stage-wise form by the dual active set (k_sdual): also state rows and S
+            import stagewise_oracle as so
+            if x_min is not None and (np.any(x0 < x_min) or np.any(x0 > x_max)):
+                raise ValueError("infeasible: x[:,1] = x0 violates the state box")
+            qq = so.stage_qp_from_ltv(A, B, c, X, U, x_ref, u_ref, Q, Rz, Sz, P, u_min, u_max, x_min=x_min, x_max=x_max, terminal=terminal)
+            rr = so.solve_stage_dual(qq, v_guess=np.zeros((N, m)))
+            if rr["status"] == 3:
+                raise ValueError("infeasible QP")
+            v = rr["v"].T
+            n_state_active = int(np.count_nonzero(rr["lam_x"]))
+        elif structured:   # the QP in its stage-wise form (riccati_active_set): no condensed Hessian, also for unstable linearisations
             rr = riccati_active_set(A, B, Q, Rz, P, np.zeros(x0.size), (u_min[:, None] - U).T, (u_max[:, None] - U).T, c=np.array(c),
                                     ebar=(X[:, 1:] - x_ref[:, 1:]).T, qu=(Rz @ (U - u_ref)).T)
             v = rr["v"].T

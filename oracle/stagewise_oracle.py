@@ -294,8 +294,7 @@ def solve_stage_dual(q: StageQP, v_guess=None, max_iter=None, tol=1e-9, wcap=Non
                 lam[:] = 0.0
                 lam[W] = lw
                 break
-            remove(int(np.argmax(viol)))
-            it += 1
+            remove(int(np.argmax(viol)))   # (not counted as an iteration: no sweep)
         s = full(lam)
     status = 1
     refined = 0

@@ -115,7 +115,7 @@ def test_random_plant_families_of_many_shapes(capi, mo, n, m, N):
         e = mo.solve_mpc_exact(p, X0[i])
         if r["status"][i] == 0:
             assert np.abs(r["u"][i] - e["u"]).max() <= U_TOL * max(1.0, np.abs(e["x"]).max())
-    assert (r["status"] == 0).mean() >= 0.9
+    assert np.all(r["status"] == 0), np.bincount(r["status"], minlength=4)   # every instance solved (stage-wise redo of what the condensed finish leaves: default on)
 
 
 def test_more_than_256_designs_beyond_64_variables(capi, mo):
@@ -126,7 +126,7 @@ def test_more_than_256_designs_beyond_64_variables(capi, mo):
     umin, umax = -np.ones(m), np.ones(m)
     sv, r = solve_batched(capi, As, Bs, N, umin, umax, X0)
     sv.close()
-    assert (r["status"] == 0).mean() >= 0.95
+    assert np.all(r["status"] == 0), np.bincount(r["status"], minlength=4)
     for i in range(0, b, 37):
         if r["status"][i] == 0:
             e = mo.solve_mpc_exact(mo.make_problem(As[i], Bs[i], N, umin, umax), X0[i])
@@ -249,7 +249,7 @@ def test_mirror_relinearises_every_step(pkg, capi, mo):
             e = mo.solve_mpc_exact(p, X0[i] * (1.0 + 0.5 * step))
             if st[i] == 0:
                 assert np.abs(res.u[i] - e["u"]).max() <= U_TOL
-        assert (st == 0).mean() >= 0.95
+        assert np.all(st == 0), np.bincount(st, minlength=4)
     C.tuning.modeler.solver.close()
     with pytest.raises(ValueError):
         pkg.proceed_controller(sys_, "model_predictive_control", N, 1, x_ref, u_ref, mpc_linearization="sometimes")
@@ -290,23 +290,23 @@ def test_relin_pipeline_on_device_equals_host_path(capi, mo):
         sd.close()
         for key in ("status", "iters", "polish_iters", "u", "x", "e_u", "e_x"):
             assert np.array_equal(a[key], b[key]), key
-        assert (a["status"] == 0).mean() >= 0.98 and t["design_ms"] > 0 and t["step_ms"] > 0
+        assert np.all(a["status"] == 0) and t["design_ms"] > 0 and t["step_ms"] > 0
         if S is None:
-            # with the structured fallback (input box, no input-rate weight) nothing stays unsolved: the instances the condensed path
-            # gives up on are solved by k_riccati, the others keep their results bit for bit
-            sf = capi.Solver(n, m, N, batch, structured_fallback=True)
-            sf.relin_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, x_ref, u_ref, Q, R, None, P, [-1, -1], [1, 1], act=f.act)
-            sf.update_initialization(X0)
-            sf.relin_fnn_step(opts)
-            c = sf.get_results()
-            sf.close()
-            assert np.all(c["status"] == 0), np.bincount(c["status"])
-            ok = a["status"] == 0
+            # without the stage-wise redo (switched off explicitly) the condensed path gives up on the open-loop unstable linearisations;
+            # with it (the default, above) nothing stays unsolved and the others keep their results bit for bit
+            sn = capi.Solver(n, m, N, batch, structured_fallback=False)
+            sn.relin_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, x_ref, u_ref, Q, R, None, P, [-1, -1], [1, 1], act=f.act)
+            sn.update_initialization(X0)
+            sn.relin_fnn_step(opts)
+            c = sn.get_results()
+            sn.close()
+            ok = c["status"] == 0
+            assert ok.mean() >= 0.9
             assert np.array_equal(a["u"][ok], c["u"][ok])
             for i in np.nonzero(~ok)[0][:4]:
                 pi = mo.make_problem(A[i], B[i], N, [-1, -1], [1, 1], x_ref=x_ref, u_ref=u_ref, P=P)
-                ex = mo.rollout(pi, X0[i], (c["u"][i] - pi.u_ref).T.reshape(-1))["x"]
-                assert np.abs(c["x"][i] - ex).max() <= 1e-9 * max(1.0, np.abs(ex).max())
+                ex = mo.rollout(pi, X0[i], (a["u"][i] - pi.u_ref).T.reshape(-1))["x"]
+                assert np.abs(a["x"][i] - ex).max() <= 1e-9 * max(1.0, np.abs(ex).max())
         for i in range(0, batch, 23):
             if a["status"][i] == 0:
                 p = mo.make_problem(A[i], B[i], N, [-1, -1], [1, 1], x_ref=x_ref, u_ref=u_ref, s=0.0 if S is None else 0.3, P=P)
@@ -401,7 +401,7 @@ def test_wave_per_instance_step_equals_the_two_launch_path(capi, mo, monkeypatch
     for a_, b_ in (("wave", "pair"), ("wave_warm", "pair_warm")):
         assert np.array_equal(res[a_]["status"], res[b_]["status"])
         ok = res[a_]["status"] == 0
-        assert ok.mean() >= 0.97
+        assert np.all(ok), np.bincount(res[a_]["status"], minlength=4)
         assert np.abs(res[a_]["u"][ok] - res[b_]["u"][ok]).max() <= 1e-9
         assert np.abs(res[a_]["x"][ok] - res[b_]["x"][ok]).max() <= 1e-8
     assert np.array_equal(res["wave"]["iters"], res["pair"]["iters"])

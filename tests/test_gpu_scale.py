@@ -138,13 +138,11 @@ def test_state_rows_full_batch_properties(capi, mo):
     s.close()
     st = r["status"]
     ok = st == 0
-    # status 1 (not certified): instances a hair's breadth on the INFEASIBLE side -- x0 clipped to 0.99 of a bound the dynamics push it
-    # over, a state riding its bound through the whole horizon, Ghat_WW singular to working precision (cond 1e9..1e19): the
-    # confirmation step finds that the working-set rows do not sit on their bounds and refuses to certify.  The LP certificate below
-    # says what they are: none of them is feasible (they miss by 5e-5 .. 6e-3).  No feasible instance is left without a certificate.
-    assert ok.sum() >= 2500 and (st == 3).sum() >= 1000 and (st == 1).sum() <= 20 and (st == 2).sum() == 0, np.bincount(st, minlength=4)
-    for i in np.flatnonzero(st == 1):
-        assert mo.feasibility_slack(p, X0[i]) > 1e-7, i
+    # Every instance is decided: solved with a certificate, or infeasible.  The condensed finish leaves a handful without a verdict
+    # (instances a hair's breadth on the INFEASIBLE side: x0 clipped to 0.99 of a bound the dynamics push it over, Ghat_WW singular to
+    # working precision); the stage-wise dual active set (k_sdual, the default redo of such instances) classifies them, and the phase-1
+    # linear programme below confirms the verdicts.
+    assert ok.sum() >= 2500 and (st == 3).sum() >= 1000 and (st == 1).sum() == 0 and (st == 2).sum() == 0, np.bincount(st, minlength=4)
     for i in np.flatnonzero(st == 3)[::97]:
         assert mo.feasibility_slack(p, X0[i]) > 1e-7, i
     for i in np.flatnonzero(ok)[::131]:
@@ -158,15 +156,9 @@ def test_state_rows_full_batch_properties(capi, mo):
     pred = np.einsum("ij,bjk->bik", p.A, ex[:, :, :-1]) + np.einsum("ij,bjk->bik", p.B, eu)
     assert np.abs(pred - ex[:, :, 1:]).max() <= 1e-9 * max(1.0, np.abs(ex).max())
     idx_ok = np.flatnonzero(ok)[::211]
-    compared = 0
-    for i in idx_ok:
-        try:
-            e = mo.solve_mpc_exact(p, X0[i])
-        except RuntimeError:     # (the checker's own bordered inverse loses the instance: it refuses to certify, nothing to compare)
-            continue
+    for i in idx_ok:   # (mo.solve_mpc_exact: when its own bordered inverse loses an instance it takes a second opinion and certifies that)
+        e = mo.solve_mpc_exact(p, X0[i])
         assert np.abs(r["u"][i] - e["u"]).max() <= U_TOL
-        compared += 1
-    assert compared >= len(idx_ok) - 2
     for i in np.flatnonzero(st == 3)[::173]:
-        with pytest.raises((ValueError, RuntimeError)):
+        with pytest.raises(ValueError):
             mo.solve_mpc_exact(p, X0[i])

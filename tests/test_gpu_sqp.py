@@ -327,10 +327,45 @@ def test_sqp_with_the_structured_qp_solver(capi, mo):
     for i in range(b):
         assert np.abs(r["x"][i] - mo.fnn_rollout(f, X0[i], r["u"][i])).max() <= 1e-9
         assert mo.nlp_kkt_residual(f, X0[i], r["u"][i], kw["x_ref"], kw["u_ref"], kw["Q"], kw["R"], kw["S"], kw["P"], kw["u_min"], kw["u_max"]) <= 1e-5
-    with pytest.raises(capi.AlmpcError):   # no state rows in the stage-wise solve
-        s3 = capi.Solver(n, m, N, 4)
+
+
+def test_structured_qp_solver_with_state_box_and_rate_weight(capi, mo):
+    """The stage-wise QP of the loop (k_sgains + k_sdual) with the rows the reference's NLP branch carries (state box,
+    .../fnn/mpc_modeler_implementation_fnn.jl:146-153) and the input-rate weight (src/sub/design_mpc.jl:423-446): against the condensed
+    route of the same loop (same QPs, other solver) and the restatement with exact QP solves."""
+    b, N, iters = 24, 20, 25
+    f = mo.synthetic_fnn(act="tanh")
+    n, m = 4, 2
+    x_ref = np.tile(np.array([0.2, -0.1, 0.05, 0.0])[:, None], (1, N + 1)); u_ref = np.tile(np.array([0.1, -0.2])[:, None], (1, N))
+    Q, R, P, S = 100.0 * np.eye(n), 0.1 * np.eye(m), 150.0 * np.eye(n), 0.2 * np.eye(m)
+    umin, umax = -np.ones(m), np.ones(m)
+    xlo, xhi = np.array([-0.12, -0.58, -0.25, -0.35]), np.array([0.25, 0.09, 0.07, 0.22])
+    X0 = x_ref[:, 0][None, :] + 0.5 * mo.splitmix_normal(0x5EED0005, 40, b, n)
+    X0 = np.clip(X0, xlo + 0.02 * (xhi - xlo), xhi - 0.02 * (xhi - xlo))
+    res = {}
+    for qp in ("condensed", "structured"):
+        s = capi.Solver(n, m, N, b)
+        s.sqp_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, x_ref, u_ref, Q, R, S, P, umin, umax, act="tanh", xmin=xlo, xmax=xhi, qp_solver=qp)
+        s.sqp_fnn_start(X0)
         try:
-            s3.sqp_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, kw["x_ref"], kw["u_ref"], kw["Q"], kw["R"], kw["S"], kw["P"], kw["u_min"], kw["u_max"],
-                             act="tanh", qp_solver="structured", xmin=-np.ones(4), xmax=np.ones(4))
-        finally:
-            s3.close()
+            s.sqp_fnn_iterate(iters)
+            skipped = np.zeros(b, dtype=int)
+        except capi.AlmpcError as e:      # instances whose first QP is infeasible are skipped and named (no elastic mode)
+            assert e.code == -6
+            skipped = s.sqp_fnn_skipped()
+        res[qp] = (s.get_results(), np.flatnonzero(skipped))
+        s.close()
+    (rc, sc), (rs, ss) = res["condensed"], res["structured"]
+    assert list(sc) == list(ss)
+    good = [i for i in range(b) if i not in ss]
+    assert len(good) >= b - 6
+    assert np.abs(rs["u"][good] - rc["u"][good]).max() <= U_TOL and np.abs(rs["x"][good] - rc["x"][good]).max() <= 1e-4
+    nact = 0
+    for i in good:
+        assert np.abs(rs["x"][i] - mo.fnn_rollout(f, X0[i], rs["u"][i])).max() <= 1e-5
+        assert np.all(rs["x"][i] <= xhi[:, None] + 1e-5) and np.all(rs["x"][i] >= xlo[:, None] - 1e-5)
+        nact += int(((rs["x"][i][:, 1:] >= xhi[:, None] - 1e-6) | (rs["x"][i][:, 1:] <= xlo[:, None] + 1e-6)).sum())
+    assert nact > 5 * len(good), "the box never binds: test inputs too tame"
+    for i in good[:3]:
+        X, U, hist = mo.sqp_fnn(f, X0[i], x_ref, u_ref, Q, R, S, P, umin, umax, iters, x_min=xlo, x_max=xhi, structured="dual")
+        assert np.abs(rs["u"][i] - U).max() <= U_TOL

