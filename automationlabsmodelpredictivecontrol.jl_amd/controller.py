@@ -167,6 +167,7 @@ class HipModeler:
         self.solver, self.opts, self.batch = solver, opts, batch
         self.relinearize = None  # dict for mpc_linearization='step' (black-box models), see _design_blackbox
         self.sqp = None          # dict for mpc_programming_type='non_linear', see _design_blackbox_nonlinear
+        self.allow_unsolved = False  # kw mpc_allow_unsolved: calculate! returns the iterate of an instance without a certificate instead of raising
 
 
 def _design_reference_mpc(state_reference, input_reference, horizon: int) -> ReferencesStateInput:
@@ -281,6 +282,7 @@ def _design_blackbox_nonlinear(system, horizon, sample_time, references, weights
                          terminal="equality" if terminal == "equality" else "none",
                          qp_solver=kws.get("mpc_sqp_qp_solver", "condensed"))   # "structured": every QP through k_riccati
     mod = HipModeler(solver, _capi.default_opts(**sopt), batch)
+    mod.allow_unsolved = bool(kws.get("mpc_allow_unsolved", False))
     mod.sqp = dict(iterations=int(kws.get("mpc_sqp_iterations", 10)), step=float(kws.get("mpc_sqp_step", 1.0)),
                    warm_start=bool(kws.get("mpc_sqp_warm_start", True)), u_prev=None,
                    step_rule=kws.get("mpc_sqp_step_rule", "merit"))
@@ -341,7 +343,9 @@ def _design_linear(system: ConstrainedLinearControlDiscreteSystem, horizon: int,
     solver.set_reference(x_ref, u_ref)
     P = solver.get_design()["P"]
     opts = _capi.default_opts(**sopt)
-    tuning = ModelPredictiveControlTuning(HipModeler(solver, opts, batch), references, horizon, weights,
+    modeler_ = HipModeler(solver, opts, batch)
+    modeler_.allow_unsolved = bool(kws.get("mpc_allow_unsolved", False))
+    tuning = ModelPredictiveControlTuning(modeler_, references, horizon, weights,
                                           TerminalIngredient(terminal, np.array(P)), float(sample_time), int(max_time))
     shape = (lambda *s: s) if batch == 1 else (lambda *s: (batch, *s))
     results = ModelPredictiveControlResults(np.empty(shape(n, horizon + 1)), np.empty(shape(n, horizon + 1)),
@@ -383,6 +387,12 @@ def calculate(C: ModelPredictiveControlController) -> None:
         raise ArithmeticError("calculate!: non-finite values in at least one instance (no solution to read)")
     if np.any(r["status"] == _capi.INFEASIBLE):  # the reference: JuMP.value throws when the solver has no primal
         raise ArithmeticError("calculate!: infeasible problem in at least one instance (state box / terminal equality)")
+    # status 1 with the exact finish on: no certificate even after the library's stage-wise redo (an iteration cap, a working set
+    # beyond 128 rows).  The reference returns a solution or throws: raise, unless kw mpc_allow_unsolved = True asked for the iterate
+    # (with polish off status 1 is OSQP's ITERATION_LIMIT, with which JuMP.value still returns)
+    if np.any(r["status"] == 1) and int(mod.opts.polish) != 0 and not getattr(mod, "allow_unsolved", False):
+        raise ArithmeticError(f"calculate!: {int((r['status'] == 1).sum())} instance(s) without an optimality certificate "
+                              "(mpc_allow_unsolved = True returns the iterate; modeler.last_status says which)")
     res = C.computation_results
     for k in ("x", "e_x", "u", "e_u"):
         getattr(res, k)[...] = r[k][0] if mod.batch == 1 else r[k]

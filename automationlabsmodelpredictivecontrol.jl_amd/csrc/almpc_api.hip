@@ -120,12 +120,20 @@ struct almpc_handle {
     // structured (Riccati) solve: the handle's only solver (ALMPC_FLAG_STRUCTURED) or the fallback for instances the condensed path
     // leaves unsolved (almpc_set_structured_fallback)
     bool structured = false;
+    // lazy redo (fallback == 2 on the shared-model, input-box-only path, whose steps are tens of microseconds and leave an instance
+    // unsolved only in corner cases): the finish counts such instances into a host-visible word; the redo kernels are launched at the
+    // next host sync point only when the count has moved -- no extra launch on the step path (measured: two idle redo launches cost
+    // 14 us per 61 us step)
+    int* hUnsolved = nullptr;      // pinned host word
+    int* dUnsolved = nullptr;      // the device's address of it
+    int unsolved_seen = 0;
+    bool lazy_pending = false;
     int fallback = 2;   // 0 off, 1 asked for (a design it cannot serve is an error), 2 default: on wherever the stage-wise solvers cover the design
     double *rQ = nullptr, *rR = nullptr, *rP = nullptr, *rKst = nullptr, *rPst = nullptr;   // device copies of Q, R (branch rule applied), shared P; gain scratch
     double* rGuess = nullptr;   // [batch][N][m] start of the next structured solve (almpc_set_start_from / opts.warm_start), else nullptr
     bool guess_ready = false;   // rGuess was filled for the NEXT almpc_calculate (consumed by it)
     bool r_has_step = false;    // a structured step has run on this design: its inputs can seed a warm start
-    hipEvent_t ev_guess = nullptr;
+    hipEvent_t ev_guess = nullptr, ev_guess_done = nullptr;
     long rP_stride = 0;   // per-instance terminal weights (batched designs): doubles between instances of bP, else 0 with rP
     bool r_batched_P = false;
     // stage-wise dual active-set solve (k_sdual, csrc/almpc_sdual.hip.h): input box, state box, terminal equality and S in the
@@ -184,6 +192,7 @@ struct almpc_handle {
         int32_t* dInts[IO_DEPTH] = {nullptr, nullptr};       // slots directly)
         hipEvent_t ev_packed[IO_DEPTH] = {nullptr, nullptr}; // compute stream: the results of the slot's step exist (copy-out stream waits)
         hipEvent_t ev_done[IO_DEPTH] = {nullptr, nullptr};   // everything the slot's request asked for has landed in pinned memory
+        hipEvent_t ev_big = nullptr;                          // the last read-back of x / e_x / u / e_u has left the result buffers (the next step waits for it)
         uint32_t want[IO_DEPTH] = {0, 0};
         long ticket[IO_DEPTH] = {-1, -1};
         long next_ticket = 0;
@@ -272,6 +281,8 @@ void free_all(almpc_handle* h) {
                     (void*)h->sd.rec, (void*)h->sd.base, (void*)h->sd.xmin, (void*)h->sd.xmax, (void*)h->sd.eqt, (void*)h->sd.ovf, (void*)h->sd.wsave, (void*)h->sd.sinv_glb, (void*)h->sd.dQ, (void*)h->sd.dR, (void*)h->sd.dS, (void*)h->sd.dP, (void*)h->sd.bad, (void*)h->sd.pc, (void*)h->sd.ct})
         if (p) (void)hipFree(p);
     if (h->ev_guess) (void)hipEventDestroy(h->ev_guess);
+    if (h->ev_guess_done) (void)hipEventDestroy(h->ev_guess_done);
+    if (h->hUnsolved) (void)hipHostFree(h->hUnsolved);
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
     h->ev.clear();
@@ -712,6 +723,21 @@ hipError_t launch_sdual(almpc_handle* h, int filter, const double* guess, int ma
     return hipErrorInvalidValue;
 }
 
+// Lazy redo (see almpc_handle::hUnsolved): called where the host is about to look at results and the stream is idle.  If the finish of
+// a step since the last look left instances unsolved, the stage-wise solvers redo them now (from the step's own result).
+int resolve_lazy_redo(almpc_handle* h) {
+    if (!h->lazy_pending) return ALMPC_OK;
+    h->lazy_pending = false;
+    if (!h->hUnsolved) return ALMPC_OK;
+    const int cur = *reinterpret_cast<volatile int*>(h->hUnsolved);
+    if (cur == h->unsolved_seen) return ALMPC_OK;
+    h->unsolved_seen = cur;
+    if (h->sd.ready) HIP_TRY(h, launch_sdual(h, 1, h->dU, 0, true));
+    if (h->mc == 0 && !h->useS && h->rKst) HIP_TRY(h, launch_riccati(h, 1, h->dU, 0));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return ALMPC_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -879,6 +905,10 @@ int almpc_set_start_from(almpc_handle* h, almpc_handle* src) {
     hipLaunchKernelGGL(k_guess_from_inputs, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, h->batch, h->m, src->N, h->N, 0,
                        (const double*)src->dU, (const double*)h->dUref, h->uref_stride, h->rGuess);
     HIP_TRY(h, hipGetLastError());
+    // ... and src's NEXT step must not overwrite its inputs before that kernel has read them: src's stream waits for it
+    if (!h->ev_guess_done) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_guess_done, hipEventDisableTiming));
+    HIP_TRY(h, hipEventRecord(h->ev_guess_done, h->stream));
+    HIP_TRY(h, hipStreamWaitEvent(src->stream, h->ev_guess_done, 0));
     h->guess_ready = true;
     return ALMPC_OK;
 }
@@ -1738,6 +1768,10 @@ int almpc_relin_fnn_advance(almpc_handle* h) {
     fp.x = h->dX0; fp.u = q.u0; fp.ppi = 1; fp.xs_group = n; fp.us_group = m;
     fp.A = h->bA; fp.B = h->bB; fp.f = q.xnext;   // (the Jacobian slots are scratch here: the next step re-linearises at the new state)
     HIP_TRY(h, launch_fnn_jacobian(fp, h->num_cus, st));
+    if (h->io.x0_slot >= 0) {   // a pinned x0 slot was read once more by the forward pass: free for the host only after it
+        HIP_TRY(h, hipEventRecord(h->io.ev_used[h->io.x0_slot], st));
+        h->io.used_pending[h->io.x0_slot] = true;
+    }
     io_release_x0(h);
     HIP_TRY(h, hipMemcpyAsync(h->dX0, q.xnext, (size_t)h->batch * n * sizeof(double), hipMemcpyDeviceToDevice, st));
     return ALMPC_OK;
@@ -2228,9 +2262,12 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
     const bool keep_state = !((o.reserved[0] & ALMPC_OPT_NO_WARM_STATE) && !h->batched && o.polish && h->mc == 0);
     if (o.warm_start && !h->state_valid)
         return fail(h, ALMPC_ERR_INVALID, "calculate: warm_start = 1, but the previous step ran with ALMPC_OPT_NO_WARM_STATE (no ADMM state was kept)");
+    // default redo of unsolved instances on the shared-model / input-box-only path: lazily, at the next host sync (see hUnsolved)
+    const bool lazy_redo = h->fallback == 2 && !h->structured && !h->batched && !h->ltv && h->mc == 0 && o.polish != 0 &&
+                           (h->sd.ready || h->rKst) && !getenv("ALMPC_EAGER_REDO");
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->io.big_copy_pending) {   // an asynchronous read-back straight from the result buffers: this step overwrites them
-        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->io.ev_done[h->io.big_copy_slot], 0));
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->io.ev_big, 0));
         h->io.big_copy_pending = false;
     }
     auto io_step_done = [&]() -> int {   // the x0 slot of an asynchronous update is free again once this step has finished
@@ -2419,6 +2456,14 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         pp.yflags = keep_state ? nullptr : h->dYflags; pp.yflag_words = h->nrb;
         pp.sglobal = h->dSglobal; pp.perm = h->dPerm; pp.ntiles = (h->batch + 15) / 16;
         pp.max_iter = o.polish_max_iter > 0 ? o.polish_max_iter : 2 * h->nz + 50;
+        if (lazy_redo) {
+            if (!h->hUnsolved) {
+                HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->hUnsolved), sizeof(int), hipHostMallocMapped));
+                *h->hUnsolved = 0; h->unsolved_seen = 0;
+                HIP_TRY(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->dUnsolved), h->hUnsolved, 0));
+            }
+            pp.unsolved = h->dUnsolved;
+        }
         // rollout fused into the tail of the polish when its trajectory buffer fits the wave's LDS slot
         fused = roll_fits;
         const bool blocked = !h->batched && h->roll_s > 0;   // shared model: blocked rollout, no trajectory buffer
@@ -2533,7 +2578,8 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
     }
     // structured fallback: instances the condensed path left without a certificate (status != 0: an active-set finish that ran into
     // its cap, a non-finite or indefinite condensed problem) are redone in the multiple-shooting form, from the step's own result
-    if (h->fallback && !h->ltv && o.polish) {
+    if (lazy_redo) h->lazy_pending = true;   // (resolve_lazy_redo at the next host sync point)
+    else if (h->fallback && !h->ltv && o.polish) {
         if (h->sd.ready && !getenv("ALMPC_DBG_NO_SDUAL_FB")) {
             if (h->relin.ready) HIP_TRY(h, launch_sgains(h, 1));   // (this step's linearisations, unsolved instances only)
             HIP_TRY(h, launch_sdual(h, 1, h->dU, 0, true));
@@ -2556,12 +2602,12 @@ int almpc_synchronize(almpc_handle* h) {
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
         const hipError_t q = hipStreamQuery(h->stream);
-        if (q == hipSuccess) return ALMPC_OK;
+        if (q == hipSuccess) return resolve_lazy_redo(h);
         if (q != hipErrorNotReady) return fail(h, ALMPC_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
         if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    return ALMPC_OK;
+    return resolve_lazy_redo(h);
 }
 
 int almpc_calculate(almpc_handle* h, const almpc_opts* opts) {
@@ -2576,6 +2622,7 @@ int almpc_get_results(almpc_handle* h, double* x, double* e_x, double* u, double
     if (!h->designed) return fail(h, ALMPC_ERR_NOT_DESIGNED, "get_results before design");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    { const int rc_ = resolve_lazy_redo(h); if (rc_ != ALMPC_OK) return rc_; }
     const size_t b = (size_t)h->batch, xs = (size_t)h->n * (h->N + 1), us = (size_t)h->nz;
     if (x) HIP_TRY(h, hipMemcpy(x, h->dX, b * xs * sizeof(double), hipMemcpyDeviceToHost));
     if (e_x) HIP_TRY(h, hipMemcpy(e_x, h->dEx, b * xs * sizeof(double), hipMemcpyDeviceToHost));
@@ -2832,10 +2879,15 @@ int almpc_advance_plant(almpc_handle* h) {
     HIP_TRY(h, hipSetDevice(h->device));
     const int per_block = 256 / h->n;
     const double* x0_in = h->dX0;
+    const int x0_slot = h->io.x0_slot;
     io_release_x0(h);   // (a pinned x0 slot is read once more here; the new states go to the handle's own device buffer)
     hipLaunchKernelGGL(k_advance_plant, dim3((h->batch + per_block - 1) / per_block), dim3(256), (size_t)per_block * h->n * sizeof(double),
                        h->stream, h->n, h->m, h->N, h->batch, h->dA, h->dB, h->dU, x0_in, h->dX0);
     HIP_TRY(h, hipGetLastError());
+    if (x0_slot >= 0) {   // the slot is free for the host again only once THIS read has finished too
+        HIP_TRY(h, hipEventRecord(h->io.ev_used[x0_slot], h->stream));
+        h->io.used_pending[x0_slot] = true;
+    }
     return ALMPC_OK;
 }
 

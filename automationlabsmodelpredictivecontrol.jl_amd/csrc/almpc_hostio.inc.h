@@ -40,9 +40,8 @@ hipError_t pinned(T** p, size_t count) {
     return hipHostMalloc(reinterpret_cast<void**>(p), count * sizeof(T), hipHostMallocDefault);
 }
 
-int io_init(almpc_handle* h) {
+int io_init_body(almpc_handle* h) {
     almpc_handle::Io& io = h->io;
-    if (io.ready) return ALMPC_OK;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamCreateWithFlags(&io.s_out, hipStreamNonBlocking));
     HIP_TRY(h, hipStreamCreateWithFlags(&io.s_in, hipStreamNonBlocking));
@@ -60,8 +59,22 @@ int io_init(almpc_handle* h) {
         for (hipEvent_t* e : {&io.ev_used[s], &io.ev_packed[s], &io.ev_done[s], &io.ev_in[s]})
             HIP_TRY(h, hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
+    HIP_TRY(h, hipEventCreateWithFlags(&io.ev_big, hipEventDisableTiming));
     io.ready = true;
     return ALMPC_OK;
+}
+
+void io_free(almpc_handle* h);
+
+int io_init(almpc_handle* h) {
+    if (h->io.ready) return ALMPC_OK;
+    const int rc = io_init_body(h);
+    if (rc != ALMPC_OK) {   // a failure half-way: release what was made (the message of the failed call survives), so that a retry starts clean
+        const std::string msg = h->err;
+        io_free(h);
+        h->err = msg;
+    }
+    return rc;
 }
 
 void io_free(almpc_handle* h) {
@@ -77,6 +90,7 @@ void io_free(almpc_handle* h) {
         for (hipEvent_t e : {io.ev_used[s], io.ev_packed[s], io.ev_done[s]})
             if (e) (void)hipEventDestroy(e);
     }
+    if (io.ev_big) (void)hipEventDestroy(io.ev_big);
     if (io.s_out) (void)hipStreamDestroy(io.s_out);
     if (io.s_in) (void)hipStreamDestroy(io.s_in);
     io = almpc_handle::Io();
@@ -155,7 +169,7 @@ int almpc_get_results_async(almpc_handle* h, uint32_t want) {
     // (the pinned slot of ticket t - IO_DEPTH is overwritten from here on: its views are valid until this call, as the header says)
     const bool big = (want & (ALMPC_WANT_X | ALMPC_WANT_E_X | ALMPC_WANT_U | ALMPC_WANT_E_U)) != 0;
     if (io.big_copy_pending && big) {   // two read-backs from the same result buffers in a row (no step between them): keep order simple
-        HIP_TRY(h, hipStreamWaitEvent(h->stream, io.ev_done[io.big_copy_slot], 0));
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, io.ev_big, 0));
         io.big_copy_pending = false;
     }
     if ((want & ALMPC_WANT_X) && !io.hX[s]) HIP_TRY(h, pinned(&io.hX[s], xs));
@@ -178,6 +192,9 @@ int almpc_get_results_async(almpc_handle* h, uint32_t want) {
         if (want & ALMPC_WANT_X) HIP_TRY(h, hipMemcpyAsync(io.hX[s], h->dX, xs * sizeof(double), hipMemcpyDeviceToHost, io.s_out));
         if (want & ALMPC_WANT_E_X) HIP_TRY(h, hipMemcpyAsync(io.hEx[s], h->dEx, xs * sizeof(double), hipMemcpyDeviceToHost, io.s_out));
         HIP_TRY(h, hipEventRecord(io.ev_done[s], io.s_out));   // (after the pack kernel as well: s_out waited for the compute stream)
+        // the next step waits for THIS read-back: an event of its own, which later small requests landing in the same slot (they
+        // re-record ev_done on the compute stream) cannot replace
+        HIP_TRY(h, hipEventRecord(io.ev_big, io.s_out));
     } else {
         HIP_TRY(h, hipEventRecord(io.ev_done[s], h->stream));
     }
@@ -244,6 +261,12 @@ int almpc_host_results(almpc_handle* h, int ticket, const double** x, const doub
 
 int almpc_get_first_input(almpc_handle* h, double* u0) {
     if (!h || !u0) return h ? fail(h, ALMPC_ERR_INVALID, "get_first_input: null u0") : ALMPC_ERR_INVALID;
+    if (h->lazy_pending) {   // (synchronous getter: settle a lazily deferred redo before the first inputs are packed)
+        HIP_TRY(h, hipSetDevice(h->device));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        const int rc_ = resolve_lazy_redo(h);
+        if (rc_ != ALMPC_OK) return rc_;
+    }
     const int t = almpc_get_results_async(h, ALMPC_WANT_FIRST_INPUT);
     if (t < 0) return t;
     return almpc_get_results_wait(h, t, nullptr, nullptr, nullptr, nullptr, u0, nullptr, nullptr, nullptr);

@@ -486,6 +486,7 @@ struct PolishParams {
                          // word beside the queue counter) and otherwise falls back to the global scratch
     int g_off;           // k_polish_sgl: offset of the wave's copy of its instance's G_i (nz rows of nzs doubles)
     int max_iter;
+    int* unsolved = nullptr;  // host-visible counter (or null): += 1 for every instance that leaves the finish with status != 0 (lazy redo, almpc_api.hip)
     int direct = 0;      // k_step_inst_wave: workgroup (= wave) b finishes instance b itself (no perm lookup)
     int fuse_rollout;    // 1: this kernel also produces u, e_u, x, e_x (roll.*), no separate k_rollout launch; 2: u, e_u only;
                          // 3: as 1 with the blocked rollout (shared model: rollM)
@@ -1469,6 +1470,8 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
     ALMPC_STAMP(inst, 11);
     ALMPC_ACC_FLUSH(inst);
     d2 wout;
+    if (p.unsolved && lane == 0 && ((give_up || fin != 0) ? st_in : 0) != 0)   // (rare: the redo is then launched at the next host sync)
+        __hip_atomic_fetch_add(p.unsolved, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (give_up) {  // keep the (feasible) ADMM iterate; status stays what ADMM reported
         wout[0] = skip ? z0 : fmin(fmax(z0, lo0), hi0);
         wout[1] = skip ? z1 : fmin(fmax(z1, lo1), hi1);

@@ -95,18 +95,26 @@ void almpc_default_opts(almpc_opts* opts);
 #define ALMPC_FLAG_TIMING 0x1u /* record HIP events around every kernel of almpc_calculate */
 /*
  * Structured (non-condensed) solve: the handle solves the multiple-shooting form the reference itself builds (states and inputs per
- * stage, dynamics as constraints: ..linear.jl:48-60) by a primal active-set method whose equality-constrained subproblems are
- * backward Riccati recursions (k_riccati) -- no condensed Hessian, so no m*N <= 128 limit and no loss of definiteness for open-loop
- * unstable models over long horizons.  Limits: n <= 32, m <= 16, m*N <= 1024.  Entry points of such a
- * handle: almpc_design_shared / almpc_design_batched (input box only: no state rows, no S; rho / sigma unused), almpc_set_reference,
- * almpc_update_initialization(_device), almpc_calculate(_async) (opts.polish_max_iter caps the working-set changes; <= 0: 20 m N + 50),
- * almpc_get_results (iters: 0, polish_iters: working-set changes), almpc_get_design (P only), almpc_comm_*.
+ * stage, dynamics as constraints: ..linear.jl:48-60) stage by stage -- no condensed Hessian, so no m*N <= 128 limit and no loss of
+ * definiteness for open-loop unstable models over long horizons.  Solver: k_sdual, a dual active-set
+ * method in constraint space whose Ghat columns are affine Riccati sweeps with the unconstrained feedback gains (the Riccati
+ * recursion runs once per model, a working-set change costs two O(N (n^2 + n m)) sweeps): input box, STATE BOX on every stage
+ * (..linear.jl:62-70), TERMINAL EQUALITY (src/sub/design_mpc.jl:330-331) and the INPUT-RATE WEIGHT S (src/sub/design_mpc.jl:423-446:
+ * the stage state is then [e_k; v_{k-1}]); working sets up to 128 rows; infeasible instances are reported as ALMPC_INFEASIBLE.
+ * Behind it, for an input box without S, k_riccati (primal active set with Riccati-recursion subproblems) takes the instances the dual
+ * method leaves without a certificate (a saturated open-loop unstable plant: Ghat_WW numerically singular).
+ * Limits: n + m <= 64 lanes (n <= 48 without S, n + m <= 48 with S; m <= 16), (N + 1)(n + m) doubles twice in 160 KB of LDS
+ * (quadrotor: N <= 255); shapes outside them but inside n <= 32, m <= 16, m*N <= 1024 run k_riccati alone (input box only).
+ * Entry points of such a handle: almpc_design_shared (xmin / xmax, almpc_set_terminal_equality, S honoured; rho / sigma unused),
+ * almpc_design_batched (+ almpc_set_state_box), almpc_sqp_fnn_* (every QP of the loop in its stage-wise form), almpc_set_reference,
+ * almpc_update_initialization(_device), almpc_calculate(_async) (opts.polish_max_iter caps the working-set changes; <= 0: 20 rows + 50),
+ * almpc_get_results (iters: 0, polish_iters: scans + steps of the dual method), almpc_get_design (P only), almpc_comm_*.
  */
 #define ALMPC_FLAG_STRUCTURED 0x2u
 
 /*
  * Create a solver for `batch` instances of an (n states, m inputs, horizon N) controller on HIP
- * device `device_id`.  Supported: 1 <= m*N <= 128, 1 <= n <= 64 (ALMPC_FLAG_STRUCTURED: m*N <= 1024, n <= 32, m <= 16).
+ * device `device_id`.  Supported: 1 <= m*N <= 128, 1 <= n <= 64 (ALMPC_FLAG_STRUCTURED: see there).
  */
 int almpc_create(almpc_handle** out, int n, int m, int N, int batch, int device_id, uint32_t flags);
 void almpc_destroy(almpc_handle* h);
@@ -127,7 +135,8 @@ const char* almpc_last_error(const almpc_handle* h);
  * Terminal constraint e_x[:,N+1] == 0 (mpc_terminal_ingredient = "equality", src/sub/design_mpc.jl:330-331):
  * call with 1 BEFORE almpc_design_shared.  Problems with state rows (state box and/or terminal equality) are
  * finished by a dual active-set method in constraint space (k_polish_gen, working sets up to 32 rows; instances beyond that are
- * redone by k_polish_gen64, up to 64 rows; beyond 64 the instance is reported as ALMPC_MAX_ITER); they require opts.polish = 1.
+ * redone by k_polish_gen64, up to 64 rows; what is still undecided goes to the stage-wise redo of almpc_set_structured_fallback,
+ * up to 128 rows); they require opts.polish = 1.
  */
 int almpc_set_terminal_equality(almpc_handle* h, int on);
 
@@ -149,13 +158,23 @@ int almpc_set_rho_profile(almpc_handle* h, int mode);
 int almpc_set_step_fusion(almpc_handle* h, int on);
 
 /*
- * Structured fallback of a condensed handle (call BEFORE the design; needs n <= 32, m <= 16, input box only, S = 0): after every
- * step the instances the condensed path left without a certificate (status != ALMPC_SOLVED: an active-set finish that ran into its
- * cap, a non-finite solve -- in practice per-instance linearisations that are open-loop unstable, whose condensed Hessian is
- * singular to working precision) are solved again in the multiple-shooting form by k_riccati, starting from the step's own result.
- * Instances that were solved are not touched.  With the SQP loop (almpc_sqp_fnn_*) the fallback solves the QP of an iteration in its
- * stage-wise form (time-varying models, defects) for the instances whose condensed Hessian came out indefinite to working precision,
- * instead of skipping them.
+ * Redo of the instances a condensed step leaves without a certificate (status != ALMPC_SOLVED: an active-set finish that ran into
+ * its cap or out of room, a non-finite or indefinite condensed problem -- in practice per-instance linearisations that are open-loop
+ * unstable, and state-row instances at the edge of feasibility) in the multiple-shooting form, by the stage-wise solvers of
+ * ALMPC_FLAG_STRUCTURED (k_sdual, then k_riccati for an input box without S), starting from the step's own result.  Instances that
+ * were solved are not touched; an infeasible state-row instance comes back as ALMPC_INFEASIBLE.
+ *   DEFAULT: ON wherever those solvers cover the design (shape limits of ALMPC_FLAG_STRUCTURED), for every design of a condensed
+ *   handle: shared (incl. state rows, terminal equality, S), per instance, re-linearisation pipeline, SQP loop (the QP of an iteration
+ *   in its stage-wise form for the instances whose condensed Hessian came out indefinite, instead of skipping them).
+ *     - per-instance / state-row / re-linearisation / SQP steps: the redo kernels are enqueued behind every step.
+ *     - shared model with an input box only (the headline path, tens of microseconds per step, unsolved instances only in corner
+ *       cases): LAZILY -- the finish counts unsolved instances into a host-visible word and the redo runs at the next point where
+ *       the host looks at results through a synchronous call (almpc_calculate, almpc_synchronize, almpc_get_results,
+ *       almpc_get_first_input): no launch on the step path (two idle redo launches would cost 14 us of a 61 us step).  A caller that
+ *       reads results only through the asynchronous tickets, or consumes them on the device (almpc_advance_plant loops), asks for the
+ *       eager form with on = 1.
+ *   on = 1: required (a design the stage-wise solvers cannot serve is an error) and always eager;  on = 0: off.
+ * Call BEFORE the design.
  */
 int almpc_set_structured_fallback(almpc_handle* h, int on);
 
@@ -178,7 +197,8 @@ int almpc_set_start_from(almpc_handle* h, almpc_handle* src);
  * almpc_set_terminal_equality these designs then build one constraint-space matrix per instance (k_ghat_inst) and the step's exact
  * finish is the dual active-set kernel of the shared-model state rows with per-instance operands.  Time-varying designs and the SQP
  * loop: the box is on xbar + dx, the terminal equality reads xbar + dx = x_ref at stage N+1; an SQP iteration whose QP is infeasible
- * is skipped for that instance (almpc_sqp_fnn_skipped) -- there is no elastic mode.  The structured solve has no state rows.
+ * is skipped for that instance (almpc_sqp_fnn_skipped) -- there is no elastic mode.  Structured handles (ALMPC_FLAG_STRUCTURED) take the
+ * same calls: there the rows are coordinates of the stage-wise trajectory (k_sdual), no constraint-space matrix is built.
  */
 int almpc_set_state_box(almpc_handle* h, const double* xmin, const double* xmax);
 
@@ -267,10 +287,10 @@ int almpc_sqp_fnn_set_step_rule(almpc_handle* h, int rule);
 
 /*
  * QP solver of the SQP loop (call before almpc_sqp_fnn_setup): 0 (default) the condensed path -- k_design_ltv, per-instance factors,
- * the step kernels --, 1 the stage-wise form for EVERY instance and iteration: k_riccati on (A_k, B_k, c_k), started from the
- * iterate's own working set (v = 0).  No Hessian is formed or inverted; with the short state vectors of the Fnn models an iteration
- * is a few backward sweeps per instance.  Same QP, same optimum (parity: oracle sqp_fnn(structured=True)).  Needs n <= 32, m <= 16,
- * no input-rate weight, no state rows.
+ * the step kernels --, 1 the stage-wise form for EVERY instance and iteration: k_sgains (Riccati recursion of the iteration's
+ * unconstrained QP on (A_k, B_k, c_k)) + k_sdual, started from the iterate's own working set (v = 0).  No Hessian is formed or
+ * inverted.  Same QP, same optimum (parity: oracle sqp_fnn(structured="dual")); takes the state box, the terminal equality and the
+ * input-rate weight as the condensed route does.  Shape limits of ALMPC_FLAG_STRUCTURED.
  */
 int almpc_sqp_fnn_set_structured(almpc_handle* h, int on);
 

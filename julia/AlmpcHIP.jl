@@ -14,7 +14,7 @@ export hip_solver_def, HipModeler, AlmpcOpts, design_hip, terminal_weight, set_s
        calculate_async!, synchronize!, relin_step_async!, advance_plant!, start_from!, update_initialization_device!, device_results, set_step_fusion!,
        set_structured_fallback!, sqp_skipped, design_instance, gradient_instance, design_ltv!, fnn_linearize, dare, default_opts,
        get_timing, timing_reset!, timing_set_stride!, timing_summary, timing_samples, relin_timing, debug_poison_lds!,
-       update_initialization_async!, results_async, results_wait!, host_results, first_input, first_input!,
+       update_initialization_async!, x0_staging, results_async, results_wait!, host_results, first_input, first_input!, ALLOW_UNSOLVED,
        HipGroup, group_design_hip, group_handle, group_shard, group_update_initialization!, group_calculate!, group_calculate_async!,
        group_synchronize!, group_read_results!
 
@@ -199,10 +199,20 @@ function check_result_sizes(mod::HipModeler, x, e_x, u, e_u)
     end
 end
 
-function throw_on_status(status)
-    # the reference never checks the solver status and lets JuMP.value throw when there is no primal (src/main/computation_mpc.jl:41-53)
+# What a per-instance status means to a caller of the reference's API.  The reference never checks the solver status and lets
+# JuMP.value throw when there is no primal (src/main/computation_mpc.jl:41-53): it returns a solution or throws.  Here:
+#   2 (non-finite) and 3 (infeasible: state box / terminal equality)  -> error, as JuMP.value would;
+#   1 (no certificate: an iteration cap or a working set beyond 128 rows, after the stage-wise redo that libalmpc runs by default,
+#      include/almpc.h almpc_set_structured_fallback)                  -> error as well, unless ALLOW_UNSOLVED[] is set: the arrays then hold
+#      the best iterate (inputs inside their box, trajectory consistent with them) and the status vector says which instances.
+#      With the exact finish switched off (opts.polish = 0) status 1 is OSQP's ITERATION_LIMIT, with which JuMP.value still returns: no error.
+const ALLOW_UNSOLVED = Ref(false)
+function throw_on_status(status; strict::Bool = true)
     any(==(2), status) && error("calculate!: non-finite values in at least one instance (no solution to read)")
     any(==(3), status) && error("calculate!: infeasible problem in at least one instance (state box / terminal equality)")
+    if strict && !ALLOW_UNSOLVED[] && any(==(1), status)
+        error("calculate!: $(count(==(1), status)) instance(s) without an optimality certificate (set AlmpcHIP.ALLOW_UNSOLVED[] = true to read the iterate)")
+    end
     return status
 end
 
@@ -222,7 +232,7 @@ function calculate!(mod::HipModeler, x::Array{Float64}, e_x::Array{Float64}, u::
             sqp_start!(mod, mod.x0)
             sqp_iterate!(mod, mod.sqp_iterations)
         end
-        return throw_on_status(read_results!(mod, x, e_x, u, e_u))
+        return throw_on_status(read_results!(mod, x, e_x, u, e_u); strict = mod.opts.polish != 0)
     end
     if first_move_only
         check(mod.handle, ccall((:almpc_calculate_async, libalmpc), Cint, (Ptr{Cvoid}, Ref{AlmpcOpts}), mod.handle, o))
@@ -580,7 +590,11 @@ end
 # the name BASELINE.json uses; absent from the reference (SURVEY.md section 0): one batched step, host in / host out
 function _model_predictive_control_computation(mod::HipModeler, X0::Matrix{Float64}, x, e_x, u, e_u; first_move_only::Bool = false)
     check_result_sizes(mod, x, e_x, u, e_u)
-    update_initialization_async!(mod, X0)
+    if mod.mode === :sqp
+        update_initialization!(mod, X0)      # the SQP loop restarts from mod.x0 (almpc_sqp_fnn_start), which only this method stores
+    else
+        update_initialization_async!(mod, X0)
+    end
     calculate!(mod, x, e_x, u, e_u; first_move_only = first_move_only)
 end
 function _model_predictive_control_computation(g::HipGroup, X0::Matrix{Float64}, x, e_x, u, e_u)

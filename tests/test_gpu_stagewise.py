@@ -146,3 +146,34 @@ def test_working_sets_beyond_the_first_tier(capi, mo, so):
         nact = int(((e["u"] >= p.u_max[:, None] - 1e-12) | (e["u"] <= p.u_min[:, None] + 1e-12)).sum())
         big += nact > 32
     assert big >= 1
+
+
+def test_default_redo_on_the_shared_condensed_path_is_lazy_and_complete(capi, mo):
+    """Condensed handle, shared model, input box only (the headline path).  A finish capped at two working-set changes leaves the
+    saturated instances with ALMPC_MAX_ITER; by default (almpc_set_structured_fallback: auto) the stage-wise solvers redo them when
+    the host looks at the results -- no launch on the step path --, switched off they stay as the finish left them."""
+    p = mo.quadrotor(30)
+    X0 = mo.quadrotor_x0_batch(256, 3.0)
+    opts = capi.default_opts(polish_max_iter=2)
+    out = {}
+    for fb in (False, None, True):
+        s = capi.Solver(12, 4, 30, len(X0), structured_fallback=fb)
+        s.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max)
+        s.update_initialization(X0)
+        s.calculate(opts)
+        out[fb] = s.get_results()
+        if fb is None:   # asynchronous step + synchronous getter: settled there
+            s.update_initialization(0.9 * X0)
+            s.calculate(opts, sync=False)
+            u0 = s.get_first_input()
+            r2 = s.get_results()
+            assert np.all(r2["status"] == 0) and np.array_equal(u0, r2["u"][:, :, 0])
+        s.close()
+    assert (out[False]["status"] == 1).sum() >= 50
+    for fb in (None, True):
+        assert np.all(out[fb]["status"] == 0)
+    assert np.array_equal(out[None]["u"], out[True]["u"])
+    done = out[False]["status"] == 0
+    assert np.array_equal(out[False]["u"][done], out[None]["u"][done])     # solved instances are not touched
+    for i in np.flatnonzero(~done)[:12]:
+        assert np.abs(out[None]["u"][i] - mo.solve_mpc_exact(p, X0[i])["u"]).max() <= U_TOL
