@@ -732,7 +732,10 @@ int resolve_lazy_redo(almpc_handle* h) {
     const int cur = *reinterpret_cast<volatile int*>(h->hUnsolved);
     if (cur == h->unsolved_seen) return ALMPC_OK;
     h->unsolved_seen = cur;
-    if (h->sd.ready) HIP_TRY(h, launch_sdual(h, 1, h->dU, 0, true));
+    if (h->sd.ready) {
+        if (h->relin.ready) HIP_TRY(h, launch_sgains(h, 1));   // (the last step's linearisations are still in the model slots)
+        HIP_TRY(h, launch_sdual(h, 1, h->dU, 0, true));
+    }
     if (h->mc == 0 && !h->useS && h->rKst) HIP_TRY(h, launch_riccati(h, 1, h->dU, 0));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return ALMPC_OK;
@@ -2263,7 +2266,9 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
     if (o.warm_start && !h->state_valid)
         return fail(h, ALMPC_ERR_INVALID, "calculate: warm_start = 1, but the previous step ran with ALMPC_OPT_NO_WARM_STATE (no ADMM state was kept)");
     // default redo of unsolved instances on the shared-model / input-box-only path: lazily, at the next host sync (see hUnsolved)
-    const bool lazy_redo = h->fallback == 2 && !h->structured && !h->batched && !h->ltv && h->mc == 0 && o.polish != 0 &&
+    // (every box-only condensed path ends in the same finish, polish_body, which does the counting: shared model, per-instance models,
+    // re-linearisation pipeline; with state rows unsolved / infeasible instances are common and the steps long: eager there)
+    const bool lazy_redo = h->fallback == 2 && !h->structured && !h->ltv && h->mc == 0 && o.polish != 0 &&
                            (h->sd.ready || h->rKst) && !getenv("ALMPC_EAGER_REDO");
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->io.big_copy_pending) {   // an asynchronous read-back straight from the result buffers: this step overwrites them

@@ -305,7 +305,7 @@ def main():
     ap.add_argument("--no-closed-loop", action="store_true")
     ap.add_argument("--no-batched-models", action="store_true", help="skip the secondary per-instance-model figure")
     ap.add_argument("--no-sqp", action="store_true", help="skip the secondary SQP (BASELINE configs[4]) figure")
-    ap.add_argument("--no-structured", action="store_true", help="skip the secondary structured-solve (N = 50) figure")
+    ap.add_argument("--no-structured", action="store_true", help="skip the secondary structured-solve (N = 50) figures")
     ap.add_argument("--no-relin", action="store_true", help="skip the secondary per-step re-linearisation (BASELINE configs[3]) figure")
     ap.add_argument("--no-api-path", action="store_true", help="skip the host-in / host-out figures (api_path_first_move, api_path_full)")
     ap.add_argument("--single-process", action="store_true",
@@ -422,6 +422,12 @@ def main():
     tsum = solver.timing_summary()
     tsamp = solver.timing_samples()["polish_ms"]   # the event pairs around k_step_fused inside the timed region, one per sampled step
     res = solver.get_results(want=("u", "status", "iters", "polish_iters"))
+    # more event pairs around the same kernel right after the timed region (same workload, every 2nd of 64 steps): the roofline's kernel
+    # time is the MEDIAN of all pairs -- four samples of a 20-step run are too few, and their mean once came out above the step itself
+    solver.timing_set_stride(2)
+    solver.timing_reset(64)
+    time_steps(solver, opts, 64, barrier)
+    tsamp_after = solver.timing_samples()["polish_ms"]
     # The headline step is ONE kernel (k_step_fused: ADMM phase + polish of the same tile).  Its two phases are timed apart on
     # the two-kernel path of the same build (almpc_set_step_fusion(0): k_admm, k_polish<true>), outside the timed region.
     solver.set_step_fusion(False)
@@ -485,11 +491,16 @@ def main():
         # kernels run on).  Two kernels per step: k_admm (FP64 MFMA bound) and k_polish (+ fused rollout; dependent
         # chains per instance, its only hardware roofline is HBM).  `roofline` is the one that took more time.
         # k_step_fused: the event pair right before / right after the kernel (the "polish" slot of the fused path), every 16th timed step
-        fused_ms = tsum["polish_ms"] / max(1, tsum["steps"])
+        tall = np.concatenate([np.asarray(tsamp, dtype=np.float64), np.asarray(tsamp_after, dtype=np.float64)])
+        fused_ms = float(np.median(tall)) if len(tall) else tsum["polish_ms"] / max(1, tsum["steps"])
+        kernel_time_source = "hip_events_median"
+        if fused_ms > 1e3 * elapsed / args.steps:   # a kernel cannot take longer than the step it is: event overhead / noise
+            fused_ms = 1e3 * elapsed / args.steps
+            kernel_time_source = "ms_per_step"
         stage_ms = {k: tsum2[k] / max(1, tsum2["steps"]) for k in ("admm_ms", "polish_ms", "rollout_ms", "total_ms")}
         iters_total = int(res["iters"].astype(np.int64).sum())
         traffic, traffic_src = {}, None
-        for nm in ("r3_hbm_traffic.json", "r2_hbm_traffic.json"):
+        for nm in ("r4_hbm_traffic.json", "r3_hbm_traffic.json", "r2_hbm_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", nm)) as f:
                     traffic = json.load(f)
@@ -522,11 +533,14 @@ def main():
                       "achieved": flops / (fused_ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                       "frac": flops / (fused_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                       "traffic": traffic.get("k_step_fused", {}).get("hbm_bytes_per_launch"), "traffic_source": traffic_src,
-                      "avg_kernel_ms": fused_ms,
-                      "kernel_ms_samples": {"n": int(len(tsamp)), "min": float(tsamp.min()) if len(tsamp) else None,
-                                            "median": float(np.median(tsamp)) if len(tsamp) else None,
-                                            "max": float(tsamp.max()) if len(tsamp) else None,
-                                            "note": f"HIP event pairs around the kernel on every {TIMING_STRIDE}th timed step (avg_kernel_ms = their mean)"},
+                      "avg_kernel_ms": fused_ms, "kernel_time_source": kernel_time_source,
+                      "kernel_ms_samples": {"n": int(len(tall)), "n_in_timed_region": int(len(tsamp)),
+                                            "min": float(tall.min()) if len(tall) else None,
+                                            "median": float(np.median(tall)) if len(tall) else None,
+                                            "max": float(tall.max()) if len(tall) else None,
+                                            "in_timed_region": [float(v) for v in tsamp],
+                                            "note": f"HIP event pairs around the kernel: every {TIMING_STRIDE}th step of the timed region + every 2nd of 64 "
+                                                    "steps right after it; avg_kernel_ms = the median of all pairs, capped by ms_per_step"},
                       "hbm_achieved_GBps": BATCH_PER_GPU * ALG_BYTES_PER_INSTANCE_STEP / (fused_ms * 1e-3) / 1e9,
                       "note": "FP64 MFMA is the only unit this kernel can saturate: the ADMM phase runs at roofline_kernels[0].frac of it, the "
                               "polish phase is a latency-bound dependent chain per instance (roofline_kernels[1]); phases timed on the "
@@ -777,9 +791,9 @@ def main():
         s3.close()
 
     if rank == 0 and world == 1 and not args.no_structured:
-        # Secondary figure: the structured (non-condensed) solve, k_riccati -- the benchmark plant over a horizon the condensed kernels
-        # cannot take (N = 50: m N = 200 > 128), 4096 instances, mixed amplitudes.  Correctness path (one wave per instance, a full
-        # Riccati sweep per working-set change): the figure says what it costs, not that it is tuned.
+        # Secondary figure: the structured (non-condensed) solve -- the benchmark plant over a horizon the condensed kernels cannot take
+        # (N = 50: m N = 200 > 128), 4096 instances, mixed amplitudes.  k_sdual: dual active set in constraint space whose Ghat columns
+        # are affine Riccati sweeps with the unconstrained gains (one wave per instance, two sweeps per working-set change).
         Ns = 50
         ps = wl.quadrotor(Ns)
         ss = capi.Solver(NX, NU, Ns, BATCH_PER_GPU, device=dev_index, structured=True)
@@ -787,13 +801,18 @@ def main():
         ss.set_reference(ps.x_ref, ps.u_ref)
         ss.update_initialization(X0)
         ss.calculate()
-        ks, bests = 5, float("inf")
-        for _rep in range(3):
-            t0 = time.perf_counter()
-            for _ in range(ks):
-                ss.calculate(sync=False)
-            ss.synchronize()
-            bests = min(bests, time.perf_counter() - t0)
+
+        def time_structured(sv, ks=5):
+            best = float("inf")
+            for _rep in range(3):
+                t0 = time.perf_counter()
+                for _ in range(ks):
+                    sv.calculate(sync=False)
+                sv.synchronize()
+                best = min(best, time.perf_counter() - t0)
+            return best / ks
+        bests = time_structured(ss)
+        ks = 1
         rs = ss.get_results(want=("status", "polish_iters", "u"))
         # horizon continuation (almpc_set_start_from): the condensed N = 30 step (the headline kernel) hands the N = 50 stage-wise solve
         # its working set; one "step" = both solves, from a cold start
@@ -805,19 +824,46 @@ def main():
                 solver.calculate(opts, sync=False)
                 ss.start_from(solver)
                 ss.calculate(sync=False)
-                ss.synchronize()    # (one step at a time: the next condensed step does not run under this step's k_riccati on the other stream)
+                ss.synchronize()    # (one step at a time: the next condensed step does not run under this step's solve on the other stream)
             bestc = min(bestc, time.perf_counter() - t0)
         rcn = ss.get_results(want=("status", "polish_iters", "u"))
         import mpc_oracle as mo
         pso = mo.make_problem(ps.A, ps.B, Ns, ps.u_min, ps.u_max)
         errs = max(float(np.abs(rs["u"][i] - mo.solve_mpc_exact(pso, X0[i])["u"]).max()) for i in range(0, 96, 8))
         errc = max(float(np.abs(rcn["u"][i] - mo.solve_mpc_exact(pso, X0[i])["u"]).max()) for i in range(0, 96, 8))
-        # k_riccati, algorithmic flops: per instance and backward stage ~ 2 (3 n^3 + 3 n^2 m + 2 n m^2) + m^3, forward ~ 2 n (n + 2 m); a solve
-        # with c changes sweeps (1 + c) times at most (partial sweeps: fewer) -- stated with c = the measured mean
-        fl_stage = 2.0 * (3 * NX ** 3 + 3 * NX * NX * NU + 2 * NX * NU * NU) + NU ** 3 + 2.0 * NX * (NX + 2 * NU)
-        sweeps = 1.0 + float(rcn["polish_iters"].mean())
-        fl = BATCH_PER_GPU * Ns * fl_stage * sweeps
-        out["structured_N50"] = {"value": ks / bests, "unit": "batch-steps/s (4096 instances, quadrotor nx=12 nu=4, N=50, Riccati active-set solve)",
+        # the rows the reference's stage-wise form carries beyond the input box: state box on every stage (..linear.jl:62-70), terminal
+        # equality (src/sub/design_mpc.jl:330-331), input-rate weight (src/sub/design_mpc.jl:423-446) -- same batch, same horizon
+        xbox = np.array([3, 3, 3, 1.5, 1.5, 1.5, 0.3, 0.3, 0.3, 1.0, 1.0, 1.0])
+        rows_out = {}
+        for name, kwd in (("state_box", dict(xmin=-xbox, xmax=xbox)), ("terminal_equality", dict(terminal="equality")),
+                          ("input_rate_weight_S5", dict(S=5.0 * np.eye(NU)))):
+            sv = capi.Solver(NX, NU, Ns, BATCH_PER_GPU, device=dev_index, structured=True)
+            sv.design_shared(ps.A, ps.B, ps.Q, ps.R, kwd.get("S", ps.S), None, ps.u_min, ps.u_max, xmin=kwd.get("xmin"), xmax=kwd.get("xmax"),
+                             terminal=kwd.get("terminal", "none"))
+            sv.set_reference(ps.x_ref, ps.u_ref)
+            Xv = np.clip(X0, -0.99 * xbox, 0.99 * xbox) if "xmin" in kwd else X0
+            sv.update_initialization(Xv)
+            sv.calculate()
+            tv = time_structured(sv, 3)
+            rv = sv.get_results(want=("status", "polish_iters", "u"))
+            pv = mo.make_problem(ps.A, ps.B, Ns, ps.u_min, ps.u_max, x_min=kwd.get("xmin"), x_max=kwd.get("xmax"), terminal=kwd.get("terminal", "none"),
+                                 s=5.0 if "S" in kwd else 0.0)
+            ev, ninf = 0.0, 0
+            for i in range(0, 96, 12):
+                try:
+                    ev = max(ev, float(np.abs(rv["u"][i] - mo.solve_mpc_exact(pv, Xv[i])["u"]).max()))
+                except ValueError:   # infeasible by the oracle: the kernel must say so too
+                    ninf += 1
+                    ev = max(ev, 0.0 if rv["status"][i] == 3 else float("inf"))
+            rows_out[name] = {"ms_per_step": 1e3 * tv, "status_counts": np.bincount(rv["status"], minlength=4).tolist(),
+                              "working_set_changes_mean": float(rv["polish_iters"].mean()), "working_set_changes_max": int(rv["polish_iters"].max()),
+                              "u_err_inf_sampled": ev, "sampled_infeasible_agree": ninf}
+            sv.close()
+        # k_sdual, algorithmic flops: a sweep is N stages x (backward + forward) x (n + m)^2 multiply-adds; an instance with c scan / step
+        # iterations sweeps about 2 + 2 c times (unconstrained solution, confirmation, response + direction per change)
+        fl_sweep = Ns * 2 * 2.0 * (NX + NU) ** 2
+        fl = BATCH_PER_GPU * fl_sweep * (2.0 + 2.0 * float(rs["polish_iters"].mean()))
+        out["structured_N50"] = {"value": ks / bests, "unit": "batch-steps/s (4096 instances, quadrotor nx=12 nu=4, N=50, stage-wise dual active-set solve)",
                                  "ms_per_step": 1e3 * bests / ks, "status_counts": np.bincount(rs["status"], minlength=3).tolist(),
                                  "working_set_changes_mean": float(rs["polish_iters"].mean()), "working_set_changes_max": int(rs["polish_iters"].max()),
                                  "u_err_inf_sampled": errs,
@@ -826,11 +872,12 @@ def main():
                                                         "working_set_changes_mean": float(rcn["polish_iters"].mean()),
                                                         "working_set_changes_max": int(rcn["polish_iters"].max()), "u_err_inf_sampled": errc,
                                                         "note": "one step = the condensed N = 30 step + almpc_set_start_from + the N = 50 stage-wise solve"},
-                                 "roofline": {"bound": "mfma", "kernel": "k_riccati_t<12,4> (FP64 vector pipeline: same 78.6 TFLOP/s peak as the matrix cores)", "achieved": fl / (bestc / kc) / 1e12, "peak": FP64_PEAK_TFLOPS,
-                                              "unit": "TFLOP/s", "frac": fl / (bestc / kc) / 1e12 / FP64_PEAK_TFLOPS,
-                                              "note": "one wave per instance, every product of a stage an LDS-resident 12 x 12 / 12 x 4 loop: bound by the "
-                                                      "dependent chain of N backward stages (~16 k cycles each), not by a throughput roofline; flops = "
-                                                      "N stages x (1 + mean changes) sweeps x the per-stage count of DESIGN.md"}}
+                                 "with_rows": rows_out,
+                                 "roofline": {"bound": "mfma", "kernel": "k_sdual<12,4,1> (FP64 vector pipeline: same 78.6 TFLOP/s peak as the matrix cores)", "achieved": fl / bests / 1e12, "peak": FP64_PEAK_TFLOPS,
+                                              "unit": "TFLOP/s", "frac": fl / bests / 1e12 / FP64_PEAK_TFLOPS,
+                                              "note": "one wave per instance, a stage of a sweep = 16 DPP-broadcast FMAs on a row of 16 lanes (~330 cycles measured with two "
+                                                      "waves per SIMD): a dependent chain of N stages per sweep and two sweeps per working-set change -- latency bound, the "
+                                                      "launch ends with its slowest instance (max changes); flops = sweeps x N x 4 (n + m)^2"}}
         ss.close()
 
     if rank == 0 and world == 1 and not args.no_sqp:
