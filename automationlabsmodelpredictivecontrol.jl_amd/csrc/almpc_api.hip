@@ -456,7 +456,7 @@ bool sdual_pick_shape(int nt, int m, int* NT, int* MC) {
         if (nt <= s[0] && m <= s[1]) { *NT = s[0]; *MC = s[1]; return true; }
     return false;
 }
-constexpr int SD_WCAP1 = 32, SD_WCAP2 = 64, SD_WCAP3 = 128;   // working-set capacity of the first launch / of the redos of the instances that outgrew it
+constexpr int SD_WCAP1 = 32, SD_WCAP2 = 64, SD_WCAP3 = 96, SD_WCAP4 = 128;   // working-set capacity of the first launch / of the redos of the instances that outgrew it
 bool sdual_shape_ok(int n, int m, int N, bool useS) {
     int NT = 0, MC = 0;
     if (!sdual_pick_shape(useS ? n + m : n, m, &NT, &MC)) return false;
@@ -638,14 +638,18 @@ hipError_t launch_sgains(almpc_handle* h, int filter) {
 
 template <int NT, int MC>
 hipError_t launch_sdual_t(almpc_handle* h, SdualParams sp, int tier0, int tier1) {
-    // first launch: every (filtered) instance with room for SD_WCAP1 rows; second: the instances that outgrew it, with SD_WCAP2;
-    // third: SD_WCAP3 rows, two working-set positions per lane, Sinv in a global scratch (rare: mostly infeasible instances whose
-    // verdict needs that many rows)
+    // tier 0: every (filtered) instance with room for SD_WCAP1 rows (several waves per workgroup); tier 1: the instances that outgrew it,
+    // SD_WCAP2 rows; tier 2: SD_WCAP4 rows, two working-set positions per lane (mostly infeasible instances whose verdict needs that
+    // many rows); tier 3: the same with Sinv in a global scratch, for shapes whose trajectories leave no room for it in LDS.
     // (tier0 = tier1 = 1: ONE launch with room for SD_WCAP2 rows -- the redo of the few instances a condensed step left unsolved)
     for (int tier = tier0; tier <= tier1; ++tier) {
-        sp.wcap = tier == 0 ? SD_WCAP1 : (tier == 1 ? SD_WCAP2 : SD_WCAP3);
+        sp.wcap = tier == 0 ? SD_WCAP1 : (tier == 1 ? SD_WCAP2 : SD_WCAP4);
         sp.only_ovf = tier > tier0;
-        sp.lds_per_wave = sdual_lds_doubles(NT, MC, sp.N, sp.wcap, tier < 2);
+        bool glb = tier == 3;
+        const bool fits128 = (size_t)sdual_lds_doubles(NT, MC, sp.N, SD_WCAP4, true) * sizeof(double) <= 160 * 1024;
+        if (tier == 2 && !fits128) continue;   // (Sinv of 128 rows does not fit beside the trajectories: the global-scratch build)
+        if (tier == 3 && fits128) continue;
+        sp.lds_per_wave = sdual_lds_doubles(NT, MC, sp.N, sp.wcap, !glb);
         const size_t per = (size_t)sp.lds_per_wave * sizeof(double);
         int waves = SDUAL_WAVES;
         while (waves > 1 && per * waves > 160 * 1024) --waves;
@@ -657,15 +661,19 @@ hipError_t launch_sdual_t(almpc_handle* h, SdualParams sp, int tier0, int tier1)
         if (per_cu * waves > 8) per_cu = 8 / waves > 0 ? 8 / waves : 1;
         int wgs = (sp.batch + waves - 1) / waves;
         int cap = h->num_cus * per_cu;
-        if (tier == 2) cap = h->num_cus;
+        if (glb) cap = h->num_cus;
         if (wgs > cap) wgs = cap;
         hipError_t e;
         if (tier < 2) {
-            e = ensure_dyn_lds(reinterpret_cast<const void*>(k_sdual<NT, MC, 1>), lds);
+            e = ensure_dyn_lds(reinterpret_cast<const void*>(k_sdual<NT, MC, 1, false>), lds);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((k_sdual<NT, MC, 1>), dim3(wgs), dim3(64 * waves), lds, h->stream, sp);
+            hipLaunchKernelGGL((k_sdual<NT, MC, 1, false>), dim3(wgs), dim3(64 * waves), lds, h->stream, sp);
+        } else if (!glb) {
+            e = ensure_dyn_lds(reinterpret_cast<const void*>(k_sdual<NT, MC, 2, false>), lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((k_sdual<NT, MC, 2, false>), dim3(wgs), dim3(64 * waves), lds, h->stream, sp);
         } else {
-            const size_t need = (size_t)wgs * waves * SD_WCAP3 * (SD_WCAP3 + 1);
+            const size_t need = (size_t)wgs * waves * sdual_sinv_doubles(SD_WCAP4);
             if (h->sd.sinv_cap < need) {
                 if (h->sd.sinv_glb) { (void)hipFree(h->sd.sinv_glb); h->sd.sinv_glb = nullptr; h->sd.sinv_cap = 0; }
                 e = dalloc(&h->sd.sinv_glb, need);
@@ -673,9 +681,9 @@ hipError_t launch_sdual_t(almpc_handle* h, SdualParams sp, int tier0, int tier1)
                 h->sd.sinv_cap = need;
             }
             sp.sinv_glb = h->sd.sinv_glb;
-            e = ensure_dyn_lds(reinterpret_cast<const void*>(k_sdual<NT, MC, 2>), lds);
+            e = ensure_dyn_lds(reinterpret_cast<const void*>(k_sdual<NT, MC, 2, true>), lds);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((k_sdual<NT, MC, 2>), dim3(wgs), dim3(64 * waves), lds, h->stream, sp);
+            hipLaunchKernelGGL((k_sdual<NT, MC, 2, true>), dim3(wgs), dim3(64 * waves), lds, h->stream, sp);
         }
         e = hipGetLastError();
         if (e != hipSuccess) return e;
@@ -716,7 +724,7 @@ hipError_t launch_sdual(almpc_handle* h, int filter, const double* guess, int ma
     const int rows = h->N * h->m + ((sd.has_box || sd.has_eq) ? h->N * h->n : 0);
     sp.max_iter = max_iter > 0 ? max_iter : 20 * rows + 50;
     sp.tol = 1e-9;
-    const int tier0 = single_launch ? 1 : 0, tier1 = single_launch ? 1 : 2;
+    const int tier0 = single_launch ? 1 : 0, tier1 = single_launch ? 1 : 3;
 #define SD_CASE(NT_, MC_) if (sd.NT == NT_ && sd.MC == MC_) return launch_sdual_t<NT_, MC_>(h, sp, tier0, tier1)
     SD_CASE(2, 2); SD_CASE(4, 2); SD_CASE(6, 2); SD_CASE(8, 4); SD_CASE(12, 4); SD_CASE(16, 4); SD_CASE(16, 8); SD_CASE(32, 16); SD_CASE(48, 16);
 #undef SD_CASE

@@ -59,9 +59,10 @@ struct SdualParams {
 };
 
 __host__ __device__ inline int sdual_tp(int NT, int MC, int N) { return (N * (NT + MC) + NT + 1) & ~1; }
+__host__ __device__ inline int sdual_sinv_doubles(int wcap) { return (wcap * (wcap + 1) / 2 + 1) & ~1; }   // packed lower triangle
 __host__ __device__ inline int sdual_lds_doubles(int NT, int MC, int N, int wcap, bool sinv_in_lds = true) {
-    // s, w: 2 TP | Sinv: wcap (wcap + 1) (first two tiers) | gbuf NT | cbuf, ubuf: 2 wcap | slist: 128 ints | blo, bhi: 2 (NT + MC) | beq: NT
-    return (2 * sdual_tp(NT, MC, N) + (sinv_in_lds ? wcap * (wcap + 1) : 0) + NT + 2 * wcap + 64 + 2 * (NT + MC) + NT + 4 + 1) & ~1;
+    // s, w: 2 TP | Sinv: wcap (wcap + 1) / 2 (packed lower triangle; not in the global-scratch build) | gbuf NT | cbuf, ubuf: 2 wcap | slist: 128 ints | blo, bhi: 2 (NT + MC) | beq: NT
+    return (2 * sdual_tp(NT, MC, N) + (sinv_in_lds ? sdual_sinv_doubles(wcap) : 0) + NT + 2 * wcap + 64 + 2 * (NT + MC) + NT + 4 + 1) & ~1;
 }
 __host__ __device__ inline int sdual_rec_row(int NT, int MC) { return 2 * NT + 2 * MC; }
 __host__ __device__ inline int sdual_rec_stage(int NT, int MC) { return (NT + MC) * sdual_rec_row(NT, MC); }
@@ -135,15 +136,15 @@ __device__ __forceinline__ void sd_dot_bcast(double& acc0, double& acc1, double 
 #define SD_ACC(S)
 #endif
 
-// <NT, MC>: padded stage-state / input dimensions; PPL: working-set positions per lane -- 1: up to 64 rows, Sinv in LDS; 2: up to
-// 128 rows, Sinv in a global scratch (the third tier: rare instances, mostly infeasible ones whose verdict needs that many rows).
-template <int NT, int MC, int PPL>
+// <NT, MC>: padded stage-state / input dimensions; PPL: working-set positions per lane (1: up to 64 rows, 2: up to 128); GLB: Sinv in
+// a global scratch instead of LDS (the last tier: rare instances, mostly infeasible ones whose verdict needs that many rows).
+template <int NT, int MC, int PPL, bool GLB>
 __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
     static_assert((NT % 2) == 0 && (MC % 2) == 0, "even dimensions (16-byte loads)");
     static_assert(PPL == 1 || PPL == 2, "one or two working-set positions per lane");
     constexpr int SP = NT + MC;          // coordinates per stage: state slot [0, NT), input slot [NT, NT + MC)
     constexpr int RL = 2 * NT + 2 * MC;  // doubles per record row
-    constexpr bool BIG = PPL == 2;
+    constexpr bool BIG = GLB;
     constexpr bool ROWDPP = SP <= 16;    // a stage fits one row of 16 lanes: DPP broadcasts instead of LDS round trips
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int wv = threadIdx.x >> 6, lane0 = threadIdx.x & 63;
@@ -152,8 +153,8 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
     double* L = smem + (size_t)wv * p.lds_per_wave;
     double* sA = L;
     double* sB = sA + TP;
-    double* SinvL = sB + TP;                   // [wcap][LD] (PPL = 1)
-    double* gbuf = SinvL + (BIG ? 0 : wcap * LD + (wcap * LD & 1));
+    double* SinvL = sB + TP;                   // packed lower triangle of wcap rows
+    double* gbuf = SinvL + (BIG ? 0 : sdual_sinv_doubles(wcap));
     double* cbuf = gbuf + NT;
     double* ubuf = cbuf + wcap;
     int* slist = reinterpret_cast<int*>(ubuf + wcap);   // [SDUAL_WSAVE] start list
@@ -161,15 +162,18 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
     double* bhi = blo + SP;
     double* beq = bhi + SP;           // [NT] terminal-equality target for x_N
     const int wpb = (int)(blockDim.x >> 6);
-    double* SinvG = BIG ? p.sinv_glb + (size_t)(blockIdx.x * wpb + wv) * wcap * LD : nullptr;
-    // Sinv element access: LDS (in-order within the wave), or the global scratch read back past the L1 (written by other lanes)
+    double* SinvG = BIG ? p.sinv_glb + (size_t)(blockIdx.x * wpb + wv) * sdual_sinv_doubles(wcap) : nullptr;
+    // Sinv is symmetric: stored as its packed lower triangle (row i = i + 1 entries at i (i + 1) / 2) -- 128 rows are 66 KB instead of
+    // 132 KB, so that every tier keeps it in LDS beside the trajectories.  Element access: LDS (in-order within the wave), or the
+    // global scratch read back past the L1 (written by other lanes).
+    auto sidx = [&](int i, int j) { return i >= j ? (i * (i + 1) >> 1) + j : (j * (j + 1) >> 1) + i; };
     auto sld = [&](int i, int j) -> double {
-        if constexpr (BIG) return __hip_atomic_load(SinvG + (size_t)i * LD + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else return SinvL[i * LD + j];
+        if constexpr (BIG) return __hip_atomic_load(SinvG + sidx(i, j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else return SinvL[sidx(i, j)];
     };
     auto sst = [&](int i, int j, double v) {
-        if constexpr (BIG) __hip_atomic_store(SinvG + (size_t)i * LD + j, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else SinvL[i * LD + j] = v;
+        if constexpr (BIG) __hip_atomic_store(SinvG + sidx(i, j), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else SinvL[sidx(i, j)] = v;
     };
     auto sfence = [&]() {
         if constexpr (BIG) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
@@ -474,8 +478,7 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
                 const int i = sl * 64 + lane;
                 if (i < nW) {
                     const double f = rpos[sl] * isc;
-                    for (int j = 0; j < nW; ++j) sst(i, j, fma(f, ubuf[j], sld(i, j)));
-                    sst(i, nW, -f);
+                    for (int j = 0; j <= i; ++j) sst(i, j, fma(f, ubuf[j], sld(i, j)));   // (the lower triangle: each element once)
                 } else if (i == nW) {
                     for (int j = 0; j < nW; ++j) sst(nW, j, -ubuf[j] * isc);
                     sst(nW, nW, isc);
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
                 const int i = sl * 64 + lane;
                 if (i < nW && i != pos) {
                     const double f = sld(i, pos) * ipiv;
-                    for (int j = 0; j < nW; ++j)
+                    for (int j = 0; j <= i; ++j)
                         if (j != pos) sst(i, j, fma(-f, sld(pos, j), sld(i, j)));
                 }
             }
@@ -507,14 +510,9 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
 #pragma unroll
                 for (int sl = 0; sl < PPL; ++sl) {
                     const int i = sl * 64 + lane;
-                    if (i < q && i != pos) sst(i, pos, sld(i, q));
+                    if (i < q && i != pos) sst(i, pos, sld(i, q));   // (symmetric storage: this is row pos as well)
                 }
-                sfence();
-                if (lane == (q & 63)) {
-                    for (int j = 0; j < q; ++j)
-                        if (j != pos) sst(pos, j, sld(q, j));
-                    sst(pos, pos, sld(q, q));
-                }
+                if (lane == (q & 63)) sst(pos, pos, sld(q, q));
                 const int wr = from_pos_i(Wrow, q), ws = from_pos_i(Wside, q);
                 const double wl = from_pos_d(lam, q), wc = from_pos_d(cpos, q);
 #pragma unroll
