@@ -322,8 +322,10 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
 
         // ---- one affine sweep over w (sources in, trajectory out).  kb: highest stage that carries a source (< 0: none -- the backward
         // pass is skipped); kend: forward stages 0..kend-1; full_problem: x_0 = e_0 and the defects count
-        auto sweep = [&](int kb, int kend, bool full_problem) {
+        auto sweep = [&](int kb_, int kend_, bool full_problem) {
             SD_T0();
+            // (wave-uniform by construction; said so to the compiler: loop control and stage addresses then stay on the scalar unit)
+            const int kb = __builtin_amdgcn_readfirstlane(kb_), kend = __builtin_amdgcn_readfirstlane(kend_);
             const bool use_c = full_problem && with_c;
             int kstart = use_c ? N - 1 : (kb >= N ? N - 1 : kb);
             if constexpr (ROWDPP) {
@@ -339,17 +341,25 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
                     if ((kb >= N || use_c) && st_l) pv = w[N * SP + l16];
                     if (GEN && use_c && st_l) pv += pcg[(size_t)(N - 1) * NT + l16];
                     double own = w[(kstart >= 0 ? kstart : 0) * SP + lsl];
+                    double wrote = 0.0;   // the value the previous stage wrote to LDS: kept in a register of its own until this stage's
+                                          // products are done, so that no accumulator is allocated over the source of a write in flight
+                                          // (a write-after-read wait of one LDS latency per stage otherwise)
                     for (int k = kstart; k >= 0; --k) {
                         if (GEN && kvar) load_bw(recg, k);
                         const double own_next = w[(k > 0 ? k - 1 : 0) * SP + lsl];
                         double acc0 = st_l ? own : 0.0, acc1 = 0.0;
                         sd_dot_bcast<0, NT>(acc0, acc1, pv, r1);
                         sd_dot_bcast<NT, MC>(acc0, acc1, own, sb);
+                        asm volatile("" :: "v"(wrote));
                         double out = acc0 + acc1;
                         if (GEN && use_c && k > 0 && st_l) out += pcg[(size_t)(k - 1) * NT + l16];
-                        if (!st_l && wr_l) w[k * SP + l16] = out;   // kff_k over the consumed input sources
-                        pv = st_l ? out : 0.0;
+                        // the value read for the next stage is taken BEFORE this stage's LDS write is issued: the wait for it would
+                        // otherwise cover the write as well (one LDS latency per stage: tools/microbench/dpp_matvec.hip, 257 -> ~150 cycles)
                         own = own_next;
+                        asm volatile("" :: "v"(own) : "memory");
+                        if (!st_l && wr_l) w[k * SP + l16] = out;   // kff_k over the consumed input sources
+                        wrote = out;
+                        pv = st_l ? out : 0.0;
                     }
                     sd_fence();
 #ifdef ALMPC_STAMPS
@@ -358,15 +368,19 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
                     SD_ACC(0);
                     double xv = st_l ? ((full_problem && l16 < n) ? e0l16 : 0.0) : w[lsl];
                     if (wr_l && st_l) w[l16] = xv;
+                    wrote = 0.0;
                     for (int k = 0; k < kend; ++k) {
                         if (GEN && kvar) load_fw(recg, k);
                         const double kf_next = w[(k + 1 < kend ? k + 1 : k) * SP + lsl];
                         double acc0 = (GEN && use_c && st_l) ? ctg[(size_t)k * NT + l16] : 0.0, acc1 = 0.0;
                         sd_dot_bcast<0, NT>(acc0, acc1, xv, r2);
                         sd_dot_bcast<NT, MC>(acc0, acc1, xv, r3);
+                        asm volatile("" :: "v"(wrote));
                         const double out = acc0 + acc1;
-                        if (wr_l) w[(st_l ? (k + 1) * SP : k * SP) + l16] = out;
                         xv = st_l ? out : kf_next;
+                        asm volatile("" :: "v"(xv) : "memory");   // (as in the backward loop: consume the read, then write)
+                        if (wr_l) w[(st_l ? (k + 1) * SP : k * SP) + l16] = out;
+                        wrote = out;
                     }
                     sd_fence();
                     SD_ACC(1);

@@ -1,7 +1,7 @@
 # Round-end sequence on the GPU box: bench.py as the driver runs it, a kernel trace, four --pmc passes (each rocprofv3 under its own
 # timeout, counters never combined with a trace), then tools/summarize_profiles.py.  TAG names the round (default r3).
 set -x
-TAG=${TAG:-r3}
+TAG=${TAG:-r4}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out
 cd /tmp; export TMPDIR=/tmp
