@@ -143,6 +143,31 @@ def load():
     L.almpc_group_calculate_async.argtypes = [_hp, ctypes.POINTER(almpc_opts)]
     L.almpc_group_synchronize.argtypes = [_hp]
     L.almpc_group_get_results.argtypes = [_hp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _ip]
+    # group forms of everything a handle can do
+    for nm_ in ("almpc_group_set_terminal_equality", "almpc_group_set_rho_profile", "almpc_group_set_structured_fallback",
+                "almpc_group_sqp_fnn_set_structured", "almpc_group_sqp_fnn_set_step_rule"):
+        getattr(L, nm_).argtypes = [_hp, ctypes.c_int]
+    L.almpc_group_set_state_box.argtypes = [_hp, _dp, _dp]
+    L.almpc_group_design_batched.argtypes = [_hp] + [_dp] * 6 + [ctypes.c_int, _dp, _dp, ctypes.c_double, ctypes.c_double]
+    L.almpc_group_relin_fnn_setup.argtypes = [_hp, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [_dp] * 12 + [ctypes.c_double, ctypes.c_double]
+    L.almpc_group_relin_fnn_step.argtypes = [_hp, ctypes.POINTER(almpc_opts)]
+    L.almpc_group_relin_fnn_step_async.argtypes = [_hp, ctypes.POINTER(almpc_opts)]
+    L.almpc_group_relin_fnn_advance.argtypes = [_hp]
+    L.almpc_group_advance_plant.argtypes = [_hp]
+    L.almpc_group_sqp_fnn_setup.argtypes = [_hp, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [_dp] * 10 + [ctypes.c_int, _dp, _dp, ctypes.c_double, ctypes.c_double]
+    L.almpc_group_sqp_fnn_start.argtypes = [_hp, _dp, _dp]
+    L.almpc_group_sqp_fnn_iterate.argtypes = [_hp, ctypes.c_int, ctypes.c_double, ctypes.POINTER(almpc_opts), _dp, _dp]
+    L.almpc_group_sqp_fnn_skipped.argtypes = [_hp, _ip]
+    L.almpc_group_x0_staging.argtypes = [_hp, ctypes.POINTER(_dp)]
+    L.almpc_group_update_initialization_staged.argtypes = [_hp, ctypes.POINTER(_dp)]
+    L.almpc_group_get_results_async.argtypes = [_hp, ctypes.c_uint32]
+    L.almpc_group_get_results_wait.argtypes = [_hp, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _ip]
+    for nm_ in ("almpc_group_set_terminal_equality", "almpc_group_set_rho_profile", "almpc_group_set_structured_fallback", "almpc_group_set_state_box",
+                "almpc_group_design_batched", "almpc_group_relin_fnn_setup", "almpc_group_relin_fnn_step", "almpc_group_relin_fnn_step_async",
+                "almpc_group_relin_fnn_advance", "almpc_group_advance_plant", "almpc_group_sqp_fnn_set_structured", "almpc_group_sqp_fnn_set_step_rule",
+                "almpc_group_sqp_fnn_setup", "almpc_group_sqp_fnn_start", "almpc_group_sqp_fnn_iterate", "almpc_group_sqp_fnn_skipped",
+                "almpc_group_x0_staging", "almpc_group_update_initialization_staged", "almpc_group_get_results_async", "almpc_group_get_results_wait"):
+        getattr(L, nm_).restype = ctypes.c_int
     L.almpc_set_start_from.argtypes = [_hp, _hp]
     L.almpc_set_start_from.restype = ctypes.c_int
     L.almpc_timing_samples.argtypes = [_hp, ctypes.c_int, ctypes.POINTER(ctypes.c_int), _fp, _fp, _fp, _fp]
@@ -644,12 +669,14 @@ class Group:
     """One process, several GPUs (almpc_group_*): one handle per entry of `devices` on its contiguous shard of the batch; every call
     fans out over the handles, nothing on the step path synchronises across devices.  Host arrays cover the whole batch."""
 
-    def __init__(self, n, m, N, batch, devices, timing=False):
+    def __init__(self, n, m, N, batch, devices, timing=False, structured=False, structured_fallback=None):
         self.L = load()
         self.n, self.m, self.N, self.batch = int(n), int(m), int(N), int(batch)
+        self.nz = self.m * self.N
         devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
         g = _hp()
-        rc = self.L.almpc_group_create(ctypes.byref(g), self.n, self.m, self.N, self.batch, len(devices), devs, FLAG_TIMING if timing else 0)
+        rc = self.L.almpc_group_create(ctypes.byref(g), self.n, self.m, self.N, self.batch, len(devices), devs,
+                                       (FLAG_TIMING if timing else 0) | (FLAG_STRUCTURED if structured else 0))
         if rc != ALMPC_OK:
             raise AlmpcError(rc, "almpc_group_create failed (are the devices visible? there is no CPU fallback)")
         self.g = g
@@ -660,10 +687,136 @@ class Group:
             self.shards.append((f.value, c.value))
         self.handles = [_HandleView(self.L, _hp(self.L.almpc_group_handle(self.g, i)), self.n, self.m, self.N, c)
                         for i, (_, c) in enumerate(self.shards)]
+        if structured_fallback is not None:
+            self._check(self.L.almpc_group_set_structured_fallback(self.g, 1 if structured_fallback else 0))
 
     def _check(self, rc):
         if rc != ALMPC_OK:
             raise AlmpcError(rc, (self.L.almpc_group_last_error(self.g) or b"").decode())
+
+    def _state_rows(self, xmin, xmax, terminal):
+        if (xmin is None) != (xmax is None):
+            raise ValueError("give both xmin and xmax or neither")
+        self._check(self.L.almpc_group_set_terminal_equality(self.g, 1 if terminal == "equality" else 0))
+        lo = None if xmin is None else np.ascontiguousarray(xmin, dtype=np.float64).reshape(self.n)
+        hi = None if xmax is None else np.ascontiguousarray(xmax, dtype=np.float64).reshape(self.n)
+        self._check(self.L.almpc_group_set_state_box(self.g, _ptr(lo), _ptr(hi)))
+
+    def design_batched(self, A_batch, B_batch, Q, R, S=None, P=None, umin=None, umax=None, rho=0.1, sigma=1e-6, rho_profile="scalar",
+                       xmin=None, xmax=None, terminal="none"):
+        """almpc_group_design_batched: arguments of Solver.design_batched for the whole batch."""
+        n, m, b = self.n, self.m, self.batch
+        self._state_rows(xmin, xmax, terminal)
+        self._check(self.L.almpc_group_set_rho_profile(self.g, {"scalar": 0, "stiffness": 1}[rho_profile]))
+        A = np.ascontiguousarray(np.asarray(A_batch, dtype=np.float64).reshape(b, n, n).transpose(0, 2, 1))
+        B = np.ascontiguousarray(np.asarray(B_batch, dtype=np.float64).reshape(b, n, m).transpose(0, 2, 1))
+        Q, R = _colmajor(Q, (n, n)), _colmajor(R, (m, m))
+        S = None if S is None else _colmajor(S, (m, m))
+        p_inst = 0
+        if P is not None:
+            P = np.asarray(P, dtype=np.float64)
+            if P.ndim == 3:
+                P = np.ascontiguousarray(P.reshape(b, n, n).transpose(0, 2, 1)); p_inst = 1
+            else:
+                P = _colmajor(P, (n, n))
+        umin = np.ascontiguousarray(umin, dtype=np.float64).reshape(m)
+        umax = np.ascontiguousarray(umax, dtype=np.float64).reshape(m)
+        self._check(self.L.almpc_group_design_batched(self.g, _ptr(A), _ptr(B), _ptr(Q), _ptr(R), _ptr(S), _ptr(P), p_inst, _ptr(umin),
+                                                      _ptr(umax), float(rho), float(sigma)))
+
+    def _fnn_args(self, W_in, W_h, b_h, W_out, x_ref, u_ref, Q, R, S, P, umin, umax, act, p_batched):
+        n, m, N = self.n, self.m, self.N
+        W_in = np.asarray(W_in, dtype=np.float64)
+        H = W_in.shape[0]
+        W_h = [np.asarray(w, dtype=np.float64) for w in W_h]
+        nl = len(W_h)
+        Wh = np.ascontiguousarray(np.stack([w.T for w in W_h])) if nl else None
+        bh = np.ascontiguousarray(np.stack([np.asarray(v, dtype=np.float64) for v in b_h])) if nl else None
+        xr = np.ascontiguousarray(np.asarray(x_ref, dtype=np.float64).reshape(n, N + 1).T)
+        ur = np.ascontiguousarray(np.asarray(u_ref, dtype=np.float64).reshape(m, N).T)
+        P = np.asarray(P, dtype=np.float64)
+        p_inst = 0
+        if p_batched and P.ndim == 3:
+            P = np.ascontiguousarray(P.reshape(self.batch, n, n).transpose(0, 2, 1)); p_inst = 1
+        else:
+            P = _colmajor(P, (n, n))
+        arrs = [_colmajor(W_in, (H, n + m)), Wh, bh, _colmajor(W_out, (n, H)), xr, ur, _colmajor(Q, (n, n)), _colmajor(R, (m, m)),
+                None if S is None else _colmajor(S, (m, m)), P,
+                np.ascontiguousarray(umin, dtype=np.float64).reshape(m), np.ascontiguousarray(umax, dtype=np.float64).reshape(m)]
+        return H, nl, FNN_ACTIVATIONS[act], arrs, p_inst
+
+    def relin_fnn_setup(self, W_in, W_h, b_h, W_out, x_ref, u_ref, Q, R, S=None, P=None, umin=None, umax=None, act="relu", rho=0.1,
+                        sigma=1e-6, rho_profile="scalar", xmin=None, xmax=None, terminal="none"):
+        self._state_rows(xmin, xmax, terminal)
+        self._check(self.L.almpc_group_set_rho_profile(self.g, {"scalar": 0, "stiffness": 1}[rho_profile]))
+        H, nl, a, arrs, _ = self._fnn_args(W_in, W_h, b_h, W_out, x_ref, u_ref, Q, R, S, P, umin, umax, act, False)
+        self._keep = arrs
+        self._check(self.L.almpc_group_relin_fnn_setup(self.g, H, nl, a, *[_ptr(v) for v in arrs], float(rho), float(sigma)))
+
+    def relin_fnn_step(self, opts: almpc_opts | None = None, sync=True):
+        fn = self.L.almpc_group_relin_fnn_step if sync else self.L.almpc_group_relin_fnn_step_async
+        self._check(fn(self.g, None if opts is None else ctypes.byref(opts)))
+
+    def relin_fnn_advance(self):
+        self._check(self.L.almpc_group_relin_fnn_advance(self.g))
+
+    def advance_plant(self):
+        self._check(self.L.almpc_group_advance_plant(self.g))
+
+    def sqp_fnn_setup(self, W_in, W_h, b_h, W_out, x_ref, u_ref, Q, R, S=None, P=None, umin=None, umax=None, act="relu", rho=0.1,
+                      sigma=1e-6, rho_profile="scalar", xmin=None, xmax=None, terminal="none", qp_solver="condensed"):
+        self._state_rows(xmin, xmax, terminal)
+        self._check(self.L.almpc_group_set_rho_profile(self.g, {"scalar": 0, "stiffness": 1}[rho_profile]))
+        self._check(self.L.almpc_group_sqp_fnn_set_structured(self.g, 1 if qp_solver == "structured" else 0))
+        H, nl, a, arrs, p_inst = self._fnn_args(W_in, W_h, b_h, W_out, x_ref, u_ref, Q, R, S, P, umin, umax, act, True)
+        self._keep = arrs
+        ptrs = [_ptr(v) for v in arrs]
+        self._check(self.L.almpc_group_sqp_fnn_setup(self.g, H, nl, a, *ptrs[:10], p_inst, ptrs[10], ptrs[11], float(rho), float(sigma)))
+
+    def sqp_fnn_start(self, x0, u_guess=None):
+        x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(self.batch, self.n)
+        ug = None if u_guess is None else np.ascontiguousarray(np.asarray(u_guess, dtype=np.float64).reshape(self.batch, self.m, self.N).transpose(0, 2, 1))
+        self._check(self.L.almpc_group_sqp_fnn_start(self.g, _ptr(x0), _ptr(ug)))
+
+    def sqp_fnn_iterate(self, iters, step_scale=1.0, opts=None, step_rule="fixed"):
+        self._check(self.L.almpc_group_sqp_fnn_set_step_rule(self.g, {"fixed": 0, "merit": 1}[step_rule]))
+        st, de = np.zeros(int(iters)), np.zeros(int(iters))
+        self._check(self.L.almpc_group_sqp_fnn_iterate(self.g, int(iters), float(step_scale), None if opts is None else ctypes.byref(opts),
+                                                       _ptr(st), _ptr(de)))
+        return st, de
+
+    def sqp_fnn_skipped(self):
+        sk = np.zeros(self.batch, dtype=np.int32)
+        self._check(self.L.almpc_group_sqp_fnn_skipped(self.g, sk.ctypes.data_as(_ip)))
+        return sk
+
+    def x0_staging(self):
+        """The handles' pinned x0 slots as numpy views ((count_i, n) each): write the shards' states there, then update_initialization_staged()."""
+        slots = (_dp * len(self.handles))()
+        self._check(self.L.almpc_group_x0_staging(self.g, slots))
+        self._slots = slots
+        return [np.ctypeslib.as_array(slots[i], shape=(c, self.n)) for i, (_, c) in enumerate(self.shards)]
+
+    def update_initialization_staged(self):
+        self._check(self.L.almpc_group_update_initialization_staged(self.g, self._slots))
+
+    def get_results_async(self, want=("u0", "status")) -> int:
+        t = self.L.almpc_group_get_results_async(self.g, _want_mask(want))
+        if t < 0:
+            self._check(t)
+        return t
+
+    def get_results_wait(self, ticket, want=("u0", "status")):
+        b, n, m, N = self.batch, self.n, self.m, self.N
+        shapes = {"x": (b, N + 1, n), "e_x": (b, N + 1, n), "u": (b, N, m), "e_u": (b, N, m), "u0": (b, m),
+                  "status": (b,), "iters": (b,), "polish_iters": (b,)}
+        order = ("x", "e_x", "u", "e_u", "u0", "status", "iters", "polish_iters")
+        bufs = {k: np.empty(shapes[k], dtype=np.int32 if k in ("status", "iters", "polish_iters") else np.float64) for k in set(want)}
+        args = [(bufs[k].ctypes.data_as(_ip if bufs[k].dtype == np.int32 else _dp) if k in bufs else None) for k in order]
+        self._check(self.L.almpc_group_get_results_wait(self.g, int(ticket), *args))
+        for k in ("x", "e_x", "u", "e_u"):
+            if k in bufs: bufs[k] = bufs[k].transpose(0, 2, 1)
+        return bufs
 
     def close(self):
         if getattr(self, "g", None):

@@ -282,6 +282,10 @@ struct almpc_group {
     std::vector<almpc_handle*> hs;
     std::vector<int> first, count;   // shard of handle i: instances [first, first + count)
     std::vector<int> tickets;
+    // almpc_group_get_results_async: group ticket t -> the handles' own tickets (ring of two, as the handles keep theirs)
+    std::vector<int> gt[2];
+    long gticket[2] = {-1, -1};
+    long next_gticket = 0;
     std::string err;
 };
 
@@ -290,6 +294,24 @@ int gfail(almpc_group* g, int code, int i) {
     if (g) g->err = "handle " + std::to_string(i) + ": " + (g->hs[i] ? g->hs[i]->err : std::string("null"));
     return code;
 }
+
+// Every handle's call on a host thread of its own (the design entry points are synchronous: uploads, design kernels, a host-side DARE):
+// all devices design at the same time instead of one after the other.  Returns the first failure.
+template <class F>
+int group_fanout(almpc_group* g, F&& call) {
+    const size_t k = g->hs.size();
+    std::vector<int> rc(k, ALMPC_OK);
+    if (k == 1) rc[0] = call((int)0);
+    else {
+        std::vector<std::thread> th;
+        for (size_t i = 0; i < k; ++i) th.emplace_back([&, i]() { rc[i] = call((int)i); });
+        for (auto& q : th) q.join();
+    }
+    for (size_t i = 0; i < k; ++i)
+        if (rc[i] != ALMPC_OK) return gfail(g, rc[i], (int)i);
+    return ALMPC_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -338,10 +360,134 @@ int almpc_group_design_shared(almpc_group* g, const double* A, const double* B, 
                               const double* P, const double* umin, const double* umax, const double* xmin, const double* xmax,
                               double rho, double sigma) {
     if (!g) return ALMPC_ERR_INVALID;
-    for (size_t i = 0; i < g->hs.size(); ++i) {
-        const int rc = almpc_design_shared(g->hs[i], A, B, Q, R, S, P, umin, umax, xmin, xmax, rho, sigma);
-        if (rc != ALMPC_OK) return gfail(g, rc, (int)i);
+    return group_fanout(g, [&](int i) { return almpc_design_shared(g->hs[i], A, B, Q, R, S, P, umin, umax, xmin, xmax, rho, sigma); });
+}
+
+// per-handle options, fanned out (each takes effect at the next design, as the single-handle calls say)
+int almpc_group_set_terminal_equality(almpc_group* g, int on) {
+    if (!g) return ALMPC_ERR_INVALID;
+    for (size_t i = 0; i < g->hs.size(); ++i) { const int rc = almpc_set_terminal_equality(g->hs[i], on); if (rc != ALMPC_OK) return gfail(g, rc, (int)i); }
+    return ALMPC_OK;
+}
+int almpc_group_set_rho_profile(almpc_group* g, int mode) {
+    if (!g) return ALMPC_ERR_INVALID;
+    for (size_t i = 0; i < g->hs.size(); ++i) { const int rc = almpc_set_rho_profile(g->hs[i], mode); if (rc != ALMPC_OK) return gfail(g, rc, (int)i); }
+    return ALMPC_OK;
+}
+int almpc_group_set_structured_fallback(almpc_group* g, int on) {
+    if (!g) return ALMPC_ERR_INVALID;
+    for (size_t i = 0; i < g->hs.size(); ++i) { const int rc = almpc_set_structured_fallback(g->hs[i], on); if (rc != ALMPC_OK) return gfail(g, rc, (int)i); }
+    return ALMPC_OK;
+}
+int almpc_group_set_state_box(almpc_group* g, const double* xmin, const double* xmax) {
+    if (!g) return ALMPC_ERR_INVALID;
+    for (size_t i = 0; i < g->hs.size(); ++i) { const int rc = almpc_set_state_box(g->hs[i], xmin, xmax); if (rc != ALMPC_OK) return gfail(g, rc, (int)i); }
+    return ALMPC_OK;
+}
+
+// one model per instance: A_batch [batch][n*n], B_batch [batch][n*m], P (NULL | n*n | [batch][n*n]) cut along the shards
+int almpc_group_design_batched(almpc_group* g, const double* A_batch, const double* B_batch, const double* Q, const double* R, const double* S,
+                               const double* P, int P_per_instance, const double* umin, const double* umax, double rho, double sigma) {
+    if (!g || !A_batch || !B_batch) return ALMPC_ERR_INVALID;
+    const size_t nn = (size_t)g->n * g->n, nm = (size_t)g->n * g->m;
+    return group_fanout(g, [&](int i) {
+        const size_t f = (size_t)g->first[i];
+        return almpc_design_batched(g->hs[i], A_batch + f * nn, B_batch + f * nm, Q, R, S, (P && P_per_instance) ? P + f * nn : P, P_per_instance,
+                                    umin, umax, rho, sigma);
+    });
+}
+
+// the re-linearisation pipeline of a black-box Fnn model (BASELINE configs[3]) on every device: shared network and references
+int almpc_group_relin_fnn_setup(almpc_group* g, int H, int L, int activation, const double* W_in, const double* W_h, const double* b_h,
+                                const double* W_out, const double* xref, const double* uref, const double* Q, const double* R,
+                                const double* S, const double* P, const double* umin, const double* umax, double rho, double sigma) {
+    if (!g) return ALMPC_ERR_INVALID;
+    return group_fanout(g, [&](int i) {
+        return almpc_relin_fnn_setup(g->hs[i], H, L, activation, W_in, W_h, b_h, W_out, xref, uref, Q, R, S, P, umin, umax, rho, sigma);
+    });
+}
+int almpc_group_relin_fnn_step_async(almpc_group* g, const almpc_opts* opts) {
+    if (!g) return ALMPC_ERR_INVALID;
+    for (size_t i = 0; i < g->hs.size(); ++i) { const int rc = almpc_relin_fnn_step_async(g->hs[i], opts); if (rc != ALMPC_OK) return gfail(g, rc, (int)i); }
+    return ALMPC_OK;
+}
+int almpc_group_relin_fnn_step(almpc_group* g, const almpc_opts* opts) {
+    const int rc = almpc_group_relin_fnn_step_async(g, opts);
+    return rc != ALMPC_OK ? rc : almpc_group_synchronize(g);
+}
+int almpc_group_relin_fnn_advance(almpc_group* g) {
+    if (!g) return ALMPC_ERR_INVALID;
+    for (size_t i = 0; i < g->hs.size(); ++i) { const int rc = almpc_relin_fnn_advance(g->hs[i]); if (rc != ALMPC_OK) return gfail(g, rc, (int)i); }
+    return ALMPC_OK;
+}
+int almpc_group_advance_plant(almpc_group* g) {
+    if (!g) return ALMPC_ERR_INVALID;
+    for (size_t i = 0; i < g->hs.size(); ++i) { const int rc = almpc_advance_plant(g->hs[i]); if (rc != ALMPC_OK) return gfail(g, rc, (int)i); }
+    return ALMPC_OK;
+}
+
+// the SQP loop (BASELINE configs[4]) on every device; P n*n (P_per_instance = 0) or [batch][n*n] cut along the shards
+int almpc_group_sqp_fnn_set_structured(almpc_group* g, int on) {
+    if (!g) return ALMPC_ERR_INVALID;
+    for (size_t i = 0; i < g->hs.size(); ++i) { const int rc = almpc_sqp_fnn_set_structured(g->hs[i], on); if (rc != ALMPC_OK) return gfail(g, rc, (int)i); }
+    return ALMPC_OK;
+}
+int almpc_group_sqp_fnn_set_step_rule(almpc_group* g, int rule) {
+    if (!g) return ALMPC_ERR_INVALID;
+    for (size_t i = 0; i < g->hs.size(); ++i) { const int rc = almpc_sqp_fnn_set_step_rule(g->hs[i], rule); if (rc != ALMPC_OK) return gfail(g, rc, (int)i); }
+    return ALMPC_OK;
+}
+int almpc_group_sqp_fnn_setup(almpc_group* g, int H, int L, int activation, const double* W_in, const double* W_h, const double* b_h,
+                              const double* W_out, const double* xref, const double* uref, const double* Q, const double* R,
+                              const double* S, const double* P, int P_per_instance, const double* umin, const double* umax, double rho,
+                              double sigma) {
+    if (!g || !P) return ALMPC_ERR_INVALID;
+    const size_t nn = (size_t)g->n * g->n;
+    return group_fanout(g, [&](int i) {
+        return almpc_sqp_fnn_setup(g->hs[i], H, L, activation, W_in, W_h, b_h, W_out, xref, uref, Q, R, S,
+                                   P_per_instance ? P + (size_t)g->first[i] * nn : P, P_per_instance, umin, umax, rho, sigma);
+    });
+}
+int almpc_group_sqp_fnn_start(almpc_group* g, const double* x0, const double* u_guess) {
+    if (!g || !x0) return ALMPC_ERR_INVALID;
+    return group_fanout(g, [&](int i) {
+        const size_t f = (size_t)g->first[i];
+        return almpc_sqp_fnn_start(g->hs[i], x0 + f * g->n, u_guess ? u_guess + f * g->m * g->N : nullptr);
+    });
+}
+// `iters` iterations on every device at the same time (each handle's loop synchronises its own stream once at the end);
+// step_inf / defect_inf: maxima over the whole batch.  A device that had to skip an instance returns ALMPC_ERR_NUMERIC as the
+// single-handle call does (the others have finished their iterations): almpc_group_sqp_fnn_skipped tells which instances.
+int almpc_group_sqp_fnn_iterate(almpc_group* g, int iters, double step_scale, const almpc_opts* opts, double* step_inf, double* defect_inf) {
+    if (!g || iters < 1) return ALMPC_ERR_INVALID;
+    const size_t k = g->hs.size();
+    std::vector<std::vector<double>> st(k, std::vector<double>((size_t)iters, 0.0)), de(k, std::vector<double>((size_t)iters, 0.0));
+    const int rc = group_fanout(g, [&](int i) { return almpc_sqp_fnn_iterate(g->hs[i], iters, step_scale, opts, st[i].data(), de[i].data()); });
+    for (int it = 0; it < iters; ++it) {
+        double a = 0.0, b = 0.0;
+        for (size_t i = 0; i < k; ++i) { a = std::max(a, st[i][it]); b = std::max(b, de[i][it]); }
+        if (step_inf) step_inf[it] = a;
+        if (defect_inf) defect_inf[it] = b;
     }
+    return rc;
+}
+int almpc_group_sqp_fnn_skipped(almpc_group* g, int32_t* skipped) {
+    if (!g || !skipped) return ALMPC_ERR_INVALID;
+    for (size_t i = 0; i < g->hs.size(); ++i) { const int rc = almpc_sqp_fnn_skipped(g->hs[i], skipped + g->first[i]); if (rc != ALMPC_OK) return gfail(g, rc, (int)i); }
+    return ALMPC_OK;
+}
+
+// zero-copy input of the next almpc_group_update_initialization: slots[i] = the pinned buffer of handle i ([count_i][n]); write the
+// shard's states there and pass the group call a NULL x0 ... (see almpc_x0_staging): here the pointers only
+int almpc_group_x0_staging(almpc_group* g, double** slots) {
+    if (!g || !slots) return ALMPC_ERR_INVALID;
+    for (size_t i = 0; i < g->hs.size(); ++i) { const int rc = almpc_x0_staging(g->hs[i], &slots[i]); if (rc != ALMPC_OK) return gfail(g, rc, (int)i); }
+    return ALMPC_OK;
+}
+// the states were written into the slots of almpc_group_x0_staging: hand every device its slot (no copy)
+int almpc_group_update_initialization_staged(almpc_group* g, double* const* slots) {
+    if (!g || !slots) return ALMPC_ERR_INVALID;
+    for (size_t i = 0; i < g->hs.size(); ++i) { const int rc = almpc_update_initialization_async(g->hs[i], slots[i]); if (rc != ALMPC_OK) return gfail(g, rc, (int)i); }
     return ALMPC_OK;
 }
 
@@ -397,6 +543,8 @@ int almpc_group_get_results(almpc_group* g, double* x, double* e_x, double* u, d
                           (u0 ? ALMPC_WANT_FIRST_INPUT : 0) | (status ? ALMPC_WANT_STATUS : 0) | (iters ? ALMPC_WANT_ITERS : 0) |
                           (polish_iters ? ALMPC_WANT_POLISH_ITERS : 0);
     if (!want) return ALMPC_OK;
+    for (size_t i = 0; i < g->hs.size(); ++i)   // (a synchronous look at the results: a lazily deferred redo is settled first, per device)
+        if (g->hs[i]->lazy_pending) { const int rc = almpc_synchronize(g->hs[i]); if (rc != ALMPC_OK) return gfail(g, rc, (int)i); }
     for (size_t i = 0; i < g->hs.size(); ++i) {
         g->tickets[i] = almpc_get_results_async(g->hs[i], want);
         if (g->tickets[i] < 0) return gfail(g, g->tickets[i], (int)i);
@@ -404,6 +552,39 @@ int almpc_group_get_results(almpc_group* g, double* x, double* e_x, double* u, d
     for (size_t i = 0; i < g->hs.size(); ++i) {
         const size_t f = (size_t)g->first[i], xs = (size_t)g->n * (g->N + 1), us = (size_t)g->m * g->N;
         const int rc = almpc_get_results_wait(g->hs[i], g->tickets[i], x ? x + f * xs : nullptr, e_x ? e_x + f * xs : nullptr,
+                                              u ? u + f * us : nullptr, e_u ? e_u + f * us : nullptr, u0 ? u0 + f * g->m : nullptr,
+                                              status ? status + f : nullptr, iters ? iters + f : nullptr,
+                                              polish_iters ? polish_iters + f : nullptr);
+        if (rc != ALMPC_OK) return gfail(g, rc, (int)i);
+    }
+    return ALMPC_OK;
+}
+
+// Asynchronous read-back of the whole batch: the request goes to every device (pack kernels / copy streams), the ticket is the group's;
+// almpc_group_get_results_wait gathers into the caller's arrays (layouts of almpc_group_get_results).  The last two tickets are kept.
+int almpc_group_get_results_async(almpc_group* g, uint32_t want) {
+    if (!g) return ALMPC_ERR_INVALID;
+    const long t = g->next_gticket;
+    const int s = (int)(t % 2);
+    g->gt[s].assign(g->hs.size(), -1);
+    for (size_t i = 0; i < g->hs.size(); ++i) {
+        g->gt[s][i] = almpc_get_results_async(g->hs[i], want);
+        if (g->gt[s][i] < 0) return gfail(g, g->gt[s][i], (int)i);
+    }
+    g->gticket[s] = t;
+    g->next_gticket += 1;
+    return (int)(t & 0x3fffffff);
+}
+int almpc_group_get_results_wait(almpc_group* g, int ticket, double* x, double* e_x, double* u, double* e_u, double* u0, int32_t* status,
+                                 int32_t* iters, int32_t* polish_iters) {
+    if (!g || ticket < 0) return ALMPC_ERR_INVALID;
+    int s = -1;
+    for (int q = 0; q < 2; ++q)
+        if (g->gticket[q] >= 0 && (int)(g->gticket[q] & 0x3fffffff) == ticket) s = q;
+    if (s < 0) { g->err = "get_results_wait: ticket is not outstanding (only the last two requests are kept)"; return ALMPC_ERR_INVALID; }
+    for (size_t i = 0; i < g->hs.size(); ++i) {
+        const size_t f = (size_t)g->first[i], xs = (size_t)g->n * (g->N + 1), us = (size_t)g->m * g->N;
+        const int rc = almpc_get_results_wait(g->hs[i], g->gt[s][i], x ? x + f * xs : nullptr, e_x ? e_x + f * xs : nullptr,
                                               u ? u + f * us : nullptr, e_u ? e_u + f * us : nullptr, u0 ? u0 + f * g->m : nullptr,
                                               status ? status + f : nullptr, iters ? iters + f : nullptr,
                                               polish_iters ? polish_iters + f : nullptr);

@@ -257,6 +257,34 @@ def single_process(args):
                       "devices": devices, "global_batch": batch, "seed": hex(seed), "setup_ramp_steps": 300},
            "status_counts": np.bincount(r["status"], minlength=3).tolist()}
     g.close()
+    if not args.no_relin:
+        # BASELINE configs[3] through the group (almpc_group_relin_fnn_*): 1024 instances per device, re-linearised every step
+        bq, nq, mq, Nq = 1024 * n, 4, 2, 20
+        W_in, W_h, b_h, W_out = wl.synthetic_fnn_weights(nq, mq)
+        f = pkg.Fnn(W_in, W_h, b_h, W_out, "relu")
+        xr = np.tile(np.array([0.2, -0.1, 0.05, 0.0])[:, None], (1, Nq + 1)); ur = np.tile(np.array([0.1, -0.2])[:, None], (1, Nq))
+        Xq = xr[:, 0][None, :] + wl.splitmix_normal(0x5EED0004, 0, bq, nq)
+        Al, Bl = capi.fnn_linearize(f.W_in, f.W_h, f.b_h, f.W_out, xr[:, -1][None, :], ur[:, -1][None, :], act="relu", device=devices[0])
+        Pq = capi.dare(Al[0], Bl[0], 100.0 * np.eye(nq), 0.1 * np.eye(mq))
+        g3 = capi.Group(nq, mq, Nq, bq, devices)
+        g3.relin_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, xr, ur, 100.0 * np.eye(nq), 0.1 * np.eye(mq), None, Pq, -np.ones(mq), np.ones(mq), act="relu")
+        g3.update_initialization(Xq, resident=True)
+
+        def run3(k):
+            g3.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(k):
+                g3.relin_fnn_step(None, sync=False)
+            g3.synchronize()
+            return time.perf_counter() - t0
+        run3(50)
+        k3 = 100
+        el3 = min(run3(k3) for _ in range(3))
+        r3 = g3.get_results(want=("status",))
+        out["config3_fnn_relin"] = {"value": n * k3 / el3, "unit": "batch-steps/s (1024 instances per device, Fnn 4-2-16x2 relu, N=20, re-linearised every step)",
+                                    "ms_per_step": 1e3 * el3 / k3, "global_batch": bq, "status_counts": np.bincount(r3["status"], minlength=3).tolist(),
+                                    "launch": "single process, almpc_group_relin_fnn_step_async on every device, then almpc_group_synchronize"}
+        g3.close()
     print(json.dumps(out))
     return 0
 

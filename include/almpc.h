@@ -411,8 +411,11 @@ int almpc_get_first_input(almpc_handle* h, double* u0);
  * appear more than once), handle i on the contiguous shard [first_i, first_i + count_i) of the batch (sizes differ by at most
  * one); instances never interact, so a group call fans out over the handles and nothing on the step path synchronises across
  * devices: almpc_group_calculate_async enqueues on every device before almpc_group_synchronize waits for any.  Host arrays are
- * those of the single-handle calls with `batch` = the whole batch.  Options that are per handle (almpc_set_rho_profile,
- * almpc_set_terminal_equality, ...) are set through almpc_group_handle(g, i) before the design.
+ * those of the single-handle calls with `batch` = the whole batch; per-instance arrays (models, terminal weights, guesses) are cut
+ * along the shards.  Everything a handle can do has a group form: the options that are set before a design (almpc_group_set_*), the
+ * shared and per-instance designs, the re-linearisation pipeline, the SQP loop, the host-facing read-back (tickets, zero-copy x0
+ * slots); the synchronous design entry points run on one host thread per device, so that all devices design at the same time.
+ * flags (ALMPC_FLAG_TIMING, ALMPC_FLAG_STRUCTURED) go to every handle; almpc_group_handle(g, i) reaches one handle directly.
  */
 typedef struct almpc_group almpc_group;
 int almpc_group_create(almpc_group** out, int n, int m, int N, int batch, int n_devices, const int* device_ids, uint32_t flags);
@@ -431,6 +434,43 @@ int almpc_group_calculate_async(almpc_group* g, const almpc_opts* opts);
 int almpc_group_synchronize(almpc_group* g);
 int almpc_group_get_results(almpc_group* g, double* x, double* e_x, double* u, double* e_u, double* u0, int32_t* status,
                             int32_t* iters, int32_t* polish_iters);
+/* options of every handle (each takes effect at the next design, as the single-handle call says) */
+int almpc_group_set_terminal_equality(almpc_group* g, int on);
+int almpc_group_set_rho_profile(almpc_group* g, int mode);
+int almpc_group_set_structured_fallback(almpc_group* g, int on);
+int almpc_group_set_state_box(almpc_group* g, const double* xmin, const double* xmax);
+/* almpc_design_batched: A_batch [batch][n*n], B_batch [batch][n*m], P NULL | n*n | [batch][n*n] (P_per_instance = 1) */
+int almpc_group_design_batched(almpc_group* g, const double* A_batch, const double* B_batch, const double* Q, const double* R,
+                               const double* S, const double* P, int P_per_instance, const double* umin, const double* umax, double rho,
+                               double sigma);
+/* almpc_relin_fnn_* (BASELINE configs[3]): the same network and references on every device; step_async + almpc_group_synchronize */
+int almpc_group_relin_fnn_setup(almpc_group* g, int H, int L, int activation, const double* W_in, const double* W_h, const double* b_h,
+                                const double* W_out, const double* xref, const double* uref, const double* Q, const double* R,
+                                const double* S, const double* P, const double* umin, const double* umax, double rho, double sigma);
+int almpc_group_relin_fnn_step(almpc_group* g, const almpc_opts* opts);
+int almpc_group_relin_fnn_step_async(almpc_group* g, const almpc_opts* opts);
+int almpc_group_relin_fnn_advance(almpc_group* g);
+int almpc_group_advance_plant(almpc_group* g);
+/* almpc_sqp_fnn_* (BASELINE configs[4]): x0 [batch][n], u_guess [batch][N][m] or NULL, P n*n or [batch][n*n]; iterate runs the devices'
+ * loops at the same time, step_inf / defect_inf are maxima over the whole batch; skipped [batch] */
+int almpc_group_sqp_fnn_set_structured(almpc_group* g, int on);
+int almpc_group_sqp_fnn_set_step_rule(almpc_group* g, int rule);
+int almpc_group_sqp_fnn_setup(almpc_group* g, int H, int L, int activation, const double* W_in, const double* W_h, const double* b_h,
+                              const double* W_out, const double* xref, const double* uref, const double* Q, const double* R,
+                              const double* S, const double* P, int P_per_instance, const double* umin, const double* umax, double rho,
+                              double sigma);
+int almpc_group_sqp_fnn_start(almpc_group* g, const double* x0, const double* u_guess);
+int almpc_group_sqp_fnn_iterate(almpc_group* g, int iters, double step_scale, const almpc_opts* opts, double* step_inf,
+                                double* defect_inf);
+int almpc_group_sqp_fnn_skipped(almpc_group* g, int32_t* skipped);
+/* host-facing path of the group: slots[i] = handle i's pinned x0 buffer ([count_i][n], almpc_x0_staging) -> write the shard's states
+ * there -> almpc_group_update_initialization_staged(g, slots) (no copy);  read-back by ticket as almpc_get_results_async / _wait, the
+ * arrays of _wait being those of almpc_group_get_results */
+int almpc_group_x0_staging(almpc_group* g, double** slots /* [almpc_group_size(g)] */);
+int almpc_group_update_initialization_staged(almpc_group* g, double* const* slots);
+int almpc_group_get_results_async(almpc_group* g, uint32_t want);
+int almpc_group_get_results_wait(almpc_group* g, int ticket, double* x, double* e_x, double* u, double* e_u, double* u0, int32_t* status,
+                                 int32_t* iters, int32_t* polish_iters);
 
 /* Design data for parity tests: H nz*nz, F nz*n (both unscaled, column-major), P n*n, d nz. */
 int almpc_get_design(almpc_handle* h, double* H, double* F, double* P, double* d);

@@ -16,7 +16,10 @@ export hip_solver_def, HipModeler, AlmpcOpts, design_hip, terminal_weight, set_s
        get_timing, timing_reset!, timing_set_stride!, timing_summary, timing_samples, relin_timing, debug_poison_lds!,
        update_initialization_async!, x0_staging, results_async, results_wait!, host_results, first_input, first_input!, ALLOW_UNSOLVED,
        HipGroup, group_design_hip, group_handle, group_shard, group_update_initialization!, group_calculate!, group_calculate_async!,
-       group_synchronize!, group_read_results!
+       group_synchronize!, group_read_results!, group_set_state_rows!, group_set_rho_profile!, group_set_structured_fallback!,
+       group_design_batched!, group_design_relin_fnn!, group_relin_step!, group_relin_advance!, group_advance_plant!, group_design_sqp_fnn!,
+       group_sqp_start!, group_sqp_iterate!, group_sqp_skipped, group_x0_staging, group_update_initialization_staged!, group_results_async,
+       group_results_wait!
 
 const libalmpc = get(ENV, "ALMPC_LIB", "libalmpc.so")
 
@@ -584,7 +587,124 @@ function group_read_results!(g::HipGroup; x = nothing, e_x = nothing, u = nothin
     GC.@preserve x e_x u e_u u0 gcheck(g.group, ccall((:almpc_group_get_results, libalmpc), Cint,
         (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}),
         g.group, pf(x), pf(e_x), pf(u), pf(e_u), pf(u0), status, C_NULL, C_NULL))
-    return throw_on_status(status)
+    return throw_on_status(status; strict = g.opts.polish != 0)
+end
+
+
+# ---- group forms of everything a handle can do (include/almpc.h: almpc_group_*) ----
+"options of every handle of the group (take effect at the next design)"
+function group_set_state_rows!(g::HipGroup; xmin::Union{Nothing,Vector{Float64}} = nothing, xmax::Union{Nothing,Vector{Float64}} = nothing,
+                               terminal::String = "none")
+    (xmin === nothing) == (xmax === nothing) || error("give both xmin and xmax or neither")
+    gcheck(g.group, ccall((:almpc_group_set_terminal_equality, libalmpc), Cint, (Ptr{Cvoid}, Cint), g.group, terminal == "equality" ? 1 : 0))
+    pmin = xmin === nothing ? Ptr{Float64}(C_NULL) : pointer(xmin)
+    pmax = xmax === nothing ? Ptr{Float64}(C_NULL) : pointer(xmax)
+    GC.@preserve xmin xmax gcheck(g.group, ccall((:almpc_group_set_state_box, libalmpc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), g.group, pmin, pmax))
+    return g
+end
+group_set_rho_profile!(g::HipGroup, profile::String) =
+    gcheck(g.group, ccall((:almpc_group_set_rho_profile, libalmpc), Cint, (Ptr{Cvoid}, Cint), g.group, profile == "stiffness" ? 1 : 0))
+group_set_structured_fallback!(g::HipGroup, on::Bool) =
+    gcheck(g.group, ccall((:almpc_group_set_structured_fallback, libalmpc), Cint, (Ptr{Cvoid}, Cint), g.group, on ? 1 : 0))
+
+"`design_batched!` for the whole batch: `A_batch` n x n x batch, `B_batch` n x m x batch, `P` nothing | n x n | n x n x batch"
+function group_design_batched!(g::HipGroup, A_batch::Array{Float64,3}, B_batch::Array{Float64,3}, Q::Matrix{Float64}, R::Matrix{Float64},
+                               S::Matrix{Float64}, P, umin::Vector{Float64}, umax::Vector{Float64}; x_ref::Matrix{Float64}, u_ref::Matrix{Float64})
+    size(A_batch, 3) == g.batch && size(B_batch, 3) == g.batch || throw(DimensionMismatch("one model per instance"))
+    pptr = P === nothing ? Ptr{Float64}(C_NULL) : pointer(P)
+    pinst = (P !== nothing && ndims(P) == 3) ? 1 : 0
+    GC.@preserve P gcheck(g.group, ccall((:almpc_group_design_batched, libalmpc), Cint,
+                   (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint,
+                    Ptr{Float64}, Ptr{Float64}, Cdouble, Cdouble),
+                   g.group, A_batch, B_batch, Q, R, S, pptr, pinst, umin, umax, g.opts.rho, g.opts.sigma))
+    gcheck(g.group, ccall((:almpc_group_set_reference, libalmpc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Cint), g.group, x_ref, u_ref, 0))
+    return g
+end
+
+"`design_relin_fnn!` on every device (BASELINE configs[3]); then `group_relin_step!`, `group_relin_advance!`"
+function group_design_relin_fnn!(g::HipGroup, W_in::Matrix{Float64}, W_h::Array{Float64,3}, b_h::Matrix{Float64}, W_out::Matrix{Float64},
+                                 activation::Integer, Q::Matrix{Float64}, R::Matrix{Float64}, S::Matrix{Float64}, P::Matrix{Float64},
+                                 umin::Vector{Float64}, umax::Vector{Float64}; x_ref::Matrix{Float64}, u_ref::Matrix{Float64})
+    gcheck(g.group, ccall((:almpc_group_relin_fnn_setup, libalmpc), Cint,
+                   (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                    Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cdouble, Cdouble),
+                   g.group, size(W_in, 1), size(W_h, 3), activation, W_in, W_h, b_h, W_out, x_ref, u_ref, Q, R, S, P, umin, umax,
+                   g.opts.rho, g.opts.sigma))
+    return g
+end
+function group_relin_step!(g::HipGroup; warm::Bool = false, async::Bool = false)
+    o0 = g.opts
+    o = Ref(AlmpcOpts(o0.rho, o0.sigma, o0.alpha, o0.eps_abs, o0.eps_rel, o0.max_iter, o0.check_every, o0.polish, o0.polish_max_iter,
+                      Int32(warm), o0.reserved))
+    if async
+        gcheck(g.group, ccall((:almpc_group_relin_fnn_step_async, libalmpc), Cint, (Ptr{Cvoid}, Ref{AlmpcOpts}), g.group, o))
+    else
+        gcheck(g.group, ccall((:almpc_group_relin_fnn_step, libalmpc), Cint, (Ptr{Cvoid}, Ref{AlmpcOpts}), g.group, o))
+    end
+end
+group_relin_advance!(g::HipGroup) = gcheck(g.group, ccall((:almpc_group_relin_fnn_advance, libalmpc), Cint, (Ptr{Cvoid},), g.group))
+group_advance_plant!(g::HipGroup) = gcheck(g.group, ccall((:almpc_group_advance_plant, libalmpc), Cint, (Ptr{Cvoid},), g.group))
+
+"`design_sqp_fnn!` on every device (BASELINE configs[4]); `P` n x n or n x n x batch"
+function group_design_sqp_fnn!(g::HipGroup, W_in::Matrix{Float64}, W_h::Array{Float64,3}, b_h::Matrix{Float64}, W_out::Matrix{Float64},
+                               activation::Integer, Q::Matrix{Float64}, R::Matrix{Float64}, S::Matrix{Float64}, P::Array{Float64},
+                               umin::Vector{Float64}, umax::Vector{Float64}; x_ref::Matrix{Float64}, u_ref::Matrix{Float64},
+                               structured_qp::Bool = false)
+    gcheck(g.group, ccall((:almpc_group_sqp_fnn_set_structured, libalmpc), Cint, (Ptr{Cvoid}, Cint), g.group, structured_qp ? 1 : 0))
+    gcheck(g.group, ccall((:almpc_group_sqp_fnn_setup, libalmpc), Cint,
+                   (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                    Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint, Ptr{Float64}, Ptr{Float64}, Cdouble, Cdouble),
+                   g.group, size(W_in, 1), size(W_h, 3), activation, W_in, W_h, b_h, W_out, x_ref, u_ref, Q, R, S, P, ndims(P) == 3 ? 1 : 0,
+                   umin, umax, g.opts.rho, g.opts.sigma))
+    return g
+end
+function group_sqp_start!(g::HipGroup, x0::Matrix{Float64}; u_guess::Union{Nothing,Array{Float64,3}} = nothing)
+    length(x0) == g.n * g.batch || throw(DimensionMismatch("x0 must hold n x batch values"))
+    pg = u_guess === nothing ? Ptr{Float64}(C_NULL) : pointer(u_guess)
+    GC.@preserve u_guess gcheck(g.group, ccall((:almpc_group_sqp_fnn_start, libalmpc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), g.group, x0, pg))
+end
+function group_sqp_iterate!(g::HipGroup, iters::Integer; step::Float64 = 1.0, merit_safeguard::Bool = true)
+    gcheck(g.group, ccall((:almpc_group_sqp_fnn_set_step_rule, libalmpc), Cint, (Ptr{Cvoid}, Cint), g.group, merit_safeguard ? 1 : 0))
+    st, de = zeros(iters), zeros(iters)
+    o = Ref(g.opts)
+    gcheck(g.group, ccall((:almpc_group_sqp_fnn_iterate, libalmpc), Cint, (Ptr{Cvoid}, Cint, Cdouble, Ref{AlmpcOpts}, Ptr{Float64}, Ptr{Float64}),
+                          g.group, iters, step, o, st, de))
+    return st, de
+end
+function group_sqp_skipped(g::HipGroup)
+    sk = Vector{Int32}(undef, g.batch)
+    gcheck(g.group, ccall((:almpc_group_sqp_fnn_skipped, libalmpc), Cint, (Ptr{Cvoid}, Ptr{Int32}), g.group, sk))
+    return sk
+end
+
+"zero-copy input: the handles' pinned x0 slots (n x count_i matrices over library memory); write the states, then `group_update_initialization_staged!`"
+function group_x0_staging(g::HipGroup)
+    k = ccall((:almpc_group_size, libalmpc), Cint, (Ptr{Cvoid},), g.group)
+    slots = Vector{Ptr{Float64}}(undef, k)
+    gcheck(g.group, ccall((:almpc_group_x0_staging, libalmpc), Cint, (Ptr{Cvoid}, Ptr{Ptr{Float64}}), g.group, slots))
+    return slots, [unsafe_wrap(Array, slots[i], (g.n, group_shard(g, i)[2])) for i in 1:k]
+end
+group_update_initialization_staged!(g::HipGroup, slots::Vector{Ptr{Float64}}) =
+    gcheck(g.group, ccall((:almpc_group_update_initialization_staged, libalmpc), Cint, (Ptr{Cvoid}, Ptr{Ptr{Float64}}), g.group, slots))
+
+"request the results of the last enqueued step of every device (`want`: mask of ALMPC_WANT_*); returns the group's ticket"
+function group_results_async(g::HipGroup, want::Integer)
+    t = ccall((:almpc_group_get_results_async, libalmpc), Cint, (Ptr{Cvoid}, UInt32), g.group, want)
+    t < 0 && gcheck(g.group, t)
+    return t
+end
+"wait for a ticket of `group_results_async` and gather into the caller's arrays (any may be `nothing`); returns the status vector"
+function group_results_wait!(g::HipGroup, ticket::Integer; x = nothing, e_x = nothing, u = nothing, e_u = nothing, u0 = nothing)
+    nx, nu = g.n * (g.N + 1) * g.batch, g.m * g.N * g.batch
+    for (name, a, want) in (("x", x, nx), ("e_x", e_x, nx), ("u", u, nu), ("e_u", e_u, nu), ("u0", u0, g.m * g.batch))
+        a === nothing || length(a) == want || throw(DimensionMismatch("$name holds $(length(a)) values, the group writes $want"))
+    end
+    status = Vector{Int32}(undef, g.batch)
+    pf(a) = a === nothing ? Ptr{Float64}(C_NULL) : pointer(a)
+    GC.@preserve x e_x u e_u u0 gcheck(g.group, ccall((:almpc_group_get_results_wait, libalmpc), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}),
+        g.group, ticket, pf(x), pf(e_x), pf(u), pf(e_u), pf(u0), status, C_NULL, C_NULL))
+    return throw_on_status(status; strict = g.opts.polish != 0)
 end
 
 # the name BASELINE.json uses; absent from the reference (SURVEY.md section 0): one batched step, host in / host out
