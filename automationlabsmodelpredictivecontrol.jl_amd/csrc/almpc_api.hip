@@ -115,6 +115,7 @@ struct almpc_handle {
         double *gS = nullptr;     // [nz] unscaled input-rate gradient 2 D'Sbar D u_ref of the shared reference
         bool have_prev = false;   // a step has been solved since setup: its inputs can seed the next step's working set
         double *u0 = nullptr, *xnext = nullptr;   // [batch][m] applied inputs, [batch][n] next states (almpc_relin_fnn_advance)
+        double *Ascr = nullptr, *Bscr = nullptr;  // Jacobian outputs of the advance's forward pass (not used)
         float ms_jac = 0, ms_design = 0, ms_step = 0;  // last timed step (almpc_relin_fnn_step with timing)
         hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     } relin;
@@ -129,6 +130,7 @@ struct almpc_handle {
     int* dUnsolved = nullptr;      // the device's address of it
     int unsolved_seen = 0;
     bool lazy_pending = false;
+    bool flag_in_finish = false;   // transient (re-linearisation step): the finish turns a flagged design into ALMPC_NON_FINITE itself
     int fallback = 2;   // 0 off, 1 asked for (a design it cannot serve is an error), 2 default: on wherever the stage-wise solvers cover the design
     double *rQ = nullptr, *rR = nullptr, *rP = nullptr, *rKst = nullptr, *rPst = nullptr;   // device copies of Q, R (branch rule applied), shared P; gain scratch
     double* rGuess = nullptr;   // [batch][N][m] start of the next structured solve (almpc_set_start_from / opts.warm_start), else nullptr
@@ -273,7 +275,7 @@ void free_all(almpc_handle* h) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : {(void*)h->relin.W_in, (void*)h->relin.W_h, (void*)h->relin.b_h, (void*)h->relin.W_out, (void*)h->relin.ulin,
-                    (void*)h->relin.Q, (void*)h->relin.R, (void*)h->relin.S, (void*)h->relin.gS, (void*)h->relin.u0, (void*)h->relin.xnext})
+                    (void*)h->relin.Q, (void*)h->relin.R, (void*)h->relin.S, (void*)h->relin.gS, (void*)h->relin.u0, (void*)h->relin.xnext, (void*)h->relin.Ascr, (void*)h->relin.Bscr})
         if (p) (void)hipFree(p);
     for (auto& e : h->relin.ev)
         if (e) (void)hipEventDestroy(e);
@@ -742,7 +744,7 @@ int resolve_lazy_redo(almpc_handle* h) {
     if (cur == h->unsolved_seen) return ALMPC_OK;
     h->unsolved_seen = cur;
     if (h->sd.ready) {
-        if (h->relin.ready) HIP_TRY(h, launch_sgains(h, 1));   // (the last step's linearisations are still in the model slots)
+        if (h->sd.per_instance) HIP_TRY(h, launch_sgains(h, 1));   // (the last step's models are still in the model slots)
         HIP_TRY(h, launch_sdual(h, 1, h->dU, 0, true));
     }
     if (h->mc == 0 && !h->useS && h->rKst) HIP_TRY(h, launch_riccati(h, 1, h->dU, 0));
@@ -1155,8 +1157,13 @@ void launch_batched_factor(almpc_handle* h, const DesignStrides& ds, double rho,
     const size_t inv_lds = 520 * sizeof(double);
     launch_design_inverse(dim3(1, gb), inv_lds, st, nz, nzs, h->bHs, 0.0, (const double*)nullptr, h->bG, h->bFlag, ds.Hs, 0L, ds.G, 1L);
     if (h->skip_admm) return;  // no ADMM phase in this solve: its KKT inverse is not needed
-    hipLaunchKernelGGL(k_design_rho, dim3(1, gb), dim3(256), 0, st, nz, nzs, h->rho_mode, rho, h->bG, h->bRho, ds.G, ds.rho);
-    launch_design_inverse(dim3(1, gb), inv_lds, st, nz, nzs, h->bHs, sigma, (const double*)h->bRho, h->bMinv, h->bFlag, ds.Hs, ds.rho, ds.Minv, 1L);
+    if (design_inverse_makes_rho(nz, nzs))   // the penalty profile is made inside the inverse's own launch
+        launch_design_inverse(dim3(1, gb), inv_lds, st, nz, nzs, h->bHs, sigma, (const double*)nullptr, h->bMinv, h->bFlag, ds.Hs, ds.rho, ds.Minv, 1L,
+                              h->bG, ds.G, h->rho_mode, rho, h->bRho);
+    else {
+        hipLaunchKernelGGL(k_design_rho, dim3(1, gb), dim3(256), 0, st, nz, nzs, h->rho_mode, rho, h->bG, h->bRho, ds.G, ds.rho);
+        launch_design_inverse(dim3(1, gb), inv_lds, st, nz, nzs, h->bHs, sigma, (const double*)h->bRho, h->bMinv, h->bFlag, ds.Hs, ds.rho, ds.Minv, 1L);
+    }
 }
 
 DesignStrides batched_strides(const almpc_handle* h, bool p_inst) {
@@ -1254,10 +1261,14 @@ hipError_t launch_batched_design(almpc_handle* h, const DesignStrides& ds, int u
     const unsigned gb = (unsigned)h->batch;
     hipStream_t st = h->stream;
     const size_t inst_lds = design_instance_lds_doubles(n, m, N) * sizeof(double);
-    hipError_t e = hipMemsetAsync(h->bFlag, 0, (size_t)h->batch * sizeof(int), st);
-    if (e != hipSuccess) return e;
+    hipError_t e = hipSuccess;
+    if (inst_lds > 160 * 1024) {   // (the LDS route below clears the flags itself)
+        e = hipMemsetAsync(h->bFlag, 0, (size_t)h->batch * sizeof(int), st);
+        if (e != hipSuccess) return e;
+    }
     if (inst_lds <= 160 * 1024) {  // structured route: H_i, F_i from the Toeplitz blocks in LDS, no Gamma panels in HBM
         DesignInstParams dp;
+        dp.flag = h->bFlag; dp.sFlag = 1;
         dp.n = n; dp.m = m; dp.N = N; dp.nz = nz; dp.useR = useR; dp.useS = useS;
         dp.A = h->bA; dp.B = h->bB; dp.P = h->bP; dp.sA = ds.A; dp.sB = ds.B; dp.sP = ds.P;
         dp.Q = dQ; dp.R = dR; dp.S = dS; dp.H = h->bH; dp.F = h->bF; dp.sH = ds.H; dp.sF = ds.F;
@@ -1500,11 +1511,11 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
     if (h->fallback && !ltv) {
         h->r_batched_P = true; h->rP_stride = p_inst ? (long)n * n : 0;
         if (sdual_shape_ok(n, m, N, useS != 0)) {
-            // stage records of every instance now (the models stay): one stage when the terminal weight is the instance's own DARE solution
+            // (one stage of records per instance when the terminal weight is the instance's own DARE solution)
             const int rc_ = sdual_setup_batched(h, Qm, Rm, useS ? &Sm : nullptr, P == nullptr && !useS,
                                                 h->boxmin.empty() ? nullptr : h->boxmin.data(), h->boxmax.empty() ? nullptr : h->boxmax.data(), h->terminal_eq != 0);
             if (rc_ != ALMPC_OK && h->fallback == 1) return rc_;
-            if (rc_ == ALMPC_OK) { HIP_TRY(h, launch_sgains(h, 0)); HIP_TRY(h, hipStreamSynchronize(h->stream)); }
+            // (the stage records are computed when a step leaves instances to redo, for those instances only: nothing here)
         } else if (h->fallback == 1 && (h->mc > 0 || useS))
             return fail(h, ALMPC_ERR_UNSUPPORTED, "structured fallback: state rows / input-rate weight need n + m <= 48 and (N + 1)(n + m) <= 4096");
         if (riccati_shape_ok(h) && h->mc == 0 && !useS) {
@@ -1747,12 +1758,19 @@ int almpc_relin_fnn_step_async(almpc_handle* h, const almpc_opts* opts) {
     almpc_default_opts(&o2);
     if (opts) o2 = *opts;
     o2.warm_start = 0;   // (the per-instance ADMM's own warm start is not what a warm step of this pipeline means)
+    // an instance whose design was flagged gets ALMPC_NON_FINITE: by the finish itself when it is polish_body (input box only), else by
+    // a launch of its own behind the step
+    const bool fold_flag = h->mc == 0 && o2.polish != 0;
+    h->flag_in_finish = fold_flag;
     const int rc = almpc_calculate_async(h, &o2);
+    h->flag_in_finish = false;
     h->skip_admm = 0;
     if (rc != ALMPC_OK) { h->designed = false; return rc; }   // (no step ran on this step's designs: the handle is not left "designed")
     q.have_prev = true;
-    hipLaunchKernelGGL(k_flag_to_status, dim3((h->batch + 255) / 256), dim3(256), 0, st, h->batch, h->bFlag, h->dStatus);
-    HIP_TRY(h, hipGetLastError());
+    if (!fold_flag) {
+        hipLaunchKernelGGL(k_flag_to_status, dim3((h->batch + 255) / 256), dim3(256), 0, st, h->batch, h->bFlag, h->dStatus);
+        HIP_TRY(h, hipGetLastError());
+    }
     if (timing) HIP_TRY(h, hipEventRecord(q.ev[3], st));
     return ALMPC_OK;
 }
@@ -1778,7 +1796,10 @@ int almpc_relin_fnn_advance(almpc_handle* h) {
     fp.n = n; fp.m = m; fp.H = q.H; fp.L = q.L; fp.act = q.act; fp.batch = h->batch;
     fp.W_in = q.W_in; fp.W_h = q.W_h; fp.b_h = q.b_h; fp.W_out = q.W_out;
     fp.x = h->dX0; fp.u = q.u0; fp.ppi = 1; fp.xs_group = n; fp.us_group = m;
-    fp.A = h->bA; fp.B = h->bB; fp.f = q.xnext;   // (the Jacobian slots are scratch here: the next step re-linearises at the new state)
+    // (the Jacobians of the forward pass go to a scratch of their own: the model slots keep the last step's linearisations, which a
+    // lazily deferred redo of that step still needs)
+    if (!q.Ascr) { HIP_TRY(h, dalloc(&q.Ascr, (size_t)h->batch * n * n)); HIP_TRY(h, dalloc(&q.Bscr, (size_t)h->batch * n * m)); }
+    fp.A = q.Ascr; fp.B = q.Bscr; fp.f = q.xnext;
     HIP_TRY(h, launch_fnn_jacobian(fp, h->num_cus, st));
     if (h->io.x0_slot >= 0) {   // a pinned x0 slot was read once more by the forward pass: free for the host only after it
         HIP_TRY(h, hipEventRecord(h->io.ev_used[h->io.x0_slot], st));
@@ -2470,6 +2491,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         pp.yflags = keep_state ? nullptr : h->dYflags; pp.yflag_words = h->nrb;
         pp.sglobal = h->dSglobal; pp.perm = h->dPerm; pp.ntiles = (h->batch + 15) / 16;
         pp.max_iter = o.polish_max_iter > 0 ? o.polish_max_iter : 2 * h->nz + 50;
+        pp.dflag = h->flag_in_finish ? h->bFlag : nullptr;
         if (lazy_redo) {
             if (!h->hUnsolved) {
                 HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->hUnsolved), sizeof(int), hipHostMallocMapped));
@@ -2595,7 +2617,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
     if (lazy_redo) h->lazy_pending = true;   // (resolve_lazy_redo at the next host sync point)
     else if (h->fallback && !h->ltv && o.polish) {
         if (h->sd.ready && !getenv("ALMPC_DBG_NO_SDUAL_FB")) {
-            if (h->relin.ready) HIP_TRY(h, launch_sgains(h, 1));   // (this step's linearisations, unsolved instances only)
+            if (h->sd.per_instance) HIP_TRY(h, launch_sgains(h, 1));   // (stage records of the unsolved instances only, from the models of this step)
             HIP_TRY(h, launch_sdual(h, 1, h->dU, 0, true));
         }
         if (h->mc == 0 && !h->useS && h->rKst && !getenv("ALMPC_DBG_NO_PRIMAL_NET")) HIP_TRY(h, launch_riccati(h, 1, h->dU, 0));

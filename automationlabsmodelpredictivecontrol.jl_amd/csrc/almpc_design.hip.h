@@ -442,9 +442,14 @@ __device__ long long g_inv_dbg[16];
 #else
 #define INV_W(N_)
 #endif
+// rho_G != null: the penalty profile of the ADMM is made HERE instead of by a launch of its own (k_design_rho: 4.6 us of a 190 us
+// re-linearisation step): rho_i = rho_mode ? rho / G_ii : rho from the inverse rho_G of the first call, written to rho_out and used as
+// the diagonal shift of this one.
 template <int NCOL>
 __global__ __launch_bounds__(256) void k_design_inverse_wave(int nz, int nzs, int batch, const double* Hs, double cshift, const double* dshift,
-                                                             double* Out, int* flag, long sHs, long sShift, long sOut, long sFlag) {
+                                                             double* Out, int* flag, long sHs, long sShift, long sOut, long sFlag,
+                                                             const double* rho_G = nullptr, long sRhoG = 0, int rho_mode = 0, double rho = 0.0,
+                                                             double* rho_out = nullptr) {
     constexpr int PB = 8;
     static_assert(NCOL % PB == 0 && NCOL > PB, "column count: a multiple of the pivot block");
     __shared__ __attribute__((aligned(16))) double wbuf_all[4][2][64];
@@ -461,7 +466,13 @@ __global__ __launch_bounds__(256) void k_design_inverse_wave(int nz, int nzs, in
     // kernel took for 40 x 40 matrices)
     INV_W(0);
     const int ic = i < nz ? i : nz - 1;
-    const double shift = cshift + (dshift ? dshift[ic] : 0.0);
+    double shift = cshift + (dshift ? dshift[ic] : 0.0);
+    if (rho_G) {
+        const double gii = rho_G[(size_t)inst * sRhoG + (size_t)ic * nzs + ic];
+        const double rv = rho_mode == 1 ? rho / gii : rho;
+        if (i < nzs) rho_out[(size_t)inst * sShift + i] = i < nz ? rv : 1.0;   // (pad rows 1, as k_design_rho)
+        shift = cshift + rv;
+    }
 #pragma unroll
     for (int c = 0; c < NCOL; ++c) S[c] = Hs[(size_t)(c < nz ? c : nz - 1) * nzs + ic];
 #pragma unroll
@@ -703,12 +714,15 @@ __global__ __launch_bounds__(64 * (128 / CW)) void k_design_inverse_c32(int nz, 
 }
 
 // launcher: the smallest register tile that holds the matrix
+// whether launch_design_inverse makes the ADMM penalty profile itself (rho_G given): the one-wave kernel does, the others need k_design_rho first
+inline bool design_inverse_makes_rho(int nz, int nzs) { return nz <= 64 && nzs <= 64 && !getenv("ALMPC_INV_TILE") && !getenv("ALMPC_NO_RHO_FUSION"); }
 inline void launch_design_inverse(dim3 grid, size_t lds, hipStream_t st, int nz, int nzs, const double* Hs, double cshift, const double* dshift,
-                                  double* Out, int* flag, long sHs, long sShift, long sOut, long sFlag) {
+                                  double* Out, int* flag, long sHs, long sShift, long sOut, long sFlag,
+                                  const double* rho_G = nullptr, long sRhoG = 0, int rho_mode = 0, double rho = 0.0, double* rho_out = nullptr) {
     if (nz <= 64 && !getenv("ALMPC_INV_TILE")) {   // one wave per matrix (grid.y = matrices, as for the tile kernels)
         const int b = (int)grid.y;
         const dim3 g2((unsigned)((b + 3) / 4));
-#define INV_WAVE(NC_) hipLaunchKernelGGL((k_design_inverse_wave<NC_>), g2, dim3(256), 0, st, nz, nzs, b, Hs, cshift, dshift, Out, flag, sHs, sShift, sOut, sFlag)
+#define INV_WAVE(NC_) hipLaunchKernelGGL((k_design_inverse_wave<NC_>), g2, dim3(256), 0, st, nz, nzs, b, Hs, cshift, dshift, Out, flag, sHs, sShift, sOut, sFlag, rho_G, sRhoG, rho_mode, rho, rho_out)
         if (nz <= 16) INV_WAVE(16); else if (nz <= 32) INV_WAVE(32); else if (nz <= 48) INV_WAVE(48); else INV_WAVE(64);
 #undef INV_WAVE
     } else if (nz <= 64) hipLaunchKernelGGL((k_design_inverse_t<2, 8>), grid, dim3(DESIGN_INVERSE_THREADS), lds, st, nz, nzs, Hs, cshift, dshift, Out, flag, sHs, sShift, sOut, sFlag);

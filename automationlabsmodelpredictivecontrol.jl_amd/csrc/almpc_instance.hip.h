@@ -540,6 +540,8 @@ struct DesignInstParams {
     const double* A; const double* B; const double* P; long sA, sB, sP;   // per instance
     const double* Q; const double* R; const double* S;                     // shared
     double* H; double* F; long sH, sF;                                     // column-major nz x nz, nz x n
+    int* flag = nullptr; long sFlag = 0;                                   // design flag of the instance: cleared here when given (instead of
+                                                                           // by a memset launch in front of every re-design)
 };
 
 __host__ __device__ inline size_t design_instance_lds_doubles(int n, int m, int N) {
@@ -571,6 +573,7 @@ __global__ __launch_bounds__(256) void k_design_instance_t(DesignInstParams p) {
     double* E = PG + (size_t)N * nm;           // [N][m*n]: E_a (then prefix sums), element (p, j) at [j*m + p]
     double* EP = E + (size_t)N * nm;           // E^P_a
     const int T = blockDim.x;
+    if (p.flag && threadIdx.x == 0) p.flag[blockIdx.x * p.sFlag] = 0;
     for (int t = threadIdx.x; t < nn; t += T) { As[t] = A[t]; Qs[t] = p.Q[t]; Ps[t] = P[t]; Phi[t] = (t % n == t / n) ? 1.0 : 0.0; }
     for (int t = threadIdx.x; t < nm; t += T) Bs[t] = B[t];
     __syncthreads();

@@ -486,6 +486,7 @@ struct PolishParams {
                          // word beside the queue counter) and otherwise falls back to the global scratch
     int g_off;           // k_polish_sgl: offset of the wave's copy of its instance's G_i (nz rows of nzs doubles)
     int max_iter;
+    const int* dflag = nullptr;   // design flags (or null): an instance whose flag is set leaves with ALMPC_NON_FINITE (re-linearisation pipeline)
     int* unsolved = nullptr;  // host-visible counter (or null): += 1 for every instance that leaves the finish with status != 0 (lazy redo, almpc_api.hip)
     int direct = 0;      // k_step_inst_wave: workgroup (= wave) b finishes instance b itself (no perm lookup)
     int fuse_rollout;    // 1: this kernel also produces u, e_u, x, e_x (roll.*), no separate k_rollout launch; 2: u, e_u only;
@@ -1483,6 +1484,7 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
             GL(p.status)[inst] = (fin == 0) ? 0 : st_in;
         }
     }
+    if (p.dflag && lane == 0 && GL(p.dflag)[inst] != 0) GL(p.status)[inst] = 2;   // (after the finish's own status write, same lane)
     if (!p.fuse_rollout) {
         if (inrow) *reinterpret_cast<d2*>(GL(p.w) + base + r0) = wout;
         return;
