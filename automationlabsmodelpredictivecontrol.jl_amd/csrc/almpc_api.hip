@@ -697,7 +697,7 @@ hipError_t launch_sdual_t(almpc_handle* h, SdualParams sp, int tier0, int tier1)
 
 // k_sdual over the batch (filter 0), over the instances whose status is not 0 (filter 1: redo after the condensed path), start from
 // `guess` (inputs [batch][N][m]) when given
-hipError_t launch_sdual(almpc_handle* h, int filter, const double* guess, int max_iter, bool single_launch = false) {
+hipError_t launch_sdual(almpc_handle* h, int filter, const double* guess, int max_iter, bool single_launch = false, int first_tier = 0) {
     const almpc_handle::Sd& sd = h->sd;
     if (!sd.ready) return hipErrorInvalidValue;
     SdualParams sp;
@@ -727,7 +727,7 @@ hipError_t launch_sdual(almpc_handle* h, int filter, const double* guess, int ma
     const int rows = h->N * h->m + ((sd.has_box || sd.has_eq) ? h->N * h->n : 0);
     sp.max_iter = max_iter > 0 ? max_iter : 20 * rows + 50;
     sp.tol = 1e-9;
-    const int tier0 = single_launch ? 1 : 0, tier1 = single_launch ? 1 : 3;
+    const int tier0 = single_launch ? 1 : first_tier, tier1 = single_launch ? 1 : 3;   // (first_tier 1: starts that are known to hold many rows)
 #define SD_CASE(NT_, MC_) if (sd.NT == NT_ && sd.MC == MC_) return launch_sdual_t<NT_, MC_>(h, sp, tier0, tier1)
     SD_CASE(2, 2); SD_CASE(4, 2); SD_CASE(6, 2); SD_CASE(8, 4); SD_CASE(12, 4); SD_CASE(16, 4); SD_CASE(16, 8); SD_CASE(32, 16); SD_CASE(48, 16);
 #undef SD_CASE
@@ -2069,13 +2069,16 @@ int almpc_sqp_fnn_iterate(almpc_handle* h, int iters, double step_scale, const a
         HIP_TRY(h, hipMemsetAsync(h->bFlag, 0, b * sizeof(int), st));
         if (q.structured_qp) {   // the QP in its stage-wise form for every instance; start: v = 0 (working set = the iterate's inputs on a bound)
             h->designed = true;
-            if (h->sd.ready) {
-                HIP_TRY(h, launch_sgains(h, 0));
-                HIP_TRY(h, launch_sdual(h, 0, h->dUref, opts ? opts->polish_max_iter : 0));
-                // (what the dual method leaves without a certificate -- saturated unstable linearisations -- goes to the primal one)
-                if (h->mc == 0 && !q.useS && h->rKst) HIP_TRY(h, launch_riccati(h, 2, h->dUref, 0));
-            } else
+            // input box without S: the primal Riccati active set (an iterate of this loop has about half of its inputs on a bound: rows a
+            // primal method holds at no cost, while the dual one pays a sweep per row of its start -- measured 0.56 against 3.1 ms per
+            // iteration at the configs[4] shape); with state rows / S: k_sgains + k_sdual
+            if (h->mc == 0 && !q.useS && h->rKst)
                 HIP_TRY(h, launch_riccati(h, 3, h->dUref, opts ? opts->polish_max_iter : 0));
+            else if (h->sd.ready) {
+                HIP_TRY(h, launch_sgains(h, 0));
+                HIP_TRY(h, launch_sdual(h, 0, h->dUref, opts ? opts->polish_max_iter : 0, false, h->nz > 48 ? 1 : 0));
+            } else
+                return fail(h, ALMPC_ERR_UNSUPPORTED, "sqp_fnn_iterate: no stage-wise QP solver for this design");
             q.since_start += 1;
             sp.stats = q.stats + 2 * it;
             hipLaunchKernelGGL(k_sqp_step, dim3((unsigned)b), dim3(256), step_lds, st, sp);

@@ -186,20 +186,15 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
     const bool has_box = p.xmin != nullptr, has_eq = p.eqt != nullptr, with_c = p.pc != nullptr;
 
     double r1[NT], sb[MC], r2[NT], r3[MC];
-    auto load_bw = [&](const double* recg, int k) {
-        const double* rk = recg + (size_t)k * p.rec_kstride + (size_t)rrow * RL;
+    auto load_half = [&](const double* recg, int k, int off, double* a, double* b) {   // one half of a record row: [NT | MC] doubles
+        const double* rk = recg + (size_t)k * p.rec_kstride + (size_t)rrow * RL + off;
 #pragma unroll
-        for (int j = 0; j < NT; j += 2) { const double2 t = *reinterpret_cast<const double2*>(rk + j); r1[j] = t.x; r1[j + 1] = t.y; }
+        for (int j = 0; j < NT; j += 2) { const double2 t = *reinterpret_cast<const double2*>(rk + j); a[j] = t.x; a[j + 1] = t.y; }
 #pragma unroll
-        for (int j = 0; j < MC; j += 2) { const double2 t = *reinterpret_cast<const double2*>(rk + NT + j); sb[j] = t.x; sb[j + 1] = t.y; }
+        for (int j = 0; j < MC; j += 2) { const double2 t = *reinterpret_cast<const double2*>(rk + NT + j); b[j] = t.x; b[j + 1] = t.y; }
     };
-    auto load_fw = [&](const double* recg, int k) {
-        const double* rk = recg + (size_t)k * p.rec_kstride + (size_t)rrow * RL + NT + MC;
-#pragma unroll
-        for (int j = 0; j < NT; j += 2) { const double2 t = *reinterpret_cast<const double2*>(rk + j); r2[j] = t.x; r2[j + 1] = t.y; }
-#pragma unroll
-        for (int j = 0; j < MC; j += 2) { const double2 t = *reinterpret_cast<const double2*>(rk + NT + j); r3[j] = t.x; r3[j + 1] = t.y; }
-    };
+    auto load_bw = [&](const double* recg, int k) { load_half(recg, k, 0, r1, sb); };
+    auto load_fw = [&](const double* recg, int k) { load_half(recg, k, NT + MC, r2, r3); };
     if (!kvar && p.rec_stride == 0) { load_bw(p.rec, 0); load_fw(p.rec, 0); }
 
     const int nwaves = gridDim.x * wpb;
@@ -344,8 +339,12 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
                     double wrote = 0.0;   // the value the previous stage wrote to LDS: kept in a register of its own until this stage's
                                           // products are done, so that no accumulator is allocated over the source of a write in flight
                                           // (a write-after-read wait of one LDS latency per stage otherwise)
+                    // stage-varying records: the NEXT stage's rows are requested before this stage's products (one L2 latency per
+                    // stage otherwise: 3.1 ms per SQP iteration at the configs[4] shape)
+                    double n1[NT], nb[MC];
+                    if (GEN && kvar && kstart >= 0) load_bw(recg, kstart);
                     for (int k = kstart; k >= 0; --k) {
-                        if (GEN && kvar) load_bw(recg, k);
+                        if (GEN && kvar) load_half(recg, k > 0 ? k - 1 : 0, 0, n1, nb);
                         const double own_next = w[(k > 0 ? k - 1 : 0) * SP + lsl];
                         double acc0 = st_l ? own : 0.0, acc1 = 0.0;
                         sd_dot_bcast<0, NT>(acc0, acc1, pv, r1);
@@ -360,6 +359,12 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
                         if (!st_l && wr_l) w[k * SP + l16] = out;   // kff_k over the consumed input sources
                         wrote = out;
                         pv = st_l ? out : 0.0;
+                        if (GEN && kvar) {
+#pragma unroll
+                            for (int j = 0; j < NT; ++j) r1[j] = n1[j];
+#pragma unroll
+                            for (int j = 0; j < MC; ++j) sb[j] = nb[j];
+                        }
                     }
                     sd_fence();
 #ifdef ALMPC_STAMPS
@@ -369,8 +374,9 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
                     double xv = st_l ? ((full_problem && l16 < n) ? e0l16 : 0.0) : w[lsl];
                     if (wr_l && st_l) w[l16] = xv;
                     wrote = 0.0;
+                    if (GEN && kvar && kend > 0) load_fw(recg, 0);
                     for (int k = 0; k < kend; ++k) {
-                        if (GEN && kvar) load_fw(recg, k);
+                        if (GEN && kvar) load_half(recg, k + 1 < N ? k + 1 : k, NT + MC, n1, nb);
                         const double kf_next = w[(k + 1 < kend ? k + 1 : k) * SP + lsl];
                         double acc0 = (GEN && use_c && st_l) ? ctg[(size_t)k * NT + l16] : 0.0, acc1 = 0.0;
                         sd_dot_bcast<0, NT>(acc0, acc1, xv, r2);
@@ -381,6 +387,12 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
                         asm volatile("" :: "v"(xv) : "memory");   // (as in the backward loop: consume the read, then write)
                         if (wr_l) w[(st_l ? (k + 1) * SP : k * SP) + l16] = out;
                         wrote = out;
+                        if (GEN && kvar) {
+#pragma unroll
+                            for (int j = 0; j < NT; ++j) r2[j] = n1[j];
+#pragma unroll
+                            for (int j = 0; j < MC; ++j) r3[j] = nb[j];
+                        }
                     }
                     sd_fence();
                     SD_ACC(1);

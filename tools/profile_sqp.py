@@ -19,7 +19,9 @@ X0 = xr[:, 0][None, :] + 0.6 * mo.splitmix_normal(0x5EED0005, 0, bq, nq)
 Al, Bl = f.jacobian(xr[:, -1], ur[:, -1])
 P = mo.dare(Al, Bl, 100.0 * np.eye(nq), 0.1 * np.eye(mq))
 s = capi.Solver(nq, mq, Nq, bq)
-s.sqp_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, xr, ur, 100.0 * np.eye(nq), 0.1 * np.eye(mq), None, P, -np.ones(mq), np.ones(mq), act="tanh")
+# env QP=structured: every iteration's QP in its stage-wise form (k_sgains + k_sdual) instead of the condensed design
+s.sqp_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, xr, ur, 100.0 * np.eye(nq), 0.1 * np.eye(mq), None, P, -np.ones(mq), np.ones(mq), act="tanh",
+                qp_solver=os.environ.get("QP", "condensed"))
 import time
 for rep in range(3):
     s.sqp_fnn_start(X0)
