@@ -727,7 +727,14 @@ hipError_t launch_sdual(almpc_handle* h, int filter, const double* guess, int ma
     const int rows = h->N * h->m + ((sd.has_box || sd.has_eq) ? h->N * h->n : 0);
     sp.max_iter = max_iter > 0 ? max_iter : 20 * rows + 50;
     sp.tol = 1e-9;
-    const int tier0 = single_launch ? 1 : first_tier, tier1 = single_launch ? 1 : 3;   // (first_tier 1: starts that are known to hold many rows)
+    // single launch (the redo behind a condensed step: few instances, occupancy does not matter): the 128-row build when its Sinv fits
+    // LDS beside the trajectories, else the 64-row one.  first_tier 1: starts that are known to hold many rows
+    int tier0 = first_tier, tier1 = 3;
+    if (single_launch) {
+        int NT_ = sd.NT, MC_ = sd.MC;
+        const bool fits128 = (size_t)sdual_lds_doubles(NT_, MC_, h->N, SD_WCAP4, true) * sizeof(double) <= 160 * 1024;
+        tier0 = tier1 = fits128 ? 2 : 1;
+    }
 #define SD_CASE(NT_, MC_) if (sd.NT == NT_ && sd.MC == MC_) return launch_sdual_t<NT_, MC_>(h, sp, tier0, tier1)
     SD_CASE(2, 2); SD_CASE(4, 2); SD_CASE(6, 2); SD_CASE(8, 4); SD_CASE(12, 4); SD_CASE(16, 4); SD_CASE(16, 8); SD_CASE(32, 16); SD_CASE(48, 16);
 #undef SD_CASE

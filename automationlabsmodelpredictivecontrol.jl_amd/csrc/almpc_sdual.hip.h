@@ -41,7 +41,7 @@ struct SdualParams {
     const double* eqt; long eqt_stride;                // [n] terminal equality target for x_N in ABSOLUTE coordinates (the state reference of stage N), or null
     const double* x0; const double* xref; long xref_stride;   // e_0 = x0 - xref_0 (x0 null: e_0 = 0); x = e + xref
     const double* uguess;                              // [batch][N][m] inputs whose bounds seed the working set, or null
-    int filter;                                        // 0 all instances; 1 status != 0; 2 status != 0 or flag != 0 (flag cleared when solved)
+    int filter;                                        // 0 all instances; 1 status == 1 (no verdict yet); 2 status != 0 or flag != 0 (flag cleared when solved)
     int* flag;
     int v_only;                                        // 1: write e_u, status, piters only
     double* x; double* ex; double* u; double* eu;      // results, layouts of almpc_get_results
@@ -210,7 +210,9 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
         asm volatile("" : "+v"(lane));
         if (p.only_ovf) {
             if (p.ovf[inst] == 0) continue;
-        } else if ((p.filter == 1 && p.status[inst] == 0) || (p.filter == 2 && p.status[inst] == 0 && p.flag[inst] == 0)) {
+        } else if ((p.filter == 1 && p.status[inst] != 1) || (p.filter == 2 && p.status[inst] == 0 && p.flag[inst] == 0)) {
+            // (filter 1 redoes what was left WITHOUT a verdict: status 1.  Solved (0) and infeasible (3) instances are decided, a
+            // non-finite one (2) has nothing to solve)
             if (p.ovf && lane == 0) p.ovf[inst] = 0;
             continue;
         }
@@ -926,7 +928,7 @@ __global__ __launch_bounds__(64 * SGAINS_WAVES) void k_sgains(SgainsParams p) {
     double* Lam = Ks + nm;   double* Li = Lam + mm;   double* Rt = Li + mm;   double* cv = Rt + mm;
     const int wpb = (int)(blockDim.x >> 6), nwaves = gridDim.x * wpb;
     for (int inst = blockIdx.x * wpb + wv; inst < p.batch; inst += nwaves) {
-        if ((p.filter == 1 && p.status[inst] == 0) || (p.filter == 2 && p.status[inst] == 0 && p.flag[inst] == 0)) continue;
+        if ((p.filter == 1 && p.status[inst] != 1) || (p.filter == 2 && p.status[inst] == 0 && p.flag[inst] == 0)) continue;
         const double* Ag = p.A + (size_t)inst * p.A_stride;
         const double* Bg = p.B + (size_t)inst * p.B_stride;
         const double* Pg = p.P + (size_t)inst * p.P_stride;
