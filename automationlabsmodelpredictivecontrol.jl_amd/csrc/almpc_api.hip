@@ -130,6 +130,8 @@ struct almpc_handle {
     int* dUnsolved = nullptr;      // the device's address of it
     int unsolved_seen = 0;
     bool lazy_pending = false;
+    bool redo_x0_from_results = false;   // set around the launches of a lazy redo: x0 = stage 1 of the step's own x (the caller may have
+                                         // handed over the next x0 since)
     bool flag_in_finish = false;   // transient (re-linearisation step): the finish turns a flagged design into ALMPC_NON_FINITE itself
     int fallback = 2;   // 0 off, 1 asked for (a design it cannot serve is an error), 2 default: on wherever the stage-wise solvers cover the design
     double *rQ = nullptr, *rR = nullptr, *rP = nullptr, *rKst = nullptr, *rPst = nullptr;   // device copies of Q, R (branch rule applied), shared P; gain scratch
@@ -411,7 +413,8 @@ hipError_t launch_riccati(almpc_handle* h, int filter, const double* guess, int 
     if (!rp.Q || !rp.R || !rp.P || !h->rKst) return hipErrorInvalidValue;   // no riccati_weights() for this design: nothing to launch with
     rp.umin = h->dUmin; rp.umax = h->dUmax;
     rp.uref = h->dUref; rp.uref_stride = h->uref_stride; rp.xref = h->dXref; rp.xref_stride = h->xref_stride;
-    rp.x0 = h->dX0; rp.uguess = guess; rp.filter = filter; rp.Kst = h->rKst; rp.Pst = h->rPst;
+    rp.x0 = h->dX0; rp.x0_stride = h->n; rp.uguess = guess; rp.filter = filter; rp.Kst = h->rKst; rp.Pst = h->rPst;
+    if (h->redo_x0_from_results) { rp.x0 = h->dX; rp.x0_stride = (long)h->n * (h->N + 1); }   // (lazy redo: see resolve_lazy_redo)
     rp.x = h->dX; rp.ex = h->dEx; rp.u = h->dU; rp.eu = h->dEu; rp.status = h->dStatus; rp.piters = h->dPiters;
     rp.max_iter = max_iter > 0 ? max_iter : 20 * h->N * h->m + 50;
     rp.tol = 1e-9;
@@ -710,7 +713,8 @@ hipError_t launch_sdual(almpc_handle* h, int filter, const double* guess, int ma
     sp.xmin = sd.has_box ? sd.xmin : nullptr; sp.xmax = sd.has_box ? sd.xmax : nullptr;
     sp.xbref = h->dXref; sp.xbref_stride = h->xref_stride;
     sp.eqt = sd.has_eq ? h->dXref + (size_t)h->N * h->n : nullptr; sp.eqt_stride = h->xref_stride;   // x_N = x_ref_N
-    sp.x0 = h->dX0; sp.xref = h->dXref; sp.xref_stride = h->xref_stride;
+    sp.x0 = h->dX0; sp.x0_stride = h->n; sp.xref = h->dXref; sp.xref_stride = h->xref_stride;
+    if (h->redo_x0_from_results) { sp.x0 = h->dX; sp.x0_stride = (long)h->n * (h->N + 1); }   // (lazy redo: see resolve_lazy_redo)
     sp.uguess = guess; sp.filter = filter; sp.flag = nullptr; sp.v_only = 0;
     sp.x = h->dX; sp.ex = h->dEx; sp.u = h->dU; sp.eu = h->dEu; sp.status = h->dStatus; sp.piters = h->dPiters;
     if (sd.sqp) {   // dx_0 = 0, variable v = u - ubar (the handle's per-instance references ARE the iterate xbar, ubar), cost terms per instance
@@ -750,6 +754,8 @@ int resolve_lazy_redo(almpc_handle* h) {
     const int cur = *reinterpret_cast<volatile int*>(h->hUnsolved);
     if (cur == h->unsolved_seen) return ALMPC_OK;
     h->unsolved_seen = cur;
+    h->redo_x0_from_results = true;
+    struct Reset { almpc_handle* h; ~Reset() { h->redo_x0_from_results = false; } } reset_{h};
     if (h->sd.ready) {
         if (h->sd.per_instance) HIP_TRY(h, launch_sgains(h, 1));   // (the last step's models are still in the model slots)
         HIP_TRY(h, launch_sdual(h, 1, h->dU, 0, true));
@@ -2306,15 +2312,24 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
     if (o.warm_start && !h->state_valid)
         return fail(h, ALMPC_ERR_INVALID, "calculate: warm_start = 1, but the previous step ran with ALMPC_OPT_NO_WARM_STATE (no ADMM state was kept)");
     // default redo of unsolved instances on the shared-model / input-box-only path: lazily, at the next host sync (see hUnsolved)
-    // (every box-only condensed path ends in the same finish, polish_body, which does the counting: shared model, per-instance models,
-    // re-linearisation pipeline; with state rows unsolved / infeasible instances are common and the steps long: eager there)
-    const bool lazy_redo = h->fallback == 2 && !h->structured && !h->ltv && h->mc == 0 && o.polish != 0 &&
-                           (h->sd.ready || h->rKst) && !getenv("ALMPC_EAGER_REDO");
+    // (every condensed path that is not the SQP loop ends in a finish that does the counting -- polish_body for an input box,
+    // polish_gen_body with state rows --: shared model, per-instance models, re-linearisation pipeline.  Infeasible instances keep
+    // their verdict and are not counted; what is counted is rare -- a handful of edge-of-feasibility instances in 4096 -- and a
+    // stage-wise solve of one of them takes about a millisecond, which an eager redo would put behind every step)
+    const bool lazy_redo = h->fallback == 2 && !h->structured && !h->ltv && o.polish != 0 &&
+                           (h->sd.ready || (h->mc == 0 && h->rKst)) && !getenv("ALMPC_EAGER_REDO");
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->io.big_copy_pending) {   // an asynchronous read-back straight from the result buffers: this step overwrites them
         HIP_TRY(h, hipStreamWaitEvent(h->stream, h->io.ev_big, 0));
         h->io.big_copy_pending = false;
     }
+    auto ensure_unsolved_word = [&]() -> hipError_t {   // the host-visible counter of the lazy redo
+        if (h->hUnsolved) return hipSuccess;
+        hipError_t e_ = hipHostMalloc(reinterpret_cast<void**>(&h->hUnsolved), sizeof(int), hipHostMallocMapped);
+        if (e_ != hipSuccess) { h->hUnsolved = nullptr; return e_; }
+        *h->hUnsolved = 0; h->unsolved_seen = 0;
+        return hipHostGetDevicePointer(reinterpret_cast<void**>(&h->dUnsolved), h->hUnsolved, 0);
+    };
     auto io_step_done = [&]() -> int {   // the x0 slot of an asynchronous update is free again once this step has finished
         h->state_valid = keep_state;     // (recorded only here: every launch of the step went out)
         if (h->io.x0_slot >= 0) {
@@ -2470,6 +2485,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         if (!h->dOverflow) HIP_TRY(h, dalloc(&h->dOverflow, (size_t)h->batch * 33 + 2));   // list, then [batch][32] working sets
         HIP_TRY(h, hipMemsetAsync(h->dOverflow, 0, 2 * sizeof(int32_t), st));
         gp.ovf = h->dOverflow; gp.ovf_ws = h->dOverflow + 2 + h->batch;
+        if (lazy_redo) { HIP_TRY(h, ensure_unsolved_word()); gp.unsolved = h->dUnsolved; }
         const dim3 grid((h->batch + PGEN_WAVES - 1) / PGEN_WAVES), block(64 * PGEN_WAVES);
         // first launch: working sets up to 32 rows, every instance; second launch: the instances the first one flagged, up to 64 rows
         const size_t l32 = (size_t)PGEN_WAVES * pgen_lds_per_wave(32) * sizeof(double);
@@ -2503,11 +2519,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         pp.max_iter = o.polish_max_iter > 0 ? o.polish_max_iter : 2 * h->nz + 50;
         pp.dflag = h->flag_in_finish ? h->bFlag : nullptr;
         if (lazy_redo) {
-            if (!h->hUnsolved) {
-                HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->hUnsolved), sizeof(int), hipHostMallocMapped));
-                *h->hUnsolved = 0; h->unsolved_seen = 0;
-                HIP_TRY(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->dUnsolved), h->hUnsolved, 0));
-            }
+            HIP_TRY(h, ensure_unsolved_word());
             pp.unsolved = h->dUnsolved;
         }
         // rollout fused into the tail of the polish when its trajectory buffer fits the wave's LDS slot

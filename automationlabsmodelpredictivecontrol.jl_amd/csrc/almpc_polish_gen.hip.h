@@ -65,14 +65,15 @@ struct PolishGenParams {
                           // second launch, [2 ...] the flagged instances; [0] and [1] are zeroed before the first launch
     int32_t* ovf_ws;      // [batch][32] working set of a flagged instance when it ran out of room, row | (side + 1) << 12, the
                           // second launch's guess ([0] = -1: none, it builds its guess from the ADMM hand-off as the first did)
+    int* unsolved = nullptr;   // host-visible count of instances left with ALMPC_MAX_ITER (lazy redo, see almpc_handle::hUnsolved), or null
     int max_iter;
     int roll_g, roll_cpl;
     RolloutParams roll;
 };
 
 constexpr int PGEN_WAVES = 4;
-// LDS per wave (doubles): Sinv WL x WL | rowbuf Rs(<=512) | pbufa WL | pbufb WL | wrow_s (WL ints) | Z trajectory shares Sinv
-__host__ __device__ constexpr int pgen_lds_per_wave(int WL) { return WL * WL + 512 + WL + WL + WL / 2; }
+// LDS per wave (doubles): Sinv WL x WL | rowbuf Rs(<=512) | s0buf Rs(<=512) | pbufa WL | pbufb WL | wrow_s (WL ints) | Z trajectory shares Sinv
+__host__ __device__ constexpr int pgen_lds_per_wave(int WL) { return WL * WL + 512 + 512 + WL + WL + WL / 2; }
 
 // Rollout through stage models (time-varying designs): Z rows [dx(k); v(k)], dx(0) in Z[0..n); lane layout as rollout_steps, the
 // stage's coefficients come from global memory and are requested one stage ahead of the chain.
@@ -146,8 +147,13 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
 #ifdef ALMPC_STAMPS
     const int stamp_id = inst + (QUEUE ? p.batch : 0);
 #define PGEN_STAMP(SLOT) ALMPC_STAMP(stamp_id, SLOT)
+    long long pg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pg_t = 0;   // main-loop phase accumulators (second region of the stamp buffer)
+#define PG_T0() do { __builtin_amdgcn_sched_barrier(0); pg_t = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PG_ACC(S) do { __builtin_amdgcn_sched_barrier(0); const long long t_ = __builtin_readcyclecounter(); pg_acc[S] += t_ - pg_t; pg_t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define PGEN_STAMP(SLOT)
+#define PG_T0()
+#define PG_ACC(S)
 #endif
     PGEN_STAMP(0);
     const double* Gh = p.Ghat + (size_t)inst * p.Ghat_stride;
@@ -182,7 +188,8 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
 
     double* Sl = smem + (size_t)wv * pgen_lds_per_wave(WL);
     double* rowbuf = Sl + WL * WL;  // [Rs]
-    double* pbufa = rowbuf + 512;
+    double* s0buf = rowbuf + 512;   // [Rs] s0 (row values of the unconstrained minimiser): read by the confirmation only, so not in registers
+    double* pbufa = s0buf + 512;
     double* pbufb = pbufa + WL;
     int* wrow_s = reinterpret_cast<int*>(pbufb + WL);
     const RolloutParams& rp = p.roll;
@@ -193,12 +200,13 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
 
     // ---- rows of this lane: pairs (2 lane, 2 lane + 1) + 128 q
     int rrow[NP][2];
-    double s0v[NP][2], sv[NP][2], lo[NP][2], hi[NP][2], gn[NP][2];
+    double sv[NP][2], lo[NP][2], hi[NP][2], ign[NP][2];   // ign: 1 / sqrt(Ghat_rr), the violation measure's scale (pad rows: 1)
     unsigned actm = 0, eqm = 0;   // bit 2 q + e: the row is in the working set / is a terminal-equality row
     double y0 = 0, y1 = 0, z0 = 0, z1 = 0;
     bool x0_bad = false;
     // unconstrained minimiser v0 and the box-ADMM iterate (input rows live in pair 0)
     {
+        double s0v[NP][2], gn[NP][2];
         const int rc = (2 * lane < nzs) ? 2 * lane : 0;
         const d2 vv = *reinterpret_cast<const d2*>(p.v0 + base + rc);
         const d2 yy = *reinterpret_cast<const d2*>(p.ys + base + rc);
@@ -305,6 +313,12 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
             eqm = 0;
             wave_fence_lds();
         }
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            d2 v; v[0] = s0v[q][0]; v[1] = s0v[q][1];
+            *reinterpret_cast<d2*>(s0buf + 2 * lane + 128 * q) = v;
+            ign[q][0] = 1.0 / gn[q][0]; ign[q][1] = 1.0 / gn[q][1];
+        }
     }
     x0_bad = __any(x0_bad);
     wave_fence_lds();
@@ -352,10 +366,8 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
             for (int t = 0; t < 8; ++t) Sl[(l0 + HS * t + hf) * WL + pos] = cur[t] + as * av[t];
         }
     };
-    // q[.] = sum_{l<k} Ghat[W_l, rows] * a_l  (a in LDS buffer ab, zero beyond k)
-    auto g_rows_times = [&](const double* ab, double (&qv)[NP][2]) {
-#pragma unroll
-        for (int q = 0; q < NP; ++q) { qv[q][0] = 0.0; qv[q][1] = 0.0; }
+    // (a in LDS buffer ab, zero beyond k)
+    auto g_rows_minus = [&](const double* ab, double (&qv)[NP][2]) {   // qv[.] -= sum_{l<k} Ghat[W_l, rows] * a_l
         for (int l0 = 0; l0 < k; l0 += CH) {   // (all NP * CH loads of a group go out before the first is used)
             d2 g[CH][NP];
             double av[CH];
@@ -373,7 +385,7 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
 #pragma unroll
             for (int t = 0; t < CH; ++t)
 #pragma unroll
-                for (int q = 0; q < NP; ++q) { qv[q][0] += g[t][q][0] * av[t]; qv[q][1] += g[t][q][1] * av[t]; }
+                for (int q = 0; q < NP; ++q) { qv[q][0] -= g[t][q][0] * av[t]; qv[q][1] -= g[t][q][1] * av[t]; }
         }
     };
     auto load_row = [&](int j, double (&gj)[NP][2]) {
@@ -388,34 +400,37 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
         double v = 0.0;
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
-            const double c = readlane_d((j & 1) ? a[q][1] : a[q][0], (j >> 1) & 63);
-            if ((j >> 7) == q) v = c;
+            // (both elements read, then a scalar select: `(j & 1) ? a[q][1] : a[q][0]` in front of the readlane made the compiler keep a
+            // copy of sv / lo / hi in scratch memory and index it -- three scratch loads per selection, a third of the iteration)
+            const double c0 = readlane_d(a[q][0], (j >> 1) & 63), c1 = readlane_d(a[q][1], (j >> 1) & 63);
+            if ((j >> 7) == q) v = (j & 1) ? c1 : c0;
         }
         return v;
     };
     auto recompute = [&]() __attribute__((always_inline)) {  // lam = Sinv (s0_W - b), s = s0 - Ghat[:,W] lam
-        put_rows(s0v);
-        const double rv = rowbuf[wrow] - wbnd;
+        const double rv = s0buf[wrow] - wbnd;
         put_pos(pbufa, (pos < k) ? rv : 0.0);
         const double lm = s_matvec(pbufa);
         lam = (pos < k) ? lm : 0.0;
         put_pos(pbufb, lam);
-        double qv[NP][2];
-        g_rows_times(pbufb, qv);
 #pragma unroll
-        for (int q = 0; q < NP; ++q) { sv[q][0] = s0v[q][0] - qv[q][0]; sv[q][1] = s0v[q][1] - qv[q][1]; }
+        for (int q = 0; q < NP; ++q) {
+            const d2 v = *reinterpret_cast<const d2*>(s0buf + 2 * lane + 128 * q);
+            sv[q][0] = v[0]; sv[q][1] = v[1];
+        }
+        g_rows_minus(pbufb, sv);
     };
     // The rows of the working set must sit on their bounds in values computed from scratch.  With an ill-conditioned Ghat_WW the
     // bordered inverse loses digits and they do not: refine the multipliers on that residual (a few rounds of iterative refinement);
     // false when it does not settle -- the instance is then NOT reported as solved.
     auto refine = [&]() -> bool {
-        put_rows(gn);
-        const double gw = rowbuf[wrow];
+        put_rows(ign);
+        const double igw = rowbuf[wrow];
         wave_fence_lds();
         for (int rr = 0; rr < 4; ++rr) {
             put_rows(sv);
             const double rv = rowbuf[wrow] - wbnd;
-            const double res = wave_max((lowhalf && pos < k) ? fabs(rv) / gw : 0.0);
+            const double res = wave_max((lowhalf && pos < k) ? fabs(rv) * igw : 0.0);
             if (res <= 1e-9) return true;
             if (rr == 3) break;
             put_pos(pbufa, (pos < k) ? rv : 0.0);
@@ -423,10 +438,7 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
             const double dlm = (pos < k) ? dl : 0.0;
             lam += dlm;
             put_pos(pbufb, dlm);
-            double qv[NP][2];
-            g_rows_times(pbufb, qv);
-#pragma unroll
-            for (int q = 0; q < NP; ++q) { sv[q][0] -= qv[q][0]; sv[q][1] -= qv[q][1]; }
+            g_rows_minus(pbufb, sv);
         }
         return false;
     };
@@ -457,9 +469,11 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
         if (with_state) {
             const double a = readlane_d(lam, rp) / spp;
             double qv[NP][2];
-            g_rows_times(pbufb, qv);
 #pragma unroll
-            for (int q = 0; q < NP; ++q) { sv[q][0] += a * qv[q][0]; sv[q][1] += a * qv[q][1]; }
+            for (int q = 0; q < NP; ++q) { qv[q][0] = 0.0; qv[q][1] = 0.0; }
+            g_rows_minus(pbufb, qv);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) { sv[q][0] -= a * qv[q][0]; sv[q][1] -= a * qv[q][1]; }
             lam -= sp * a;
         }
         s_rank1(sp, pbufb, -1.0 / spp);
@@ -499,12 +513,7 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
         dp = gjj - wave_sum(lowhalf ? c * u : 0.0);
     };
     // second half: d = Ghat[:,j] - Ghat[:,W] u  (u in pbufb)
-    auto dir_d = [&](const double (&gj)[NP][2], double (&dv)[NP][2]) __attribute__((always_inline)) {
-        double qv[NP][2];
-        g_rows_times(pbufb, qv);
-#pragma unroll
-        for (int q = 0; q < NP; ++q) { dv[q][0] = gj[q][0] - qv[q][0]; dv[q][1] = gj[q][1] - qv[q][1]; }
-    };
+    auto dir_d = [&](double (&gj)[NP][2]) __attribute__((always_inline)) { g_rows_minus(pbufb, gj); };   // in place: gj becomes d
 
     const bool skip = (st_in == 2) || x0_bad;
     bool give_up = skip;
@@ -604,6 +613,7 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
         bool fresh = false;
         while (it < max_iter) {
             ++it;
+            PG_T0();
             // most violated row outside W, in the H'^-1 metric
             double vbest = -__builtin_inf();
             int which = 0;
@@ -612,7 +622,7 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     // (rows beyond R have infinite bounds: their measure is -inf by itself)
-                    const double v = !((actm >> (2 * q + e)) & 1u) ? fmax(sv[q][e] - hi[q][e], lo[q][e] - sv[q][e]) / gn[q][e] : -__builtin_inf();
+                    const double v = !((actm >> (2 * q + e)) & 1u) ? fmax(sv[q][e] - hi[q][e], lo[q][e] - sv[q][e]) * ign[q][e] : -__builtin_inf();
                     if (v > vbest) { vbest = v; which = 2 * q + e; }
                 }
             const double vmax = wave_max(vbest);
@@ -620,7 +630,9 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
             if (!(vmax > 1e-9)) {
                 if (fresh) { fin = 0; break; }
                 recompute();  // confirm on values computed from scratch
-                if (k > 0 && !refine()) { fin = 1; break; }   // (measured: rebuilding the inverse from the rows does not rescue these --
+                const bool ref_ok = !(k > 0) || refine();
+                PG_ACC(6);
+                if (!ref_ok) { fin = 1; break; }   // (measured: rebuilding the inverse from the rows does not rescue these --
                                                               // their Ghat_WW is singular to working precision: edge of feasibility)
                 fresh = true;
                 --it;
@@ -635,11 +647,14 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
             const double bp = sd > 0 ? hip : lop;
             double lam_p = 0.0;
             bool added = false;
+            PG_ACC(0);
             while (it < max_iter) {
                 if (k == WL) { fin = 1; give_up = true; overflow = true; break; }
-                double u, dp, gjj, dv[NP][2], gj[NP][2];
-                dir_u(pr, gj, u, dp, gjj);
-                dir_d(gj, dv);
+                double u, dp, gjj, dv[NP][2];
+                dir_u(pr, dv, u, dp, gjj);
+                PG_ACC(1);
+                dir_d(dv);
+                PG_ACC(2);
                 const bool dependent = !(dp > 1e-12 * gjj);
                 const double spn = row_value(sv, pr);
                 const double tau2 = dependent ? (double)sd * __builtin_inf() : (spn - bp) / dp;
@@ -650,6 +665,7 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
                 const bool pos_blk = cand && lam != 0.0 && (ti * sd > 0.0);
                 const double tabs = zero_blk ? 0.0 : (pos_blk ? fabs(ti) : __builtin_inf());
                 const double tau1 = wave_min(tabs);
+                PG_ACC(3);
                 if (dependent && !(tau1 < __builtin_inf())) { fin = 3; break; }
                 if (tau1 < fabs(tau2)) {  // partial step, drop the blocking row, try again
                     const double tau = sd * tau1;
@@ -663,6 +679,7 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
                     if (pos == blk) lam = 0.0;
                     remove_pos(blk, false);
                     ++it;
+                    PG_ACC(4);
                     continue;
                 }
 #pragma unroll
@@ -671,6 +688,7 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
                 lam_p += tau2;
                 border(pr, u, 1.0 / dp, bp, sd, lam_p);
                 added = true;
+                PG_ACC(5);
                 break;
             }
             if (!added) break;
@@ -679,7 +697,10 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
     if (x0_bad && st_in != 2) fin = 3;
     PGEN_STAMP(5);
 #ifdef ALMPC_STAMPS
-    if (g_stamps && lane == 0) { g_stamps[(size_t)stamp_id * 16 + 9] = it; g_stamps[(size_t)stamp_id * 16 + 10] = k; }
+    if (g_stamps && lane == 0) {
+        g_stamps[(size_t)stamp_id * 16 + 9] = it; g_stamps[(size_t)stamp_id * 16 + 10] = k;
+        for (int i_ = 0; i_ < 8; ++i_) g_stamps[(size_t)(2 * p.batch + stamp_id) * 16 + i_] = pg_acc[i_];
+    }
 #endif
 
     // ---- result: w = input rows of s (pair 0), then the fused rollout
@@ -695,8 +716,11 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
     }
     if (lane == 0) {
         p.piters[inst] = it;
-        p.status[inst] = (st_in == 2) ? 2 : ((fin == 0) ? 0 : (fin == 3 ? 3 : 1));
-        if (!QUEUE && overflow && fin != 3) p.ovf[2 + atomicAdd(p.ovf, 1)] = inst;
+        const int st_out = (st_in == 2) ? 2 : ((fin == 0) ? 0 : (fin == 3 ? 3 : 1));
+        p.status[inst] = st_out;
+        const bool requeue = !QUEUE && overflow && fin != 3;   // (the second launch decides about this one)
+        if (requeue) p.ovf[2 + atomicAdd(p.ovf, 1)] = inst;
+        if (p.unsolved && st_out == 1 && !requeue) __hip_atomic_fetch_add(p.unsolved, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (!QUEUE && overflow && fin != 3 && lane < 32)   // (WL = 32 here: both half-waves mirror the positions)
         p.ovf_ws[(size_t)inst * 32 + lane] = guess_overflow ? -1 : (wrow | ((wsd + 1) << 12));

@@ -32,7 +32,8 @@ struct RiccatiParams {
     const double* umin; const double* umax;   // [m]
     const double* uref; long uref_stride;     // [N][m]
     const double* xref; long xref_stride;     // [N+1][n]
-    const double* x0;                          // [batch][n]
+    const double* x0;                          // [batch][x0_stride >= n]
+    long x0_stride;
     const double* uguess;                      // [batch][N][m] start (e.g. the condensed path's result) or null: clipped LQR
     int filter;                                // 1: only instances with status != 0 (fallback after the condensed path);
                                                // 2: only instances with flag != 0 or status != 0, flag cleared when solved (SQP loop)
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(64 * RICCATI_WAVES) void k_riccati_t(RiccatiParams 
             // (the gains were stored by other lanes of this wave: made visible at device scope, read back past the L1 and one stage ahead)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __builtin_amdgcn_wave_barrier();
-            if (lane < n) { const double e0 = p.x0 ? p.x0[(size_t)inst * n + lane] - xrg[lane] : 0.0; ev[lane] = e0; exg[lane] = e0; }
+            if (lane < n) { const double e0 = p.x0 ? p.x0[(size_t)inst * p.x0_stride + lane] - xrg[lane] : 0.0; ev[lane] = e0; exg[lane] = e0; }
             double kreg[9];   // (n m + m) / 64 <= 9 for n <= 32, m <= 16
             auto kload = [&](int k) {
 #pragma unroll
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(64 * RICCATI_WAVES) void k_riccati_t(RiccatiParams 
         };
         // trajectory of vcur (after a partial step the stored one is vstar's)
         auto rollout_cur = [&]() {
-            if (lane < n) { const double e0 = p.x0 ? p.x0[(size_t)inst * n + lane] - xrg[lane] : 0.0; ev[lane] = e0; exg[lane] = e0; }
+            if (lane < n) { const double e0 = p.x0 ? p.x0[(size_t)inst * p.x0_stride + lane] - xrg[lane] : 0.0; ev[lane] = e0; exg[lane] = e0; }
             rw_fence();
             for (int k = 0; k < N; ++k) {
                 load_stage(k);
@@ -515,7 +516,7 @@ __global__ __launch_bounds__(64 * RICCATI_WAVES) void k_riccati_t(RiccatiParams 
         for (int t = lane; t < (N + 1) * n; t += 64) {
             const double e = exg[t];
             p.ex[(size_t)inst * (N + 1) * n + t] = e;
-            p.x[(size_t)inst * (N + 1) * n + t] = (t < n) ? p.x0[(size_t)inst * n + t] : e + xrg[t];
+            p.x[(size_t)inst * (N + 1) * n + t] = (t < n) ? p.x0[(size_t)inst * p.x0_stride + t] : e + xrg[t];
         }
         if (lane == 0) {
             p.status[inst] = bad ? 2 : (fin == 0 ? 0 : 1);

@@ -40,6 +40,7 @@ struct SdualParams {
     const double* xbref; long xbref_stride;            // [N+1][n]: state bounds are xmin - xbref_k .. xmax - xbref_k
     const double* eqt; long eqt_stride;                // [n] terminal equality target for x_N in ABSOLUTE coordinates (the state reference of stage N), or null
     const double* x0; const double* xref; long xref_stride;   // e_0 = x0 - xref_0 (x0 null: e_0 = 0); x = e + xref
+    long x0_stride;                                    // doubles between the x0 of two instances (n; n (N + 1) when x0 is read from a result buffer)
     const double* uguess;                              // [batch][N][m] inputs whose bounds seed the working set, or null
     int filter;                                        // 0 all instances; 1 status == 1 (no verdict yet); 2 status != 0 or flag != 0 (flag cleared when solved)
     int* flag;
@@ -232,9 +233,9 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
         double* s = sA;    // row values of the current iterate (= the trajectory)
         double* w = sB;    // sources of a sweep, then its result
         double e0l = 0.0;  // e_0 (state lanes)
-        if (lane < n) e0l = p.x0 ? p.x0[(size_t)inst * n + lane] - (xrg ? xrg[lane] : 0.0) : 0.0;
+        if (lane < n) e0l = p.x0 ? p.x0[(size_t)inst * p.x0_stride + lane] - (xrg ? xrg[lane] : 0.0) : 0.0;
         double e0l16 = 0.0;   // the same per row of 16 lanes (DPP build)
-        if (ROWDPP && (lane & 15) < n) e0l16 = p.x0 ? p.x0[(size_t)inst * n + (lane & 15)] - (xrg ? xrg[lane & 15] : 0.0) : 0.0;
+        if (ROWDPP && (lane & 15) < n) e0l16 = p.x0 ? p.x0[(size_t)inst * p.x0_stride + (lane & 15)] - (xrg ? xrg[lane & 15] : 0.0) : 0.0;
 
         // The row values in s are kept in ABSOLUTE coordinates (u = v + u_ref, x = e + x_ref): bounds are then per-slot constants (no
         // reference offset on the scan's path); a sweep produces deviations, the offsets are added once after every full solve.
@@ -873,7 +874,7 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
                 const double xr = xrg ? xrg[t] : 0.0, xb = xbr ? xbr[t] : 0.0;
                 // (the row values carry the offset of the BOUNDS' reference xbref; the outputs are relative to xref: the same array for an
                 // MPC problem)
-                const double xa = k == 0 ? (p.x0 ? p.x0[(size_t)inst * n + i] : xr) : s[k * SP + i] - xb + xr;
+                const double xa = k == 0 ? (p.x0 ? p.x0[(size_t)inst * p.x0_stride + i] : xr) : s[k * SP + i] - xb + xr;
                 p.x[(size_t)inst * (N + 1) * n + t] = xa;
                 p.ex[(size_t)inst * (N + 1) * n + t] = xa - xr;
             }

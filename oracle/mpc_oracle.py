@@ -451,6 +451,7 @@ def solve_qp_dual_active_set(Ghat, s0, lo, hi, eq=None, W0=None, side0=None, max
     eq = np.zeros(R, dtype=bool) if eq is None else eq
     max_iter = 20 * R + 50 if max_iter is None else max_iter
     gn = np.sqrt(np.maximum(np.diag(Ghat), 1e-300))  # row norms in the H'^-1 metric, for the violation measure
+    ign = 1.0 / gn                                   # (the measure multiplies by the reciprocal, as k_polish_gen does: same decisions)
     W, side = [], {}
     Sinv = np.zeros((0, 0))
     lam = np.zeros(R)
@@ -509,7 +510,7 @@ def solve_qp_dual_active_set(Ghat, s0, lo, hi, eq=None, W0=None, side0=None, max
         it += 1
         inW = np.zeros(R, dtype=bool)
         inW[W] = True
-        viol = np.where(inW, -np.inf, np.maximum(s - hi, lo - s) / gn)
+        viol = np.where(inW, -np.inf, np.maximum(s - hi, lo - s) * ign)
         p_ = int(np.argmax(viol))
         if viol[p_] <= tol:
             status = 0

@@ -22,7 +22,7 @@ for _ in range(2): s.calculate(o)
 L = s.L
 L.almpc_dbg_stamps_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
 L.almpc_dbg_stamps_fetch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
-W = 2 * b
+W = 4 * b
 assert L.almpc_dbg_stamps_enable(s.h, W) == 0
 s.calculate(o)
 out = np.zeros((W, 16), dtype=np.int64)
@@ -52,6 +52,10 @@ for tier, sl in (("first launch (32 rows)", slice(0, b)), ("second launch (64 ro
     big = its >= 5
     if big.any():
         print(f"   main-loop cycles per iteration (instances with >= 5): median {int(np.median(ml[big] / its[big]))}")
+    acc = out[2 * b:][sl][on]
+    tot_ml = max(1, int(ml.sum()))
+    for j, nm in enumerate(("scan + selection", "dir_u (row j, c, u = Sinv c, dp)", "dir_d (Ghat[W,:]' u)", "step lengths", "partial step + removal", "full step + border", "confirmation")):
+        print(f"   main loop: {nm:34s} {100.0 * acc[:, j].sum() / tot_ml:5.1f} % of the main-loop cycles")
     gb = (st[:, 2] - st[:, 1])
     nzk = kg > 0
     if nzk.any():

@@ -13,7 +13,8 @@ for amp, box in CASES:
     xmax = box * np.array([1, 1, 1, .5, .5, .5, .1, .1, .1, .1, .1, .1]) * 3.0
     X0 = np.clip(X0, -0.99 * xmax, 0.99 * xmax)
     for terminal in ("none", "equality"):
-        s = capi.Solver(12, 4, 30, b, timing=True)
+        fb = {"0": False, "1": True}.get(os.environ.get("FALLBACK", ""), None)   # FALLBACK=0: what the condensed finish alone leaves
+        s = capi.Solver(12, 4, 30, b, timing=True, structured_fallback=fb)
         s.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max, xmin=-xmax, xmax=xmax, rho=30.0, rho_profile="stiffness", terminal=terminal)
         s.set_reference(p.x_ref, p.u_ref); s.update_initialization(X0)
         o = capi.default_opts(rho=30.0, max_iter=8, check_every=8)
@@ -27,4 +28,7 @@ for amp, box in CASES:
         r = s.get_results(want=("status", "polish_iters", "x"))
         print(f"amp {amp} box x{box} terminal {terminal}: step {1e6*el:.0f} us (admm {1e3*ts['admm_ms']/ts['steps']:.0f}, finish {1e3*ts['polish_ms']/ts['steps']:.0f}), status {np.bincount(r['status'], minlength=4).tolist()}, "
               f"finish its mean {r['polish_iters'].mean():.1f} max {r['polish_iters'].max()}")
+        if fb is False and (r["status"] == 1).any():
+            bad = np.flatnonzero(r["status"] == 1)
+            print(f"    left unsolved by the finish: {len(bad)} instances, finish iterations there {sorted(r['polish_iters'][bad].tolist())[-12:]}")
         s.close()
