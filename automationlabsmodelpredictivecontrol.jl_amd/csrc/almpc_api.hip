@@ -67,6 +67,7 @@ struct almpc_handle {
     int terminal_eq = 0, has_box = 0, mc = 0, R = 0, Rs = 0, np_pairs = 0;
     double *dGhat = nullptr, *dGnorm = nullptr, *dXmin = nullptr, *dXmax = nullptr;
     int *dRowTraj = nullptr, *dRowEq = nullptr, *dRowXidx = nullptr, *dRowState = nullptr;
+    double* dOvfSinv = nullptr;    // [batch][32 * 32 + 32] k_polish_gen -> k_polish_gen64: inverse and bounds of a flagged instance
     int32_t* dOverflow = nullptr;  // [2 + batch] k_polish_gen: count, cursor and list of instances to redo with the 64-row build
     int* dRowMap = nullptr;        // [N*n] state (stage k+2, i) -> state-row index or -1 (k_ghat_inst)
     double *dGhatE = nullptr, *dWinvE = nullptr;  // shared design with the terminal equality: original rows E of Ghat, Ghat_EE^-1
@@ -271,7 +272,7 @@ void free_all(almpc_handle* h) {
                     h->dXref, h->dUref, h->dFS, h->dV0S, h->dRho, h->dRollM, h->dX0, h->dXs, h->dZs, h->dYs, h->dV0, h->dW, h->dX, h->dEx,
                     h->dU, h->dEu, h->dStatus, h->dIters, h->dPiters, h->dPerm, h->dYflags, h->dSglobal, h->dGhat, h->dGnorm, h->dXmin,
                     h->dXmax, h->dRowTraj, h->dRowEq, h->dRowXidx, h->dRowState, h->dRowMap, h->dGhatE, h->dWinvE, h->lA, h->lB, h->lC, h->lE, h->bA, h->bB, h->bMinv, h->bG, h->bHs, h->bFs,
-                    h->bVs, h->bD, h->bRho, h->bH, h->bF, h->bPhi, h->bGk, h->bGam, h->bW, h->bWP, h->bP, h->bFlag, h->bQ, h->dOverflow, h->wQ, h->wR, h->wS,
+                    h->bVs, h->bD, h->bRho, h->bH, h->bF, h->bPhi, h->bGk, h->bGam, h->bW, h->bWP, h->bP, h->bFlag, h->bQ, h->dOverflow, h->dOvfSinv, h->wQ, h->wR, h->wS,
                     h->sqp.W_in, h->sqp.W_h, h->sqp.b_h, h->sqp.W_out, h->sqp.A, h->sqp.B, h->sqp.c, h->sqp.fval, h->sqp.ebar,
                     h->sqp.qadd, h->sqp.xref, h->sqp.uref, h->sqp.Q, h->sqp.R, h->sqp.S, h->sqp.bad, h->sqp.stats, h->sqp.mer, h->sqp.xback, h->sqp.uback, h->sqp.dxback, h->sqp.vback};
     for (void* p : ptrs)
@@ -2484,7 +2485,8 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         gp.roll_g = roll_g; gp.roll_cpl = roll_cpl; gp.roll = rp;
         if (!h->dOverflow) HIP_TRY(h, dalloc(&h->dOverflow, (size_t)h->batch * 33 + 2));   // list, then [batch][32] working sets
         HIP_TRY(h, hipMemsetAsync(h->dOverflow, 0, 2 * sizeof(int32_t), st));
-        gp.ovf = h->dOverflow; gp.ovf_ws = h->dOverflow + 2 + h->batch;
+        if (!h->dOvfSinv) HIP_TRY(h, dalloc(&h->dOvfSinv, (size_t)h->batch * (32 * 32 + 32)));
+        gp.ovf = h->dOverflow; gp.ovf_ws = h->dOverflow + 2 + h->batch; gp.ovf_sinv = h->dOvfSinv;
         if (lazy_redo) { HIP_TRY(h, ensure_unsolved_word()); gp.unsolved = h->dUnsolved; }
         const dim3 grid((h->batch + PGEN_WAVES - 1) / PGEN_WAVES), block(64 * PGEN_WAVES);
         // first launch: working sets up to 32 rows, every instance; second launch: the instances the first one flagged, up to 64 rows

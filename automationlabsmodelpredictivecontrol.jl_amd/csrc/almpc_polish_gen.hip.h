@@ -65,6 +65,8 @@ struct PolishGenParams {
                           // second launch, [2 ...] the flagged instances; [0] and [1] are zeroed before the first launch
     int32_t* ovf_ws;      // [batch][32] working set of a flagged instance when it ran out of room, row | (side + 1) << 12, the
                           // second launch's guess ([0] = -1: none, it builds its guess from the ADMM hand-off as the first did)
+    double* ovf_sinv = nullptr;  // [batch][32 * 32 + 32] of a flagged instance: the 32 x 32 inverse and the positions' bounds at that moment, so
+                                 // that the second launch continues instead of bordering the 32 rows in again (105 k cycles), or null
     int* unsolved = nullptr;   // host-visible count of instances left with ALMPC_MAX_ITER (lazy redo, see almpc_handle::hUnsolved), or null
     int max_iter;
     int roll_g, roll_cpl;
@@ -126,10 +128,14 @@ template <int NP, int WL>
 __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double* smem) {
     static_assert(WL == 32 || WL == 64, "working-set capacity: 32 (mirrored half-waves) or 64 (one position per lane)");
     constexpr int HS = 64 / WL;  // lanes per position: 2 = the half-waves split the columns of a sweep, 1 = no split
-    constexpr int CH = NP >= 3 ? 4 : 8;  // rows of Ghat per group of loads: NP * CH <= 16 loads (32 registers) in flight per lane
+    constexpr int CH = (NP >= 3 && WL == 32) ? 4 : 8;  // rows of Ghat per group of loads: NP * CH <= 16 loads (64 registers) in flight per lane; 32 in the second launch (512 registers)
     constexpr bool QUEUE = WL == 64;  // the 64-row build is the second launch: persistent waves pull flagged instances
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6, lane0 = threadIdx.x & 63;
   do {  // (one pass in the first launch)
+    // (second launch: the lane index made opaque per instance -- otherwise everything that depends on it alone is hoisted out of this
+    // loop and kept live across the whole solve: 650 live registers, 134 of them in scratch memory)
+    int lane = lane0;
+    if (QUEUE) asm volatile("" : "+v"(lane));
     int inst;
     if (QUEUE) {
         if (p.ovf[0] == 0) return;  // (nothing flagged: leave without touching the cursor)
@@ -366,6 +372,10 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
             for (int t = 0; t < 8; ++t) Sl[(l0 + HS * t + hf) * WL + pos] = cur[t] + as * av[t];
         }
     };
+    // Rows of Ghat for the working set, CH at a time.  (Measured and dropped: a second group in flight, and group 0 requested as soon
+    // as W is final so that it travels under the next iteration's scan -- 64 more live registers each, and the NP = 4 build, at 256
+    // already, answers with 0.5 - 1.2 KB of scratch per lane; in the second launch's build, which may use 512, the compiler parks the
+    // arriving group in AGPRs behind a full wait and the iteration gets slower, 14 k -> 16 k cycles.)
     // (a in LDS buffer ab, zero beyond k)
     auto g_rows_minus = [&](const double* ab, double (&qv)[NP][2]) {   // qv[.] -= sum_{l<k} Ghat[W_l, rows] * a_l
         for (int l0 = 0; l0 < k; l0 += CH) {   // (all NP * CH loads of a group go out before the first is used)
@@ -458,7 +468,7 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
         if (pos == k) { wrow = j; wsd = sd; wbnd = bval; lam = lamj; }
         if (lane == 0) wrow_s[k] = j;
         mark(j, true, bval);
-        k += 1;
+        k = __builtin_amdgcn_readfirstlane(k + 1);
         wave_fence_lds();
     };
     // remove position rp; with_state: move s and lam so that lam_rp becomes 0 first (used to restore dual feasibility)
@@ -497,16 +507,24 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
         if (pos == last) lam = 0.0;
         if (lane == 0) wrow_s[last] = 0;
         mark(jrem, false, 0.0);
-        k -= 1;
+        k = __builtin_amdgcn_readfirstlane(k - 1);
         wave_fence_lds();
     };
     // direction of adding row j, first half: c = Ghat[W,j] -> u = Sinv c (also left in pbufb), dp = Ghat_jj - c'u
     auto dir_u = [&](int j, double (&gj)[NP][2], double& u, double& dp, double& gjj, bool loaded = false) __attribute__((always_inline)) {
-        if (!loaded) load_row(j, gj);
-        put_rows(gj);
-        const double cv = rowbuf[wrow];
+        double cv, gd;
+        if (!loaded) {
+            // main loop: c = Ghat[j, W] (symmetry) gathered straight from the row in L2 next to the row's own loads -- no trip through LDS
+            load_row(j, gj);
+            cv = Gh[(size_t)j * Rs + wrow];
+            gd = Gh[(size_t)j * Rs + j];
+        } else {   // guess build: the row was requested one step ahead, the working set has changed since
+            put_rows(gj);
+            cv = rowbuf[wrow];
+            gd = rowbuf[j];
+        }
         const double c = (pos < k) ? cv : 0.0;
-        gjj = rowbuf[j];
+        gjj = readlane_d(gd, 0);
         put_pos(pbufa, c);
         u = s_matvec(pbufa);
         put_pos(pbufb, u);
@@ -560,13 +578,30 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
         // guessed rows live in registers of lane = guess index (up to 64 of them)
         int g_row = (lane < cnt && lane < 64) ? ibuf[lane] : 0;
         int g_sd = (lane < cnt && lane < 64) ? ibuf[64 + lane] : 0;
-        if (QUEUE) {   // second launch: start from the working set the first launch had when it ran out of room
+        if constexpr (QUEUE) {   // second launch: start from the working set the first launch had when it ran out of room
             const int w0 = p.ovf_ws[(size_t)inst * 32];
             if (w0 >= 0) {
                 const int wv_ = p.ovf_ws[(size_t)inst * 32 + (lane & 31)];
                 cnt = 32;
                 g_row = lane < 32 ? (wv_ & 0xFFF) : 0;
                 g_sd = lane < 32 ? ((wv_ >> 12) & 3) - 1 : 0;
+                if (p.ovf_sinv) {   // ... and from its inverse: nothing to border in again
+                    const double* sv_ = p.ovf_sinv + (size_t)inst * (32 * 32 + 32);
+                    double col[32];
+#pragma unroll
+                    for (int t = 0; t < 32; ++t) col[t] = sv_[t * 32 + (lane & 31)];
+                    const double bnd_ = sv_[32 * 32 + (lane & 31)];
+                    if (lane < 32) {
+#pragma unroll
+                        for (int t = 0; t < 32; ++t) Sl[t * WL + lane] = col[t];
+                        wrow = g_row; wsd = g_sd; wbnd = bnd_;
+                        wrow_s[lane] = g_row;
+                    }
+                    for (int i = 0; i < 32; ++i) mark(__builtin_amdgcn_readlane(g_row, i), true, 0.0);
+                    k = 32;
+                    cnt = 0;
+                    wave_fence_lds();
+                }
             }
         }
         wave_fence_lds();
@@ -615,15 +650,18 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
             ++it;
             PG_T0();
             // most violated row outside W, in the H'^-1 metric
-            double vbest = -__builtin_inf();
+            // (each lane keeps side and bound of its own best row: the owner's are read with three v_readlane pairs, where picking them
+            // out of sv / hi / lo by the row number took 48)
+            double vbest = -__builtin_inf(), bbest = 0.0;
             int which = 0;
 #pragma unroll
             for (int q = 0; q < NP; ++q)
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     // (rows beyond R have infinite bounds: their measure is -inf by itself)
-                    const double v = !((actm >> (2 * q + e)) & 1u) ? fmax(sv[q][e] - hi[q][e], lo[q][e] - sv[q][e]) * ign[q][e] : -__builtin_inf();
-                    if (v > vbest) { vbest = v; which = 2 * q + e; }
+                    const double over = sv[q][e] - hi[q][e], under = lo[q][e] - sv[q][e];
+                    const double v = !((actm >> (2 * q + e)) & 1u) ? fmax(over, under) * ign[q][e] : -__builtin_inf();
+                    if (v > vbest) { vbest = v; which = (2 * q + e) | (over > 0.0 ? 16 : 0); bbest = over > 0.0 ? hi[q][e] : lo[q][e]; }
                 }
             const double vmax = wave_max(vbest);
             if (!(vmax == vmax) || !(vmax < __builtin_inf())) { fin = 1; break; }  // numerical breakdown: never report it as solved
@@ -641,10 +679,9 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
             fresh = false;
             const int owner = __builtin_ctzll(__ballot(vbest == vmax));
             const int wsel = __builtin_amdgcn_readlane(which, owner);
-            const int pr = 2 * owner + (wsel & 1) + 128 * (wsel >> 1);
-            const double sp_ = row_value(sv, pr), hip = row_value(hi, pr), lop = row_value(lo, pr);
-            const int sd = sp_ > hip ? 1 : -1;
-            const double bp = sd > 0 ? hip : lop;
+            const int pr = 2 * owner + (wsel & 1) + 128 * ((wsel & 15) >> 1);
+            const int sd = (wsel & 16) ? 1 : -1;
+            const double bp = readlane_d(bbest, owner);
             double lam_p = 0.0;
             bool added = false;
             PG_ACC(0);
@@ -722,8 +759,15 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
         if (requeue) p.ovf[2 + atomicAdd(p.ovf, 1)] = inst;
         if (p.unsolved && st_out == 1 && !requeue) __hip_atomic_fetch_add(p.unsolved, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    if (!QUEUE && overflow && fin != 3 && lane < 32)   // (WL = 32 here: both half-waves mirror the positions)
-        p.ovf_ws[(size_t)inst * 32 + lane] = guess_overflow ? -1 : (wrow | ((wsd + 1) << 12));
+    if (!QUEUE && overflow && fin != 3) {   // (WL = 32 here: both half-waves mirror the positions)
+        if (lane < 32) p.ovf_ws[(size_t)inst * 32 + lane] = guess_overflow ? -1 : (wrow | ((wsd + 1) << 12));
+        if (p.ovf_sinv && !guess_overflow) {
+            double* sv_ = p.ovf_sinv + (size_t)inst * (32 * 32 + 32);
+#pragma unroll 4
+            for (int t = 0; t < 32; t += 2) sv_[(t + (lane >> 5)) * 32 + (lane & 31)] = Sl[(t + (lane >> 5)) * WL + (lane & 31)];
+            if (lane < 32) sv_[32 * 32 + lane] = wbnd;
+        }
+    }
     wave_fence_lds();
     {
         const int r0 = 2 * lane, r1 = 2 * lane + 1;

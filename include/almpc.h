@@ -166,13 +166,16 @@ int almpc_set_step_fusion(almpc_handle* h, int on);
  *   DEFAULT: ON wherever those solvers cover the design (shape limits of ALMPC_FLAG_STRUCTURED), for every design of a condensed
  *   handle: shared (incl. state rows, terminal equality, S), per instance, re-linearisation pipeline, SQP loop (the QP of an iteration
  *   in its stage-wise form for the instances whose condensed Hessian came out indefinite, instead of skipping them).
- *     - designs with state rows and the SQP loop: the redo kernels are enqueued behind every step / inside every iteration.
- *     - input box only (shared model -- the headline path, tens of microseconds per step --, per-instance models, re-linearisation
- *       pipeline): LAZILY -- the finish counts unsolved instances into a host-visible word and the redo runs at the next point where
- *       the host looks at results through a synchronous call (almpc_calculate, almpc_synchronize, almpc_get_results,
- *       almpc_get_first_input, almpc_relin_fnn_step): no launch on the step path (two idle redo launches cost 14 us -- of a 61 us
- *       step on the headline path).  A caller that reads results only through the asynchronous tickets, or consumes them on the
- *       device (almpc_advance_plant / almpc_relin_fnn_advance loops), asks for the eager form with on = 1.
+ *     - the SQP loop: the redo kernels are enqueued inside every iteration.
+ *     - every other condensed design (shared model -- the headline path, tens of microseconds per step --, per-instance models,
+ *       re-linearisation pipeline; input box or state rows): LAZILY -- the finish counts the instances it leaves with ALMPC_MAX_ITER
+ *       into a host-visible word and the redo runs at the next point where the host looks at results through a synchronous call
+ *       (almpc_calculate, almpc_synchronize, almpc_get_results, almpc_get_first_input, almpc_relin_fnn_step): no launch on the
+ *       step path (two idle redo launches cost 14 us -- of a 61 us step on the headline path; with state rows a stage-wise solve
+ *       of ONE edge-of-feasibility instance takes about a millisecond, and 1 - 12 instances in 4096 need one).  The redo takes x0
+ *       from the step's own result (x[:, 1]), so handing over the next x0 before looking at the results is safe; references and
+ *       models must still be the step's.  A caller that reads results only through the asynchronous tickets, or consumes them on
+ *       the device (almpc_advance_plant / almpc_relin_fnn_advance loops), asks for the eager form with on = 1.
  *   on = 1: required (a design the stage-wise solvers cannot serve is an error) and always eager;  on = 0: off.
  * Call BEFORE the design.
  */
