@@ -1164,12 +1164,26 @@ int ensure_batched_alloc(almpc_handle* h) {
 }
 
 // H_i (column-major, in bH) -> Jacobi scaling d_i, H'_i, F'_i, G_i = H'_i^-1, rho_i, Minv_i = (H'_i + sigma I + diag(rho_i))^-1
-void launch_batched_factor(almpc_handle* h, const DesignStrides& ds, double rho, double sigma, hipStream_t st) {
+// (scaled: the producer of H_i has done the scaling as its own tail)
+// (with_v: also V_i = -G_i F'_i -- inside the first inverse's launch where that kernel can, else by launch_neg_gm_batched)
+void launch_batched_factor(almpc_handle* h, const DesignStrides& ds, double rho, double sigma, hipStream_t st, bool scaled = false, bool with_v = false) {
     const int n = h->n, nz = h->nz, nzs = h->nzs;
     const unsigned gb = (unsigned)h->batch;
-    hipLaunchKernelGGL(k_design_scale, dim3(1, gb), dim3(256), 0, st, nz, nzs, n, h->bH, h->bF, h->bD, h->bHs, h->bFs, h->bFlag, ds);
+    if (!scaled) hipLaunchKernelGGL(k_design_scale, dim3(1, gb), dim3(256), 0, st, nz, nzs, n, h->bH, h->bF, h->bD, h->bHs, h->bFs, h->bFlag, ds);
     const size_t inv_lds = 520 * sizeof(double);
-    launch_design_inverse(dim3(1, gb), inv_lds, st, nz, nzs, h->bHs, 0.0, (const double*)nullptr, h->bG, h->bFlag, ds.Hs, 0L, ds.G, 1L);
+    if (!h->skip_admm && h->rho_mode == 0 && design_inverse_makes_rho(nz, nzs) && design_inverse_makes_v(nz) && !getenv("ALMPC_DBG_SPLIT_INVERSES")) {
+        // scalar rho: the ADMM's KKT inverse does not need G_i -- both inverses, the penalty profile and V_i in ONE launch
+        launch_design_inverse(dim3(1, gb), inv_lds, st, nz, nzs, h->bHs, 0.0, (const double*)nullptr, h->bG, h->bFlag, ds.Hs, ds.rho, ds.G, 1L,
+                              (const double*)nullptr, 0L, 0, rho, h->bRho, with_v ? h->bFs : nullptr, h->bVs, ds.Fs, n, h->bMinv, ds.Minv, sigma);
+        return;
+    }
+    if (with_v && design_inverse_makes_v(nz))   // V_i = -G_i F'_i from the rows of G_i the inverse's wave still holds
+        launch_design_inverse(dim3(1, gb), inv_lds, st, nz, nzs, h->bHs, 0.0, (const double*)nullptr, h->bG, h->bFlag, ds.Hs, 0L, ds.G, 1L,
+                              (const double*)nullptr, 0L, 0, 0.0, (double*)nullptr, h->bFs, h->bVs, ds.Fs, n);
+    else {
+        launch_design_inverse(dim3(1, gb), inv_lds, st, nz, nzs, h->bHs, 0.0, (const double*)nullptr, h->bG, h->bFlag, ds.Hs, 0L, ds.G, 1L);
+        if (with_v) launch_neg_gm_batched(st, gb, nz, nzs, n, h->bG, h->bFs, h->bVs, ds.G, ds.Fs);
+    }
     if (h->skip_admm) return;  // no ADMM phase in this solve: its KKT inverse is not needed
     if (design_inverse_makes_rho(nz, nzs))   // the penalty profile is made inside the inverse's own launch
         launch_design_inverse(dim3(1, gb), inv_lds, st, nz, nzs, h->bHs, sigma, (const double*)nullptr, h->bMinv, h->bFlag, ds.Hs, ds.rho, ds.Minv, 1L,
@@ -1280,12 +1294,17 @@ hipError_t launch_batched_design(almpc_handle* h, const DesignStrides& ds, int u
         e = hipMemsetAsync(h->bFlag, 0, (size_t)h->batch * sizeof(int), st);
         if (e != hipSuccess) return e;
     }
+    bool scaled = false;
     if (inst_lds <= 160 * 1024) {  // structured route: H_i, F_i from the Toeplitz blocks in LDS, no Gamma panels in HBM
         DesignInstParams dp;
         dp.flag = h->bFlag; dp.sFlag = 1;
         dp.n = n; dp.m = m; dp.N = N; dp.nz = nz; dp.useR = useR; dp.useS = useS;
         dp.A = h->bA; dp.B = h->bB; dp.P = h->bP; dp.sA = ds.A; dp.sB = ds.B; dp.sP = ds.P;
         dp.Q = dQ; dp.R = dR; dp.S = dS; dp.H = h->bH; dp.F = h->bF; dp.sH = ds.H; dp.sF = ds.F;
+        if (nz <= 128 && design_instance_lds_doubles(n, m, N) >= 128 && !getenv("ALMPC_DBG_SPLIT_SCALE")) {   // the scaling rides along (k_design_scale's body, one launch less)
+            dp.d = h->bD; dp.Hs = h->bHs; dp.Fs = h->bFs; dp.sd = ds.d; dp.sHs = ds.Hs; dp.sFs = ds.Fs; dp.nzs = nzs;
+        }
+        scaled = dp.Hs != nullptr;
 #define DESIGN_INST(NC_, MC_)                                                                                \
     do {                                                                                                     \
         e = ensure_dyn_lds(reinterpret_cast<const void*>(k_design_instance_t<NC_, MC_>), inst_lds);          \
@@ -1312,8 +1331,7 @@ hipError_t launch_batched_design(almpc_handle* h, const DesignStrides& ds, int u
     if (e != hipSuccess) return e;
     DesignStrides ds2 = ds;
     ds2.h_symmetric = (inst_lds <= 160 * 1024) ? 1 : 0;   // (the LDS route writes both halves of H_i from one value)
-    launch_batched_factor(h, ds2, rho, sigma, st);
-    launch_neg_gm_batched(st, gb, nz, nzs, n, h->bG, h->bFs, h->bVs, ds.G, ds.Fs);
+    launch_batched_factor(h, ds2, rho, sigma, st, scaled, true);
     return hipGetLastError();
 }
 

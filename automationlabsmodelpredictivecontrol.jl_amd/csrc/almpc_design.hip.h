@@ -178,11 +178,10 @@ __global__ __launch_bounds__(768) void k_design_hessian(HessParams p) {
 // ---- scaling -------------------------------------------------------------------------------------
 // d = diag(H)^-1/2 (pad rows 1), Hs (ld = nzs, symmetrised) = D H D, Fs (ld = nzs) = D F.  flag[0] != 0 on a
 // non-positive diagonal.
-__global__ __launch_bounds__(256) void k_design_scale(int nz, int nzs, int n, const double* H, const double* F,
-                                                      double* d, double* Hs, double* Fs, int* flag, DesignStrides st) {
-    H += blockIdx.y * st.H; F += blockIdx.y * st.F; d += blockIdx.y * st.d; Hs += blockIdx.y * st.Hs; Fs += blockIdx.y * st.Fs;
-    flag += blockIdx.y * st.flag;
-    __shared__ double ds[128];  // nz <= 128 (almpc_create); the scaling is read nz^2 times
+// (a device function: the producers of H_i whose workgroup holds one instance -- k_design_instance_t -- run it as their own tail on the
+// H_i they have just written, one launch less per design; ds: 128 doubles of LDS)
+__device__ __forceinline__ void design_scale_body(int nz, int nzs, int n, const double* H, const double* F, double* d, double* Hs,
+                                                  double* Fs, int* flag, int h_symmetric, double* ds) {
     for (int t = threadIdx.x; t < nzs; t += blockDim.x) {
         double v = 1.0;
         if (t < nz) {
@@ -194,7 +193,7 @@ __global__ __launch_bounds__(256) void k_design_scale(int nz, int nzs, int n, co
         if (t < 128) ds[t] = v;
     }
     __syncthreads();
-    if (st.h_symmetric && (nz & 1) == 0) {
+    if (h_symmetric && (nz & 1) == 0) {
         // H_i came out symmetric (LDS route of k_design_instance) and columns are 16-byte aligned: two rows per load and store, two pairs
         // per thread and pass, (column, row pair) carried along instead of divided out
         const int hp = nz >> 1, total = hp * nz, step = 2 * (int)blockDim.x, dc = step / hp, dr = step - dc * hp;
@@ -235,7 +234,7 @@ __global__ __launch_bounds__(256) void k_design_scale(int nz, int nzs, int n, co
                 const bool in = t0 + u < nz * nz;
                 cc[u] = in ? c : nz - 1; rr[u] = in ? r : nz - 1;
                 ha[u] = H[(size_t)cc[u] * nz + rr[u]];
-                hb[u] = st.h_symmetric ? ha[u] : H[(size_t)rr[u] * nz + cc[u]];   // (0.5 (a + a) = a exactly)
+                hb[u] = h_symmetric ? ha[u] : H[(size_t)rr[u] * nz + cc[u]];   // (0.5 (a + a) = a exactly)
                 if (++r == nz) { r = 0; ++c; }
             }
 #pragma unroll
@@ -249,6 +248,14 @@ __global__ __launch_bounds__(256) void k_design_scale(int nz, int nzs, int n, co
         const int r = t % nz, c = t / nz;
         Fs[(size_t)c * nzs + r] = ds[r] * F[(size_t)c * nz + r];
     }
+}
+
+__global__ __launch_bounds__(256) void k_design_scale(int nz, int nzs, int n, const double* H, const double* F,
+                                                      double* d, double* Hs, double* Fs, int* flag, DesignStrides st) {
+    H += blockIdx.y * st.H; F += blockIdx.y * st.F; d += blockIdx.y * st.d; Hs += blockIdx.y * st.Hs; Fs += blockIdx.y * st.Fs;
+    flag += blockIdx.y * st.flag;
+    __shared__ double ds[128];  // nz <= 128 (almpc_create); the scaling is read nz^2 times
+    design_scale_body(nz, nzs, n, H, F, d, Hs, Fs, flag, st.h_symmetric, ds);
 }
 
 // ---- K5: Out = (Hs + c I + diag(dshift))^-1 ----------------------------------------------------------------
@@ -449,15 +456,24 @@ template <int NCOL>
 __global__ __launch_bounds__(256) void k_design_inverse_wave(int nz, int nzs, int batch, const double* Hs, double cshift, const double* dshift,
                                                              double* Out, int* flag, long sHs, long sShift, long sOut, long sFlag,
                                                              const double* rho_G = nullptr, long sRhoG = 0, int rho_mode = 0, double rho = 0.0,
-                                                             double* rho_out = nullptr) {
+                                                             double* rho_out = nullptr, const double* vM = nullptr, double* vOut = nullptr,
+                                                             long sV = 0, int vcols = 0, double* Out2 = nullptr, long sOut2 = 0,
+                                                             double cshift2 = 0.0) {
     constexpr int PB = 8;
     static_assert(NCOL % PB == 0 && NCOL > PB, "column count: a multiple of the pivot block");
     __shared__ __attribute__((aligned(16))) double wbuf_all[4][2][64];
     const int lane = threadIdx.x & 63;
-    const int inst = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int inst = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // Out2 != null: BOTH inverses of a per-instance design in one launch (scalar rho: the second does not need the first) -- waves
+    // batch .. 2 batch - 1 form Out2 = (Hs + (cshift2 + rho) I)^-1 and write the (constant) penalty profile; a wave per matrix is
+    // latency bound, 1024 of them are one per SIMD: the second inverse rides in the empty issue slots instead of taking its own 28 us
+    const bool second = Out2 != nullptr && inst >= batch;
+    if (second) inst -= batch;
     if (inst >= batch) return;
     double* wbuf = &wbuf_all[threadIdx.x >> 6][0][0];
-    Hs += (size_t)inst * sHs; Out += (size_t)inst * sOut; flag += (size_t)inst * sFlag;
+    Hs += (size_t)inst * sHs; flag += (size_t)inst * sFlag;
+    if (second) { Out = Out2 + (size_t)inst * sOut2; cshift = cshift2; vM = nullptr; }
+    else Out += (size_t)inst * sOut;
     if (dshift) dshift += (size_t)inst * sShift;
     const int i = lane;
     double S[NCOL];
@@ -467,7 +483,10 @@ __global__ __launch_bounds__(256) void k_design_inverse_wave(int nz, int nzs, in
     INV_W(0);
     const int ic = i < nz ? i : nz - 1;
     double shift = cshift + (dshift ? dshift[ic] : 0.0);
-    if (rho_G) {
+    if (second) {
+        if (i < nzs) rho_out[(size_t)inst * sShift + i] = i < nz ? rho : 1.0;   // (pad rows 1, as k_design_rho)
+        shift = cshift + rho;
+    } else if (rho_G) {
         const double gii = rho_G[(size_t)inst * sRhoG + (size_t)ic * nzs + ic];
         const double rv = rho_mode == 1 ? rho / gii : rho;
         if (i < nzs) rho_out[(size_t)inst * sShift + i] = i < nz ? rv : 1.0;   // (pad rows 1, as k_design_rho)
@@ -562,6 +581,29 @@ __global__ __launch_bounds__(256) void k_design_inverse_wave(int nz, int nzs, in
         if (i < nz && col < nz) Out[(size_t)col * nzs + i] = S[c];
     }
     if (__any(bad) && lane == 0) atomicExch(flag, 2);
+    // vM != null: V = -Out vM (nz x vcols, leading dimension nzs: the per-instance V_i = -G_i F'_i of a design) from the rows this wave
+    // still holds, instead of a launch of its own that reads G_i back (k_neg_gm_cols: 7 us of a 186 us re-linearisation step).  Column
+    // by column: lane j publishes vM[j, c] at the position of column j, every lane reads the NCOL values back at wave-uniform
+    // addresses -- the pivot-row mechanism once more.
+    if (vM) {
+        const double* Mi = vM + (size_t)inst * sV;
+        double* Vi = vOut + (size_t)inst * sV;
+        int pos = i - (nrot % NCOL); if (pos < 0) pos += NCOL;
+        for (int c = 0; c < vcols; ++c) {
+            const double mv = Mi[(size_t)c * nzs + ic];
+            wave_fence_lds();
+            if (i < NCOL) wbuf[pos] = i < nz ? mv : 0.0;
+            wave_fence_lds();
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int q = 0; q < NCOL; q += 2) {
+                const d2 w2 = *reinterpret_cast<const d2*>(wbuf + q);
+                a0 = __builtin_fma(S[q], w2[0], a0);
+                a1 = __builtin_fma(S[q + 1], w2[1], a1);
+            }
+            if (i < nz) Vi[(size_t)c * nzs + i] = -(a0 + a1);
+        }
+    }
     INV_W(3);
 }
 
@@ -716,13 +758,17 @@ __global__ __launch_bounds__(64 * (128 / CW)) void k_design_inverse_c32(int nz, 
 // launcher: the smallest register tile that holds the matrix
 // whether launch_design_inverse makes the ADMM penalty profile itself (rho_G given): the one-wave kernel does, the others need k_design_rho first
 inline bool design_inverse_makes_rho(int nz, int nzs) { return nz <= 64 && nzs <= 64 && !getenv("ALMPC_INV_TILE") && !getenv("ALMPC_NO_RHO_FUSION"); }
+// (the one-wave-per-matrix kernel can also form V = -Out vM from the rows it holds: see there)
+inline bool design_inverse_makes_v(int nz) { return nz <= 64 && !getenv("ALMPC_INV_TILE") && !getenv("ALMPC_DBG_SPLIT_NEGGM"); }
 inline void launch_design_inverse(dim3 grid, size_t lds, hipStream_t st, int nz, int nzs, const double* Hs, double cshift, const double* dshift,
                                   double* Out, int* flag, long sHs, long sShift, long sOut, long sFlag,
-                                  const double* rho_G = nullptr, long sRhoG = 0, int rho_mode = 0, double rho = 0.0, double* rho_out = nullptr) {
+                                  const double* rho_G = nullptr, long sRhoG = 0, int rho_mode = 0, double rho = 0.0, double* rho_out = nullptr,
+                                  const double* vM = nullptr, double* vOut = nullptr, long sV = 0, int vcols = 0,
+                                  double* Out2 = nullptr, long sOut2 = 0, double cshift2 = 0.0) {
     if (nz <= 64 && !getenv("ALMPC_INV_TILE")) {   // one wave per matrix (grid.y = matrices, as for the tile kernels)
         const int b = (int)grid.y;
-        const dim3 g2((unsigned)((b + 3) / 4));
-#define INV_WAVE(NC_) hipLaunchKernelGGL((k_design_inverse_wave<NC_>), g2, dim3(256), 0, st, nz, nzs, b, Hs, cshift, dshift, Out, flag, sHs, sShift, sOut, sFlag, rho_G, sRhoG, rho_mode, rho, rho_out)
+        const dim3 g2((unsigned)(((Out2 ? 2 * b : b) + 3) / 4));
+#define INV_WAVE(NC_) hipLaunchKernelGGL((k_design_inverse_wave<NC_>), g2, dim3(256), 0, st, nz, nzs, b, Hs, cshift, dshift, Out, flag, sHs, sShift, sOut, sFlag, rho_G, sRhoG, rho_mode, rho, rho_out, vM, vOut, sV, vcols, Out2, sOut2, cshift2)
         if (nz <= 16) INV_WAVE(16); else if (nz <= 32) INV_WAVE(32); else if (nz <= 48) INV_WAVE(48); else INV_WAVE(64);
 #undef INV_WAVE
     } else if (nz <= 64) hipLaunchKernelGGL((k_design_inverse_t<2, 8>), grid, dim3(DESIGN_INVERSE_THREADS), lds, st, nz, nzs, Hs, cshift, dshift, Out, flag, sHs, sShift, sOut, sFlag);

@@ -542,6 +542,8 @@ struct DesignInstParams {
     double* H; double* F; long sH, sF;                                     // column-major nz x nz, nz x n
     int* flag = nullptr; long sFlag = 0;                                   // design flag of the instance: cleared here when given (instead of
                                                                            // by a memset launch in front of every re-design)
+    // the Jacobi scaling as the tail of this kernel (design_scale_body on the H_i, F_i just written) when Hs is given: d_i, H'_i, F'_i
+    double* d = nullptr; double* Hs = nullptr; double* Fs = nullptr; long sd = 0, sHs = 0, sFs = 0; int nzs = 0;
 };
 
 __host__ __device__ inline size_t design_instance_lds_doubles(int n, int m, int N) {
@@ -661,6 +663,12 @@ __global__ __launch_bounds__(256) void k_design_instance_t(DesignInstParams p) {
             H[(size_t)col * nz + row] = v;
             if (d > 0) H[(size_t)row * nz + col] = v;
         }
+    }
+    if (p.Hs) {   // scaling of what this workgroup has just written (L2 / L1 resident), flag needed: p.flag
+        __threadfence_block();
+        __syncthreads();   // (every LDS buffer above is dead now: the scaling's 128 doubles sit at the start; the host checks the size)
+        design_scale_body(nz, p.nzs, n, H, F, p.d + blockIdx.x * p.sd, p.Hs + blockIdx.x * p.sHs, p.Fs + blockIdx.x * p.sFs,
+                          p.flag + blockIdx.x * p.sFlag, 1, smem);
     }
 }
 
