@@ -73,7 +73,7 @@ struct PolishGenParams {
     RolloutParams roll;
 };
 
-constexpr int PGEN_WAVES = 4;
+constexpr int PGEN_WAVES = 1;   // one instance per workgroup: a CU's eight slots are refilled instance by instance (with four per workgroup a slot waited for the slowest of four: 346 -> ... us)
 // LDS per wave (doubles): Sinv WL x WL | rowbuf Rs(<=512) | s0buf Rs(<=512) | pbufa WL | pbufb WL | wrow_s (WL ints) | Z trajectory shares Sinv
 __host__ __device__ constexpr int pgen_lds_per_wave(int WL) { return WL * WL + 512 + 512 + WL + WL + WL / 2; }
 
