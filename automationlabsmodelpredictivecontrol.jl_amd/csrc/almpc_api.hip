@@ -2095,10 +2095,13 @@ int almpc_sqp_fnn_iterate(almpc_handle* h, int iters, double step_scale, const a
     lp.n = n; lp.m = m; lp.N = N; lp.nz = nz; lp.useR = q.useR; lp.useS = q.useS;
     lp.A = q.A; lp.B = q.B; lp.c = q.c; lp.ebar = q.ebar; lp.P = h->bP; lp.sP = q.sP; lp.Q = q.Q; lp.R = q.R; lp.S = q.S;
     lp.qadd = q.qadd; lp.H = h->bH; lp.q = h->bQ;
+    // register-tile design kernel: scaling, scaled gradient and the flag reset ride along as its tail (three launches less per iteration)
+    const bool ltv_scales = ltv_reg_path(h) && nz <= 128 && !q.structured_qp && !getenv("ALMPC_DBG_SPLIT_SCALE");
+    if (ltv_scales) { lp.sc_d = h->bD; lp.sc_Hs = h->bHs; lp.sc_fS = h->dFS; lp.sc_flag = h->bFlag; lp.nzs = nzs; }
     for (int it = 0; it < iters; ++it) {
         HIP_TRY(h, launch_fnn_jacobian(fp, h->num_cus, st));
         hipLaunchKernelGGL(k_sqp_prepare, dim3((unsigned)b), dim3(256), 0, st, sp);
-        HIP_TRY(h, hipMemsetAsync(h->bFlag, 0, b * sizeof(int), st));
+        if (!ltv_scales) HIP_TRY(h, hipMemsetAsync(h->bFlag, 0, b * sizeof(int), st));
         if (q.structured_qp) {   // the QP in its stage-wise form for every instance; start: v = 0 (working set = the iterate's inputs on a bound)
             h->designed = true;
             // input box without S: the primal Riccati active set (an iterate of this loop has about half of its inputs on a bound: rows a
@@ -2119,9 +2122,9 @@ int almpc_sqp_fnn_iterate(almpc_handle* h, int iters, double step_scale, const a
         }
         HIP_TRY(h, launch_design_ltv(h, lp, st));
         h->skip_admm = (q.guess_from_iterate && q.since_start > 0) ? 1 : 0;
-        launch_batched_factor(h, ds, h->rho, h->sigma, st);
+        launch_batched_factor(h, ds, h->rho, h->sigma, st, ltv_scales);
         if (h->mc > 0) HIP_TRY(h, launch_ghat_inst(h, q.A, q.B));
-        hipLaunchKernelGGL(k_fs_scale, dim3(256), dim3(256), 0, st, h->batch, nz, nzs, h->bQ, (long)nz, h->bD, h->dFS);
+        if (!ltv_scales) hipLaunchKernelGGL(k_fs_scale, dim3(256), dim3(256), 0, st, h->batch, nz, nzs, h->bQ, (long)nz, h->bD, h->dFS);
         hipLaunchKernelGGL(k_neg_gm, dim3(1, (unsigned)b), dim3(256), 0, st, nz, nzs, 1, nz, h->bG, h->dFS, h->dV0S, (long)nz * nzs, (long)nz);
         HIP_TRY(h, hipGetLastError());
         h->designed = true;

@@ -689,6 +689,10 @@ struct DesignLtvParams {
     const double* Q; const double* R; const double* S;
     const double* qadd;                      // [batch][nz] input part of the gradient (host), nullable
     double* H; double* q;                    // [batch][nz*nz] column-major, [batch][nz]
+    // k_design_ltv_reg only, sc_Hs given: the Jacobi scaling as the kernel's tail (design_scale_body on the H_i just written: d_i, the
+    // symmetrised H'_i; the design flag cleared at the start and set there) and the scaled gradient fS_i = d_i .* q_i -- the SQP
+    // iteration's k_design_scale, k_fs_scale and flag memset (three launches) ride along
+    double* sc_d = nullptr; double* sc_Hs = nullptr; double* sc_fS = nullptr; int* sc_flag = nullptr; int nzs = 0;
 };
 
 __host__ __device__ inline size_t design_ltv_lds_doubles(int n, int m, int N) {
@@ -993,7 +997,16 @@ __global__ __launch_bounds__((128 / TS) * (128 / TS)) void k_design_ltv_reg(Desi
                 H[(size_t)c * nz + r] = v;
             }
         }
-    if (tid < nz) p.q[inst * nz + tid] = 2.0 * qacc + (p.qadd ? p.qadd[inst * nz + tid] : 0.0);
+    const double qv = 2.0 * qacc + ((p.qadd && tid < nz) ? p.qadd[inst * nz + tid] : 0.0);
+    if (tid < nz) p.q[inst * nz + tid] = qv;
+    if (p.sc_Hs) {
+        if (tid == 0) p.sc_flag[inst] = 0;
+        __threadfence_block();
+        __syncthreads();   // (every LDS buffer is dead: the scaling's 128 doubles sit at the start)
+        design_scale_body(nz, p.nzs, 0, H, nullptr, p.sc_d + inst * (size_t)p.nzs, p.sc_Hs + inst * (size_t)nz * p.nzs, nullptr,
+                          p.sc_flag + inst, 0, smem);
+        if (tid < nz) p.sc_fS[inst * nz + tid] = qv * smem[tid];
+    }
 }
 
 // fS_i = d_i .* g: the constant part of the scaled gradient (g = 2 D'Sbar D u_ref, shared or per instance) for every instance
