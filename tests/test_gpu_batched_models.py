@@ -409,3 +409,49 @@ def test_wave_per_instance_step_equals_the_two_launch_path(capi, mo, monkeypatch
         if res["wave"]["status"][i] == 0:
             pi = mo.make_problem(A[i], B[i], N, -np.ones(m), np.ones(m), x_ref=x_ref, u_ref=u_ref, P=P)
             assert np.abs(res["wave"]["u"][i] - mo.solve_mpc_exact(pi, X0[i])["u"]).max() <= 1e-6
+
+
+def test_fused_design_chain_equals_the_split_launches(capi, mo, monkeypatch):
+    """Per-instance designs with nz <= 64 run the Jacobi scaling as the tail of k_design_instance_t, form V_i inside the first inverse's
+    launch and, with a scalar rho, both inverses in one launch (csrc/almpc_api.hip: launch_batched_factor).  The split launches
+    (ALMPC_DBG_SPLIT_*) are the same operations on the same operands: same scaling bit for bit, same statuses and iteration counts;
+    with the stiffness profile (two inverse launches) as well."""
+    n, m, N, b = 4, 2, 20, 200
+    f = mo.synthetic_fnn(act="relu")
+    x_ref = np.tile(np.array([0.2, -0.1, 0.05, 0.0])[:, None], (1, N + 1)); u_ref = np.tile(np.array([0.1, -0.2])[:, None], (1, N))
+    X0 = x_ref[:, 0][None, :] + mo.splitmix_normal(0x5EED0004, 0, b, n)
+    A = np.empty((b, n, n)); B = np.empty((b, n, m))
+    for i in range(b):
+        A[i], B[i] = f.jacobian(X0[i], u_ref[:, 0])
+    Q, R, P = 100.0 * np.eye(n), 0.1 * np.eye(m), 150.0 * np.eye(n)
+    switches = ("ALMPC_DBG_SPLIT_SCALE", "ALMPC_DBG_SPLIT_NEGGM", "ALMPC_DBG_SPLIT_INVERSES")
+    for profile, rho in (("scalar", 0.1), ("stiffness", 5.0)):
+        res = {}
+        for tag in ("fused", "split"):
+            for k in switches:
+                if tag == "split":
+                    monkeypatch.setenv(k, "1")
+                else:
+                    monkeypatch.delenv(k, raising=False)
+            s = capi.Solver(n, m, N, b)
+            s.design_batched(A, B, Q, R, None, P, -np.ones(m), np.ones(m), rho=rho, rho_profile=profile)
+            s.set_reference(x_ref, u_ref)
+            s.update_initialization(X0)
+            s.calculate(capi.default_opts(rho=rho))
+            res[tag] = (s.get_results(), [s.get_design_instance(i) for i in (0, 77, b - 1)])
+            s.close()
+        for k in switches:
+            monkeypatch.delenv(k, raising=False)
+        (rf, df), (rs, dsp) = res["fused"], res["split"]
+        for a_, b_ in zip(df, dsp):
+            assert np.array_equal(a_["d"], b_["d"]) and np.array_equal(a_["H"], b_["H"]) and np.array_equal(a_["F"], b_["F"])
+        assert np.array_equal(rf["status"], rs["status"]) and np.all(rf["status"] == 0)
+        assert np.array_equal(rf["iters"], rs["iters"]) and np.array_equal(rf["polish_iters"], rs["polish_iters"])
+        # V_i sums its products in another order: rounding-level differences, amplified by the conditioning of the instance (the
+        # register Gauss-Jordan inverse carries a few eps cond): both forms within 1e-6 of the exact optimum where they differ most
+        dev = np.abs(rf["u"] - rs["u"]).reshape(b, -1).max(axis=1)
+        assert np.median(dev) <= 1e-11 and dev.max() <= 5e-7
+        i = int(np.argmax(dev))
+        pi = mo.make_problem(A[i], B[i], N, -np.ones(m), np.ones(m), x_ref=x_ref, u_ref=u_ref, P=P)
+        e = mo.solve_mpc_exact(pi, X0[i])["u"]
+        assert np.abs(rf["u"][i] - e).max() <= 1e-6 and np.abs(rs["u"][i] - e).max() <= 1e-6

@@ -369,3 +369,22 @@ def test_structured_qp_solver_with_state_box_and_rate_weight(capi, mo):
     for i in good[:3]:
         X, U, hist = mo.sqp_fnn(f, X0[i], x_ref, u_ref, Q, R, S, P, umin, umax, iters, x_min=xlo, x_max=xhi, structured="dual")
         assert np.abs(rs["u"][i] - U).max() <= U_TOL
+
+
+def test_scaling_in_the_design_kernels_tail_equals_the_split_launches(capi, mo, monkeypatch):
+    """An iteration's Jacobi scaling, scaled gradient and flag reset ride in the tail of k_design_ltv_reg (three launches less):
+    the same operations on the same operands as k_design_scale / k_fs_scale behind it (ALMPC_DBG_SPLIT_SCALE) -- identical iterates."""
+    res = {}
+    for tag in ("fused", "split"):
+        if tag == "split":
+            monkeypatch.setenv("ALMPC_DBG_SPLIT_SCALE", "1")
+        else:
+            monkeypatch.delenv("ALMPC_DBG_SPLIT_SCALE", raising=False)
+        f, s, kw, X0 = _setup(capi, mo, 32, 30)
+        s.sqp_fnn_start(X0)
+        s.sqp_fnn_iterate(12)
+        res[tag] = s.get_results()
+        s.close()
+    monkeypatch.delenv("ALMPC_DBG_SPLIT_SCALE", raising=False)
+    assert np.array_equal(res["fused"]["status"], res["split"]["status"])
+    assert np.array_equal(res["fused"]["u"], res["split"]["u"]) and np.array_equal(res["fused"]["x"], res["split"]["x"])
