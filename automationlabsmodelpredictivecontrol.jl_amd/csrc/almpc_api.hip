@@ -1279,17 +1279,30 @@ hipError_t launch_design_ltv(almpc_handle* h, const DesignLtvParams& lp, hipStre
     return hipGetLastError();
 }
 
+// whether k_design_instance_t can linearise the network itself (LDS route with room for the weights and one wave's scratch)
+bool design_fuses_fnn(const almpc_handle* h, int H, int L) {
+    const size_t lds = (design_instance_lds_doubles(h->n, h->m, h->N) + fnn_weights_doubles(h->n, h->m, H, L) + fnn_wave_scratch_doubles(h->n, h->m, H)) * sizeof(double);
+    return lds <= 160 * 1024 && !getenv("ALMPC_DBG_SPLIT_JACOBIAN");
+}
+
 // The per-instance design from DEVICE-resident operands (bA, bB, bP; weights dQ, dR, dS): prediction matrices, H_i and F_i,
 // scaling, both inverses, V_i.  Launches only (handle's stream); the caller checks bFlag.
+// fuse_fnn: the models are linearisations of this network at fuse_fnn->x / u (re-linearisation pipeline): done by the design kernel's
+// own workgroups when *fused comes back true -- else the caller launches the Jacobians first
 hipError_t launch_batched_design(almpc_handle* h, const DesignStrides& ds, int useR, int useS, const double* dQ, const double* dR,
-                                 const double* dS, double rho, double sigma) {
+                                 const double* dS, double rho, double sigma, const FnnParams* fuse_fnn = nullptr) {
     const int n = h->n, m = h->m, N = h->N, nz = h->nz, nzs = h->nzs, nrb = h->nrb;
     const int njf = (n + 15) / 16, ps = 16 * njf, gs = nzs;
     const int kr = ((n * N + HESS_KC - 1) / HESS_KC) * HESS_KC;
     const unsigned gb = (unsigned)h->batch;
     hipStream_t st = h->stream;
-    const size_t inst_lds = design_instance_lds_doubles(n, m, N) * sizeof(double);
+    size_t inst_lds = design_instance_lds_doubles(n, m, N) * sizeof(double);
     hipError_t e = hipSuccess;
+    size_t fnn_off = 0;
+    if (fuse_fnn) {   // (the caller has checked design_fuses_fnn)
+        fnn_off = design_instance_lds_doubles(n, m, N);
+        inst_lds += (fnn_weights_doubles(n, m, fuse_fnn->H, fuse_fnn->L) + fnn_wave_scratch_doubles(n, m, fuse_fnn->H)) * sizeof(double);
+    }
     if (inst_lds > 160 * 1024) {   // (the LDS route below clears the flags itself)
         e = hipMemsetAsync(h->bFlag, 0, (size_t)h->batch * sizeof(int), st);
         if (e != hipSuccess) return e;
@@ -1305,6 +1318,7 @@ hipError_t launch_batched_design(almpc_handle* h, const DesignStrides& ds, int u
             dp.d = h->bD; dp.Hs = h->bHs; dp.Fs = h->bFs; dp.sd = ds.d; dp.sHs = ds.Hs; dp.sFs = ds.Fs; dp.nzs = nzs;
         }
         scaled = dp.Hs != nullptr;
+        if (fuse_fnn) { dp.fnn_on = 1; dp.fnn_off = fnn_off; dp.fnn = *fuse_fnn; }
 #define DESIGN_INST(NC_, MC_)                                                                                \
     do {                                                                                                     \
         e = ensure_dyn_lds(reinterpret_cast<const void*>(k_design_instance_t<NC_, MC_>), inst_lds);          \
@@ -1764,7 +1778,8 @@ int almpc_relin_fnn_step_async(almpc_handle* h, const almpc_opts* opts) {
     fp.W_in = q.W_in; fp.W_h = q.W_h; fp.b_h = q.b_h; fp.W_out = q.W_out;
     fp.x = h->dX0; fp.u = q.ulin; fp.ppi = 1; fp.xs_group = n; fp.us_group = m;
     fp.A = h->bA; fp.B = h->bB; fp.f = nullptr;
-    HIP_TRY(h, launch_fnn_jacobian(fp, h->num_cus, st));
+    const bool fuse_jac = design_fuses_fnn(h, q.H, q.L);   // the design kernel's workgroups linearise their own instance
+    if (!fuse_jac) HIP_TRY(h, launch_fnn_jacobian(fp, h->num_cus, st));
     if (timing) HIP_TRY(h, hipEventRecord(q.ev[1], st));
     // 2. the reference's QP for every (A_i, B_i): H_i, F_i, scaling, inverses, V_i; reference-dependent vectors.  A warm step
     // (opts.warm_start = 1 after a solved step) takes its working-set guess from the previous step's inputs shifted by one stage
@@ -1773,7 +1788,7 @@ int almpc_relin_fnn_step_async(almpc_handle* h, const almpc_opts* opts) {
     h->skip_admm = warm ? 2 : 0;
     const DesignStrides ds = batched_strides(h, false);
     {
-        const hipError_t e_ = launch_batched_design(h, ds, q.useR, q.useS, q.Q, q.R, q.S, h->rho, h->sigma);
+        const hipError_t e_ = launch_batched_design(h, ds, q.useR, q.useS, q.Q, q.R, q.S, h->rho, h->sigma, fuse_jac ? &fp : nullptr);
         if (e_ != hipSuccess) { h->skip_admm = 0; return fail(h, ALMPC_ERR_HIP, std::string("relin design: ") + hipGetErrorString(e_)); }
     }
     if (h->mc > 0) HIP_TRY(h, launch_ghat_inst(h, nullptr, nullptr));

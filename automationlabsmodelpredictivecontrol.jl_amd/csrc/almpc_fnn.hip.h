@@ -109,26 +109,38 @@ __host__ __device__ inline size_t fnn_w_lds_doubles(int n, int m, int H, int L) 
     return weights + FNN_W_WAVES * per_wave;
 }
 
-__global__ __launch_bounds__(64 * FNN_W_WAVES) void k_fnn_jacobian_w(FnnParams p) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+// weights of the network into LDS (all threads of the workgroup; the caller synchronises): Win | Wh | bh | Wout
+__device__ __forceinline__ void fnn_stage_weights(const FnnParams& p, double* smem) {
     const int n = p.n, m = p.m, H = p.H, L = p.L, nin = n + m;
-    double* Win = smem;                               // H x nin column-major
-    double* Wh = Win + (size_t)H * nin;               // [L] H x H column-major
-    double* bh = Wh + (size_t)L * H * H;              // [L] H
-    double* Wout = bh + (size_t)L * H;                // n x H column-major
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double* y = Wout + (size_t)n * H + (size_t)wv * (2 * (size_t)H + 2 * (size_t)H * nin + nin);
-    double* yn = y + H;
-    double* J = yn + H;                               // [H][nin] row-major
-    double* Jn = J + (size_t)H * nin;
-    double* z = Jn + (size_t)H * nin;
+    double* Win = smem;
+    double* Wh = Win + (size_t)H * nin;
+    double* bh = Wh + (size_t)L * H * H;
+    double* Wout = bh + (size_t)L * H;
     for (int t = threadIdx.x; t < H * nin; t += blockDim.x) Win[t] = p.W_in[t];
     for (int t = threadIdx.x; t < L * H * H; t += blockDim.x) Wh[t] = p.W_h[t];
     for (int t = threadIdx.x; t < L * H; t += blockDim.x) bh[t] = p.b_h[t];
     for (int t = threadIdx.x; t < n * H; t += blockDim.x) Wout[t] = p.W_out[t];
-    __syncthreads();
+}
+__host__ __device__ inline size_t fnn_weights_doubles(int n, int m, int H, int L) {
+    return (size_t)H * (n + m) + (size_t)L * H * H + (size_t)L * H + (size_t)n * H;
+}
+__host__ __device__ inline size_t fnn_wave_scratch_doubles(int n, int m, int H) { return 2 * (size_t)H + 2 * (size_t)H * (n + m) + (n + m); }
+
+// Jacobians (and value) of the network at ONE point by ONE wave: weights staged at `wsm` (fnn_stage_weights), `y` = the wave's own
+// scratch (fnn_wave_scratch_doubles).  Also the tail of nothing and the head of k_design_instance_t in the re-linearisation
+// pipeline (the instance's workgroup linearises its own model: one launch less per step).
+__device__ __forceinline__ void fnn_jacobian_point(const FnnParams& p, int inst, int lane, const double* wsm, double* y) {
+    const int n = p.n, m = p.m, H = p.H, L = p.L, nin = n + m;
+    const double* Win = wsm;                          // H x nin column-major
+    const double* Wh = Win + (size_t)H * nin;         // [L] H x H column-major
+    const double* bh = Wh + (size_t)L * H * H;        // [L] H
+    const double* Wout = bh + (size_t)L * H;          // n x H column-major
+    double* yn = y + H;
+    double* J = yn + H;                               // [H][nin] row-major
+    double* Jn = J + (size_t)H * nin;
+    double* z = Jn + (size_t)H * nin;
     auto wsync = []() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
-    for (int inst = blockIdx.x * FNN_W_WAVES + wv; inst < p.batch; inst += gridDim.x * FNN_W_WAVES) {
+    {
         const double* xp = p.x + (size_t)(inst / p.ppi) * p.xs_group + (size_t)(inst % p.ppi) * n;
         const double* up = p.u + (size_t)(inst / p.ppi) * p.us_group + (size_t)(inst % p.ppi) * m;
         for (int t = lane; t < nin; t += 64) z[t] = t < n ? xp[t] : up[t - n];
@@ -181,6 +193,16 @@ __global__ __launch_bounds__(64 * FNN_W_WAVES) void k_fnn_jacobian_w(FnnParams p
             }
         wsync();  // the next point overwrites z, y, J
     }
+}
+
+__global__ __launch_bounds__(64 * FNN_W_WAVES) void k_fnn_jacobian_w(FnnParams p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double* y = smem + fnn_weights_doubles(p.n, p.m, p.H, p.L) + (size_t)wv * fnn_wave_scratch_doubles(p.n, p.m, p.H);
+    fnn_stage_weights(p, smem);
+    __syncthreads();
+    for (int inst = blockIdx.x * FNN_W_WAVES + wv; inst < p.batch; inst += gridDim.x * FNN_W_WAVES)
+        fnn_jacobian_point(p, inst, lane, smem, y);
 }
 
 }  // namespace almpc

@@ -544,6 +544,9 @@ struct DesignInstParams {
                                                                            // by a memset launch in front of every re-design)
     // the Jacobi scaling as the tail of this kernel (design_scale_body on the H_i, F_i just written) when Hs is given: d_i, H'_i, F'_i
     double* d = nullptr; double* Hs = nullptr; double* Fs = nullptr; long sd = 0, sHs = 0, sFs = 0; int nzs = 0;
+    // the re-linearisation pipeline: the instance's own workgroup linearises its model first (fnn_jacobian_point by wave 0 into A, B,
+    // which are then read back as before) when fnn_on; network weights + one wave's scratch at smem + fnn_off
+    int fnn_on = 0; size_t fnn_off = 0; FnnParams fnn;
 };
 
 __host__ __device__ inline size_t design_instance_lds_doubles(int n, int m, int N) {
@@ -575,6 +578,15 @@ __global__ __launch_bounds__(256) void k_design_instance_t(DesignInstParams p) {
     double* E = PG + (size_t)N * nm;           // [N][m*n]: E_a (then prefix sums), element (p, j) at [j*m + p]
     double* EP = E + (size_t)N * nm;           // E^P_a
     const int T = blockDim.x;
+    if (p.fnn_on) {
+        double* wsm = smem + p.fnn_off;
+        fnn_stage_weights(p.fnn, wsm);
+        __syncthreads();
+        if (threadIdx.x < 64)
+            fnn_jacobian_point(p.fnn, blockIdx.x, threadIdx.x, wsm, wsm + fnn_weights_doubles(p.fnn.n, p.fnn.m, p.fnn.H, p.fnn.L));
+        __threadfence_block();
+        __syncthreads();   // (A_i, B_i are in the handle's model slots now: read back below, by the step's rollout and by the redo)
+    }
     if (p.flag && threadIdx.x == 0) p.flag[blockIdx.x * p.sFlag] = 0;
     for (int t = threadIdx.x; t < nn; t += T) { As[t] = A[t]; Qs[t] = p.Q[t]; Ps[t] = P[t]; Phi[t] = (t % n == t / n) ? 1.0 : 0.0; }
     for (int t = threadIdx.x; t < nm; t += T) Bs[t] = B[t];
