@@ -160,6 +160,7 @@ struct almpc_handle {
         int32_t* ovf = nullptr;
         int32_t* wsave = nullptr;   // [batch][SDUAL_WSAVE] working set of an instance that ran out of room (start of the next tier)
         double* sinv_glb = nullptr; size_t sinv_cap = 0;   // third tier: Sinv of 128 x 129 per wave of its grid
+        double* ghat = nullptr; size_t ghat_cap = 0; bool ghat_ready = false, ghat_building = false;   // shared model: cached sweep responses [TP][TP] (k_sdual: SdualParams::ghat)
         std::vector<double> S;               // symmetrised S (base terms of time-varying input references)
     } sd;
     // multi-GPU (almpc_comm_*): this handle's rank in an RCCL communicator of one process per GPU
@@ -284,7 +285,7 @@ void free_all(almpc_handle* h) {
         if (e) (void)hipEventDestroy(e);
     if (h->comm && rccl_api().ok) (void)rccl_api().CommDestroy(h->comm);
     for (void* p : {(void*)h->dComm4, (void*)h->dU0, (void*)h->dU0all, (void*)h->rQ, (void*)h->rR, (void*)h->rP, (void*)h->rKst, (void*)h->rPst, (void*)h->rGuess,
-                    (void*)h->sd.rec, (void*)h->sd.base, (void*)h->sd.xmin, (void*)h->sd.xmax, (void*)h->sd.eqt, (void*)h->sd.ovf, (void*)h->sd.wsave, (void*)h->sd.sinv_glb, (void*)h->sd.dQ, (void*)h->sd.dR, (void*)h->sd.dS, (void*)h->sd.dP, (void*)h->sd.bad, (void*)h->sd.pc, (void*)h->sd.ct})
+                    (void*)h->sd.rec, (void*)h->sd.base, (void*)h->sd.xmin, (void*)h->sd.xmax, (void*)h->sd.eqt, (void*)h->sd.ovf, (void*)h->sd.wsave, (void*)h->sd.sinv_glb, (void*)h->sd.ghat, (void*)h->sd.dQ, (void*)h->sd.dR, (void*)h->sd.dS, (void*)h->sd.dP, (void*)h->sd.bad, (void*)h->sd.pc, (void*)h->sd.ct})
         if (p) (void)hipFree(p);
     if (h->ev_guess) (void)hipEventDestroy(h->ev_guess);
     if (h->ev_guess_done) (void)hipEventDestroy(h->ev_guess_done);
@@ -473,6 +474,8 @@ bool sdual_shape_ok(int n, int m, int N, bool useS) {
 
 // Stage records of a SHARED model on the device (host Riccati, design time), state box / terminal equality / S of the design.
 // Rm: the reference's branch rule applied (zeros when R[1,1] == 0); Sm null: no input-rate term.
+hipError_t launch_sdual(almpc_handle* h, int filter, const double* guess, int max_iter, bool single_launch = false, int first_tier = 0);
+
 int sdual_setup_shared(almpc_handle* h, const hm::mat& Am, const hm::mat& Bm, const hm::mat& Qm, const hm::mat& Rm, const hm::mat* Sm,
                        const hm::mat& Pm, const double* xmin, const double* xmax, bool terminal_eq) {
     const int n = h->n, m = h->m, N = h->N;
@@ -511,6 +514,23 @@ int sdual_setup_shared(almpc_handle* h, const hm::mat& Am, const hm::mat& Bm, co
     sd.has_base = false; sd.base_stride = 0;
     sd.per_instance = false; sd.gain_N = 0; sd.sqp = false;
     sd.ready = true;
+    // cached responses: every coordinate that can be a row, one sweep each, once (k_sdual's build mode on min(TP, 2048) waves)
+    sd.ghat_ready = false;
+    const size_t TP = (size_t)sdual_tp(sd.NT, sd.MC, N);
+    if (TP * TP * sizeof(double) <= ((size_t)256 << 20) && !getenv("ALMPC_SDUAL_NO_GHAT")) {
+        if (sd.ghat_cap < TP * TP) {
+            if (sd.ghat) { (void)hipFree(sd.ghat); sd.ghat = nullptr; sd.ghat_cap = 0; }
+            HIP_TRY(h, dalloc(&sd.ghat, TP * TP));
+            sd.ghat_cap = TP * TP;
+        }
+        HIP_TRY(h, hipMemsetAsync(sd.ghat, 0, TP * TP * sizeof(double), h->stream));
+        sd.ghat_building = true;
+        const hipError_t build_rc = launch_sdual(h, 0, nullptr, 0);
+        sd.ghat_building = false;
+        HIP_TRY(h, build_rc);
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        sd.ghat_ready = true;
+    }
     return ALMPC_OK;
 }
 
@@ -701,7 +721,7 @@ hipError_t launch_sdual_t(almpc_handle* h, SdualParams sp, int tier0, int tier1)
 
 // k_sdual over the batch (filter 0), over the instances whose status is not 0 (filter 1: redo after the condensed path), start from
 // `guess` (inputs [batch][N][m]) when given
-hipError_t launch_sdual(almpc_handle* h, int filter, const double* guess, int max_iter, bool single_launch = false, int first_tier = 0) {
+hipError_t launch_sdual(almpc_handle* h, int filter, const double* guess, int max_iter, bool single_launch, int first_tier) {
     const almpc_handle::Sd& sd = h->sd;
     if (!sd.ready) return hipErrorInvalidValue;
     SdualParams sp;
@@ -728,6 +748,19 @@ hipError_t launch_sdual(almpc_handle* h, int filter, const double* guess, int ma
     }
     sp.ovf = sd.ovf; sp.only_ovf = 0; sp.wsave = sd.wsave;
     sp.gbad = sd.per_instance ? sd.bad : nullptr;
+    sp.ghat = (sd.ghat_ready && !sd.per_instance && !sd.sqp && sd.rec_stride == 0) ? sd.ghat : nullptr;
+    if (sd.ghat_building) {   // design time: the waves walk the coordinates (no instance data is read)
+        const int TP = sdual_tp(sd.NT, sd.MC, h->N);
+        sp.build_ghat = 1; sp.ghat_out = sd.ghat; sp.ghat = nullptr;
+        sp.batch = TP < 2048 ? TP : 2048;
+        sp.uref_stride = 0; sp.xbref = nullptr; sp.xbref_stride = 0; sp.x0 = nullptr; sp.xref = nullptr; sp.xref_stride = 0;
+        sp.eqt = sd.has_eq ? sd.rec : nullptr; sp.eqt_stride = 0;   // (has_eq decides which coordinates can be rows; the target values are not used)
+        sp.umin = sd.rec; sp.umax = sd.rec; sp.uref = sd.rec;       // (read into the bound tables, not used: the handle's own arrays may not exist yet)
+        sp.x = sp.ex = sp.u = sp.eu = nullptr; sp.status = nullptr; sp.piters = nullptr;
+        sp.base = nullptr; sp.pc = nullptr; sp.ct = nullptr; sp.uguess = nullptr; sp.filter = 0; sp.flag = nullptr;
+        sp.ovf = nullptr; sp.wsave = nullptr; sp.gbad = nullptr;
+        single_launch = false; first_tier = 0;
+    }
     sp.rows_state = (sd.has_box || sd.has_eq) ? 1 : 0;
     const int rows = h->N * h->m + ((sd.has_box || sd.has_eq) ? h->N * h->n : 0);
     sp.max_iter = max_iter > 0 ? max_iter : 20 * rows + 50;
@@ -735,6 +768,7 @@ hipError_t launch_sdual(almpc_handle* h, int filter, const double* guess, int ma
     // single launch (the redo behind a condensed step: few instances, occupancy does not matter): the 128-row build when its Sinv fits
     // LDS beside the trajectories, else the 64-row one.  first_tier 1: starts that are known to hold many rows
     int tier0 = first_tier, tier1 = 3;
+    if (sd.ghat_building) tier1 = 0;
     if (single_launch) {
         int NT_ = sd.NT, MC_ = sd.MC;
         const bool fits128 = (size_t)sdual_lds_doubles(NT_, MC_, h->N, SD_WCAP4, true) * sizeof(double) <= 160 * 1024;

@@ -57,6 +57,14 @@ struct SdualParams {
     int wcap;                                          // working-set capacity (<= 64 PPL)
     int lds_per_wave;                                  // doubles
     double* sinv_glb;                                  // PPL = 2 builds: [waves in the grid][wcap (wcap + 1)] scratch for Sinv
+    // Shared model: the responses do not depend on the instance -- column t of ghat ([TP][TP]) is the sweep response to the source -0.5 on
+    // coordinate t, built once at design time (build_ghat: `batch` waves walk the coordinates that can be rows and store their sweeps
+    // to ghat_out).  With it a working-set change costs NO sweep: the response of the new row is a column load, the direction is the
+    // column minus the working set's columns times r (L2 resident: 1.9 MB at N = 30, 5.3 MB at N = 50) -- a latency chain of two sweeps
+    // (40-60 k cycles) becomes a stream of |W| + 1 columns.  Full solves (start, confirmation) stay sweeps.
+    const double* ghat = nullptr;
+    double* ghat_out = nullptr;
+    int build_ghat = 0;
 };
 
 __host__ __device__ inline int sdual_tp(int NT, int MC, int N) { return (N * (NT + MC) + NT + 1) & ~1; }
@@ -577,6 +585,21 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
             sd_fence();
         };
 
+        if (p.build_ghat) {   // design time: this wave's share of the columns of ghat
+            for (int t = inst; t < N * SP + NT; t += p.batch) {
+                const int k = t / SP, j = t - k * SP;
+                const bool can_be_row = j >= NT ? (j - NT < m && k < N) : (j < n && k >= 1 && (has_box || (has_eq && k == N)));
+                if (!can_be_row) continue;
+                zero_w();
+                sd_fence();
+                if (lane == 0) w[t] = -0.5;
+                sd_fence();
+                sweep(stage_of(t), N, false);
+                for (int i = lane; i < TP; i += 64) p.ghat_out[(size_t)t * TP + i] = w[i];
+                sd_fence();
+            }
+            continue;
+        }
         int it = 0, status = 1;
         bool bad = false, overflow = false;
         // ---- stage 1 of the reference is x0 itself: outside the state box -> infeasible
@@ -624,7 +647,7 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
             }
             // ---- sources of this pass's sweep
             int kb, kend;
-            bool full = false;
+            bool full = false, use_sweep = true;
             if (mode == M_FULL) {
                 if (bsg) { for (int t = lane; t < TP; t += 64) w[t] = bsg[t]; }
                 else zero_w();
@@ -641,9 +664,67 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
                     publish(cpos);
                     sinv_mul(cbuf, rpos);
                 }
+                const int tsrc = mode == M_START ? (slist[si] >> 2) : pr;
+                if (p.ghat) {   // cached responses (shared model): no sweep
+                    use_sweep = false;
+                    const double* gp = p.ghat + (size_t)tsrc * TP;
+                    if (mode != M_DIR) {
+                        for (int t0 = 0; t0 < TP; t0 += 512) {   // (the column's loads in flight together: one at a time is an L2 round trip each)
+                            double v[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) { const int t = t0 + 64 * j + lane; v[j] = gp[t < TP ? t : TP - 1]; }
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) { const int t = t0 + 64 * j + lane; if (t < TP) w[t] = v[j]; }
+                        }
+                    } else {
+                        // w = R_p - sum_l r_l R_{W_l}: rows and coefficients of the working set through LDS (slist is free after the start)
+#pragma unroll
+                        for (int sl = 0; sl < PPL; ++sl)
+                            if (sl * 64 + lane < nW) { ubuf[sl * 64 + lane] = rpos[sl]; slist[sl * 64 + lane] = Wrow[sl]; }
+                        sd_fence();
+                        for (int t0 = 0; t0 < TP; t0 += 256) {   // four coordinates per lane and pass, two columns at a time (8 loads in
+                            // flight): all this kernel's registers allow -- it sits at 241 - 253 without this loop, which leaves a direction
+                            // at an L2 round trip per column pair (25 k cycles at 41 rows, against 50 k for the two sweeps it replaces).
+                            // Measured and dropped: eight coordinates x four columns inlined (240 B of scratch per lane), as a function of
+                            // its own (the call site spills as much), in a build whose sweeps fetch the records themselves (the record
+                            // registers stay live all the same)
+                            double acc[4];
+                            int tc[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int t = t0 + 64 * j + lane;
+                                tc[j] = t < TP ? t : TP - 1;
+                                acc[j] = gp[tc[j]];
+                            }
+                            int l = 0;
+                            for (; l + 2 <= nW; l += 2) {
+                                const double* g0 = p.ghat + (size_t)__builtin_amdgcn_readfirstlane(slist[l]) * TP;
+                                const double* g1 = p.ghat + (size_t)__builtin_amdgcn_readfirstlane(slist[l + 1]) * TP;
+                                const double r0 = ubuf[l], r1 = ubuf[l + 1];
+                                double a0[4], a1[4];
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) { a0[j] = g0[tc[j]]; a1[j] = g1[tc[j]]; }
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) acc[j] = fma(-r1, a1[j], fma(-r0, a0[j], acc[j]));
+                            }
+                            if (l < nW) {
+                                const double* g0 = p.ghat + (size_t)__builtin_amdgcn_readfirstlane(slist[l]) * TP;
+                                const double r0 = ubuf[l];
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) acc[j] = fma(-r0, g0[tc[j]], acc[j]);
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int t = t0 + 64 * j + lane;
+                                if (t < TP) w[t] = acc[j];
+                            }
+                        }
+                    }
+                    sd_fence();
+                    kb = 0; kend = 0;
+                } else {
                 zero_w();
                 sd_fence();
-                const int tsrc = mode == M_START ? (slist[si] >> 2) : pr;
                 if (lane == 0) w[tsrc] = -0.5;
                 if (mode == M_DIR) {
 #pragma unroll
@@ -655,9 +736,10 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
                 const int km = ksrc > kmaxW ? ksrc : kmaxW;
                 kb = mode == M_DIR ? km : ksrc;
                 kend = mode == M_DIR ? N : (mode == M_START ? st_kend : (km + 1 < N ? km + 1 : N));
+                }
                 SD_ACC(3);
             }
-            sweep(kb, kend, full);
+            if (use_sweep) sweep(kb, kend, full);
             // ---- what the sweep was for
             if (mode == M_FULL) {
                 double* t_ = s; s = w; w = t_;
