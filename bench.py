@@ -972,7 +972,7 @@ def main():
         try:
             import csv
             ks, src = {}, None
-            for cand in ("r3_sqp_kernel_stats.csv", "r2_sqp_kernel_stats.csv"):
+            for cand in ("r4_sqp_kernel_stats.csv", "r3_sqp_kernel_stats.csv", "r2_sqp_kernel_stats.csv"):
                 if os.path.exists(os.path.join(ROOT, "profiles", cand)):
                     src = cand
                     break
