@@ -691,15 +691,23 @@ hipError_t launch_sdual_t(almpc_handle* h, SdualParams sp, int tier0, int tier1)
         if (glb) cap = h->num_cus;
         if (wgs > cap) wgs = cap;
         hipError_t e;
+        const size_t lds_gh = lds + (size_t)sdual_rec_stage(NT, MC) * sizeof(double);   // (+ the workgroup's copy of a stage-invariant record)
+        // cached responses: the build whose sweeps fetch their records stage by stage where working-set changes dominate (see k_sdual)
+        const bool gh = sp.ghat != nullptr && lds_gh <= 160 * 1024 && (sp.xmin != nullptr || sp.rec_kstride != 0) && !getenv("ALMPC_SDUAL_NO_GH");
         if (tier < 2) {
-            e = ensure_dyn_lds(reinterpret_cast<const void*>(k_sdual<NT, MC, 1, false>), lds);
+            const void* kf = gh ? reinterpret_cast<const void*>(k_sdual<NT, MC, 1, false, true>) : reinterpret_cast<const void*>(k_sdual<NT, MC, 1, false, false>);
+            e = ensure_dyn_lds(kf, gh ? lds_gh : lds);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((k_sdual<NT, MC, 1, false>), dim3(wgs), dim3(64 * waves), lds, h->stream, sp);
+            if (gh) hipLaunchKernelGGL((k_sdual<NT, MC, 1, false, true>), dim3(wgs), dim3(64 * waves), lds_gh, h->stream, sp);
+            else hipLaunchKernelGGL((k_sdual<NT, MC, 1, false, false>), dim3(wgs), dim3(64 * waves), lds, h->stream, sp);
         } else if (!glb) {
-            e = ensure_dyn_lds(reinterpret_cast<const void*>(k_sdual<NT, MC, 2, false>), lds);
+            const void* kf = gh ? reinterpret_cast<const void*>(k_sdual<NT, MC, 2, false, true>) : reinterpret_cast<const void*>(k_sdual<NT, MC, 2, false, false>);
+            e = ensure_dyn_lds(kf, gh ? lds_gh : lds);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((k_sdual<NT, MC, 2, false>), dim3(wgs), dim3(64 * waves), lds, h->stream, sp);
+            if (gh) hipLaunchKernelGGL((k_sdual<NT, MC, 2, false, true>), dim3(wgs), dim3(64 * waves), lds_gh, h->stream, sp);
+            else hipLaunchKernelGGL((k_sdual<NT, MC, 2, false, false>), dim3(wgs), dim3(64 * waves), lds, h->stream, sp);
         } else {
+            sp.ghat = nullptr;   // (the global-scratch build has no cached-response variant: sweeps)
             const size_t need = (size_t)wgs * waves * sdual_sinv_doubles(SD_WCAP4);
             if (h->sd.sinv_cap < need) {
                 if (h->sd.sinv_glb) { (void)hipFree(h->sd.sinv_glb); h->sd.sinv_glb = nullptr; h->sd.sinv_cap = 0; }

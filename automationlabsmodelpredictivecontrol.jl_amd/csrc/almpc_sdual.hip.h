@@ -147,7 +147,13 @@ __device__ __forceinline__ void sd_dot_bcast(double& acc0, double& acc1, double 
 
 // <NT, MC>: padded stage-state / input dimensions; PPL: working-set positions per lane (1: up to 64 rows, 2: up to 128); GLB: Sinv in
 // a global scratch instead of LDS (the last tier: rare instances, mostly infeasible ones whose verdict needs that many rows).
-template <int NT, int MC, int PPL, bool GLB>
+// GH: a build for cached responses (SdualParams::ghat != null) whose sweeps (full solves only) take the stage-varying path -- the
+// records are fetched stage by stage, also when they do not vary (then from a copy in LDS) -- so that no record register is live
+// outside a sweep: the column stream of a direction then has the registers for 32 loads in flight.  Its sweeps are slower (0.74 against
+// 0.52 ms on the input-box benchmark, where two or three full solves are most of an instance's work); it pays where working-set changes
+// dominate: state box 4.8 -> 4.3 ms, `S` 0.71 -> 0.63 ms, the redo of edge-of-feasibility instances 1.37 -> 1.2 ms.  The host picks
+// it for problems with a state box or stage-varying records; the others stream from the resident-record build.
+template <int NT, int MC, int PPL, bool GLB, bool GH = false>
 __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
     static_assert((NT % 2) == 0 && (MC % 2) == 0, "even dimensions (16-byte loads)");
     static_assert(PPL == 1 || PPL == 2, "one or two working-set positions per lane");
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
     const bool is_state_lane = lane0 < NT, is_input_lane = lane0 >= NT && lane0 < SP;
     // record row of this lane0: the DPP build repeats the stage in every row of 16 lanes; else idle lanes shadow the last row
     const int rrow = ROWDPP ? ((lane0 & 15) < SP ? (lane0 & 15) : SP - 1) : (lane0 < SP ? lane0 : SP - 1);
-    const bool kvar = p.rec_kstride != 0;
+    const bool kvar = GH || p.rec_kstride != 0;
     const bool has_box = p.xmin != nullptr, has_eq = p.eqt != nullptr, with_c = p.pc != nullptr;
 
     double r1[NT], sb[MC], r2[NT], r3[MC];
@@ -205,6 +211,16 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
     auto load_bw = [&](const double* recg, int k) { load_half(recg, k, 0, r1, sb); };
     auto load_fw = [&](const double* recg, int k) { load_half(recg, k, NT + MC, r2, r3); };
     if (!kvar && p.rec_stride == 0) { load_bw(p.rec, 0); load_fw(p.rec, 0); }
+    // GH build: a stage-invariant record (4 KB for the quadrotor) is copied to LDS once per workgroup, behind the waves' own buffers; the
+    // sweeps' stage-by-stage fetches then come from there (an LDS latency, requested one stage ahead) instead of from L2
+    const double* recl = smem + (size_t)(blockDim.x >> 6) * p.lds_per_wave;
+    if constexpr (GH) {
+        if (p.rec_kstride == 0) {
+            double* dst = smem + (size_t)(blockDim.x >> 6) * p.lds_per_wave;
+            for (int i = threadIdx.x; i < sdual_rec_stage(NT, MC); i += blockDim.x) dst[i] = p.rec[i];
+            __syncthreads();
+        }
+    }
 
     const int nwaves = gridDim.x * wpb;
     for (int inst = blockIdx.x * wpb + wv; inst < p.batch; inst += nwaves) {
@@ -230,6 +246,7 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
         long long sd_nbw = 0, sd_nfw = 0;
 #endif
         const double* recg = p.rec + (size_t)inst * p.rec_stride;
+        if constexpr (GH) { if (p.rec_kstride == 0) recg = recl; }   // (stage-invariant records: the workgroup's copy in LDS)
         const double* urg = p.uref + (size_t)inst * p.uref_stride;
         const double* xbr = p.xbref ? p.xbref + (size_t)inst * p.xbref_stride : nullptr;
         const double* xrg = p.xref ? p.xref + (size_t)inst * p.xref_stride : nullptr;
@@ -585,21 +602,6 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
             sd_fence();
         };
 
-        if (p.build_ghat) {   // design time: this wave's share of the columns of ghat
-            for (int t = inst; t < N * SP + NT; t += p.batch) {
-                const int k = t / SP, j = t - k * SP;
-                const bool can_be_row = j >= NT ? (j - NT < m && k < N) : (j < n && k >= 1 && (has_box || (has_eq && k == N)));
-                if (!can_be_row) continue;
-                zero_w();
-                sd_fence();
-                if (lane == 0) w[t] = -0.5;
-                sd_fence();
-                sweep(stage_of(t), N, false);
-                for (int i = lane; i < TP; i += 64) p.ghat_out[(size_t)t * TP + i] = w[i];
-                sd_fence();
-            }
-            continue;
-        }
         int it = 0, status = 1;
         bool bad = false, overflow = false;
         // ---- stage 1 of the reference is x0 itself: outside the state box -> infeasible
@@ -618,9 +620,10 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
         //   M_RESP   response of the most violated row p: c = Ghat[W, p], Ghat_pp
         //   M_DIR    direction Ghat (e_p - sum_w r_w e_w) in row space: ratio test, step, drop of a blocking row or addition of p
         //   M_TOP    (no sweep) pick the most violated row or go and confirm
-        enum { M_FULL, M_START, M_RESP, M_DIR, M_TOP };
+        enum { M_FULL, M_START, M_RESP, M_DIR, M_TOP, M_BUILD };   // M_BUILD: design time, the columns of ghat (SdualParams::build_ghat)
         enum { A_INIT, A_TOP, A_CONFIRM };
-        int mode = M_FULL, after = A_INIT;
+        int mode = p.build_ghat ? M_BUILD : M_FULL, after = A_INIT;
+        int bt = inst - p.batch;   // (build mode: this wave's coordinates are inst, inst + batch, ...)
         int ns = 0, si = 0, st_kend = N, refined = 0;
         int pr = 0, sd = 0;
         double bp = 0.0, lam_p = 0.0, gpp = 0.0;
@@ -648,7 +651,20 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
             // ---- sources of this pass's sweep
             int kb, kend;
             bool full = false, use_sweep = true;
-            if (mode == M_FULL) {
+            if (mode == M_BUILD) {   // next coordinate of this wave that can be a row: unit source, full-length response
+                bool found = false;
+                for (bt += p.batch; bt < N * SP + NT; bt += p.batch) {
+                    const int k = bt / SP, j = bt - k * SP;
+                    found = j >= NT ? (j - NT < m && k < N) : (j < n && k >= 1 && (has_box || (has_eq && k == N)));
+                    if (found) break;
+                }
+                if (!found) break;
+                zero_w();
+                sd_fence();
+                if (lane == 0) w[bt] = -0.5;
+                sd_fence();
+                kb = stage_of(bt); kend = N;
+            } else if (mode == M_FULL) {
                 if (bsg) { for (int t = lane; t < TP; t += 64) w[t] = bsg[t]; }
                 else zero_w();
                 sd_fence();
@@ -682,39 +698,45 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
                         for (int sl = 0; sl < PPL; ++sl)
                             if (sl * 64 + lane < nW) { ubuf[sl * 64 + lane] = rpos[sl]; slist[sl * 64 + lane] = Wrow[sl]; }
                         sd_fence();
-                        for (int t0 = 0; t0 < TP; t0 += 256) {   // four coordinates per lane and pass, two columns at a time (8 loads in
-                            // flight): all this kernel's registers allow -- it sits at 241 - 253 without this loop, which leaves a direction
-                            // at an L2 round trip per column pair (25 k cycles at 41 rows, against 50 k for the two sweeps it replaces).
-                            // Measured and dropped: eight coordinates x four columns inlined (240 B of scratch per lane), as a function of
-                            // its own (the call site spills as much), in a build whose sweeps fetch the records themselves (the record
-                            // registers stay live all the same)
-                            double acc[4];
-                            int tc[4];
+                        // GH build: eight coordinates per lane and pass, four columns at a time -- 32 loads in flight per lane; the build that
+                        // keeps the stage records resident has the registers for four coordinates x two columns (a direction is then an L2
+                        // round trip per column pair: 25 k cycles at 41 rows, against 50 k for the two sweeps it replaces)
+                        constexpr int CPL = GH ? 8 : 4, LU = GH ? 4 : 2;
+                        for (int t0 = 0; t0 < TP; t0 += 64 * CPL) {
+                            double acc[CPL];
+                            int tc[CPL];
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
+                            for (int j = 0; j < CPL; ++j) {
                                 const int t = t0 + 64 * j + lane;
                                 tc[j] = t < TP ? t : TP - 1;
                                 acc[j] = gp[tc[j]];
                             }
                             int l = 0;
-                            for (; l + 2 <= nW; l += 2) {
-                                const double* g0 = p.ghat + (size_t)__builtin_amdgcn_readfirstlane(slist[l]) * TP;
-                                const double* g1 = p.ghat + (size_t)__builtin_amdgcn_readfirstlane(slist[l + 1]) * TP;
-                                const double r0 = ubuf[l], r1 = ubuf[l + 1];
-                                double a0[4], a1[4];
+                            for (; l + LU <= nW; l += LU) {
+                                double a_[LU][CPL], r_[LU];
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) { a0[j] = g0[tc[j]]; a1[j] = g1[tc[j]]; }
+                                for (int u = 0; u < LU; ++u) {
+                                    const double* gl = p.ghat + (size_t)__builtin_amdgcn_readfirstlane(slist[l + u]) * TP;
+                                    r_[u] = ubuf[l + u];
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) acc[j] = fma(-r1, a1[j], fma(-r0, a0[j], acc[j]));
+                                    for (int j = 0; j < CPL; ++j) a_[u][j] = gl[tc[j]];
+                                }
+#pragma unroll
+                                for (int u = 0; u < LU; ++u)
+#pragma unroll
+                                    for (int j = 0; j < CPL; ++j) acc[j] = fma(-r_[u], a_[u][j], acc[j]);
                             }
-                            if (l < nW) {
-                                const double* g0 = p.ghat + (size_t)__builtin_amdgcn_readfirstlane(slist[l]) * TP;
+                            for (; l < nW; ++l) {
+                                const double* gl = p.ghat + (size_t)__builtin_amdgcn_readfirstlane(slist[l]) * TP;
                                 const double r0 = ubuf[l];
+                                double a_[CPL];
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) acc[j] = fma(-r0, g0[tc[j]], acc[j]);
+                                for (int j = 0; j < CPL; ++j) a_[j] = gl[tc[j]];
+#pragma unroll
+                                for (int j = 0; j < CPL; ++j) acc[j] = fma(-r0, a_[j], acc[j]);
                             }
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
+                            for (int j = 0; j < CPL; ++j) {
                                 const int t = t0 + 64 * j + lane;
                                 if (t < TP) w[t] = acc[j];
                             }
@@ -741,7 +763,10 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
             }
             if (use_sweep) sweep(kb, kend, full);
             // ---- what the sweep was for
-            if (mode == M_FULL) {
+            if (mode == M_BUILD) {
+                for (int i = lane; i < TP; i += 64) p.ghat_out[(size_t)bt * TP + i] = w[i];
+                sd_fence();
+            } else if (mode == M_FULL) {
                 double* t_ = s; s = w; w = t_;
                 to_abs();
                 if (after == A_INIT) {
@@ -923,6 +948,7 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
                 }
             }
         }
+        if (p.build_ghat) continue;
         // a working set that ran out of room: kept for the next tier (rows and sides; the multipliers are recomputed there)
         if (overflow && !bad && p.wsave) {
 #pragma unroll
