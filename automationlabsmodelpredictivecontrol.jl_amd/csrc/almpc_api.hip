@@ -691,7 +691,7 @@ hipError_t launch_sdual_t(almpc_handle* h, SdualParams sp, int tier0, int tier1)
         if (glb) cap = h->num_cus;
         if (wgs > cap) wgs = cap;
         hipError_t e;
-        const size_t lds_gh = lds + (size_t)sdual_rec_stage(NT, MC) * sizeof(double);   // (+ the workgroup's copy of a stage-invariant record)
+        const size_t lds_gh = lds + (size_t)(NT + MC) * (sdual_rec_row(NT, MC) + 2) * sizeof(double);   // (+ the workgroup's copy of a stage-invariant record, rows padded)
         // cached responses: the build whose sweeps fetch their records stage by stage where working-set changes dominate (see k_sdual)
         const bool gh = sp.ghat != nullptr && lds_gh <= 160 * 1024 && (sp.xmin != nullptr || sp.rec_kstride != 0) && !getenv("ALMPC_SDUAL_NO_GH");
         if (tier < 2) {

@@ -200,9 +200,12 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
     const bool kvar = GH || p.rec_kstride != 0;
     const bool has_box = p.xmin != nullptr, has_eq = p.eqt != nullptr, with_c = p.pc != nullptr;
 
+    // row stride of the records being read: RL, or RL + 2 for the GH build's copy in LDS (rows 256 B apart would put all sixteen rows of a
+    // stage on the same four banks: measured 1.8 - 2.5 k cycles per stage instead of 0.3 - 0.5 k)
+    const int rrl = (GH && p.rec_kstride == 0) ? RL + 2 : RL;
     double r1[NT], sb[MC], r2[NT], r3[MC];
     auto load_half = [&](const double* recg, int k, int off, double* a, double* b) {   // one half of a record row: [NT | MC] doubles
-        const double* rk = recg + (size_t)k * p.rec_kstride + (size_t)rrow * RL + off;
+        const double* rk = recg + (size_t)k * p.rec_kstride + (size_t)rrow * rrl + off;
 #pragma unroll
         for (int j = 0; j < NT; j += 2) { const double2 t = *reinterpret_cast<const double2*>(rk + j); a[j] = t.x; a[j + 1] = t.y; }
 #pragma unroll
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
     if constexpr (GH) {
         if (p.rec_kstride == 0) {
             double* dst = smem + (size_t)(blockDim.x >> 6) * p.lds_per_wave;
-            for (int i = threadIdx.x; i < sdual_rec_stage(NT, MC); i += blockDim.x) dst[i] = p.rec[i];
+            for (int i = threadIdx.x; i < sdual_rec_stage(NT, MC); i += blockDim.x) dst[(i / RL) * (RL + 2) + i % RL] = p.rec[i];
             __syncthreads();
         }
     }
