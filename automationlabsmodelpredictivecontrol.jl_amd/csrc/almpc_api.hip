@@ -692,8 +692,8 @@ hipError_t launch_sdual_t(almpc_handle* h, SdualParams sp, int tier0, int tier1)
         if (wgs > cap) wgs = cap;
         hipError_t e;
         const size_t lds_gh = lds + (size_t)(NT + MC) * (sdual_rec_row(NT, MC) + 2) * sizeof(double);   // (+ the workgroup's copy of a stage-invariant record, rows padded)
-        // cached responses: the build whose sweeps fetch their records stage by stage where working-set changes dominate (see k_sdual)
-        const bool gh = sp.ghat != nullptr && lds_gh <= 160 * 1024 && (sp.xmin != nullptr || sp.rec_kstride != 0) && !getenv("ALMPC_SDUAL_NO_GH");
+        // cached responses: the build whose sweeps fetch their records stage by stage and whose column stream runs four times deeper (see k_sdual)
+        const bool gh = sp.ghat != nullptr && lds_gh <= 160 * 1024 && !getenv("ALMPC_SDUAL_NO_GH");
         if (tier < 2) {
             const void* kf = gh ? reinterpret_cast<const void*>(k_sdual<NT, MC, 1, false, true>) : reinterpret_cast<const void*>(k_sdual<NT, MC, 1, false, false>);
             e = ensure_dyn_lds(kf, gh ? lds_gh : lds);

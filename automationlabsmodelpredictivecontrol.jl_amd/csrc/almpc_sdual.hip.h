@@ -147,12 +147,12 @@ __device__ __forceinline__ void sd_dot_bcast(double& acc0, double& acc1, double 
 
 // <NT, MC>: padded stage-state / input dimensions; PPL: working-set positions per lane (1: up to 64 rows, 2: up to 128); GLB: Sinv in
 // a global scratch instead of LDS (the last tier: rare instances, mostly infeasible ones whose verdict needs that many rows).
-// GH: a build for cached responses (SdualParams::ghat != null) whose sweeps (full solves only) take the stage-varying path -- the
-// records are fetched stage by stage, also when they do not vary (then from a copy in LDS) -- so that no record register is live
-// outside a sweep: the column stream of a direction then has the registers for 32 loads in flight.  Its sweeps are slower (0.74 against
-// 0.52 ms on the input-box benchmark, where two or three full solves are most of an instance's work); it pays where working-set changes
-// dominate: state box 4.8 -> 4.3 ms, `S` 0.71 -> 0.63 ms, the redo of edge-of-feasibility instances 1.37 -> 1.2 ms.  The host picks
-// it for problems with a state box or stage-varying records; the others stream from the resident-record build.
+// GH: the build for cached responses (SdualParams::ghat != null).  Its sweeps (full solves only) take the stage-varying path -- the
+// records are fetched stage by stage, also when they do not vary (then from a copy in LDS, rows padded against bank conflicts) -- so
+// that no record register is live outside a sweep: the column stream of a direction then has the registers for 32 loads in flight
+// (8 in the build that keeps the records resident, which still serves shapes whose LDS has no room for the copy).  A stage of its
+// sweeps costs 0.7 k cycles instead of 0.3 - 0.5 k; with two or three full solves per instance that is less than the stream gains:
+// N = 50 input box 0.53 -> 0.50 ms, state box 4.8 -> 4.0, `S` 0.71 -> 0.62, the redo of edge-of-feasibility instances 1.37 -> 1.2 ms.
 template <int NT, int MC, int PPL, bool GLB, bool GH = false>
 __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
     static_assert((NT % 2) == 0 && (MC % 2) == 0, "even dimensions (16-byte loads)");
