@@ -535,7 +535,15 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
                 const int i = sl * 64 + lane;
                 if (i < nW) {
                     const double f = rpos[sl] * isc;
-                    for (int j = 0; j <= i; ++j) sst(i, j, fma(f, ubuf[j], sld(i, j)));   // (the lower triangle: each element once)
+                    // (the lower triangle: each element once; four at a time -- one element per trip is an LDS round trip per element,
+                    // 7 k cycles per bordering at 40 rows)
+                    int j = 0;
+                    for (; j + 4 <= i + 1; j += 4) {
+                        const double a0 = sld(i, j), a1 = sld(i, j + 1), a2 = sld(i, j + 2), a3 = sld(i, j + 3);
+                        const double u0 = ubuf[j], u1 = ubuf[j + 1], u2 = ubuf[j + 2], u3 = ubuf[j + 3];
+                        sst(i, j, fma(f, u0, a0)); sst(i, j + 1, fma(f, u1, a1)); sst(i, j + 2, fma(f, u2, a2)); sst(i, j + 3, fma(f, u3, a3));
+                    }
+                    for (; j <= i; ++j) sst(i, j, fma(f, ubuf[j], sld(i, j)));
                 } else if (i == nW) {
                     for (int j = 0; j < nW; ++j) sst(nW, j, -ubuf[j] * isc);
                     sst(nW, nW, isc);
@@ -558,7 +566,16 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
                 const int i = sl * 64 + lane;
                 if (i < nW && i != pos) {
                     const double f = sld(i, pos) * ipiv;
-                    for (int j = 0; j <= i; ++j)
+                    int j = 0;
+                    for (; j + 4 <= i + 1; j += 4) {   // (four elements per trip, as in border)
+                        const double a0 = sld(i, j), a1 = sld(i, j + 1), a2 = sld(i, j + 2), a3 = sld(i, j + 3);
+                        const double p0 = sld(pos, j), p1 = sld(pos, j + 1), p2 = sld(pos, j + 2), p3 = sld(pos, j + 3);
+                        if (j != pos) sst(i, j, fma(-f, p0, a0));
+                        if (j + 1 != pos) sst(i, j + 1, fma(-f, p1, a1));
+                        if (j + 2 != pos) sst(i, j + 2, fma(-f, p2, a2));
+                        if (j + 3 != pos) sst(i, j + 3, fma(-f, p3, a3));
+                    }
+                    for (; j <= i; ++j)
                         if (j != pos) sst(i, j, fma(-f, sld(pos, j), sld(i, j)));
                 }
             }
