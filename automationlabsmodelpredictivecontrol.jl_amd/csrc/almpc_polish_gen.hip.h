@@ -17,8 +17,9 @@
 // One wave per instance; lane l owns row pairs (2l, 2l+1) + 128 q, q < NP (R <= 128 NP).  Same machinery as
 // k_polish: Sinv = (Ghat_WW)^-1 in LDS (WL x WL, identity padded), position-distributed data in registers, LDS broadcasts,
 // DPP reductions, branch-free sweeps.  Two builds: WL = 32 (both half-waves mirror the 32 positions and split the columns of
-// every sweep; 9 KB of LDS per wave) runs on every instance; an instance whose working set outgrows 32 rows is flagged and
-// redone by the WL = 64 build (one position per lane, 38 KB per wave) in a second launch that every other wave leaves at once.
+// every sweep; 17 KB of LDS per single-wave workgroup) runs on every instance; an instance whose working set outgrows 32 rows is
+// flagged and continued by the WL = 64 build (one position per lane, 42 KB per wave) in a second launch that every other wave leaves
+// at once -- from the first launch's working set AND inverse (ovf_ws, ovf_sinv).
 #pragma once
 #include "almpc_kernels.hip.h"
 
@@ -73,7 +74,9 @@ struct PolishGenParams {
     RolloutParams roll;
 };
 
-constexpr int PGEN_WAVES = 1;   // one instance per workgroup: a CU's eight slots are refilled instance by instance (with four per workgroup a slot waited for the slowest of four: 346 -> ... us)
+// one instance per workgroup of the first launch: a CU's eight slots are refilled instance by instance (with four per workgroup a slot
+// waited for the slowest of four: tight box 550 -> 487 us for the finish of 4096 instances)
+constexpr int PGEN_WAVES = 1;
 // LDS per wave (doubles): Sinv WL x WL | rowbuf Rs(<=512) | s0buf Rs(<=512) | pbufa WL | pbufb WL | wrow_s (WL ints) | Z trajectory shares Sinv
 __host__ __device__ constexpr int pgen_lds_per_wave(int WL) { return WL * WL + 512 + 512 + WL + WL + WL / 2; }
 
