@@ -68,6 +68,9 @@ struct almpc_handle {
     double *dGhat = nullptr, *dGnorm = nullptr, *dXmin = nullptr, *dXmax = nullptr;
     int *dRowTraj = nullptr, *dRowEq = nullptr, *dRowXidx = nullptr, *dRowState = nullptr;
     double* dOvfSinv = nullptr;    // [batch][32 * 32 + 32] k_polish_gen -> k_polish_gen64: inverse and bounds of a flagged instance
+    double* dVsPlain = nullptr;    // [n][nzs] V = -G F' (shared design with state rows): operand of the s0 table
+    double* dS0Basis = nullptr;    // [(n + 1)][Rs] PolishGenParams::s0_basis
+    bool s0_basis_ok = false;
     int32_t* dOverflow = nullptr;  // [2 + batch] k_polish_gen: count, cursor and list of instances to redo with the 64-row build
     int* dRowMap = nullptr;        // [N*n] state (stage k+2, i) -> state-row index or -1 (k_ghat_inst)
     double *dGhatE = nullptr, *dWinvE = nullptr;  // shared design with the terminal equality: original rows E of Ghat, Ghat_EE^-1
@@ -273,7 +276,7 @@ void free_all(almpc_handle* h) {
                     h->dXref, h->dUref, h->dFS, h->dV0S, h->dRho, h->dRollM, h->dX0, h->dXs, h->dZs, h->dYs, h->dV0, h->dW, h->dX, h->dEx,
                     h->dU, h->dEu, h->dStatus, h->dIters, h->dPiters, h->dPerm, h->dYflags, h->dSglobal, h->dGhat, h->dGnorm, h->dXmin,
                     h->dXmax, h->dRowTraj, h->dRowEq, h->dRowXidx, h->dRowState, h->dRowMap, h->dGhatE, h->dWinvE, h->lA, h->lB, h->lC, h->lE, h->bA, h->bB, h->bMinv, h->bG, h->bHs, h->bFs,
-                    h->bVs, h->bD, h->bRho, h->bH, h->bF, h->bPhi, h->bGk, h->bGam, h->bW, h->bWP, h->bP, h->bFlag, h->bQ, h->dOverflow, h->dOvfSinv, h->wQ, h->wR, h->wS,
+                    h->bVs, h->bD, h->bRho, h->bH, h->bF, h->bPhi, h->bGk, h->bGam, h->bW, h->bWP, h->bP, h->bFlag, h->bQ, h->dOverflow, h->dOvfSinv, h->dVsPlain, h->dS0Basis, h->wQ, h->wR, h->wS,
                     h->sqp.W_in, h->sqp.W_h, h->sqp.b_h, h->sqp.W_out, h->sqp.A, h->sqp.B, h->sqp.c, h->sqp.fval, h->sqp.ebar,
                     h->sqp.qadd, h->sqp.xref, h->sqp.uref, h->sqp.Q, h->sqp.R, h->sqp.S, h->sqp.bad, h->sqp.stats, h->sqp.mer, h->sqp.xback, h->sqp.uback, h->sqp.dxback, h->sqp.vback};
     for (void* p : ptrs)
@@ -808,6 +811,29 @@ int resolve_lazy_redo(almpc_handle* h) {
     return ALMPC_OK;
 }
 
+// Table of the state rows' s0 (PolishGenParams::s0_basis) for a shared design: after the design and after every change of the shared
+// references (v0S).  Leaves s0_basis_ok false where the table does not apply (the finish then rolls v0 out).
+int build_s0_basis(almpc_handle* h) {
+    h->s0_basis_ok = false;
+    if (h->mc <= 0 || h->batched || h->ltv || h->structured || !h->dVsPlain || !h->dRowTraj || getenv("ALMPC_NO_S0_BASIS")) return ALMPC_OK;
+    int roll_g = 1;
+    while (2 * roll_g * h->n <= 64) roll_g *= 2;
+    const int roll_C = h->n + h->m;
+    int roll_cpl = (roll_C + roll_g - 1) / roll_g;
+    if (!((size_t)(h->N + 1) * roll_C <= 32 * 32 && roll_cpl <= 8)) return ALMPC_OK;
+    roll_cpl = roll_cpl <= 1 ? 1 : (roll_cpl <= 2 ? 2 : (roll_cpl <= 4 ? 4 : 8));
+    if (!h->dS0Basis) HIP_TRY(h, dalloc(&h->dS0Basis, (size_t)(h->n + 1) * h->Rs));
+    S0BasisParams bp;
+    bp.n = h->n; bp.m = h->m; bp.N = h->N; bp.nz = h->nz; bp.nzs = h->nzs; bp.R = h->R; bp.Rs = h->Rs; bp.roll_g = roll_g; bp.roll_cpl = roll_cpl;
+    bp.A = h->dA; bp.B = h->dB; bp.Vs = h->dVsPlain; bp.v0S = (h->dV0S && h->fS_stride == 0) ? h->dV0S : nullptr; bp.dvec = h->dD;
+    bp.row_traj = h->dRowTraj; bp.out = h->dS0Basis;
+    hipLaunchKernelGGL(k_s0_basis, dim3((unsigned)(h->n + 1)), dim3(64), (size_t)(h->N + 1) * roll_C * sizeof(double), h->stream, bp);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->s0_basis_ok = true;
+    return ALMPC_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1065,9 +1091,11 @@ int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const
     for (int k = 0; k < N; ++k)
         for (int i = 0; i < n; ++i)
             if (h->has_box || (h->terminal_eq && k == N - 1)) rowsel.push_back(k * n + i);
+    h->s0_basis_ok = false;
+    if (!rowsel.empty() && !h->dVsPlain) HIP_TRY(h, dalloc(&h->dVsPlain, (size_t)n * h->nzs));
     int rc = design_shared_device(h->stream, n, m, N, h->nzs, h->nrb, h->ks, h->ksf, Am, Bm, Qm, Rm, Sm, Pm, rho, sigma,
                                   h->dMinvFrag, h->dVFrag, h->dHFrag, h->dFFrag, h->dG, h->dD, h->H, h->F, h->d, h->err,
-                                  rowsel, h->Rs, h->dGhat, h->dGnorm, h->rho_mode, h->dRho);
+                                  rowsel, h->Rs, h->dGhat, h->dGnorm, h->rho_mode, h->dRho, rowsel.empty() ? nullptr : h->dVsPlain);
     if (rc != ALMPC_OK) return rc;
     if (h->terminal_eq && h->mc >= n && !getenv("ALMPC_NO_EQ_PROJECTION")) {
         // the n terminal-equality rows (the last n state rows) are in every working set: eliminate them here, once
@@ -2353,6 +2381,7 @@ int almpc_set_reference(almpc_handle* h, const double* xref, const double* uref,
     h->uref_stride = per_instance ? (long)us : 0;
     h->fS_stride = (per_instance || h->batched) ? (long)us : 0;
     { const int rc_ = sdual_update_base(h, uref, cnt); if (rc_ != ALMPC_OK) return rc_; }
+    { const int rc_ = build_s0_basis(h); if (rc_ != ALMPC_OK) return rc_; }   // (v0S has changed)
     h->designed = true;
     return ALMPC_OK;
 }
@@ -2566,6 +2595,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         if (!h->dOvfSinv) HIP_TRY(h, dalloc(&h->dOvfSinv, (size_t)h->batch * (32 * 32 + 32)));
         gp.ovf = h->dOverflow; gp.ovf_ws = h->dOverflow + 2 + h->batch; gp.ovf_sinv = h->dOvfSinv;
         if (lazy_redo) { HIP_TRY(h, ensure_unsolved_word()); gp.unsolved = h->dUnsolved; }
+        if (h->s0_basis_ok && !h->batched && !h->ltv && h->fS_stride == 0) gp.s0_basis = h->dS0Basis;   // (shared model, shared references)
         const dim3 grid((h->batch + PGEN_WAVES - 1) / PGEN_WAVES), block(64 * PGEN_WAVES);
         // first launch: working sets up to 32 rows, every instance; second launch: the instances the first one flagged, up to 64 rows
         const size_t l32 = (size_t)PGEN_WAVES * pgen_lds_per_wave(32) * sizeof(double);

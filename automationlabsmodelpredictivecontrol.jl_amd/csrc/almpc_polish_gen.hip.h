@@ -66,6 +66,11 @@ struct PolishGenParams {
                           // second launch, [2 ...] the flagged instances; [0] and [1] are zeroed before the first launch
     int32_t* ovf_ws;      // [batch][32] working set of a flagged instance when it ran out of room, row | (side + 1) << 12, the
                           // second launch's guess ([0] = -1: none, it builds its guess from the ADMM hand-off as the first did)
+    // Shared model AND shared references: the row values of the unconstrained minimiser are affine in e0 -- s0_state = M1 e0 + m0 with
+    // M1 = C'V + Phi, m0 = C' v0S (the v0 rollout of the prologue, 15 - 17 k cycles on one wave, becomes n + 1 coalesced rows of a
+    // design-time table).  s0_basis: [(n + 1)][Rs], row j < n = the state-row values for e0 = unit_j (v0 = V[:, j]), row n = for e0 = 0
+    // (v0 = v0S); built by k_s0_basis with this kernel's own rollout.  Null: roll out.
+    const double* s0_basis = nullptr;
     double* ovf_sinv = nullptr;  // [batch][32 * 32 + 32] of a flagged instance: the 32 x 32 inverse and the positions' bounds at that moment, so
                                  // that the second launch continues instead of bordering the 32 rows in again (105 k cycles), or null
     int* unsolved = nullptr;   // host-visible count of instances left with ALMPC_MAX_ITER (lazy redo, see almpc_handle::hUnsolved), or null
@@ -263,7 +268,35 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
         }
         wave_fence_lds();
         PGEN_STAMP(11);
-        roll(Z);
+        const bool use_basis = p.s0_basis != nullptr;
+        double s0b[NP][2];
+        if (!use_basis) roll(Z);
+        else {   // s0 of the lane's rows = basis[n] + sum_j e0_j basis[j]  (e0 sits in Z[0 .. n))
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const int off = 2 * lane + 128 * q;
+                const d2 b = *reinterpret_cast<const d2*>(p.s0_basis + (size_t)n * Rs + (off < Rs ? off : 0));
+                s0b[q][0] = b[0]; s0b[q][1] = b[1];
+            }
+            for (int j0 = 0; j0 < n; j0 += 4) {   // (four basis rows = 4 NP loads in flight)
+                d2 bj[4][NP];
+                double ej[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + u < n ? j0 + u : n - 1;
+                    ej[u] = j0 + u < n ? Z[j] : 0.0;
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) {
+                        const int off = 2 * lane + 128 * q;
+                        bj[u][q] = *reinterpret_cast<const d2*>(p.s0_basis + (size_t)j * Rs + (off < Rs ? off : 0));
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) { s0b[q][0] = fma(ej[u], bj[u][q][0], s0b[q][0]); s0b[q][1] = fma(ej[u], bj[u][q][1], s0b[q][1]); }
+            }
+        }
         PGEN_STAMP(12);
 #pragma unroll
         for (int q = 0; q < NP; ++q)
@@ -273,7 +306,7 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
                 const bool valid = r < R;
                 if (!valid) gn[q][e] = 1.0;
                 if (valid && r >= nz && eq_[q][e] != 0) eqm |= 1u << (2 * q + e);
-                const double zst = Z[tr_[q][e]];   // state row: value e_x[i,k] of the v0 trajectory (row 0 of Z for the others)
+                const double zst = use_basis ? s0b[q][e] : Z[tr_[q][e]];   // state row: value e_x[i,k] of the v0 trajectory (row 0 of Z for the others)
                 if (q == 0 && r < nz) {  // input row, bounds exactly as k_admm forms them
                     const double di = 1.0 / (e ? dv[1] : dv[0]);
                     lo[q][e] = (umn[e] - urf[e]) * di;
@@ -931,6 +964,33 @@ __global__ __launch_bounds__(GHAT_THREADS) void k_ghat_inst(GhatInstParams p) {
         const double v = r < R ? Gh[(size_t)r * Rs + r] : 1.0;
         gn[r] = sqrt(v > 0.0 ? v : 1.0);
     }
+}
+
+// Design-time table for PolishGenParams::s0_basis: block j < n rolls out (e0 = unit_j, v0 = V[:, j]), block n (e0 = 0, v0 = v0S) with
+// the finish's own rollout and reads the state rows where the finish reads them.
+struct S0BasisParams {
+    int n, m, N, nz, nzs, R, Rs, roll_g, roll_cpl;
+    const double* A; const double* B; const double* Vs; const double* v0S; const double* dvec; const int* row_traj;
+    double* out;   // [(n + 1)][Rs], zero where no state row sits
+};
+__global__ __launch_bounds__(64) void k_s0_basis(S0BasisParams p) {
+    extern __shared__ __attribute__((aligned(16))) double Z[];
+    const int j = blockIdx.x, lane = threadIdx.x, n = p.n, m = p.m, N = p.N, C = n + m;
+    for (int t = lane; t < (N + 1) * C; t += 64) Z[t] = 0.0;
+    wave_fence_lds();
+    for (int r = lane; r < p.nz; r += 64) {
+        const double v = j < n ? p.Vs[(size_t)j * p.nzs + r] : (p.v0S ? p.v0S[r] : 0.0);
+        Z[(size_t)(r / m) * C + n + r % m] = v * p.dvec[r];
+    }
+    if (lane < n) Z[lane] = (lane == j) ? 1.0 : 0.0;
+    wave_fence_lds();
+    switch (p.roll_cpl) {
+        case 1: rollout_steps<1>(Z, n, m, N, p.roll_g, lane, p.A, p.B); break;
+        case 2: rollout_steps<2>(Z, n, m, N, p.roll_g, lane, p.A, p.B); break;
+        case 4: rollout_steps<4>(Z, n, m, N, p.roll_g, lane, p.A, p.B); break;
+        default: rollout_steps<8>(Z, n, m, N, p.roll_g, lane, p.A, p.B); break;
+    }
+    for (int r = lane; r < p.Rs; r += 64) p.out[(size_t)j * p.Rs + r] = (r >= p.nz && r < p.R) ? Z[p.row_traj[r]] : 0.0;
 }
 
 // first launch: one wave per instance, working sets up to 32 rows (two waves per SIMD: at most 256 registers)
