@@ -328,21 +328,41 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
             }
             wave_fence_lds();
             double lamE = 0.0;
-            if (lane < ne)
-                for (int e2 = 0; e2 < ne; ++e2) {
-                    const double b = p.eq_off ? -p.eq_off[(size_t)inst * p.eq_stride + e2] : 0.0;
-                    lamE += p.WinvE[lane * ne + e2] * (rowbuf[eq0 + e2] - b);
+            {   // (same sum, four terms' loads in flight per trip; lanes >= ne read row 0 and drop the result)
+                const int lr = lane < ne ? lane : 0;
+                for (int e0_ = 0; e0_ < ne; e0_ += 4) {
+                    double wv_[4], bv_[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int e2 = e0_ + u < ne ? e0_ + u : ne - 1;
+                        wv_[u] = p.WinvE[lr * ne + e2];
+                        bv_[u] = p.eq_off ? -p.eq_off[(size_t)inst * p.eq_stride + e2] : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (e0_ + u < ne) lamE += wv_[u] * (rowbuf[eq0 + e0_ + u] - bv_[u]);
                 }
+                if (lane >= ne) lamE = 0.0;
+            }
             if (lane < WL) pbufa[lane] = (lane < ne) ? lamE : 0.0;   // (ne <= n <= 32 <= WL)
             wave_fence_lds();
-            for (int e2 = 0; e2 < ne; ++e2) {
-                const double le = pbufa[e2];
+            for (int e0_ = 0; e0_ < ne; e0_ += 4) {   // (four rows of GhatE = 4 NP loads in flight: one row per trip was an L2 round trip per row)
+                d2 g[4][NP];
+                double le[4];
 #pragma unroll
-                for (int q = 0; q < NP; ++q) {
-                    const int off = 2 * lane + 128 * q;
-                    const d2 g = *reinterpret_cast<const d2*>(p.GhatE + (size_t)e2 * Rs + (off < Rs ? off : 0));
-                    s0v[q][0] -= g[0] * le; s0v[q][1] -= g[1] * le;
+                for (int u = 0; u < 4; ++u) {
+                    const int e2 = e0_ + u < ne ? e0_ + u : ne - 1;
+                    le[u] = e0_ + u < ne ? pbufa[e2] : 0.0;
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) {
+                        const int off = 2 * lane + 128 * q;
+                        g[u][q] = *reinterpret_cast<const d2*>(p.GhatE + (size_t)e2 * Rs + (off < Rs ? off : 0));
+                    }
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) { s0v[q][0] -= g[u][q][0] * le[u]; s0v[q][1] -= g[u][q][1] * le[u]; }
             }
 #pragma unroll
             for (int q = 0; q < NP; ++q)
