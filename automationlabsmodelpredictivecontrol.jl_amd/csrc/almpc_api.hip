@@ -2599,12 +2599,12 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         const dim3 grid((h->batch + PGEN_WAVES - 1) / PGEN_WAVES), block(64 * PGEN_WAVES);
         // first launch: working sets up to 32 rows, every instance; second launch: the instances the first one flagged, up to 64 rows
         const size_t l32 = (size_t)PGEN_WAVES * pgen_lds_per_wave(32) * sizeof(double);
-        const size_t l64 = (size_t)pgen_lds_per_wave(64) * sizeof(double);
+        const size_t l64 = (size_t)pgen_coop_lds_doubles() * sizeof(double);   // (wave 0's buffers + job word + three partial sums)
 #define PGEN_LAUNCH(NP_)                                                                                                         \
     do {                                                                                                                         \
         hipLaunchKernelGGL((k_polish_gen<NP_>), grid, block, l32, st, gp);                                                       \
         HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(k_polish_gen64<NP_>), l64));                                     \
-        hipLaunchKernelGGL((k_polish_gen64<NP_>), dim3(4 * h->num_cus < h->batch ? 4 * h->num_cus : h->batch), dim3(64), l64, st, gp); \
+        hipLaunchKernelGGL((k_polish_gen64<NP_>), dim3(3 * h->num_cus < h->batch ? 3 * h->num_cus : h->batch), dim3(64 * (PGEN_HELPERS + 1)), l64, st, gp); \
     } while (0)
         switch (h->np_pairs) {
             case 1: PGEN_LAUNCH(1); break;

@@ -82,6 +82,7 @@ struct PolishGenParams {
 // one instance per workgroup of the first launch: a CU's eight slots are refilled instance by instance (with four per workgroup a slot
 // waited for the slowest of four: tight box 550 -> 487 us for the finish of 4096 instances)
 constexpr int PGEN_WAVES = 1;
+constexpr int PGEN_HELPERS = 1;   // helper waves of the second launch's workgroup (see k_polish_gen64)
 // LDS per wave (doubles): Sinv WL x WL | rowbuf Rs(<=512) | s0buf Rs(<=512) | pbufa WL | pbufb WL | wrow_s (WL ints) | Z trajectory shares Sinv
 __host__ __device__ constexpr int pgen_lds_per_wave(int WL) { return WL * WL + 512 + 512 + WL + WL + WL / 2; }
 
@@ -132,13 +133,14 @@ __device__ __forceinline__ void rollout_steps_ltv(double* Z, int n, int m, int N
     }
 }
 
-template <int NP, int WL>
+// COOP (second launch): the workgroup's other three waves take shares of the Ghat[W,:] stream (pgen_helper below)
+template <int NP, int WL, bool COOP = false>
 __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double* smem) {
     static_assert(WL == 32 || WL == 64, "working-set capacity: 32 (mirrored half-waves) or 64 (one position per lane)");
     constexpr int HS = 64 / WL;  // lanes per position: 2 = the half-waves split the columns of a sweep, 1 = no split
     constexpr int CH = (NP >= 3 && WL == 32) ? 4 : 8;  // rows of Ghat per group of loads: NP * CH <= 16 loads (64 registers) in flight per lane; 32 in the second launch (512 registers)
     constexpr bool QUEUE = WL == 64;  // the 64-row build is the second launch: persistent waves pull flagged instances
-    const int wv = threadIdx.x >> 6, lane0 = threadIdx.x & 63;
+    const int wv = COOP ? 0 : (threadIdx.x >> 6), lane0 = threadIdx.x & 63;
   do {  // (one pass in the first launch)
     // (second launch: the lane index made opaque per instance -- otherwise everything that depends on it alone is hoisted out of this
     // loop and kept live across the whole solve: 650 live registers, 134 of them in scratch memory)
@@ -434,6 +436,45 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
     // arriving group in AGPRs behind a full wait and the iteration gets slower, 14 k -> 16 k cycles.)
     // (a in LDS buffer ab, zero beyond k)
     auto g_rows_minus = [&](const double* ab, double (&qv)[NP][2]) {   // qv[.] -= sum_{l<k} Ghat[W_l, rows] * a_l
+        if constexpr (COOP) {
+            // rows l = 0, 4, 8, ... here; l = w, w + 4, ... on helper wave w, whose partial sums come back through LDS.  Two workgroup
+            // barriers per call; the coefficients are in pbufb (the only buffer this is ever called with), the rows in wrow_s.
+            int* job = reinterpret_cast<int*>(smem + pgen_lds_per_wave(WL));
+            double* part = smem + pgen_lds_per_wave(WL) + 2;
+            if (lane == 0) { job[0] = k; job[1] = inst; }
+            __syncthreads();
+            constexpr int NW = PGEN_HELPERS + 1;
+            for (int l0 = 0; l0 < k; l0 += NW * CH) {
+                d2 g[CH][NP];
+                double av[CH];
+#pragma unroll
+                for (int t = 0; t < CH; ++t) {
+                    const int l = l0 + NW * t;
+                    const int lc = l < k ? l : 0;
+                    const double* row = Gh + (size_t)__builtin_amdgcn_readlane(wrow, lc) * Rs;
+                    av[t] = l < k ? ab[lc] : 0.0;
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) {
+                        const int off = 2 * lane + 128 * q;
+                        g[t][q] = *reinterpret_cast<const d2*>(row + (off < Rs ? off : 0));
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < CH; ++t)
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) { qv[q][0] -= g[t][q][0] * av[t]; qv[q][1] -= g[t][q][1] * av[t]; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < PGEN_HELPERS; ++w)
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {   // (helper 1 writes into rowbuf -- free while this runs --, 2 and 3 behind the job word)
+                    const double* src = w == 0 ? rowbuf : part + (size_t)(w - 1) * 512;
+                    const d2 t = *reinterpret_cast<const d2*>(src + 2 * lane + 128 * q);
+                    qv[q][0] -= t[0]; qv[q][1] -= t[1];
+                }
+            return;
+        }
         for (int l0 = 0; l0 < k; l0 += CH) {   // (all NP * CH loads of a group go out before the first is used)
             d2 g[CH][NP];
             double av[CH];
@@ -1020,12 +1061,70 @@ __global__ __launch_bounds__(64 * PGEN_WAVES) __attribute__((amdgpu_waves_per_eu
     polish_gen_body<NP, 32>(p, smem);
 }
 
-// second launch: the instances the first one flagged, working sets up to 64 rows; single-wave workgroups (38 KB of LDS each:
-// four per CU, and an empty queue costs a few microseconds -- 152 KB workgroups took 45 us to launch and leave)
+// Helper wave w = 1..3 of the second launch's workgroup: waits for a job (k rows, instance), sums its share of
+// sum_l Ghat[W_l, :] a_l (rows l = w, w + 4, ...; a in pbufb, W in wrow_s: the main wave's LDS) into its slice of `part`, and waits
+// again; k < 0: the main wave is done.  Barrier for barrier the mirror of polish_gen_body<.., COOP>::g_rows_minus.
 template <int NP>
-__global__ __launch_bounds__(64) void k_polish_gen64(PolishGenParams p) {
+__device__ __forceinline__ void pgen_helper(const PolishGenParams& p, double* smem, int w) {
+    constexpr int WL = 64, CH = 8;
+    const int lane = threadIdx.x & 63;
+    const double* pbufb = smem + WL * WL + 512 + 512 + WL;
+    const int* wrow_s = reinterpret_cast<const int*>(pbufb + WL);
+    const int* job = reinterpret_cast<const int*>(smem + pgen_lds_per_wave(WL));
+    double* part = w == 1 ? smem + WL * WL /* the main wave's rowbuf: free during a stream */ : smem + pgen_lds_per_wave(WL) + 2 + (size_t)(w - 2) * 512;
+    const int Rs = p.Rs;
+    for (;;) {
+        __syncthreads();
+        const int k = job[0];
+        if (k < 0) return;
+        const double* Gh = p.Ghat + (size_t)job[1] * p.Ghat_stride;
+        double acc[NP][2];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) { acc[q][0] = 0.0; acc[q][1] = 0.0; }
+        constexpr int NW = PGEN_HELPERS + 1;
+        for (int l0 = w; l0 < k; l0 += NW * CH) {
+            d2 g[CH][NP];
+            double av[CH];
+#pragma unroll
+            for (int t = 0; t < CH; ++t) {
+                const int l = l0 + NW * t;
+                const int lc = l < k ? l : 0;
+                const double* row = Gh + (size_t)wrow_s[lc] * Rs;
+                av[t] = l < k ? pbufb[lc] : 0.0;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const int off = 2 * lane + 128 * q;
+                    g[t][q] = *reinterpret_cast<const d2*>(row + (off < Rs ? off : 0));
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < CH; ++t)
+#pragma unroll
+                for (int q = 0; q < NP; ++q) { acc[q][0] += g[t][q][0] * av[t]; acc[q][1] += g[t][q][1] * av[t]; }
+        }
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            d2 v; v[0] = acc[q][0]; v[1] = acc[q][1];
+            *reinterpret_cast<d2*>(part + 2 * lane + 128 * q) = v;
+        }
+        __syncthreads();
+    }
+}
+__host__ __device__ constexpr int pgen_coop_lds_doubles() { return pgen_lds_per_wave(64) + 2 + (PGEN_HELPERS > 1 ? PGEN_HELPERS - 1 : 0) * 512; }
+
+// second launch: the instances the first one flagged, working sets up to 64 rows.  One instance per workgroup of FOUR waves: wave 0
+// runs the finish, waves 1 - 3 take three quarters of every Ghat[W,:] stream -- with 250 - 400 flagged instances on 256 CUs the chip
+// is idle otherwise, and a single wave's stream of 40 - 64 rows was half of its 13 k cycles per working-set change
+template <int NP>
+__global__ __launch_bounds__(64 * (PGEN_HELPERS + 1)) void k_polish_gen64(PolishGenParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    polish_gen_body<NP, 64>(p, smem);
+    const int w = threadIdx.x >> 6;
+    if (w == 0) {
+        polish_gen_body<NP, 64, true>(p, smem);
+        int* job = reinterpret_cast<int*>(smem + pgen_lds_per_wave(64));
+        if ((threadIdx.x & 63) == 0) job[0] = -1;
+        __syncthreads();
+    } else pgen_helper<NP>(p, smem, w);
 }
 
 }  // namespace almpc
