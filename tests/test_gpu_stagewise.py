@@ -219,3 +219,61 @@ def test_default_redo_with_state_rows_is_lazy_complete_and_uses_the_steps_own_x0
             assert out[None]["status"][i] == 0 and np.abs(out[None]["u"][i] - e["u"]).max() <= U_TOL
         except ValueError:
             assert out[None]["status"][i] == 3
+
+
+def test_cached_responses_equal_the_sweeps(capi, mo, monkeypatch):
+    """Shared model: the responses of the unconstrained problem are cached once per design (SdualParams::ghat) and a working-set change
+    streams columns instead of running two sweeps.  Same decisions (statuses, change counts) and the same optimum as the sweep-only
+    kernel (ALMPC_SDUAL_NO_GHAT), with a state box, the terminal equality and S."""
+    q = mo.quadrotor(30)
+    for kw, amp in ((dict(x_min=-XMAX, x_max=XMAX), 3.0), (dict(terminal="equality"), 1.0), (dict(s=5.0), 3.0)):
+        p = mo.make_problem(q.A, q.B, 30, q.u_min, q.u_max, **kw)
+        X0 = mo.quadrotor_x0_batch(128, amp)
+        if p.x_min is not None:
+            X0 = np.clip(X0, -0.99 * XMAX, 0.99 * XMAX)
+        res = {}
+        for tag in ("cached", "sweeps"):
+            if tag == "sweeps":
+                monkeypatch.setenv("ALMPC_SDUAL_NO_GHAT", "1")
+            else:
+                monkeypatch.delenv("ALMPC_SDUAL_NO_GHAT", raising=False)
+            res[tag] = _solve(capi, p, X0)
+        monkeypatch.delenv("ALMPC_SDUAL_NO_GHAT", raising=False)
+        a, b = res["cached"], res["sweeps"]
+        assert np.array_equal(a["status"], b["status"]) and set(np.unique(a["status"])) <= {0, 3}
+        ok = a["status"] == 0
+        assert ok.sum() >= 24
+        assert np.array_equal(a["polish_iters"][ok], b["polish_iters"][ok])
+        assert np.abs(a["u"][ok] - b["u"][ok]).max() <= 1e-9
+
+
+def test_s0_table_of_the_state_row_finish_equals_the_rollout(capi, mo, monkeypatch):
+    """Condensed handle with state rows, shared model and references: the state rows' s0 comes from the design-time affine map
+    (k_s0_basis) instead of the prologue's rollout of v0 (ALMPC_NO_S0_BASIS): same statuses, same optimum -- also after a change of
+    the references (the constant part of the map is rebuilt by almpc_set_reference)."""
+    p = mo.quadrotor(30)
+    xmax = np.array([1, 1, 1, .5, .5, .5, .1, .1, .1, .1, .1, .1]) * 3.0
+    X0 = np.clip(mo.quadrotor_x0_batch(256, 1.0), -0.99 * xmax, 0.99 * xmax)
+    u_ref = 0.01 * np.sin(np.arange(30))[None, :] * np.ones((4, 1))
+    res = {}
+    for tag in ("table", "rollout"):
+        if tag == "rollout":
+            monkeypatch.setenv("ALMPC_NO_S0_BASIS", "1")
+        else:
+            monkeypatch.delenv("ALMPC_NO_S0_BASIS", raising=False)
+        s = capi.Solver(12, 4, 30, len(X0))
+        s.design_shared(p.A, p.B, p.Q, p.R, 5.0 * np.eye(4), None, p.u_min, p.u_max, xmin=-xmax, xmax=xmax, rho=30.0, rho_profile="stiffness")
+        out = []
+        for ur in (np.zeros((4, 30)), u_ref):
+            s.set_reference(p.x_ref, ur)
+            s.update_initialization(X0)
+            s.calculate(capi.default_opts(rho=30.0, max_iter=8, check_every=8))
+            out.append(s.get_results())
+        res[tag] = out
+        s.close()
+    monkeypatch.delenv("ALMPC_NO_S0_BASIS", raising=False)
+    for a, b in zip(res["table"], res["rollout"]):
+        assert np.array_equal(a["status"], b["status"]) and set(np.unique(a["status"])) <= {0, 3}
+        ok = a["status"] == 0
+        assert ok.sum() >= 64
+        assert np.abs(a["u"][ok] - b["u"][ok]).max() <= 1e-9
