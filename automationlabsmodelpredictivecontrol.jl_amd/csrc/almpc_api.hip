@@ -2219,7 +2219,11 @@ int almpc_sqp_fnn_iterate(almpc_handle* h, int iters, double step_scale, const a
         // structured fallback: an instance whose condensed Hessian came out indefinite to working precision (open-loop unstable
         // linearisation over the horizon) or whose QP was left unsolved gets this iteration's QP solved in its stage-wise form
         if (h->fallback) {
-            if (h->sd.ready) { HIP_TRY(h, launch_sgains(h, 2)); HIP_TRY(h, launch_sdual(h, 2, nullptr, 0, true)); }
+            // input box without S: the primal Riccati active set alone -- the solver this loop's stage-wise QP route uses for such problems
+            // (an iterate holds half of its inputs on bounds; a saturated unstable linearisation is where the dual method has no
+            // certificate) --, ONE idle launch per iteration instead of three; with state rows / S: k_sgains + k_sdual
+            const bool primal_only = h->mc == 0 && !q.useS && h->rKst && !getenv("ALMPC_SQP_REDO_DUAL_FIRST");
+            if (h->sd.ready && !primal_only) { HIP_TRY(h, launch_sgains(h, 2)); HIP_TRY(h, launch_sdual(h, 2, nullptr, 0, true)); }
             if (h->mc == 0 && !q.useS && h->rKst) HIP_TRY(h, launch_riccati(h, 2, nullptr, 0));
         }
         q.since_start += 1;
