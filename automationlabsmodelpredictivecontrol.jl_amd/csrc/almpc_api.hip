@@ -1236,18 +1236,24 @@ int ensure_batched_alloc(almpc_handle* h) {
 // H_i (column-major, in bH) -> Jacobi scaling d_i, H'_i, F'_i, G_i = H'_i^-1, rho_i, Minv_i = (H'_i + sigma I + diag(rho_i))^-1
 // (scaled: the producer of H_i has done the scaling as its own tail)
 // (with_v: also V_i = -G_i F'_i -- inside the first inverse's launch where that kernel can, else by launch_neg_gm_batched)
-void launch_batched_factor(almpc_handle* h, const DesignStrides& ds, double rho, double sigma, hipStream_t st, bool scaled = false, bool with_v = false) {
+// (v1M / v1Out: instead of V_i, ONE column per instance -- the SQP iteration's v0S_i = -G_i fS_i, [batch][nz] each)
+void launch_batched_factor(almpc_handle* h, const DesignStrides& ds, double rho, double sigma, hipStream_t st, bool scaled = false, bool with_v = false,
+                           const double* v1M = nullptr, double* v1Out = nullptr) {
     const int n = h->n, nz = h->nz, nzs = h->nzs;
     const unsigned gb = (unsigned)h->batch;
     if (!scaled) hipLaunchKernelGGL(k_design_scale, dim3(1, gb), dim3(256), 0, st, nz, nzs, n, h->bH, h->bF, h->bD, h->bHs, h->bFs, h->bFlag, ds);
     const size_t inv_lds = 520 * sizeof(double);
-    if (!h->skip_admm && h->rho_mode == 0 && design_inverse_makes_rho(nz, nzs) && design_inverse_makes_v(nz) && !getenv("ALMPC_DBG_SPLIT_INVERSES")) {
+    if (!v1M && !h->skip_admm && h->rho_mode == 0 && design_inverse_makes_rho(nz, nzs) && nz <= 64 && design_inverse_makes_v(nz) && !getenv("ALMPC_DBG_SPLIT_INVERSES")) {
         // scalar rho: the ADMM's KKT inverse does not need G_i -- both inverses, the penalty profile and V_i in ONE launch
         launch_design_inverse(dim3(1, gb), inv_lds, st, nz, nzs, h->bHs, 0.0, (const double*)nullptr, h->bG, h->bFlag, ds.Hs, ds.rho, ds.G, 1L,
                               (const double*)nullptr, 0L, 0, rho, h->bRho, with_v ? h->bFs : nullptr, h->bVs, ds.Fs, n, h->bMinv, ds.Minv, sigma);
         return;
     }
-    if (with_v && design_inverse_makes_v(nz))   // V_i = -G_i F'_i from the rows of G_i the inverse's wave still holds
+    if (v1M && design_inverse_makes_v(nz))   // one column per instance from the rows / columns of G_i the inverse still holds
+        launch_design_inverse(dim3(1, gb), inv_lds, st, nz, nzs, h->bHs, 0.0, (const double*)nullptr, h->bG, h->bFlag, ds.Hs, 0L, ds.G, 1L,
+                              (const double*)nullptr, 0L, 0, 0.0, (double*)nullptr, v1M, v1Out, (long)nz, 1, (double*)nullptr, 0L, 0.0, nz);
+    else if (with_v && nz <= 64 && design_inverse_makes_v(nz))   // V_i = -G_i F'_i from the rows of G_i the inverse's wave still holds (the
+                                                                  // column-split kernel: measured slower than k_neg_gm_cols for n columns)
         launch_design_inverse(dim3(1, gb), inv_lds, st, nz, nzs, h->bHs, 0.0, (const double*)nullptr, h->bG, h->bFlag, ds.Hs, 0L, ds.G, 1L,
                               (const double*)nullptr, 0L, 0, 0.0, (double*)nullptr, h->bFs, h->bVs, ds.Fs, n);
     else {
@@ -2207,10 +2213,12 @@ int almpc_sqp_fnn_iterate(almpc_handle* h, int iters, double step_scale, const a
         }
         HIP_TRY(h, launch_design_ltv(h, lp, st));
         h->skip_admm = (q.guess_from_iterate && q.since_start > 0) ? 1 : 0;
-        launch_batched_factor(h, ds, h->rho, h->sigma, st, ltv_scales);
+        // (with the scaling in the design kernel's tail fS_i exists before the inverse: v0S_i = -G_i fS_i comes out of the inverse's launch)
+        const bool v0_in_inverse = ltv_scales && design_inverse_makes_v(nz);
+        launch_batched_factor(h, ds, h->rho, h->sigma, st, ltv_scales, false, v0_in_inverse ? h->dFS : nullptr, h->dV0S);
         if (h->mc > 0) HIP_TRY(h, launch_ghat_inst(h, q.A, q.B));
         if (!ltv_scales) hipLaunchKernelGGL(k_fs_scale, dim3(256), dim3(256), 0, st, h->batch, nz, nzs, h->bQ, (long)nz, h->bD, h->dFS);
-        hipLaunchKernelGGL(k_neg_gm, dim3(1, (unsigned)b), dim3(256), 0, st, nz, nzs, 1, nz, h->bG, h->dFS, h->dV0S, (long)nz * nzs, (long)nz);
+        if (!v0_in_inverse) hipLaunchKernelGGL(k_neg_gm, dim3(1, (unsigned)b), dim3(256), 0, st, nz, nzs, 1, nz, h->bG, h->dFS, h->dV0S, (long)nz * nzs, (long)nz);
         HIP_TRY(h, hipGetLastError());
         h->designed = true;
         const int rc = almpc_calculate_async(h, opts);

@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256) void k_design_inverse_wave(int nz, int nzs, in
                                                              const double* rho_G = nullptr, long sRhoG = 0, int rho_mode = 0, double rho = 0.0,
                                                              double* rho_out = nullptr, const double* vM = nullptr, double* vOut = nullptr,
                                                              long sV = 0, int vcols = 0, double* Out2 = nullptr, long sOut2 = 0,
-                                                             double cshift2 = 0.0) {
+                                                             double cshift2 = 0.0, int vld = 0) {
     constexpr int PB = 8;
     static_assert(NCOL % PB == 0 && NCOL > PB, "column count: a multiple of the pivot block");
     __shared__ __attribute__((aligned(16))) double wbuf_all[4][2][64];
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256) void k_design_inverse_wave(int nz, int nzs, in
         double* Vi = vOut + (size_t)inst * sV;
         int pos = i - (nrot % NCOL); if (pos < 0) pos += NCOL;
         for (int c = 0; c < vcols; ++c) {
-            const double mv = Mi[(size_t)c * nzs + ic];
+            const double mv = Mi[(size_t)c * vld + ic];
             wave_fence_lds();
             if (i < NCOL) wbuf[pos] = i < nz ? mv : 0.0;
             wave_fence_lds();
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256) void k_design_inverse_wave(int nz, int nzs, in
                 a0 = __builtin_fma(S[q], w2[0], a0);
                 a1 = __builtin_fma(S[q + 1], w2[1], a1);
             }
-            if (i < nz) Vi[(size_t)c * nzs + i] = -(a0 + a1);
+            if (i < nz) Vi[(size_t)c * vld + i] = -(a0 + a1);
         }
     }
     INV_W(3);
@@ -622,8 +622,11 @@ __global__ __launch_bounds__(256) void k_design_inverse_wave(int nz, int nzs, in
 // CW: columns per wave (128 / CW waves per matrix).
 template <int CW, bool HOIST>
 __global__ __launch_bounds__(64 * (128 / CW)) void k_design_inverse_c32(int nz, int nzs, const double* Hs, double cshift, const double* dshift,
-                                                            double* Out, int* flag, long sHs, long sShift, long sOut, long sFlag) {
+                                                            double* Out, int* flag, long sHs, long sShift, long sOut, long sFlag,
+                                                            const double* vM = nullptr, double* vOut = nullptr, long sV = 0, int vcols = 0,
+                                                            int vld = 0) {
     __shared__ __attribute__((aligned(16))) double wb[2][128];
+    __shared__ double vred[128 / CW][128];   // (vM != null: the waves' partial sums of V = -Out vM)
     __shared__ double ips[2];
     __shared__ int badp;
     Hs += blockIdx.y * sHs; Out += blockIdx.y * sOut; flag += blockIdx.y * sFlag;
@@ -751,6 +754,35 @@ __global__ __launch_bounds__(64 * (128 / CW)) void k_design_inverse_c32(int nz, 
             const int i = lane + 64 * a, col = CW * q + c;
             if (i < nz && col < nz) Out[(size_t)col * nzs + i] = S[a][c];
         }
+    // vM != null: V = -Out vM (nz x vcols, leading dimension vld) from the columns the waves still hold -- wave q sums its CW columns,
+    // the partial sums meet in LDS -- instead of a launch of its own that reads the inverse back (k_neg_gm / k_neg_gm_cols)
+    if (vM) {
+        const double* Mi = vM + blockIdx.y * sV;
+        double* Vi = vOut + blockIdx.y * sV;
+        for (int vc = 0; vc < vcols; ++vc) {
+            double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                const int col = CW * q + c;
+                const double mv = col < nz ? Mi[(size_t)vc * vld + col] : 0.0;   // (wave-uniform address)
+                p0 = __builtin_fma(S[0][c], mv, p0);
+                p1 = __builtin_fma(S[1][c], mv, p1);
+            }
+            vred[q][lane] = p0; vred[q][lane + 64] = p1;
+            __syncthreads();
+            if (q == 0) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int i = lane + 64 * a;
+                    double sum = 0.0;
+#pragma unroll
+                    for (int w = 0; w < 128 / CW; ++w) sum += vred[w][i];
+                    if (i < nz) Vi[(size_t)vc * vld + i] = -sum;
+                }
+            }
+            __syncthreads();
+        }
+    }
     __syncthreads();
     if (threadIdx.x == 0 && badp) atomicExch(flag, 2);
 }
@@ -759,23 +791,24 @@ __global__ __launch_bounds__(64 * (128 / CW)) void k_design_inverse_c32(int nz, 
 // whether launch_design_inverse makes the ADMM penalty profile itself (rho_G given): the one-wave kernel does, the others need k_design_rho first
 inline bool design_inverse_makes_rho(int nz, int nzs) { return nz <= 64 && nzs <= 64 && !getenv("ALMPC_INV_TILE") && !getenv("ALMPC_NO_RHO_FUSION"); }
 // (the one-wave-per-matrix kernel can also form V = -Out vM from the rows it holds: see there)
-inline bool design_inverse_makes_v(int nz) { return nz <= 64 && !getenv("ALMPC_INV_TILE") && !getenv("ALMPC_DBG_SPLIT_NEGGM"); }
+inline bool design_inverse_makes_v(int nz) { return nz <= 128 && !getenv("ALMPC_INV_TILE") && !getenv("ALMPC_DBG_SPLIT_NEGGM"); }   // (one-wave and column-split kernels)
 inline void launch_design_inverse(dim3 grid, size_t lds, hipStream_t st, int nz, int nzs, const double* Hs, double cshift, const double* dshift,
                                   double* Out, int* flag, long sHs, long sShift, long sOut, long sFlag,
                                   const double* rho_G = nullptr, long sRhoG = 0, int rho_mode = 0, double rho = 0.0, double* rho_out = nullptr,
                                   const double* vM = nullptr, double* vOut = nullptr, long sV = 0, int vcols = 0,
-                                  double* Out2 = nullptr, long sOut2 = 0, double cshift2 = 0.0) {
+                                  double* Out2 = nullptr, long sOut2 = 0, double cshift2 = 0.0, int vld = 0) {
+    if (vld == 0) vld = nzs;
     if (nz <= 64 && !getenv("ALMPC_INV_TILE")) {   // one wave per matrix (grid.y = matrices, as for the tile kernels)
         const int b = (int)grid.y;
         const dim3 g2((unsigned)(((Out2 ? 2 * b : b) + 3) / 4));
-#define INV_WAVE(NC_) hipLaunchKernelGGL((k_design_inverse_wave<NC_>), g2, dim3(256), 0, st, nz, nzs, b, Hs, cshift, dshift, Out, flag, sHs, sShift, sOut, sFlag, rho_G, sRhoG, rho_mode, rho, rho_out, vM, vOut, sV, vcols, Out2, sOut2, cshift2)
+#define INV_WAVE(NC_) hipLaunchKernelGGL((k_design_inverse_wave<NC_>), g2, dim3(256), 0, st, nz, nzs, b, Hs, cshift, dshift, Out, flag, sHs, sShift, sOut, sFlag, rho_G, sRhoG, rho_mode, rho, rho_out, vM, vOut, sV, vcols, Out2, sOut2, cshift2, vld)
         if (nz <= 16) INV_WAVE(16); else if (nz <= 32) INV_WAVE(32); else if (nz <= 48) INV_WAVE(48); else INV_WAVE(64);
 #undef INV_WAVE
     } else if (nz <= 64) hipLaunchKernelGGL((k_design_inverse_t<2, 8>), grid, dim3(DESIGN_INVERSE_THREADS), lds, st, nz, nzs, Hs, cshift, dshift, Out, flag, sHs, sShift, sOut, sFlag);
     else if (!getenv("ALMPC_INV_TILE")) {
         const char* cwv = getenv("ALMPC_INV_CW");   // (experiment: columns per wave)
         const int cw = cwv ? atoi(cwv) : (grid.y <= 256 ? 16 : 32);   // one matrix per CU: eight waves of 16 columns (51 against 59 us at nz 100)
-#define INV_C32(CW_, H_) hipLaunchKernelGGL((k_design_inverse_c32<CW_, H_>), grid, dim3(64 * (128 / CW_)), 0, st, nz, nzs, Hs, cshift, dshift, Out, flag, sHs, sShift, sOut, sFlag)
+#define INV_C32(CW_, H_) hipLaunchKernelGGL((k_design_inverse_c32<CW_, H_>), grid, dim3(64 * (128 / CW_)), 0, st, nz, nzs, Hs, cshift, dshift, Out, flag, sHs, sShift, sOut, sFlag, vM, vOut, sV, vcols, vld)
         if (grid.y <= 256) { if (cw == 8) INV_C32(8, true); else if (cw == 16) INV_C32(16, true); else INV_C32(32, true); }
         else { if (cw == 8) INV_C32(8, false); else if (cw == 16) INV_C32(16, false); else INV_C32(32, false); }
 #undef INV_C32

@@ -373,7 +373,7 @@ def test_structured_qp_solver_with_state_box_and_rate_weight(capi, mo):
 
 def test_scaling_in_the_design_kernels_tail_equals_the_split_launches(capi, mo, monkeypatch):
     """An iteration's Jacobi scaling, scaled gradient and flag reset ride in the tail of k_design_ltv_reg (three launches less):
-    the same operations on the same operands as k_design_scale / k_fs_scale behind it (ALMPC_DBG_SPLIT_SCALE) -- identical iterates."""
+    the same operations on the same operands as k_design_scale / k_fs_scale behind it (ALMPC_DBG_SPLIT_SCALE) -- the same iterates."""
     res = {}
     for tag in ("fused", "split"):
         if tag == "split":
@@ -387,4 +387,5 @@ def test_scaling_in_the_design_kernels_tail_equals_the_split_launches(capi, mo, 
         s.close()
     monkeypatch.delenv("ALMPC_DBG_SPLIT_SCALE", raising=False)
     assert np.array_equal(res["fused"]["status"], res["split"]["status"])
-    assert np.array_equal(res["fused"]["u"], res["split"]["u"]) and np.array_equal(res["fused"]["x"], res["split"]["x"])
+    # (with the scaling in the tail, v0S_i = -G_i fS_i also comes out of the inverse's launch: another summation order, rounding level)
+    assert np.abs(res["fused"]["u"] - res["split"]["u"]).max() <= 1e-9 and np.abs(res["fused"]["x"] - res["split"]["x"]).max() <= 1e-9
