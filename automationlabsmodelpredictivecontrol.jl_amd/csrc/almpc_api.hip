@@ -1288,7 +1288,8 @@ hipError_t launch_fnn_jacobian(const FnnParams& p, int num_cus, hipStream_t st) 
     const size_t lw = fnn_w_lds_doubles(p.n, p.m, p.H, p.L) * sizeof(double);
     if (lw <= 64 * 1024 && !getenv("ALMPC_FNN_WG")) {
         int wgs = (p.batch + FNN_W_WAVES - 1) / FNN_W_WAVES;
-        const int cap = num_cus * 4;  // 16 waves per CU
+        const int cap = num_cus * 8;  // 32 waves per CU: a point is a latency chain on one wave (18 us); 16 waves per CU took 55 us for the
+                                      // 12800 points of an SQP iteration, 32 take 48 (52 workgroups per CU: 49.5)
         if (wgs > cap) wgs = cap;
         hipLaunchKernelGGL(k_fnn_jacobian_w, dim3(wgs), dim3(64 * FNN_W_WAVES), lw, st, p);
         return hipGetLastError();
