@@ -1285,13 +1285,17 @@ DesignStrides batched_strides(const almpc_handle* h, bool p_inst) {
 // per point.
 hipError_t launch_fnn_jacobian(const FnnParams& p, int num_cus, hipStream_t st) {
     const size_t nin = (size_t)p.n + p.m;
-    const size_t lw = fnn_w_lds_doubles(p.n, p.m, p.H, p.L) * sizeof(double);
+    // small networks (H (n + m) <= 192 entries of the Jacobian being propagated): two points per wave, one per half-wave
+    // (four points per wave, a quarter-wave each: measured no better, 0.305 against 0.303 ms per SQP iteration)
+    const int ppw = ((size_t)p.H * nin <= 192 && !getenv("ALMPC_FNN_ONE_POINT_PER_WAVE")) ? 2 : 1;
+    const size_t lw = fnn_w_lds_doubles(p.n, p.m, p.H, p.L, ppw) * sizeof(double);
     if (lw <= 64 * 1024 && !getenv("ALMPC_FNN_WG")) {
-        int wgs = (p.batch + FNN_W_WAVES - 1) / FNN_W_WAVES;
+        int wgs = (p.batch + FNN_W_WAVES * ppw - 1) / (FNN_W_WAVES * ppw);
         const int cap = num_cus * 8;  // 32 waves per CU: a point is a latency chain on one wave (18 us); 16 waves per CU took 55 us for the
                                       // 12800 points of an SQP iteration, 32 take 48 (52 workgroups per CU: 49.5)
         if (wgs > cap) wgs = cap;
-        hipLaunchKernelGGL(k_fnn_jacobian_w, dim3(wgs), dim3(64 * FNN_W_WAVES), lw, st, p);
+        if (ppw == 2) hipLaunchKernelGGL((k_fnn_jacobian_w<32>), dim3(wgs), dim3(64 * FNN_W_WAVES), lw, st, p);
+        else hipLaunchKernelGGL((k_fnn_jacobian_w<64>), dim3(wgs), dim3(64 * FNN_W_WAVES), lw, st, p);
         return hipGetLastError();
     }
     const size_t lds = (2 * (size_t)p.H + 2 * (size_t)p.H * nin + nin) * sizeof(double);

@@ -102,11 +102,12 @@ __global__ __launch_bounds__(256) void k_fnn_jacobian(FnnParams p) {
 // workgroup barrier inside the loop.  Same arithmetic, same summation order as k_fnn_jacobian (bit-identical results).
 constexpr int FNN_W_WAVES = 4;
 
-__host__ __device__ inline size_t fnn_w_lds_doubles(int n, int m, int H, int L) {
+// (ppw: points per wave and pass, 1 or 2: see fnn_jacobian_point)
+__host__ __device__ inline size_t fnn_w_lds_doubles(int n, int m, int H, int L, int ppw = 1) {
     const size_t nin = (size_t)n + m;
     const size_t weights = (size_t)H * nin + (size_t)L * H * H + (size_t)L * H + (size_t)n * H;
     const size_t per_wave = 2 * (size_t)H + 2 * (size_t)H * nin + nin;
-    return weights + FNN_W_WAVES * per_wave;
+    return weights + FNN_W_WAVES * ppw * per_wave;
 }
 
 // weights of the network into LDS (all threads of the workgroup; the caller synchronises): Win | Wh | bh | Wout
@@ -129,7 +130,13 @@ __host__ __device__ inline size_t fnn_wave_scratch_doubles(int n, int m, int H) 
 // Jacobians (and value) of the network at ONE point by ONE wave: weights staged at `wsm` (fnn_stage_weights), `y` = the wave's own
 // scratch (fnn_wave_scratch_doubles).  Also the tail of nothing and the head of k_design_instance_t in the re-linearisation
 // pipeline (the instance's workgroup linearises its own model: one launch less per step).
-__device__ __forceinline__ void fnn_jacobian_point(const FnnParams& p, int inst, int lane, const double* wsm, double* y) {
+// LW: lanes per point (64: the wave works on one point; 32: each half-wave on its own -- small networks leave most lanes of a wave
+// idle, and a point is a latency chain: two at a time halve the passes).  inst_ may lie beyond the batch (its half then computes on
+// point 0 and stores nothing); lane: the lane within the point's LW lanes; y: the point's own scratch.
+template <int LW = 64>
+__device__ __forceinline__ void fnn_jacobian_point(const FnnParams& p, int inst_, int lane, const double* wsm, double* y) {
+    const bool valid = inst_ < p.batch;
+    const int inst = valid ? inst_ : 0;
     const int n = p.n, m = p.m, H = p.H, L = p.L, nin = n + m;
     const double* Win = wsm;                          // H x nin column-major
     const double* Wh = Win + (size_t)H * nin;         // [L] H x H column-major
@@ -143,25 +150,25 @@ __device__ __forceinline__ void fnn_jacobian_point(const FnnParams& p, int inst,
     {
         const double* xp = p.x + (size_t)(inst / p.ppi) * p.xs_group + (size_t)(inst % p.ppi) * n;
         const double* up = p.u + (size_t)(inst / p.ppi) * p.us_group + (size_t)(inst % p.ppi) * m;
-        for (int t = lane; t < nin; t += 64) z[t] = t < n ? xp[t] : up[t - n];
+        for (int t = lane; t < nin; t += LW) z[t] = t < n ? xp[t] : up[t - n];
         wsync();
-        for (int i = lane; i < H; i += 64) {
+        for (int i = lane; i < H; i += LW) {
             double s = 0.0;
             for (int c = 0; c < nin; ++c) s += Win[(size_t)c * H + i] * z[c];
             y[i] = s;
         }
-        for (int t = lane; t < H * nin; t += 64) J[t] = Win[(size_t)(t % nin) * H + t / nin];
+        for (int t = lane; t < H * nin; t += LW) J[t] = Win[(size_t)(t % nin) * H + t / nin];
         wsync();
         for (int l = 0; l < L; ++l) {
             const double* W = Wh + (size_t)l * H * H;
             const double* b = bh + (size_t)l * H;
-            for (int i = lane; i < H; i += 64) {
+            for (int i = lane; i < H; i += LW) {
                 double s = b[i];
                 for (int j = 0; j < H; ++j) s += W[(size_t)j * H + i] * y[j];
                 yn[i] = s;  // pre-activation
             }
             wsync();
-            for (int t = lane; t < H * nin; t += 64) {
+            for (int t = lane; t < H * nin; t += LW) {
                 const int i = t / nin, c = t % nin;
                 double s = 0.0;
                 for (int j = 0; j < H; ++j) s += W[(size_t)j * H + i] * J[(size_t)j * nin + c];
@@ -170,39 +177,43 @@ __device__ __forceinline__ void fnn_jacobian_point(const FnnParams& p, int inst,
                 Jn[t] = der == 0.0 ? 0.0 : der * s;
             }
             wsync();
-            for (int i = lane; i < H; i += 64) {
+            for (int i = lane; i < H; i += LW) {
                 double val, der;
                 fnn_act(p.act, yn[i], val, der);
                 y[i] = val;
             }
-            for (int t = lane; t < H * nin; t += 64) J[t] = Jn[t];
+            for (int t = lane; t < H * nin; t += LW) J[t] = Jn[t];
             wsync();
         }
-        for (int t = lane; t < n * nin; t += 64) {
+        for (int t = lane; t < n * nin; t += LW) {
             const int i = t % n, c = t / n;
             double s = 0.0;
             for (int j = 0; j < H; ++j) s += Wout[(size_t)j * n + i] * J[(size_t)j * nin + c];
+            if (!valid) continue;
             if (c < n) p.A[(size_t)inst * n * n + (size_t)c * n + i] = s;
             else p.B[(size_t)inst * n * m + (size_t)(c - n) * n + i] = s;
         }
         if (p.f)
-            for (int i = lane; i < n; i += 64) {
+            for (int i = lane; i < n; i += LW) {
                 double s = 0.0;
                 for (int j = 0; j < H; ++j) s += Wout[(size_t)j * n + i] * y[j];
-                p.f[(size_t)inst * n + i] = s;
+                if (valid) p.f[(size_t)inst * n + i] = s;
             }
         wsync();  // the next point overwrites z, y, J
     }
 }
 
+template <int LW>
 __global__ __launch_bounds__(64 * FNN_W_WAVES) void k_fnn_jacobian_w(FnnParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double* y = smem + fnn_weights_doubles(p.n, p.m, p.H, p.L) + (size_t)wv * fnn_wave_scratch_doubles(p.n, p.m, p.H);
+    constexpr int PPW = 64 / LW;   // points per wave and pass
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane / LW, hl = lane % LW;
+    double* y = smem + fnn_weights_doubles(p.n, p.m, p.H, p.L) + (size_t)(wv * PPW + sub) * fnn_wave_scratch_doubles(p.n, p.m, p.H);
     fnn_stage_weights(p, smem);
     __syncthreads();
-    for (int inst = blockIdx.x * FNN_W_WAVES + wv; inst < p.batch; inst += gridDim.x * FNN_W_WAVES)
-        fnn_jacobian_point(p, inst, lane, smem, y);
+    const int stride = gridDim.x * FNN_W_WAVES * PPW;
+    for (int i0 = (blockIdx.x * FNN_W_WAVES + wv) * PPW; i0 < p.batch; i0 += stride)   // (uniform trip count per wave: i0, not i0 + sub)
+        fnn_jacobian_point<LW>(p, i0 + sub, hl, smem, y);
 }
 
 }  // namespace almpc
