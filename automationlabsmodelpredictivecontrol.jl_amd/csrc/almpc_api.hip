@@ -16,6 +16,23 @@
 #include "almpc_host_math.h"
 #include "../../include/almpc.h"
 
+// The heavy kernel templates are compiled by their own translation units (almpc_tu_*.hip, one per kernel family, built in parallel);
+// here their instantiations are only DECLARED.  The lists are generated from a unity build (tools/gen_instances.py); an instantiation
+// that is missing from them is simply compiled here, as everything is with -DALMPC_UNITY (one translation unit: the diagnostic
+// -DALMPC_STAMPS build, whose stamp buffer is a device variable of ONE code object).
+#ifndef ALMPC_UNITY
+#define ALMPC_KERNEL_INSTANCE(...) extern template __global__ __VA_ARGS__;
+#include "instances/sdual_a.inc"
+#include "instances/sdual_b.inc"
+#include "instances/sdual_c.inc"
+#include "instances/polish_gen.inc"
+#include "instances/step.inc"
+#include "instances/instance.inc"
+#include "instances/design_a.inc"
+#include "instances/design_b.inc"
+#undef ALMPC_KERNEL_INSTANCE
+#endif
+
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -2732,8 +2749,8 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
                 pp.sg_off = per_wave;
                 pp.g_off = per_wave + POLISH_GLB_PER_INST;
                 pp.lds_per_wave = (int)sgl_wave;
-                HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(k_polish_sgl), (size_t)(l_sgl)));
-                hipLaunchKernelGGL(k_polish_sgl, dim3(pp.ntiles * 16), dim3(64), l_sgl, st, pp);
+                HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(k_polish_sgl<0>), (size_t)(l_sgl)));
+                hipLaunchKernelGGL((k_polish_sgl<0>), dim3(pp.ntiles * 16), dim3(64), l_sgl, st, pp);
             } else {
             HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(k_polish<false>), l));
             hipLaunchKernelGGL((k_polish<false>), dim3((pp.ntiles * 16 + POLISH_WAVES - 1) / POLISH_WAVES), dim3(64 * POLISH_WAVES), l, st, pp);

@@ -52,7 +52,7 @@ inline RcclApi& rccl_api() {
 }
 
 // out[0] = 1 (this rank), out[1] = instances with status != 0, out[2] = max ADMM iterations, out[3] = max polish iterations
-__global__ __launch_bounds__(1024) void k_comm_summary(int batch, const int32_t* status, const int32_t* iters, const int32_t* piters,
+inline __global__ __launch_bounds__(1024) void k_comm_summary(int batch, const int32_t* status, const int32_t* iters, const int32_t* piters,
                                                        long long* out) {
     __shared__ long long sh[3][16];
     long long bad = 0, mi = 0, mp = 0;
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(1024) void k_comm_summary(int batch, const int32_t*
 }
 
 // dst[i][a] = u[i][0][a]: the first input of every instance, packed for the all-gather
-__global__ __launch_bounds__(256) void k_pack_first_input(int batch, int m, int N, const double* u, double* dst) {
+inline __global__ __launch_bounds__(256) void k_pack_first_input(int batch, int m, int N, const double* u, double* dst) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < (long)batch * m) dst[t] = u[(t / m) * (long)m * N + (t % m)];
 }

@@ -30,7 +30,7 @@ struct DesignStrides {
 
 // ---- K1/K2 -------------------------------------------------------------------------------------
 // One workgroup.  Phi[k] (n x n, column-major) = A^(k+1); Gk[k] (n x m, column-major) = A^k B.
-__global__ __launch_bounds__(256) void k_design_blocks(int n, int m, int N, const double* A, const double* B,
+inline __global__ __launch_bounds__(256) void k_design_blocks(int n, int m, int N, const double* A, const double* B,
                                                        double* Phi, double* Gk, DesignStrides st) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     A += blockIdx.y * st.A; B += blockIdx.y * st.B; Phi += blockIdx.y * st.Phi; Gk += blockIdx.y * st.Gk;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void k_design_blocks(int n, int m, int N, cons
 // ---- Gamma, W = Qbar Gamma, WP = Qbar Phi -------------------------------------------------------
 // Block k = stage k (rows k*n .. k*n+n-1).  Row-major with strides gs (Gam, W) and ps (WP); buffers are
 // zero-initialised by the host so padding rows/columns stay zero.
-__global__ __launch_bounds__(256) void k_design_gamma(int n, int m, int N, const double* Q, const double* P,
+inline __global__ __launch_bounds__(256) void k_design_gamma(int n, int m, int N, const double* Q, const double* P,
                                                       const double* Phi, const double* Gk, double* Gam, double* W,
                                                       double* WP, int gs, int ps, DesignStrides st) {
     const int k = blockIdx.x;
@@ -112,7 +112,7 @@ struct HessParams {
 
 constexpr int HESS_KC = 32;
 
-__global__ __launch_bounds__(768) void k_design_hessian(HessParams p) {
+inline __global__ __launch_bounds__(768) void k_design_hessian(HessParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     p.Gam += blockIdx.y * p.st.Gam; p.W += blockIdx.y * p.st.Gam; p.WP += blockIdx.y * p.st.WP;
     p.H += blockIdx.y * p.st.H; p.F += blockIdx.y * p.st.F;
@@ -250,7 +250,7 @@ __device__ __forceinline__ void design_scale_body(int nz, int nzs, int n, const 
     }
 }
 
-__global__ __launch_bounds__(256) void k_design_scale(int nz, int nzs, int n, const double* H, const double* F,
+inline __global__ __launch_bounds__(256) void k_design_scale(int nz, int nzs, int n, const double* H, const double* F,
                                                       double* d, double* Hs, double* Fs, int* flag, DesignStrides st) {
     H += blockIdx.y * st.H; F += blockIdx.y * st.F; d += blockIdx.y * st.d; Hs += blockIdx.y * st.Hs; Fs += blockIdx.y * st.Fs;
     flag += blockIdx.y * st.flag;
@@ -821,7 +821,7 @@ inline void launch_design_inverse(dim3 grid, size_t lds, hipStream_t st, int nz,
 // Gauss-Jordan kernel's few-times-larger constant: 4.5e-12 against 2.9e-10 in bench.py's u_err_inf).
 // One workgroup, matrix in LDS (ld = nz+1 to spread banks).  Cholesky (right-looking), in-place inverse of
 // the triangular factor, then X'X.  flag[0] != 0 if a pivot is not positive.
-__global__ __launch_bounds__(512) void k_design_inverse_chol(int nz, int nzs, const double* Hs, double cshift, const double* dshift,
+inline __global__ __launch_bounds__(512) void k_design_inverse_chol(int nz, int nzs, const double* Hs, double cshift, const double* dshift,
                                                         double* Out, int* flag, long sHs, long sShift, long sOut, long sFlag) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     Hs += blockIdx.y * sHs; Out += blockIdx.y * sOut; flag += blockIdx.y * sFlag;
@@ -877,7 +877,7 @@ __global__ __launch_bounds__(512) void k_design_inverse_chol(int nz, int nzs, co
 }
 
 // ---- ADMM penalty per row: scalar rho (OSQP), or the stiffness profile rho_i = rho / G_ii (G = H'^-1), pad rows 1
-__global__ __launch_bounds__(256) void k_design_rho(int nz, int nzs, int mode, double rho, const double* G, double* rhovec,
+inline __global__ __launch_bounds__(256) void k_design_rho(int nz, int nzs, int mode, double rho, const double* G, double* rhovec,
                                                     long sG, long sRho) {
     G += blockIdx.y * sG; rhovec += blockIdx.y * sRho;
     for (int t = threadIdx.x; t < nzs; t += blockDim.x)
@@ -886,7 +886,7 @@ __global__ __launch_bounds__(256) void k_design_rho(int nz, int nzs, int mode, d
 
 // ---- dense (column-major, ld) -> MFMA A-fragment layout ---------------------------------------------
 // frag[(rb*ks + s)*64 + l] = M[rb*16 + (l&15)][4 s + (l>>4)]  (zero outside rows x cols)
-__global__ __launch_bounds__(256) void k_pack_frags(const double* M, int rows, int cols, int ld, int nrb, int ks,
+inline __global__ __launch_bounds__(256) void k_pack_frags(const double* M, int rows, int cols, int ld, int nrb, int ks,
                                                     double* frag) {
     const int total = nrb * ks * 64;
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
@@ -899,7 +899,7 @@ __global__ __launch_bounds__(256) void k_pack_frags(const double* M, int rows, i
 // ---- Out[:, c] = -G M[:, c] for a few columns (leading dimension ld for M and Out; G dense symmetric, leading dimension nzs).
 // Design-time / set_reference-time helper for the polish's unconstrained minimiser v0 = -G f' = (-G F') e0 + (-G fS):
 // with V = -G F' packed like F', k_admm gets v0 from n columns instead of a second nz x nz product per step.
-__global__ __launch_bounds__(256) void k_neg_gm(int nz, int nzs, int ncols, int ld, const double* G, const double* M, double* Out,
+inline __global__ __launch_bounds__(256) void k_neg_gm(int nz, int nzs, int ncols, int ld, const double* G, const double* M, double* Out,
                                                 long sG, long sM) {
     G += blockIdx.y * sG; M += blockIdx.y * sM; Out += blockIdx.y * sM;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < (long)ncols * nz; t += (long)gridDim.x * blockDim.x) {
@@ -976,7 +976,7 @@ inline void launch_neg_gm_batched(hipStream_t st, unsigned batch, int nz, int nz
 
 // ---- constraint space for state rows (state box / terminal equality): Ghat = A G A',  A = [I; C'],  C' = Gamma[rows] D ----
 // Cold path: one thread per output element.
-__global__ __launch_bounds__(256) void k_build_cprime(int mc, int nz, int nzs, int gs, const int* rowsel, const double* Gam,
+inline __global__ __launch_bounds__(256) void k_build_cprime(int mc, int nz, int nzs, int gs, const int* rowsel, const double* Gam,
                                                       const double* d, double* Cp) {
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < mc * nzs; t += gridDim.x * blockDim.x) {
         const int r = t / nzs, c = t % nzs;
@@ -984,7 +984,7 @@ __global__ __launch_bounds__(256) void k_build_cprime(int mc, int nz, int nzs, i
     }
 }
 // CG[r][c] = sum_j Cp[r][j] G[j][c]
-__global__ __launch_bounds__(256) void k_cg(int mc, int nz, int nzs, const double* Cp, const double* G, double* CG) {
+inline __global__ __launch_bounds__(256) void k_cg(int mc, int nz, int nzs, const double* Cp, const double* G, double* CG) {
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < mc * nzs; t += gridDim.x * blockDim.x) {
         const int r = t / nzs, c = t % nzs;
         double s = 0.0;
@@ -993,7 +993,7 @@ __global__ __launch_bounds__(256) void k_cg(int mc, int nz, int nzs, const doubl
         CG[t] = s;
     }
 }
-__global__ __launch_bounds__(256) void k_ghat(int nz, int mc, int nzs, int Rs, const double* G, const double* Cp,
+inline __global__ __launch_bounds__(256) void k_ghat(int nz, int mc, int nzs, int Rs, const double* G, const double* Cp,
                                               const double* CG, double* Ghat, double* gnorm) {
     const int R = nz + mc;
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < R * Rs; t += gridDim.x * blockDim.x) {
@@ -1015,7 +1015,7 @@ __global__ __launch_bounds__(256) void k_ghat(int nz, int mc, int nzs, int Rs, c
 
 // Terminal equality eliminated at design time: Ghat -= GhatE' Y with Y = Ghat_EE^-1 GhatE (host), rows / columns E exactly zero,
 // gnorm from the projected diagonal (1 on E).  One thread per element.
-__global__ __launch_bounds__(256) void k_ghat_project(int R, int Rs, int ne, int eq0, const double* GhatE, const double* Y, double* Ghat,
+inline __global__ __launch_bounds__(256) void k_ghat_project(int R, int Rs, int ne, int eq0, const double* GhatE, const double* Y, double* Ghat,
                                                       double* gnorm) {
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < R * Rs; t += gridDim.x * blockDim.x) {
         const int a = t / Rs, b = t % Rs;

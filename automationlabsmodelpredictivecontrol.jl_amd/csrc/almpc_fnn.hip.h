@@ -36,7 +36,7 @@ __device__ __forceinline__ void fnn_act(int act, double a, double& val, double& 
     }
 }
 
-__global__ __launch_bounds__(256) void k_fnn_jacobian(FnnParams p) {
+inline __global__ __launch_bounds__(256) void k_fnn_jacobian(FnnParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int n = p.n, m = p.m, H = p.H, nin = n + m;
     double* y = smem;             // [H]

@@ -24,7 +24,7 @@ namespace {
 
 // u0[i][a] = u[i][0][a] and copies of the three per-instance words of the step: everything small a host caller wants after a step,
 // packed into the slot's own buffers so that the next step (which rewrites u / status / iters) can start while they travel
-__global__ __launch_bounds__(256) void k_pack_step_summary(int batch, int m, int N, const double* u, const int32_t* status,
+inline __global__ __launch_bounds__(256) void k_pack_step_summary(int batch, int m, int N, const double* u, const int32_t* status,
                                                            const int32_t* iters, const int32_t* piters, double* u0, int32_t* ints) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < (long)batch * m) u0[t] = u[(t / m) * (long)m * N + (t % m)];

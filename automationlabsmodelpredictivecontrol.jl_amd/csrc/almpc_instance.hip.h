@@ -14,6 +14,8 @@
 // Iteration formulas, termination test and outputs are those of k_admm (OSQP Algorithm 1, box form).
 #pragma once
 #include "almpc_kernels.hip.h"
+#include "almpc_design.hip.h"   // design_scale_body
+#include "almpc_fnn.hip.h"      // FnnParams
 
 namespace almpc {
 
@@ -54,7 +56,7 @@ constexpr int ADMM_INST_PPW = 16;       // column PAIRS per wave, compile-time b
 // the other iterates.  Every wave carries the whole iterate redundantly (two rows per lane), so the right-hand side
 // entries of column pair j are two v_readlane pairs from lane j; only the 4 partial vectors of a product cross waves
 // (LDS, double buffered: ONE barrier per iteration).
-__global__ __launch_bounds__(ADMM_INST_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_admm_inst(AdmmInstParams p) {
+inline __global__ __launch_bounds__(ADMM_INST_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_admm_inst(AdmmInstParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int nz = p.nz, nzs = p.nzs, n = p.n;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -461,7 +463,7 @@ __global__ __launch_bounds__(64) void k_step_inst_wave(AdmmInstParams ip, Polish
 // the result is the same as with the ADMM guess; what goes away is the ADMM phase AND the KKT inverse it needs -- one of the two
 // n_z x n_z inverses of every iteration.  One wave per instance, same output arrays as k_admm_inst.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_guess_iterate(AdmmInstParams p) {
+inline __global__ __launch_bounds__(256) void k_guess_iterate(AdmmInstParams p) {
     const int nz = p.nz, nzs = p.nzs, n = p.n, lane = threadIdx.x & 63;
     const int inst = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (inst >= p.batch) return;
@@ -493,7 +495,7 @@ __global__ __launch_bounds__(256) void k_guess_iterate(AdmmInstParams p) {
 // guess is the previous step's input trajectory shifted by one stage (stage k <- stage k+1, the last stage repeated) -- the classic
 // MPC warm start.  z = that point in the new scaled coordinates, clipped to the box; working set = its rows on a bound.  The finish
 // is exact whatever its start; what goes away is the ADMM phase and the KKT inverse of the design.  uprev: [batch][N][m].
-__global__ __launch_bounds__(256) void k_guess_shift(AdmmInstParams p, const double* uprev, int N) {
+inline __global__ __launch_bounds__(256) void k_guess_shift(AdmmInstParams p, const double* uprev, int N) {
     const int nz = p.nz, nzs = p.nzs, n = p.n, m = p.m, lane = threadIdx.x & 63;
     const int inst = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (inst >= p.batch) return;
@@ -712,7 +714,7 @@ __host__ __device__ inline size_t design_ltv_lds_doubles(int n, int m, int N) {
     return nz * nz + 3 * (size_t)n * nz + 4 * (size_t)n * n + (size_t)n * m + 3 * (size_t)n + nz;
 }
 
-__global__ __launch_bounds__(256) void k_design_ltv(DesignLtvParams p) {
+inline __global__ __launch_bounds__(256) void k_design_ltv(DesignLtvParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int n = p.n, m = p.m, N = p.N, nz = p.nz, nn = n * n, nm = n * m;
     const size_t inst = blockIdx.x;
@@ -1022,7 +1024,7 @@ __global__ __launch_bounds__((128 / TS) * (128 / TS)) void k_design_ltv_reg(Desi
 }
 
 // fS_i = d_i .* g: the constant part of the scaled gradient (g = 2 D'Sbar D u_ref, shared or per instance) for every instance
-__global__ __launch_bounds__(256) void k_fs_scale(int batch, int nz, int nzs, const double* g, long g_stride, const double* d,
+inline __global__ __launch_bounds__(256) void k_fs_scale(int batch, int nz, int nzs, const double* g, long g_stride, const double* d,
                                                   double* fS) {
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < (long)batch * nz; t += (long)gridDim.x * blockDim.x) {
         const long i = t / nz;
@@ -1033,7 +1035,7 @@ __global__ __launch_bounds__(256) void k_fs_scale(int batch, int nz, int nzs, co
 
 // Per-step re-linearisation pipeline: an instance whose design failed (non-positive diagonal / pivot: bFlag != 0) is reported through
 // its solve status instead of a host-side error, so that the pipeline needs no host round trip.
-__global__ __launch_bounds__(256) void k_flag_to_status(int batch, const int* flag, int32_t* status) {
+inline __global__ __launch_bounds__(256) void k_flag_to_status(int batch, const int* flag, int32_t* status) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < batch && flag[i] != 0) status[i] = 2;  // ALMPC_NON_FINITE: no usable solution for this instance
 }

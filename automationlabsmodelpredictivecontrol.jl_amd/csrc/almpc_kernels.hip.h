@@ -1683,6 +1683,8 @@ void k_polish(PolishParams p_arg) {
 }
 
 // per-instance models, small batches: single-wave workgroups, G_i and the second-tier Sinv in LDS (one workgroup per CU)
+// (a template only so that it is compiled where it is instantiated -- almpc_tu_step.hip -- and not by every file that reads this header)
+template <int UNUSED = 0>
 __global__ __launch_bounds__(64) void k_polish_sgl(PolishParams p_arg) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     polish_body<false, false, 0, true>(p_arg, smem);
@@ -1803,7 +1805,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_rollout(RolloutParams p) {
 
 // Closed loop on the device: x0 <- A x0 + B u[:,1] for every instance (the plant the controller was designed for), so that a
 // receding-horizon run needs no host round trip between steps.  One thread per (instance, state).
-__global__ __launch_bounds__(256) void k_advance_plant(int n, int m, int N, int batch, const double* A, const double* B,
+inline __global__ __launch_bounds__(256) void k_advance_plant(int n, int m, int N, int batch, const double* A, const double* B,
                                                       const double* u, const double* x0_in, double* x0) {
     extern __shared__ __attribute__((aligned(16))) double smem[];  // old x0 of the block's instances
     const int per_block = blockDim.x / n;  // instances per block
@@ -1821,7 +1823,7 @@ __global__ __launch_bounds__(256) void k_advance_plant(int n, int m, int N, int 
 
 // Test hook: fill the LDS of every CU with NaN bit patterns so that a kernel that reads LDS it did not write shows up
 // as a wrong result instead of passing on stale finite values (tests/test_gpu_parity.py poisons before it solves).
-__global__ __launch_bounds__(1024) void k_poison_lds(unsigned long long pattern, int words, unsigned long long* sink) {
+inline __global__ __launch_bounds__(1024) void k_poison_lds(unsigned long long pattern, int words, unsigned long long* sink) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     unsigned long long* w = reinterpret_cast<unsigned long long*>(smem);
     for (int t = threadIdx.x; t < words; t += blockDim.x) w[t] = pattern;

@@ -1034,7 +1034,7 @@ struct S0BasisParams {
     const double* A; const double* B; const double* Vs; const double* v0S; const double* dvec; const int* row_traj;
     double* out;   // [(n + 1)][Rs], zero where no state row sits
 };
-__global__ __launch_bounds__(64) void k_s0_basis(S0BasisParams p) {
+inline __global__ __launch_bounds__(64) void k_s0_basis(S0BasisParams p) {
     extern __shared__ __attribute__((aligned(16))) double Z[];
     const int j = blockIdx.x, lane = threadIdx.x, n = p.n, m = p.m, N = p.N, C = n + m;
     for (int t = lane; t < (N + 1) * C; t += 64) Z[t] = 0.0;

@@ -98,7 +98,7 @@ __device__ __forceinline__ int wave_min_i(int v) {
 // (shift = 1: the receding-horizon shift of the previous step, the last stage repeated), the input reference beyond them.  The
 // source may have a shorter horizon (horizon continuation: the condensed path at N = 30 hands the stage-wise path at N = 50 its
 // working set -- the active bounds of an MPC problem with the DARE terminal weight sit in the early stages).
-__global__ __launch_bounds__(256) void k_guess_from_inputs(int batch, int m, int Nsrc, int N, int shift, const double* usrc, const double* uref,
+inline __global__ __launch_bounds__(256) void k_guess_from_inputs(int batch, int m, int Nsrc, int N, int shift, const double* usrc, const double* uref,
                                                            long uref_stride, double* dst) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long)batch * N * m) return;

@@ -1045,7 +1045,7 @@ __host__ __device__ inline int sgains_lds_doubles(int nt, int m) {
 }
 constexpr int SGAINS_WAVES = 4;
 
-__global__ __launch_bounds__(64 * SGAINS_WAVES) void k_sgains(SgainsParams p) {
+inline __global__ __launch_bounds__(64 * SGAINS_WAVES) void k_sgains(SgainsParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = p.n, nt = p.nt, m = p.m, N = p.N, NT = p.NT, MC = p.MC;

@@ -51,7 +51,7 @@ struct SqpParams {
 // point is rejected: the iterate goes back to the last accepted point plus HALF the step (both kept), this iteration's QP -- built
 // at the rejected point -- is void for the instance (redo flag: k_sqp_step leaves it alone), and the next iteration tests the
 // shorter step.  Accepted steps double the factor back up to 1; at 1/64 a step is accepted regardless.
-__global__ __launch_bounds__(256) void k_sqp_prepare(SqpParams p) {
+inline __global__ __launch_bounds__(256) void k_sqp_prepare(SqpParams p) {
     const int n = p.n, m = p.m, N = p.N, nz = p.nz;
     const size_t i = blockIdx.x;
     double* xbw = p.xbar + i * (size_t)(N + 1) * n;
@@ -151,7 +151,7 @@ __host__ __device__ inline size_t sqp_step_lds_doubles(int n, int m, int N) {
     return (size_t)sqp_step_chunk(n, m, N) * ((size_t)n * n + (size_t)n * m + n) + (size_t)(N + 1) * n + (size_t)m * N + 16;
 }
 
-__global__ __launch_bounds__(256) void k_sqp_step(SqpParams p) {
+inline __global__ __launch_bounds__(256) void k_sqp_step(SqpParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int skip;
     const int n = p.n, m = p.m, N = p.N, nz = p.nz, tid = threadIdx.x, nn = n * n, nm = n * m, E = nn + nm + n;
@@ -267,7 +267,7 @@ struct FnnRolloutParams {
     double* xbar;         // [batch][(N+1)][n]
 };
 
-__global__ __launch_bounds__(256) void k_fnn_rollout(FnnRolloutParams p) {
+inline __global__ __launch_bounds__(256) void k_fnn_rollout(FnnRolloutParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int n = p.n, m = p.m, H = p.H, nin = n + m;
     double* y = smem;        // [H]
