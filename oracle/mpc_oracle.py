@@ -1003,7 +1003,26 @@ def admm_box(Hs, fs, lo, hi, rho=0.1, sigma=1e-6, alpha=1.6, eps_abs=1e-3, eps_r
     return dict(x=x, z=z, y=y, iters=it, status=status)
 
 
-def polish_active_set(G, v0, lo, hi, z, y, max_iter=None, refine=True):
+def saturated_lqr_rollout(p: "MPCProblem", x0):
+    """Seed candidate for the active-set finish (round-4 review, item 1; measured in tools/exp_lqr_seed.py and NOT adopted,
+    DESIGN.md section 4): with P = DARE (src/sub/design_mpc.jl:327) the unconstrained optimum of the reference's QP is the LQR
+    feedback, so roll the plant forward under u_k = clip(-K e_k) with the clipping propagated through the state,
+    e_{k+1} = A e_k + B u_k.  Returns (v, side): the feasible input sequence v = vec(e_u) (unscaled, stage-major like `condense`)
+    and side[j] in {-1, 0, +1}: row j was cut off at its lower / upper bound."""
+    K = np.linalg.solve(p.R + p.B.T @ p.P @ p.B, p.B.T @ p.P @ p.A)
+    e = np.asarray(x0, dtype=np.float64) - p.x_ref[:, 0]
+    v = np.empty((p.N, p.m))
+    side = np.zeros((p.N, p.m), dtype=int)
+    for k in range(p.N):
+        lo_k, hi_k = p.u_min - p.u_ref[:, k], p.u_max - p.u_ref[:, k]
+        uk = -K @ e
+        side[k] = np.where(uk < lo_k, -1, np.where(uk > hi_k, 1, 0))
+        v[k] = np.clip(uk, lo_k, hi_k)
+        e = p.A @ e + p.B @ v[k]
+    return v.reshape(-1), side.reshape(-1)
+
+
+def polish_active_set(G, v0, lo, hi, z, y, max_iter=None, refine=True, seed=None):
     """Polish = exact active-set finish started from the ADMM iterate, in the scaled
     coordinates of ``design_shared`` (OSQP's polish guesses the active rows from the sign of
     y and solves one equality-constrained KKT system; here the guess is then corrected by
@@ -1017,7 +1036,11 @@ def polish_active_set(G, v0, lo, hi, z, y, max_iter=None, refine=True):
     explicitly and updated by bordering (add) / Schur down-dating (remove), the form the
     HIP kernel uses because every step of it is lane-parallel.
 
-    Returns dict(w, iters, n_add, n_remove, n_active).
+    `seed` (optional, one entry per row: -1 / 0 / +1) replaces the sign-of-y guess: those rows start in the working set at
+    their lower / upper bound (z must be feasible; it is moved onto the bounds of the seeded rows).  The optimum does not
+    depend on the seed, only the number of changes does (tools/exp_lqr_seed.py).
+
+    Returns dict(w, iters, n_add, n_remove, n_active, n_purged, side).
     """
     nz = v0.size
     max_iter = 2 * nz + 50 if max_iter is None else max_iter
@@ -1047,7 +1070,11 @@ def polish_active_set(G, v0, lo, hi, z, y, max_iter=None, refine=True):
 
     w = np.clip(z, lo, hi)
     for j in range(nz):
-        if y[j] < 0 and w[j] <= lo[j]:
+        if seed is not None:
+            if seed[j] != 0:
+                w[j] = lo[j] if seed[j] < 0 else hi[j]
+                add(j, -1 if seed[j] < 0 else +1)
+        elif y[j] < 0 and w[j] <= lo[j]:
             add(j, -1)
         elif y[j] > 0 and w[j] >= hi[j]:
             add(j, +1)
@@ -1106,7 +1133,10 @@ def polish_active_set(G, v0, lo, hi, z, y, max_iter=None, refine=True):
             break
         remove(i)
         n_rem += 1
-    return dict(w=np.clip(w, lo, hi), iters=it + n_purged, n_add=n_add, n_remove=n_rem, n_active=len(W))
+    fin = np.zeros(nz, dtype=int)
+    for j in W:
+        fin[j] = side[j]
+    return dict(w=np.clip(w, lo, hi), iters=it + n_purged, n_add=n_add, n_remove=n_rem, n_active=len(W), n_purged=n_purged, side=fin)
 
 
 def design_shared(p: MPCProblem, rho=0.1, sigma=1e-6, rho_profile="scalar"):

@@ -509,3 +509,30 @@ def test_feasibility_certificate_by_linear_programming(mo):
     assert np.abs(e["x"][:, -1]).max() <= 1e-9
     with pytest.raises((ValueError, RuntimeError)):
         mo.solve_mpc_exact(pb, np.array([4.9, 4.0]))
+
+
+def test_saturated_lqr_seed_is_a_superset_guess_and_the_finish_does_not_depend_on_the_seed(mo):
+    """Round-4 review item 1 (tools/exp_lqr_seed.py): the saturated closed-loop LQR rollout as the finish's seed.  The optimum
+    must not depend on the seed; on amplitude-1 quadrotor states the seed is already the optimal working set (zero changes),
+    and ADMM's sign(y) guess is a subset of the final set while the LQR seed is a superset of it."""
+    p = mo.quadrotor()
+    des = mo.design_shared(p, rho=45.0, rho_profile="stiffness")
+    zero_changes = 0
+    for i, amp in ((0, 1.0), (1, 1.0), (2, 1.0), (3, 3.0), (4, 3.0), (5, 3.0)):
+        x0 = mo.quadrotor_x0_batch(1, amp, first_instance=i)[0]
+        fs = des["Fs"] @ (x0 - p.x_ref[:, 0]) + des["fS"]
+        v0 = -des["G"] @ fs
+        r = mo.admm_box(des["Hs"], fs, des["lo"], des["hi"], rho=des["rho_vec"], sigma=des["sigma"], max_iter=6, check_every=6,
+                        Minv=des["Minv"], unscale=des["d"])
+        a = mo.polish_active_set(des["G"], v0, des["lo"], des["hi"], r["z"], r["y"])
+        v, side = mo.saturated_lqr_rollout(p, x0)
+        assert np.all(v >= np.tile(p.u_min, p.N) - 1e-15) and np.all(v <= np.tile(p.u_max, p.N) + 1e-15)
+        b = mo.polish_active_set(des["G"], v0, des["lo"], des["hi"], v / des["d"], None, seed=side)
+        assert np.max(np.abs(a["w"] - b["w"])) < 1e-7
+        assert np.array_equal(a["side"], b["side"])
+        exact = mo.solve_mpc_exact(p, x0)
+        assert np.max(np.abs(b["w"] * des["d"] - (exact["u"] - p.u_ref).T.reshape(-1))) < 1e-6
+        if amp == 1.0:
+            zero_changes += int(b["n_add"] + b["n_remove"] + b["n_purged"] == 0)
+            assert np.all((side != 0) | (a["side"] == 0))      # final set inside the LQR seed
+    assert zero_changes == 3
