@@ -106,6 +106,7 @@ struct almpc_handle {
     double *bPhi = nullptr, *bGk = nullptr, *bGam = nullptr, *bW = nullptr, *bWP = nullptr, *bP = nullptr;
     int* bFlag = nullptr;
     bool batched_alloc = false;
+    bool minv_packed = false;   // bMinv holds packed lower triangles (stride packed_tri_doubles): k_admm_inst<true>
     // SQP outer loop for a black-box Fnn model (almpc_sqp_fnn_*): the network, the stage data of the current linearisation
     struct Sqp {
         bool ready = false, started = false;
@@ -153,6 +154,14 @@ struct almpc_handle {
     bool lazy_pending = false;
     bool redo_x0_from_results = false;   // set around the launches of a lazy redo: x0 = stage 1 of the step's own x (the caller may have
                                          // handed over the next x0 since)
+    // Gated redo (round 5): where results leave without a synchronous host look -- the asynchronous tickets (almpc_get_results_async)
+    // and the device-resident loops (almpc_advance_plant, almpc_relin_fnn_advance) -- the redo launches are enqueued behind the step
+    // with a GATE: the finish of step s stores s in dRedoGate when it leaves an instance undecided, and a gated launch returns at once
+    // unless the word holds its step's number.  Every read path hands out "solution or verdict" (src/main/computation_mpc.jl:41-53)
+    // at the cost of two (three with per-instance stage records) empty launches per step on those paths only.
+    int* dRedoGate = nullptr;
+    int step_serial = 0;                 // number of the last enqueued step (1, 2, ...)
+    bool redo_gate_on = false;           // set around the launches of a gated redo
     bool flag_in_finish = false;   // transient (re-linearisation step): the finish turns a flagged design into ALMPC_NON_FINITE itself
     int fallback = 2;   // 0 off, 1 asked for (a design it cannot serve is an error), 2 default: on wherever the stage-wise solvers cover the design
     double *rQ = nullptr, *rR = nullptr, *rP = nullptr, *rKst = nullptr, *rPst = nullptr;   // device copies of Q, R (branch rule applied), shared P; gain scratch
@@ -180,7 +189,7 @@ struct almpc_handle {
         int32_t* ovf = nullptr;
         int32_t* wsave = nullptr;   // [batch][SDUAL_WSAVE] working set of an instance that ran out of room (start of the next tier)
         double* sinv_glb = nullptr; size_t sinv_cap = 0;   // third tier: Sinv of 128 x 129 per wave of its grid
-        double* ghat = nullptr; size_t ghat_cap = 0; bool ghat_ready = false, ghat_building = false;   // shared model: cached sweep responses [TP][TP] (k_sdual: SdualParams::ghat)
+        double* ghat = nullptr; size_t ghat_cap = 0; bool ghat_ready = false, ghat_building = false, ghat_wanted = false;   // shared model: cached sweep responses [TP][TP] (k_sdual: SdualParams::ghat)
         std::vector<double> S;               // symmetrised S (base terms of time-varying input references)
     } sd;
     // multi-GPU (almpc_comm_*): this handle's rank in an RCCL communicator of one process per GPU
@@ -310,6 +319,7 @@ void free_all(almpc_handle* h) {
     if (h->ev_guess) (void)hipEventDestroy(h->ev_guess);
     if (h->ev_guess_done) (void)hipEventDestroy(h->ev_guess_done);
     if (h->hUnsolved) (void)hipHostFree(h->hUnsolved);
+    if (h->dRedoGate) (void)hipFree(h->dRedoGate);
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
     h->ev.clear();
@@ -437,6 +447,7 @@ hipError_t launch_riccati(almpc_handle* h, int filter, const double* guess, int 
     rp.uref = h->dUref; rp.uref_stride = h->uref_stride; rp.xref = h->dXref; rp.xref_stride = h->xref_stride;
     rp.x0 = h->dX0; rp.x0_stride = h->n; rp.uguess = guess; rp.filter = filter; rp.Kst = h->rKst; rp.Pst = h->rPst;
     if (h->redo_x0_from_results) { rp.x0 = h->dX; rp.x0_stride = (long)h->n * (h->N + 1); }   // (lazy redo: see resolve_lazy_redo)
+    if (h->redo_gate_on) { rp.gate = h->dRedoGate; rp.gate_val = h->step_serial; }
     rp.x = h->dX; rp.ex = h->dEx; rp.u = h->dU; rp.eu = h->dEu; rp.status = h->dStatus; rp.piters = h->dPiters;
     rp.max_iter = max_iter > 0 ? max_iter : 20 * h->N * h->m + 50;
     rp.tol = 1e-9;
@@ -495,6 +506,7 @@ bool sdual_shape_ok(int n, int m, int N, bool useS) {
 // Stage records of a SHARED model on the device (host Riccati, design time), state box / terminal equality / S of the design.
 // Rm: the reference's branch rule applied (zeros when R[1,1] == 0); Sm null: no input-rate term.
 hipError_t launch_sdual(almpc_handle* h, int filter, const double* guess, int max_iter, bool single_launch = false, int first_tier = 0);
+hipError_t sdual_build_ghat(almpc_handle* h);
 
 int sdual_setup_shared(almpc_handle* h, const hm::mat& Am, const hm::mat& Bm, const hm::mat& Qm, const hm::mat& Rm, const hm::mat* Sm,
                        const hm::mat& Pm, const double* xmin, const double* xmax, bool terminal_eq) {
@@ -534,24 +546,40 @@ int sdual_setup_shared(almpc_handle* h, const hm::mat& Am, const hm::mat& Bm, co
     sd.has_base = false; sd.base_stride = 0;
     sd.per_instance = false; sd.gain_N = 0; sd.sqp = false;
     sd.ready = true;
-    // cached responses: every coordinate that can be a row, one sweep each, once (k_sdual's build mode on min(TP, 2048) waves)
+    // cached responses (sdual_build_ghat): at design time for a structured handle, whose every step uses them; on a condensed handle,
+    // where k_sdual is only the redo of what a step leaves undecided, at the first redo -- most such handles (the headline path) never
+    // leave an instance undecided and should not pay TP^2 doubles and one sweep per coordinate at every design
     sd.ghat_ready = false;
-    const size_t TP = (size_t)sdual_tp(sd.NT, sd.MC, N);
-    if (TP * TP * sizeof(double) <= ((size_t)256 << 20) && !getenv("ALMPC_SDUAL_NO_GHAT")) {
-        if (sd.ghat_cap < TP * TP) {
-            if (sd.ghat) { (void)hipFree(sd.ghat); sd.ghat = nullptr; sd.ghat_cap = 0; }
-            HIP_TRY(h, dalloc(&sd.ghat, TP * TP));
-            sd.ghat_cap = TP * TP;
-        }
-        HIP_TRY(h, hipMemsetAsync(sd.ghat, 0, TP * TP * sizeof(double), h->stream));
-        sd.ghat_building = true;
-        const hipError_t build_rc = launch_sdual(h, 0, nullptr, 0);
-        sd.ghat_building = false;
-        HIP_TRY(h, build_rc);
+    sd.ghat_wanted = !getenv("ALMPC_SDUAL_NO_GHAT");
+    if (sd.ghat_wanted && (h->flags & ALMPC_FLAG_STRUCTURED)) {
+        HIP_TRY(h, sdual_build_ghat(h));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
-        sd.ghat_ready = true;
     }
     return ALMPC_OK;
+}
+
+// Cached responses of a shared model: every coordinate that can be a row, one sweep each, once (k_sdual's build mode on
+// min(TP, 2048) waves), TP x TP doubles.  Memory cap 256 MB per handle (TP <= 5792: e.g. the quadrotor with S up to N = 361); above it
+// the table is not built and a working-set change costs two sweeps again (SdualParams::ghat == null).  Enqueued on the handle's stream.
+hipError_t sdual_build_ghat(almpc_handle* h) {
+    almpc_handle::Sd& sd = h->sd;
+    sd.ghat_wanted = false;   // (one attempt per design)
+    const size_t TP = (size_t)sdual_tp(sd.NT, sd.MC, h->N);
+    if (TP * TP * sizeof(double) > ((size_t)256 << 20)) return hipSuccess;
+    if (sd.ghat_cap < TP * TP) {
+        if (sd.ghat) { (void)hipFree(sd.ghat); sd.ghat = nullptr; sd.ghat_cap = 0; }
+        hipError_t e = dalloc(&sd.ghat, TP * TP);
+        if (e != hipSuccess) return e;
+        sd.ghat_cap = TP * TP;
+    }
+    hipError_t e = hipMemsetAsync(sd.ghat, 0, TP * TP * sizeof(double), h->stream);
+    if (e != hipSuccess) return e;
+    sd.ghat_building = true;
+    e = launch_sdual(h, 0, nullptr, 0);
+    sd.ghat_building = false;
+    if (e != hipSuccess) return e;
+    sd.ghat_ready = true;
+    return hipSuccess;
 }
 
 // Linear cost terms of the stage-wise problem that depend on the references: only the input-rate term does (it is on u = v + u_ref,
@@ -656,6 +684,7 @@ hipError_t launch_sgains(almpc_handle* h, int filter) {
     gp.rec = sd.rec; gp.rec_stride = sd.rec_stride;
     gp.pc = nullptr; gp.ct = nullptr; gp.pc_stride = 0;
     gp.bad = sd.bad;
+    if (h->redo_gate_on) { gp.gate = h->dRedoGate; gp.gate_val = h->step_serial; }
     if (sd.sqp) {   // the QP of the current SQP iteration: stage models, defects, state errors and input gradient of the loop
         const almpc_handle::Sqp& q = h->sqp;
         const long N = h->N;
@@ -750,8 +779,12 @@ hipError_t launch_sdual_t(almpc_handle* h, SdualParams sp, int tier0, int tier1)
 // k_sdual over the batch (filter 0), over the instances whose status is not 0 (filter 1: redo after the condensed path), start from
 // `guess` (inputs [batch][N][m]) when given
 hipError_t launch_sdual(almpc_handle* h, int filter, const double* guess, int max_iter, bool single_launch, int first_tier) {
+    if (!h->sd.ready) return hipErrorInvalidValue;
+    if (h->sd.ghat_wanted && !h->sd.ghat_ready && !h->sd.ghat_building && !h->sd.per_instance && !h->sd.sqp) {   // first use on a condensed handle
+        const hipError_t eb = sdual_build_ghat(h);
+        if (eb != hipSuccess) return eb;
+    }
     const almpc_handle::Sd& sd = h->sd;
-    if (!sd.ready) return hipErrorInvalidValue;
     SdualParams sp;
     std::memset(&sp, 0, sizeof(sp));
     sp.n = h->n; sp.nt = sd.nt; sp.m = h->m; sp.N = h->N; sp.batch = h->batch;
@@ -764,6 +797,7 @@ hipError_t launch_sdual(almpc_handle* h, int filter, const double* guess, int ma
     sp.eqt = sd.has_eq ? h->dXref + (size_t)h->N * h->n : nullptr; sp.eqt_stride = h->xref_stride;   // x_N = x_ref_N
     sp.x0 = h->dX0; sp.x0_stride = h->n; sp.xref = h->dXref; sp.xref_stride = h->xref_stride;
     if (h->redo_x0_from_results) { sp.x0 = h->dX; sp.x0_stride = (long)h->n * (h->N + 1); }   // (lazy redo: see resolve_lazy_redo)
+    if (h->redo_gate_on) { sp.gate = h->dRedoGate; sp.gate_val = h->step_serial; }
     sp.uguess = guess; sp.filter = filter; sp.flag = nullptr; sp.v_only = 0;
     sp.x = h->dX; sp.ex = h->dEx; sp.u = h->dU; sp.eu = h->dEu; sp.status = h->dStatus; sp.piters = h->dPiters;
     if (sd.sqp) {   // dx_0 = 0, variable v = u - ubar (the handle's per-instance references ARE the iterate xbar, ubar), cost terms per instance
@@ -826,6 +860,27 @@ int resolve_lazy_redo(almpc_handle* h) {
     if (h->mc == 0 && !h->useS && h->rKst) HIP_TRY(h, launch_riccati(h, 1, h->dU, 0));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return ALMPC_OK;
+}
+
+// Gated redo behind the last enqueued step (no host look, no synchronisation): see almpc_handle::dRedoGate.  Called where the step's
+// results are about to be consumed without a synchronous call; does nothing unless a lazily deferred redo is pending.
+int enqueue_gated_redo(almpc_handle* h) {
+    if (!h->lazy_pending || !h->dRedoGate || getenv("ALMPC_NO_GATED_REDO")) return ALMPC_OK;
+    h->redo_x0_from_results = true; h->redo_gate_on = true;
+    struct Reset { almpc_handle* h; ~Reset() { h->redo_x0_from_results = false; h->redo_gate_on = false; } } reset_{h};
+    if (h->sd.ready) {
+        if (h->sd.per_instance) HIP_TRY(h, launch_sgains(h, 1));
+        HIP_TRY(h, launch_sdual(h, 1, h->dU, 0, true));
+    }
+    if (h->mc == 0 && !h->useS && h->rKst) HIP_TRY(h, launch_riccati(h, 1, h->dU, 0));
+    h->lazy_pending = false;   // (this step is settled on the stream; a later synchronous look has nothing left to do for it)
+    return ALMPC_OK;
+}
+
+// A new design voids a redo that was deferred for a step of the previous one (its models, references and results are about to go)
+void drop_lazy_redo(almpc_handle* h) {
+    h->lazy_pending = false;
+    if (h->hUnsolved) h->unsolved_seen = *reinterpret_cast<volatile int*>(h->hUnsolved);
 }
 
 // Table of the state rows' s0 (PolishGenParams::s0_basis) for a shared design: after the design and after every change of the shared
@@ -1030,6 +1085,7 @@ int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const
                         const double* S, const double* P, const double* umin, const double* umax,
                         const double* xmin, const double* xmax, double rho, double sigma) {
     if (!h) return ALMPC_ERR_INVALID;
+    drop_lazy_redo(h);
     if (!A || !B || !Q || !R || !umin || !umax) return fail(h, ALMPC_ERR_INVALID, "design: null matrix pointer");
     if (h->structured) {   // ALMPC_FLAG_STRUCTURED: no condensed matrices at all; rho / sigma are not used
         const int n = h->n, m = h->m, N = h->N;
@@ -1262,6 +1318,7 @@ void launch_batched_factor(almpc_handle* h, const DesignStrides& ds, double rho,
     const size_t inv_lds = 520 * sizeof(double);
     if (!v1M && !h->skip_admm && h->rho_mode == 0 && design_inverse_makes_rho(nz, nzs) && nz <= 64 && design_inverse_makes_v(nz) && !getenv("ALMPC_DBG_SPLIT_INVERSES")) {
         // scalar rho: the ADMM's KKT inverse does not need G_i -- both inverses, the penalty profile and V_i in ONE launch
+        h->minv_packed = false;
         launch_design_inverse(dim3(1, gb), inv_lds, st, nz, nzs, h->bHs, 0.0, (const double*)nullptr, h->bG, h->bFlag, ds.Hs, ds.rho, ds.G, 1L,
                               (const double*)nullptr, 0L, 0, rho, h->bRho, with_v ? h->bFs : nullptr, h->bVs, ds.Fs, n, h->bMinv, ds.Minv, sigma);
         return;
@@ -1278,12 +1335,16 @@ void launch_batched_factor(almpc_handle* h, const DesignStrides& ds, double rho,
         if (with_v) launch_neg_gm_batched(st, gb, nz, nzs, n, h->bG, h->bFs, h->bVs, ds.G, ds.Fs);
     }
     if (h->skip_admm) return;  // no ADMM phase in this solve: its KKT inverse is not needed
+    h->minv_packed = design_inverse_can_pack(nz);   // the ADMM's KKT inverse as its packed triangle: half the stream of k_admm_inst
+    const long sMinv = h->minv_packed ? packed_tri_doubles(nz) : ds.Minv;
     if (design_inverse_makes_rho(nz, nzs))   // the penalty profile is made inside the inverse's own launch
         launch_design_inverse(dim3(1, gb), inv_lds, st, nz, nzs, h->bHs, sigma, (const double*)nullptr, h->bMinv, h->bFlag, ds.Hs, ds.rho, ds.Minv, 1L,
                               h->bG, ds.G, h->rho_mode, rho, h->bRho);
     else {
         hipLaunchKernelGGL(k_design_rho, dim3(1, gb), dim3(256), 0, st, nz, nzs, h->rho_mode, rho, h->bG, h->bRho, ds.G, ds.rho);
-        launch_design_inverse(dim3(1, gb), inv_lds, st, nz, nzs, h->bHs, sigma, (const double*)h->bRho, h->bMinv, h->bFlag, ds.Hs, ds.rho, ds.Minv, 1L);
+        launch_design_inverse(dim3(1, gb), inv_lds, st, nz, nzs, h->bHs, sigma, (const double*)h->bRho, h->bMinv, h->bFlag, ds.Hs, ds.rho, sMinv, 1L,
+                              (const double*)nullptr, 0L, 0, 0.0, (double*)nullptr, (const double*)nullptr, (double*)nullptr, 0L, 0, (double*)nullptr, 0L, 0.0, 0,
+                              h->minv_packed ? 1 : 0);
     }
 }
 
@@ -1451,6 +1512,7 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
                           const double* S, const double* P, int P_per_instance, const double* umin, const double* umax,
                           double rho, double sigma, const LtvInputs* ltv) {
     if (!h) return ALMPC_ERR_INVALID;
+    drop_lazy_redo(h);
     if (h->structured) {   // one model per instance, structured solve: models and terminal weights on the device, nothing condensed
         if (ltv) return fail(h, ALMPC_ERR_UNSUPPORTED, "structured solve: time-varying designs go through almpc_sqp_fnn_* (stage models on the device)");
         if (!A_batch || !B_batch || !Q || !R || !umin || !umax) return fail(h, ALMPC_ERR_INVALID, "design_batched: null matrix pointer");
@@ -1710,6 +1772,7 @@ int almpc_design_ltv(almpc_handle* h, const double* A_all, const double* B_all, 
                      const double* ubar, const double* xref, const double* uref, const double* Q, const double* R, const double* S,
                      const double* P, int P_per_instance, const double* umin, const double* umax, double rho, double sigma) {
     if (!h) return ALMPC_ERR_INVALID;
+    drop_lazy_redo(h);
     if (!A_all || !B_all || !xbar || !ubar || !Q || !R || !P || !umin || !umax)
         return fail(h, ALMPC_ERR_INVALID, "design_ltv: null pointer (P must be given: there is no single model to take a DARE of)");
     const int n = h->n, m = h->m, N = h->N, nz = h->nz;
@@ -1763,6 +1826,7 @@ int almpc_relin_fnn_setup(almpc_handle* h, int H, int L, int activation, const d
                           const double* W_out, const double* xref, const double* uref, const double* Q, const double* R,
                           const double* S, const double* P, const double* umin, const double* umax, double rho, double sigma) {
     if (!h) return ALMPC_ERR_INVALID;
+    drop_lazy_redo(h);
     if (H < 1 || L < 0 || !W_in || !W_out || (L > 0 && (!W_h || !b_h)) || !Q || !R || !P || !umin || !umax)
         return fail(h, ALMPC_ERR_INVALID, "relin_fnn_setup: null pointer or bad network shape (P must be given: the terminal weight "
                                           "comes from the linearisation at the last reference, src/sub/design_mpc.jl:312-327)");
@@ -1850,6 +1914,9 @@ int almpc_relin_fnn_setup(almpc_handle* h, int H, int L, int activation, const d
             const int rc_ = sdual_setup_batched(h, Qm, Rm, q.useS ? &Sm : nullptr, false,
                                                 h->boxmin.empty() ? nullptr : h->boxmin.data(), h->boxmax.empty() ? nullptr : h->boxmax.data(), h->terminal_eq != 0);
             if (rc_ != ALMPC_OK && h->fallback == 1) return rc_;
+            // the references were uploaded above, not through almpc_set_reference (which this pipeline refuses): the input-rate terms
+            // of a horizon-varying u_ref (+-S (u_ref[k-1] - u_ref[k])) have to reach the stage-wise redo from here
+            if (rc_ == ALMPC_OK) { const int rb_ = sdual_update_base(h, ur.data(), 1); if (rb_ != ALMPC_OK) return rb_; }
         } else if (h->fallback == 1 && (h->mc > 0 || q.useS))
             return fail(h, ALMPC_ERR_UNSUPPORTED, "structured fallback: state rows / input-rate weight need n + m <= 48 and (N + 1)(n + m) <= 4096");
         if (riccati_shape_ok(h) && h->mc == 0 && !q.useS) {
@@ -1933,6 +2000,7 @@ int almpc_relin_fnn_advance(almpc_handle* h) {
     almpc_handle::Relin& q = h->relin;
     if (!q.ready || !q.have_prev) return fail(h, ALMPC_ERR_NOT_DESIGNED, "relin_fnn_advance needs a solved almpc_relin_fnn_step");
     HIP_TRY(h, hipSetDevice(h->device));
+    { const int rc_ = enqueue_gated_redo(h); if (rc_ != ALMPC_OK) return rc_; }   // (the network is driven by decided instances' inputs only)
     const int n = h->n, m = h->m;
     hipStream_t st = h->stream;
     const size_t cnt = (size_t)h->batch * m;
@@ -1977,6 +2045,7 @@ int almpc_sqp_fnn_setup(almpc_handle* h, int H, int L, int activation, const dou
                         const double* S, const double* P, int P_per_instance, const double* umin, const double* umax, double rho,
                         double sigma) {
     if (!h) return ALMPC_ERR_INVALID;
+    drop_lazy_redo(h);
     if (H < 1 || L < 0 || !W_in || !W_out || (L > 0 && (!W_h || !b_h)) || !Q || !R || !P || !umin || !umax)
         return fail(h, ALMPC_ERR_INVALID, "sqp_fnn_setup: null pointer or bad network shape (P must be given)");
     if (activation < 0 || activation > 4) return fail(h, ALMPC_ERR_UNSUPPORTED, "sqp_fnn_setup: activation must be 0..4");
@@ -2470,8 +2539,13 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         hipError_t e_ = hipHostMalloc(reinterpret_cast<void**>(&h->hUnsolved), sizeof(int), hipHostMallocMapped);
         if (e_ != hipSuccess) { h->hUnsolved = nullptr; return e_; }
         *h->hUnsolved = 0; h->unsolved_seen = 0;
+        e_ = dalloc(&h->dRedoGate, 1);
+        if (e_ != hipSuccess) return e_;
+        e_ = hipMemset(h->dRedoGate, 0, sizeof(int));   // (step numbers start at 1)
+        if (e_ != hipSuccess) return e_;
         return hipHostGetDevicePointer(reinterpret_cast<void**>(&h->dUnsolved), h->hUnsolved, 0);
     };
+    h->step_serial += 1;
     auto io_step_done = [&]() -> int {   // the x0 slot of an asynchronous update is free again once this step has finished
         h->state_valid = keep_state;     // (recorded only here: every launch of the step went out)
         if (h->io.x0_slot >= 0) {
@@ -2546,14 +2620,17 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         if (!inst_pending) return ALMPC_OK;
         inst_pending = false;
         HIP_TRY(h, ev0());
-        const size_t l = (12 * (size_t)h->nzs + 64 + 2 * (size_t)h->m) * sizeof(double);
+        const bool packed = h->minv_packed;
+        const size_t l = admm_inst_lds_doubles(h->nz, h->nzs, h->m, packed) * sizeof(double);
         if (l > 64 * 1024)
-            HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(k_admm_inst), (size_t)(l)));
+            HIP_TRY(h, ensure_dyn_lds(packed ? reinterpret_cast<const void*>(k_admm_inst<true>) : reinterpret_cast<const void*>(k_admm_inst<false>), (size_t)(l)));
         // persistent grid: as many workgroups as fit the CUs at once (LDS bound; 512 threads each, at most 4 per CU)
         const int per_cu = 2;  // register bound: 2 x 256 threads at up to 256 VGPRs each fill the CU's register file
         int wgs = h->num_cus * per_cu;
         if (wgs > h->batch) wgs = h->batch;
-        hipLaunchKernelGGL(k_admm_inst, dim3(wgs), dim3(ADMM_INST_THREADS), l, st, ip);
+        ip.minv_stride = packed ? packed_tri_doubles(h->nz) : 0;
+        if (packed) hipLaunchKernelGGL((k_admm_inst<true>), dim3(wgs), dim3(ADMM_INST_THREADS), l, st, ip);
+        else hipLaunchKernelGGL((k_admm_inst<false>), dim3(wgs), dim3(ADMM_INST_THREADS), l, st, ip);
         HIP_TRY(h, hipGetLastError());
         return ALMPC_OK;
     };
@@ -2628,7 +2705,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         HIP_TRY(h, hipMemsetAsync(h->dOverflow, 0, 2 * sizeof(int32_t), st));
         if (!h->dOvfSinv) HIP_TRY(h, dalloc(&h->dOvfSinv, (size_t)h->batch * (32 * 32 + 32)));
         gp.ovf = h->dOverflow; gp.ovf_ws = h->dOverflow + 2 + h->batch; gp.ovf_sinv = h->dOvfSinv;
-        if (lazy_redo) { HIP_TRY(h, ensure_unsolved_word()); gp.unsolved = h->dUnsolved; }
+        if (lazy_redo) { HIP_TRY(h, ensure_unsolved_word()); gp.unsolved = h->dUnsolved; gp.redo_gate = h->dRedoGate; gp.step_serial = h->step_serial; }
         if (h->s0_basis_ok && !h->batched && !h->ltv && h->fS_stride == 0) gp.s0_basis = h->dS0Basis;   // (shared model, shared references)
         const dim3 grid((h->batch + PGEN_WAVES - 1) / PGEN_WAVES), block(64 * PGEN_WAVES);
         // first launch: working sets up to 32 rows, every instance; second launch: the instances the first one flagged, up to 64 rows
@@ -2664,7 +2741,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         pp.dflag = h->flag_in_finish ? h->bFlag : nullptr;
         if (lazy_redo) {
             HIP_TRY(h, ensure_unsolved_word());
-            pp.unsolved = h->dUnsolved;
+            pp.unsolved = h->dUnsolved; pp.redo_gate = h->dRedoGate; pp.step_serial = h->step_serial;
         }
         // rollout fused into the tail of the polish when its trajectory buffer fits the wave's LDS slot
         fused = roll_fits;
@@ -3079,6 +3156,7 @@ int almpc_advance_plant(almpc_handle* h) {
     if (!h->designed) return fail(h, ALMPC_ERR_NOT_DESIGNED, "advance_plant before design");
     if (h->batched) return fail(h, ALMPC_ERR_UNSUPPORTED, "advance_plant: per-instance models have no shared plant (advance the states on the caller's side)");
     HIP_TRY(h, hipSetDevice(h->device));
+    { const int rc_ = enqueue_gated_redo(h); if (rc_ != ALMPC_OK) return rc_; }   // the plant must not be driven by an undecided instance's iterate
     const int per_block = 256 / h->n;
     const double* x0_in = h->dX0;
     const int x0_slot = h->io.x0_slot;

@@ -624,7 +624,9 @@ template <int CW, bool HOIST>
 __global__ __launch_bounds__(64 * (128 / CW)) void k_design_inverse_c32(int nz, int nzs, const double* Hs, double cshift, const double* dshift,
                                                             double* Out, int* flag, long sHs, long sShift, long sOut, long sFlag,
                                                             const double* vM = nullptr, double* vOut = nullptr, long sV = 0, int vcols = 0,
-                                                            int vld = 0) {
+                                                            int vld = 0, int packed_out = 0) {
+    // packed_out: Out is the packed lower triangle of the (symmetric) inverse, column by column (packed_tri_off; sOut = its stride):
+    // what k_admm_inst<true> streams -- half the bytes written here and read there
     __shared__ __attribute__((aligned(16))) double wb[2][128];
     __shared__ double vred[128 / CW][128];   // (vM != null: the waves' partial sums of V = -Out vM)
     __shared__ double ips[2];
@@ -752,7 +754,8 @@ __global__ __launch_bounds__(64 * (128 / CW)) void k_design_inverse_c32(int nz, 
 #pragma unroll
         for (int c = 0; c < CW; ++c) {
             const int i = lane + 64 * a, col = CW * q + c;
-            if (i < nz && col < nz) Out[(size_t)col * nzs + i] = S[a][c];
+            if (packed_out) { if (i < nz && col <= i) Out[packed_tri_off(nz, col) + (i - col)] = S[a][c]; }
+            else if (i < nz && col < nz) Out[(size_t)col * nzs + i] = S[a][c];
         }
     // vM != null: V = -Out vM (nz x vcols, leading dimension vld) from the columns the waves still hold -- wave q sums its CW columns,
     // the partial sums meet in LDS -- instead of a launch of its own that reads the inverse back (k_neg_gm / k_neg_gm_cols)
@@ -791,12 +794,15 @@ __global__ __launch_bounds__(64 * (128 / CW)) void k_design_inverse_c32(int nz, 
 // whether launch_design_inverse makes the ADMM penalty profile itself (rho_G given): the one-wave kernel does, the others need k_design_rho first
 inline bool design_inverse_makes_rho(int nz, int nzs) { return nz <= 64 && nzs <= 64 && !getenv("ALMPC_INV_TILE") && !getenv("ALMPC_NO_RHO_FUSION"); }
 // (the one-wave-per-matrix kernel can also form V = -Out vM from the rows it holds: see there)
+// whether launch_design_inverse can write the packed lower triangle (the column-split kernel, 64 < nz <= 128)
+inline bool design_inverse_can_pack(int nz) { return nz > 64 && nz <= 128 && !getenv("ALMPC_INV_TILE") && !getenv("ALMPC_NO_PACKED_MINV"); }
 inline bool design_inverse_makes_v(int nz) { return nz <= 128 && !getenv("ALMPC_INV_TILE") && !getenv("ALMPC_DBG_SPLIT_NEGGM"); }   // (one-wave and column-split kernels)
 inline void launch_design_inverse(dim3 grid, size_t lds, hipStream_t st, int nz, int nzs, const double* Hs, double cshift, const double* dshift,
                                   double* Out, int* flag, long sHs, long sShift, long sOut, long sFlag,
                                   const double* rho_G = nullptr, long sRhoG = 0, int rho_mode = 0, double rho = 0.0, double* rho_out = nullptr,
                                   const double* vM = nullptr, double* vOut = nullptr, long sV = 0, int vcols = 0,
-                                  double* Out2 = nullptr, long sOut2 = 0, double cshift2 = 0.0, int vld = 0) {
+                                  double* Out2 = nullptr, long sOut2 = 0, double cshift2 = 0.0, int vld = 0, int packed_out = 0) {
+    // (packed_out: only the column-split kernel writes the packed triangle; the caller asks design_inverse_can_pack first)
     if (vld == 0) vld = nzs;
     if (nz <= 64 && !getenv("ALMPC_INV_TILE")) {   // one wave per matrix (grid.y = matrices, as for the tile kernels)
         const int b = (int)grid.y;
@@ -808,7 +814,7 @@ inline void launch_design_inverse(dim3 grid, size_t lds, hipStream_t st, int nz,
     else if (!getenv("ALMPC_INV_TILE")) {
         const char* cwv = getenv("ALMPC_INV_CW");   // (experiment: columns per wave)
         const int cw = cwv ? atoi(cwv) : (grid.y <= 256 ? 16 : 32);   // one matrix per CU: eight waves of 16 columns (51 against 59 us at nz 100)
-#define INV_C32(CW_, H_) hipLaunchKernelGGL((k_design_inverse_c32<CW_, H_>), grid, dim3(64 * (128 / CW_)), 0, st, nz, nzs, Hs, cshift, dshift, Out, flag, sHs, sShift, sOut, sFlag, vM, vOut, sV, vcols, vld)
+#define INV_C32(CW_, H_) hipLaunchKernelGGL((k_design_inverse_c32<CW_, H_>), grid, dim3(64 * (128 / CW_)), 0, st, nz, nzs, Hs, cshift, dshift, Out, flag, sHs, sShift, sOut, sFlag, vM, vOut, sV, vcols, vld, packed_out)
         if (grid.y <= 256) { if (cw == 8) INV_C32(8, true); else if (cw == 16) INV_C32(16, true); else INV_C32(32, true); }
         else { if (cw == 8) INV_C32(8, false); else if (cw == 16) INV_C32(16, false); else INV_C32(32, false); }
 #undef INV_C32

@@ -163,6 +163,9 @@ int almpc_get_results_async(almpc_handle* h, uint32_t want) {
     { const int rc = io_init(h); if (rc != ALMPC_OK) return rc; }
     almpc_handle::Io& io = h->io;
     HIP_TRY(h, hipSetDevice(h->device));
+    // "solution or verdict" on the ticket path too: what the step's finish left undecided is redone on the stream before the results
+    // are packed (gated launches: nothing runs unless the step left something)
+    { const int rc = enqueue_gated_redo(h); if (rc != ALMPC_OK) return rc; }
     const long t = io.next_ticket;
     const int s = (int)(t % almpc_handle::IO_DEPTH);
     const size_t b = (size_t)h->batch, xs = b * h->n * (h->N + 1), us = b * h->nz;

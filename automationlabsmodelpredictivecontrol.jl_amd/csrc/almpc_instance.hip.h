@@ -21,7 +21,9 @@ namespace almpc {
 
 struct AdmmInstParams {
     int nz, n, m, batch, nzs;
-    const double* Minv;   // [batch][nz][nzs]  (H'_i + sigma I + diag(rho_i))^-1, symmetric
+    const double* Minv;   // [batch][nz][nzs]  (H'_i + sigma I + diag(rho_i))^-1, symmetric -- or, for k_admm_inst<true>, its packed
+                          // lower triangle [batch][minv_stride], column by column (packed_tri_off): HALF the bytes of the step's stream
+    long minv_stride = 0; // doubles per instance of the packed form (even)
     const double* Hs;     // [batch][nz][nzs]  H'_i (warm start only)
     const double* Fs;     // [batch][n][nzs]   F'_i = D_i F_i, column-major
     const double* Vs;     // [batch][n][nzs]   V_i = -H'_i^-1 F'_i
@@ -47,6 +49,11 @@ struct AdmmInstParams {
 constexpr int ADMM_INST_THREADS = 256;  // 4 waves, one per SIMD
 constexpr int ADMM_INST_PPW = 16;       // column PAIRS per wave, compile-time bound: nz <= 128 -> 64 pairs over 4 waves
 
+// LDS of k_admm_inst (doubles): [packed triangle (PACKED only)] | 3 x 4 partial vectors | e0 | bounds
+inline size_t admm_inst_lds_doubles(int nz, int nzs, int m, bool packed) {
+    return (packed ? (size_t)packed_tri_doubles(nz) : 0) + 12 * (size_t)nzs + 64 + 2 * (size_t)m;
+}
+
 // Persistent workgroups, TWO per CU: workgroup b solves instances b, b + gridDim.x, ...
 // The KKT inverse of an instance never touches LDS.  Lane l owns the row pair (2l, 2l+1) and wave w the column pairs
 // (2j, 2j+1), j = w, w + 4, ...: the 30 x 16 bytes a thread needs are exactly what coalesced 16-byte-per-lane loads deliver
@@ -56,8 +63,21 @@ constexpr int ADMM_INST_PPW = 16;       // column PAIRS per wave, compile-time b
 // the other iterates.  Every wave carries the whole iterate redundantly (two rows per lane), so the right-hand side
 // entries of column pair j are two v_readlane pairs from lane j; only the 4 partial vectors of a product cross waves
 // (LDS, double buffered: ONE barrier per iteration).
-inline __global__ __launch_bounds__(ADMM_INST_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_admm_inst(AdmmInstParams p) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+//
+// PACKED (round 5): M_i^-1 is symmetric, and streaming it whole reads every off-diagonal element twice.  Here the instance's matrix
+// is its packed lower triangle (58 KB instead of 123 KB for nz = 120).  Lane l needs elements (2l, c) and (2l + 1, c) for its wave's
+// columns c -- for c above the rows that is a strided walk over the triangle, which no coalesced load delivers -- so the triangle
+// lands in LDS first (direct global -> LDS loads, 1 KB per wave instruction, no registers) and every lane gathers its 64 elements
+// from there ONCE per instance-step (ds_read_b64 at (max, min)); the iterations run from registers exactly as before.  The stream of
+// the NEXT instance is requested as soon as the gather is done and lands under this instance's iterations (the LDS-only barriers of
+// the loop do not wait for it); every other global load of an instance is therefore issued BEFORE that request (the memory counter
+// retires in order: a later load could not be waited for without waiting for the 58 KB as well).
+template <bool PACKED>
+__global__ __launch_bounds__(ADMM_INST_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_admm_inst(AdmmInstParams p) {
+    extern __shared__ __attribute__((aligned(16))) double smem_all[];
+    const long tri_doubles = PACKED ? packed_tri_doubles(p.nz) : 0;
+    double* tri = smem_all;                 // [tri_doubles] packed triangle of the instance being set up
+    double* smem = smem_all + tri_doubles;
     const int nz = p.nz, nzs = p.nzs, n = p.n;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, and the compiler knows it: column offsets stay scalar
@@ -76,6 +96,22 @@ inline __global__ __launch_bounds__(ADMM_INST_THREADS) __attribute__((amdgpu_wav
     const int npairs = (nz + 1) / 2;
 
     for (int t = tid; t < p.m; t += ADMM_INST_THREADS) { bnd[t] = p.umin[t]; bnd[p.m + t] = p.umax[t]; }
+    // PACKED: request the triangle of instance i into LDS: wave w takes the 1 KB pieces w, w + 4, ...
+    auto request_tri = [&](const double* minv, long stride, int i) __attribute__((always_inline)) {
+        const char* src = reinterpret_cast<const char*>(minv + (size_t)i * stride);
+        const int bytes = (int)(tri_doubles * 8);
+        // Inline assembly on purpose: the compiler treats a global -> LDS load it knows about as a pending LDS write and makes every
+        // later LDS barrier and LDS read wait for it (vmcnt(0)) -- the stream would not run under the iterations at all.  It does not
+        // look inside the asm; the one wait this stream needs is the explicit s_waitcnt in front of the gather.  M0 carries the LDS
+        // address (the hardware adds 16 bytes per lane); the s_nop is the wait state between a scalar write of M0 and the instruction.
+        const uint32_t tri_lds = (uint32_t)(uintptr_t)tri;
+        for (int off = wv * 1024; off < bytes; off += NW * 1024)
+            if (off + lane * 16 < bytes)
+                asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src + off + lane * 16), "{m0}"(__builtin_amdgcn_readfirstlane(tri_lds + (uint32_t)off)) : "memory");
+    };
+    if constexpr (PACKED) {
+        if ((int)blockIdx.x < p.batch) request_tri(GL(p.Minv), p.minv_stride, blockIdx.x);
+    }
 
     for (int inst = blockIdx.x; inst < p.batch; inst += gridDim.x) {
         // parameters re-read through an opaque kernarg pointer per instance: otherwise every instance-independent load is
@@ -86,7 +122,7 @@ inline __global__ __launch_bounds__(ADMM_INST_THREADS) __attribute__((amdgpu_wav
         ISTAMP(0);
         // ---- one batch of loads: this wave's column pairs of M_i^-1, its columns of F'_i and V_i, the row constants, e0
         d2 mcol[2 * PPW];
-        {
+        if constexpr (!PACKED) {
             const double* Mi = GL(q.Minv) + (size_t)inst * nz * nzs;
 #pragma unroll
             for (int u = 0; u < PPW; ++u) {
@@ -97,7 +133,10 @@ inline __global__ __launch_bounds__(ADMM_INST_THREADS) __attribute__((amdgpu_wav
             }
         }
         d2 cf[PFC], cv[PFC];
-        {
+        const int ra = own0 ? r0 : 0, rb = own1 ? r1 : 0;
+        d2 pdd, prh;
+        double ur0, ur1, fS0, fS1, vS0, vS1;
+        auto issue_small = [&]() __attribute__((always_inline)) {   // this wave's columns of F'_i and V_i, the row constants
             const double* Fi = GL(q.Fs) + (size_t)inst * n * nzs;
             const double* Vi = GL(q.Vs) + (size_t)inst * n * nzs;
 #pragma unroll
@@ -107,15 +146,39 @@ inline __global__ __launch_bounds__(ADMM_INST_THREADS) __attribute__((amdgpu_wav
                 cf[u] = *reinterpret_cast<const d2*>(Fi + (size_t)cc * nzs + rc);
                 cv[u] = *reinterpret_cast<const d2*>(Vi + (size_t)cc * nzs + rc);
             }
+            pdd = *reinterpret_cast<const d2*>(GL(q.dvec) + (size_t)inst * nzs + rc);
+            prh = *reinterpret_cast<const d2*>(GL(q.rhovec) + (size_t)inst * nzs + rc);
+            ur0 = GL(q.uref)[(size_t)inst * q.uref_stride + ra]; ur1 = GL(q.uref)[(size_t)inst * q.uref_stride + rb];
+            fS0 = GL(q.fS)[(size_t)inst * nz + ra]; fS1 = GL(q.fS)[(size_t)inst * nz + rb];
+            vS0 = GL(q.v0S)[(size_t)inst * nz + ra]; vS1 = GL(q.v0S)[(size_t)inst * nz + rb];
+        };
+        issue_small();   // (full layout: with the matrix stream, one batch of loads; PACKED: they land under the wait for the triangle)
+        double e0v = 0.0;
+        if (tid < n) e0v = GL(q.x0)[(size_t)inst * n + tid] - GL(q.xref)[(size_t)inst * q.xref_stride + tid];
+        if constexpr (PACKED) __builtin_amdgcn_s_waitcnt(0);   // this wave's pieces of the instance's triangle have landed in LDS
+        lds_barrier();  // the previous instance is done with the LDS vectors (PACKED: and every wave's pieces are there)
+        if (tid < n) e0s[tid] = e0v;
+        if constexpr (PACKED) {
+            // gather: element (r, c) of the symmetric matrix = packed (max, min); rows beyond nz are the zero padding of the full layout
+            // (the row index is made opaque HERE: otherwise all 64 addresses are formed above the barrier and spilled -- 36 scratch round
+            // trips per instance --; with it they are formed sixteen at a time next to their reads)
+            int r0g = r0;
+            asm volatile("" : "+v"(r0g));
+#pragma unroll
+            for (int u = 0; u < PPW; ++u) {
+                const int j = wv + NW * u;                  // column pair (2j, 2j+1)
+                const int c0 = 2 * j < nz ? 2 * j : 0, c1 = 2 * j + 1 < nz ? 2 * j + 1 : 0;
+                const int ra_ = own0 ? r0g : 0, rb_ = own1 ? r0g + 1 : 0;
+                auto at = [&](int r, int c) __attribute__((always_inline)) -> double {
+                    const int a = r < c ? r : c, b = r < c ? c : r;
+                    return tri[packed_tri_off(nz, a) + (b - a)];
+                };
+                const double e00 = at(ra_, c0), e10 = at(rb_, c0), e01 = at(ra_, c1), e11 = at(rb_, c1);
+                mcol[2 * u][0] = own0 ? e00 : 0.0; mcol[2 * u][1] = own1 ? e10 : 0.0;
+                mcol[2 * u + 1][0] = own0 ? e01 : 0.0; mcol[2 * u + 1][1] = own1 ? e11 : 0.0;
+                if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        const int ra = own0 ? r0 : 0, rb = own1 ? r1 : 0;
-        const d2 pdd = *reinterpret_cast<const d2*>(GL(q.dvec) + (size_t)inst * nzs + rc);
-        const d2 prh = *reinterpret_cast<const d2*>(GL(q.rhovec) + (size_t)inst * nzs + rc);
-        const double ur0 = GL(q.uref)[(size_t)inst * q.uref_stride + ra], ur1 = GL(q.uref)[(size_t)inst * q.uref_stride + rb];
-        const double fS0 = GL(q.fS)[(size_t)inst * nz + ra], fS1 = GL(q.fS)[(size_t)inst * nz + rb];
-        const double vS0 = GL(q.v0S)[(size_t)inst * nz + ra], vS1 = GL(q.v0S)[(size_t)inst * nz + rb];
-        lds_barrier();  // the previous instance is done with the LDS vectors
-        if (tid < n) e0s[tid] = GL(q.x0)[(size_t)inst * n + tid] - GL(q.xref)[(size_t)inst * q.xref_stride + tid];
         double dv[2], lo[2], hi[2], fs[2], v0[2], rho[2];
         {
             const double di0 = 1.0 / (own0 ? pdd[0] : 1.0), di1 = 1.0 / (own1 ? pdd[1] : 1.0);
@@ -127,6 +190,12 @@ inline __global__ __launch_bounds__(ADMM_INST_THREADS) __attribute__((amdgpu_wav
             v0[0] = own0 ? vS0 : 0.0; v0[1] = own1 ? vS1 : 0.0;   // + V e0 below
         }
         lds_barrier();
+        if constexpr (PACKED) {
+            // every wave has gathered and every global load of this instance has been waited for (the s_waitcnt above): the NEXT
+            // instance's triangle may come, and lands under this instance's gradient and iterations.  (A warm start reads more of
+            // this instance from global memory first -- its loads would queue behind the 58 KB -- and requests after that.)
+            if (!q.warm && inst + (int)gridDim.x < q.batch) request_tri(GL(q.Minv), q.minv_stride, inst + (int)gridDim.x);
+        }
         ISTAMP(1);
 
         // ---- f' = F' e0 + fS, v0 = V e0 + v0S: wave w multiplies columns w, w + 4, ...
@@ -198,6 +267,12 @@ inline __global__ __launch_bounds__(ADMM_INST_THREADS) __attribute__((amdgpu_wav
 #pragma unroll
         for (int j = 0; j < 2; ++j) rown[j] = sigma * x[j] - fs[j] + rho[j] * (z[j] - yt[j]);  // pad rows: 0
         lds_barrier();  // the partial buffers are free again
+        if constexpr (PACKED) {   // every load of this instance has been consumed and every wave has gathered: the next triangle may come
+            // (explicit vmcnt(0) first: a register loaded above and first READ below the request would otherwise be waited for with
+            // vmcnt(0) there -- the request is a loop, the compiler cannot count its loads -- i.e. for the whole 58 KB, at once)
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            if (q.warm && inst + (int)gridDim.x < q.batch) request_tri(GL(q.Minv), q.minv_stride, inst + (int)gridDim.x);
+        }
         ISTAMP(3);
         ISTAMP(4);
         bool active = true;

@@ -65,6 +65,12 @@ __device__ long long* g_stamps = nullptr;  // [waves][16]
 #define ALMPC_ACC_FLUSH(WAVE_ID) do { } while (0)
 #endif
 
+// Packed lower triangle of a symmetric nz x nz matrix, column by column: element (i, c), i >= c, at packed_tri_off(nz, c) + i - c.
+// A column is contiguous in i, so the inverse kernels write it coalesced (k_design_inverse_c32, packed_out) and a reader that wants
+// element (r, c) of the full matrix takes (max, min).  packed_tri_doubles: per-instance stride, rounded up to whole 16-byte pairs.
+__host__ __device__ inline int packed_tri_off(int nz, int c) { return c * nz - (c * (c - 1)) / 2; }
+__host__ __device__ inline long packed_tri_doubles(int nz) { return ((long)nz * (nz + 1) / 2 + 1) & ~1L; }
+
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2v __attribute__((ext_vector_type(2)));
 
@@ -488,6 +494,8 @@ struct PolishParams {
     int max_iter;
     const int* dflag = nullptr;   // design flags (or null): an instance whose flag is set leaves with ALMPC_NON_FINITE (re-linearisation pipeline)
     int* unsolved = nullptr;  // host-visible counter (or null): += 1 for every instance that leaves the finish with status != 0 (lazy redo, almpc_api.hip)
+    int* redo_gate = nullptr; // device word (or null): = step_serial when this step leaves an instance with status != 0 -- what a redo launch
+    int step_serial = 0;      // that was enqueued behind the step without a host look tests before it does anything (SdualParams::gate)
     int direct = 0;      // k_step_inst_wave: workgroup (= wave) b finishes instance b itself (no perm lookup)
     int fuse_rollout;    // 1: this kernel also produces u, e_u, x, e_x (roll.*), no separate k_rollout launch; 2: u, e_u only;
                          // 3: as 1 with the blocked rollout (shared model: rollM)
@@ -1471,8 +1479,10 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
     ALMPC_STAMP(inst, 11);
     ALMPC_ACC_FLUSH(inst);
     d2 wout;
-    if (p.unsolved && lane == 0 && ((give_up || fin != 0) ? st_in : 0) != 0)   // (rare: the redo is then launched at the next host sync)
+    if (p.unsolved && lane == 0 && ((give_up || fin != 0) ? st_in : 0) != 0) {   // (rare: the redo is then launched at the next host sync)
         __hip_atomic_fetch_add(p.unsolved, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (p.redo_gate) *GL(p.redo_gate) = p.step_serial;   // (every writer of a step stores the same value)
+    }
     if (give_up) {  // keep the (feasible) ADMM iterate; status stays what ADMM reported
         wout[0] = skip ? z0 : fmin(fmax(z0, lo0), hi0);
         wout[1] = skip ? z1 : fmin(fmax(z1, lo1), hi1);

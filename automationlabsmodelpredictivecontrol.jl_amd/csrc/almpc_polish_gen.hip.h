@@ -74,6 +74,7 @@ struct PolishGenParams {
     double* ovf_sinv = nullptr;  // [batch][32 * 32 + 32] of a flagged instance: the 32 x 32 inverse and the positions' bounds at that moment, so
                                  // that the second launch continues instead of bordering the 32 rows in again (105 k cycles), or null
     int* unsolved = nullptr;   // host-visible count of instances left with ALMPC_MAX_ITER (lazy redo, see almpc_handle::hUnsolved), or null
+    int* redo_gate = nullptr; int step_serial = 0;   // as PolishParams::redo_gate
     int max_iter;
     int roll_g, roll_cpl;
     RolloutParams roll;
@@ -854,7 +855,10 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
         p.status[inst] = st_out;
         const bool requeue = !QUEUE && overflow && fin != 3;   // (the second launch decides about this one)
         if (requeue) p.ovf[2 + atomicAdd(p.ovf, 1)] = inst;
-        if (p.unsolved && st_out == 1 && !requeue) __hip_atomic_fetch_add(p.unsolved, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (p.unsolved && st_out == 1 && !requeue) {
+            __hip_atomic_fetch_add(p.unsolved, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (p.redo_gate) *p.redo_gate = p.step_serial;
+        }
     }
     if (!QUEUE && overflow && fin != 3) {   // (WL = 32 here: both half-waves mirror the positions)
         if (lane < 32) p.ovf_ws[(size_t)inst * 32 + lane] = guess_overflow ? -1 : (wrow | ((wsd + 1) << 12));

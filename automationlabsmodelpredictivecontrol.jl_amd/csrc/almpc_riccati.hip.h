@@ -55,6 +55,7 @@ struct RiccatiParams {
     int max_iter;
     double tol;
     int lds_per_wave;                          // doubles
+    const int* gate = nullptr; int gate_val = 0;   // the launch does nothing unless *gate == gate_val (SdualParams::gate)
 };
 
 __host__ __device__ inline int riccati_lds_doubles(int n, int m, int N) {
@@ -119,6 +120,7 @@ constexpr int RICCATI_CLIP_START = 4;   // see the start of the active-set loop
 template <int NC, int MC>
 __global__ __launch_bounds__(64 * RICCATI_WAVES) void k_riccati_t(RiccatiParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    if (p.gate && __builtin_nontemporal_load(p.gate) != p.gate_val) return;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = NC ? NC : p.n, m = MC ? MC : p.m, N = p.N, nm = n * m, nn = n * n, mm = m * m;
     const int mx = n > m ? n : m;

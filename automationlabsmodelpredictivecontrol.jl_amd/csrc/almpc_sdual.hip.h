@@ -65,6 +65,10 @@ struct SdualParams {
     const double* ghat = nullptr;
     double* ghat_out = nullptr;
     int build_ghat = 0;
+    // gate (or null): the launch does nothing unless *gate == gate_val -- the redo behind a condensed step enqueued WITHOUT knowing
+    // whether that step left anything undecided (its finish stores its step number in the word when it does, see PolishParams::redo_gate)
+    const int* gate = nullptr;
+    int gate_val = 0;
 };
 
 __host__ __device__ inline int sdual_tp(int NT, int MC, int N) { return (N * (NT + MC) + NT + 1) & ~1; }
@@ -162,6 +166,7 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
     constexpr bool BIG = GLB;
     constexpr bool ROWDPP = SP <= 16;    // a stage fits one row of 16 lanes: DPP broadcasts instead of LDS round trips
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    if (p.gate && __builtin_nontemporal_load(p.gate) != p.gate_val) return;   // (uniform: nothing to redo behind that step)
     const int wv = threadIdx.x >> 6, lane0 = threadIdx.x & 63;
     const int n = p.n, m = p.m, N = p.N, wcap = p.wcap, LD = wcap + 1;
     const int TP = sdual_tp(NT, MC, N);
@@ -1028,7 +1033,7 @@ struct SgainsParams {
     const double* P; long P_stride;                // n x n terminal weight
     const double* Q; const double* R; const double* S;   // shared weights; R with the reference's branch rule applied; S null: none
     const double* c; long c_stride;                // [N][n] defects or null
-    int filter; const int32_t* status; const int* flag;   // as k_sdual: 1 status != 0, 2 status != 0 or flag != 0
+    int filter; const int32_t* status; const int* flag;   // exactly k_sdual's codes: 1 status == 1 (no verdict yet), 2 status != 0 or flag != 0
     double* rec; long rec_stride;                  // [N][NT + MC][2 NT + 2 MC] per instance
     double* pc; double* ct; long pc_stride;        // [N][NT] per instance (with c)
     // linear cost terms of an SQP iteration's QP, written to base [batch][TP] (k_sdual's `base`) when base != null:
@@ -1038,6 +1043,7 @@ struct SgainsParams {
     double* base; long base_stride;
     int* bad;                                      // [batch] or null: 1 = R + B'PB not positive definite for some stage
     int lds_per_wave;
+    const int* gate = nullptr; int gate_val = 0;   // as SdualParams::gate
 };
 __host__ __device__ inline int sgains_lds_doubles(int nt, int m) {
     // At, Pn, PA, Pw: 4 nt^2 | Bt, PB: 2 nt m | Gm, K: 2 m nt | Lam, Li, Rt: 3 m^2 | cv: nt
@@ -1047,6 +1053,7 @@ constexpr int SGAINS_WAVES = 4;
 
 inline __global__ __launch_bounds__(64 * SGAINS_WAVES) void k_sgains(SgainsParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    if (p.gate && __builtin_nontemporal_load(p.gate) != p.gate_val) return;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = p.n, nt = p.nt, m = p.m, N = p.N, NT = p.NT, MC = p.MC;
     const int nn = nt * nt, nm = nt * m, mm = m * m, RL = 2 * NT + 2 * MC;

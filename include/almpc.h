@@ -158,11 +158,16 @@ int almpc_set_rho_profile(almpc_handle* h, int mode);
 int almpc_set_step_fusion(almpc_handle* h, int on);
 
 /*
- * Redo of the instances a condensed step leaves without a certificate (status != ALMPC_SOLVED: an active-set finish that ran into
- * its cap or out of room, a non-finite or indefinite condensed problem -- in practice per-instance linearisations that are open-loop
- * unstable, and state-row instances at the edge of feasibility) in the multiple-shooting form, by the stage-wise solvers of
- * ALMPC_FLAG_STRUCTURED (k_sdual, then k_riccati for an input box without S), starting from the step's own result.  Instances that
- * were solved are not touched; an infeasible state-row instance comes back as ALMPC_INFEASIBLE.
+ * Redo of the instances a condensed step leaves without a certificate in the multiple-shooting form, by the stage-wise solvers of
+ * ALMPC_FLAG_STRUCTURED, starting from the step's own result.  Which instances, exactly:
+ *   - status ALMPC_MAX_ITER (1: an active-set finish that ran into its cap or out of room -- in practice per-instance linearisations
+ *     that are open-loop unstable, and state-row instances at the edge of feasibility) go to the dual solver k_sdual (input box,
+ *     state box, terminal equality, S);
+ *   - with an input box only and S = 0 the primal solver k_riccati then takes everything that is still not ALMPC_SOLVED, i.e. also
+ *     status ALMPC_NON_FINITE (2) instances whose condensed problem was flagged indefinite to working precision (a design flag, not
+ *     a non-finite input: the stage-wise form does not form that Hessian).  With state rows or S such an instance keeps status 2.
+ * Instances that were solved are not touched; an instance the finish has already found infeasible keeps its verdict
+ * (ALMPC_INFEASIBLE); an undecided state-row instance that turns out infeasible comes back as ALMPC_INFEASIBLE.
  *   DEFAULT: ON wherever those solvers cover the design (shape limits of ALMPC_FLAG_STRUCTURED), for every design of a condensed
  *   handle: shared (incl. state rows, terminal equality, S), per instance, re-linearisation pipeline, SQP loop (the QP of an iteration
  *   in its stage-wise form for the instances whose condensed Hessian came out indefinite, instead of skipping them).

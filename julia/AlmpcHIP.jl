@@ -689,7 +689,8 @@ group_update_initialization_staged!(g::HipGroup, slots::Vector{Ptr{Float64}}) =
 
 "request the results of the last enqueued step of every device (`want`: mask of ALMPC_WANT_*); returns the group's ticket"
 function group_results_async(g::HipGroup, want::Integer)
-    t = ccall((:almpc_group_get_results_async, libalmpc), Cint, (Ptr{Cvoid}, UInt32), g.group, want)
+    # `group_results_wait!` always reads the status (solution or throw, src/main/computation_mpc.jl:41-53): it is part of every request
+    t = ccall((:almpc_group_get_results_async, libalmpc), Cint, (Ptr{Cvoid}, UInt32), g.group, UInt32(want) | WANT_STATUS)
     t < 0 && gcheck(g.group, t)
     return t
 end
