@@ -754,7 +754,12 @@ __global__ __launch_bounds__(64 * (128 / CW)) void k_design_inverse_c32(int nz, 
 #pragma unroll
         for (int c = 0; c < CW; ++c) {
             const int i = lane + 64 * a, col = CW * q + c;
-            if (packed_out) { if (i < nz && col <= i) Out[packed_tri_off(nz, col) + (i - col)] = S[a][c]; }
+            if (packed_out) {
+                if (i < nz && col <= i) Out[packed_tri_off(nz, col) + (i - col)] = S[a][c];
+                // (nz even: an even column is followed by one pad entry; it keeps a copy of M[col+1][col], which lets the reader
+                // of the diagonal block take its off-diagonal entry from either side -- see k_admm_inst<true>)
+                if (i < nz && i == col + 1 && ((nz - col) & 1) == 0) Out[packed_tri_off(nz, col) + (nz - col)] = S[a][c];
+            }
             else if (i < nz && col < nz) Out[(size_t)col * nzs + i] = S[a][c];
         }
     // vM != null: V = -Out vM (nz x vcols, leading dimension vld) from the columns the waves still hold -- wave q sums its CW columns,
@@ -795,7 +800,7 @@ __global__ __launch_bounds__(64 * (128 / CW)) void k_design_inverse_c32(int nz, 
 inline bool design_inverse_makes_rho(int nz, int nzs) { return nz <= 64 && nzs <= 64 && !getenv("ALMPC_INV_TILE") && !getenv("ALMPC_NO_RHO_FUSION"); }
 // (the one-wave-per-matrix kernel can also form V = -Out vM from the rows it holds: see there)
 // whether launch_design_inverse can write the packed lower triangle (the column-split kernel, 64 < nz <= 128)
-inline bool design_inverse_can_pack(int nz) { return nz > 64 && nz <= 128 && !getenv("ALMPC_INV_TILE") && !getenv("ALMPC_NO_PACKED_MINV"); }
+inline bool design_inverse_can_pack(int nz) { return nz > 64 && nz <= 128 && (nz & 1) == 0 && !getenv("ALMPC_INV_TILE") && !getenv("ALMPC_NO_PACKED_MINV"); }
 inline bool design_inverse_makes_v(int nz) { return nz <= 128 && !getenv("ALMPC_INV_TILE") && !getenv("ALMPC_DBG_SPLIT_NEGGM"); }   // (one-wave and column-split kernels)
 inline void launch_design_inverse(dim3 grid, size_t lds, hipStream_t st, int nz, int nzs, const double* Hs, double cshift, const double* dshift,
                                   double* Out, int* flag, long sHs, long sShift, long sOut, long sFlag,

@@ -51,7 +51,7 @@ constexpr int ADMM_INST_PPW = 16;       // column PAIRS per wave, compile-time b
 
 // LDS of k_admm_inst (doubles): [packed triangle (PACKED only)] | 3 x 4 partial vectors | e0 | bounds
 inline size_t admm_inst_lds_doubles(int nz, int nzs, int m, bool packed) {
-    return (packed ? (size_t)packed_tri_doubles(nz) : 0) + 12 * (size_t)nzs + 64 + 2 * (size_t)m;
+    return (packed ? (size_t)packed_tri_doubles(nz) + 2 : 0) + 12 * (size_t)nzs + 64 + 2 * (size_t)m;
 }
 
 // Persistent workgroups, TWO per CU: workgroup b solves instances b, b + gridDim.x, ...
@@ -76,8 +76,9 @@ template <bool PACKED>
 __global__ __launch_bounds__(ADMM_INST_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_admm_inst(AdmmInstParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem_all[];
     const long tri_doubles = PACKED ? packed_tri_doubles(p.nz) : 0;
-    double* tri = smem_all;                 // [tri_doubles] packed triangle of the instance being set up
-    double* smem = smem_all + tri_doubles;
+    double* tri = smem_all;                 // [tri_doubles | 0 0] packed triangle of the instance being set up, two zeros behind it
+    double* smem = smem_all + tri_doubles + (PACKED ? 2 : 0);
+    if (PACKED && threadIdx.x == 0) { tri[tri_doubles] = 0.0; tri[tri_doubles + 1] = 0.0; }   // (visible after the first barrier)
     const int nz = p.nz, nzs = p.nzs, n = p.n;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, and the compiler knows it: column offsets stay scalar
@@ -132,13 +133,12 @@ __global__ __launch_bounds__(ADMM_INST_THREADS) __attribute__((amdgpu_waves_per_
                 mcol[2 * u + 1] = *reinterpret_cast<const d2*>(Mi + (size_t)c1 * nzs + rc);
             }
         }
-        d2 cf[PFC], cv[PFC];
         const int ra = own0 ? r0 : 0, rb = own1 ? r1 : 0;
-        d2 pdd, prh;
-        double ur0, ur1, fS0, fS1, vS0, vS1;
-        auto issue_small = [&]() __attribute__((always_inline)) {   // this wave's columns of F'_i and V_i, the row constants
-            const double* Fi = GL(q.Fs) + (size_t)inst * n * nzs;
-            const double* Vi = GL(q.Vs) + (size_t)inst * n * nzs;
+        d2 cf[PFC], cv[PFC], pdd, prh;
+        double ur0, ur1, fS0, fS1, vS0, vS1, e0v;
+        auto issue_small = [&](int ii) __attribute__((always_inline)) {   // this wave's columns of F'_i and V_i, the row constants, e0
+            const double* Fi = GL(q.Fs) + (size_t)ii * n * nzs;
+            const double* Vi = GL(q.Vs) + (size_t)ii * n * nzs;
 #pragma unroll
             for (int u = 0; u < PFC; ++u) {
                 const int c = wv + NW * u;
@@ -146,36 +146,44 @@ __global__ __launch_bounds__(ADMM_INST_THREADS) __attribute__((amdgpu_waves_per_
                 cf[u] = *reinterpret_cast<const d2*>(Fi + (size_t)cc * nzs + rc);
                 cv[u] = *reinterpret_cast<const d2*>(Vi + (size_t)cc * nzs + rc);
             }
-            pdd = *reinterpret_cast<const d2*>(GL(q.dvec) + (size_t)inst * nzs + rc);
-            prh = *reinterpret_cast<const d2*>(GL(q.rhovec) + (size_t)inst * nzs + rc);
-            ur0 = GL(q.uref)[(size_t)inst * q.uref_stride + ra]; ur1 = GL(q.uref)[(size_t)inst * q.uref_stride + rb];
-            fS0 = GL(q.fS)[(size_t)inst * nz + ra]; fS1 = GL(q.fS)[(size_t)inst * nz + rb];
-            vS0 = GL(q.v0S)[(size_t)inst * nz + ra]; vS1 = GL(q.v0S)[(size_t)inst * nz + rb];
+            pdd = *reinterpret_cast<const d2*>(GL(q.dvec) + (size_t)ii * nzs + rc);
+            prh = *reinterpret_cast<const d2*>(GL(q.rhovec) + (size_t)ii * nzs + rc);
+            ur0 = GL(q.uref)[(size_t)ii * q.uref_stride + ra]; ur1 = GL(q.uref)[(size_t)ii * q.uref_stride + rb];
+            fS0 = GL(q.fS)[(size_t)ii * nz + ra]; fS1 = GL(q.fS)[(size_t)ii * nz + rb];
+            vS0 = GL(q.v0S)[(size_t)ii * nz + ra]; vS1 = GL(q.v0S)[(size_t)ii * nz + rb];
+            e0v = 0.0;
+            if (tid < n) e0v = GL(q.x0)[(size_t)ii * n + tid] - GL(q.xref)[(size_t)ii * q.xref_stride + tid];
         };
-        issue_small();   // (full layout: with the matrix stream, one batch of loads; PACKED: they land under the wait for the triangle)
-        double e0v = 0.0;
-        if (tid < n) e0v = GL(q.x0)[(size_t)inst * n + tid] - GL(q.xref)[(size_t)inst * q.xref_stride + tid];
+        // (measured and dropped: requesting these for the NEXT instance right behind the iterations -- live across that instance's
+        // gather they are spilled, 52 registers)
+        issue_small(inst);   // (full layout: with the matrix stream, one batch of loads; PACKED: they land under the wait for the triangle)
         if constexpr (PACKED) __builtin_amdgcn_s_waitcnt(0);   // this wave's pieces of the instance's triangle have landed in LDS
         lds_barrier();  // the previous instance is done with the LDS vectors (PACKED: and every wave's pieces are there)
         if (tid < n) e0s[tid] = e0v;
         if constexpr (PACKED) {
-            // gather: element (r, c) of the symmetric matrix = packed (max, min); rows beyond nz are the zero padding of the full layout
-            // (the row index is made opaque HERE: otherwise all 64 addresses are formed above the barrier and spilled -- 36 scratch round
-            // trips per instance --; with it they are formed sixteen at a time next to their reads)
-            int r0g = r0;
-            asm volatile("" : "+v"(r0g));
+            // gather: the 2 x 2 block (rows 2l, 2l+1) x (columns 2j, 2j+1) of the symmetric matrix is the STORED block (b, a) =
+            // (max(l, j), min(l, j)), two aligned 16-byte LDS reads (nz is even here; see packed_tri_off):
+            //   A = column 2a at row 2b     -> (M[2b][2a],   M[2b+1][2a])
+            //   B = column 2a+1 at row 2b-1 -> (M[2b][2a+1], M[2b+1][2a+1])      (b == a: the first entry is the pad behind column 2a,
+            //                                                                      where the inverse kernel keeps a copy of M[2a+1][2a])
+            // and, by symmetry, e00 = A0, e11 = B1, (e10, e01) = (A1, B0) on and below the diagonal, (B0, A1) above it: min / max
+            // address arithmetic and ONE select mask per block.  Rows / columns beyond nz read the two zeros behind the triangle.
+            // (The lane index is made opaque HERE: otherwise every address is formed above the barrier and spilled.)
+            int lg = lane;
+            asm volatile("" : "+v"(lg));
+            const int zi = (int)tri_doubles;
 #pragma unroll
             for (int u = 0; u < PPW; ++u) {
                 const int j = wv + NW * u;                  // column pair (2j, 2j+1)
-                const int c0 = 2 * j < nz ? 2 * j : 0, c1 = 2 * j + 1 < nz ? 2 * j + 1 : 0;
-                const int ra_ = own0 ? r0g : 0, rb_ = own1 ? r0g + 1 : 0;
-                auto at = [&](int r, int c) __attribute__((always_inline)) -> double {
-                    const int a = r < c ? r : c, b = r < c ? c : r;
-                    return tri[packed_tri_off(nz, a) + (b - a)];
-                };
-                const double e00 = at(ra_, c0), e10 = at(rb_, c0), e01 = at(ra_, c1), e11 = at(rb_, c1);
-                mcol[2 * u][0] = own0 ? e00 : 0.0; mcol[2 * u][1] = own1 ? e10 : 0.0;
-                mcol[2 * u + 1][0] = own0 ? e01 : 0.0; mcol[2 * u + 1][1] = own1 ? e11 : 0.0;
+                const bool valid = own0 && 2 * j < nz;
+                const int a = lg < j ? lg : j, b = lg < j ? j : lg;
+                const int ia = valid ? packed_tri_off(nz, 2 * a) + 2 * (b - a) : zi;
+                const int ib = valid ? packed_tri_off(nz, 2 * a + 1) + 2 * (b - a) - 1 : zi;
+                const d2 A = *reinterpret_cast<const d2*>(tri + ia);
+                const d2 B = *reinterpret_cast<const d2*>(tri + ib);
+                const bool above = lg < j;
+                mcol[2 * u][0] = A[0]; mcol[2 * u][1] = above ? B[0] : A[1];
+                mcol[2 * u + 1][0] = above ? A[1] : B[0]; mcol[2 * u + 1][1] = B[1];
                 if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
         }

@@ -68,8 +68,19 @@ __device__ long long* g_stamps = nullptr;  // [waves][16]
 // Packed lower triangle of a symmetric nz x nz matrix, column by column: element (i, c), i >= c, at packed_tri_off(nz, c) + i - c.
 // A column is contiguous in i, so the inverse kernels write it coalesced (k_design_inverse_c32, packed_out) and a reader that wants
 // element (r, c) of the full matrix takes (max, min).  packed_tri_doubles: per-instance stride, rounded up to whole 16-byte pairs.
-__host__ __device__ inline int packed_tri_off(int nz, int c) { return c * nz - (c * (c - 1)) / 2; }
-__host__ __device__ inline long packed_tri_doubles(int nz) { return ((long)nz * (nz + 1) / 2 + 1) & ~1L; }
+// Columns are padded so that packed_tri_off(c) - c is even: element (r, c) with r even then sits on a 16-byte boundary, and so does
+// (c, r') read as column c's entries r', r' + 1 for even r' -- every 2 x 2 block a lane of k_admm_inst<true> gathers is two
+// aligned 16-byte LDS reads, whichever side of the diagonal it lies on.
+__host__ __device__ inline int packed_tri_off(int nz, int c) {
+    // column c holds nz - c entries; an odd-numbered column of an even-sized matrix (and vice versa) is followed by one pad double
+    // exactly when that keeps off(c + 1) - (c + 1) even.  Closed form: off(c) = sum_{k<c} (nz - k + pad_k), pad_k = (nz - k + 1) & 1
+    // with off(0) = 0 (even): off(k+1) - (k+1) = off(k) - k + (nz - k + pad_k) - 1 stays even iff nz - k + pad_k is odd.
+    const int full = c * nz - (c * (c - 1)) / 2;
+    // pad_k = 1 when (nz - k) is even: k in [0, c) with k == nz (mod 2)
+    const int pads = (nz & 1) ? (c / 2) : ((c + 1) / 2);
+    return full + pads;
+}
+__host__ __device__ inline long packed_tri_doubles(int nz) { return ((long)packed_tri_off(nz, nz) + 1) & ~1L; }
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2v __attribute__((ext_vector_type(2)));
