@@ -191,6 +191,11 @@ struct almpc_handle {
         double* sinv_glb = nullptr; size_t sinv_cap = 0;   // third tier: Sinv of 128 x 129 per wave of its grid
         double* ghat = nullptr; size_t ghat_cap = 0; bool ghat_ready = false, ghat_building = false, ghat_wanted = false;   // shared model: cached sweep responses [TP][TP] (k_sdual: SdualParams::ghat)
         std::vector<double> S;               // symmetrised S (base terms of time-varying input references)
+        // reachability screen of the state box (k_state_box_screen): tables of the shared model and references, verdicts per instance
+        double *scr_phi = nullptr, *scr_g = nullptr, *scr_rm = nullptr, *scr_rp = nullptr;
+        int32_t* scr_verdict = nullptr;
+        size_t scr_cap = 0;                  // N the table buffers were sized for
+        bool scr_ready = false;              // tables match the current model / references
     } sd;
     // multi-GPU (almpc_comm_*): this handle's rank in an RCCL communicator of one process per GPU
     ncclComm_t comm = nullptr;
@@ -314,7 +319,8 @@ void free_all(almpc_handle* h) {
         if (e) (void)hipEventDestroy(e);
     if (h->comm && rccl_api().ok) (void)rccl_api().CommDestroy(h->comm);
     for (void* p : {(void*)h->dComm4, (void*)h->dU0, (void*)h->dU0all, (void*)h->rQ, (void*)h->rR, (void*)h->rP, (void*)h->rKst, (void*)h->rPst, (void*)h->rGuess,
-                    (void*)h->sd.rec, (void*)h->sd.base, (void*)h->sd.xmin, (void*)h->sd.xmax, (void*)h->sd.eqt, (void*)h->sd.ovf, (void*)h->sd.wsave, (void*)h->sd.sinv_glb, (void*)h->sd.ghat, (void*)h->sd.dQ, (void*)h->sd.dR, (void*)h->sd.dS, (void*)h->sd.dP, (void*)h->sd.bad, (void*)h->sd.pc, (void*)h->sd.ct})
+                    (void*)h->sd.rec, (void*)h->sd.base, (void*)h->sd.xmin, (void*)h->sd.xmax, (void*)h->sd.eqt, (void*)h->sd.ovf, (void*)h->sd.wsave, (void*)h->sd.sinv_glb, (void*)h->sd.ghat, (void*)h->sd.dQ, (void*)h->sd.dR, (void*)h->sd.dS, (void*)h->sd.dP, (void*)h->sd.bad, (void*)h->sd.pc, (void*)h->sd.ct,
+                    (void*)h->sd.scr_phi, (void*)h->sd.scr_g, (void*)h->sd.scr_rm, (void*)h->sd.scr_rp, (void*)h->sd.scr_verdict})
         if (p) (void)hipFree(p);
     if (h->ev_guess) (void)hipEventDestroy(h->ev_guess);
     if (h->ev_guess_done) (void)hipEventDestroy(h->ev_guess_done);
@@ -545,6 +551,7 @@ int sdual_setup_shared(almpc_handle* h, const hm::mat& Am, const hm::mat& Bm, co
     sd.S = Sm ? *Sm : hm::mat();
     sd.has_base = false; sd.base_stride = 0;
     sd.per_instance = false; sd.gain_N = 0; sd.sqp = false;
+    sd.scr_ready = false;
     sd.ready = true;
     // cached responses (sdual_build_ghat): at design time for a structured handle, whose every step uses them; on a condensed handle,
     // where k_sdual is only the redo of what a step leaves undecided, at the first redo -- most such handles (the headline path) never
@@ -588,6 +595,7 @@ hipError_t sdual_build_ghat(almpc_handle* h) {
 int sdual_update_base(almpc_handle* h, const double* uref, size_t cnt) {
     almpc_handle::Sd& sd = h->sd;
     sd.has_base = false; sd.base_stride = 0;
+    sd.scr_ready = false;   // (the screen's interval table depends on the input reference)
     if (!sd.ready || !sd.useS) return ALMPC_OK;
     const int n = h->n, m = h->m, N = h->N, SP = sd.NT + sd.MC;
     const size_t TP = (size_t)sdual_tp(sd.NT, sd.MC, N), us = (size_t)h->nz;
@@ -824,6 +832,38 @@ hipError_t launch_sdual(almpc_handle* h, int filter, const double* guess, int ma
         single_launch = false; first_tier = 0;
     }
     sp.rows_state = (sd.has_box || sd.has_eq) ? 1 : 0;
+    // state box of a shared model with shared references, every instance solved from scratch: the reachability screen first (one
+    // table kernel per design / reference change, one small launch per solve) -- instances it certifies infeasible never reach a sweep
+    if (sd.has_box && !sd.ghat_building && !sd.per_instance && !sd.sqp && filter == 0 && first_tier == 0 && sp.x0 && h->uref_stride == 0 &&
+        h->xref_stride == 0 && h->dA && h->dB && !getenv("ALMPC_SDUAL_NO_SCREEN")) {
+        almpc_handle::Sd& sdw = h->sd;
+        const size_t n_ = (size_t)h->n, m_ = (size_t)h->m, N_ = (size_t)h->N;
+        hipError_t e;
+        if (sdw.scr_cap < N_) {
+            for (double** q : {&sdw.scr_phi, &sdw.scr_g, &sdw.scr_rm, &sdw.scr_rp}) if (*q) { (void)hipFree(*q); *q = nullptr; }
+            if ((e = dalloc(&sdw.scr_phi, N_ * n_ * n_)) != hipSuccess || (e = dalloc(&sdw.scr_g, N_ * n_ * m_)) != hipSuccess ||
+                (e = dalloc(&sdw.scr_rm, N_ * n_)) != hipSuccess || (e = dalloc(&sdw.scr_rp, N_ * n_)) != hipSuccess) return e;
+            sdw.scr_cap = N_; sdw.scr_ready = false;
+        }
+        if (!sdw.scr_verdict && (e = dalloc(&sdw.scr_verdict, (size_t)h->batch)) != hipSuccess) return e;
+        ScreenParams cp;
+        cp.n = h->n; cp.m = h->m; cp.N = h->N; cp.batch = h->batch;
+        cp.A = h->dA; cp.B = h->dB; cp.umin = h->dUmin; cp.umax = h->dUmax; cp.uref = h->dUref;
+        cp.xmin = sd.xmin; cp.xmax = sd.xmax; cp.xref = h->dXref; cp.x0 = sp.x0; cp.x0_stride = sp.x0_stride;
+        cp.phi = sdw.scr_phi; cp.gtab = sdw.scr_g; cp.rm = sdw.scr_rm; cp.rp = sdw.scr_rp; cp.verdict = sdw.scr_verdict;
+        if (!sdw.scr_ready) {
+            hipLaunchKernelGGL(k_screen_tables, dim3(1), dim3(256), 0, h->stream, cp);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            sdw.scr_ready = true;
+        }
+        if ((e = hipMemsetAsync(sdw.scr_verdict, 0, (size_t)h->batch * sizeof(int32_t), h->stream)) != hipSuccess) return e;
+        const dim3 sg((unsigned)((h->batch + 63) / 64), (unsigned)h->N);
+#define SCR_CASE(NT_) if (h->n <= NT_) hipLaunchKernelGGL((k_state_box_screen<NT_>), sg, dim3(64), 0, h->stream, cp)
+        SCR_CASE(4); else SCR_CASE(8); else SCR_CASE(12); else SCR_CASE(16); else SCR_CASE(32); else SCR_CASE(48); else return hipErrorInvalidValue;
+#undef SCR_CASE
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        sp.screen = sdw.scr_verdict;
+    }
     const int rows = h->N * h->m + ((sd.has_box || sd.has_eq) ? h->N * h->n : 0);
     sp.max_iter = max_iter > 0 ? max_iter : 20 * rows + 50;
     sp.tol = 1e-9;

@@ -69,6 +69,9 @@ struct SdualParams {
     // whether that step left anything undecided (its finish stores its step number in the word when it does, see PolishParams::redo_gate)
     const int* gate = nullptr;
     int gate_val = 0;
+    // screen (or null): [batch] verdicts of k_state_box_screen -- 1: the state box cannot be met whatever the inputs (a reachability
+    // certificate); the instance leaves with ALMPC_INFEASIBLE before any sweep
+    const int32_t* screen = nullptr;
 };
 
 __host__ __device__ inline int sdual_tp(int NT, int MC, int N) { return (N * (NT + MC) + NT + 1) & ~1; }
@@ -241,6 +244,22 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
         // instead of being hoisted out of this loop into registers that stay live across the whole solve)
         int lane = lane0;
         asm volatile("" : "+v"(lane));
+        if (p.screen && !p.only_ovf && p.screen[inst] != 0) {   // certified infeasible by the reachability screen: no trajectory to hand out
+            for (int t = lane; t < N * m; t += 64) {
+                const double ur = p.uref[(size_t)inst * p.uref_stride + t];
+                if (!p.v_only) p.u[(size_t)inst * N * m + t] = ur;
+                p.eu[(size_t)inst * N * m + t] = 0.0;
+            }
+            if (!p.v_only)
+                for (int t = lane; t < (N + 1) * n; t += 64) {
+                    const double xr = p.xref ? p.xref[(size_t)inst * p.xref_stride + t] : 0.0;
+                    const double xa = (t < n && p.x0) ? p.x0[(size_t)inst * p.x0_stride + t] : xr;
+                    p.x[(size_t)inst * (N + 1) * n + t] = xa;
+                    p.ex[(size_t)inst * (N + 1) * n + t] = xa - xr;
+                }
+            if (lane == 0) { p.status[inst] = 3; p.piters[inst] = 0; if (p.ovf) p.ovf[inst] = 0; }
+            continue;
+        }
         if (p.only_ovf) {
             if (p.ovf[inst] == 0) continue;
         } else if ((p.filter == 1 && p.status[inst] != 1) || (p.filter == 2 && p.status[inst] == 0 && p.flag[inst] == 0)) {
@@ -1021,6 +1040,97 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
     }
 }
 
+
+// ---- infeasibility pre-screen of the state box (round 5) ---------------------------------------------------------------------------
+// The reference constrains the state on every stage (..linear.jl:62-70).  A dual active-set method proves infeasibility only by
+// walking into a dependent violated row -- about 70 rows and all three capacity tiers for the benchmark's instances whose x0 sits
+// 1 % inside a bound the dynamics push it over.  Most of those are infeasible for a reason that needs no solve: coordinate i of the
+// state at stage k,  x_k,i = xref_k,i + (A^k e0)_i + sum_{j<k} (A^(k-1-j) B (u_j - uref_j))_i,  ranges over an INTERVAL as the inputs range
+// over their box (no other constraint considered: a superset of what is reachable), and when that interval misses [xmin_i, xmax_i] no
+// admissible input sequence exists.  Sound by construction (a necessary condition of feasibility; the tests hold every verdict against
+// the phase-1 linear programme, oracle: feasibility_slack); not complete: what passes goes through the method as before.
+//   k_screen_tables   one workgroup, once per design / reference change: Phi_k = A^k [N][n][n], G_d = A^d B (scratch), and the interval
+//                     ends Rm_k,i / Rp_k,i = sum_{j<k} sum_a min / max(G_(k-1-j)[i,a] (umin_a - uref_j,a), G[i,a] (umax_a - uref_j,a)).
+//   k_state_box_screen  thread = (instance, stage): n dot products with the rows of Phi_k (wave-uniform operands), two compares per row.
+// Shared model and shared references only (the tables are per model and reference).
+struct ScreenParams {
+    int n, m, N, batch;
+    const double* A; const double* B;              // shared model, column-major
+    const double* umin; const double* umax;        // [m]
+    const double* uref;                            // [N][m] shared
+    const double* xmin; const double* xmax;        // [n]
+    const double* xref;                            // [N+1][n] shared
+    const double* x0; long x0_stride;
+    double* phi;                                   // [N][n][n]  Phi_k = A^k, k = 1..N (row-major: phi[(k-1) n n + i n + j])
+    double* gtab;                                  // [N][n][m]  G_d = A^d B (scratch of the table kernel)
+    double* rm; double* rp;                        // [N][n]
+    int32_t* verdict;                              // [batch], zeroed by the caller
+};
+
+inline __global__ __launch_bounds__(256) void k_screen_tables(ScreenParams p) {
+    const int n = p.n, m = p.m, N = p.N, tid = threadIdx.x;
+    // Phi_1 = A, G_0 = B; then Phi_k = A Phi_(k-1), G_d = A G_(d-1): N - 1 dependent steps of one workgroup (design time)
+    for (int t = tid; t < n * n; t += 256) p.phi[(t / n) * n + t % n] = p.A[(size_t)(t % n) * n + t / n];
+    for (int t = tid; t < n * m; t += 256) p.gtab[(t / m) * m + t % m] = p.B[(size_t)(t % m) * n + t / m];
+    __syncthreads();
+    for (int k = 1; k < N; ++k) {
+        const double* ph = p.phi + (size_t)(k - 1) * n * n;
+        const double* gp = p.gtab + (size_t)(k - 1) * n * m;
+        for (int t = tid; t < n * n; t += 256) {
+            const int i = t / n, j = t % n;
+            double a = 0.0;
+            for (int l = 0; l < n; ++l) a += p.A[(size_t)l * n + i] * ph[l * n + j];
+            p.phi[(size_t)k * n * n + t] = a;
+        }
+        for (int t = tid; t < n * m; t += 256) {
+            const int i = t / m, a_ = t % m;
+            double a = 0.0;
+            for (int l = 0; l < n; ++l) a += p.A[(size_t)l * n + i] * gp[l * m + a_];
+            p.gtab[(size_t)k * n * m + t] = a;
+        }
+        __syncthreads();   // (global memory written and read by the same workgroup: the barrier's fence covers it)
+    }
+    for (int t = tid; t < N * n; t += 256) {
+        const int k = t / n + 1, i = t % n;   // state stage k = 1..N
+        double lo = 0.0, hi = 0.0;
+        for (int j = 0; j < k; ++j) {
+            const double* g = p.gtab + (size_t)(k - 1 - j) * n * m + (size_t)i * m;
+            for (int a_ = 0; a_ < m; ++a_) {
+                const double ur = p.uref[(size_t)j * m + a_];
+                const double c0 = g[a_] * (p.umin[a_] - ur), c1 = g[a_] * (p.umax[a_] - ur);
+                lo += fmin(c0, c1); hi += fmax(c0, c1);
+            }
+        }
+        p.rm[t] = lo; p.rp[t] = hi;
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(64) void k_state_box_screen(ScreenParams p) {
+    const int n = p.n, inst = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y + 1;   // state stage k = 1..N
+    if (inst >= p.batch) return;
+    double acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = 0.0;
+    const double* ph = p.phi + (size_t)(k - 1) * n * n;
+    for (int j = 0; j < n; ++j) {
+        const double ej = p.x0[(size_t)inst * p.x0_stride + j] - p.xref[j];
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+            if (i < n) acc[i] = __builtin_fma(ph[i * n + j], ej, acc[i]);   // (ph[...]: the same address in every lane)
+    }
+    bool out = false;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+        if (i < n) {
+            const double xf = acc[i] + p.xref[(size_t)k * n + i];
+            const double lo = xf + p.rm[(size_t)(k - 1) * n + i], hi = xf + p.rp[(size_t)(k - 1) * n + i];
+            const double w = p.xmax[i] - p.xmin[i];
+            const double tol = 1e-7 * (w > 0.0 && w < 1e299 ? w : 1.0);   // only the clearly unreachable: the method decides the rest
+            if (lo > p.xmax[i] + tol || hi < p.xmin[i] - tol) out = true;
+        }
+    if (out) p.verdict[inst] = 1;   // (every writer stores the same value)
+}
 
 // ---- stage records of models PER INSTANCE (and per stage: the QP of an SQP iteration): the backward Riccati recursion of the
 // unconstrained problem, once per instance and solve -- the device counterpart of hm::stage_records (csrc/almpc_host_math.h; oracle:
