@@ -188,6 +188,7 @@ struct almpc_handle {
         double *pc = nullptr, *ct = nullptr;   // [batch][N][NT] P_{k+1} c_k, c_k
         int32_t* ovf = nullptr;
         int32_t* wsave = nullptr;   // [batch][SDUAL_WSAVE] working set of an instance that ran out of room (start of the next tier)
+        double* sinv_save = nullptr;   // [batch][sdual_sinv_doubles(SDUAL_SINV_SAVE)] its inverse (allocated at the first multi-tier solve)
         double* sinv_glb = nullptr; size_t sinv_cap = 0;   // third tier: Sinv of 128 x 129 per wave of its grid
         double* ghat = nullptr; size_t ghat_cap = 0; bool ghat_ready = false, ghat_building = false, ghat_wanted = false;   // shared model: cached sweep responses [TP][TP] (k_sdual: SdualParams::ghat)
         std::vector<double> S;               // symmetrised S (base terms of time-varying input references)
@@ -320,7 +321,7 @@ void free_all(almpc_handle* h) {
     if (h->comm && rccl_api().ok) (void)rccl_api().CommDestroy(h->comm);
     for (void* p : {(void*)h->dComm4, (void*)h->dU0, (void*)h->dU0all, (void*)h->rQ, (void*)h->rR, (void*)h->rP, (void*)h->rKst, (void*)h->rPst, (void*)h->rGuess,
                     (void*)h->sd.rec, (void*)h->sd.base, (void*)h->sd.xmin, (void*)h->sd.xmax, (void*)h->sd.eqt, (void*)h->sd.ovf, (void*)h->sd.wsave, (void*)h->sd.sinv_glb, (void*)h->sd.ghat, (void*)h->sd.dQ, (void*)h->sd.dR, (void*)h->sd.dS, (void*)h->sd.dP, (void*)h->sd.bad, (void*)h->sd.pc, (void*)h->sd.ct,
-                    (void*)h->sd.scr_phi, (void*)h->sd.scr_g, (void*)h->sd.scr_rm, (void*)h->sd.scr_rp, (void*)h->sd.scr_verdict})
+                    (void*)h->sd.sinv_save, (void*)h->sd.scr_phi, (void*)h->sd.scr_g, (void*)h->sd.scr_rm, (void*)h->sd.scr_rp, (void*)h->sd.scr_verdict})
         if (p) (void)hipFree(p);
     if (h->ev_guess) (void)hipEventDestroy(h->ev_guess);
     if (h->ev_guess_done) (void)hipEventDestroy(h->ev_guess_done);
@@ -726,6 +727,13 @@ hipError_t launch_sdual_t(almpc_handle* h, SdualParams sp, int tier0, int tier1)
     // SD_WCAP2 rows; tier 2: SD_WCAP4 rows, two working-set positions per lane (mostly infeasible instances whose verdict needs that
     // many rows); tier 3: the same with Sinv in a global scratch, for shapes whose trajectories leave no room for it in LDS.
     // (tier0 = tier1 = 1: ONE launch with room for SD_WCAP2 rows -- the redo of the few instances a condensed step left unsolved)
+    if (tier1 > tier0 && sp.wsave && !sp.build_ghat && !getenv("ALMPC_SDUAL_NO_SINV_HANDOVER")) {   // tiers hand each other the inverse of their working set
+        if (!h->sd.sinv_save) {
+            const hipError_t e_ = dalloc(&h->sd.sinv_save, (size_t)h->batch * sdual_sinv_doubles(SDUAL_SINV_SAVE));
+            if (e_ != hipSuccess) return e_;
+        }
+        sp.sinv_save = h->sd.sinv_save;
+    }
     for (int tier = tier0; tier <= tier1; ++tier) {
         sp.wcap = tier == 0 ? SD_WCAP1 : (tier == 1 ? SD_WCAP2 : SD_WCAP4);
         sp.only_ovf = tier > tier0;

@@ -50,6 +50,9 @@ struct SdualParams {
     int32_t* ovf;                                      // [batch] or null: 1 + rows = the working set outgrew wcap (the caller redoes it with more room)
     const int* gbad;                                   // [batch] or null: 1 = the instance's stage records are not usable (k_sgains: R + B'PB not positive definite): left alone
     int32_t* wsave;                                    // [batch][SDUAL_WSAVE] or null: that working set (row << 2 | side code), the start of the next tier
+    double* sinv_save;                                 // [batch][sdual_sinv_doubles(SDUAL_SINV_SAVE)] or null: (G_WW)^-1 of that working set (packed lower
+                                                       // triangle) when it has at most SDUAL_SINV_SAVE rows: the next tier starts from it
+                                                       // instead of bordering the rows in again one response each (round 5)
     int only_ovf;                                      // 1: only instances with ovf != 0 (second tier)
     int rows_state;                                    // 1: the problem has state rows (an "infeasible" verdict is meaningful)
     int max_iter;
@@ -123,6 +126,7 @@ __device__ __forceinline__ void sd_argmin(double& v, int& idx) {
 
 constexpr int SDUAL_WAVES = 4;
 constexpr int SDUAL_WSAVE = 128;   // rows of a start list (saved working set of a tier / guess)
+constexpr int SDUAL_SINV_SAVE = 64;   // largest working set whose inverse is handed to the next tier (the capacities of the first two)
 
 // acc += coef * (src of lane J of this lane's row of 16): one VOP2 DPP instruction, no LDS and no scalar register on the way
 // (v_fmac_f64 takes the row_newbcast control on gfx90a and later).  FIRST: two wait states between the VALU write of src and its
@@ -664,14 +668,51 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
         //   M_RESP   response of the most violated row p: c = Ghat[W, p], Ghat_pp
         //   M_DIR    direction Ghat (e_p - sum_w r_w e_w) in row space: ratio test, step, drop of a blocking row or addition of p
         //   M_TOP    (no sweep) pick the most violated row or go and confirm
-        enum { M_FULL, M_START, M_RESP, M_DIR, M_TOP, M_BUILD };   // M_BUILD: design time, the columns of ghat (SdualParams::build_ghat)
+        enum { M_FULL, M_START, M_RESP, M_DIR, M_TOP, M_BUILD, M_STARTED };   // M_BUILD: design time, the columns of ghat (SdualParams::build_ghat)
         enum { A_INIT, A_TOP, A_CONFIRM };
         int mode = p.build_ghat ? M_BUILD : M_FULL, after = A_INIT;
         int bt = inst - p.batch;   // (build mode: this wave's coordinates are inst, inst + batch, ...)
         int ns = 0, si = 0, st_kend = N, refined = 0;
         int pr = 0, sd = 0;
         double bp = 0.0, lam_p = 0.0, gpp = 0.0;
+        // end of a start (the rows of the start list are in the working set, with their inverse): multipliers from s0, rows whose
+        // multiplier has the wrong sign leave, then the full solve.  Reached from the last M_START pass, or directly when a smaller tier
+        // handed over its working set WITH its inverse (M_STARTED: no sweep).
+        auto settle_start = [&]() {
+                // multipliers of the start from s0; rows whose multiplier has the wrong sign leave, worst first
+                while (nW > 0) {
+                    double dv[PPL], lw[PPL];
+#pragma unroll
+                    for (int sl = 0; sl < PPL; ++sl) dv[sl] = (sl * 64 + lane < nW) ? s[Wrow[sl]] - bound_of_row(Wrow[sl], Wside[sl]) : 0.0;
+                    publish(dv);
+                    sinv_mul(cbuf, lw);
+                    double vv = -__builtin_inf(), lm = 0.0;
+                    int vi = 0x7fffffff;
+#pragma unroll
+                    for (int sl = 0; sl < PPL; ++sl)
+                        if (sl * 64 + lane < nW) {
+                            lm = fmax(lm, fabs(lw[sl]));
+                            if (Wside[sl] != 0) {
+                                const double viol = Wside[sl] > 0 ? -lw[sl] : lw[sl];
+                                if (viol > vv || (viol == vv && Wrow[sl] < vi)) { vv = viol; vi = Wrow[sl]; }
+                            }
+                        }
+                    lm = wave_max(lm);
+                    sd_argmax(vv, vi);
+                    if (!(vv > 1e-12 * fmax(1.0, lm))) {
+#pragma unroll
+                        for (int sl = 0; sl < PPL; ++sl) lam[sl] = (sl * 64 + lane < nW) ? lw[sl] : 0.0;
+                        break;
+                    }
+                    const int pos = pos_of_row(vi);
+                    sd_fence();
+                    remove_pos(pos);   // (not counted as an iteration: no sweep, O(|W|^2) -- the count is of scans + steps)
+                }
+                if (nW > 0) { mode = M_FULL; after = A_TOP; }
+                else mode = M_TOP;
+        };
         for (;;) {
+            if (mode == M_STARTED) { settle_start(); continue; }
             if (mode == M_TOP) {
                 if (it >= p.max_iter || overflow) break;
                 ++it;
@@ -823,11 +864,42 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
                     // the start list: saved working set of the previous tier, or terminal-equality rows + the guess's inputs on a bound
                     ns = 0;
                     int kg = -1;
+                    bool handed = false;
                     if (p.only_ovf && p.wsave) {
                         const int cnt = p.ovf[inst] - 1;
                         for (int i = lane; i < cnt; i += 64) slist[i] = p.wsave[(size_t)inst * SDUAL_WSAVE + i];
                         ns = cnt;
                         kg = N;
+                        if (p.sinv_save && cnt > 0 && cnt <= SDUAL_SINV_SAVE && cnt < wcap) {
+                            // the previous tier's inverse: the working set is installed as it stood -- no response, no bordering per row
+                            sd_fence();
+                            const double* sv = p.sinv_save + (size_t)inst * sdual_sinv_doubles(SDUAL_SINV_SAVE);
+                            const int cntd = (cnt * (cnt + 1)) >> 1;
+                            for (int i = lane; i < cntd; i += 64) {
+                                if constexpr (BIG) __hip_atomic_store(SinvG + i, sv[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                else SinvL[i] = sv[i];
+                            }
+                            int km = -1;
+                            for (int i = 0; i < cnt; ++i) {
+                                const int code = slist[i];
+                                const int t = code >> 2;
+                                if (lane == own_lane(t)) inW |= 1ull << own_bit(t);
+                                const int ks = stage_of(t);
+                                km = ks > km ? ks : km;
+                            }
+#pragma unroll
+                            for (int sl = 0; sl < PPL; ++sl) {
+                                const int i = sl * 64 + lane;
+                                if (i < cnt) {
+                                    const int code = slist[i];
+                                    Wrow[sl] = code >> 2; Wside[sl] = (code & 2) ? 0 : ((code & 1) ? 1 : -1); lam[sl] = 0.0;
+                                }
+                            }
+                            kmaxW = km > kmaxW ? km : kmaxW;
+                            nW = cnt;
+                            sfence();
+                            handed = true;
+                        }
                     } else {
                         if (has_eq) {
                             if (lane < n) slist[lane] = ((N * SP + lane) << 2) | 2;
@@ -862,8 +934,8 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
                     st_kend = kg + 1 < N ? kg + 1 : N;
                     sd_fence();
                     si = 0;
-                    mode = ns > 0 ? M_START : M_TOP;
-                    if (ns > 0 && nW >= wcap) { overflow = true; break; }
+                    mode = handed ? M_STARTED : (ns > 0 ? M_START : M_TOP);   // (handed over: straight to the multipliers of the start)
+                    if (!handed && ns > 0 && nW >= wcap) { overflow = true; break; }
                 } else if (after == A_TOP) mode = M_TOP;
                 else {
                     // confirmation from scratch: working-set rows on their bounds, nothing else violated
@@ -896,49 +968,19 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
                     } else mode = M_TOP;
                 }
             } else if (mode == M_START) {
-                const int code = slist[si];
-                const int t = code >> 2, sdr = (code & 2) ? 0 : ((code & 1) ? 1 : -1);
-                gather_c();
-                const double g_tt = w[t];
-                sd_fence();
-                publish(cpos);
-                sinv_mul(cbuf, rpos);
-                (void)border(t, sdr, g_tt);
-                ++si;
-                if (si < ns && nW >= wcap) { overflow = true; break; }
-                if (si >= ns) {
-                    // multipliers of the start from s0; rows whose multiplier has the wrong sign leave, worst first
-                    while (nW > 0) {
-                        double dv[PPL], lw[PPL];
-#pragma unroll
-                        for (int sl = 0; sl < PPL; ++sl) dv[sl] = (sl * 64 + lane < nW) ? s[Wrow[sl]] - bound_of_row(Wrow[sl], Wside[sl]) : 0.0;
-                        publish(dv);
-                        sinv_mul(cbuf, lw);
-                        double vv = -__builtin_inf(), lm = 0.0;
-                        int vi = 0x7fffffff;
-#pragma unroll
-                        for (int sl = 0; sl < PPL; ++sl)
-                            if (sl * 64 + lane < nW) {
-                                lm = fmax(lm, fabs(lw[sl]));
-                                if (Wside[sl] != 0) {
-                                    const double viol = Wside[sl] > 0 ? -lw[sl] : lw[sl];
-                                    if (viol > vv || (viol == vv && Wrow[sl] < vi)) { vv = viol; vi = Wrow[sl]; }
-                                }
-                            }
-                        lm = wave_max(lm);
-                        sd_argmax(vv, vi);
-                        if (!(vv > 1e-12 * fmax(1.0, lm))) {
-#pragma unroll
-                            for (int sl = 0; sl < PPL; ++sl) lam[sl] = (sl * 64 + lane < nW) ? lw[sl] : 0.0;
-                            break;
-                        }
-                        const int pos = pos_of_row(vi);
-                        sd_fence();
-                        remove_pos(pos);   // (not counted as an iteration: no sweep, O(|W|^2) -- the count is of scans + steps)
-                    }
-                    if (nW > 0) { mode = M_FULL; after = A_TOP; }
-                    else mode = M_TOP;
+                if (si < ns) {
+                    const int code = slist[si];
+                    const int t = code >> 2, sdr = (code & 2) ? 0 : ((code & 1) ? 1 : -1);
+                    gather_c();
+                    const double g_tt = w[t];
+                    sd_fence();
+                    publish(cpos);
+                    sinv_mul(cbuf, rpos);
+                    (void)border(t, sdr, g_tt);
+                    ++si;
+                    if (si < ns && nW >= wcap) { overflow = true; break; }
                 }
+                if (si >= ns) settle_start();
             } else if (mode == M_RESP) {
                 gather_c();
                 gpp = w[pr];
@@ -999,6 +1041,14 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
             for (int sl = 0; sl < PPL; ++sl) {
                 const int i = sl * 64 + lane;
                 if (i < nW && i < SDUAL_WSAVE) p.wsave[(size_t)inst * SDUAL_WSAVE + i] = (Wrow[sl] << 2) | (Wside[sl] == 0 ? 2 : (Wside[sl] > 0 ? 1 : 0));
+            }
+            if (p.sinv_save && nW <= SDUAL_SINV_SAVE) {   // ... and its inverse, packed as it is held
+                double* sv = p.sinv_save + (size_t)inst * sdual_sinv_doubles(SDUAL_SINV_SAVE);
+                const int cntd = (nW * (nW + 1)) >> 1;
+                for (int i = lane; i < cntd; i += 64) {
+                    if constexpr (BIG) sv[i] = __hip_atomic_load(SinvG + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else sv[i] = SinvL[i];
+                }
             }
         }
         if (status == 3 && !p.rows_state) status = 1;   // an input box alone is never infeasible: a numerical verdict, not a certificate
