@@ -189,6 +189,8 @@ struct almpc_handle {
         int32_t* ovf = nullptr;
         int32_t* wsave = nullptr;   // [batch][SDUAL_WSAVE] working set of an instance that ran out of room (start of the next tier)
         double* sinv_save = nullptr;   // [batch][sdual_sinv_doubles(SDUAL_SINV_SAVE)] its inverse (allocated at the first multi-tier solve)
+        int32_t* start_ws = nullptr;   // [batch][64] working sets the state-row finish of the LAST step gave up with (PolishGenParams::redo_ws)
+        bool start_ws_fresh = false;   // ... written by the last enqueued step (cleared by every step that does not run that finish)
         double* sinv_glb = nullptr; size_t sinv_cap = 0;   // third tier: Sinv of 128 x 129 per wave of its grid
         double* ghat = nullptr; size_t ghat_cap = 0; bool ghat_ready = false, ghat_building = false, ghat_wanted = false;   // shared model: cached sweep responses [TP][TP] (k_sdual: SdualParams::ghat)
         std::vector<double> S;               // symmetrised S (base terms of time-varying input references)
@@ -321,7 +323,7 @@ void free_all(almpc_handle* h) {
     if (h->comm && rccl_api().ok) (void)rccl_api().CommDestroy(h->comm);
     for (void* p : {(void*)h->dComm4, (void*)h->dU0, (void*)h->dU0all, (void*)h->rQ, (void*)h->rR, (void*)h->rP, (void*)h->rKst, (void*)h->rPst, (void*)h->rGuess,
                     (void*)h->sd.rec, (void*)h->sd.base, (void*)h->sd.xmin, (void*)h->sd.xmax, (void*)h->sd.eqt, (void*)h->sd.ovf, (void*)h->sd.wsave, (void*)h->sd.sinv_glb, (void*)h->sd.ghat, (void*)h->sd.dQ, (void*)h->sd.dR, (void*)h->sd.dS, (void*)h->sd.dP, (void*)h->sd.bad, (void*)h->sd.pc, (void*)h->sd.ct,
-                    (void*)h->sd.sinv_save, (void*)h->sd.scr_phi, (void*)h->sd.scr_g, (void*)h->sd.scr_rm, (void*)h->sd.scr_rp, (void*)h->sd.scr_verdict})
+                    (void*)h->sd.sinv_save, (void*)h->sd.start_ws, (void*)h->sd.scr_phi, (void*)h->sd.scr_g, (void*)h->sd.scr_rm, (void*)h->sd.scr_rp, (void*)h->sd.scr_verdict})
         if (p) (void)hipFree(p);
     if (h->ev_guess) (void)hipEventDestroy(h->ev_guess);
     if (h->ev_guess_done) (void)hipEventDestroy(h->ev_guess_done);
@@ -815,6 +817,7 @@ hipError_t launch_sdual(almpc_handle* h, int filter, const double* guess, int ma
     if (h->redo_x0_from_results) { sp.x0 = h->dX; sp.x0_stride = (long)h->n * (h->N + 1); }   // (lazy redo: see resolve_lazy_redo)
     if (h->redo_gate_on) { sp.gate = h->dRedoGate; sp.gate_val = h->step_serial; }
     sp.uguess = guess; sp.filter = filter; sp.flag = nullptr; sp.v_only = 0;
+    if (filter == 1 && sd.start_ws && sd.start_ws_fresh && !sd.sqp) sp.start_ws = sd.start_ws;   // (the redo behind a state-row finish)
     sp.x = h->dX; sp.ex = h->dEx; sp.u = h->dU; sp.eu = h->dEu; sp.status = h->dStatus; sp.piters = h->dPiters;
     if (sd.sqp) {   // dx_0 = 0, variable v = u - ubar (the handle's per-instance references ARE the iterate xbar, ubar), cost terms per instance
         const almpc_handle::Sqp& q = h->sqp;
@@ -882,7 +885,11 @@ hipError_t launch_sdual(almpc_handle* h, int filter, const double* guess, int ma
     if (single_launch) {
         int NT_ = sd.NT, MC_ = sd.MC;
         const bool fits128 = (size_t)sdual_lds_doubles(NT_, MC_, h->N, SD_WCAP4, true) * sizeof(double) <= 160 * 1024;
-        tier0 = tier1 = fits128 ? 2 : 1;
+        // (round 5: the 64-row build first -- one working-set position per lane: its Sinv products, borderings and column streams are
+        // cheaper per change than the 128-row build's -- and the 128-row build only for what outgrows it, which costs little since the
+        // tiers hand over their inverse; ALMPC_SDUAL_REDO_128=1: the one 128-row launch of round 4)
+        tier0 = (fits128 && getenv("ALMPC_SDUAL_REDO_128")) ? 2 : 1;
+        tier1 = fits128 ? 2 : 1;
     }
 #define SD_CASE(NT_, MC_) if (sd.NT == NT_ && sd.MC == MC_) return launch_sdual_t<NT_, MC_>(h, sp, tier0, tier1)
     SD_CASE(2, 2); SD_CASE(4, 2); SD_CASE(6, 2); SD_CASE(8, 4); SD_CASE(12, 4); SD_CASE(16, 4); SD_CASE(16, 8); SD_CASE(32, 16); SD_CASE(48, 16);
@@ -1805,6 +1812,84 @@ int design_batched_common(almpc_handle* h, const double* A_batch, const double* 
 }
 }  // namespace
 
+namespace {
+// almpc_relin_fnn_setup on an ALMPC_FLAG_STRUCTURED handle: network, references and weights on the device, the per-instance model and
+// terminal-weight slots, and the stage-wise solver's per-instance set-up (records per stage: the terminal weight is the caller's P).
+int relin_setup_structured(almpc_handle* h, int H, int L, int activation, const double* W_in, const double* W_h, const double* b_h,
+                           const double* W_out, const double* xref, const double* uref, const double* Q, const double* R, const double* S,
+                           const double* P, const double* umin, const double* umax) {
+    const int n = h->n, m = h->m, N = h->N, nz = h->nz;
+    const size_t b = (size_t)h->batch, nin = (size_t)n + m;
+    if ((2 * (size_t)H + 2 * (size_t)H * nin + nin) * sizeof(double) > 160 * 1024)
+        return fail(h, ALMPC_ERR_UNSUPPORTED, "relin_fnn_setup: the network's forward-mode Jacobian must fit the 160 KB of LDS");
+    for (int i = 0; i < m; ++i)
+        if (!(umin[i] <= umax[i])) return fail(h, ALMPC_ERR_INVALID, "relin_fnn_setup: umin > umax");
+    h->designed = false;
+    h->sqp.ready = h->sqp.started = false;
+    h->relin.ready = false;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    auto sym = [](const double* M, int k) {
+        hm::mat o((size_t)k * k, 0.0);
+        if (M)
+            for (int j = 0; j < k; ++j)
+                for (int i = 0; i < k; ++i) o[(size_t)j * k + i] = 0.5 * (M[(size_t)j * k + i] + M[(size_t)i * k + j]);
+        return o;
+    };
+    const hm::mat Qm = sym(Q, n), Rm = sym(R, m), Sm = sym(S, m), Pm = sym(P, n);
+    const bool useS = Rm[0] != 0.0 && S && Sm[0] != 0.0;
+    if (!sdual_shape_ok(n, m, N, useS))
+        return fail(h, ALMPC_ERR_UNSUPPORTED, "relin_fnn_setup (structured): n (+ m with an input-rate weight) <= 48, m <= 16 and (N + 1)(n + m) <= 4096");
+    almpc_handle::Relin& q = h->relin;
+    for (void* p_ : {(void*)q.W_in, (void*)q.W_h, (void*)q.b_h, (void*)q.W_out, (void*)q.ulin, (void*)q.Q, (void*)q.R, (void*)q.S, (void*)q.gS})
+        if (p_) (void)hipFree(p_);
+    q.W_in = q.W_h = q.b_h = q.W_out = q.ulin = q.Q = q.R = q.S = q.gS = nullptr;
+    auto up = [&](double** d, const double* src, size_t cnt) -> hipError_t {
+        hipError_t e = dalloc(d, cnt ? cnt : 1);
+        if (e == hipSuccess && src && cnt) e = hipMemcpy(*d, src, cnt * sizeof(double), hipMemcpyHostToDevice);
+        return e;
+    };
+    std::vector<double> xr((size_t)n * (N + 1), 0.0), ur((size_t)nz, 0.0);
+    if (xref) xr.assign(xref, xref + xr.size());
+    if (uref) ur.assign(uref, uref + ur.size());
+    std::vector<double> ul(b * m);
+    for (size_t i = 0; i < b; ++i)
+        for (int a = 0; a < m; ++a) ul[i * m + a] = ur[a];  // every instance linearises at the first input reference
+    HIP_TRY(h, up(&q.W_in, W_in, (size_t)H * nin)); HIP_TRY(h, up(&q.W_h, W_h, (size_t)L * H * H)); HIP_TRY(h, up(&q.b_h, b_h, (size_t)L * H));
+    HIP_TRY(h, up(&q.W_out, W_out, (size_t)n * H)); HIP_TRY(h, up(&q.ulin, ul.data(), ul.size()));
+    if (!h->bA) HIP_TRY(h, dalloc(&h->bA, b * n * n));
+    if (!h->bB) HIP_TRY(h, dalloc(&h->bB, b * n * m));
+    if (!h->bP) HIP_TRY(h, dalloc(&h->bP, b * n * n));
+    HIP_TRY(h, hipMemset(h->bA, 0, b * n * n * sizeof(double)));
+    HIP_TRY(h, hipMemset(h->bB, 0, b * n * m * sizeof(double)));
+    HIP_TRY(h, hipMemcpy(h->bP, Pm.data(), Pm.size() * sizeof(double), hipMemcpyHostToDevice));
+    h->batched = true; h->ltv = false; h->r_batched_P = true; h->rP_stride = 0;
+    h->sd.ready = false;
+    {
+        const int rc_ = sdual_setup_batched(h, Qm, Rm, useS ? &Sm : nullptr, false, h->boxmin.empty() ? nullptr : h->boxmin.data(),
+                                            h->boxmax.empty() ? nullptr : h->boxmax.data(), h->terminal_eq != 0);
+        if (rc_ != ALMPC_OK) return rc_;
+    }
+    if (riccati_shape_ok(h)) { const int rc_ = riccati_weights(h, Qm, Rm, nullptr); if (rc_ != ALMPC_OK) return rc_; }
+    HIP_TRY(h, hipMemcpy(h->dUmin, umin, m * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->dUmax, umax, m * sizeof(double), hipMemcpyHostToDevice));
+    h->P = Pm; h->H.clear(); h->F.clear(); h->d.clear();
+    h->hS = Sm; h->useS = useS ? 1 : 0;
+    h->has_box = h->boxmin.empty() ? 0 : 1;
+    for (auto& e : q.ev)
+        if (!e) HIP_TRY(h, hipEventCreate(&e));
+    q.H = H; q.L = L; q.act = activation; q.have_prev = false; q.useR = Rm[0] != 0.0; q.useS = useS;
+    if (!q.u0) HIP_TRY(h, dalloc(&q.u0, b * m));
+    if (!q.xnext) HIP_TRY(h, dalloc(&q.xnext, b * n));
+    h->r_has_step = false;
+    h->designed = true;
+    const int rc_ref = almpc_set_reference(h, xr.data(), ur.data(), 0);   // (also the input-rate terms of a horizon-varying u_ref: sdual_update_base)
+    if (rc_ref != ALMPC_OK) { h->designed = false; return rc_ref; }
+    q.ready = true;
+    return ALMPC_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int almpc_design_batched(almpc_handle* h, const double* A_batch, const double* B_batch, const double* Q, const double* R,
@@ -1878,9 +1963,8 @@ int almpc_relin_fnn_setup(almpc_handle* h, int H, int L, int activation, const d
     if (H < 1 || L < 0 || !W_in || !W_out || (L > 0 && (!W_h || !b_h)) || !Q || !R || !P || !umin || !umax)
         return fail(h, ALMPC_ERR_INVALID, "relin_fnn_setup: null pointer or bad network shape (P must be given: the terminal weight "
                                           "comes from the linearisation at the last reference, src/sub/design_mpc.jl:312-327)");
-    if (h->structured)
-        return fail(h, ALMPC_ERR_UNSUPPORTED, "relin_fnn_setup: a handle created with ALMPC_FLAG_STRUCTURED has no condensed per-instance designs");
     if (activation < 0 || activation > 4) return fail(h, ALMPC_ERR_UNSUPPORTED, "relin_fnn_setup: activation must be 0..4");
+    if (h->structured) return relin_setup_structured(h, H, L, activation, W_in, W_h, b_h, W_out, xref, uref, Q, R, S, P, umin, umax);
     if (!(rho > 0.0) || !(sigma >= 0.0)) return fail(h, ALMPC_ERR_INVALID, "relin_fnn_setup: rho must be > 0 and sigma >= 0");
     const int n = h->n, m = h->m, N = h->N, nz = h->nz;
     const size_t b = (size_t)h->batch, nin = (size_t)n + m;
@@ -1991,6 +2075,26 @@ int almpc_relin_fnn_step_async(almpc_handle* h, const almpc_opts* opts) {
     fp.W_in = q.W_in; fp.W_h = q.W_h; fp.b_h = q.b_h; fp.W_out = q.W_out;
     fp.x = h->dX0; fp.u = q.ulin; fp.ppi = 1; fp.xs_group = n; fp.us_group = m;
     fp.A = h->bA; fp.B = h->bB; fp.f = nullptr;
+    if (h->structured) {
+        // Structured handle (m N beyond the condensed limit, round 5): Jacobians -> the stage records of every instance's own
+        // unconstrained problem (k_sgains) -> the stage-wise dual active set (k_sdual), warm-started from the previous step's inputs
+        // shifted by one stage when opts->warm_start is set.  No Hessian is formed: the reference's Fnn-LP delegation has no horizon
+        // limit (.../fnn/mpc_modeler_implementation_fnn.jl:23-58) and neither has this route.
+        HIP_TRY(h, launch_fnn_jacobian(fp, h->num_cus, st));
+        if (timing) HIP_TRY(h, hipEventRecord(q.ev[1], st));
+        HIP_TRY(h, launch_sgains(h, 0));
+        if (timing) HIP_TRY(h, hipEventRecord(q.ev[2], st));
+        h->designed = true;
+        almpc_opts o2;
+        almpc_default_opts(&o2);
+        if (opts) o2 = *opts;
+        if (!q.have_prev) o2.warm_start = 0;
+        const int rc = almpc_calculate_async(h, &o2);
+        if (rc != ALMPC_OK) { h->designed = false; return rc; }
+        q.have_prev = true;
+        if (timing) HIP_TRY(h, hipEventRecord(q.ev[3], st));
+        return ALMPC_OK;
+    }
     const bool fuse_jac = design_fuses_fnn(h, q.H, q.L);   // the design kernel's workgroups linearise their own instance
     if (!fuse_jac) HIP_TRY(h, launch_fnn_jacobian(fp, h->num_cus, st));
     if (timing) HIP_TRY(h, hipEventRecord(q.ev[1], st));
@@ -2594,6 +2698,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         return hipHostGetDevicePointer(reinterpret_cast<void**>(&h->dUnsolved), h->hUnsolved, 0);
     };
     h->step_serial += 1;
+    h->sd.start_ws_fresh = false;
     auto io_step_done = [&]() -> int {   // the x0 slot of an asynchronous update is free again once this step has finished
         h->state_valid = keep_state;     // (recorded only here: every launch of the step went out)
         if (h->io.x0_slot >= 0) {
@@ -2754,6 +2859,11 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         if (!h->dOvfSinv) HIP_TRY(h, dalloc(&h->dOvfSinv, (size_t)h->batch * (32 * 32 + 32)));
         gp.ovf = h->dOverflow; gp.ovf_ws = h->dOverflow + 2 + h->batch; gp.ovf_sinv = h->dOvfSinv;
         if (lazy_redo) { HIP_TRY(h, ensure_unsolved_word()); gp.unsolved = h->dUnsolved; gp.redo_gate = h->dRedoGate; gp.step_serial = h->step_serial; }
+        if (h->fallback && !h->ltv && h->sd.ready && !h->sd.sqp && !getenv("ALMPC_NO_REDO_START")) {   // a stage-wise redo may follow: it starts from what this finish gives up with
+            if (!h->sd.start_ws) HIP_TRY(h, dalloc(&h->sd.start_ws, (size_t)h->batch * 64));
+            gp.redo_ws = h->sd.start_ws; gp.redo_sp = h->sd.NT + h->sd.MC; gp.redo_nt = h->sd.NT;
+            h->sd.start_ws_fresh = true;
+        }
         if (h->s0_basis_ok && !h->batched && !h->ltv && h->fS_stride == 0) gp.s0_basis = h->dS0Basis;   // (shared model, shared references)
         const dim3 grid((h->batch + PGEN_WAVES - 1) / PGEN_WAVES), block(64 * PGEN_WAVES);
         // first launch: working sets up to 32 rows, every instance; second launch: the instances the first one flagged, up to 64 rows

@@ -75,6 +75,11 @@ struct PolishGenParams {
                                  // that the second launch continues instead of bordering the 32 rows in again (105 k cycles), or null
     int* unsolved = nullptr;   // host-visible count of instances left with ALMPC_MAX_ITER (lazy redo, see almpc_handle::hUnsolved), or null
     int* redo_gate = nullptr; int step_serial = 0;   // as PolishParams::redo_gate
+    // start of the stage-wise redo (round 5): an instance this finish leaves undecided hands k_sdual its working set, in the coordinates
+    // of the stage-wise form -- [batch][64]: count, then (coordinate << 2 | 1 upper / 0 lower / 2 equality) -- or null.  The rows are then
+    // bordered in one cached response each instead of being found again one scan / direction / ratio test at a time.
+    int32_t* redo_ws = nullptr;
+    int redo_sp = 0, redo_nt = 0;   // k_sdual's stage layout: coordinates per stage, offset of the input slot
     int max_iter;
     int roll_g, roll_cpl;
     RolloutParams roll;
@@ -859,6 +864,20 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
             __hip_atomic_fetch_add(p.unsolved, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (p.redo_gate) *p.redo_gate = p.step_serial;
         }
+    }
+    if (p.redo_ws) {
+        const int st_out = (st_in == 2) ? 2 : ((fin == 0) ? 0 : (fin == 3 ? 3 : 1));
+        const bool requeue = !QUEUE && overflow && fin != 3;
+        int32_t* rw = p.redo_ws + (size_t)inst * 64;
+        if (st_out == 1 && !requeue && !give_up) {
+            const int pos = WL == 32 ? (lane & 31) : lane;
+            if (lane < WL && pos < k && pos < 63) {
+                const int xi = p.row_xidx[wrow];
+                const int t = wrow < p.nz ? (wrow / p.m) * p.redo_sp + p.redo_nt + wrow % p.m : (xi / p.n) * p.redo_sp + xi % p.n;
+                rw[1 + pos] = (t << 2) | (wsd == 0 ? 2 : (wsd > 0 ? 1 : 0));
+            }
+            if (lane == 0) rw[0] = k < 63 ? k : 63;
+        } else if (lane == 0) rw[0] = 0;
     }
     if (!QUEUE && overflow && fin != 3) {   // (WL = 32 here: both half-waves mirror the positions)
         if (lane < 32) p.ovf_ws[(size_t)inst * 32 + lane] = guess_overflow ? -1 : (wrow | ((wsd + 1) << 12));

@@ -75,6 +75,9 @@ struct SdualParams {
     // screen (or null): [batch] verdicts of k_state_box_screen -- 1: the state box cannot be met whatever the inputs (a reachability
     // certificate); the instance leaves with ALMPC_INFEASIBLE before any sweep
     const int32_t* screen = nullptr;
+    // start_ws (or null): [batch][64] working set a condensed finish gave up with (PolishGenParams::redo_ws: count, then codes as in
+    // wsave): the start list of its redo, in place of the inputs of uguess that sit on a bound
+    const int32_t* start_ws = nullptr;
 };
 
 __host__ __device__ inline int sdual_tp(int NT, int MC, int N) { return (N * (NT + MC) + NT + 1) & ~1; }
@@ -906,7 +909,19 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
                             ns = n;
                             kg = N;
                         }
-                        if (p.uguess) {
+                        int nws = 0;
+                        if (p.start_ws) {
+                            const int32_t* rw = p.start_ws + (size_t)inst * 64;
+                            nws = rw[0];
+                            if (nws > wcap - 16 - ns) nws = wcap - 16 - ns > 0 ? wcap - 16 - ns : 0;   // (room left for what the method still has to add)
+                            if (lane < nws) slist[ns + lane] = rw[1 + lane];
+                            int kk = -1;
+                            if (lane < nws) { const int tt = rw[1 + lane] >> 2; kk = stage_of(tt); }
+                            kk = sd_wave_max_i(kk);
+                            kg = kk > kg ? kk : kg;
+                            ns += nws;
+                        }
+                        if (p.uguess && nws == 0) {
                             for (int t0 = 0; t0 < N * m; t0 += 64) {   // trajectory order, 64 inputs per ballot
                                 const int t = t0 + lane;
                                 int sdl = 0, tt = 0;

@@ -159,12 +159,14 @@ def test_structured_handle_refuses_what_it_does_not_build(capi, mo):
         assert np.abs(r["u"][i] - mo.solve_mpc_exact(p, np.array(x0))["u"]).max() <= U_TOL
     with pytest.raises(capi.AlmpcError):
         capi.Solver(40, 2, 10, 1, structured=True)      # n > 32
-    # the condensed per-instance pipelines are refused (ALMPC_ERR_UNSUPPORTED), not launched with null operands
+    # the re-linearisation pipeline is the stage-wise one on a structured handle (round 5: the test below); here only that it is taken
     f = mo.synthetic_fnn(act="tanh")
     s = capi.Solver(4, 2, 10, 2, structured=True)
     xr, ur = np.zeros((4, 11)), np.zeros((2, 10))
-    with pytest.raises(capi.AlmpcError) as ei:
-        s.relin_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, xr, ur, 100.0 * np.eye(4), 0.1 * np.eye(2), None, 150.0 * np.eye(4), [-1, -1], [1, 1], act="tanh")
+    s.relin_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, xr, ur, 100.0 * np.eye(4), 0.1 * np.eye(2), None, 150.0 * np.eye(4), [-1, -1], [1, 1], act="tanh")
+    with pytest.raises(capi.AlmpcError) as ei:     # ... within the stage-wise solver's shape limits
+        capi.Solver(30, 2, 160, 2, structured=True).relin_fnn_setup(np.zeros((4, 32)), [], [], np.zeros((30, 4)), None, None, 100.0 * np.eye(30),
+                                                                    0.1 * np.eye(2), None, 150.0 * np.eye(30), [-1, -1], [1, 1], act="tanh")
     assert ei.value.code == -4
     # an SQP loop on a structured handle is the stage-wise one; it takes the input-rate weight too (tests/test_gpu_stagewise.py)
     s.sqp_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, xr, ur, 100.0 * np.eye(4), 0.1 * np.eye(2), 0.5 * np.eye(2), 150.0 * np.eye(4), [-1, -1], [1, 1], act="tanh")
@@ -298,3 +300,80 @@ def test_horizon_continuation_and_warm_start(capi, mo):
         assert rw["polish_iters"].sum() <= 1.2 * rc["polish_iters"].sum()
         s50.update_initialization(x); s50.calculate(warm)   # leave the warm result in place for the next shift
     s30.close(); s50.close()
+
+
+def test_relinearisation_pipeline_on_a_structured_handle_beyond_the_condensed_horizon(capi, mo):
+    """Round-4 review, item 5: the reference's Fnn-LP delegation has no horizon limit (.../fnn/mpc_modeler_implementation_fnn.jl:23-58);
+    almpc_relin_fnn_* refused ALMPC_FLAG_STRUCTURED handles.  A quadrotor-size network (n 12, m 4) at N = 50 -- m N = 200, no condensed
+    handle exists -- re-linearised at every instance's own state: k_fnn_jacobian_w -> k_sgains -> k_sdual on the device, every
+    instance against the exact oracle on ITS OWN (A_i, B_i), cold and in closed loop with warm steps, with a state box and S, and as
+    a group of two handles."""
+    n, m, N, batch = 12, 4, 50, 256
+    f = mo.synthetic_fnn(n=n, m=m, H=24, L=2, seed=0x5EED0044, act="tanh")
+    x_ref, u_ref = np.zeros(n), np.zeros(m)
+    X0 = 0.5 * mo.splitmix_normal(0x5EED0045, 0, batch, n)
+    Q, R = 100.0 * np.eye(n), 0.1 * np.eye(m)
+    umin, umax = -0.3 * np.ones(m), 0.3 * np.ones(m)
+    Al, Bl = f.jacobian(x_ref, u_ref)
+    P = mo.dare(Al, Bl, Q, R)     # terminal weight as the reference takes it: linearisation at the last reference
+    xr, ur = np.tile(x_ref[:, None], (1, N + 1)), np.tile(u_ref[:, None], (1, N))
+    sv = capi.Solver(n, m, N, batch, structured=True)
+    sv.relin_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, xr, ur, Q, R, None, P, umin, umax, act=f.act)
+    sv.update_initialization(X0)
+    sv.relin_fnn_step()
+    r = sv.get_results()
+    assert np.all(r["status"] == 0), np.bincount(r["status"])
+    nact = 0
+    for i in range(0, batch, 8):
+        Ai, Bi = f.jacobian(X0[i], u_ref)
+        p = mo.make_problem(Ai, Bi, N, umin, umax, x_ref=x_ref, u_ref=u_ref, P=P)
+        e = mo.solve_mpc_structured(p, X0[i])
+        assert np.abs(r["u"][i] - e["u"]).max() <= U_TOL, i
+        nact += int(((e["u"] <= umin[:, None] + 1e-12) | (e["u"] >= umax[:, None] - 1e-12)).sum())
+    assert nact > 40
+    # closed loop on the network with warm steps: every warm step equals the cold solve of the same state
+    warm = capi.default_opts(warm_start=1)
+    cold = capi.Solver(n, m, N, batch, structured=True)
+    cold.relin_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, xr, ur, Q, R, None, P, umin, umax, act=f.act)
+    for _ in range(3):
+        sv.relin_fnn_advance()
+        sv.relin_fnn_step(warm)
+        rw = sv.get_results(want=("u", "x", "status"))
+        cold.update_initialization(rw["x"][:, :, 0].copy())
+        cold.relin_fnn_step()
+        rc = cold.get_results(want=("u", "status"))
+        assert np.all(rw["status"] == 0) and np.all(rc["status"] == 0)
+        assert np.abs(rw["u"] - rc["u"]).max() <= 1e-6
+    cold.close()
+    sv.close()
+    # state box + input-rate weight + a horizon-varying input reference (the S terms of the reference reach the solver's base vector)
+    urv = 0.02 * np.sin(np.arange(N))[None, :] * np.ones((m, 1))
+    xbox = 2.0 * np.ones(n)
+    S = 3.0 * np.eye(m)
+    sb = capi.Solver(n, m, N, batch, structured=True)
+    sb.relin_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, xr, urv, Q, R, S, P, umin, umax, act=f.act, xmin=-xbox, xmax=xbox)
+    sb.update_initialization(X0)
+    sb.relin_fnn_step()
+    rb = sb.get_results(want=("u", "status"))
+    sb.close()
+    checked = 0
+    for i in range(0, batch, 16):
+        Ai, Bi = f.jacobian(X0[i], urv[:, 0])
+        p = mo.make_problem(Ai, Bi, N, umin, umax, x_ref=xr, u_ref=urv, P=P, s=3.0, x_min=-xbox, x_max=xbox)
+        try:
+            e = mo.solve_mpc_exact(p, X0[i])
+        except ValueError:
+            assert rb["status"][i] == 3, i
+            continue
+        assert rb["status"][i] == 0, (i, rb["status"][i])
+        assert np.abs(rb["u"][i] - e["u"]).max() <= 1e-5, i
+        checked += 1
+    assert checked >= 8
+    # a group of two handles on device 0 equals the single handle
+    g = capi.Group(n, m, N, batch, [0, 0], structured=True)
+    g.relin_fnn_setup(f.W_in, f.W_h, f.b_h, f.W_out, xr, ur, Q, R, None, P, umin, umax, act=f.act)
+    g.update_initialization(X0)
+    g.relin_fnn_step()
+    rg = g.get_results(want=("u", "status"))
+    g.close()
+    assert np.array_equal(rg["status"], r["status"]) and np.array_equal(rg["u"], r["u"])
