@@ -86,6 +86,7 @@ struct almpc_handle {
     int *dRowTraj = nullptr, *dRowEq = nullptr, *dRowXidx = nullptr, *dRowState = nullptr;
     double* dOvfSinv = nullptr;    // [batch][32 * 32 + 32] k_polish_gen -> k_polish_gen64: inverse and bounds of a flagged instance
     double* dVsPlain = nullptr;    // [n][nzs] V = -G F' (shared design with state rows): operand of the s0 table
+    double* dPlain = nullptr;      // small shared designs (nzs <= 64): dense [Minv | H' | F' | V] for the one-wave-per-instance step
     double* dS0Basis = nullptr;    // [(n + 1)][Rs] PolishGenParams::s0_basis
     bool s0_basis_ok = false;
     int32_t* dOverflow = nullptr;  // [2 + batch] k_polish_gen: count, cursor and list of instances to redo with the 64-row build
@@ -310,7 +311,7 @@ void free_all(almpc_handle* h) {
                     h->dXref, h->dUref, h->dFS, h->dV0S, h->dRho, h->dRollM, h->dX0, h->dXs, h->dZs, h->dYs, h->dV0, h->dW, h->dX, h->dEx,
                     h->dU, h->dEu, h->dStatus, h->dIters, h->dPiters, h->dPerm, h->dYflags, h->dSglobal, h->dGhat, h->dGnorm, h->dXmin,
                     h->dXmax, h->dRowTraj, h->dRowEq, h->dRowXidx, h->dRowState, h->dRowMap, h->dGhatE, h->dWinvE, h->lA, h->lB, h->lC, h->lE, h->bA, h->bB, h->bMinv, h->bG, h->bHs, h->bFs,
-                    h->bVs, h->bD, h->bRho, h->bH, h->bF, h->bPhi, h->bGk, h->bGam, h->bW, h->bWP, h->bP, h->bFlag, h->bQ, h->dOverflow, h->dOvfSinv, h->dVsPlain, h->dS0Basis, h->wQ, h->wR, h->wS,
+                    h->bVs, h->bD, h->bRho, h->bH, h->bF, h->bPhi, h->bGk, h->bGam, h->bW, h->bWP, h->bP, h->bFlag, h->bQ, h->dOverflow, h->dOvfSinv, h->dVsPlain, h->dPlain, h->dS0Basis, h->wQ, h->wR, h->wS,
                     h->sqp.W_in, h->sqp.W_h, h->sqp.b_h, h->sqp.W_out, h->sqp.A, h->sqp.B, h->sqp.c, h->sqp.fval, h->sqp.ebar,
                     h->sqp.qadd, h->sqp.xref, h->sqp.uref, h->sqp.Q, h->sqp.R, h->sqp.S, h->sqp.bad, h->sqp.stats, h->sqp.mer, h->sqp.xback, h->sqp.uback, h->sqp.dxback, h->sqp.vback};
     for (void* p : ptrs)
@@ -888,7 +889,7 @@ hipError_t launch_sdual(almpc_handle* h, int filter, const double* guess, int ma
         // (round 5: the 64-row build first -- one working-set position per lane: its Sinv products, borderings and column streams are
         // cheaper per change than the 128-row build's -- and the 128-row build only for what outgrows it, which costs little since the
         // tiers hand over their inverse; ALMPC_SDUAL_REDO_128=1: the one 128-row launch of round 4)
-        tier0 = (fits128 && getenv("ALMPC_SDUAL_REDO_128")) ? 2 : 1;
+        tier0 = (fits128 && (getenv("ALMPC_SDUAL_REDO_128") || h->redo_gate_on)) ? 2 : 1;   // (a gated redo: one launch)
         tier1 = fits128 ? 2 : 1;
     }
 #define SD_CASE(NT_, MC_) if (sd.NT == NT_ && sd.MC == MC_) return launch_sdual_t<NT_, MC_>(h, sp, tier0, tier1)
@@ -923,11 +924,15 @@ int enqueue_gated_redo(almpc_handle* h) {
     if (!h->lazy_pending || !h->dRedoGate || getenv("ALMPC_NO_GATED_REDO")) return ALMPC_OK;
     h->redo_x0_from_results = true; h->redo_gate_on = true;
     struct Reset { almpc_handle* h; ~Reset() { h->redo_x0_from_results = false; h->redo_gate_on = false; } } reset_{h};
-    if (h->sd.ready) {
+    // As few launches as possible: an empty gated launch still costs 3 - 4 us of stream time on a 60 us step.  An input box alone
+    // (no state rows, no S): the primal Riccati active set by itself -- it is the solver that needs no certificate from another one
+    // (slower per instance than the dual method, but what it gets here is rare) --, ONE launch.  Otherwise the dual method's
+    // 128-row build in one launch (+ the stage records of per-instance models).
+    if (h->mc == 0 && !h->useS && h->rKst) HIP_TRY(h, launch_riccati(h, 1, h->dU, 0));
+    else if (h->sd.ready) {
         if (h->sd.per_instance) HIP_TRY(h, launch_sgains(h, 1));
         HIP_TRY(h, launch_sdual(h, 1, h->dU, 0, true));
     }
-    if (h->mc == 0 && !h->useS && h->rKst) HIP_TRY(h, launch_riccati(h, 1, h->dU, 0));
     h->lazy_pending = false;   // (this step is settled on the stream; a later synchronous look has nothing left to do for it)
     return ALMPC_OK;
 }
@@ -1221,9 +1226,11 @@ int almpc_design_shared(almpc_handle* h, const double* A, const double* B, const
             if (h->has_box || (h->terminal_eq && k == N - 1)) rowsel.push_back(k * n + i);
     h->s0_basis_ok = false;
     if (!rowsel.empty() && !h->dVsPlain) HIP_TRY(h, dalloc(&h->dVsPlain, (size_t)n * h->nzs));
+    if (h->nzs <= 64 && !h->dPlain) HIP_TRY(h, dalloc(&h->dPlain, 2 * (size_t)h->nz * h->nzs + 2 * (size_t)n * h->nzs));
     int rc = design_shared_device(h->stream, n, m, N, h->nzs, h->nrb, h->ks, h->ksf, Am, Bm, Qm, Rm, Sm, Pm, rho, sigma,
                                   h->dMinvFrag, h->dVFrag, h->dHFrag, h->dFFrag, h->dG, h->dD, h->H, h->F, h->d, h->err,
-                                  rowsel, h->Rs, h->dGhat, h->dGnorm, h->rho_mode, h->dRho, rowsel.empty() ? nullptr : h->dVsPlain);
+                                  rowsel, h->Rs, h->dGhat, h->dGnorm, h->rho_mode, h->dRho, rowsel.empty() ? nullptr : h->dVsPlain,
+                                  h->nzs <= 64 ? h->dPlain : nullptr);
     if (rc != ALMPC_OK) return rc;
     if (h->terminal_eq && h->mc >= n && !getenv("ALMPC_NO_EQ_PROJECTION")) {
         // the n terminal-equality rows (the last n state rows) are in every working set: eliminate them here, once
@@ -2759,6 +2766,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
         ip.piters = h->dPiters; ip.perm = h->dPerm;
         ip.sigma = o.sigma; ip.alpha = o.alpha; ip.eps_abs = o.eps_abs; ip.eps_rel = o.eps_rel;
         ip.max_iter = o.max_iter; ip.check_every = o.check_every; ip.warm = o.warm_start ? 1 : 0;
+        ip.mat_stride = (long)h->nz * h->nzs; ip.fv_stride = (long)h->n * h->nzs; ip.vec_stride = h->nzs; ip.fs_stride = h->nz;
         if (h->skip_admm) {
             if (!o.polish) return fail(h, ALMPC_ERR_INVALID, "calculate: the SQP loop needs opts.polish = 1");
             HIP_TRY(h, ev0());
@@ -2945,6 +2953,47 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
                 HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(k_step_fused<8, 32>), (size_t)(l_step)));
                 hipLaunchKernelGGL((k_step_fused<8, 32>), dim3(pp.ntiles), dim3(512), l_step, st, ap, pp);
             }
+                } else if (admm_pending && !h->batched && h->nzs <= 64 && fused && h->dPlain && !h->ltv &&
+                           !(getenv("ALMPC_NO_SHARED_WAVE") && getenv("ALMPC_NO_SHARED_WAVE")[0] == '1') &&
+                           (long)h->batch <= (getenv("ALMPC_SHARED_WAVE_MAX_BATCH") ? atol(getenv("ALMPC_SHARED_WAVE_MAX_BATCH")) : (long)2 * h->num_cus) &&
+                           ((size_t)SL.total + (size_t)per_wave) * sizeof(double) <= 64 * 1024) {
+            // small SHARED problems in small batches (configs[0], the reference's own test sizes: one instance, N 5 - 15, m 2 -> nz
+            // 10 - 30; round 5): the two-launch path gives them a 16-instance MFMA tile they cannot fill and two launch ramps.  ONE
+            // kernel, one wave per instance -- k_step_inst_wave with operand strides of zero: every wave reads the same dense
+            // Minv / F' / V (a few KB, L1 / L2 resident), runs the ADMM iterations from registers and then the single-wave finish
+            // (G through L1: 13 KB at nz 40).  Measured (tools/time_small_shared.py, QTP fixture, N 5 / N 20, us per step): batch 1
+            // 16.9 / 21.8 against 29.7 / 33.1, batch 64 20 / 45 against 43 / 56, batch 512 30 / 58 against 44 / 58; from 2048
+            // instances on a wave per 10 - 40-row problem wastes the machine (63 / 113 against 45 / 70 us; 65,536: 1.8 / 2.3 ms
+            // against 0.32 / 0.68 ms): up to two instances per CU take this path, larger batches the tile path.
+            admm_pending = false;
+            HIP_TRY(h, ev0());
+            const size_t mm = (size_t)h->nz * h->nzs, fv = (size_t)h->n * h->nzs;
+            ip.nz = h->nz; ip.n = h->n; ip.m = h->m; ip.batch = h->batch; ip.nzs = h->nzs;
+            ip.Minv = h->dPlain; ip.Hs = h->dPlain + mm; ip.Fs = h->dPlain + 2 * mm; ip.Vs = h->dPlain + 2 * mm + fv;
+            ip.dvec = h->dD; ip.rhovec = h->dRho;
+            ip.mat_stride = 0; ip.fv_stride = 0; ip.vec_stride = 0; ip.fs_stride = h->fS_stride;
+            ip.fS = h->dFS; ip.v0S = h->dV0S; ip.umin = h->dUmin; ip.umax = h->dUmax;
+            ip.uref = h->dUref; ip.uref_stride = h->uref_stride; ip.xref = h->dXref; ip.xref_stride = h->xref_stride; ip.x0 = h->dX0;
+            ip.xs = h->dXs; ip.zs = h->dZs; ip.ys = h->dYs; ip.v0 = h->dV0; ip.status = h->dStatus; ip.iters = h->dIters;
+            ip.piters = h->dPiters; ip.perm = h->dPerm;
+            ip.sigma = o.sigma; ip.alpha = o.alpha; ip.eps_abs = o.eps_abs; ip.eps_rel = o.eps_rel;
+            ip.max_iter = o.max_iter; ip.check_every = o.check_every; ip.warm = o.warm_start ? 1 : 0;
+            pp.yflags = nullptr; pp.yflag_words = 0;   // (this ADMM phase hands over y itself)
+            const size_t l_sgl = ((size_t)SL.total + (size_t)per_wave) * sizeof(double);
+            pp.sg_off = -1; pp.g_off = 0;
+            pp.lds_per_wave = per_wave;
+            pp.direct = 1;
+            if (timing) HIP_TRY(h, hipEventRecord(ev[1], st));
+#define STEP_SHARED(NZC_)                                                                                            \
+    do {                                                                                                             \
+        HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(k_step_inst_wave<NZC_>), l_sgl));                    \
+        hipLaunchKernelGGL((k_step_inst_wave<NZC_>), dim3((unsigned)h->batch), dim3(64), l_sgl, st, ip, pp);         \
+    } while (0)
+            if (h->nzs <= 16) STEP_SHARED(16);
+            else if (h->nzs <= 32) STEP_SHARED(32);
+            else if (h->nzs <= 48) STEP_SHARED(48);
+            else STEP_SHARED(64);
+#undef STEP_SHARED
                 } else if (inst_pending && h->nzs <= 64 && fused && !(getenv("ALMPC_NO_INST_WAVE") && getenv("ALMPC_NO_INST_WAVE")[0] == '1') &&
                            ((size_t)SL.total + (size_t)per_wave + (size_t)h->nz * h->nzs) * sizeof(double) <= 64 * 1024) {
             // small per-instance problems (BASELINE configs[3]): ONE wave per instance for the whole step -- ADMM with the KKT

@@ -1048,7 +1048,9 @@ inline int design_shared_device(hipStream_t stream, int n, int m, int N, int nzs
                                 double* dG, double* dD, std::vector<double>& hH, std::vector<double>& hF,
                                 std::vector<double>& hd, std::string& err, const std::vector<int>& rowsel = std::vector<int>(),
                                 int Rs = 0, double* dGhat = nullptr, double* dGnorm = nullptr, int rho_mode = 0,
-                                double* dRho = nullptr, double* dVsOut = nullptr) {
+                                double* dRho = nullptr, double* dVsOut = nullptr, double* dPlainOut = nullptr) {
+    // dPlainOut (or null): [Minv nz x nzs | H' nz x nzs | F' n x nzs | V n x nzs], the dense column-major operands before they are packed
+    // into MFMA fragments -- what the one-wave-per-instance step of small shared problems reads (k_step_inst_wave with stride 0)
     const int nz = m * N;
     const int useR = R[0] != 0.0, useS = useR && S[0] != 0.0;  // the reference tests only element [1,1]
     auto symmetrise = [](std::vector<double>& M, int k) {
@@ -1119,6 +1121,13 @@ inline int design_shared_device(hipStream_t stream, int n, int m, int N, int nzs
     hipLaunchKernelGGL(k_neg_gm, dim3(32), dim3(256), 0, stream, nz, nzs, n, nzs, dG, dFs, dVs, 0L, 0L);
     hipLaunchKernelGGL(k_pack_frags, dim3(32), dim3(256), 0, stream, dVs, nz, n, nzs, nrb, ksf, dVFrag);
     if (dVsOut) DTRY(hipMemcpyAsync(dVsOut, dVs, (size_t)n * nzs * sizeof(double), hipMemcpyDeviceToDevice, stream));   // (plain V: the s0 table of the state-row finish)
+    if (dPlainOut) {
+        const size_t mm = (size_t)nz * nzs, fv = (size_t)n * nzs;
+        DTRY(hipMemcpyAsync(dPlainOut, dMinv, mm * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        DTRY(hipMemcpyAsync(dPlainOut + mm, dHs, mm * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        DTRY(hipMemcpyAsync(dPlainOut + 2 * mm, dFs, fv * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        DTRY(hipMemcpyAsync(dPlainOut + 2 * mm + fv, dVs, fv * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    }
     hipLaunchKernelGGL(k_pack_frags, dim3(32), dim3(256), 0, stream, dHs, nz, nz, nzs, nrb, ks, dHFrag);
     hipLaunchKernelGGL(k_pack_frags, dim3(32), dim3(256), 0, stream, dFs, nz, n, nzs, nrb, ksf, dFFrag);
     DTRY(hipGetLastError());

@@ -24,6 +24,9 @@ struct AdmmInstParams {
     const double* Minv;   // [batch][nz][nzs]  (H'_i + sigma I + diag(rho_i))^-1, symmetric -- or, for k_admm_inst<true>, its packed
                           // lower triangle [batch][minv_stride], column by column (packed_tri_off): HALF the bytes of the step's stream
     long minv_stride = 0; // doubles per instance of the packed form (even)
+    // admm_wave_body (k_step_inst_wave) only: doubles between two instances' operands -- nz nzs / n nzs / nzs / nz for models per
+    // instance, ZERO for a model shared by the batch (round 5: the one-kernel step of small shared problems)
+    long mat_stride = 0, fv_stride = 0, vec_stride = 0, fs_stride = 0;
     const double* Hs;     // [batch][nz][nzs]  H'_i (warm start only)
     const double* Fs;     // [batch][n][nzs]   F'_i = D_i F_i, column-major
     const double* Vs;     // [batch][n][nzs]   V_i = -H'_i^-1 F'_i
@@ -409,22 +412,22 @@ __device__ __forceinline__ void admm_wave_body(const AdmmInstParams& q, const in
     // ---- loads: row r of M_i^-1 (= column r, symmetric: element (r, c) at c * nzs + r), the row constants, e0
     double mrow[NZC];
     {
-        const double* Mi = GL(q.Minv) + (size_t)inst * nz * nzs + r;
+        const double* Mi = GL(q.Minv) + (size_t)inst * q.mat_stride + r;
 #pragma unroll
         for (int c = 0; c < NZC; ++c) mrow[c] = (c < nz) ? Mi[(size_t)c * nzs] : 0.0;
     }
-    const double dvr = own ? GL(q.dvec)[(size_t)inst * nzs + r] : 1.0;
-    const double rho = own ? GL(q.rhovec)[(size_t)inst * nzs + r] : 1.0;
+    const double dvr = own ? GL(q.dvec)[(size_t)inst * q.vec_stride + r] : 1.0;
+    const double rho = own ? GL(q.rhovec)[(size_t)inst * q.vec_stride + r] : 1.0;
     const double ur = GL(q.uref)[(size_t)inst * q.uref_stride + r];
-    double fs = own ? GL(q.fS)[(size_t)inst * nz + r] : 0.0;
-    double v0 = own ? GL(q.v0S)[(size_t)inst * nz + r] : 0.0;
+    double fs = own ? GL(q.fS)[(size_t)inst * q.fs_stride + r] : 0.0;
+    double v0 = own ? GL(q.v0S)[(size_t)inst * q.fs_stride + r] : 0.0;
     const double e0l = (lane < n) ? GL(q.x0)[(size_t)inst * n + lane] - GL(q.xref)[(size_t)inst * q.xref_stride + lane] : 0.0;
     const double dinv = 1.0 / dvr;
     const double lo = own ? (q.umin[r % q.m] - ur) * dinv : 0.0, hi = own ? (q.umax[r % q.m] - ur) * dinv : 0.0;
     // ---- f' = F'_i e0 + fS, v0 = V_i e0 + v0S: column c of F'_i / V_i is one coalesced load, e0_c comes from lane c
     {
-        const double* Fi = GL(q.Fs) + (size_t)inst * n * nzs + r;
-        const double* Vi = GL(q.Vs) + (size_t)inst * n * nzs + r;
+        const double* Fi = GL(q.Fs) + (size_t)inst * q.fv_stride + r;
+        const double* Vi = GL(q.Vs) + (size_t)inst * q.fv_stride + r;
         for (int c0 = 0; c0 < n; c0 += 4) {
             double fc[4], vc[4];
 #pragma unroll
@@ -445,7 +448,7 @@ __device__ __forceinline__ void admm_wave_body(const AdmmInstParams& q, const in
         const size_t o = (size_t)inst * nzs + r;
         if (own) { x = GL(q.xs)[o]; yt = GL(q.ys)[o] / rho; z = fmin(fmax(GL(q.zs)[o], lo), hi); }
         // px = H'_i x: one product with the instance's scaled Hessian, column by column from global memory
-        const double* Hi = GL(q.Hs) + (size_t)inst * nz * nzs + r;
+        const double* Hi = GL(q.Hs) + (size_t)inst * q.mat_stride + r;
         double a = 0.0;
         for (int c = 0; c < nz; ++c) a += Hi[(size_t)c * nzs] * readlane_d(x, c);
         px = own ? a : 0.0;

@@ -97,3 +97,19 @@ def synthetic_fnn_weights(n=4, m=2, H=16, L=2, seed=0x5EED0004):
 def scale_to_radius(W_out, A0, radius=0.95):
     """W_out rescaled so that the Jacobian at the origin (A0, computed with the unscaled W_out) has the given spectral radius."""
     return W_out * (radius / max(1e-12, float(np.max(np.abs(np.linalg.eigvals(A0))))))
+
+
+def qtp_fixture(N=5):
+    """The reference's own test size (test/computation_mpc_test.jl:981-1054): quadruple-tank model n 4, m 2 as its test fixture
+    test/models_saved/linear_regressor_train_result.jls holds it (Float32 coefficients, widened), N = 5, x_ref 0.65, u_ref 1.2,
+    u in [0, 4] x [0, 3.26], Q = 100 I, R = 0.1 I, no state box.  The matrices are DATA of that fixture (the oracle decodes the
+    same values from the blob: tests/test_host_logic.py keeps the two in step)."""
+    A = np.array([[0.9680719971656799, -0.004229385405778885, 0.020768633112311363, 0.0012167866807430983],
+                  [-0.008298816159367561, 0.9640175700187683, 0.0032141467090696096, 0.018493792042136192],
+                  [-0.01220669038593769, -0.005800441838800907, 0.9852687120437622, 0.0007298348937183619],
+                  [-0.0077879056334495544, -0.011747360229492188, 0.004276304971426725, 0.9848219752311707]])
+    B = np.array([[0.00622002687305212, 4.157558942097239e-05], [9.120091999648139e-05, 0.00806921161711216],
+                  [-0.00022227228328119963, 0.012224327772855759], [0.01440966036170721, -0.00029592248029075563]])
+    return types.SimpleNamespace(A=A, B=B, N=N, n=4, m=2, Q=100.0 * np.eye(4), R=0.1 * np.eye(2), S=np.zeros((2, 2)),
+                                 u_min=np.array([0.0, 0.0]), u_max=np.array([4.0, 3.26]),
+                                 x_ref=0.65 * np.ones((4, N + 1)), u_ref=1.2 * np.ones((2, N)))

@@ -338,6 +338,7 @@ def main():
                          "bench's batch 8..25 are within 1 % of each other (the step ends with the finish of its hardest instance), 4..6 are "
                          "twice as slow (DESIGN.md section 4)")
     ap.add_argument("--no-structured", action="store_true", help="skip the secondary structured-solve (N = 50) figures")
+    ap.add_argument("--no-small-shared", action="store_true", help="skip the secondary small-shared-model figure (the reference's own test size, 65,536 instances)")
     ap.add_argument("--no-state-rows", action="store_true", help="skip the secondary state-row (state box + terminal equality, N = 30) figure")
     ap.add_argument("--no-relin", action="store_true", help="skip the secondary per-step re-linearisation (BASELINE configs[3]) figure")
     ap.add_argument("--no-api-path", action="store_true", help="skip the host-in / host-out figures (api_path_first_move, api_path_full)")
@@ -723,15 +724,21 @@ def main():
         tb = sb.timing_summary()
         rb = sb.get_results(want=("status",))
         nzs_ = 16 * ((NZ + 15) // 16)
-        # k_admm_inst, algorithmic bytes per instance: M_i^-1 (nz x nzs), F'_i and V_i (n x nzs each), d, rho, fS, v0S, x0 in;
-        # x, z, y, v0 out
-        admm_bytes = BATCH_PER_GPU * 8 * (NZ * nzs_ + 2 * NX * nzs_ + 2 * nzs_ + 2 * NZ + NX + 4 * nzs_)
+        # k_admm_inst<true>, algorithmic bytes per instance (round 5): the packed lower triangle of the symmetric M_i^-1 -- nz (nz + 1) / 2
+        # entries + one pad per even column (packed_tri_doubles: 7,320 doubles at nz 120 against the 15,360 of the full nz x nzs layout
+        # that rounds 1 - 4 streamed) --, F'_i and V_i (n x nzs each), d, rho, fS, v0S, x0 in; x, z, y, v0 out
+        tri_ = (NZ * (NZ + 1) // 2 + (NZ + 1) // 2 + 1) & ~1 if NZ % 2 == 0 else NZ * nzs_
+        admm_bytes = BATCH_PER_GPU * 8 * (tri_ + 2 * NX * nzs_ + 2 * nzs_ + 2 * NZ + NX + 4 * nzs_)
+        admm_bytes_full = BATCH_PER_GPU * 8 * (NZ * nzs_ + 2 * NX * nzs_ + 2 * nzs_ + 2 * NZ + NX + 4 * nzs_)
         admm_ms_b = tb["admm_ms"] / max(1, tb["steps"])
         out["per_instance_models"] = {
             "value": kb / elb, "unit": "batch-steps/s (4096 instances, one model per instance)", "ms_per_step": 1e3 * elb / kb,
             "design_ms": 1e3 * t_design, "first_design_ms": 1e3 * t_design_first, "status_counts": np.bincount(rb["status"], minlength=3).tolist(),
             "stage_ms": {k: tb[k] / max(1, tb["steps"]) for k in ("admm_ms", "polish_ms", "total_ms")},
-            "roofline": {"bound": "hbm", "kernel": "k_admm_inst (KKT inverse streamed HBM -> registers once per instance-step)",
+            "roofline": {"bound": "hbm", "kernel": "k_admm_inst<packed> (packed triangle of the KKT inverse streamed HBM -> LDS once per instance-step, gathered into registers)",
+                         "algorithmic_bytes_per_launch_full_matrix_layout": admm_bytes_full,
+                         "note": "half the stream of rounds 1 - 4 at the same kernel time: the kernel is no longer bound by HBM but by the per-instance chain "
+                                 "(gather, gradient, K iterations of ~2.3 k cycles, hand-off) of two workgroups per CU -- frac is of the HBM peak all the same",
                          "achieved": admm_bytes / (admm_ms_b * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": admm_bytes / (admm_ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "traffic": traffic.get("k_admm_inst", {}).get("hbm_bytes_per_launch") if rank == 0 else None,
@@ -849,6 +856,54 @@ def main():
                     "floor of this shape is the sum of those chains (~0.15 ms: 40 pivots at ~1 k cycles per inverse, the ADMM iterations + the finish in "
                     "k_step_inst_wave), not bytes or flops"}
         s3.close()
+        # The same pipeline beyond the condensed horizon (round 5): a quadrotor-size network (n 12, m 4, 24 x 2 tanh) at N = 50 --
+        # m N = 200: no condensed handle exists -- on an ALMPC_FLAG_STRUCTURED handle: Jacobians -> k_sgains -> k_sdual, 256 instances
+        n5, m5, N5, b5 = 12, 4, 50, 256
+        Wi5, Wh5, bh5, Wo5 = wl.synthetic_fnn_weights(n5, m5, H=24, L=2, seed=0x5EED0044)
+        A05, _ = capi.fnn_linearize(Wi5, Wh5, bh5, Wo5, np.zeros((1, n5)), np.zeros((1, m5)), act="tanh", device=dev_index)
+        Wo5 = wl.scale_to_radius(Wo5, A05[0])
+        Al5, Bl5 = capi.fnn_linearize(Wi5, Wh5, bh5, Wo5, np.zeros((1, n5)), np.zeros((1, m5)), act="tanh", device=dev_index)
+        P5 = capi.dare(Al5[0], Bl5[0], 100.0 * np.eye(n5), 0.1 * np.eye(m5))
+        X05 = 0.5 * wl.splitmix_normal(0x5EED0045, 0, b5, n5)
+        s5 = capi.Solver(n5, m5, N5, b5, device=dev_index, structured=True)
+        s5.relin_fnn_setup(Wi5, Wh5, bh5, Wo5, np.zeros((n5, N5 + 1)), np.zeros((m5, N5)), 100.0 * np.eye(n5), 0.1 * np.eye(m5), None, P5,
+                           -0.3 * np.ones(m5), 0.3 * np.ones(m5), act="tanh")
+        s5.update_initialization(X05)
+        s5.relin_fnn_step()
+        best5 = float("inf")
+        for _rep in range(3):
+            t0 = time.perf_counter()
+            for _ in range(10):
+                s5.relin_fnn_step(sync=False)
+            s5.synchronize()
+            best5 = min(best5, (time.perf_counter() - t0) / 10)
+        r5 = s5.get_results(want=("u", "status", "polish_iters"))
+        fo5 = mo.FnnModel(Wi5, Wh5, bh5, Wo5, "tanh")
+        err5 = 0.0
+        for i in range(0, b5, 32):
+            Ai, Bi = fo5.jacobian(X05[i], np.zeros(m5))
+            pi = mo.make_problem(Ai, Bi, N5, -0.3 * np.ones(m5), 0.3 * np.ones(m5), P=P5)
+            err5 = max(err5, float(np.abs(r5["u"][i] - mo.solve_mpc_structured(pi, X05[i])["u"]).max()))
+        bestw5 = float("inf")
+        o5w = capi.default_opts(warm_start=1)
+        for _rep in range(3):
+            s5.update_initialization(X05)
+            s5.relin_fnn_step()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                s5.relin_fnn_advance()
+                s5.relin_fnn_step(o5w, sync=False)
+            s5.synchronize()
+            bestw5 = min(bestw5, (time.perf_counter() - t0) / 20)
+        st5w = s5.get_results(want=("status",))["status"]
+        s5.close()
+        out["relin_structured_N50"] = {"value": 1.0 / best5, "unit": "batch-steps/s (256 instances, Fnn 12-4-24x2 tanh, N=50, re-linearised every step, stage-wise solve)",
+                                       "ms_per_step": 1e3 * best5, "status_counts": np.bincount(r5["status"], minlength=4).tolist(),
+                                       "working_set_changes_mean": float(r5["polish_iters"].mean()), "working_set_changes_max": int(r5["polish_iters"].max()),
+                                       "u_err_inf_sampled": err5,
+                                       "closed_loop_warm": {"ms_per_step": 1e3 * bestw5, "status_counts_last": np.bincount(st5w, minlength=4).tolist()},
+                                       "note": "almpc_relin_fnn_step on an ALMPC_FLAG_STRUCTURED handle: k_fnn_jacobian_w -> k_sgains (Riccati recursion of "
+                                               "every instance's unconstrained problem) -> k_sdual; m N = 200 is beyond the condensed kernels"}
 
     if rank == 0 and world == 1 and not args.no_structured:
         # Secondary figure: the structured (non-condensed) solve -- the benchmark plant over a horizon the condensed kernels cannot take
@@ -947,6 +1002,49 @@ def main():
                                                       "waves per SIMD): a dependent chain of N stages per sweep and two sweeps per working-set change -- latency bound, the "
                                                       "launch ends with its slowest instance (max changes); flops = sweeps x N x 4 (n + m)^2"}}
         ss.close()
+
+    if rank == 0 and world == 1 and not args.no_small_shared:
+        # Secondary figure: the reference's own test size (test/computation_mpc_test.jl:981-1054: quadruple-tank fixture, n 4, m 2, N 5 --
+        # nz 10), library defaults.  One instance = the reference's call (latency), 512 and 65,536 Monte-Carlo initial states around the
+        # reference (throughput).  Up to two instances per CU run ONE kernel per step, one wave per instance (k_step_inst_wave on the
+        # shared operands, round 5); larger batches the tile path (k_admm's 16-instance MFMA tile + k_polish) -- each leg also on the
+        # other path (ALMPC_NO_SHARED_WAVE / ALMPC_SHARED_WAVE_MAX_BATCH) for comparison.
+        pq = wl.qtp_fixture()
+        import mpc_oracle as mo
+        pqo = mo.make_problem(pq.A, pq.B, pq.N, pq.u_min, pq.u_max, x_ref=pq.x_ref[:, 0], u_ref=pq.u_ref[:, 0])
+        legs_q = {}
+        for bq in (1, 512, 65536):
+            Xq = 0.65 + 0.25 * wl.splitmix_normal(0x5EED0051, 0, bq, 4)
+            if bq == 1:
+                Xq[0] = 0.6          # the reference's own initial state (test/computation_mpc_test.jl:1040)
+            row = {}
+            for nm_, env_ in (("default_path", {}), ("two_launch_path", {"ALMPC_NO_SHARED_WAVE": "1"}), ("one_wave_per_instance", {"ALMPC_SHARED_WAVE_MAX_BATCH": "1000000000"})):
+                os.environ.update(env_)
+                try:
+                    sq_ = capi.Solver(pq.n, pq.m, pq.N, bq, device=dev_index)
+                    sq_.design_shared(pq.A, pq.B, pq.Q, pq.R, pq.S, None, pq.u_min, pq.u_max)
+                    sq_.set_reference(pq.x_ref, pq.u_ref)
+                    sq_.update_initialization(Xq)
+                    for _ in range(5):
+                        sq_.calculate()
+                    best = float("inf")
+                    for _rep in range(3):
+                        t0 = time.perf_counter()
+                        for _ in range(50):
+                            sq_.calculate(sync=False)
+                        sq_.synchronize()
+                        best = min(best, (time.perf_counter() - t0) / 50)
+                    rq = sq_.get_results(want=("u", "status"))
+                    sq_.close()
+                finally:
+                    for k_ in env_:
+                        os.environ.pop(k_, None)
+                row[nm_] = {"us_per_step": 1e6 * best, "instance_steps_per_s": bq / best, "unsolved": int((rq["status"] != 0).sum())}
+                if nm_ == "default_path":
+                    row["u_err_inf_sampled"] = max(float(np.abs(rq["u"][i] - mo.solve_mpc_exact(pqo, Xq[i])["u"]).max()) for i in range(0, bq, 4099))
+            legs_q["batch_%d" % bq] = row
+        out["small_shared_qtp"] = dict(legs_q, workload="quadruple-tank fixture of the reference's tests, n 4, m 2, N 5 (nz 10), library defaults (rho 0.1, K <= 25); "
+                                                        "batch 1: x0 = 0.6 as the reference's test")
 
     if rank == 0 and world == 1 and not args.no_state_rows:
         # Secondary figure: the reference's state box on every stage (mpc_state_constraint, ..linear.jl:62-70) + terminal equality

@@ -319,6 +319,11 @@ int almpc_sqp_fnn_set_structured(almpc_handle* h, int on);
  *           (the exact finish makes the two starts equivalent).
  *   advance x0 <- fnn(x0, u[:,1]) on the device: the closed loop of the black-box model itself, no host round trip.
  *   timing  (ALMPC_FLAG_TIMING) milliseconds of the last step's three stages.
+ * On an ALMPC_FLAG_STRUCTURED handle (round 5; m N beyond the condensed limit -- the reference's delegation has no horizon limit,
+ * .../fnn/mpc_modeler_implementation_fnn.jl:23-58) the same calls run the stage-wise route: Jacobians -> the Riccati recursion of
+ * every instance's own unconstrained problem (k_sgains) -> the stage-wise dual active set (k_sdual) with the input box, the state box,
+ * the terminal equality and S; rho / sigma are not used; opts->warm_start = 1 starts from the previous inputs shifted by one stage.
+ * Shape limits of ALMPC_FLAG_STRUCTURED; an instance whose recursion meets a non-positive R + B'PB is left with ALMPC_MAX_ITER.
  */
 int almpc_relin_fnn_setup(almpc_handle* h, int H, int L, int activation, const double* W_in, const double* W_h, const double* b_h,
                           const double* W_out, const double* xref, const double* uref, const double* Q, const double* R,

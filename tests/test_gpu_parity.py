@@ -698,6 +698,58 @@ def test_fused_step_kernel_equals_two_kernel_path(capi, mo):
     assert np.abs(out[True][0]["u"][7] - e["u"]).max() <= U_TOL
 
 
+def test_one_wave_step_of_small_shared_problems_equals_the_two_launch_path(capi, mo, qtp_ab):
+    """Round 5 (review item 8): shared-model problems with nz <= 64 -- configs[0] (double integrator, nz 10), the reference's own test
+    size (QTP fixture, N 5, m 2: test/computation_mpc_test.jl:981-1054) and a mid-size one (N 20: nz 40) -- run ONE kernel per step,
+    one wave per instance (k_step_inst_wave on the shared operands).  Same statuses, same ADMM iteration counts and u within 1e-9 of
+    the two-launch path (ALMPC_NO_SHARED_WAVE=1: k_admm's 16-instance MFMA tile + k_polish), cold and warm, every instance within
+    1e-6 of the exact oracle; no-warm-state option and per-instance references included."""
+    import os
+    cases = []
+    p = mo.double_integrator()
+    cases.append((p, np.array([[1.0, 0.0], [3.0, -1.0], [-4.0, 2.0], [0.2, 0.1], [9.0, 0.0]])))
+    A, B = qtp_ab
+    pq = mo.qtp_linear_fixture_problem(A, B)
+    cases.append((pq, 0.6 + 0.3 * mo.splitmix_normal(7, 0, 37, 4)))
+    pm = mo.make_problem(A, B, 20, [0.0, 0.0], [4.0, 3.26], x_ref=0.65 * np.ones(4), u_ref=1.2 * np.ones(2))
+    cases.append((pm, 0.65 + 0.8 * mo.splitmix_normal(8, 0, 70, 4)))
+    for p, X0 in cases:
+        b = len(X0)
+        out = {}
+        for env in ("0", "1"):
+            os.environ["ALMPC_NO_SHARED_WAVE"] = env
+            try:
+                s = capi.Solver(p.n, p.m, p.N, b)
+                s.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max)
+                s.set_reference(p.x_ref, p.u_ref)
+                s.update_initialization(X0)
+                s.calculate()
+                a = s.get_results()
+                s.update_initialization(X0 * 0.95)
+                s.calculate(capi.default_opts(warm_start=1))
+                w = s.get_results()
+                s.update_initialization(X0)
+                s.calculate(capi.default_opts(keep_warm_state=False))
+                nw = s.get_results()
+                uref_i = np.repeat(p.u_ref[None], b, 0) + 0.01 * np.arange(b)[:, None, None]
+                s.set_reference(np.repeat(p.x_ref[None], b, 0), uref_i, per_instance=True)
+                s.calculate()
+                pi = s.get_results()
+                s.close()
+                out[env] = (a, w, nw, pi)
+            finally:
+                os.environ.pop("ALMPC_NO_SHARED_WAVE", None)
+        for k in range(4):
+            f, t = out["0"][k], out["1"][k]
+            assert np.array_equal(f["status"], t["status"]) and np.all(f["status"] == 0), (p.nz, k)
+            assert np.array_equal(f["iters"], t["iters"]), (p.nz, k)
+            assert np.abs(f["u"] - t["u"]).max() <= 1e-9, (p.nz, k, np.abs(f["u"] - t["u"]).max())
+            assert np.abs(f["x"] - t["x"]).max() <= 1e-8, (p.nz, k)
+        for i in range(0, b, 3):
+            e = mo.solve_mpc_exact(p, X0[i])
+            assert np.abs(out["0"][0]["u"][i] - e["u"]).max() <= U_TOL, (p.nz, i)
+
+
 def test_step_without_warm_state_gives_identical_results(capi, mo):
     """ALMPC_OPT_NO_WARM_STATE (opts.reserved[0]): the step skips the stores of the ADMM x and y (the polish gets the signs of y as
     flag words): bit-identical results on both kernel paths, and a warm start right after such a step is refused."""

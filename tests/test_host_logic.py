@@ -93,6 +93,14 @@ def test_workloads_module_matches_the_oracle_generators(pkg, mo):
     A0, _ = mo.FnnModel(W_in, W_h, b_h, W_out, "tanh").jacobian(np.zeros(4), np.zeros(2))
     assert np.array_equal(W_in, fo.W_in) and np.array_equal(W_h[1], fo.W_h[1]) and np.array_equal(b_h[0], fo.b_h[0])
     assert np.array_equal(wl.scale_to_radius(W_out, A0), fo.W_out)
+    # the reference's own test size: the product-side constants are the values the oracle decodes from the reference-held fixture
+    import os
+    from conftest import ROOT
+    Af, Bf = mo.decode_linear_regressor_fixture(open(os.path.join(ROOT, "tests", "golden", "linear_regressor_train_result.jls"), "rb").read())
+    qf, qfo = wl.qtp_fixture(), mo.qtp_linear_fixture_problem(Af, Bf)
+    assert np.array_equal(qf.A, Af) and np.array_equal(qf.B, Bf)
+    for k in ("Q", "R", "S", "u_min", "u_max", "x_ref", "u_ref"):
+        assert np.array_equal(getattr(qf, k), getattr(qfo, k)), k
 
 
 def test_reference_side_patch_applies_to_the_reference(tmp_path):
