@@ -595,6 +595,36 @@ def feasibility_slack(p: MPCProblem, x0):
     return t
 
 
+def reachability_screen(p: MPCProblem, x0, tol=1e-7):
+    """Restatement of k_state_box_screen (csrc/almpc_sdual.hip.h; round 5): a SOUND, incomplete infeasibility test of the state box
+    (.../linear/mpc_modeler_implementation_linear.jl:62-70).  Coordinate i of x_k = x_ref_k + A^k e0 + sum_{j<k} A^(k-1-j) B (u_j - u_ref_j)
+    ranges over an interval as the inputs range over their box (no other constraint considered: a superset of what is reachable);
+    if that interval misses [x_min_i, x_max_i] no admissible input sequence exists.  Returns the first stage (1..N) at which some
+    coordinate is unreachable, or 0.  `feasibility_slack` (the phase-1 LP) is the complete answer it must never contradict."""
+    if p.x_min is None:
+        return 0
+    n, N = p.n, p.N
+    G = [p.B]
+    for _ in range(1, N):
+        G.append(p.A @ G[-1])
+    e = np.asarray(x0, dtype=np.float64) - p.x_ref[:, 0]
+    width = p.x_max - p.x_min
+    t = tol * np.where(np.isfinite(width) & (width > 0), width, 1.0)
+    for k in range(1, N + 1):
+        e = p.A @ e
+        lo = np.zeros(n)
+        hi = np.zeros(n)
+        for j in range(k):
+            c0 = G[k - 1 - j] * (p.u_min - p.u_ref[:, j])[None, :]
+            c1 = G[k - 1 - j] * (p.u_max - p.u_ref[:, j])[None, :]
+            lo += np.minimum(c0, c1).sum(1)
+            hi += np.maximum(c0, c1).sum(1)
+        xf = e + p.x_ref[:, k]
+        if np.any(xf + lo > p.x_max + t) or np.any(xf + hi < p.x_min - t):
+            return k
+    return 0
+
+
 def solve_mpc_exact(p: MPCProblem, x0, return_info=False):
     """One MPC step, exact (KKT-certified).  Box-only problems: primal active set on the condensed QP.  With the
     state box and/or the terminal equality: dual active set in constraint space (`solve_qp_dual_active_set`),

@@ -1,0 +1,136 @@
+"""Round-5 mechanisms against their own A/B switches (pytest -m gpu): each one changes HOW a result is reached, never the result.
+  * the reachability screen of the state box in front of the stage-wise solve (ALMPC_SDUAL_NO_SCREEN) -- reference: the state box on
+    every stage, .../linear/mpc_modeler_implementation_linear.jl:62-70; every screened verdict is also held against the phase-1 LP;
+  * the capacity tiers of k_sdual handing over the inverse of their working set (ALMPC_SDUAL_NO_SINV_HANDOVER);
+  * the stage-wise redo starting from the working set the state-row finish gave up with (ALMPC_NO_REDO_START);
+  * the packed-triangle KKT inverse of k_admm_inst (ALMPC_NO_PACKED_MINV), even and odd nz.
+The switches are read with getenv at call time, so one process can run both sides."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+XBOX = np.array([3, 3, 3, 1.5, 1.5, 1.5, 0.3, 0.3, 0.3, 1.0, 1.0, 1.0])
+
+
+def _both(env, fn):
+    out = {}
+    for v in ("0", "1"):
+        if v == "1":
+            os.environ[env] = "1"
+        try:
+            out[v] = fn()
+        finally:
+            os.environ.pop(env, None)
+    return out["0"], out["1"]
+
+
+def _mixed_x0(mo, batch, first=0):
+    amp = np.array([0.3, 1.0, 3.0])[np.arange(first, first + batch) % 3]
+    return mo.splitmix_normal(0x5EED0002, first, batch, 12) * mo.QUADROTOR_X0_SCALE[None] * amp[:, None]
+
+
+def test_reachability_screen_changes_no_verdict_and_is_certified_by_the_lp(capi, mo):
+    N, batch = 50, 1536
+    p = mo.make_problem(*mo.quadrotor_model(), N, mo.quadrotor().u_min, mo.quadrotor().u_max, x_min=-XBOX, x_max=XBOX)
+    X0 = np.clip(_mixed_x0(mo, batch), -0.99 * XBOX, 0.99 * XBOX)
+
+    def run():
+        s = capi.Solver(12, 4, N, batch, structured=True)
+        s.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max, xmin=p.x_min, xmax=p.x_max)
+        s.set_reference(p.x_ref, p.u_ref)
+        s.update_initialization(X0)
+        s.calculate()
+        r = s.get_results(want=("u", "status", "polish_iters"))
+        s.close()
+        return r
+    on, off = _both("ALMPC_SDUAL_NO_SCREEN", run)
+    assert np.array_equal(on["status"], off["status"])
+    assert set(np.unique(on["status"])) <= {0, 3}
+    ok = on["status"] == 0
+    assert np.abs(on["u"][ok] - off["u"][ok]).max() <= 1e-9
+    screened = np.flatnonzero((on["status"] == 3) & (on["polish_iters"] == 0))   # decided without a single working-set change
+    assert len(screened) >= 100 and (on["status"] == 3).sum() > len(screened) * 0 + 100
+    for i in list(screened[:6]) + list(screened[-6:]):
+        assert mo.feasibility_slack(p, X0[i]) > 1e-9, i          # the phase-1 LP agrees: no admissible input sequence
+    for i in np.flatnonzero(ok)[:4]:
+        assert mo.feasibility_slack(p, X0[i]) <= 1e-9, i
+
+
+def test_tier_handover_of_the_inverse_changes_nothing(capi, mo):
+    N, batch = 50, 768
+    p = mo.make_problem(*mo.quadrotor_model(), N, mo.quadrotor().u_min, mo.quadrotor().u_max, x_min=-XBOX, x_max=XBOX, terminal="equality")
+    X0 = np.clip(_mixed_x0(mo, batch, first=4096), -0.99 * XBOX, 0.99 * XBOX)
+
+    def run():
+        os.environ["ALMPC_SDUAL_NO_SCREEN"] = "1"      # (so that the infeasible instances do walk the tiers)
+        try:
+            s = capi.Solver(12, 4, N, batch, structured=True)
+            s.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max, xmin=p.x_min, xmax=p.x_max, terminal="equality")
+            s.set_reference(p.x_ref, p.u_ref)
+            s.update_initialization(X0)
+            s.calculate()
+            r = s.get_results(want=("u", "status", "polish_iters"))
+            s.close()
+        finally:
+            os.environ.pop("ALMPC_SDUAL_NO_SCREEN", None)
+        return r
+    on, off = _both("ALMPC_SDUAL_NO_SINV_HANDOVER", run)
+    assert np.array_equal(on["status"], off["status"]) and set(np.unique(on["status"])) <= {0, 3}
+    assert (on["status"] == 3).sum() >= 20                # infeasible instances: their verdict needs ~70 rows, i.e. all three tiers
+    ok = on["status"] == 0
+    assert np.abs(on["u"][ok] - off["u"][ok]).max() <= 1e-8
+    i = int(np.flatnonzero(ok & (on["polish_iters"] >= 10))[0])
+    assert np.abs(on["u"][i] - mo.solve_mpc_exact(p, X0[i])["u"]).max() <= 1e-6
+
+
+def test_redo_started_from_the_finishs_working_set_reaches_the_same_verdicts(capi, mo):
+    p = mo.quadrotor()
+    batch = 4096
+    xmax = np.array([1, 1, 1, .5, .5, .5, .1, .1, .1, .1, .1, .1]) * 3.0
+    X0 = np.clip(mo.quadrotor_x0_batch(batch, 1.0), -0.99 * xmax, 0.99 * xmax)
+
+    def run():
+        s = capi.Solver(12, 4, 30, batch)
+        s.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max, xmin=-xmax, xmax=xmax, rho=30.0, rho_profile="stiffness", terminal="equality")
+        s.set_reference(p.x_ref, p.u_ref)
+        s.update_initialization(X0)
+        s.calculate(capi.default_opts(rho=30.0, max_iter=8, check_every=8))
+        r = s.get_results(want=("u", "status"))
+        s.close()
+        return r
+    on, off = _both("ALMPC_NO_REDO_START", run)
+    assert np.array_equal(on["status"], off["status"]) and set(np.unique(on["status"])) <= {0, 3}
+    ok = on["status"] == 0
+    assert np.abs(on["u"][ok] - off["u"][ok]).max() <= 1e-9
+
+
+@pytest.mark.parametrize("m,N", [(4, 30), (3, 23)])      # nz 120 (packed triangle), nz 69 (odd: the full layout stays)
+def test_packed_kkt_inverse_of_the_per_instance_step(capi, mo, m, N):
+    n, batch = 6, 96
+    rng = np.random.default_rng(5)
+    A0 = 0.9 * np.eye(n) + 0.08 * rng.standard_normal((n, n))
+    B0 = rng.standard_normal((n, m)) * 0.3
+    A = np.repeat(A0[None], batch, 0) + 0.02 * rng.standard_normal((batch, n, n))
+    B = np.repeat(B0[None], batch, 0) * (1.0 + 0.05 * rng.standard_normal((batch, 1, 1)))
+    X0 = 2.0 * rng.standard_normal((batch, n))
+    umin, umax = -0.4 * np.ones(m), 0.4 * np.ones(m)
+
+    def run():
+        s = capi.Solver(n, m, N, batch)
+        s.design_batched(A, B, 100.0 * np.eye(n), 0.1 * np.eye(m), None, None, umin, umax)
+        s.update_initialization(X0)
+        s.calculate(capi.default_opts(max_iter=12, check_every=12))
+        r = s.get_results(want=("u", "status", "iters"))
+        s.calculate(capi.default_opts(max_iter=12, check_every=12, warm_start=1))
+        w = s.get_results(want=("u", "status"))
+        s.close()
+        return r, w
+    (on, onw), (off, offw) = _both("ALMPC_NO_PACKED_MINV", run)
+    assert np.all(on["status"] == 0) and np.all(off["status"] == 0) and np.array_equal(on["iters"], off["iters"])
+    assert np.abs(on["u"] - off["u"]).max() <= 1e-9 and np.abs(onw["u"] - offw["u"]).max() <= 1e-9
+    for i in range(0, batch, 17):
+        pi = mo.make_problem(A[i], B[i], N, umin, umax)
+        assert np.abs(on["u"][i] - mo.solve_mpc_exact(pi, X0[i])["u"]).max() <= 1e-6, i

@@ -536,3 +536,28 @@ def test_saturated_lqr_seed_is_a_superset_guess_and_the_finish_does_not_depend_o
             zero_changes += int(b["n_add"] + b["n_remove"] + b["n_purged"] == 0)
             assert np.all((side != 0) | (a["side"] == 0))      # final set inside the LQR seed
     assert zero_changes == 3
+
+
+def test_reachability_screen_never_contradicts_the_phase1_lp(mo):
+    """The interval screen of the state box (k_state_box_screen; round 5) is a necessary condition of feasibility: whatever it rejects
+    the phase-1 LP rejects too, and on the benchmark's clipped states it finds most of the infeasible instances at stage 1."""
+    xbox = np.array([3, 3, 3, 1.5, 1.5, 1.5, 0.3, 0.3, 0.3, 1.0, 1.0, 1.0])
+    q = mo.quadrotor(20)
+    p = mo.make_problem(q.A, q.B, 20, q.u_min, q.u_max, x_min=-xbox, x_max=xbox)
+    amp = np.array([0.3, 1.0, 3.0])
+    caught = lp_inf = 0
+    for i in range(60):
+        x0 = np.clip(mo.quadrotor_x0_batch(1, amp[i % 3], first_instance=i)[0], -0.99 * xbox, 0.99 * xbox)
+        k = mo.reachability_screen(p, x0)
+        inf = mo.feasibility_slack(p, x0) > 1e-9
+        assert not (k and not inf), (i, k)        # sound
+        caught += bool(k)
+        lp_inf += bool(inf)
+    assert lp_inf >= 8 and caught >= lp_inf - 3     # incomplete, but close on this workload
+    # a time-varying input reference and a non-zero state reference go through the same rule
+    pr = mo.make_problem(q.A, q.B, 20, q.u_min, q.u_max, x_min=-xbox, x_max=xbox, x_ref=0.2 * np.ones(12),
+                         u_ref=0.01 * np.sin(np.arange(20))[None, :] * np.ones((4, 1)))
+    for i in range(12):
+        x0 = np.clip(mo.quadrotor_x0_batch(1, 3.0, first_instance=100 + i)[0], -0.99 * xbox, 0.99 * xbox)
+        if mo.reachability_screen(pr, x0):
+            assert mo.feasibility_slack(pr, x0) > 1e-9, i
