@@ -190,6 +190,7 @@ struct almpc_handle {
         int32_t* ovf = nullptr;
         int32_t* wsave = nullptr;   // [batch][SDUAL_WSAVE] working set of an instance that ran out of room (start of the next tier)
         double* sinv_save = nullptr;   // [batch][sdual_sinv_doubles(SDUAL_SINV_SAVE)] its inverse (allocated at the first multi-tier solve)
+        double* start_inv = nullptr;   // [batch][sdual_sinv_doubles(SDUAL_SINV_SAVE)] inverse of a redo's start (k_sdual_start; allocated at the first such redo)
         int32_t* start_ws = nullptr;   // [batch][64] working sets the state-row finish of the LAST step gave up with (PolishGenParams::redo_ws)
         bool start_ws_fresh = false;   // ... written by the last enqueued step (cleared by every step that does not run that finish)
         double* sinv_glb = nullptr; size_t sinv_cap = 0;   // third tier: Sinv of 128 x 129 per wave of its grid
@@ -324,7 +325,7 @@ void free_all(almpc_handle* h) {
     if (h->comm && rccl_api().ok) (void)rccl_api().CommDestroy(h->comm);
     for (void* p : {(void*)h->dComm4, (void*)h->dU0, (void*)h->dU0all, (void*)h->rQ, (void*)h->rR, (void*)h->rP, (void*)h->rKst, (void*)h->rPst, (void*)h->rGuess,
                     (void*)h->sd.rec, (void*)h->sd.base, (void*)h->sd.xmin, (void*)h->sd.xmax, (void*)h->sd.eqt, (void*)h->sd.ovf, (void*)h->sd.wsave, (void*)h->sd.sinv_glb, (void*)h->sd.ghat, (void*)h->sd.dQ, (void*)h->sd.dR, (void*)h->sd.dS, (void*)h->sd.dP, (void*)h->sd.bad, (void*)h->sd.pc, (void*)h->sd.ct,
-                    (void*)h->sd.sinv_save, (void*)h->sd.start_ws, (void*)h->sd.scr_phi, (void*)h->sd.scr_g, (void*)h->sd.scr_rm, (void*)h->sd.scr_rp, (void*)h->sd.scr_verdict})
+                    (void*)h->sd.sinv_save, (void*)h->sd.start_inv, (void*)h->sd.start_ws, (void*)h->sd.scr_phi, (void*)h->sd.scr_g, (void*)h->sd.scr_rm, (void*)h->sd.scr_rp, (void*)h->sd.scr_verdict})
         if (p) (void)hipFree(p);
     if (h->ev_guess) (void)hipEventDestroy(h->ev_guess);
     if (h->ev_guess_done) (void)hipEventDestroy(h->ev_guess_done);
@@ -892,10 +893,43 @@ hipError_t launch_sdual(almpc_handle* h, int filter, const double* guess, int ma
         tier0 = (fits128 && (getenv("ALMPC_SDUAL_REDO_128") || h->redo_gate_on)) ? 2 : 1;   // (a gated redo: one launch)
         tier1 = fits128 ? 2 : 1;
     }
+    // the redo's start (the finish's working set + the terminal-equality rows) with its inverse, built in registers from the cached
+    // responses before the solve: k_sdual_start (csrc/almpc_sdual.hip.h)
+    if (sp.start_ws && sp.ghat && tier0 >= 1 && !getenv("ALMPC_SDUAL_NO_START_BUILD")) {
+        almpc_handle::Sd& sdw = h->sd;
+        if (!sdw.start_inv) {
+            const hipError_t e_ = dalloc(&sdw.start_inv, (size_t)h->batch * sdual_sinv_doubles(SDUAL_SINV_SAVE));
+            if (e_ != hipSuccess) return e_;
+        }
+        SdualStartParams tp;
+        std::memset(&tp, 0, sizeof(tp));
+        tp.batch = h->batch; tp.n = h->n; tp.N = h->N; tp.SP = sd.NT + sd.MC; tp.TP = sdual_tp(sd.NT, sd.MC, h->N);
+        tp.wcap = tier0 == 1 ? SD_WCAP2 : SD_WCAP4; tp.has_eq = sd.has_eq ? 1 : 0;
+        tp.status = h->dStatus; tp.gate = sp.gate; tp.gate_val = sp.gate_val;
+        tp.ghat = sp.ghat; tp.start_ws = sdw.start_ws; tp.start_inv = sdw.start_inv;
+        int wgs = (h->batch + SDUAL_START_WAVES - 1) / SDUAL_START_WAVES;
+        if (wgs > h->num_cus * 2) wgs = h->num_cus * 2;
+        hipLaunchKernelGGL(k_sdual_start, dim3(wgs), dim3(64 * SDUAL_START_WAVES), 0, h->stream, tp);
+        const hipError_t e_ = hipGetLastError();
+        if (e_ != hipSuccess) return e_;
+        sp.start_inv = sdw.start_inv;
+    }
 #define SD_CASE(NT_, MC_) if (sd.NT == NT_ && sd.MC == MC_) return launch_sdual_t<NT_, MC_>(h, sp, tier0, tier1)
     SD_CASE(2, 2); SD_CASE(4, 2); SD_CASE(6, 2); SD_CASE(8, 4); SD_CASE(12, 4); SD_CASE(16, 4); SD_CASE(16, 8); SD_CASE(32, 16); SD_CASE(48, 16);
 #undef SD_CASE
     return hipErrorInvalidValue;
+}
+
+// Wait for the handle's stream: poll for a while before the blocking wait, whose wake-up (interrupt + scheduler) costs 0.1 - 15 ms on
+// this pool -- more than the kernels waited for.
+hipError_t stream_wait_polling(almpc_handle* h) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipStreamQuery(h->stream);
+        if (q != hipErrorNotReady) return q;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
+    }
+    return hipStreamSynchronize(h->stream);
 }
 
 // Lazy redo (see almpc_handle::hUnsolved): called where the host is about to look at results and the stream is idle.  If the finish of
@@ -914,7 +948,7 @@ int resolve_lazy_redo(almpc_handle* h) {
         HIP_TRY(h, launch_sdual(h, 1, h->dU, 0, true));
     }
     if (h->mc == 0 && !h->useS && h->rKst) HIP_TRY(h, launch_riccati(h, 1, h->dU, 0));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, stream_wait_polling(h));   // (a redo is 0.1 - 0.4 ms of kernels: the blocking wait's wake-up alone was seen to double that)
     return ALMPC_OK;
 }
 

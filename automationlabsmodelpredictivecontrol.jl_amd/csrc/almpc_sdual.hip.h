@@ -78,7 +78,12 @@ struct SdualParams {
     // start_ws (or null): [batch][64] working set a condensed finish gave up with (PolishGenParams::redo_ws: count, then codes as in
     // wsave): the start list of its redo, in place of the inputs of uguess that sit on a bound
     const int32_t* start_ws = nullptr;
+    // start_inv (or null): [batch][sdual_sinv_doubles(SDUAL_SINV_SAVE)] -- k_sdual_start ran before this launch: an entry of start_ws whose
+    // count carries SDUAL_START_BUILT lists the COMPLETE start (terminal-equality rows first, dependent rows left out) and its inverse is
+    // here (packed lower triangle): the working set is installed as it stands, no response and no bordering per row
+    const double* start_inv = nullptr;
 };
+constexpr int SDUAL_START_BUILT = 1 << 16;
 
 __host__ __device__ inline int sdual_tp(int NT, int MC, int N) { return (N * (NT + MC) + NT + 1) & ~1; }
 __host__ __device__ inline int sdual_sinv_doubles(int wcap) { return (wcap * (wcap + 1) / 2 + 1) & ~1; }   // packed lower triangle
@@ -278,6 +283,7 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
 #ifdef ALMPC_STAMPS
         long long sd_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sd_t = 0;
         long long sd_nbw = 0, sd_nfw = 0;
+        const long long sd_body0 = __builtin_readcyclecounter(), sd_wall0 = __builtin_amdgcn_s_memrealtime();
 #endif
         const double* recg = p.rec + (size_t)inst * p.rec_stride;
         if constexpr (GH) { if (p.rec_kstride == 0) recg = recl; }   // (stage-invariant records: the workgroup's copy in LDS)
@@ -682,6 +688,7 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
         // multiplier has the wrong sign leave, then the full solve.  Reached from the last M_START pass, or directly when a smaller tier
         // handed over its working set WITH its inverse (M_STARTED: no sweep).
         auto settle_start = [&]() {
+                SD_T0();
                 // multipliers of the start from s0; rows whose multiplier has the wrong sign leave, worst first
                 while (nW > 0) {
                     double dv[PPL], lw[PPL];
@@ -711,6 +718,7 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
                     sd_fence();
                     remove_pos(pos);   // (not counted as an iteration: no sweep, O(|W|^2) -- the count is of scans + steps)
                 }
+                SD_ACC(5);
                 if (nW > 0) { mode = M_FULL; after = A_TOP; }
                 else mode = M_TOP;
         };
@@ -868,15 +876,10 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
                     ns = 0;
                     int kg = -1;
                     bool handed = false;
-                    if (p.only_ovf && p.wsave) {
-                        const int cnt = p.ovf[inst] - 1;
-                        for (int i = lane; i < cnt; i += 64) slist[i] = p.wsave[(size_t)inst * SDUAL_WSAVE + i];
-                        ns = cnt;
-                        kg = N;
-                        if (p.sinv_save && cnt > 0 && cnt <= SDUAL_SINV_SAVE && cnt < wcap) {
-                            // the previous tier's inverse: the working set is installed as it stood -- no response, no bordering per row
+                    // a working set whose inverse is at hand (the previous tier's, or the one k_sdual_start built): installed as it stands
+                    // -- no response, no bordering per row.  slist holds its cnt codes.
+                    auto install = [&](const double* sv, int cnt) {
                             sd_fence();
-                            const double* sv = p.sinv_save + (size_t)inst * sdual_sinv_doubles(SDUAL_SINV_SAVE);
                             const int cntd = (cnt * (cnt + 1)) >> 1;
                             for (int i = lane; i < cntd; i += 64) {
                                 if constexpr (BIG) __hip_atomic_store(SinvG + i, sv[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -902,7 +905,21 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
                             nW = cnt;
                             sfence();
                             handed = true;
-                        }
+                    };
+                    const int32_t* rw = p.start_ws ? p.start_ws + (size_t)inst * 64 : nullptr;
+                    if (p.only_ovf && p.wsave) {
+                        const int cnt = p.ovf[inst] - 1;
+                        for (int i = lane; i < cnt; i += 64) slist[i] = p.wsave[(size_t)inst * SDUAL_WSAVE + i];
+                        ns = cnt;
+                        kg = N;
+                        if (p.sinv_save && cnt > 0 && cnt <= SDUAL_SINV_SAVE && cnt < wcap)
+                            install(p.sinv_save + (size_t)inst * sdual_sinv_doubles(SDUAL_SINV_SAVE), cnt);
+                    } else if (rw && p.start_inv && (rw[0] & SDUAL_START_BUILT)) {
+                        const int cnt = rw[0] & (SDUAL_START_BUILT - 1);
+                        if (lane < cnt) slist[lane] = rw[1 + lane];
+                        ns = cnt;
+                        kg = N;
+                        if (cnt > 0) install(p.start_inv + (size_t)inst * sdual_sinv_doubles(SDUAL_SINV_SAVE), cnt);
                     } else {
                         if (has_eq) {
                             if (lane < n) slist[lane] = ((N * SP + lane) << 2) | 2;
@@ -910,8 +927,7 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
                             kg = N;
                         }
                         int nws = 0;
-                        if (p.start_ws) {
-                            const int32_t* rw = p.start_ws + (size_t)inst * 64;
+                        if (rw) {
                             nws = rw[0];
                             if (nws > wcap - 16 - ns) nws = wcap - 16 - ns > 0 ? wcap - 16 - ns : 0;   // (room left for what the method still has to add)
                             if (lane < nws) slist[ns + lane] = rw[1 + lane];
@@ -1072,6 +1088,8 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
             for (int c_ = 0; c_ < 6; ++c_) g_stamps[(size_t)inst * 16 + c_] = sd_acc[c_];
             g_stamps[(size_t)inst * 16 + 8] = it; g_stamps[(size_t)inst * 16 + 9] = sd_nbw; g_stamps[(size_t)inst * 16 + 10] = sd_nfw;
             g_stamps[(size_t)inst * 16 + 11] = nW;
+            g_stamps[(size_t)inst * 16 + 6] = __builtin_readcyclecounter() - sd_body0;   // (the whole solve of this instance)
+            g_stamps[(size_t)inst * 16 + 12] = sd_wall0; g_stamps[(size_t)inst * 16 + 13] = __builtin_amdgcn_s_memrealtime();   // (100 MHz)
         }
 #endif
         // ---- outputs
@@ -1101,6 +1119,116 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
             p.piters[inst] = it;
             if (p.filter == 2 && st_out == 0) p.flag[inst] = 0;
         }
+        sd_fence();
+    }
+}
+
+// ---- start of a redo, built in registers (round 5) ---------------------------------------------------------------------------------
+// The redo behind a state-row finish starts from the working set the finish gave up with (SdualParams::start_ws) plus the terminal-equality
+// rows: 40 - 48 rows on the benchmark's edge-of-feasibility instances.  k_sdual borders them in one at a time -- a column load, a product
+// with Sinv and a rank-one update through LDS per row, 10 k cycles each: 400 k of the 550 k cycles such an instance took.  With a shared
+// model the matrix G_WW is a GATHER from the cached responses (ghat[t_i][t_j]), and its inverse a symmetric Gauss-Jordan sweep that runs
+// in registers: lane i holds row i (64 doubles), the pivot row goes through 512 bytes of LDS (one lane writes it, every lane reads it
+// back as broadcasts, and reads its own element of the pivot COLUMN from it -- the matrix stays symmetric).  Rows are swept in list order,
+// so the pivot of row k is its Schur complement on the rows accepted before it -- exactly the quantity the bordering tests: a dependent
+// row (pivot <= 1e-12 G_kk) is left out, as there.  One wave per instance, 1.6 k cycles per row at 41 rows.
+// Output: the inverse (packed lower triangle of the accepted rows, in list order) to start_inv, the accepted codes back into start_ws
+// with SDUAL_START_BUILT in the count.  Sweep convention: after the rows K,  M_KK = -(G_KK)^-1,  M_iK = G_iK (G_KK)^-1,  the rest the Schur
+// complement.
+struct SdualStartParams {
+    int batch, n, N, SP, TP, wcap, has_eq;
+    const int32_t* status;      // [batch]: instances with status 1 only
+    const int* gate; int gate_val;
+    const double* ghat;         // [TP][TP]
+    int32_t* start_ws;          // [batch][64], in and out
+    double* start_inv;          // [batch][sdual_sinv_doubles(SDUAL_SINV_SAVE)]
+};
+constexpr int SDUAL_START_WAVES = 4;
+
+inline __global__ __launch_bounds__(64 * SDUAL_START_WAVES) void k_sdual_start(SdualStartParams p) {
+    static_assert(SDUAL_SINV_SAVE == 64, "one row of the start per lane");
+    __shared__ __attribute__((aligned(16))) double s_prow[SDUAL_START_WAVES][64];
+    __shared__ double s_gd[SDUAL_START_WAVES][64];
+    __shared__ int s_code[SDUAL_START_WAVES][64];
+    if (p.gate && __builtin_nontemporal_load(p.gate) != p.gate_val) return;
+    const int wv = threadIdx.x >> 6, lane0 = threadIdx.x & 63;
+    double* pw = s_prow[wv];
+    double* gd = s_gd[wv];
+    int* code = s_code[wv];
+    const int TP = p.TP;
+    for (int inst = blockIdx.x * SDUAL_START_WAVES + wv; inst < p.batch; inst += gridDim.x * SDUAL_START_WAVES) {
+        if (p.status[inst] != 1) continue;
+        int32_t* rw = p.start_ws + (size_t)inst * 64;
+        const int head = rw[0];
+        if (head & SDUAL_START_BUILT) continue;   // (built by an earlier launch behind the same step)
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        // the list, as k_sdual would assemble it: terminal-equality rows, then the finish's rows as far as the capacity allows
+        const int ne = p.has_eq ? p.n : 0;
+        int nws = head;
+        const int room = (p.wcap - 16 < 63 ? p.wcap - 16 : 63) - ne;
+        if (nws > room) nws = room > 0 ? room : 0;
+        const int cnt = ne + nws;
+        int mycode = 0;
+        if (lane < ne) mycode = ((p.N * p.SP + lane) << 2) | 2;
+        else if (lane < cnt) mycode = rw[1 + lane - ne];
+        code[lane] = mycode;
+        const int ti = mycode >> 2;
+        sd_fence();
+        double r[64];
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            r[j] = 0.0;
+            if (j < cnt) {   // (uniform)
+                const int tj = __builtin_amdgcn_readfirstlane(code[j]) >> 2;
+                const size_t a = lane >= j ? (size_t)ti * TP + tj : (size_t)tj * TP + ti;
+                if (lane < cnt) r[j] = p.ghat[a];
+            }
+        }
+        gd[lane] = lane < cnt ? p.ghat[(size_t)ti * TP + ti] : 1.0;
+        sd_fence();
+        unsigned long long acc = 0ull;   // accepted rows
+        for (int k = 0; k < cnt; ++k) {
+            if (lane == k) {
+#pragma unroll
+                for (int j = 0; j < 64; j += 2) *reinterpret_cast<double2*>(pw + j) = make_double2(r[j], r[j + 1]);
+            }
+            sd_fence();
+            const double col = pw[lane];
+            const double d = pw[k];
+            if (!(d > 1e-12 * gd[k])) { sd_fence(); continue; }   // dependent on the rows before it: left out
+            acc |= 1ull << k;
+            const double invd = 1.0 / d;
+            const double f = col * invd;
+            const bool piv = lane == k;
+#pragma unroll
+            for (int j0 = 0; j0 < 64; j0 += 8) {
+                if (j0 < cnt) {
+#pragma unroll
+                    for (int j = j0; j < j0 + 8; j += 2) {
+                        const double2 pj = *reinterpret_cast<const double2*>(pw + j);
+                        const double u0 = fma(-f, pj.x, r[j]), u1 = fma(-f, pj.y, r[j + 1]);
+                        r[j] = j == k ? (piv ? -invd : f) : (piv ? pj.x * invd : u0);
+                        r[j + 1] = j + 1 == k ? (piv ? -invd : f) : (piv ? pj.y * invd : u1);
+                    }
+                }
+            }
+            sd_fence();   // (the pivot row is read before the next one is written)
+        }
+        // ---- out: accepted rows in list order
+        const int na = __popcll(acc);
+        const bool mine = lane < cnt && ((acc >> lane) & 1ull);
+        const int pi = __popcll(acc & ((1ull << lane) - 1ull));
+        double* out = p.start_inv + (size_t)inst * sdual_sinv_doubles(SDUAL_SINV_SAVE);
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            if (j < cnt && ((acc >> j) & 1ull)) {   // (uniform)
+                const int pj = __popcll(acc & ((1ull << j) - 1ull));
+                if (mine && lane >= j) out[(pi * (pi + 1) >> 1) + pj] = -r[j];
+            }
+        }
+        if (mine) rw[1 + pi] = mycode;
+        if (lane == 0) rw[0] = na | SDUAL_START_BUILT;
         sd_fence();
     }
 }

@@ -107,6 +107,42 @@ def test_redo_started_from_the_finishs_working_set_reaches_the_same_verdicts(cap
     assert np.abs(on["u"][ok] - off["u"][ok]).max() <= 1e-9
 
 
+@pytest.mark.parametrize("box,cap", [(1.0, 0), (3.0, 3), (3.0, 12)])
+def test_redo_start_built_in_registers_equals_the_bordered_one(capi, mo, box, cap):
+    """k_sdual_start (the start's inverse as a Gauss-Jordan sweep in registers, from the cached responses) against k_sdual's own
+    row-by-row bordering of the same list (ALMPC_SDUAL_NO_START_BUILD).  box 1.0: the benchmark's edge-of-feasibility instances (the redo
+    ends in an infeasibility verdict); box 3.0 with the finish capped at `cap` changes: feasible instances handed over half-way, whose
+    redo must end in the optimum -- held against the exact solver of the oracle as well."""
+    p = mo.quadrotor()
+    batch = 1024
+    xmax = box * np.array([1, 1, 1, .5, .5, .5, .1, .1, .1, .1, .1, .1]) * 3.0
+    X0 = np.clip(mo.quadrotor_x0_batch(batch, 1.0), -0.99 * xmax, 0.99 * xmax)
+
+    def run(fallback=None):
+        s = capi.Solver(12, 4, 30, batch, structured_fallback=fallback)
+        s.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max, xmin=-xmax, xmax=xmax, rho=30.0, rho_profile="stiffness", terminal="equality")
+        s.set_reference(p.x_ref, p.u_ref)
+        s.update_initialization(X0)
+        o = capi.default_opts(rho=30.0, max_iter=8, check_every=8)
+        if cap:
+            o.polish_max_iter = cap
+        s.calculate(o)
+        r = s.get_results(want=("u", "status", "polish_iters"))
+        s.close()
+        return r
+    built, bordered = _both("ALMPC_SDUAL_NO_START_BUILD", run)
+    assert np.array_equal(built["status"], bordered["status"]) and set(np.unique(built["status"])) <= {0, 3}
+    ok = built["status"] == 0
+    assert np.abs(built["u"][ok] - bordered["u"][ok]).max() <= 1e-9
+    if cap:
+        alone = run(fallback=False)   # what the finish alone leaves: the redo must have had work to do
+        redone = np.flatnonzero((alone["status"] == 1) & ok)
+        assert len(redone) >= (20 if cap <= 3 else 1)
+        pb = mo.make_problem(*mo.quadrotor_model(), 30, p.u_min, p.u_max, x_min=-xmax, x_max=xmax, terminal="equality")
+        for i in redone[:3]:
+            assert np.abs(built["u"][i] - mo.solve_mpc_exact(pb, X0[i])["u"]).max() <= 1e-6
+
+
 @pytest.mark.parametrize("m,N", [(4, 30), (3, 23)])      # nz 120 (packed triangle), nz 69 (odd: the full layout stays)
 def test_packed_kkt_inverse_of_the_per_instance_step(capi, mo, m, N):
     n, batch = 6, 96

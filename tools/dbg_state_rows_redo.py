@@ -39,6 +39,8 @@ for case in cases:
           f"{len(bad)} left by the finish")
     if os.environ.get("STAMPS"):
         names = ["sweeps: backward", "sweeps: forward", "scan", "Sinv c, sources / columns", "ratio test, step", "border / remove"]
+        w0 = stamps[bad, 12].min()
+        print("   wall clock (us from the first body start): " + ", ".join(f"{i}: {(stamps[i, 12] - w0) / 100:.0f}..{(stamps[i, 13] - w0) / 100:.0f} ({int(stamps[i, 6])} cyc)" for i in bad))
         for i in bad[:6]:
             print(f"   instance {i}: k_sdual cycles " + ", ".join(f"{nm} {int(stamps[i, c])}" for c, nm in enumerate(names)) + f"; changes {stamps[i, 8]}, bw stages {stamps[i, 9]}, fw stages {stamps[i, 10]}, rows {stamps[i, 11]}")
     for i in bad[:16]:
