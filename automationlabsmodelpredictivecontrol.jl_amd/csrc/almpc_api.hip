@@ -163,6 +163,8 @@ struct almpc_handle {
     int* dRedoGate = nullptr;
     int step_serial = 0;                 // number of the last enqueued step (1, 2, ...)
     bool redo_gate_on = false;           // set around the launches of a gated redo
+    bool redo_expected = false;          // the last synchronous look found undecided instances (see wait_and_settle)
+    bool redo_predicted = false;         // set around the launches of a gated redo that is EXPECTED to have work (tier policy of a plain redo)
     bool flag_in_finish = false;   // transient (re-linearisation step): the finish turns a flagged design into ALMPC_NON_FINITE itself
     int fallback = 2;   // 0 off, 1 asked for (a design it cannot serve is an error), 2 default: on wherever the stage-wise solvers cover the design
     double *rQ = nullptr, *rR = nullptr, *rP = nullptr, *rKst = nullptr, *rPst = nullptr;   // device copies of Q, R (branch rule applied), shared P; gain scratch
@@ -190,6 +192,7 @@ struct almpc_handle {
         int32_t* ovf = nullptr;
         int32_t* wsave = nullptr;   // [batch][SDUAL_WSAVE] working set of an instance that ran out of room (start of the next tier)
         double* sinv_save = nullptr;   // [batch][sdual_sinv_doubles(SDUAL_SINV_SAVE)] its inverse (allocated at the first multi-tier solve)
+        int tier_serial = 0;           // number of the last launch_sdual_t call (the tiers' gate value)
         double* start_inv = nullptr;   // [batch][sdual_sinv_doubles(SDUAL_SINV_SAVE)] inverse of a redo's start (k_sdual_start; allocated at the first such redo)
         int32_t* start_ws = nullptr;   // [batch][64] working sets the state-row finish of the LAST step gave up with (PolishGenParams::redo_ws)
         bool start_ws_fresh = false;   // ... written by the last enqueued step (cleared by every step that does not run that finish)
@@ -550,9 +553,9 @@ int sdual_setup_shared(almpc_handle* h, const hm::mat& Am, const hm::mat& Bm, co
         HIP_TRY(h, hipMemcpy(sd.xmax, xmax, n * sizeof(double), hipMemcpyHostToDevice));
     }
     sd.has_eq = terminal_eq;
-    if (!sd.ovf) HIP_TRY(h, dalloc(&sd.ovf, (size_t)h->batch));
+    if (!sd.ovf) HIP_TRY(h, dalloc(&sd.ovf, (size_t)h->batch + 2));   // (+ the tiers' gate word: SdualParams::ovf_gate)
     if (!sd.wsave) HIP_TRY(h, dalloc(&sd.wsave, (size_t)h->batch * SDUAL_WSAVE));
-    HIP_TRY(h, hipMemset(sd.ovf, 0, (size_t)h->batch * sizeof(int32_t)));
+    HIP_TRY(h, hipMemset(sd.ovf, 0, ((size_t)h->batch + 2) * sizeof(int32_t)));
     sd.S = Sm ? *Sm : hm::mat();
     sd.has_base = false; sd.base_stride = 0;
     sd.per_instance = false; sd.gain_N = 0; sd.sqp = false;
@@ -669,8 +672,8 @@ int sdual_setup_batched(almpc_handle* h, const hm::mat& Qm, const hm::mat& Rm, c
         HIP_TRY(h, hipMemcpy(sd.xmax, xmax, n * sizeof(double), hipMemcpyHostToDevice));
     }
     sd.has_eq = terminal_eq;
-    if (!sd.ovf) HIP_TRY(h, dalloc(&sd.ovf, (size_t)h->batch));
-    HIP_TRY(h, hipMemset(sd.ovf, 0, (size_t)h->batch * sizeof(int32_t)));
+    if (!sd.ovf) HIP_TRY(h, dalloc(&sd.ovf, (size_t)h->batch + 2));   // (+ the tiers' gate word: SdualParams::ovf_gate)
+    HIP_TRY(h, hipMemset(sd.ovf, 0, ((size_t)h->batch + 2) * sizeof(int32_t)));
     if (!sd.wsave) HIP_TRY(h, dalloc(&sd.wsave, (size_t)h->batch * SDUAL_WSAVE));
     if (!sd.bad) HIP_TRY(h, dalloc(&sd.bad, (size_t)h->batch));
     HIP_TRY(h, hipMemset(sd.bad, 0, (size_t)h->batch * sizeof(int)));
@@ -738,6 +741,9 @@ hipError_t launch_sdual_t(almpc_handle* h, SdualParams sp, int tier0, int tier1)
         }
         sp.sinv_save = h->sd.sinv_save;
     }
+    // the later tiers return at once unless an earlier one of THIS call ran out of room (it stores the call's number in the gate word):
+    // their scan for flagged instances alone is 16 dependent loads per wave, 9 us of an idle launch on 4096 instances
+    if (sp.ovf && !sp.build_ghat) { sp.ovf_gate = sp.ovf + sp.batch; sp.ovf_gate_val = ++h->sd.tier_serial; }
     for (int tier = tier0; tier <= tier1; ++tier) {
         sp.wcap = tier == 0 ? SD_WCAP1 : (tier == 1 ? SD_WCAP2 : SD_WCAP4);
         sp.only_ovf = tier > tier0;
@@ -890,7 +896,7 @@ hipError_t launch_sdual(almpc_handle* h, int filter, const double* guess, int ma
         // (round 5: the 64-row build first -- one working-set position per lane: its Sinv products, borderings and column streams are
         // cheaper per change than the 128-row build's -- and the 128-row build only for what outgrows it, which costs little since the
         // tiers hand over their inverse; ALMPC_SDUAL_REDO_128=1: the one 128-row launch of round 4)
-        tier0 = (fits128 && (getenv("ALMPC_SDUAL_REDO_128") || h->redo_gate_on)) ? 2 : 1;   // (a gated redo: one launch)
+        tier0 = (fits128 && (getenv("ALMPC_SDUAL_REDO_128") || (h->redo_gate_on && !h->redo_predicted))) ? 2 : 1;   // (a gated redo that is not expected to have work: one launch)
         tier1 = fits128 ? 2 : 1;
     }
     // the redo's start (the finish's working set + the terminal-equality rows) with its inverse, built in registers from the cached
@@ -907,8 +913,10 @@ hipError_t launch_sdual(almpc_handle* h, int filter, const double* guess, int ma
         tp.wcap = tier0 == 1 ? SD_WCAP2 : SD_WCAP4; tp.has_eq = sd.has_eq ? 1 : 0;
         tp.status = h->dStatus; tp.gate = sp.gate; tp.gate_val = sp.gate_val;
         tp.ghat = sp.ghat; tp.start_ws = sdw.start_ws; tp.start_inv = sdw.start_inv;
-        int wgs = (h->batch + SDUAL_START_WAVES - 1) / SDUAL_START_WAVES;
-        if (wgs > h->num_cus * 2) wgs = h->num_cus * 2;
+        // (one workgroup per instance at a time; a workgroup looks at up to 64 SDUAL_START_WAVES instances)
+        int wgs = h->batch < h->num_cus * 4 ? h->batch : h->num_cus * 4;
+        const int wmin = (h->batch + 64 * SDUAL_START_WAVES - 1) / (64 * SDUAL_START_WAVES);
+        if (wgs < wmin) wgs = wmin;
         hipLaunchKernelGGL(k_sdual_start, dim3(wgs), dim3(64 * SDUAL_START_WAVES), 0, h->stream, tp);
         const hipError_t e_ = hipGetLastError();
         if (e_ != hipSuccess) return e_;
@@ -939,6 +947,7 @@ int resolve_lazy_redo(almpc_handle* h) {
     h->lazy_pending = false;
     if (!h->hUnsolved) return ALMPC_OK;
     const int cur = *reinterpret_cast<volatile int*>(h->hUnsolved);
+    h->redo_expected = cur != h->unsolved_seen;
     if (cur == h->unsolved_seen) return ALMPC_OK;
     h->unsolved_seen = cur;
     h->redo_x0_from_results = true;
@@ -971,9 +980,35 @@ int enqueue_gated_redo(almpc_handle* h) {
     return ALMPC_OK;
 }
 
+// Synchronous look: wait for the handle's stream, then settle the last step's deferred redo.  A closed loop that leaves instances
+// undecided tends to leave them step after step (the same plants sit at the edge of feasibility), and a redo enqueued AFTER the host has
+// seen the count pays a wake-up and a launch latency with the GPU idle: when the previous look found undecided instances, the redo goes
+// on the stream GATED behind the step before the wait -- it runs without the host in between if the step left anything, and costs two
+// idle launches if it did not.  The look itself then only reads the count, to know what to expect of the next step.
+int wait_and_settle(almpc_handle* h, bool blocking_only = false) {
+    bool predicted = false;
+    if (h->lazy_pending && h->redo_expected && h->dRedoGate && h->hUnsolved && !getenv("ALMPC_NO_PREDICTED_REDO")) {
+        h->redo_predicted = true;
+        const int rc = enqueue_gated_redo(h);
+        h->redo_predicted = false;
+        if (rc != ALMPC_OK) return rc;
+        predicted = !h->lazy_pending;
+    }
+    if (blocking_only) HIP_TRY(h, hipStreamSynchronize(h->stream));
+    else HIP_TRY(h, stream_wait_polling(h));
+    if (predicted) {
+        const int cur = *reinterpret_cast<volatile int*>(h->hUnsolved);
+        h->redo_expected = cur != h->unsolved_seen;
+        h->unsolved_seen = cur;
+        return ALMPC_OK;
+    }
+    return resolve_lazy_redo(h);
+}
+
 // A new design voids a redo that was deferred for a step of the previous one (its models, references and results are about to go)
 void drop_lazy_redo(almpc_handle* h) {
     h->lazy_pending = false;
+    h->redo_expected = false;
     if (h->hUnsolved) h->unsolved_seen = *reinterpret_cast<volatile int*>(h->hUnsolved);
 }
 
@@ -3117,17 +3152,9 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
 int almpc_synchronize(almpc_handle* h) {
     if (!h) return ALMPC_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
-    // A step is tens of microseconds: poll the stream for a while before falling back to the blocking wait, whose wake-up
-    // (interrupt + scheduler) was seen to cost up to ~15 ms on this pool -- 200 steps' worth.
-    const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
-        const hipError_t q = hipStreamQuery(h->stream);
-        if (q == hipSuccess) return resolve_lazy_redo(h);
-        if (q != hipErrorNotReady) return fail(h, ALMPC_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
-    }
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    return resolve_lazy_redo(h);
+    // A step is tens of microseconds: the wait polls the stream for a while before falling back to the blocking wait, whose wake-up
+    // (interrupt + scheduler) was seen to cost up to ~15 ms on this pool -- 200 steps' worth (stream_wait_polling).
+    return wait_and_settle(h);
 }
 
 int almpc_calculate(almpc_handle* h, const almpc_opts* opts) {
@@ -3141,8 +3168,7 @@ int almpc_get_results(almpc_handle* h, double* x, double* e_x, double* u, double
     if (!h) return ALMPC_ERR_INVALID;
     if (!h->designed) return fail(h, ALMPC_ERR_NOT_DESIGNED, "get_results before design");
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    { const int rc_ = resolve_lazy_redo(h); if (rc_ != ALMPC_OK) return rc_; }
+    { const int rc_ = wait_and_settle(h, true); if (rc_ != ALMPC_OK) return rc_; }
     const size_t b = (size_t)h->batch, xs = (size_t)h->n * (h->N + 1), us = (size_t)h->nz;
     if (x) HIP_TRY(h, hipMemcpy(x, h->dX, b * xs * sizeof(double), hipMemcpyDeviceToHost));
     if (e_x) HIP_TRY(h, hipMemcpy(e_x, h->dEx, b * xs * sizeof(double), hipMemcpyDeviceToHost));

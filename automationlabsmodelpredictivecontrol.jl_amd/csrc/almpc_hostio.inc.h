@@ -266,8 +266,7 @@ int almpc_get_first_input(almpc_handle* h, double* u0) {
     if (!h || !u0) return h ? fail(h, ALMPC_ERR_INVALID, "get_first_input: null u0") : ALMPC_ERR_INVALID;
     if (h->lazy_pending) {   // (synchronous getter: settle a lazily deferred redo before the first inputs are packed)
         HIP_TRY(h, hipSetDevice(h->device));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        const int rc_ = resolve_lazy_redo(h);
+        const int rc_ = wait_and_settle(h, true);
         if (rc_ != ALMPC_OK) return rc_;
     }
     const int t = almpc_get_results_async(h, ALMPC_WANT_FIRST_INPUT);

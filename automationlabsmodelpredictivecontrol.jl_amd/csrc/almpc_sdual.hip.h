@@ -54,6 +54,8 @@ struct SdualParams {
                                                        // triangle) when it has at most SDUAL_SINV_SAVE rows: the next tier starts from it
                                                        // instead of bordering the rows in again one response each (round 5)
     int only_ovf;                                      // 1: only instances with ovf != 0 (second tier)
+    int32_t* ovf_gate; int ovf_gate_val;               // (or null) a launch that flags an instance stores the value in the word; an only_ovf
+                                                       // launch returns at once unless the word holds it (nothing was flagged in this call)
     int rows_state;                                    // 1: the problem has state rows (an "infeasible" verdict is meaningful)
     int max_iter;
     double tol;
@@ -182,6 +184,7 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
     constexpr bool ROWDPP = SP <= 16;    // a stage fits one row of 16 lanes: DPP broadcasts instead of LDS round trips
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if (p.gate && __builtin_nontemporal_load(p.gate) != p.gate_val) return;   // (uniform: nothing to redo behind that step)
+    if (p.only_ovf && p.ovf_gate && __builtin_nontemporal_load(p.ovf_gate) != p.ovf_gate_val) return;   // (no tier before this one ran out of room)
     const int wv = threadIdx.x >> 6, lane0 = threadIdx.x & 63;
     const int n = p.n, m = p.m, N = p.N, wcap = p.wcap, LD = wcap + 1;
     const int TP = sdual_tp(NT, MC, N);
@@ -1095,6 +1098,7 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
         // ---- outputs
         const int st_out = bad ? 2 : status;
         if (p.ovf && lane == 0) p.ovf[inst] = (overflow && !bad) ? 1 + (nW < SDUAL_WSAVE ? nW : SDUAL_WSAVE) : 0;
+        if (p.ovf_gate && overflow && !bad && lane == 0) *p.ovf_gate = p.ovf_gate_val;
         for (int t = lane; t < N * m; t += 64) {
             const int k = t / m, a = t - k * m;
             const double ur = urg[t];
@@ -1128,10 +1132,12 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
 // rows: 40 - 48 rows on the benchmark's edge-of-feasibility instances.  k_sdual borders them in one at a time -- a column load, a product
 // with Sinv and a rank-one update through LDS per row, 10 k cycles each: 400 k of the 550 k cycles such an instance took.  With a shared
 // model the matrix G_WW is a GATHER from the cached responses (ghat[t_i][t_j]), and its inverse a symmetric Gauss-Jordan sweep that runs
-// in registers: lane i holds row i (64 doubles), the pivot row goes through 512 bytes of LDS (one lane writes it, every lane reads it
+// in registers: lane i holds row i, the pivot row goes through 512 bytes of LDS (one lane writes it, every lane reads it
 // back as broadcasts, and reads its own element of the pivot COLUMN from it -- the matrix stays symmetric).  Rows are swept in list order,
 // so the pivot of row k is its Schur complement on the rows accepted before it -- exactly the quantity the bordering tests: a dependent
-// row (pivot <= 1e-12 G_kk) is left out, as there.  One wave per instance, 1.6 k cycles per row at 41 rows.
+// row (pivot <= 1e-12 G_kk) is left out, as there.  One workgroup of four waves per instance, each wave holding 16 columns of every row
+// (one wave with all 64 columns: 4.1 k cycles per pivot, 77 us at 45 rows; four waves meet at ONE barrier per pivot -- the pivot-row buffer
+// is double buffered).
 // Output: the inverse (packed lower triangle of the accepted rows, in list order) to start_inv, the accepted codes back into start_ws
 // with SDUAL_START_BUILT in the count.  Sweep convention: after the rows K,  M_KK = -(G_KK)^-1,  M_iK = G_iK (G_KK)^-1,  the rest the Schur
 // complement.
@@ -1143,24 +1149,31 @@ struct SdualStartParams {
     int32_t* start_ws;          // [batch][64], in and out
     double* start_inv;          // [batch][sdual_sinv_doubles(SDUAL_SINV_SAVE)]
 };
-constexpr int SDUAL_START_WAVES = 4;
+constexpr int SDUAL_START_WAVES = 4;   // waves per instance: wave w holds columns [16 w, 16 w + 16) of every row
 
 inline __global__ __launch_bounds__(64 * SDUAL_START_WAVES) void k_sdual_start(SdualStartParams p) {
-    static_assert(SDUAL_SINV_SAVE == 64, "one row of the start per lane");
-    __shared__ __attribute__((aligned(16))) double s_prow[SDUAL_START_WAVES][64];
-    __shared__ double s_gd[SDUAL_START_WAVES][64];
-    __shared__ int s_code[SDUAL_START_WAVES][64];
+    static_assert(SDUAL_SINV_SAVE == 64 && SDUAL_START_WAVES * 16 == 64, "one row of the start per lane, 16 columns per wave");
+    __shared__ __attribute__((aligned(16))) double s_prow[2][64];   // the pivot row, double buffered: one barrier per pivot
+    __shared__ double s_gd[64];
+    __shared__ int s_code[64];
+    __shared__ int s_head[64 * SDUAL_START_WAVES];
     if (p.gate && __builtin_nontemporal_load(p.gate) != p.gate_val) return;
-    const int wv = threadIdx.x >> 6, lane0 = threadIdx.x & 63;
-    double* pw = s_prow[wv];
-    double* gd = s_gd[wv];
-    int* code = s_code[wv];
+    const int wv = threadIdx.x >> 6, lane0 = threadIdx.x & 63, c0 = 16 * wv;
     const int TP = p.TP;
-    for (int inst = blockIdx.x * SDUAL_START_WAVES + wv; inst < p.batch; inst += gridDim.x * SDUAL_START_WAVES) {
-        if (p.status[inst] != 1) continue;
+    // the workgroup's instances are blockIdx.x + t gridDim.x: thread t looks at the t-th one (one round trip for the lot)
+    {
+        const long inst = (long)blockIdx.x + (long)threadIdx.x * gridDim.x;
+        int hd = SDUAL_START_BUILT;   // (nothing to do)
+        if (inst < p.batch && p.status[inst] == 1) hd = p.start_ws[(size_t)inst * 64];
+        s_head[threadIdx.x] = hd;
+    }
+    __syncthreads();
+    for (int tt = 0; tt < 64 * SDUAL_START_WAVES; ++tt) {
+        const int inst = blockIdx.x + tt * gridDim.x;
+        if (inst >= p.batch) break;
+        const int head = s_head[tt];
+        if (head & SDUAL_START_BUILT) continue;   // (decided, or built by an earlier launch behind the same step)
         int32_t* rw = p.start_ws + (size_t)inst * 64;
-        const int head = rw[0];
-        if (head & SDUAL_START_BUILT) continue;   // (built by an earlier launch behind the same step)
         int lane = lane0;
         asm volatile("" : "+v"(lane));
         // the list, as k_sdual would assemble it: terminal-equality rows, then the finish's rows as far as the capacity allows
@@ -1172,48 +1185,50 @@ inline __global__ __launch_bounds__(64 * SDUAL_START_WAVES) void k_sdual_start(S
         int mycode = 0;
         if (lane < ne) mycode = ((p.N * p.SP + lane) << 2) | 2;
         else if (lane < cnt) mycode = rw[1 + lane - ne];
-        code[lane] = mycode;
         const int ti = mycode >> 2;
-        sd_fence();
-        double r[64];
+        __syncthreads();   // (the previous instance's tables have been read)
+        if (wv == 0) {
+            s_code[lane] = mycode;
+            s_gd[lane] = lane < cnt ? p.ghat[(size_t)ti * TP + ti] : 1.0;
+        }
+        __syncthreads();
+        double r[16];
 #pragma unroll
-        for (int j = 0; j < 64; ++j) {
-            r[j] = 0.0;
+        for (int jj = 0; jj < 16; ++jj) {
+            const int j = c0 + jj;
+            r[jj] = 0.0;
             if (j < cnt) {   // (uniform)
-                const int tj = __builtin_amdgcn_readfirstlane(code[j]) >> 2;
+                const int tj = __builtin_amdgcn_readfirstlane(s_code[j]) >> 2;
                 const size_t a = lane >= j ? (size_t)ti * TP + tj : (size_t)tj * TP + ti;
-                if (lane < cnt) r[j] = p.ghat[a];
+                if (lane < cnt) r[jj] = p.ghat[a];
             }
         }
-        gd[lane] = lane < cnt ? p.ghat[(size_t)ti * TP + ti] : 1.0;
-        sd_fence();
-        unsigned long long acc = 0ull;   // accepted rows
+        unsigned long long acc = 0ull;   // accepted rows (every wave keeps the same record)
         for (int k = 0; k < cnt; ++k) {
+            double* pw = s_prow[k & 1];
             if (lane == k) {
 #pragma unroll
-                for (int j = 0; j < 64; j += 2) *reinterpret_cast<double2*>(pw + j) = make_double2(r[j], r[j + 1]);
+                for (int jj = 0; jj < 16; jj += 2) *reinterpret_cast<double2*>(pw + c0 + jj) = make_double2(r[jj], r[jj + 1]);
             }
-            sd_fence();
+            __syncthreads();
             const double col = pw[lane];
             const double d = pw[k];
-            if (!(d > 1e-12 * gd[k])) { sd_fence(); continue; }   // dependent on the rows before it: left out
+            if (!(d > 1e-12 * s_gd[k])) continue;   // dependent on the rows before it: left out (uniform over the workgroup)
             acc |= 1ull << k;
+            if (c0 >= cnt) continue;                // (this wave's columns are beyond the list; it still meets the barriers)
             const double invd = 1.0 / d;
-            const double f = col * invd;
             const bool piv = lane == k;
+            // row i != k: r_ij -= (col_i / d) prow_j; the pivot row itself: prow_j / d = 0 - (-1/d) prow_j; column k: col_i / d, -1/d on the pivot
+            const double f = piv ? -invd : col * invd;
+            const double fix = piv ? -invd : f;
+            const int kk = k - c0;
 #pragma unroll
-            for (int j0 = 0; j0 < 64; j0 += 8) {
-                if (j0 < cnt) {
-#pragma unroll
-                    for (int j = j0; j < j0 + 8; j += 2) {
-                        const double2 pj = *reinterpret_cast<const double2*>(pw + j);
-                        const double u0 = fma(-f, pj.x, r[j]), u1 = fma(-f, pj.y, r[j + 1]);
-                        r[j] = j == k ? (piv ? -invd : f) : (piv ? pj.x * invd : u0);
-                        r[j + 1] = j + 1 == k ? (piv ? -invd : f) : (piv ? pj.y * invd : u1);
-                    }
-                }
+            for (int jj = 0; jj < 16; jj += 2) {
+                const double2 pj = *reinterpret_cast<const double2*>(pw + c0 + jj);
+                const double u0 = fma(-f, pj.x, piv ? 0.0 : r[jj]), u1 = fma(-f, pj.y, piv ? 0.0 : r[jj + 1]);
+                r[jj] = jj == kk ? fix : u0;
+                r[jj + 1] = jj + 1 == kk ? fix : u1;
             }
-            sd_fence();   // (the pivot row is read before the next one is written)
         }
         // ---- out: accepted rows in list order
         const int na = __popcll(acc);
@@ -1221,15 +1236,17 @@ inline __global__ __launch_bounds__(64 * SDUAL_START_WAVES) void k_sdual_start(S
         const int pi = __popcll(acc & ((1ull << lane) - 1ull));
         double* out = p.start_inv + (size_t)inst * sdual_sinv_doubles(SDUAL_SINV_SAVE);
 #pragma unroll
-        for (int j = 0; j < 64; ++j) {
+        for (int jj = 0; jj < 16; ++jj) {
+            const int j = c0 + jj;
             if (j < cnt && ((acc >> j) & 1ull)) {   // (uniform)
                 const int pj = __popcll(acc & ((1ull << j) - 1ull));
-                if (mine && lane >= j) out[(pi * (pi + 1) >> 1) + pj] = -r[j];
+                if (mine && lane >= j) out[(pi * (pi + 1) >> 1) + pj] = -r[jj];
             }
         }
-        if (mine) rw[1 + pi] = mycode;
-        if (lane == 0) rw[0] = na | SDUAL_START_BUILT;
-        sd_fence();
+        if (wv == 0) {
+            if (mine) rw[1 + pi] = mycode;
+            if (lane == 0) rw[0] = na | SDUAL_START_BUILT;
+        }
     }
 }
 

@@ -3,6 +3,8 @@
     every stage, .../linear/mpc_modeler_implementation_linear.jl:62-70; every screened verdict is also held against the phase-1 LP;
   * the capacity tiers of k_sdual handing over the inverse of their working set (ALMPC_SDUAL_NO_SINV_HANDOVER);
   * the stage-wise redo starting from the working set the state-row finish gave up with (ALMPC_NO_REDO_START);
+  * the start of that redo with its inverse built in registers by k_sdual_start (ALMPC_SDUAL_NO_START_BUILD);
+  * the redo enqueued gated behind the step BEFORE a synchronous look when the previous look found work (ALMPC_NO_PREDICTED_REDO);
   * the packed-triangle KKT inverse of k_admm_inst (ALMPC_NO_PACKED_MINV), even and odd nz.
 The switches are read with getenv at call time, so one process can run both sides."""
 import os
@@ -141,6 +143,36 @@ def test_redo_start_built_in_registers_equals_the_bordered_one(capi, mo, box, ca
         pb = mo.make_problem(*mo.quadrotor_model(), 30, p.u_min, p.u_max, x_min=-xmax, x_max=xmax, terminal="equality")
         for i in redone[:3]:
             assert np.abs(built["u"][i] - mo.solve_mpc_exact(pb, X0[i])["u"]).max() <= 1e-6
+
+
+def test_redo_enqueued_ahead_of_the_look_equals_the_redo_after_it(capi, mo):
+    """A synchronous look that found undecided instances makes the NEXT step's redo go on the stream gated behind the step, before the
+    host waits (wait_and_settle; ALMPC_NO_PREDICTED_REDO=1: always after the look).  Four looked-at steps of the tight box + equality
+    batch, the last two from a moved x0 that leaves nothing undecided: same results either way, never an undecided instance."""
+    p = mo.quadrotor()
+    batch = 2048
+    xmax = np.array([1, 1, 1, .5, .5, .5, .1, .1, .1, .1, .1, .1]) * 3.0
+    X0 = np.clip(mo.quadrotor_x0_batch(batch, 1.0), -0.99 * xmax, 0.99 * xmax)
+
+    def run():
+        s = capi.Solver(12, 4, 30, batch)
+        s.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max, xmin=-xmax, xmax=xmax, rho=30.0, rho_profile="stiffness", terminal="equality")
+        s.set_reference(p.x_ref, p.u_ref)
+        o = capi.default_opts(rho=30.0, max_iter=8, check_every=8)
+        out = []
+        for x0 in (X0, X0, 0.25 * X0, 0.25 * X0, X0):
+            s.update_initialization(x0)
+            s.calculate(o)
+            out.append(s.get_results(want=("u", "status")))
+        s.close()
+        return out
+    ahead, after = _both("ALMPC_NO_PREDICTED_REDO", run)
+    for a, b in zip(ahead, after):
+        assert np.array_equal(a["status"], b["status"]) and set(np.unique(a["status"])) <= {0, 3}
+        ok = a["status"] == 0
+        assert np.abs(a["u"][ok] - b["u"][ok]).max() <= 1e-9
+    assert (ahead[0]["status"] == 3).sum() > (ahead[2]["status"] == 3).sum()
+    assert np.array_equal(ahead[0]["status"], ahead[4]["status"])
 
 
 @pytest.mark.parametrize("m,N", [(4, 30), (3, 23)])      # nz 120 (packed triangle), nz 69 (odd: the full layout stays)
