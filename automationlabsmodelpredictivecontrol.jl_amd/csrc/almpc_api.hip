@@ -80,6 +80,7 @@ struct almpc_handle {
                                   // 2 (re-linearisation pipeline, warm steps): guess = the previous step's inputs shifted by one stage
     int fuse_step = 1;            // one kernel per step when the shape allows (almpc_set_step_fusion / ALMPC_NO_FUSED_STEP=1)
     double* dSglobal = nullptr;  // polish scratch for working sets beyond 32 rows
+    int32_t* dStartRows = nullptr;   // [batch][65] row list of a guessed working set whose inverse sits in dSglobal (k_guess_iterate_ws)
     // state rows (state box / terminal equality): constraint-space data for k_polish_gen
     int terminal_eq = 0, has_box = 0, mc = 0, R = 0, Rs = 0, np_pairs = 0;
     double *dGhat = nullptr, *dGnorm = nullptr, *dXmin = nullptr, *dXmax = nullptr;
@@ -313,7 +314,7 @@ void free_all(almpc_handle* h) {
     io_free(h);
     void* ptrs[] = {h->dMinvFrag, h->dVFrag, h->dHFrag, h->dFFrag, h->dG, h->dD, h->dUmin, h->dUmax, h->dA, h->dB,
                     h->dXref, h->dUref, h->dFS, h->dV0S, h->dRho, h->dRollM, h->dX0, h->dXs, h->dZs, h->dYs, h->dV0, h->dW, h->dX, h->dEx,
-                    h->dU, h->dEu, h->dStatus, h->dIters, h->dPiters, h->dPerm, h->dYflags, h->dSglobal, h->dGhat, h->dGnorm, h->dXmin,
+                    h->dU, h->dEu, h->dStatus, h->dIters, h->dPiters, h->dPerm, h->dYflags, h->dSglobal, h->dStartRows, h->dGhat, h->dGnorm, h->dXmin,
                     h->dXmax, h->dRowTraj, h->dRowEq, h->dRowXidx, h->dRowState, h->dRowMap, h->dGhatE, h->dWinvE, h->lA, h->lB, h->lC, h->lE, h->bA, h->bB, h->bMinv, h->bG, h->bHs, h->bFs,
                     h->bVs, h->bD, h->bRho, h->bH, h->bF, h->bPhi, h->bGk, h->bGam, h->bW, h->bWP, h->bP, h->bFlag, h->bQ, h->dOverflow, h->dOvfSinv, h->dVsPlain, h->dPlain, h->dS0Basis, h->wQ, h->wR, h->wS,
                     h->sqp.W_in, h->sqp.W_h, h->sqp.b_h, h->sqp.W_out, h->sqp.A, h->sqp.B, h->sqp.c, h->sqp.fval, h->sqp.ebar,
@@ -2508,9 +2509,12 @@ int almpc_sqp_fnn_iterate(almpc_handle* h, int iters, double step_scale, const a
     // register-tile design kernel: scaling, scaled gradient and the flag reset ride along as its tail (three launches less per iteration)
     const bool ltv_scales = ltv_reg_path(h) && nz <= 128 && !q.structured_qp && !getenv("ALMPC_DBG_SPLIT_SCALE");
     if (ltv_scales) { lp.sc_d = h->bD; lp.sc_Hs = h->bHs; lp.sc_fS = h->dFS; lp.sc_flag = h->bFlag; lp.nzs = nzs; }
+    // ... and k_sqp_prepare as its head (its outputs are that kernel's inputs): a fourth launch less
+    const bool prep_in_design = ltv_scales && !getenv("ALMPC_DBG_SPLIT_PREPARE");
+    if (prep_in_design) { lp.prep_on = 1; lp.prep = sp; }
     for (int it = 0; it < iters; ++it) {
         HIP_TRY(h, launch_fnn_jacobian(fp, h->num_cus, st));
-        hipLaunchKernelGGL(k_sqp_prepare, dim3((unsigned)b), dim3(256), 0, st, sp);
+        if (!prep_in_design) hipLaunchKernelGGL(k_sqp_prepare, dim3((unsigned)b), dim3(256), 0, st, sp);
         if (!ltv_scales) HIP_TRY(h, hipMemsetAsync(h->bFlag, 0, b * sizeof(int), st));
         if (q.structured_qp) {   // the QP in its stage-wise form for every instance; start: v = 0 (working set = the iterate's inputs on a bound)
             h->designed = true;
@@ -2825,6 +2829,7 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
     };
 
     AdmmInstParams ip;
+    bool guess_ws = false;       // this step's guess came with the inverse of its working set (k_guess_iterate_ws)
     bool inst_pending = false;   // per-instance ADMM not launched yet: small problems go out fused with their finish (k_step_inst_wave)
     if (h->batched) {  // per-instance models: one workgroup per instance, KKT inverse in LDS
         ip.nz = h->nz; ip.n = h->n; ip.m = h->m; ip.batch = h->batch; ip.nzs = h->nzs;
@@ -2840,7 +2845,15 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
             if (!o.polish) return fail(h, ALMPC_ERR_INVALID, "calculate: the SQP loop needs opts.polish = 1");
             HIP_TRY(h, ev0());
             if (h->skip_admm == 2) hipLaunchKernelGGL(k_guess_shift, dim3((h->batch + 3) / 4), dim3(256), 0, st, ip, (const double*)h->dU, h->N);
-            else hipLaunchKernelGGL(k_guess_iterate, dim3((h->batch + 3) / 4), dim3(256), 0, st, ip);
+            else if (h->nzs <= 128 && h->nzs > 64 && h->batch <= 2 * h->num_cus && h->dSglobal && h->bG && !getenv("ALMPC_NO_GUESS_WS")) {
+                // the guess of an SQP iteration AND the inverse of its working set (33..64 of the inputs on a bound), four waves per
+                // instance: k_guess_iterate_ws; installed by k_polish_sgl<1> below
+                if (!h->dStartRows) HIP_TRY(h, dalloc(&h->dStartRows, (size_t)h->batch * 65));
+                GuessWsParams gw;
+                gw.G = h->bG; gw.G_stride = (long)h->nz * h->nzs; gw.sinv = h->dSglobal; gw.rows = h->dStartRows;
+                hipLaunchKernelGGL(k_guess_iterate_ws, dim3((unsigned)h->batch), dim3(256), 0, st, ip, gw);
+                guess_ws = true;
+            } else hipLaunchKernelGGL(k_guess_iterate, dim3((h->batch + 3) / 4), dim3(256), 0, st, ip);
             HIP_TRY(h, hipGetLastError());
         } else {
             inst_pending = true;
@@ -3102,8 +3115,14 @@ int almpc_calculate_async(almpc_handle* h, const almpc_opts* user) {
                 pp.sg_off = per_wave;
                 pp.g_off = per_wave + POLISH_GLB_PER_INST;
                 pp.lds_per_wave = (int)sgl_wave;
+                if (guess_ws) {
+                    pp.start_rows = h->dStartRows;
+                    HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(k_polish_sgl<1>), (size_t)(l_sgl)));
+                    hipLaunchKernelGGL((k_polish_sgl<1>), dim3(pp.ntiles * 16), dim3(64), l_sgl, st, pp);
+                } else {
                 HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(k_polish_sgl<0>), (size_t)(l_sgl)));
                 hipLaunchKernelGGL((k_polish_sgl<0>), dim3(pp.ntiles * 16), dim3(64), l_sgl, st, pp);
+                }
             } else {
             HIP_TRY(h, ensure_dyn_lds(reinterpret_cast<const void*>(k_polish<false>), l));
             hipLaunchKernelGGL((k_polish<false>), dim3((pp.ntiles * 16 + POLISH_WAVES - 1) / POLISH_WAVES), dim3(64 * POLISH_WAVES), l, st, pp);

@@ -577,6 +577,168 @@ inline __global__ __launch_bounds__(256) void k_guess_iterate(AdmmInstParams p) 
     }
 }
 
+// k_guess_iterate_ws: k_guess_iterate for nz <= 128 with the inverse of the guessed working set made on the spot (round 5).  An SQP
+// iterate has about half of its inputs on a bound (50 of 100 at the configs[4] shape), and the single-wave finish builds the inverse of
+// such a set as 32 rows of Gauss-Jordan in registers + one bordering in memory mode per further row, 6 k cycles each: 108 k of the
+// 190 k cycles of that launch, with 255 of the chip's 256 CUs holding one wave.  Here: ONE WORKGROUP of four waves per instance; thread r
+// forms row r of the guess exactly as k_guess_iterate does; the flagged rows (y != 0), ascending, are the working set; if it has 33..64
+// rows, K = G_i[W, W] is gathered (lane = position, wave w = positions 16 w .. 16 w + 15 as columns) and inverted by the symmetric
+// Gauss-Jordan sweep of k_sdual_start (two pivot rows at a time through LDS, double buffered: one barrier per PAIR of pivots; K is positive
+// definite: no row is left out, a non-positive pivot voids the start), and written to the finish's second-tier scratch (64 x 64,
+// identity padded) with the row list beside it (PolishParams::start_rows).  The finish compares the list with its own reading of the
+// guess before it installs anything.
+struct GuessWsParams {
+    const double* G; long G_stride;   // G_i = H_i'^-1, dense [nz][nzs]
+    double* sinv;                     // [batch][64 * 64]  (PolishParams::sglobal)
+    int32_t* rows;                    // [batch][65] count (0: no start) + rows
+};
+
+inline __global__ __launch_bounds__(256) void k_guess_iterate_ws(AdmmInstParams p, GuessWsParams w) {
+    __shared__ __attribute__((aligned(16))) double s_prow[2][128];   // two pivot rows per step, double buffered: one barrier per step
+    __shared__ int s_rows[64];
+    __shared__ int s_cnt[4];
+    const int nz = p.nz, nzs = p.nzs, n = p.n, tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), c0 = 16 * wv;   // (wave-uniform, and the compiler knows it: the column tests below stay scalar)
+    const int inst = blockIdx.x;
+    const size_t o = (size_t)inst * nzs;
+    // ---- the guess, one row per thread (nzs <= 128: the host's condition)
+    if (wv == 0) ALMPC_STAMP(inst, 0);
+#ifdef ALMPC_STAMPS
+    if (g_stamps && tid == 0) g_stamps[(size_t)inst * 16 + 6] = __builtin_amdgcn_s_memrealtime();
+#endif
+    double y = 0.0;
+    if (tid < nzs) {
+        const int r = tid;
+        double v = 0.0, z = 0.0;
+        if (r < nz) {
+            const double* Vi = p.Vs + (size_t)inst * n * nzs;
+            v = p.v0S[(size_t)inst * nz + r];
+            for (int c = 0; c < n; ++c)
+                v += Vi[(size_t)c * nzs + r] * (p.x0[(size_t)inst * n + c] - p.xref[(size_t)inst * p.xref_stride + c]);
+            const double ur = p.uref[(size_t)inst * p.uref_stride + r], di = 1.0 / p.dvec[o + r];
+            const double lo = (p.umin[r % p.m] - ur) * di, hi = (p.umax[r % p.m] - ur) * di;  // as k_admm_inst forms them
+            z = fmin(fmax(0.0, lo), hi);
+            y = (hi <= 0.0) ? 1.0 : ((lo >= 0.0) ? -1.0 : 0.0);
+        }
+        p.xs[o + r] = z; p.zs[o + r] = z; p.ys[o + r] = y; p.v0[o + r] = v;
+    }
+    if (tid == 0) {
+        p.iters[inst] = 0;
+        p.status[inst] = 1;   // "not converged": the finish sets 0 when it certifies the optimum
+        p.piters[inst] = 0;
+        p.perm[inst] = inst;
+    }
+    // ---- the working set: flagged rows in ascending order (rows 0..63 sit on wave 0, 64..127 on wave 1)
+    if (wv == 0) ALMPC_STAMP(inst, 1);
+    const bool flagged = tid < nz && y != 0.0;
+    const unsigned long long fm = __ballot(flagged);
+    if (lane == 0) s_cnt[wv] = __popcll(fm);
+    __syncthreads();
+    const int k0 = s_cnt[0] + s_cnt[1];
+    {
+        const int before = (wv == 0 ? 0 : s_cnt[0]) + __popcll(fm & ((1ull << lane) - 1ull));
+        if (flagged && before < 64) s_rows[before] = tid;
+    }
+    __syncthreads();
+    int32_t* rws = w.rows + (size_t)inst * 65;
+    if (k0 <= 32 || k0 > 64) {   // (uniform) the finish's register mode takes such a set at once, or it is beyond the second tier
+        if (tid == 0) rws[0] = 0;
+        return;
+    }
+    // ---- K = G_i[W, W]: lane = position i, this wave's columns = positions c0 .. c0 + 15; (max, min) addressing: exactly symmetric
+    if (wv == 0) ALMPC_STAMP(inst, 2);
+    const double* Gi = w.G + (size_t)inst * w.G_stride;
+    const int ri = lane < k0 ? s_rows[lane] : 0;
+    double r[16];
+    {   // (clamped addresses, no branch per element: all sixteen loads in flight before the first wait)
+        int rj[16];
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) rj[jj] = s_rows[c0 + jj < k0 ? c0 + jj : 0];
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+            const int a = ri > rj[jj] ? ri : rj[jj], b = ri > rj[jj] ? rj[jj] : ri;
+            r[jj] = Gi[(size_t)a * nzs + b];
+        }
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) r[jj] = (c0 + jj < k0 && lane < k0) ? r[jj] : 0.0;
+    }
+    bool bad = false;
+#ifdef ALMPC_STAMPS
+    long long dbg_acc[2] = {0, 0};
+#endif
+    // two pivots per publication and barrier (gj16_pivot2); the last one of an odd set alone
+    if (wv == 0) ALMPC_STAMP(inst, 3);
+    for (int k = 0, step = 0; k < k0; ++step) {
+        double* pw0 = s_prow[step & 1];
+        double* pw1 = pw0 + 64;
+        const bool two = k + 1 < k0;
+        if (lane == k || (two && lane == k + 1)) {
+            double* pw = lane == k ? pw0 : pw1;
+#pragma unroll
+            for (int jj = 0; jj < 16; jj += 2) *reinterpret_cast<double2*>(pw + c0 + jj) = make_double2(r[jj], r[jj + 1]);
+        }
+#ifdef ALMPC_STAMPS
+        long long tq0 = __builtin_readcyclecounter();
+#endif
+        __syncthreads();
+#ifdef ALMPC_STAMPS
+        long long tq1 = __builtin_readcyclecounter();
+        dbg_acc[0] += tq1 - tq0;
+#endif
+        double pj0[16], pj1[16];   // (every read of the pivot rows in one batch, in front of the pivot tests)
+#pragma unroll
+        for (int jj = 0; jj < 16; jj += 2) {
+            const double2 t2 = *reinterpret_cast<const double2*>(pw0 + c0 + jj);
+            pj0[jj] = t2.x; pj0[jj + 1] = t2.y;
+        }
+        const double col0 = pw0[lane], d11 = pw0[k];
+#ifdef ALMPC_STAMPS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        tq0 = __builtin_readcyclecounter();
+        dbg_acc[1] += tq0 - tq1;
+#endif
+        if (two) {
+#pragma unroll
+            for (int jj = 0; jj < 16; jj += 2) {
+                const double2 t2 = *reinterpret_cast<const double2*>(pw1 + c0 + jj);
+                pj1[jj] = t2.x; pj1[jj + 1] = t2.y;
+            }
+            const double col1 = pw1[lane], d12 = pw0[k + 1], d22 = pw1[k + 1];
+            const double s22 = d22 - d12 * d12 / d11;
+            if (!(d11 > 0.0) || !(s22 > 0.0)) { bad = true; break; }   // (uniform: every wave reads the same pivots)
+            if (c0 < k0) gj16_pivot2(r, pj0, pj1, col0, col1, d11, d12, s22, c0, k, lane);   // (else: columns beyond the set; the wave still meets the barriers)
+            k += 2;
+        } else {
+            if (!(d11 > 0.0)) { bad = true; break; }
+            if (c0 < k0) gj16_pivot(r, pj0, col0, d11, c0, k, lane);
+            k += 1;
+        }
+    }
+    if (bad) {
+        if (tid == 0) rws[0] = 0;
+        return;
+    }
+    // ---- out: column j of the 64 x 64 second-tier matrix, identity beyond the set
+    if (wv == 0) ALMPC_STAMP(inst, 4);
+#ifdef ALMPC_STAMPS
+    if (g_stamps && tid == 0) { g_stamps[(size_t)inst * 16 + 13] = dbg_acc[0]; g_stamps[(size_t)inst * 16 + 14] = dbg_acc[1]; }
+#endif
+    double* out = w.sinv + (size_t)inst * 64 * 64;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        const int j = c0 + jj;
+        out[(size_t)j * 64 + lane] = (j < k0 && lane < k0) ? -r[jj] : (lane == j ? 1.0 : 0.0);
+    }
+    if (wv == 0) {
+        if (lane < k0) rws[1 + lane] = ri;
+        if (lane == 0) rws[0] = k0;
+    }
+    if (wv == 0) ALMPC_STAMP(inst, 5);
+#ifdef ALMPC_STAMPS
+    if (g_stamps && tid == 0) g_stamps[(size_t)inst * 16 + 7] = __builtin_amdgcn_s_memrealtime();
+#endif
+}
+
 // k_guess_shift: the same hand-off for a receding-horizon step with per-instance models (almpc_relin_fnn_step, warm_start = 1): the
 // guess is the previous step's input trajectory shifted by one stage (stage k <- stage k+1, the last stage repeated) -- the classic
 // MPC warm start.  z = that point in the new scaled coordinates, clipped to the box; working set = its rows on a bound.  The finish
@@ -781,6 +943,132 @@ __global__ __launch_bounds__(256) void k_design_instance_t(DesignInstParams p) {
 // per instance walks the stages, propagates the row block and g~ (one n x n product each) and accumulates H and q in LDS:
 // O(nz^2 n N / 3) flops, H_i and q_i are the only things written.  The R, S part of the gradient is added from qadd.
 // ------------------------------------------------------------------------------------------------
+// ---- SQP outer loop: parameters of its glue kernels (csrc/almpc_sqp.hip.h) and the part that rides along in k_design_ltv_reg ----
+struct SqpParams {
+    int n, m, N, nz, batch, useR, useS;
+    const double* xref;   // [(N+1)][n] shared state reference
+    const double* uref;   // [N][m]     shared input reference
+    const double* R; const double* S;   // m x m, symmetrised
+    const double* umin; const double* umax;
+    double* xbar;         // [batch][(N+1)][n]
+    double* ubar;         // [batch][N][m]
+    const double* fval;   // [batch][N][n]  network outputs at (xbar_k, ubar_k)
+    const double* A; const double* B;   // [batch][N][n*n], [batch][N][n*m]
+    double* c;            // [batch][N][n]  defects f(xbar_k, ubar_k) - xbar_{k+1}
+    double* ebar;         // [batch][N][n]  xbar_{k+1} - xref_{k+1}
+    double* qadd;         // [batch][nz]    2 Rbar (ubar - uref) + 2 D'Sbar D ubar
+    const double* v;      // [batch][N][m]  QP solution (the step kernels' e_u output); overwritten with ubar - uref
+    const int* flag;      // [batch] design failure of this iteration (non-zero: skip the update)
+    const int* status;    // [batch] status of the QP solve (2 = non-finite: skip the update)
+    int* bad;             // [batch] sticky: some iteration of this instance was skipped
+    unsigned long long* stats;  // [2]: bit patterns of max |v| and max |c| over the batch (non-negative doubles order like integers)
+    double step_scale;
+    // step rule 1 (merit-function safeguard): see k_sqp_prepare
+    int adaptive;
+    double mu;            // weight of the defects in the merit function J + mu |defects|_1
+    const double* Q; const double* P; long sP;   // cost weights for J (P shared or per instance)
+    double* mer;          // [batch][4]: step factor a, merit of the last accepted point, redo flag (1: this iteration is void), spare
+    double* xback; double* uback;   // [batch][(N+1) n], [batch][nz]: last accepted point
+    double* dxback; double* vback;  // its step (dx of every stage, v), so that a rejected trial can be re-taken shorter
+    double *x, *ex, *u, *eu;    // result buffers: the iterate after the update
+};
+
+// Before the QP: defects, state errors and the input part of the gradient, one workgroup per instance.
+// Step rule 1.  Full Gauss-Newton steps are not globally convergent (3 of the 256 benchmark instances end in a cycle), and
+// heuristics on |v| alone misfire in the first iterations, where growing steps are normal.  The safeguard is the classical l1
+// merit function phi = J(x, u) + mu |f(x, u) - x+|_1, evaluated a posteriori: the network outputs at the point reached by the last
+// step are computed by THIS iteration's linearisation anyway, so the test costs one reduction.  If phi did not decrease, the
+// point is rejected: the iterate goes back to the last accepted point plus HALF the step (both kept), this iteration's QP -- built
+// at the rejected point -- is void for the instance (redo flag: k_sqp_step leaves it alone), and the next iteration tests the
+// shorter step.  Accepted steps double the factor back up to 1; at 1/64 a step is accepted regardless.
+// A device function: k_sqp_prepare is one caller, the head of k_design_ltv_reg the other (DesignLtvParams::prep_on: one launch less per
+// iteration; the first 256 threads of that kernel's workgroup do exactly what the kernel's 256 did).
+__device__ inline void sqp_prepare_body(const SqpParams& p, const size_t i) {
+    const int n = p.n, m = p.m, N = p.N, nz = p.nz;
+    const int tid = threadIdx.x < 256 ? (int)threadIdx.x : 0x3fffffff, nthr = 256;   // (threads beyond 256 only meet the barriers)
+    double* xbw = p.xbar + i * (size_t)(N + 1) * n;
+    double* ubw = p.ubar + i * (size_t)nz;
+    if (p.adaptive) {
+        __shared__ double red[8];
+        __shared__ int reject;
+        double part = 0.0;
+        const double* Pm = p.P + i * p.sP;
+        for (int t = tid; t < (N + 1) * n; t += nthr) {   // e_x' W e_x, W = Q for stages 1..N, P for N+1
+            const int k = t / n, r = t % n;
+            const double* W = (k == N) ? Pm : p.Q;
+            double sdot = 0.0;
+            for (int j = 0; j < n; ++j) sdot += W[(size_t)j * n + r] * (xbw[k * n + j] - p.xref[k * n + j]);
+            part += (xbw[t] - p.xref[t]) * sdot;
+        }
+        for (int t = tid; t < nz; t += nthr) {
+            const int k = t / m, a = t % m;
+            if (p.useR) {
+                double sdot = 0.0;
+                for (int c2 = 0; c2 < m; ++c2) sdot += p.R[(size_t)c2 * m + a] * (ubw[k * m + c2] - p.uref[k * m + c2]);
+                part += (ubw[t] - p.uref[t]) * sdot;
+            }
+            if (p.useS && k + 1 < N) {
+                double sdot = 0.0;
+                for (int c2 = 0; c2 < m; ++c2) sdot += p.S[(size_t)c2 * m + a] * (ubw[k * m + c2] - ubw[(k + 1) * m + c2]);
+                part += (ubw[t] - ubw[t + m]) * sdot;
+            }
+        }
+        for (int t = tid; t < N * n; t += nthr) part += p.mu * fabs(p.fval[i * (size_t)N * n + t] - xbw[n + t]);
+        part = wave_sum(part);
+        if ((threadIdx.x & 63) == 0 && threadIdx.x < 256) red[threadIdx.x >> 6] = part;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double phi = (red[0] + red[1]) + (red[2] + red[3]);
+            double a = p.mer[4 * i], ref = p.mer[4 * i + 1];
+            // (a non-finite phi is rejected like an increase; the first iteration after `start` has ref = +inf)
+            const bool ok = (phi <= ref + 1e-12 * fabs(ref) + 1e-300) || a <= 1.0 / 64.0;
+            if (ok) { ref = phi; a = fmin(1.0, 2.0 * a); }
+            else a *= 0.5;
+            p.mer[4 * i] = a; p.mer[4 * i + 1] = ref; p.mer[4 * i + 2] = ok ? 0.0 : 1.0;
+            red[4] = a;
+            reject = ok ? 0 : 1;
+        }
+        __syncthreads();
+        if (reject) {  // back to the last accepted point plus the shorter step
+            const double a = red[4];
+            for (int t = tid; t < (N + 1) * n; t += nthr)
+                xbw[t] = p.xback[i * (size_t)(N + 1) * n + t] + a * p.dxback[i * (size_t)(N + 1) * n + t];
+            for (int t = tid; t < nz; t += nthr) {
+                const int am = t % m;
+                ubw[t] = fmin(fmax(p.uback[i * (size_t)nz + t] + a * p.vback[i * (size_t)nz + t], p.umin[am]), p.umax[am]);
+            }
+            __syncthreads();
+        }
+    }
+    const double* xb = xbw;
+    const double* ub = ubw;
+    for (int t = tid; t < N * n; t += nthr) {
+        const double xn = xb[n + t];  // stage k+1, component j  (t = k*n + j)
+        p.c[i * (size_t)N * n + t] = p.fval[i * (size_t)N * n + t] - xn;
+        p.ebar[i * (size_t)N * n + t] = xn - p.xref[n + t];
+    }
+    for (int t = tid; t < nz; t += nthr) {
+        const int k = t / m, a = t % m;
+        double g = 0.0;
+        if (p.useR) {
+            double s = 0.0;
+            for (int c2 = 0; c2 < m; ++c2) s += p.R[(size_t)c2 * m + a] * (ub[k * m + c2] - p.uref[k * m + c2]);
+            g += 2.0 * s;
+        }
+        if (p.useS) {  // the input-rate cost is on u itself (src/sub/design_mpc.jl:423-446): row t of 2 D'Sbar D ubar
+            double s = 0.0;
+            for (int c2 = 0; c2 < m; ++c2) {
+                const double sac = p.S[(size_t)c2 * m + a];
+                if (k + 1 < N) s += sac * (ub[k * m + c2] - ub[(k + 1) * m + c2]);
+                if (k > 0) s -= sac * (ub[(k - 1) * m + c2] - ub[k * m + c2]);
+            }
+            g += 2.0 * s;
+        }
+        p.qadd[i * (size_t)nz + t] = g;
+    }
+}
+
+
 struct DesignLtvParams {
     int n, m, N, nz, useR, useS;
     const double* A; const double* B;        // [batch][N][n*n], [batch][N][n*m]  (column-major blocks)
@@ -793,6 +1081,10 @@ struct DesignLtvParams {
     // symmetrised H'_i; the design flag cleared at the start and set there) and the scaled gradient fS_i = d_i .* q_i -- the SQP
     // iteration's k_design_scale, k_fs_scale and flag memset (three launches) ride along
     double* sc_d = nullptr; double* sc_Hs = nullptr; double* sc_fS = nullptr; int* sc_flag = nullptr; int nzs = 0;
+    // k_design_ltv_reg only, prep_on: the SQP iteration's k_sqp_prepare (defects c, state errors ebar, input gradient qadd, the merit
+    // test of the last step) as the kernel's HEAD -- its outputs are this kernel's inputs
+    int prep_on = 0;
+    SqpParams prep;
 };
 
 __host__ __device__ inline size_t design_ltv_lds_doubles(int n, int m, int N) {
@@ -909,6 +1201,10 @@ __global__ __launch_bounds__((128 / TS) * (128 / TS)) void k_design_ltv_reg(Desi
     constexpr int NZP = LTV_REG_NZ;
     const int n = NC > 0 ? NC : p.n, m = p.m, N = p.N, nz = p.nz, nn = n * n, nm = n * m, nab = nn + nm;
     const size_t inst = blockIdx.x;
+    if (p.prep_on) {   // the SQP iteration's defects, state errors and input gradient (this kernel's inputs) and its merit test
+        sqp_prepare_body(p.prep, inst);
+        __syncthreads();
+    }
     double* Gc = smem;                    // [n][NZP] current row block of Gamma~ (row l of the block, column c)
     double* Gn = Gc + (size_t)n * NZP;
     double* T = Gn + (size_t)n * NZP;     // Q_k times the row block

@@ -490,6 +490,8 @@ struct PolishParams {
     int32_t* status;     // in: ADMM status; out: final
     int32_t* piters;
     double* sglobal;     // [batch][64*64] scratch for working sets beyond 32 rows
+    const int32_t* start_rows = nullptr;   // START builds (k_polish_sgl<1>), or null: [batch][65] count + rows (ascending) of a guessed working set of
+                                           // 33..64 rows whose inverse k_guess_iterate_ws has left in sglobal (64 x 64, identity padded): installed at once
     const int32_t* perm; // [ntiles*16] per-tile processing order written by k_admm (hard instances first, -1 = pad)
     int ntiles;          // ADMM tiles (16 instances each)
     int lds_per_wave;    // doubles of LDS per wave (>= POLISH_LDS_MIN_PER_WAVE and >= the rollout trajectory buffer)
@@ -532,6 +534,56 @@ __device__ __forceinline__ double fast_rcp_d(double v) {
     r = __builtin_fma(__builtin_fma(-v, r, 1.0), r, r);
     r = __builtin_fma(__builtin_fma(-v, r, 1.0), r, r);
     return r;
+}
+
+// One pivot of the symmetric Gauss-Jordan sweep of a matrix held one ROW per lane, this wave holding 16 of its columns (c0 .. c0 + 15)
+// in registers (k_sdual_start, k_guess_iterate_ws: the waves of a workgroup share the columns).  The pivot row has been published
+// through LDS by the pivot lanes and read by the caller in one batch: pj = this wave's 16 entries of it (wave-uniform reads), col = the
+// lane's own entry, which is also its element of the pivot COLUMN, the matrix being symmetric, d = the pivot.  (Measured and dropped:
+// taking the 16 entries out of `col` with v_readlane instead of reading them from LDS -- 41.6 -> 48.7 us for the 50-row sets of the
+// SQP iteration: a readlane feeding a vector operand costs its ~38-cycle link 32 times per pivot.)
+// Sweep convention: after the rows K, M_KK = -(G_KK)^-1, M_iK = G_iK (G_KK)^-1, the rest the Schur complement.  Row i != k:
+// r_ij -= (col_i / d) pj_j; the pivot row: pj_j / d (= 0 - (-1/d) pj_j: the lane's old row is masked by `keep`); column k: col_i / d,
+// and -1/d on the pivot (the pivot lane's factor).
+__device__ __forceinline__ void gj16_pivot(double (&r)[16], const double (&pj)[16], const double col, const double d, const int c0, const int k,
+                                           const int lane) {
+    const double invd = fast_rcp_d(d);
+    const bool piv = lane == k;
+    const double f = piv ? -invd : col * invd;
+    const double keep = piv ? 0.0 : 1.0;
+    // (column k: f on every lane -- the pivot lane's f IS -1/d.  A select per register on a scalar condition; a switch over the
+    // sixteen registers instead made the compiler copy the whole array at every node of its branch tree)
+    const int kk = k - c0;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        const double u = __builtin_fma(-f, pj[jj], keep * r[jj]);
+        r[jj] = (jj == kk) ? f : u;
+    }
+}
+
+// Two pivots (k, k + 1) of the same sweep behind ONE publication and barrier: sweeping k and then k + 1 is the block sweep on the pair,
+//   [f0 f1] = [col0 col1] D^-1,  D = [d11 d12; d12 d22] (entries k, k + 1 of the two published rows),  r_ij -= f0 pj0_j + f1 pj1_j,
+// with D^-1 from the sequential formulas (1 / d11, then 1 / (d22 - d12^2 / d11): the second pivot exactly as the one-by-one sweep
+// forms it).  The two pivot rows become D^-1 [row_k; row_k+1]: the same FMAs with (f0, f1) = -(row of D^-1) and the lane's old row
+// masked; columns k and k + 1 of every row are (f0, f1).  The caller has tested both pivots (d11 and s22 = d22 - d12^2 / d11).
+__device__ __forceinline__ void gj16_pivot2(double (&r)[16], const double (&pj0)[16], const double (&pj1)[16], const double col0, const double col1,
+                                            const double d11, const double d12, const double s22, const int c0, const int k, const int lane) {
+    const double i11 = fast_rcp_d(d11);
+    const double t = d12 * i11;
+    const double e11 = fast_rcp_d(s22);
+    const double e01 = -t * e11;
+    const double e00 = __builtin_fma(-t, e01, i11);   // 1 / d11 + t^2 / s22
+    const bool p0 = lane == k, p1 = lane == k + 1;
+    double f0 = __builtin_fma(col0, e00, col1 * e01), f1 = __builtin_fma(col0, e01, col1 * e11);
+    f0 = p0 ? -e00 : (p1 ? -e01 : f0);
+    f1 = p0 ? -e01 : (p1 ? -e11 : f1);
+    const double keep = (p0 || p1) ? 0.0 : 1.0;
+    const int kk = k - c0;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        const double u = __builtin_fma(-f1, pj1[jj], __builtin_fma(-f0, pj0[jj], keep * r[jj]));
+        r[jj] = (jj == kk) ? f0 : ((jj == kk + 1) ? f1 : u);   // (columns k, k + 1: selects on scalar conditions, see gj16_pivot)
+    }
 }
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -775,7 +827,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 // workgroups whose LDS holds the instance's own G_i (requested with direct global -> LDS loads at the start of the instance) and
 // the 64 x 64 Sinv of a working set beyond 32 rows -- a bordering step beyond 32 rows is then two sweeps over LDS instead of
 // one over global scratch and one over rows of G_i in L2.
-template <bool GLDS, bool GPRE, int KOFF, bool SGL = false>
+template <bool GLDS, bool GPRE, int KOFF, bool SGL = false, bool START = false>
 __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* smem) {
     const PolishParams& p = p_arg;
     constexpr int CH = (GLDS || SGL) ? 8 : 16;   // (16 for the LDS homes too: measured -6 % on the headline, round 3)  // positions per chunk of G rows (LDS latency needs fewer loads in flight than L2 latency)
@@ -1367,6 +1419,45 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
         if (s0 != 0) { ibuf[p0] = r0; ibuf[64 + p0] = s0; }
         if (s1 != 0) { ibuf[p1] = r1; ibuf[64 + p1] = s1; }
         wave_fence_lds();
+        bool started = false;
+        if constexpr (START) {
+            // A guessed set of 33..64 rows whose inverse was built ahead of this kernel (four waves per instance, in registers:
+            // k_guess_iterate_ws): installed in the second tier as it stands.  Left to this kernel, the first 32 rows are one Gauss-Jordan
+            // sweep in registers and every further row a bordering in memory mode, 6 k cycles each -- 108 k of the 190 k cycles of an
+            // SQP iteration's finish (50 inputs of 100 on a bound).  The list is compared row by row: a guess this kernel reads differently
+            // (a bound within rounding of the iterate) takes the ordinary route.
+            if (p.start_rows && k0 > 32) {
+                const int32_t* sr = GL(p.start_rows) + (size_t)inst * 65;
+                const bool same = sr[0] == k0 && (lane >= k0 || sr[1 + lane] == ibuf[lane]);
+                if (__all(same)) {
+                    started = true;
+                    k = k0;
+                    wrow = lane < k0 ? ibuf[lane] : 0;
+                    wsd = lane < k0 ? ibuf[64 + lane] : 0;
+                    wave_fence_lds();
+                    if (s0 != 0) { act0 = true; bnd0 = s0 > 0 ? hi0 : lo0; }
+                    if (s1 != 0) { act1 = true; bnd1 = s1 > 0 ? hi1 : lo1; }
+                    put_rows(s0 > 0 ? hi0 : lo0, s1 > 0 ? hi1 : lo1);
+                    wbnd = lane < k0 ? rowbuf[wrow] : 0.0;
+                    lam = 0.0;
+                    wrow_s[lane] = wrow;
+                    const double* src = GL(p.sglobal) + (size_t)inst * POLISH_GLB_PER_INST;
+                    if (Sg != src) {
+                        for (int c = 0; c < 64; c += 8) {
+                            double v[8];
+#pragma unroll
+                            for (int t = 0; t < 8; ++t) v[t] = src[(c + t) * 64 + lane];
+#pragma unroll
+                            for (int t = 0; t < 8; ++t) Sg[(c + t) * 64 + lane] = v[t];
+                        }
+                    }
+                    sync_s(PolishMode<true>{});
+                    recompute(PolishMode<true>{});
+                    overflow = true;   // continue in memory mode below
+                }
+            }
+        }
+        if (!started) {
         k = k0 < 32 ? k0 : 32;
         if (pos < k) { wrow = ibuf[pos]; wsd = ibuf[64 + pos]; }
         // pending rows (positions >= 32) are remembered on the lanes of the same number
@@ -1462,6 +1553,7 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
             fresh = false;
             overflow = true;  // continue in global mode below
         }
+        }  // !started
     }
     ALMPC_STAMP(inst, 10);
     if (!give_up) {
@@ -1705,10 +1797,11 @@ void k_polish(PolishParams p_arg) {
 
 // per-instance models, small batches: single-wave workgroups, G_i and the second-tier Sinv in LDS (one workgroup per CU)
 // (a template only so that it is compiled where it is instantiated -- almpc_tu_step.hip -- and not by every file that reads this header)
-template <int UNUSED = 0>
+// START = 1: the build that can install a guessed working set whose inverse was made ahead of it (PolishParams::start_rows)
+template <int START = 0>
 __global__ __launch_bounds__(64) void k_polish_sgl(PolishParams p_arg) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    polish_body<false, false, 0, true>(p_arg, smem);
+    polish_body<false, false, 0, true, START != 0>(p_arg, smem);
 }
 
 // ------------------------------------------------------------------------------------------------

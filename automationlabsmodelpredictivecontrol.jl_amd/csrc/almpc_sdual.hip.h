@@ -1136,8 +1136,8 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
 // back as broadcasts, and reads its own element of the pivot COLUMN from it -- the matrix stays symmetric).  Rows are swept in list order,
 // so the pivot of row k is its Schur complement on the rows accepted before it -- exactly the quantity the bordering tests: a dependent
 // row (pivot <= 1e-12 G_kk) is left out, as there.  One workgroup of four waves per instance, each wave holding 16 columns of every row
-// (one wave with all 64 columns: 4.1 k cycles per pivot, 77 us at 45 rows; four waves meet at ONE barrier per pivot -- the pivot-row buffer
-// is double buffered).
+// (one wave with all 64 columns: 4.1 k cycles per pivot, 77 us at 45 rows; four waves meet at ONE barrier per PAIR of pivots -- the block
+// sweep on two rows, gj16_pivot2 -- and the pivot-row buffer is double buffered).
 // Output: the inverse (packed lower triangle of the accepted rows, in list order) to start_inv, the accepted codes back into start_ws
 // with SDUAL_START_BUILT in the count.  Sweep convention: after the rows K,  M_KK = -(G_KK)^-1,  M_iK = G_iK (G_KK)^-1,  the rest the Schur
 // complement.
@@ -1153,12 +1153,12 @@ constexpr int SDUAL_START_WAVES = 4;   // waves per instance: wave w holds colum
 
 inline __global__ __launch_bounds__(64 * SDUAL_START_WAVES) void k_sdual_start(SdualStartParams p) {
     static_assert(SDUAL_SINV_SAVE == 64 && SDUAL_START_WAVES * 16 == 64, "one row of the start per lane, 16 columns per wave");
-    __shared__ __attribute__((aligned(16))) double s_prow[2][64];   // the pivot row, double buffered: one barrier per pivot
+    __shared__ __attribute__((aligned(16))) double s_prow[2][128];   // two pivot rows per step, double buffered: one barrier per step
     __shared__ double s_gd[64];
     __shared__ int s_code[64];
     __shared__ int s_head[64 * SDUAL_START_WAVES];
     if (p.gate && __builtin_nontemporal_load(p.gate) != p.gate_val) return;
-    const int wv = threadIdx.x >> 6, lane0 = threadIdx.x & 63, c0 = 16 * wv;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane0 = threadIdx.x & 63, c0 = 16 * wv;   // (wave-uniform, and the compiler knows it)
     const int TP = p.TP;
     // the workgroup's instances are blockIdx.x + t gridDim.x: thread t looks at the t-th one (one round trip for the lot)
     {
@@ -1193,42 +1193,54 @@ inline __global__ __launch_bounds__(64 * SDUAL_START_WAVES) void k_sdual_start(S
         }
         __syncthreads();
         double r[16];
+        {   // (clamped addresses, no branch per element: all sixteen loads in flight before the first wait)
+            int tj[16];
 #pragma unroll
-        for (int jj = 0; jj < 16; ++jj) {
-            const int j = c0 + jj;
-            r[jj] = 0.0;
-            if (j < cnt) {   // (uniform)
-                const int tj = __builtin_amdgcn_readfirstlane(s_code[j]) >> 2;
-                const size_t a = lane >= j ? (size_t)ti * TP + tj : (size_t)tj * TP + ti;
-                if (lane < cnt) r[jj] = p.ghat[a];
-            }
+            for (int jj = 0; jj < 16; ++jj) tj[jj] = s_code[c0 + jj < cnt ? c0 + jj : 0] >> 2;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) r[jj] = p.ghat[lane >= c0 + jj ? (size_t)ti * TP + tj[jj] : (size_t)tj[jj] * TP + ti];
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) r[jj] = (c0 + jj < cnt && lane < cnt) ? r[jj] : 0.0;
         }
         unsigned long long acc = 0ull;   // accepted rows (every wave keeps the same record)
-        for (int k = 0; k < cnt; ++k) {
-            double* pw = s_prow[k & 1];
-            if (lane == k) {
+        // two pivots per publication and barrier (gj16_pivot2) where both are accepted; the tests are the one-by-one sweep's
+        for (int k = 0, step = 0; k < cnt; ++step) {
+            double* pw0 = s_prow[step & 1];
+            double* pw1 = pw0 + 64;
+            const bool two = k + 1 < cnt;
+            if (lane == k || (two && lane == k + 1)) {
+                double* pw = lane == k ? pw0 : pw1;
 #pragma unroll
                 for (int jj = 0; jj < 16; jj += 2) *reinterpret_cast<double2*>(pw + c0 + jj) = make_double2(r[jj], r[jj + 1]);
             }
             __syncthreads();
-            const double col = pw[lane];
-            const double d = pw[k];
-            if (!(d > 1e-12 * s_gd[k])) continue;   // dependent on the rows before it: left out (uniform over the workgroup)
-            acc |= 1ull << k;
-            if (c0 >= cnt) continue;                // (this wave's columns are beyond the list; it still meets the barriers)
-            const double invd = 1.0 / d;
-            const bool piv = lane == k;
-            // row i != k: r_ij -= (col_i / d) prow_j; the pivot row itself: prow_j / d = 0 - (-1/d) prow_j; column k: col_i / d, -1/d on the pivot
-            const double f = piv ? -invd : col * invd;
-            const double fix = piv ? -invd : f;
-            const int kk = k - c0;
+            double pj0[16], pj1[16];   // (every read of the pivot rows in one batch, in front of the pivot tests)
 #pragma unroll
             for (int jj = 0; jj < 16; jj += 2) {
-                const double2 pj = *reinterpret_cast<const double2*>(pw + c0 + jj);
-                const double u0 = fma(-f, pj.x, piv ? 0.0 : r[jj]), u1 = fma(-f, pj.y, piv ? 0.0 : r[jj + 1]);
-                r[jj] = jj == kk ? fix : u0;
-                r[jj + 1] = jj + 1 == kk ? fix : u1;
+                const double2 t2 = *reinterpret_cast<const double2*>(pw0 + c0 + jj);
+                pj0[jj] = t2.x; pj0[jj + 1] = t2.y;
             }
+            const double col0 = pw0[lane], d11 = pw0[k];
+            double col1 = 0.0, d12 = 0.0, d22 = 0.0;
+            if (two) {
+#pragma unroll
+                for (int jj = 0; jj < 16; jj += 2) {
+                    const double2 t2 = *reinterpret_cast<const double2*>(pw1 + c0 + jj);
+                    pj1[jj] = t2.x; pj1[jj + 1] = t2.y;
+                }
+                col1 = pw1[lane]; d12 = pw0[k + 1]; d22 = pw1[k + 1];
+            }
+            // (uniform over the workgroup: every wave reads the same pivots)
+            if (!(d11 > 1e-12 * s_gd[k])) { k += 1; continue; }   // dependent on the rows before it: left out; k + 1 is published again
+            acc |= 1ull << k;
+            const double s22 = two ? d22 - d12 * d12 / d11 : 0.0;
+            if (two && s22 > 1e-12 * s_gd[k + 1]) {
+                acc |= 1ull << (k + 1);
+                if (c0 < cnt) gj16_pivot2(r, pj0, pj1, col0, col1, d11, d12, s22, c0, k, lane);   // (else: columns beyond the list; the wave still meets the barriers)
+            } else {
+                if (c0 < cnt) gj16_pivot(r, pj0, col0, d11, c0, k, lane);   // (alone: the last row, or k + 1 depends on the rows up to k: left out)
+            }
+            k += 2;
         }
         // ---- out: accepted rows in list order
         const int na = __popcll(acc);

@@ -11,130 +11,15 @@
 #include <hip/hip_runtime.h>
 #include "almpc_fnn.hip.h"
 #include "almpc_kernels.hip.h"  // wave_max
+#include "almpc_instance.hip.h" // SqpParams, sqp_prepare_body
 
 namespace almpc {
 
-struct SqpParams {
-    int n, m, N, nz, batch, useR, useS;
-    const double* xref;   // [(N+1)][n] shared state reference
-    const double* uref;   // [N][m]     shared input reference
-    const double* R; const double* S;   // m x m, symmetrised
-    const double* umin; const double* umax;
-    double* xbar;         // [batch][(N+1)][n]
-    double* ubar;         // [batch][N][m]
-    const double* fval;   // [batch][N][n]  network outputs at (xbar_k, ubar_k)
-    const double* A; const double* B;   // [batch][N][n*n], [batch][N][n*m]
-    double* c;            // [batch][N][n]  defects f(xbar_k, ubar_k) - xbar_{k+1}
-    double* ebar;         // [batch][N][n]  xbar_{k+1} - xref_{k+1}
-    double* qadd;         // [batch][nz]    2 Rbar (ubar - uref) + 2 D'Sbar D ubar
-    const double* v;      // [batch][N][m]  QP solution (the step kernels' e_u output); overwritten with ubar - uref
-    const int* flag;      // [batch] design failure of this iteration (non-zero: skip the update)
-    const int* status;    // [batch] status of the QP solve (2 = non-finite: skip the update)
-    int* bad;             // [batch] sticky: some iteration of this instance was skipped
-    unsigned long long* stats;  // [2]: bit patterns of max |v| and max |c| over the batch (non-negative doubles order like integers)
-    double step_scale;
-    // step rule 1 (merit-function safeguard): see k_sqp_prepare
-    int adaptive;
-    double mu;            // weight of the defects in the merit function J + mu |defects|_1
-    const double* Q; const double* P; long sP;   // cost weights for J (P shared or per instance)
-    double* mer;          // [batch][4]: step factor a, merit of the last accepted point, redo flag (1: this iteration is void), spare
-    double* xback; double* uback;   // [batch][(N+1) n], [batch][nz]: last accepted point
-    double* dxback; double* vback;  // its step (dx of every stage, v), so that a rejected trial can be re-taken shorter
-    double *x, *ex, *u, *eu;    // result buffers: the iterate after the update
-};
+// (struct SqpParams and sqp_prepare_body: csrc/almpc_instance.hip.h, beside the design kernel whose head runs them)
 
 // Before the QP: defects, state errors and the input part of the gradient, one workgroup per instance.
-// Step rule 1.  Full Gauss-Newton steps are not globally convergent (3 of the 256 benchmark instances end in a cycle), and
-// heuristics on |v| alone misfire in the first iterations, where growing steps are normal.  The safeguard is the classical l1
-// merit function phi = J(x, u) + mu |f(x, u) - x+|_1, evaluated a posteriori: the network outputs at the point reached by the last
-// step are computed by THIS iteration's linearisation anyway, so the test costs one reduction.  If phi did not decrease, the
-// point is rejected: the iterate goes back to the last accepted point plus HALF the step (both kept), this iteration's QP -- built
-// at the rejected point -- is void for the instance (redo flag: k_sqp_step leaves it alone), and the next iteration tests the
-// shorter step.  Accepted steps double the factor back up to 1; at 1/64 a step is accepted regardless.
-inline __global__ __launch_bounds__(256) void k_sqp_prepare(SqpParams p) {
-    const int n = p.n, m = p.m, N = p.N, nz = p.nz;
-    const size_t i = blockIdx.x;
-    double* xbw = p.xbar + i * (size_t)(N + 1) * n;
-    double* ubw = p.ubar + i * (size_t)nz;
-    if (p.adaptive) {
-        __shared__ double red[8];
-        __shared__ int reject;
-        double part = 0.0;
-        const double* Pm = p.P + i * p.sP;
-        for (int t = threadIdx.x; t < (N + 1) * n; t += blockDim.x) {   // e_x' W e_x, W = Q for stages 1..N, P for N+1
-            const int k = t / n, r = t % n;
-            const double* W = (k == N) ? Pm : p.Q;
-            double sdot = 0.0;
-            for (int j = 0; j < n; ++j) sdot += W[(size_t)j * n + r] * (xbw[k * n + j] - p.xref[k * n + j]);
-            part += (xbw[t] - p.xref[t]) * sdot;
-        }
-        for (int t = threadIdx.x; t < nz; t += blockDim.x) {
-            const int k = t / m, a = t % m;
-            if (p.useR) {
-                double sdot = 0.0;
-                for (int c2 = 0; c2 < m; ++c2) sdot += p.R[(size_t)c2 * m + a] * (ubw[k * m + c2] - p.uref[k * m + c2]);
-                part += (ubw[t] - p.uref[t]) * sdot;
-            }
-            if (p.useS && k + 1 < N) {
-                double sdot = 0.0;
-                for (int c2 = 0; c2 < m; ++c2) sdot += p.S[(size_t)c2 * m + a] * (ubw[k * m + c2] - ubw[(k + 1) * m + c2]);
-                part += (ubw[t] - ubw[t + m]) * sdot;
-            }
-        }
-        for (int t = threadIdx.x; t < N * n; t += blockDim.x) part += p.mu * fabs(p.fval[i * (size_t)N * n + t] - xbw[n + t]);
-        part = wave_sum(part);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const double phi = (red[0] + red[1]) + (red[2] + red[3]);
-            double a = p.mer[4 * i], ref = p.mer[4 * i + 1];
-            // (a non-finite phi is rejected like an increase; the first iteration after `start` has ref = +inf)
-            const bool ok = (phi <= ref + 1e-12 * fabs(ref) + 1e-300) || a <= 1.0 / 64.0;
-            if (ok) { ref = phi; a = fmin(1.0, 2.0 * a); }
-            else a *= 0.5;
-            p.mer[4 * i] = a; p.mer[4 * i + 1] = ref; p.mer[4 * i + 2] = ok ? 0.0 : 1.0;
-            red[4] = a;
-            reject = ok ? 0 : 1;
-        }
-        __syncthreads();
-        if (reject) {  // back to the last accepted point plus the shorter step
-            const double a = red[4];
-            for (int t = threadIdx.x; t < (N + 1) * n; t += blockDim.x)
-                xbw[t] = p.xback[i * (size_t)(N + 1) * n + t] + a * p.dxback[i * (size_t)(N + 1) * n + t];
-            for (int t = threadIdx.x; t < nz; t += blockDim.x) {
-                const int am = t % m;
-                ubw[t] = fmin(fmax(p.uback[i * (size_t)nz + t] + a * p.vback[i * (size_t)nz + t], p.umin[am]), p.umax[am]);
-            }
-            __syncthreads();
-        }
-    }
-    const double* xb = xbw;
-    const double* ub = ubw;
-    for (int t = threadIdx.x; t < N * n; t += blockDim.x) {
-        const double xn = xb[n + t];  // stage k+1, component j  (t = k*n + j)
-        p.c[i * (size_t)N * n + t] = p.fval[i * (size_t)N * n + t] - xn;
-        p.ebar[i * (size_t)N * n + t] = xn - p.xref[n + t];
-    }
-    for (int t = threadIdx.x; t < nz; t += blockDim.x) {
-        const int k = t / m, a = t % m;
-        double g = 0.0;
-        if (p.useR) {
-            double s = 0.0;
-            for (int c2 = 0; c2 < m; ++c2) s += p.R[(size_t)c2 * m + a] * (ub[k * m + c2] - p.uref[k * m + c2]);
-            g += 2.0 * s;
-        }
-        if (p.useS) {  // the input-rate cost is on u itself (src/sub/design_mpc.jl:423-446): row t of 2 D'Sbar D ubar
-            double s = 0.0;
-            for (int c2 = 0; c2 < m; ++c2) {
-                const double sac = p.S[(size_t)c2 * m + a];
-                if (k + 1 < N) s += sac * (ub[k * m + c2] - ub[(k + 1) * m + c2]);
-                if (k > 0) s -= sac * (ub[(k - 1) * m + c2] - ub[k * m + c2]);
-            }
-            g += 2.0 * s;
-        }
-        p.qadd[i * (size_t)nz + t] = g;
-    }
-}
+// (see sqp_prepare_body)
+inline __global__ __launch_bounds__(256) void k_sqp_prepare(SqpParams p) { sqp_prepare_body(p, blockIdx.x); }
 
 // After the QP: dx_{k+1} = A_k dx_k + B_k v_k + c_k (dx_0 = 0), xbar += s dx, ubar += s v; one workgroup per instance.
 // The recursion is a dependent chain of N small products.  All of its operands are staged in LDS first -- [A_k | B_k | c_k] of

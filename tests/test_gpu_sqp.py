@@ -389,3 +389,32 @@ def test_scaling_in_the_design_kernels_tail_equals_the_split_launches(capi, mo, 
     assert np.array_equal(res["fused"]["status"], res["split"]["status"])
     # (with the scaling in the tail, v0S_i = -G_i fS_i also comes out of the inverse's launch: another summation order, rounding level)
     assert np.abs(res["fused"]["u"] - res["split"]["u"]).max() <= 1e-9 and np.abs(res["fused"]["x"] - res["split"]["x"]).max() <= 1e-9
+
+
+@pytest.mark.parametrize("env", ["ALMPC_DBG_SPLIT_PREPARE", "ALMPC_NO_GUESS_WS"])
+def test_round5_folds_of_the_iteration_change_no_iterate(capi, mo, monkeypatch, env):
+    """Round 5, two launches' worth of the iteration moved: (i) k_sqp_prepare runs as the head of k_design_ltv_reg
+    (ALMPC_DBG_SPLIT_PREPARE=1: the separate launch) -- the same 256 threads doing the same arithmetic; (ii) the guess of the finish
+    comes with the inverse of its working set, built by four waves per instance (k_guess_iterate_ws, two pivots per barrier) and
+    installed by k_polish_sgl<1> (ALMPC_NO_GUESS_WS=1: k_guess_iterate, and the finish borders the rows beyond 32 in one at a time) --
+    another order of operations for the same inverse.  N = 50: 100 inputs, about half of them on a bound after a few iterations.
+    The merit safeguard is on in one of the runs (its test is part of the prepare step)."""
+    res = {}
+    for tag in ("new", "old"):
+        if tag == "old":
+            monkeypatch.setenv(env, "1")
+        else:
+            monkeypatch.delenv(env, raising=False)
+        f, s, kw, X0 = _setup(capi, mo, 48, 50, amp=0.9)
+        s.sqp_fnn_start(X0)
+        s.sqp_fnn_iterate(6)
+        st, de = s.sqp_fnn_iterate(6, step_rule="merit")
+        res[tag] = (s.get_results(), st, de)
+        s.close()
+    monkeypatch.delenv(env, raising=False)
+    a, b = res["new"][0], res["old"][0]
+    assert np.array_equal(a["status"], b["status"]) and np.all(a["status"] == 0)
+    assert np.abs(a["u"] - b["u"]).max() <= 1e-9 and np.abs(a["x"] - b["x"]).max() <= 1e-9
+    assert np.allclose(res["new"][1], res["old"][1], rtol=1e-6, atol=1e-12)
+    nb = (np.abs(a["u"]) >= 1.0 - 1e-12).reshape(48, -1).sum(axis=1)
+    assert nb.max() > 32   # (working sets beyond the finish's register mode: the installed inverse was used)

@@ -26,6 +26,11 @@ d = np.diff(o[ok][:, [8, 9, 10, 11, 12]], axis=1)
 for i, nm in enumerate(names):
     v = d[:, i]
     print(f"{nm:28s} cycles: median {int(np.median(v)):7d}  p90 {int(np.percentile(v,90)):7d}  max {v.max():7d}")
+g = np.diff(o[:, 0:6], axis=1)
+for i, nm in enumerate(["guess", "flags + positions", "gather K", "Gauss-Jordan", "write-out"]):
+    print(f"k_guess_iterate_ws {nm:20s} cycles: median {int(np.median(g[:, i])):7d}  max {g[:, i].max():7d}")
+print("k_guess_iterate_ws inside the sweep: publication + barrier", int(np.median(o[:, 13])), " reads of the pivot rows", int(np.median(o[:, 14])))
+print("k_guess_iterate_ws wall clock us: median", np.median(o[:, 7] - o[:, 6]) / 100, " cycles per us:", np.median((o[:, 5] - o[:, 0]) / np.maximum(1, (o[:, 7] - o[:, 6]) / 100)))
 print("instances stamped", int(ok.sum()), " total median", int(np.median(o[ok][:, 12] - o[ok][:, 8])), "max", int((o[ok][:, 12] - o[ok][:, 8]).max()))
 u = s.get_results(want=('u',))['u']
 na = (np.abs(u) >= 1.0).reshape(bq, -1).sum(axis=1)
