@@ -1144,7 +1144,7 @@ def main():
         try:
             import csv
             ks, src = {}, None
-            for cand in ("r4_sqp_kernel_stats.csv", "r3_sqp_kernel_stats.csv", "r2_sqp_kernel_stats.csv"):
+            for cand in ("r5_sqp_kernel_stats.csv", "r4_sqp_kernel_stats.csv", "r3_sqp_kernel_stats.csv", "r2_sqp_kernel_stats.csv"):
                 if os.path.exists(os.path.join(ROOT, "profiles", cand)):
                     src = cand
                     break
@@ -1173,8 +1173,8 @@ def main():
                + 2 * nzq * nzq + 10 * 2 * nzq * nzq)
         secq = best / its
         out["sqp_fnn"]["roofline"] = {
-            "bound": "mfma", "kernel": "k_polish_sgl / k_design_ltv_reg (~85 us each: the two longest of the 13 launches; the 100 x 100 Gauss-Jordan inverse "
-                                       "k_design_inverse_c32<16,true> is third at ~52 us)",
+            "bound": "mfma", "kernel": "k_design_ltv_reg (~90 us: the longest of the 11 launches; the 100 x 100 Gauss-Jordan inverse k_design_inverse_c32<16,true> "
+                                       "~51 us, the Jacobians ~40 us, k_guess_iterate_ws ~30 us, k_sqp_step ~27 us, k_polish_sgl<1> ~24 us)",
             "achieved": bq * flq / secq / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": bq * flq / secq / 1e12 / FP64_PEAK_TFLOPS,
             "traffic": None, "algorithmic_flops_per_instance_iteration": flq,
             "note": "FP64 vector pipeline (78.6 TFLOP/s peak, as the matrix cores); 256 instances are one workgroup per CU in every kernel of "
