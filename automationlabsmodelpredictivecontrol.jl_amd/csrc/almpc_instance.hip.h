@@ -649,7 +649,7 @@ inline __global__ __launch_bounds__(256) void k_guess_iterate_ws(AdmmInstParams 
     if (wv == 0) ALMPC_STAMP(inst, 2);
     const double* Gi = w.G + (size_t)inst * w.G_stride;
     const int ri = lane < k0 ? s_rows[lane] : 0;
-    double r[16];
+    gj16_row r;
     {   // (clamped addresses, no branch per element: all sixteen loads in flight before the first wait)
         int rj[16];
 #pragma unroll
@@ -704,9 +704,9 @@ inline __global__ __launch_bounds__(256) void k_guess_iterate_ws(AdmmInstParams 
                 pj1[jj] = t2.x; pj1[jj + 1] = t2.y;
             }
             const double col1 = pw1[lane], d12 = pw0[k + 1], d22 = pw1[k + 1];
-            const double s22 = d22 - d12 * d12 / d11;
+            const double i11 = fast_rcp_d(d11), t = d12 * i11, s22 = __builtin_fma(-t, d12, d22);
             if (!(d11 > 0.0) || !(s22 > 0.0)) { bad = true; break; }   // (uniform: every wave reads the same pivots)
-            if (c0 < k0) gj16_pivot2(r, pj0, pj1, col0, col1, d11, d12, s22, c0, k, lane);   // (else: columns beyond the set; the wave still meets the barriers)
+            if (c0 < k0) gj16_pivot2(r, pj0, pj1, col0, col1, i11, t, s22, c0, k, lane);   // (else: columns beyond the set; the wave still meets the barriers)
             k += 2;
         } else {
             if (!(d11 > 0.0)) { bad = true; break; }

@@ -545,31 +545,32 @@ __device__ __forceinline__ double fast_rcp_d(double v) {
 // Sweep convention: after the rows K, M_KK = -(G_KK)^-1, M_iK = G_iK (G_KK)^-1, the rest the Schur complement.  Row i != k:
 // r_ij -= (col_i / d) pj_j; the pivot row: pj_j / d (= 0 - (-1/d) pj_j: the lane's old row is masked by `keep`); column k: col_i / d,
 // and -1/d on the pivot (the pivot lane's factor).
-__device__ __forceinline__ void gj16_pivot(double (&r)[16], const double (&pj)[16], const double col, const double d, const int c0, const int k,
+typedef double gj16_row[16];
+// (Measured and dropped, round 5: the rows as an ext_vector_type(16) with the pivot columns written at a wave-uniform DYNAMIC index.
+// The compiler if-converts the guarded write into an indexed move on a COPY of the array followed by a select per register -- no
+// fewer instructions -- and executes the indexed move also when the guard is false, with an index outside the array: a GPU memory
+// fault on the first run.  A select per register on a scalar condition it is.)
+__device__ __forceinline__ void gj16_pivot(gj16_row& r, const double (&pj)[16], const double col, const double d, const int c0, const int k,
                                            const int lane) {
     const double invd = fast_rcp_d(d);
     const bool piv = lane == k;
     const double f = piv ? -invd : col * invd;
     const double keep = piv ? 0.0 : 1.0;
-    // (column k: f on every lane -- the pivot lane's f IS -1/d.  A select per register on a scalar condition; a switch over the
-    // sixteen registers instead made the compiler copy the whole array at every node of its branch tree)
     const int kk = k - c0;
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) {
         const double u = __builtin_fma(-f, pj[jj], keep * r[jj]);
-        r[jj] = (jj == kk) ? f : u;
+        r[jj] = (jj == kk) ? f : u;   // column k: f on every lane -- the pivot lane's f IS -1/d
     }
 }
 
 // Two pivots (k, k + 1) of the same sweep behind ONE publication and barrier: sweeping k and then k + 1 is the block sweep on the pair,
 //   [f0 f1] = [col0 col1] D^-1,  D = [d11 d12; d12 d22] (entries k, k + 1 of the two published rows),  r_ij -= f0 pj0_j + f1 pj1_j,
-// with D^-1 from the sequential formulas (1 / d11, then 1 / (d22 - d12^2 / d11): the second pivot exactly as the one-by-one sweep
-// forms it).  The two pivot rows become D^-1 [row_k; row_k+1]: the same FMAs with (f0, f1) = -(row of D^-1) and the lane's old row
-// masked; columns k and k + 1 of every row are (f0, f1).  The caller has tested both pivots (d11 and s22 = d22 - d12^2 / d11).
-__device__ __forceinline__ void gj16_pivot2(double (&r)[16], const double (&pj0)[16], const double (&pj1)[16], const double col0, const double col1,
-                                            const double d11, const double d12, const double s22, const int c0, const int k, const int lane) {
-    const double i11 = fast_rcp_d(d11);
-    const double t = d12 * i11;
+// with D^-1 from the sequential formulas (i11 = 1 / d11, t = d12 i11, s22 = d22 - t d12, then 1 / s22: the second pivot as the one-by-one
+// sweep forms it; the caller has computed them for its pivot tests).  The two pivot rows become D^-1 [row_k; row_k+1]: the same FMAs
+// with (f0, f1) = -(row of D^-1) and the lane's old row masked; columns k and k + 1 of every row are (f0, f1).
+__device__ __forceinline__ void gj16_pivot2(gj16_row& r, const double (&pj0)[16], const double (&pj1)[16], const double col0, const double col1,
+                                            const double i11, const double t, const double s22, const int c0, const int k, const int lane) {
     const double e11 = fast_rcp_d(s22);
     const double e01 = -t * e11;
     const double e00 = __builtin_fma(-t, e01, i11);   // 1 / d11 + t^2 / s22
@@ -582,7 +583,7 @@ __device__ __forceinline__ void gj16_pivot2(double (&r)[16], const double (&pj0)
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) {
         const double u = __builtin_fma(-f1, pj1[jj], __builtin_fma(-f0, pj0[jj], keep * r[jj]));
-        r[jj] = (jj == kk) ? f0 : ((jj == kk + 1) ? f1 : u);   // (columns k, k + 1: selects on scalar conditions, see gj16_pivot)
+        r[jj] = (jj == kk) ? f0 : ((jj == kk + 1) ? f1 : u);   // (columns k, k + 1: selects on scalar conditions)
     }
 }
 

@@ -1192,7 +1192,7 @@ inline __global__ __launch_bounds__(64 * SDUAL_START_WAVES) void k_sdual_start(S
             s_gd[lane] = lane < cnt ? p.ghat[(size_t)ti * TP + ti] : 1.0;
         }
         __syncthreads();
-        double r[16];
+        gj16_row r;
         {   // (clamped addresses, no branch per element: all sixteen loads in flight before the first wait)
             int tj[16];
 #pragma unroll
@@ -1233,10 +1233,11 @@ inline __global__ __launch_bounds__(64 * SDUAL_START_WAVES) void k_sdual_start(S
             // (uniform over the workgroup: every wave reads the same pivots)
             if (!(d11 > 1e-12 * s_gd[k])) { k += 1; continue; }   // dependent on the rows before it: left out; k + 1 is published again
             acc |= 1ull << k;
-            const double s22 = two ? d22 - d12 * d12 / d11 : 0.0;
+            const double i11 = fast_rcp_d(d11), t = d12 * i11;
+            const double s22 = two ? __builtin_fma(-t, d12, d22) : 0.0;
             if (two && s22 > 1e-12 * s_gd[k + 1]) {
                 acc |= 1ull << (k + 1);
-                if (c0 < cnt) gj16_pivot2(r, pj0, pj1, col0, col1, d11, d12, s22, c0, k, lane);   // (else: columns beyond the list; the wave still meets the barriers)
+                if (c0 < cnt) gj16_pivot2(r, pj0, pj1, col0, col1, i11, t, s22, c0, k, lane);   // (else: columns beyond the list; the wave still meets the barriers)
             } else {
                 if (c0 < cnt) gj16_pivot(r, pj0, col0, d11, c0, k, lane);   // (alone: the last row, or k + 1 depends on the rows up to k: left out)
             }
