@@ -1150,10 +1150,13 @@ def main():
                     break
             with open(os.path.join(ROOT, "profiles", src)) as f:
                 for row in csv.DictReader(f):
-                    for short in ("k_design_ltv_reg", "k_design_inverse_c32", "k_design_inverse_t<4, 16", "k_polish_sgl", "k_sqp_step", "k_sqp_prepare",
-                                  "k_guess_iterate", "k_fnn_jacobian_w", "k_design_scale", "k_fnn_rollout"):
+                    # (k_polish_sgl<1> / k_guess_iterate_ws: the iterations that start from a guess with the inverse of its working set;
+                    # k_polish_sgl<0>: the first iteration after a start, which has an ADMM phase)
+                    for short in ("k_design_ltv_reg", "k_design_inverse_c32", "k_design_inverse_t<4, 16", "k_polish_sgl<1>", "k_polish_sgl<0>", "k_sqp_step",
+                                  "k_sqp_prepare", "k_guess_iterate_ws", "k_guess_iterate(", "k_fnn_jacobian_w", "k_design_scale", "k_fnn_rollout", "k_riccati_t"):
                         if short in row["Name"]:
-                            ks[short.split("<")[0]] = round(float(row["AverageNs"]) / 1e3, 1)
+                            key = short.rstrip("(") if short.startswith(("k_polish_sgl", "k_guess_iterate")) else short.split("<")[0]
+                            ks[key] = round(float(row["AverageNs"]) / 1e3, 1)
             if ks:
                 nzq = mq * Nq
                 inv_us = ks.get("k_design_inverse_c32") or ks.get("k_design_inverse_t")

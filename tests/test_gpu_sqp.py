@@ -418,3 +418,30 @@ def test_round5_folds_of_the_iteration_change_no_iterate(capi, mo, monkeypatch, 
     assert np.allclose(res["new"][1], res["old"][1], rtol=1e-6, atol=1e-12)
     nb = (np.abs(a["u"]) >= 1.0 - 1e-12).reshape(48, -1).sum(axis=1)
     assert nb.max() > 32   # (working sets beyond the finish's register mode: the installed inverse was used)
+
+
+@pytest.mark.parametrize("N", [33, 45, 64])
+def test_guess_with_the_working_sets_inverse_at_the_edges_of_its_range(capi, mo, monkeypatch, N):
+    """k_guess_iterate_ws serves 64 < nzs <= 128 and installs working sets of 33..64 rows.  N = 33: nz 66, sets around the lower edge
+    (32 rows and fewer take the finish's register mode: the kernel must say "no start"); N = 45: nz 90, rows on both of its row waves;
+    N = 64: nz 128, the largest shape, sets up to and beyond 64 rows (beyond: no start either).  Same iterates as k_guess_iterate
+    (ALMPC_NO_GUESS_WS=1), and the exact restatement for one instance."""
+    res = {}
+    for tag in ("new", "old"):
+        if tag == "old":
+            monkeypatch.setenv("ALMPC_NO_GUESS_WS", "1")
+        else:
+            monkeypatch.delenv("ALMPC_NO_GUESS_WS", raising=False)
+        f, s, kw, X0 = _setup(capi, mo, 24, N, amp=1.2)
+        s.sqp_fnn_start(X0)
+        s.sqp_fnn_iterate(10)
+        res[tag] = s.get_results()
+        s.close()
+    monkeypatch.delenv("ALMPC_NO_GUESS_WS", raising=False)
+    a, b = res["new"], res["old"]
+    assert np.array_equal(a["status"], b["status"]) and np.all(a["status"] == 0)
+    assert np.abs(a["u"] - b["u"]).max() <= 1e-9 and np.abs(a["x"] - b["x"]).max() <= 1e-9
+    nb = (np.abs(a["u"]) >= 1.0 - 1e-12).reshape(24, -1).sum(axis=1)
+    assert nb.max() > 32 and nb.min() < nb.max()
+    X, U, hist = mo.sqp_fnn(f, X0[3], kw["x_ref"], kw["u_ref"], kw["Q"], kw["R"], kw["S"], kw["P"], kw["u_min"], kw["u_max"], 10)
+    assert np.abs(a["u"][3] - U).max() <= U_TOL
