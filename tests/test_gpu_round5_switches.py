@@ -145,6 +145,50 @@ def test_redo_start_built_in_registers_equals_the_bordered_one(capi, mo, box, ca
             assert np.abs(built["u"][i] - mo.solve_mpc_exact(pb, X0[i])["u"]).max() <= 1e-6
 
 
+@pytest.mark.parametrize("shape", ["double_integrator", "random_6x3"])
+def test_redo_start_on_other_shapes_than_the_benchmarks(capi, mo, shape):
+    """k_sdual_start is written for any stage size (its coordinates come from SdualStartParams::SP / TP): the finish capped at 2
+    changes on a double integrator (NT 2, MC 2 build) and on a random 6-state, 3-input plant (NT 6 -> the 8 x 4 build) with a
+    state box and the terminal equality -- every instance handed over half-way; the redo, started from the finish's rows with the
+    inverse built in registers, against the bordered start and against the exact oracle."""
+    if shape == "double_integrator":
+        A, B = np.array([[1.0, 1.0], [0.0, 1.0]]), np.array([[0.5], [1.0]])
+        p = mo.make_problem(A, B, 20, [-1.0], [1.0], x_min=[-12.0, -1.5], x_max=[12.0, 1.5], terminal="equality")
+        X0 = np.stack([np.linspace(-6.0, 6.0, 96), np.tile([0.0, 0.4, -0.4], 32)], axis=1)
+    else:
+        rng = np.random.default_rng(65)
+        A = rng.standard_normal((6, 6)); A *= 0.95 / np.max(np.abs(np.linalg.eigvals(A)))
+        B = rng.standard_normal((6, 3))
+        p = mo.make_problem(A, B, 16, -0.3 * np.ones(3), 0.3 * np.ones(3), x_min=-4.0 * np.ones(6), x_max=4.0 * np.ones(6), terminal="equality", q=10.0, r=1.0)
+        X0 = 0.8 * rng.standard_normal((96, 6))
+    batch = len(X0)
+
+    def run(cap, fallback=None):
+        s = capi.Solver(p.n, p.m, p.N, batch, structured_fallback=fallback)
+        s.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max, xmin=p.x_min, xmax=p.x_max, terminal="equality")
+        s.set_reference(p.x_ref, p.u_ref)
+        s.update_initialization(X0)
+        o = capi.default_opts(max_iter=2, check_every=2)   # (a poor guess of the working set: the finish has changes to make)
+        o.polish_max_iter = cap
+        s.calculate(o)
+        r = s.get_results(want=("u", "status"))
+        s.close()
+        return r
+    built, bordered = _both("ALMPC_SDUAL_NO_START_BUILD", lambda: run(2))
+    assert np.array_equal(built["status"], bordered["status"]) and set(np.unique(built["status"])) <= {0, 3}
+    ok = built["status"] == 0
+    assert ok.sum() >= batch // 3
+    assert np.abs(built["u"][ok] - bordered["u"][ok]).max() <= 1e-9
+    alone = run(2, fallback=False)
+    redone = np.flatnonzero((alone["status"] == 1) & ok)
+    assert len(redone) >= 8, np.bincount(alone["status"], minlength=4)
+    for i in redone[:4]:
+        assert np.abs(built["u"][i] - mo.solve_mpc_exact(p, X0[i])["u"]).max() <= 1e-6
+    for i in np.flatnonzero(built["status"] == 3)[:3]:
+        with pytest.raises(ValueError):
+            mo.solve_mpc_exact(p, X0[i])
+
+
 def test_redo_enqueued_ahead_of_the_look_equals_the_redo_after_it(capi, mo):
     """A synchronous look that found undecided instances makes the NEXT step's redo go on the stream gated behind the step, before the
     host waits (wait_and_settle; ALMPC_NO_PREDICTED_REDO=1: always after the look).  Four looked-at steps of the tight box + equality
