@@ -911,7 +911,8 @@ hipError_t launch_sdual(almpc_handle* h, int filter, const double* guess, int ma
         SdualStartParams tp;
         std::memset(&tp, 0, sizeof(tp));
         tp.batch = h->batch; tp.n = h->n; tp.N = h->N; tp.SP = sd.NT + sd.MC; tp.TP = sdual_tp(sd.NT, sd.MC, h->N);
-        tp.wcap = tier0 == 1 ? SD_WCAP2 : SD_WCAP4; tp.has_eq = sd.has_eq ? 1 : 0;
+        // (the list is built for the LARGEST tier of this call: the first tier installs it if it leaves room to work, else hands it on)
+        tp.wcap = (tier0 == 1 && tier1 < 2) ? SD_WCAP2 : SD_WCAP4; tp.has_eq = sd.has_eq ? 1 : 0;
         tp.status = h->dStatus; tp.gate = sp.gate; tp.gate_val = sp.gate_val;
         tp.ghat = sp.ghat; tp.start_ws = sdw.start_ws; tp.start_inv = sdw.start_inv;
         // (one workgroup per instance at a time; a workgroup looks at up to 64 SDUAL_START_WAVES instances)

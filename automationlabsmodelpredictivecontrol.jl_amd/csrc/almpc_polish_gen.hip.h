@@ -869,7 +869,9 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
         const int st_out = (st_in == 2) ? 2 : ((fin == 0) ? 0 : (fin == 3 ? 3 : 1));
         const bool requeue = !QUEUE && overflow && fin != 3;
         int32_t* rw = p.redo_ws + (size_t)inst * 64;
-        if (st_out == 1 && !requeue && !give_up) {
+        // (also when the finish GAVE UP for want of room: its rows -- the full capacity of them -- are a valid working set, and the
+        // instance that needs 65 rows is exactly the one whose redo from scratch costs a millisecond)
+        if (st_out == 1 && !requeue && k > 0) {
             const int pos = WL == 32 ? (lane & 31) : lane;
             if (lane < WL && pos < k && pos < 63) {
                 const int xi = p.row_xidx[wrow];

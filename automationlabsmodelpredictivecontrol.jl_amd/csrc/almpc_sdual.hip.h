@@ -923,6 +923,12 @@ __global__ __launch_bounds__(64 * SDUAL_WAVES, 2) void k_sdual(SdualParams p) {
                         ns = cnt;
                         kg = N;
                         if (cnt > 0) install(p.start_inv + (size_t)inst * sdual_sinv_doubles(SDUAL_SINV_SAVE), cnt);
+                        // a start at the LIST's capacity (63 rows: the finish gave up for want of room, or the list was cut) goes to
+                        // the next tier AS IT STANDS (rows and inverse through the tiers' hand-over): this tier has no position left to
+                        // work with.  (Starts with a few positions to spare stay: the 128-row build is slower per change, and running
+                        // out of room here costs little since the tiers hand over their inverse.)  The ONE instance of the amplitude-3
+                        // state-box batch that needs 65 rows: redo 1.04 ms from scratch -> 0.26 ms.
+                        if (cnt >= SDUAL_SINV_SAVE - 1 && cnt > wcap - 8 && handed && p.sinv_save && p.ovf && p.wsave) { overflow = true; break; }
                     } else {
                         if (has_eq) {
                             if (lane < n) slist[lane] = ((N * SP + lane) << 2) | 2;
