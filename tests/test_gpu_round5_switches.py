@@ -189,6 +189,39 @@ def test_redo_start_on_other_shapes_than_the_benchmarks(capi, mo, shape):
             mo.solve_mpc_exact(p, X0[i])
 
 
+def test_instance_that_outgrows_the_finish_is_redone_from_the_finishs_rows(capi, mo):
+    """Amplitude 3, state box 3 x the x0 scale, no terminal equality: instance 556 of the benchmark batch needs 65 rows -- one more than
+    the state-row finish holds.  The finish gives up for want of room and (round 5) still hands over its rows; the start kernel builds
+    their inverse for the LARGEST tier and the 64-row tier passes the start on as it stands: 2 changes instead of 60 from scratch
+    (1.04 -> 0.26 ms).  Same answer as the redo from scratch (ALMPC_NO_REDO_START=1) and as the oracle's exact solver."""
+    p = mo.quadrotor()
+    batch = 640
+    xmax = 3.0 * np.array([1, 1, 1, .5, .5, .5, .1, .1, .1, .1, .1, .1]) * 3.0
+    X0 = np.clip(mo.quadrotor_x0_batch(batch, 3.0), -0.99 * xmax, 0.99 * xmax)
+
+    def run():
+        s = capi.Solver(12, 4, 30, batch)
+        s.design_shared(p.A, p.B, p.Q, p.R, p.S, None, p.u_min, p.u_max, xmin=-xmax, xmax=xmax, rho=30.0, rho_profile="stiffness")
+        s.set_reference(p.x_ref, p.u_ref)
+        s.update_initialization(X0)
+        s.calculate(capi.default_opts(rho=30.0, max_iter=8, check_every=8))
+        r = s.get_results(want=("u", "x", "status", "polish_iters"))
+        s.close()
+        return r
+    start, scratch = _both("ALMPC_NO_REDO_START", run)
+    assert np.array_equal(start["status"], scratch["status"]) and set(np.unique(start["status"])) <= {0, 3}
+    ok = start["status"] == 0
+    assert np.abs(start["u"][ok] - scratch["u"][ok]).max() <= 1e-8
+    i = 556
+    assert start["status"][i] == 0 and scratch["status"][i] == 0   # (polish_iters counts the LAST tier's changes only: not comparable)
+    pb = mo.make_problem(*mo.quadrotor_model(), 30, p.u_min, p.u_max, x_min=-xmax, x_max=xmax)
+    e = mo.solve_mpc_exact(pb, X0[i])   # (certified by the method-independent KKT test; a second opinion where its own inverse loses the instance)
+    assert np.abs(start["u"][i] - e["u"]).max() <= 1e-6
+    nrows = int(((e["u"] >= p.u_max[:, None] - 1e-9) | (e["u"] <= p.u_min[:, None] + 1e-9)).sum() +
+                ((np.abs(e["x"][:, 1:]) >= xmax[:, None] - 1e-9)).sum())
+    assert nrows >= 64   # (the capacity of the finish: one more row, weakly active, is what its 64-row build runs out of room with)
+
+
 def test_redo_enqueued_ahead_of_the_look_equals_the_redo_after_it(capi, mo):
     """A synchronous look that found undecided instances makes the NEXT step's redo go on the stream gated behind the step, before the
     host waits (wait_and_settle; ALMPC_NO_PREDICTED_REDO=1: always after the look).  Four looked-at steps of the tight box + equality
