@@ -833,7 +833,7 @@ __device__ __forceinline__ void polish_body(const PolishParams& p_arg, double* s
     const PolishParams& p = p_arg;
     constexpr int CH = (GLDS || SGL) ? 8 : 16;   // (16 for the LDS homes too: measured -6 % on the headline, round 3)  // positions per chunk of G rows (LDS latency needs fewer loads in flight than L2 latency)
     constexpr int NWV = GLDS ? POLISH_WAVES_GLDS : (SGL ? 1 : POLISH_WAVES);  // waves per workgroup
-    const int wv = threadIdx.x >> 6, lane_k = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane_k = threadIdx.x & 63;   // (wave-uniform, and the compiler knows it)
     const int nz = p.nz, nzs = p.nzs;
     const double* Gp = p.G;
     const int gs = GLDS ? ((nz + 1) & ~1) : nzs;  // row stride of G as the waves read it: compact in LDS, nzs in global memory
@@ -1819,7 +1819,7 @@ __global__ __launch_bounds__(64 * NRB) __attribute__((amdgpu_waves_per_eu(2, 2))
 void k_step_fused(AdmmParams ap, PolishParams pp) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if constexpr (NRB != POLISH_WAVES_GLDS) return;   // (experimental builds with another polish width have no fused step)
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // (wave-uniform, and the compiler knows it)
     const int gs = (pp.nz + 1) & ~1, hs = gs / 2;  // rows of G packed to stride gs in LDS (as polish_body<true, ...> reads them)
     auto request_g = [&]() __attribute__((always_inline)) {
         for (int r = wv; r < pp.nz; r += NRB) {

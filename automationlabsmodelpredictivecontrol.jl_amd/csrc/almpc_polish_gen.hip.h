@@ -146,7 +146,7 @@ __device__ __forceinline__ void polish_gen_body(const PolishGenParams& p, double
     constexpr int HS = 64 / WL;  // lanes per position: 2 = the half-waves split the columns of a sweep, 1 = no split
     constexpr int CH = (NP >= 3 && WL == 32) ? 4 : 8;  // rows of Ghat per group of loads: NP * CH <= 16 loads (64 registers) in flight per lane; 32 in the second launch (512 registers)
     constexpr bool QUEUE = WL == 64;  // the 64-row build is the second launch: persistent waves pull flagged instances
-    const int wv = COOP ? 0 : (threadIdx.x >> 6), lane0 = threadIdx.x & 63;
+    const int wv = COOP ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane0 = threadIdx.x & 63;   // (wave-uniform, and the compiler knows it)
   do {  // (one pass in the first launch)
     // (second launch: the lane index made opaque per instance -- otherwise everything that depends on it alone is hoisted out of this
     // loop and kept live across the whole solve: 650 live registers, 134 of them in scratch memory)
