@@ -666,53 +666,61 @@ inline __global__ __launch_bounds__(256) void k_guess_iterate_ws(AdmmInstParams 
 #ifdef ALMPC_STAMPS
     long long dbg_acc[2] = {0, 0};
 #endif
-    // two pivots per publication and barrier (gj16_pivot2); the last one of an odd set alone
+    // two pivots per publication and barrier (gj16_pivot2); the last one of an odd set alone.  The loop over the pivots is unrolled by
+    // 16 so that the register holding a pivot column is a compile-time index (see gj16_pivot)
     if (wv == 0) ALMPC_STAMP(inst, 3);
-    for (int k = 0, step = 0; k < k0; ++step) {
-        double* pw0 = s_prow[step & 1];
-        double* pw1 = pw0 + 64;
-        const bool two = k + 1 < k0;
-        if (lane == k || (two && lane == k + 1)) {
-            double* pw = lane == k ? pw0 : pw1;
+    int step = 0;
+    for (int kb = 0; kb < k0 && !bad; kb += 16) {
+        const bool own = c0 == kb;
+        gj_static_for<0, 8>([&](auto jc) -> bool {
+            constexpr int JJ = 2 * decltype(jc)::value;
+            const int k = kb + JJ;
+            if (k >= k0) return false;
+            double* pw0 = s_prow[step & 1];
+            double* pw1 = pw0 + 64;
+            ++step;
+            const bool two = k + 1 < k0;
+            if (lane == k || (two && lane == k + 1)) {
+                double* pw = lane == k ? pw0 : pw1;
 #pragma unroll
-            for (int jj = 0; jj < 16; jj += 2) *reinterpret_cast<double2*>(pw + c0 + jj) = make_double2(r[jj], r[jj + 1]);
-        }
+                for (int jj = 0; jj < 16; jj += 2) *reinterpret_cast<double2*>(pw + c0 + jj) = make_double2(r[jj], r[jj + 1]);
+            }
 #ifdef ALMPC_STAMPS
-        long long tq0 = __builtin_readcyclecounter();
+            long long tq0 = __builtin_readcyclecounter();
 #endif
-        __syncthreads();
+            __syncthreads();
 #ifdef ALMPC_STAMPS
-        long long tq1 = __builtin_readcyclecounter();
-        dbg_acc[0] += tq1 - tq0;
+            long long tq1 = __builtin_readcyclecounter();
+            dbg_acc[0] += tq1 - tq0;
 #endif
-        double pj0[16], pj1[16];   // (every read of the pivot rows in one batch, in front of the pivot tests)
-#pragma unroll
-        for (int jj = 0; jj < 16; jj += 2) {
-            const double2 t2 = *reinterpret_cast<const double2*>(pw0 + c0 + jj);
-            pj0[jj] = t2.x; pj0[jj + 1] = t2.y;
-        }
-        const double col0 = pw0[lane], d11 = pw0[k];
-#ifdef ALMPC_STAMPS
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        tq0 = __builtin_readcyclecounter();
-        dbg_acc[1] += tq0 - tq1;
-#endif
-        if (two) {
+            double pj0[16], pj1[16];   // (every read of the pivot rows in one batch, in front of the pivot tests)
 #pragma unroll
             for (int jj = 0; jj < 16; jj += 2) {
-                const double2 t2 = *reinterpret_cast<const double2*>(pw1 + c0 + jj);
-                pj1[jj] = t2.x; pj1[jj + 1] = t2.y;
+                const double2 t2 = *reinterpret_cast<const double2*>(pw0 + c0 + jj);
+                pj0[jj] = t2.x; pj0[jj + 1] = t2.y;
             }
-            const double col1 = pw1[lane], d12 = pw0[k + 1], d22 = pw1[k + 1];
-            const double i11 = fast_rcp_d(d11), t = d12 * i11, s22 = __builtin_fma(-t, d12, d22);
-            if (!(d11 > 0.0) || !(s22 > 0.0)) { bad = true; break; }   // (uniform: every wave reads the same pivots)
-            if (c0 < k0) gj16_pivot2(r, pj0, pj1, col0, col1, i11, t, s22, c0, k, lane);   // (else: columns beyond the set; the wave still meets the barriers)
-            k += 2;
-        } else {
-            if (!(d11 > 0.0)) { bad = true; break; }
-            if (c0 < k0) gj16_pivot(r, pj0, col0, d11, c0, k, lane);
-            k += 1;
-        }
+            const double col0 = pw0[lane], d11 = pw0[k];
+#ifdef ALMPC_STAMPS
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            tq0 = __builtin_readcyclecounter();
+            dbg_acc[1] += tq0 - tq1;
+#endif
+            if (two) {
+#pragma unroll
+                for (int jj = 0; jj < 16; jj += 2) {
+                    const double2 t2 = *reinterpret_cast<const double2*>(pw1 + c0 + jj);
+                    pj1[jj] = t2.x; pj1[jj + 1] = t2.y;
+                }
+                const double col1 = pw1[lane], d12 = pw0[k + 1], d22 = pw1[k + 1];
+                const double i11 = fast_rcp_d(d11), t = d12 * i11, s22 = __builtin_fma(-t, d12, d22);
+                if (!(d11 > 0.0) || !(s22 > 0.0)) { bad = true; return false; }   // (uniform: every wave reads the same pivots)
+                if (c0 < k0) gj16_pivot2<JJ>(r, pj0, pj1, col0, col1, i11, t, s22, own, k, lane);   // (else: columns beyond the set; the wave still meets the barriers)
+            } else {
+                if (!(d11 > 0.0)) { bad = true; return false; }
+                if (c0 < k0) gj16_pivot<JJ>(r, pj0, col0, d11, own, k, lane);
+            }
+            return true;
+        });
     }
     if (bad) {
         if (tid == 0) rws[0] = 0;

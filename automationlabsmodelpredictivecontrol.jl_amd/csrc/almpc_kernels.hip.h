@@ -22,6 +22,7 @@
 #include <map>
 #include <mutex>
 #include <utility>
+#include <type_traits>
 
 namespace almpc {
 
@@ -550,27 +551,32 @@ typedef double gj16_row[16];
 // The compiler if-converts the guarded write into an indexed move on a COPY of the array followed by a select per register -- no
 // fewer instructions -- and executes the indexed move also when the guard is false, with an index outside the array: a GPU memory
 // fault on the first run.  A select per register on a scalar condition it is.)
-__device__ __forceinline__ void gj16_pivot(gj16_row& r, const double (&pj)[16], const double col, const double d, const int c0, const int k,
+// JJ: the register that holds column k, a COMPILE-TIME index (the callers unroll their pivot loop by 16: pivot k sits at position k & 15 of
+// the wave that owns it); own: this wave holds column k (wave-uniform).  With the index known the pivot column is one guarded move --
+// as a select per register on `jj == k - c0` it was 4 vector + 4 scalar instructions for each of the 16 registers, and per PAIR of
+// pivots twice that: 130 of the 230 instructions of a step (2.3 k cycles per step measured; the sweep is bound by its instruction count).
+template <int JJ>
+__device__ __forceinline__ void gj16_pivot(gj16_row& r, const double (&pj)[16], const double col, const double d, const bool own, const int k,
                                            const int lane) {
     const double invd = fast_rcp_d(d);
     const bool piv = lane == k;
     const double f = piv ? -invd : col * invd;
     const double keep = piv ? 0.0 : 1.0;
-    const int kk = k - c0;
 #pragma unroll
-    for (int jj = 0; jj < 16; ++jj) {
-        const double u = __builtin_fma(-f, pj[jj], keep * r[jj]);
-        r[jj] = (jj == kk) ? f : u;   // column k: f on every lane -- the pivot lane's f IS -1/d
-    }
+    for (int jj = 0; jj < 16; ++jj) r[jj] = __builtin_fma(-f, pj[jj], keep * r[jj]);
+    if (own) r[JJ] = f;   // column k: f on every lane -- the pivot lane's f IS -1/d
 }
 
 // Two pivots (k, k + 1) of the same sweep behind ONE publication and barrier: sweeping k and then k + 1 is the block sweep on the pair,
 //   [f0 f1] = [col0 col1] D^-1,  D = [d11 d12; d12 d22] (entries k, k + 1 of the two published rows),  r_ij -= f0 pj0_j + f1 pj1_j,
 // with D^-1 from the sequential formulas (i11 = 1 / d11, t = d12 i11, s22 = d22 - t d12, then 1 / s22: the second pivot as the one-by-one
 // sweep forms it; the caller has computed them for its pivot tests).  The two pivot rows become D^-1 [row_k; row_k+1]: the same FMAs
-// with (f0, f1) = -(row of D^-1) and the lane's old row masked; columns k and k + 1 of every row are (f0, f1).
+// with (f0, f1) = -(row of D^-1) and the lane's old row masked; columns k and k + 1 of every row are (f0, f1).  JJ even: both columns
+// sit on the same wave.
+template <int JJ>
 __device__ __forceinline__ void gj16_pivot2(gj16_row& r, const double (&pj0)[16], const double (&pj1)[16], const double col0, const double col1,
-                                            const double i11, const double t, const double s22, const int c0, const int k, const int lane) {
+                                            const double i11, const double t, const double s22, const bool own, const int k, const int lane) {
+    static_assert((JJ & 1) == 0 && JJ + 1 < 16, "a pair starts at an even position");
     const double e11 = fast_rcp_d(s22);
     const double e01 = -t * e11;
     const double e00 = __builtin_fma(-t, e01, i11);   // 1 / d11 + t^2 / s22
@@ -579,11 +585,17 @@ __device__ __forceinline__ void gj16_pivot2(gj16_row& r, const double (&pj0)[16]
     f0 = p0 ? -e00 : (p1 ? -e01 : f0);
     f1 = p0 ? -e01 : (p1 ? -e11 : f1);
     const double keep = (p0 || p1) ? 0.0 : 1.0;
-    const int kk = k - c0;
 #pragma unroll
-    for (int jj = 0; jj < 16; ++jj) {
-        const double u = __builtin_fma(-f1, pj1[jj], __builtin_fma(-f0, pj0[jj], keep * r[jj]));
-        r[jj] = (jj == kk) ? f0 : ((jj == kk + 1) ? f1 : u);   // (columns k, k + 1: selects on scalar conditions)
+    for (int jj = 0; jj < 16; ++jj) r[jj] = __builtin_fma(-f1, pj1[jj], __builtin_fma(-f0, pj0[jj], keep * r[jj]));
+    if (own) { r[JJ] = f0; r[JJ + 1] = f1; }
+}
+
+// f(integral_constant<int, I>) for I = 0 .. N - 1, until it returns false
+template <int I, int N, class F>
+__device__ __forceinline__ void gj_static_for(F&& f) {
+    if constexpr (I < N) {
+        if (!f(std::integral_constant<int, I>{})) return;
+        gj_static_for<I + 1, N>(f);
     }
 }
 

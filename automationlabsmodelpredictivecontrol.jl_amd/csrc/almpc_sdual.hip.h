@@ -1209,45 +1209,61 @@ inline __global__ __launch_bounds__(64 * SDUAL_START_WAVES) void k_sdual_start(S
             for (int jj = 0; jj < 16; ++jj) r[jj] = (c0 + jj < cnt && lane < cnt) ? r[jj] : 0.0;
         }
         unsigned long long acc = 0ull;   // accepted rows (every wave keeps the same record)
-        // two pivots per publication and barrier (gj16_pivot2) where both are accepted; the tests are the one-by-one sweep's
-        for (int k = 0, step = 0; k < cnt; ++step) {
-            double* pw0 = s_prow[step & 1];
-            double* pw1 = pw0 + 64;
-            const bool two = k + 1 < cnt;
-            if (lane == k || (two && lane == k + 1)) {
-                double* pw = lane == k ? pw0 : pw1;
+        // two pivots per publication and barrier (gj16_pivot2) where both are accepted; the tests are the one-by-one sweep's.  The loop over
+        // the rows is unrolled by 16 so that the register holding a pivot column is a compile-time index (see gj16_pivot): position jj of
+        // a block of 16 rows is row kb + jj; a pair starts at an even position only
+        int step = 0;
+        for (int kb = 0; kb < cnt; kb += 16) {
+            const bool own = c0 == kb;
+            bool consumed = false;   // this position was the second row of the pair before it
+            gj_static_for<0, 16>([&](auto jc) -> bool {
+                constexpr int JJ = decltype(jc)::value;
+                const int k = kb + JJ;
+                if (k >= cnt) return false;
+                if (consumed) { consumed = false; return true; }
+                double* pw0 = s_prow[step & 1];
+                double* pw1 = pw0 + 64;
+                ++step;
+                const bool two = (JJ & 1) == 0 && k + 1 < cnt;
+                if (lane == k || (two && lane == k + 1)) {
+                    double* pw = lane == k ? pw0 : pw1;
 #pragma unroll
-                for (int jj = 0; jj < 16; jj += 2) *reinterpret_cast<double2*>(pw + c0 + jj) = make_double2(r[jj], r[jj + 1]);
-            }
-            __syncthreads();
-            double pj0[16], pj1[16];   // (every read of the pivot rows in one batch, in front of the pivot tests)
-#pragma unroll
-            for (int jj = 0; jj < 16; jj += 2) {
-                const double2 t2 = *reinterpret_cast<const double2*>(pw0 + c0 + jj);
-                pj0[jj] = t2.x; pj0[jj + 1] = t2.y;
-            }
-            const double col0 = pw0[lane], d11 = pw0[k];
-            double col1 = 0.0, d12 = 0.0, d22 = 0.0;
-            if (two) {
+                    for (int jj = 0; jj < 16; jj += 2) *reinterpret_cast<double2*>(pw + c0 + jj) = make_double2(r[jj], r[jj + 1]);
+                }
+                __syncthreads();
+                double pj0[16], pj1[16];   // (every read of the pivot rows in one batch, in front of the pivot tests)
 #pragma unroll
                 for (int jj = 0; jj < 16; jj += 2) {
-                    const double2 t2 = *reinterpret_cast<const double2*>(pw1 + c0 + jj);
-                    pj1[jj] = t2.x; pj1[jj + 1] = t2.y;
+                    const double2 t2 = *reinterpret_cast<const double2*>(pw0 + c0 + jj);
+                    pj0[jj] = t2.x; pj0[jj + 1] = t2.y;
                 }
-                col1 = pw1[lane]; d12 = pw0[k + 1]; d22 = pw1[k + 1];
-            }
-            // (uniform over the workgroup: every wave reads the same pivots)
-            if (!(d11 > 1e-12 * s_gd[k])) { k += 1; continue; }   // dependent on the rows before it: left out; k + 1 is published again
-            acc |= 1ull << k;
-            const double i11 = fast_rcp_d(d11), t = d12 * i11;
-            const double s22 = two ? __builtin_fma(-t, d12, d22) : 0.0;
-            if (two && s22 > 1e-12 * s_gd[k + 1]) {
-                acc |= 1ull << (k + 1);
-                if (c0 < cnt) gj16_pivot2(r, pj0, pj1, col0, col1, i11, t, s22, c0, k, lane);   // (else: columns beyond the list; the wave still meets the barriers)
-            } else {
-                if (c0 < cnt) gj16_pivot(r, pj0, col0, d11, c0, k, lane);   // (alone: the last row, or k + 1 depends on the rows up to k: left out)
-            }
-            k += 2;
+                const double col0 = pw0[lane], d11 = pw0[k];
+                double col1 = 0.0, d12 = 0.0, d22 = 0.0;
+                if (two) {
+#pragma unroll
+                    for (int jj = 0; jj < 16; jj += 2) {
+                        const double2 t2 = *reinterpret_cast<const double2*>(pw1 + c0 + jj);
+                        pj1[jj] = t2.x; pj1[jj + 1] = t2.y;
+                    }
+                    col1 = pw1[lane]; d12 = pw0[k + 1]; d22 = pw1[k + 1];
+                }
+                // (uniform over the workgroup: every wave reads the same pivots)
+                if (!(d11 > 1e-12 * s_gd[k])) return true;   // dependent on the rows before it: left out (the next position is published afresh)
+                acc |= 1ull << k;
+                const double i11 = fast_rcp_d(d11), t = d12 * i11;
+                const double s22 = two ? __builtin_fma(-t, d12, d22) : 0.0;
+                if constexpr ((JJ & 1) == 0) {
+                    if (two && s22 > 1e-12 * s_gd[k + 1]) {
+                        acc |= 1ull << (k + 1);
+                        if (c0 < cnt) gj16_pivot2<JJ>(r, pj0, pj1, col0, col1, i11, t, s22, own, k, lane);   // (else: columns beyond the list; the wave still meets the barriers)
+                        consumed = true;
+                        return true;
+                    }
+                }
+                // alone: an odd position, the last row, or k + 1 depends on the rows up to k (it is tested again at its own position, and left out there)
+                if (c0 < cnt) gj16_pivot<JJ>(r, pj0, col0, d11, own, k, lane);
+                return true;
+            });
         }
         // ---- out: accepted rows in list order
         const int na = __popcll(acc);
